@@ -1,0 +1,283 @@
+/*
+ * fm_oracle.c -- CPU restatement of the libFM predict + SGD hot path.
+ * TEST INFRASTRUCTURE ONLY (see fm_oracle.h).  Every function cites the reference lines it follows.
+ * Build: oracle/Makefile  ->  oracle/libfm_oracle.so
+ */
+#include "fm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define V(m, f, j) ((m)->v[(size_t)(f) * (size_t)(m)->n + (size_t)(j)])
+
+/* fm_model::predict(x, sum, sum_sqr)                      /root/reference/src/fm_core/fm_model.h:105-127
+ * Same loop nest and summation order: bias, linear terms in row order, then f outer / i inner. */
+double fmo_predict_row(const fmo_model *m, const fmo_entry *row, uint32_t size,
+                       double *sum, double *sum_sqr) {
+  double result = 0;
+  if (m->k0) result += m->w0;                                   /* :107-109 */
+  if (m->k1) {
+    for (uint32_t i = 0; i < size; i++)                         /* :110-115 */
+      result += m->w[row[i].id] * row[i].value;
+  }
+  for (int f = 0; f < m->k; f++) {                              /* :116-126 */
+    sum[f] = 0;
+    sum_sqr[f] = 0;
+    for (uint32_t i = 0; i < size; i++) {
+      double d = V(m, f, row[i].id) * row[i].value;
+      sum[f] += d;
+      sum_sqr[f] += d * d;
+    }
+    result += 0.5 * (sum[f] * sum[f] - sum_sqr[f]);
+  }
+  return result;
+}
+
+/* fm_SGD                                                   /root/reference/src/fm_core/fm_sgd.h:33-51
+ * Update order: w0, then every w in row order, then V f-major; sum[f] is NOT refreshed. */
+void fmo_sgd_step(fmo_model *m, double learn_rate, const fmo_entry *row, uint32_t size,
+                  double multiplier, const double *sum) {
+  if (m->k0) {
+    m->w0 -= learn_rate * (multiplier + m->reg0 * m->w0);       /* :34-37 */
+  }
+  if (m->k1) {
+    for (uint32_t i = 0; i < size; i++) {                       /* :38-43 */
+      double *w = &m->w[row[i].id];
+      *w -= learn_rate * (multiplier * row[i].value + m->regw * (*w));
+    }
+  }
+  for (int f = 0; f < m->k; f++) {                              /* :44-50 */
+    for (uint32_t i = 0; i < size; i++) {
+      double *v = &V(m, f, row[i].id);
+      double grad = sum[f] * row[i].value - (*v) * row[i].value * row[i].value;
+      *v -= learn_rate * (multiplier * grad + m->regv * (*v));
+    }
+  }
+}
+
+/* loss multiplier                   /root/reference/src/libfm/src/fm_learn_sgd_element.h:58-65 */
+double fmo_multiplier(int task, double p, double y, double min_target, double max_target) {
+  double mult = 0;
+  if (task == FMO_TASK_REGRESSION) {
+    p = (max_target < p) ? max_target : p;                      /* std::min(max_target, p) */
+    p = (min_target > p) ? min_target : p;                      /* std::max(min_target, p) */
+    mult = -(y - p);
+  } else if (task == FMO_TASK_CLASSIFICATION) {
+    mult = -y * (1.0 - 1.0 / (1.0 + exp(-y * p)));
+  }
+  return mult;
+}
+
+/* one pass of the row loop             /root/reference/src/libfm/src/fm_learn_sgd_element.h:56-67 */
+void fmo_sgd_epoch_online(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                          double min_target, double max_target) {
+  double *sum = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  double *sum_sqr = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  for (uint32_t r = 0; r < d->n_rows; r++) {
+    const fmo_entry *row = d->entries + d->row_ptr[r];
+    uint32_t size = (uint32_t)(d->row_ptr[r + 1] - d->row_ptr[r]);
+    double p = fmo_predict_row(m, row, size, sum, sum_sqr);
+    double mult = fmo_multiplier(task, p, (double)d->target[r], min_target, max_target);
+    fmo_sgd_step(m, learn_rate, row, size, mult, sum);
+  }
+  free(sum);
+  free(sum_sqr);
+}
+
+/* predict_case in a loop                      /root/reference/src/libfm/src/fm_learn.h:63-65 */
+void fmo_predict_raw(const fmo_model *m, const fmo_data *d, double *out) {
+  double *sum = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  double *sum_sqr = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  for (uint32_t r = 0; r < d->n_rows; r++) {
+    const fmo_entry *row = d->entries + d->row_ptr[r];
+    uint32_t size = (uint32_t)(d->row_ptr[r + 1] - d->row_ptr[r]);
+    out[r] = fmo_predict_row(m, row, size, sum, sum_sqr);
+  }
+  free(sum);
+  free(sum_sqr);
+}
+
+/* fm_learn_sgd::predict                    /root/reference/src/libfm/src/fm_learn_sgd.h:76-90 */
+void fmo_predict_out(const fmo_model *m, const fmo_data *d, int task,
+                     double min_target, double max_target, double *out) {
+  fmo_predict_raw(m, d, out);
+  for (uint32_t r = 0; r < d->n_rows; r++) {
+    double p = out[r];
+    if (task == FMO_TASK_REGRESSION) {
+      p = (max_target < p) ? max_target : p;
+      p = (min_target > p) ? min_target : p;
+    } else {
+      p = 1.0 / (1.0 + exp(-p));
+    }
+    out[r] = p;
+  }
+}
+
+/* fm_learn::evaluate_classification / evaluate_regression   /root/reference/src/libfm/src/fm_learn.h:113-153 */
+double fmo_evaluate(const fmo_model *m, const fmo_data *d, int task,
+                    double min_target, double max_target, double *mae) {
+  double *sum = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  double *sum_sqr = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  double result;
+  if (task == FMO_TASK_CLASSIFICATION) {
+    int num_correct = 0;                                       /* :113-130 */
+    for (uint32_t r = 0; r < d->n_rows; r++) {
+      const fmo_entry *row = d->entries + d->row_ptr[r];
+      uint32_t size = (uint32_t)(d->row_ptr[r + 1] - d->row_ptr[r]);
+      double p = fmo_predict_row(m, row, size, sum, sum_sqr);
+      double y = (double)d->target[r];
+      if (((p >= 0) && (y >= 0)) || ((p < 0) && (y < 0))) num_correct++;
+    }
+    if (mae) *mae = NAN;
+    result = (double)num_correct / (double)d->n_rows;
+  } else {
+    double rmse_sum_sqr = 0, mae_sum_abs = 0;                  /* :132-153 */
+    for (uint32_t r = 0; r < d->n_rows; r++) {
+      const fmo_entry *row = d->entries + d->row_ptr[r];
+      uint32_t size = (uint32_t)(d->row_ptr[r + 1] - d->row_ptr[r]);
+      double p = fmo_predict_row(m, row, size, sum, sum_sqr);
+      p = (max_target < p) ? max_target : p;
+      p = (min_target > p) ? min_target : p;
+      double err = p - (double)d->target[r];
+      rmse_sum_sqr += err * err;
+      mae_sum_abs += fabs(err);
+    }
+    if (mae) *mae = mae_sum_abs / d->n_rows;
+    result = sqrt(rmse_sum_sqr / d->n_rows);
+  }
+  free(sum);
+  free(sum_sqr);
+  return result;
+}
+
+/* The minibatch restatement (see fm_oracle.h).  Derived from fm_sgd.h:33-51 applied per occurrence
+ * with batch-start parameters; reduces to fmo_sgd_epoch_online when batch == w0_chunk == 1. */
+void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                             double min_target, double max_target,
+                             uint32_t batch, uint32_t w0_chunk) {
+  const int k = m->k;
+  const size_t n = (size_t)m->n;
+  if (batch == 0 || batch > d->n_rows) batch = d->n_rows;
+  if (w0_chunk == 0 || w0_chunk > batch) w0_chunk = batch;
+  const size_t kk = (size_t)(k > 0 ? k : 1);
+  double *S = (double *)malloc(sizeof(double) * (size_t)batch * kk);
+  double *rest = (double *)malloc(sizeof(double) * batch);
+  double *mult = (double *)malloc(sizeof(double) * batch);
+  double *sum_sqr = (double *)malloc(sizeof(double) * kk);
+  double *dw = (double *)calloc(n, sizeof(double));
+  double *dv = (double *)calloc(n * kk, sizeof(double));
+
+  for (uint32_t r0 = 0; r0 < d->n_rows; r0 += batch) {
+    uint32_t nb = (d->n_rows - r0 < batch) ? (d->n_rows - r0) : batch;
+    /* step 1: sums from batch-start parameters (fm_model.h:110-126 without the bias) */
+    for (uint32_t e = 0; e < nb; e++) {
+      const fmo_entry *row = d->entries + d->row_ptr[r0 + e];
+      uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
+      double res = 0;
+      if (m->k1)
+        for (uint32_t i = 0; i < size; i++) res += m->w[row[i].id] * row[i].value;
+      for (int f = 0; f < k; f++) {
+        double s = 0, q = 0;
+        for (uint32_t i = 0; i < size; i++) {
+          double dd = V(m, f, row[i].id) * row[i].value;
+          s += dd;
+          q += dd * dd;
+        }
+        S[(size_t)e * kk + f] = s;
+        sum_sqr[f] = q;
+        res += 0.5 * (s * s - q);
+      }
+      rest[e] = res;
+    }
+    /* step 2: w0 micro-chunks (fm_learn_sgd_element.h:57-65 + fm_sgd.h:34-37) */
+    for (uint32_t c0 = 0; c0 < nb; c0 += w0_chunk) {
+      uint32_t nc = (nb - c0 < w0_chunk) ? (nb - c0) : w0_chunk;
+      double w0s = m->k0 ? m->w0 : 0.0;
+      double acc = 0;
+      for (uint32_t e = c0; e < c0 + nc; e++) {
+        double p = w0s + rest[e];
+        mult[e] = fmo_multiplier(task, p, (double)d->target[r0 + e], min_target, max_target);
+        acc += mult[e] + m->reg0 * w0s;
+      }
+      if (m->k0) {
+        if (nc == 1) m->w0 -= learn_rate * (mult[c0] + m->reg0 * m->w0);  /* literal form at chunk 1 */
+        else         m->w0 -= learn_rate * acc;
+      }
+    }
+    /* step 3: per-occurrence deltas from batch-start w, v (fm_sgd.h:38-50) */
+    for (uint32_t e = 0; e < nb; e++) {
+      const fmo_entry *row = d->entries + d->row_ptr[r0 + e];
+      uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
+      if (m->k1)
+        for (uint32_t i = 0; i < size; i++) {
+          double w = m->w[row[i].id];
+          dw[row[i].id] += -(learn_rate * (mult[e] * row[i].value + m->regw * w));
+        }
+      for (int f = 0; f < k; f++)
+        for (uint32_t i = 0; i < size; i++) {
+          double v = V(m, f, row[i].id);
+          double x = row[i].value;
+          double grad = S[(size_t)e * kk + f] * x - v * x * x;
+          dv[(size_t)f * n + row[i].id] += -(learn_rate * (mult[e] * grad + m->regv * v));
+        }
+    }
+    /* apply and clear the touched deltas */
+    for (uint32_t e = 0; e < nb; e++) {
+      const fmo_entry *row = d->entries + d->row_ptr[r0 + e];
+      uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
+      for (uint32_t i = 0; i < size; i++) {
+        size_t j = row[i].id;
+        if (m->k1 && dw[j] != 0.0) { m->w[j] += dw[j]; dw[j] = 0.0; }
+        for (int f = 0; f < k; f++) {
+          double *p = &dv[(size_t)f * n + j];
+          if (*p != 0.0) { V(m, f, j) += *p; *p = 0.0; }
+        }
+      }
+    }
+  }
+  free(S); free(rest); free(mult); free(sum_sqr); free(dw); free(dv);
+}
+
+/* ------------------------------- synthetic workload ------------------------------- */
+
+uint64_t fmo_mix64(uint64_t x) {          /* splitmix64 finaliser */
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+  x ^= x >> 31;
+  return x;
+}
+
+static uint64_t synth_key(uint64_t seed, uint64_t row, uint32_t field) {
+  return fmo_mix64(seed + 0x9E3779B97F4A7C15ULL * (row + 1) + 0xC2B2AE3D27D4EB4FULL * ((uint64_t)field + 1));
+}
+
+uint32_t fmo_synth_id(uint64_t seed, uint64_t row, uint32_t field, uint32_t field_size) {
+  uint64_t h = synth_key(seed, row, field);
+  uint32_t off = (uint32_t)(((h >> 32) * (uint64_t)field_size) >> 32);   /* multiply-high range map */
+  return field * field_size + off;
+}
+
+float fmo_synth_target(uint64_t seed, uint64_t row) {
+  return (synth_key(seed, row, 0xFFFFFFFFu) & 1) ? 1.0f : -1.0f;
+}
+
+void fmo_synth_rows(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint64_t n,
+                    fmo_entry *entries, uint64_t *row_ptr, float *target) {
+  uint32_t fs = (uint32_t)(n / nnz);
+  for (uint32_t r = 0; r < n_rows; r++) {
+    row_ptr[r] = (uint64_t)r * nnz;
+    for (uint32_t t = 0; t < nnz; t++) {
+      entries[(size_t)r * nnz + t].id = fmo_synth_id(seed, row0 + r, t, fs);
+      entries[(size_t)r * nnz + t].value = 1.0f;
+    }
+    target[r] = fmo_synth_target(seed, row0 + r);
+  }
+  row_ptr[n_rows] = (uint64_t)n_rows * nnz;
+}
+
+double fmo_init_value(uint64_t seed, uint64_t j, uint32_t f, double stdev) {
+  uint64_t h = fmo_mix64(seed ^ (j * 0x9E3779B97F4A7C15ULL + (uint64_t)f * 0xD6E8FEB86659FD93ULL + 0x1234567ULL));
+  double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);   /* [0,1) */
+  return stdev * (2.0 * u - 1.0) * 1.7320508075688772;
+}

@@ -1,0 +1,153 @@
+/*
+ * fm_oracle.h -- CPU restatement of the libFM hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for the MI355X HIP path.  It is NOT part of the
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may link or call it.  It restates, in plain C and in the reference's own
+ * precision (fp32 data, fp64 parameters and accumulators), the algorithms of
+ *
+ *   fm_model::predict            /root/reference/src/fm_core/fm_model.h:105-127
+ *   fm_SGD                       /root/reference/src/fm_core/fm_sgd.h:33-51
+ *   fm_learn_sgd_element::learn  /root/reference/src/libfm/src/fm_learn_sgd_element.h:48-78
+ *   fm_learn_sgd::predict        /root/reference/src/libfm/src/fm_learn_sgd.h:76-90
+ *   fm_learn::evaluate_*         /root/reference/src/libfm/src/fm_learn.h:113-153
+ *   fm_learn_mcmc (ALS part)     /root/reference/src/libfm/src/fm_learn_mcmc.h:148-378,406-428,643-732,792-847
+ *
+ * Parity pin: the restatement is checked bit-for-bit (fp64) against the real
+ * reference compiled from /root/reference (oracle/_ref/ref_harness, built by
+ * oracle/Makefile) and against the committed fixtures in tests/golden/ that the
+ * harness generated (tests/golden/make_golden.py).
+ *
+ * Parameter layout is the reference's (fm_model.h:46-48, matrix.h:165-170):
+ *   w0 double; w[n] double; v[k][n] double, FACTOR-major (v[f*n + j]), but with
+ *   size_t indexing so that k*n >= 2^32 works (the stock reference overflows there).
+ * Input layout is the reference's (fmatrix.h:34-42, Data.h:237-270): one contiguous
+ *   array of {uint32 id; float value} in row order + row offsets.
+ */
+#ifndef FM_ORACLE_H_
+#define FM_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint32_t id; float value; } fmo_entry;   /* sparse_entry<float>, fmatrix.h:34-37 */
+
+typedef struct {
+  uint64_t n;        /* num_attribute                       fm_model.h:51 */
+  int32_t  k;        /* num_factor                          fm_model.h:54 */
+  int32_t  k0, k1;   /* use bias / use 1-way interactions   fm_model.h:53 */
+  double   w0;
+  double  *w;        /* [n]                                  */
+  double  *v;        /* [k][n] factor-major                  */
+  double   reg0, regw, regv;
+} fmo_model;
+
+typedef struct {
+  const fmo_entry *entries;   /* contiguous, row order */
+  const uint64_t  *row_ptr;   /* [n_rows+1]            */
+  const float     *target;    /* [n_rows]              */
+  uint32_t         n_rows;
+} fmo_data;
+
+enum { FMO_TASK_REGRESSION = 0, FMO_TASK_CLASSIFICATION = 1 };  /* fm_learn.h:45-47 */
+
+/* fm_model::predict with side outputs sum[k], sum_sqr[k]  (fm_model.h:105-127) */
+double fmo_predict_row(const fmo_model *m, const fmo_entry *row, uint32_t size,
+                       double *sum, double *sum_sqr);
+
+/* fm_SGD  (fm_sgd.h:33-51) */
+void fmo_sgd_step(fmo_model *m, double learn_rate, const fmo_entry *row, uint32_t size,
+                  double multiplier, const double *sum);
+
+/* loss multiplier of fm_learn_sgd_element::learn (fm_learn_sgd_element.h:58-65) */
+double fmo_multiplier(int task, double p, double y, double min_target, double max_target);
+
+/* one epoch of the strictly-online loop (fm_learn_sgd_element.h:56-67) */
+void fmo_sgd_epoch_online(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                          double min_target, double max_target);
+
+/* raw y-hat for every row (fm_learn.h:63-65 predict_case in a loop) */
+void fmo_predict_raw(const fmo_model *m, const fmo_data *d, double *out);
+
+/* fm_learn_sgd::predict: clamp (regression) or sigmoid (classification)  (fm_learn_sgd.h:76-90) */
+void fmo_predict_out(const fmo_model *m, const fmo_data *d, int task,
+                     double min_target, double max_target, double *out);
+
+/* fm_learn::evaluate_regression -> rmse (and mae), evaluate_classification -> accuracy
+ * (fm_learn.h:113-153).  Returns the value evaluate() returns; *mae may be NULL. */
+double fmo_evaluate(const fmo_model *m, const fmo_data *d, int task,
+                    double min_target, double max_target, double *mae);
+
+/*
+ * The minibatch restatement of fm_SGD used by the GPU "minibatch" mode:
+ *   1. for every example e of the batch, from the BATCH-START parameters:
+ *        S_ef, Q_e, lin_e  (the sums of fm_model.h:111-125);
+ *        rest_e = lin_e + 0.5*(sum_f S_ef^2 - Q_e)
+ *   2. w0 is advanced in micro-chunks of `w0_chunk` consecutive examples: inside a chunk every
+ *      example sees the w0 at chunk start, p_e = w0 + rest_e, mult_e = fmo_multiplier(p_e, y_e),
+ *      then w0 -= lr * sum_{e in chunk}(mult_e + reg0*w0)              (fm_sgd.h:34-37 per example)
+ *   3. every occurrence (e, j, x) adds, computed from the batch-start w[j], v[f][j]:
+ *        dw[j]    += -lr*(mult_e*x + regw*w[j])                          (fm_sgd.h:38-43)
+ *        dv[f][j] += -lr*(mult_e*(S_ef*x - v[f][j]*x*x) + regv*v[f][j])  (fm_sgd.h:44-50)
+ *      and the sums are applied at batch end.
+ * With batch == 1 and w0_chunk == 1 this IS the reference loop for rows without a repeated id, up to
+ * the last ulp of p (the rule adds w0 to rest_e last, fm_model.h:107-115 adds it first); the tests
+ * hold it to rtol 1e-11 against the real reference.  batch == 0 means "whole data set".
+ */
+void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                             double min_target, double max_target,
+                             uint32_t batch, uint32_t w0_chunk);
+
+/* ---------------- ALS (coordinate descent; "MCMC without sampling", libfm.cpp:135-139) ---------------- */
+
+typedef struct {
+  const fmo_entry *entries;   /* X^T: per FEATURE list of {row id, value}  (Data.h:292-341) */
+  const uint64_t  *col_ptr;   /* [n+1] */
+  uint64_t         n;         /* features */
+  uint32_t         n_rows;
+} fmo_data_t;
+
+typedef struct { double e, q; } fmo_eq;   /* e_q_term, fm_learn_mcmc.h:46-49 */
+
+/* build X^T from X (Data::create_data_t, Data.h:292-341); caller frees *entries_t, *col_ptr */
+void fmo_transpose(const fmo_data *d, uint64_t n, fmo_entry **entries_t, uint64_t **col_ptr);
+
+/* predict_data_and_write_to_eterms, non-relational part (fm_learn_mcmc.h:148-378): cache[c].e = y-hat(c) */
+void fmo_als_predict_eterms(const fmo_model *m, const fmo_data_t *dt, fmo_eq *cache);
+
+/* one ALS sweep = draw_all with do_sample=0, do_multilevel=0 (fm_learn_mcmc.h:430-641):
+ * draw_w0 (:643-683), draw_w (:685-732) for every feature, then per factor add_main_q (:406-428)
+ * + draw_v (:792-847).  cache[c].e must hold (y-hat - y) on entry and holds it on exit.
+ * alpha=1, mu=0, lambdas = reg (fm_learn_mcmc.h:1099-1125 with libfm.cpp:326-365). */
+void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache,
+                   double w0_lambda_unused, double w_lambda, double v_lambda);
+
+/* full ALS iteration loop of fm_learn_mcmc_simultaneous::_learn for task regression with
+ * do_sample = 0 (fm_learn_mcmc_simultaneous.h:56-150): returns after num_iter sweeps with the
+ * model updated; test predictions (last iterate, clamped) written to test_pred if non-NULL. */
+void fmo_als_learn(fmo_model *m, const fmo_data *train, const fmo_data *test, int num_iter,
+                   double w_lambda, double v_lambda, double min_target, double max_target,
+                   double *test_pred);
+
+/* ---------------- synthetic workload (shared definition with the HIP generator) ---------------- */
+
+/* One-hot field-structured rows: field t owns ids [t*fs, (t+1)*fs), fs = n/nnz;
+ * id = t*fs + hash(seed,row,t) mod-ish fs; value 1.0; target = +1/-1 from a hash bit. */
+uint64_t fmo_mix64(uint64_t x);
+uint32_t fmo_synth_id(uint64_t seed, uint64_t row, uint32_t field, uint32_t field_size);
+float    fmo_synth_target(uint64_t seed, uint64_t row);
+void     fmo_synth_rows(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint64_t n,
+                        fmo_entry *entries, uint64_t *row_ptr, float *target);
+
+/* deterministic cheap parameter fill used by bench.py for BOTH legs (not the reference RNG):
+ * v[f][j] = stdev * u(seed, j, f) with u uniform in [-sqrt3, sqrt3) (unit variance). */
+double fmo_init_value(uint64_t seed, uint64_t j, uint32_t f, double stdev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FM_ORACLE_H_ */

@@ -1,0 +1,226 @@
+"""ctypes binding of oracle/libfm_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (libfm_amd) never does; it fails loudly when its HIP library is missing.
+
+The functions mirror oracle/fm_oracle.h (which cites the reference file:line for each).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfm_oracle.so")
+REF_DIR = os.path.join(HERE, "_ref")
+REF_HARNESS = os.path.join(REF_DIR, "ref_harness")
+REF_LIBFM = os.path.join(REF_DIR, "libFM")
+
+ENTRY_DTYPE = np.dtype([("id", np.uint32), ("value", np.float32)])  # sparse_entry<float>, fmatrix.h:34-37
+
+TASK_REGRESSION = 0
+TASK_CLASSIFICATION = 1
+
+
+def build(force=False):
+    """(Re)build the oracle .so (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(LIB_PATH) or \
+            os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(HERE, f))
+                                             for f in ("fm_oracle.c", "fm_oracle_als.c", "fm_oracle.h")):
+        subprocess.check_call(["make", "-s", "-C", HERE, os.path.join(HERE, "libfm_oracle.so")])
+    if os.path.exists("/root/reference/src/libfm/libfm.cpp"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+class _Model(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("k", C.c_int32), ("k0", C.c_int32), ("k1", C.c_int32),
+                ("w0", C.c_double), ("w", C.c_void_p), ("v", C.c_void_p),
+                ("reg0", C.c_double), ("regw", C.c_double), ("regv", C.c_double)]
+
+
+class _Data(C.Structure):
+    _fields_ = [("entries", C.c_void_p), ("row_ptr", C.c_void_p), ("target", C.c_void_p),
+                ("n_rows", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.fmo_predict_raw.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_void_p]
+        L.fmo_predict_out.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.fmo_evaluate.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+        L.fmo_evaluate.restype = C.c_double
+        L.fmo_sgd_epoch_online.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double]
+        L.fmo_sgd_epoch_minibatch.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32]
+        L.fmo_multiplier.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.fmo_multiplier.restype = C.c_double
+        L.fmo_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fmo_synth_id.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.fmo_synth_id.restype = C.c_uint32
+        L.fmo_init_value.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double]
+        L.fmo_init_value.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+class Model:
+    """Reference-layout FM parameters: w0, w[n], v[k][n] factor-major fp64 (fm_model.h:46-48)."""
+
+    def __init__(self, n, k, k0=True, k1=True, reg0=0.0, regw=0.0, regv=0.0):
+        self.n, self.k, self.k0, self.k1 = int(n), int(k), bool(k0), bool(k1)
+        self.reg0, self.regw, self.regv = float(reg0), float(regw), float(regv)
+        self.w0 = 0.0
+        self.w = np.zeros(self.n, dtype=np.float64)
+        self.v = np.zeros((self.k, self.n), dtype=np.float64)
+
+    def copy(self):
+        m = Model(self.n, self.k, self.k0, self.k1, self.reg0, self.regw, self.regv)
+        m.w0 = self.w0
+        m.w[:] = self.w
+        m.v[:] = self.v
+        return m
+
+    def _c(self):
+        assert self.w.flags.c_contiguous and self.v.flags.c_contiguous
+        return _Model(self.n, self.k, int(self.k0), int(self.k1), self.w0,
+                      self.w.ctypes.data, self.v.ctypes.data, self.reg0, self.regw, self.regv)
+
+    @staticmethod
+    def from_dump(path, **kw):
+        """Read a ref_harness parameter dump (magic FMXP, u64 n, i32 k, f64 w0, w[n], v[k][n])."""
+        with open(path, "rb") as f:
+            raw = f.read()
+        assert raw[:4] == b"FMXP", path
+        n = int(np.frombuffer(raw, dtype=np.uint64, count=1, offset=4)[0])
+        k = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=12)[0])
+        m = Model(n, k, **kw)
+        vals = np.frombuffer(raw, dtype=np.float64, offset=16)
+        m.w0 = float(vals[0])
+        m.w[:] = vals[1:1 + n]
+        m.v[:] = vals[1 + n:1 + n + k * n].reshape(k, n)
+        return m
+
+
+class Data:
+    """CSR with the reference's AoS entries: {u32 id; f32 value}[nnz], row_ptr u64[n_rows+1], target f32."""
+
+    def __init__(self, entries, row_ptr, target):
+        self.entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        self.target = np.ascontiguousarray(target, dtype=np.float32)
+        self.n_rows = len(self.target)
+        assert len(self.row_ptr) == self.n_rows + 1
+
+    @property
+    def row_sizes(self):
+        return np.diff(self.row_ptr.astype(np.int64)).astype(np.uint32)
+
+    @property
+    def num_feature(self):
+        return int(self.entries["id"].max()) + 1 if len(self.entries) else 0
+
+    def _c(self):
+        return _Data(self.entries.ctypes.data, self.row_ptr.ctypes.data, self.target.ctypes.data, self.n_rows)
+
+    @staticmethod
+    def from_rows(rows, target):
+        """rows: list of lists of (id, value)."""
+        sizes = np.array([len(r) for r in rows], dtype=np.uint64)
+        row_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        ent = np.zeros(int(row_ptr[-1]), dtype=ENTRY_DTYPE)
+        p = 0
+        for r in rows:
+            for (i, v) in r:
+                ent[p] = (i, v)
+                p += 1
+        return Data(ent, row_ptr, target)
+
+    def write_libsvm(self, path):
+        """libsvm text the reference parser accepts (Data.h:192-285)."""
+        with open(path, "w") as f:
+            for r in range(self.n_rows):
+                a, b = int(self.row_ptr[r]), int(self.row_ptr[r + 1])
+                toks = ["%.9g" % self.target[r]]
+                toks += ["%d:%.9g" % (int(e["id"]), float(e["value"])) for e in self.entries[a:b]]
+                f.write(" ".join(toks) + "\n")
+
+    @staticmethod
+    def read_libsvm(path):
+        rows, ys = [], []
+        with open(path) as f:
+            for line in f:
+                line = line.strip()
+                if not line or line.startswith("#"):
+                    continue
+                toks = line.split()
+                ys.append(np.float32(toks[0]))
+                rows.append([(int(t.split(":")[0]), np.float32(t.split(":")[1])) for t in toks[1:]])
+        return Data.from_rows(rows, np.array(ys, dtype=np.float32))
+
+
+def predict_raw(m, d):
+    out = np.zeros(d.n_rows, dtype=np.float64)
+    cm, cd = m._c(), d._c()
+    lib().fmo_predict_raw(C.byref(cm), C.byref(cd), out.ctypes.data)
+    return out
+
+
+def predict_out(m, d, task, min_target, max_target):
+    out = np.zeros(d.n_rows, dtype=np.float64)
+    cm, cd = m._c(), d._c()
+    lib().fmo_predict_out(C.byref(cm), C.byref(cd), task, min_target, max_target, out.ctypes.data)
+    return out
+
+
+def evaluate(m, d, task, min_target, max_target):
+    mae = C.c_double(0)
+    cm, cd = m._c(), d._c()
+    r = lib().fmo_evaluate(C.byref(cm), C.byref(cd), task, min_target, max_target, C.byref(mae))
+    return r, mae.value
+
+
+def sgd_epoch_online(m, d, task, lr, min_target, max_target):
+    cm, cd = m._c(), d._c()
+    lib().fmo_sgd_epoch_online(C.byref(cm), C.byref(cd), task, lr, min_target, max_target)
+    m.w0 = cm.w0
+
+
+def sgd_epoch_minibatch(m, d, task, lr, min_target, max_target, batch, w0_chunk):
+    cm, cd = m._c(), d._c()
+    lib().fmo_sgd_epoch_minibatch(C.byref(cm), C.byref(cd), task, lr, min_target, max_target, batch, w0_chunk)
+    m.w0 = cm.w0
+
+
+def synth_rows(seed, row0, n_rows, nnz, n):
+    ent = np.zeros(n_rows * nnz, dtype=ENTRY_DTYPE)
+    rp = np.zeros(n_rows + 1, dtype=np.uint64)
+    y = np.zeros(n_rows, dtype=np.float32)
+    lib().fmo_synth_rows(seed, row0, n_rows, nnz, n, ent.ctypes.data, rp.ctypes.data, y.ctypes.data)
+    return Data(ent, rp, y)
+
+
+def init_values(seed, n, k, stdev):
+    """fmo_init_value for every (j, f), vectorised in numpy (bit-identical to the C function)."""
+    j = np.arange(n, dtype=np.uint64)[None, :]
+    f = np.arange(k, dtype=np.uint64)[:, None]
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) ^ (j * np.uint64(0x9E3779B97F4A7C15) + f * np.uint64(0xD6E8FEB86659FD93) + np.uint64(0x1234567))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return stdev * (2.0 * u - 1.0) * 1.7320508075688772
+
+
+def run_ref_harness(args, cwd=None):
+    """Run oracle/_ref/ref_harness (the real reference classes).  Raises if it is not built."""
+    if not os.path.exists(REF_HARNESS):
+        raise FileNotFoundError("oracle/_ref/ref_harness not built (needs /root/reference); run make -C oracle")
+    return subprocess.run([REF_HARNESS] + [str(a) for a in args], cwd=cwd, check=True,
+                          capture_output=True, text=True)

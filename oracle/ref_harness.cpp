@@ -1,0 +1,198 @@
+// ref_harness.cpp -- drives the REAL reference (srendle/libfm) classes and dumps full-precision state.
+//
+// TEST INFRASTRUCTURE ONLY.  This translation unit is ours; it #includes the reference headers where
+// they lie (-I/root/reference/src, never copied) and is compiled by oracle/Makefile into
+// oracle/_ref/ref_harness.  It exists because the stock binary only prints 6 significant digits
+// (matrix.h:332-342, fm_model.h:132-154); the parity pin needs raw doubles.
+//
+// The reference defines non-inline functions in its headers, so everything lives in this one TU
+// (same constraint as src/libfm/libfm.cpp:49-57).
+//
+// usage:
+//   ref_harness sgd  <train> <test> <task r|c> <k0> <k1> <k> <iters> <lr> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
+//   ref_harness als  <train> <test> <task r|c> <k0> <k1> <k> <iters> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
+//   ref_harness mcmc <train> <test> <task r|c> <k0> <k1> <k> <iters> <init_stdev> <seed> <out_prefix>
+//   ref_harness time_sgd <n> <k> <nnz> <rows> <seed>        (CPU baseline: reference fm_model::predict + fm_SGD on
+//                                                             the synthetic workload of oracle/fm_oracle.c, 1 thread)
+// outputs (<out_prefix>.*):
+//   .init.bin / .final.bin : magic 'FMXP', u64 n, i32 k, f64 w0, f64 w[n], f64 v[k][n]  (reference layout)
+//   .pred_raw.bin          : f64[num_test]  fm_learn::predict_case per test row after training
+//   .pred_out.bin          : f64[num_test]  fml->predict(test, pred)   (what -out writes)
+//   .eval.txt              : one line per epoch: evaluate(train) evaluate(test) with %.17g
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+#include <iterator>
+#include <algorithm>
+#include <iomanip>
+#include <sys/time.h>
+#include "util/util.h"
+#include "util/cmdline.h"
+#include "fm_core/fm_model.h"
+#include "libfm/src/Data.h"
+#include "libfm/src/fm_learn.h"
+#include "libfm/src/fm_learn_sgd.h"
+#include "libfm/src/fm_learn_sgd_element.h"
+#include "libfm/src/fm_learn_sgd_element_adapt_reg.h"
+#include "libfm/src/fm_learn_mcmc_simultaneous.h"
+
+#include "fm_oracle.h"   // only for the synthetic-row generator used by time_sgd
+
+static void dump_params(const std::string& path, fm_model& fm) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) { perror(path.c_str()); exit(2); }
+  const char magic[4] = {'F', 'M', 'X', 'P'};
+  unsigned long long n = fm.num_attribute;
+  int k = fm.num_factor;
+  fwrite(magic, 1, 4, f);
+  fwrite(&n, sizeof(n), 1, f);
+  fwrite(&k, sizeof(k), 1, f);
+  fwrite(&fm.w0, sizeof(double), 1, f);
+  fwrite(fm.w.value, sizeof(double), n, f);
+  for (int i = 0; i < k; i++) fwrite(fm.v.value[i], sizeof(double), n, f);
+  fclose(f);
+}
+
+static void dump_vec(const std::string& path, const double* p, size_t n) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) { perror(path.c_str()); exit(2); }
+  fwrite(p, sizeof(double), n, f);
+  fclose(f);
+}
+
+// exposes the protected per-row predictor of the learner base class
+template <class L> struct Open : public L {
+  double raw(Data& d) { return this->predict_case(d); }
+};
+
+static void set_task(fm_learn* fml, const std::string& task, Data& train, Data& test) {
+  // src/libfm/libfm.cpp:298-309
+  if (task == "r") {
+    fml->task = 0;
+  } else {
+    fml->task = 1;
+    for (uint i = 0; i < train.target.dim; i++) { if (train.target(i) <= 0.0) { train.target(i) = -1.0; } else { train.target(i) = 1.0; } }
+    for (uint i = 0; i < test.target.dim; i++) { if (test.target(i) <= 0.0) { test.target(i) = -1.0; } else { test.target(i) = 1.0; } }
+  }
+}
+
+static double wall() { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+
+static int run_time_sgd(int argc, char** argv) {
+  if (argc < 7) { fprintf(stderr, "time_sgd <n> <k> <nnz> <rows> <seed>\n"); return 2; }
+  unsigned long long n = strtoull(argv[2], 0, 10);
+  int k = atoi(argv[3]); uint nnz = atoi(argv[4]); uint rows = atoi(argv[5]);
+  unsigned long long seed = strtoull(argv[6], 0, 10);
+  if ((unsigned long long)k * n >= (1ULL << 32)) {
+    fprintf(stderr, "k*n >= 2^32: the stock reference cannot allocate this (matrix.h:167-169)\n");
+    return 3;
+  }
+  fm_model fm;
+  fm.num_attribute = (uint)n; fm.num_factor = k; fm.k0 = true; fm.k1 = true;
+  fm.init_stdev = 0; fm.init_mean = 0;       // ran_gaussian short-circuits (random.h:164-166): fast fill
+  fm.init();
+  fm.regv = 0.001;
+  for (int f = 0; f < k; f++) for (unsigned long long j = 0; j < n; j += 1) fm.v.value[f][j] = 0.01 * (((j * 2654435761ULL + f * 40503ULL) & 1023) / 512.0 - 1.0);
+  std::vector<fmo_entry> ent((size_t)rows * nnz); std::vector<uint64_t> rp(rows + 1); std::vector<float> y(rows);
+  fmo_synth_rows(seed, 0, rows, nnz, n, ent.data(), rp.data(), y.data());
+  DVector<double> sum, sum_sqr; sum.setSize(k); sum_sqr.setSize(k);
+  double t0 = wall();
+  for (uint r = 0; r < rows; r++) {
+    sparse_row<FM_FLOAT> row; row.data = (sparse_entry<FM_FLOAT>*)&ent[(size_t)r * nnz]; row.size = nnz;
+    double p = fm.predict(row, sum, sum_sqr);
+    double mult = -y[r] * (1.0 - 1.0 / (1.0 + exp(-y[r] * p)));
+    fm_SGD(&fm, 0.01, row, mult, sum);
+  }
+  double t1 = wall();
+  printf("{\"rows\": %u, \"seconds\": %.6f, \"examples_per_sec\": %.3f, \"w0\": %.17g}\n", rows, t1 - t0, rows / (t1 - t0), fm.w0);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "see header of ref_harness.cpp\n"); return 2; }
+  std::string mode = argv[1];
+  if (mode == "time_sgd") return run_time_sgd(argc, argv);
+  try {
+    int a = 2;
+    std::string train_file = argv[a++], test_file = argv[a++], task = argv[a++];
+    int k0 = atoi(argv[a++]), k1 = atoi(argv[a++]), k = atoi(argv[a++]);
+    int iters = atoi(argv[a++]);
+    double lr = 0, reg0 = 0, regw = 0, regv = 0;
+    if (mode == "sgd") lr = atof(argv[a++]);
+    if (mode != "mcmc") { reg0 = atof(argv[a++]); regw = atof(argv[a++]); regv = atof(argv[a++]); }
+    double init_stdev = atof(argv[a++]);
+    long seed = atol(argv[a++]);
+    std::string prefix = argv[a++];
+
+    srand(seed);                                               // libfm.cpp:115-116
+    const bool is_sgd = (mode == "sgd");
+    Data train(0, is_sgd, !is_sgd);                            // libfm.cpp:143-148
+    train.load(train_file);
+    Data test(0, is_sgd, !is_sgd);
+    test.load(test_file);
+    uint num_all_attribute = std::max(train.num_feature, test.num_feature);   // libfm.cpp:203
+    DataMetaInfo meta(num_all_attribute);
+    meta.num_relations = 0;
+    train.relation.setSize(0); test.relation.setSize(0);
+
+    fm_model fm;                                               // libfm.cpp:245-258
+    fm.num_attribute = num_all_attribute;
+    fm.init_stdev = init_stdev;
+    fm.k0 = k0 != 0; fm.k1 = k1 != 0; fm.num_factor = k;
+    fm.init();
+
+    FILE* ev = fopen((prefix + ".eval.txt").c_str(), "w");
+    if (is_sgd) {
+      Open<fm_learn_sgd_element>* fml = new Open<fm_learn_sgd_element>();
+      fml->num_iter = 1;
+      fml->fm = &fm; fml->max_target = train.max_target; fml->min_target = train.min_target; fml->meta = &meta;
+      set_task(fml, task, train, test);
+      fml->log = NULL;
+      fml->init();
+      fm.reg0 = reg0; fm.regw = regw; fm.regv = regv;         // libfm.cpp:366-385
+      fml->learn_rate = lr; fml->learn_rates.init(lr);        // libfm.cpp:391-395
+      dump_params(prefix + ".init.bin", fm);
+      for (int it = 0; it < iters; it++) {
+        fml->learn(train, test);                               // one epoch of fm_learn_sgd_element.h:53-67
+        fprintf(ev, "%.17g %.17g\n", fml->evaluate(train), fml->evaluate(test));
+      }
+      dump_params(prefix + ".final.bin", fm);
+      std::vector<double> raw(test.num_cases);
+      for (test.data->begin(); !test.data->end(); test.data->next()) raw[test.data->getRowIndex()] = fml->raw(test);
+      dump_vec(prefix + ".pred_raw.bin", raw.data(), raw.size());
+      DVector<double> pred; pred.setSize(test.num_cases);
+      fml->predict(test, pred);
+      dump_vec(prefix + ".pred_out.bin", pred.value, pred.dim);
+    } else {
+      const bool is_als = (mode == "als");
+      fm.w.init_normal(fm.init_mean, fm.init_stdev);          // libfm.cpp:283
+      fm_learn_mcmc_simultaneous* fml = new fm_learn_mcmc_simultaneous();
+      fml->validation = NULL;
+      fml->num_iter = iters;
+      fml->num_eval_cases = test.num_cases;
+      fml->do_sample = !is_als;                                // libfm.cpp:135-139
+      fml->do_multilevel = !is_als;
+      fml->fm = &fm; fml->max_target = train.max_target; fml->min_target = train.min_target; fml->meta = &meta;
+      set_task(fml, task, train, test);
+      fml->log = NULL;
+      fml->init();
+      fm.reg0 = reg0; fm.regw = regw; fm.regv = regv;         // libfm.cpp:346-352
+      fml->w_lambda.init(fm.regw); fml->v_lambda.init(fm.regv);
+      dump_params(prefix + ".init.bin", fm);
+      fml->learn(train, test);
+      dump_params(prefix + ".final.bin", fm);
+      DVector<double> pred; pred.setSize(test.num_cases);
+      fml->predict(test, pred);                                // fm_learn_mcmc.h:380-404
+      dump_vec(prefix + ".pred_out.bin", pred.value, pred.dim);
+    }
+    fclose(ev);
+  } catch (std::string& e) {
+    std::cerr << "ERROR: " << e << std::endl; return 1;
+  } catch (char const*& e) {
+    std::cerr << "ERROR: " << e << std::endl; return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by running the REAL reference.
+
+Needs /root/reference (build container only): `make -C oracle` compiles oracle/_ref/ref_harness from the
+reference sources where they lie; this script feeds it seeded data sets (tests/datagen.py) and stores the
+inputs, the configuration and the reference's full-precision outputs.  The fixtures pin the C restatement
+(oracle/fm_oracle.c) in the `-m "not gpu"` tests and the HIP path in the `-m gpu` tests; the GPU box has no
+/root/reference, so the committed .npz files are what travels.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import datagen  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+CASES = {
+    # name: (generator, kwargs_train, kwargs_test, config)
+    "sgd_reg_ml": dict(gen="movielens_shaped", train=dict(n_users=120, n_items=80, n_rows=600, seed=11),
+                       test=dict(n_users=120, n_items=80, n_rows=150, seed=12),
+                       cfg=dict(task="r", k0=1, k1=1, k=8, iters=5, lr=0.01, reg=(0.0, 0.0, 0.01), init_stdev=0.1, seed=42)),
+    "sgd_cls_ragged": dict(gen="ragged_real", train=dict(n_features=300, n_rows=400, max_nnz=12, seed=21, empty_every=50),
+                           test=dict(n_features=300, n_rows=100, max_nnz=12, seed=22),
+                           cfg=dict(task="c", k0=1, k1=1, k=16, iters=4, lr=0.02, reg=(0.001, 0.002, 0.003), init_stdev=0.05, seed=7)),
+    "sgd_reg_ragged_nolin": dict(gen="ragged_real", train=dict(n_features=200, n_rows=300, max_nnz=9, seed=31, classification=False),
+                                 test=dict(n_features=200, n_rows=80, max_nnz=9, seed=32, classification=False),
+                                 cfg=dict(task="r", k0=0, k1=0, k=4, iters=3, lr=0.01, reg=(0.0, 0.0, 0.02), init_stdev=0.1, seed=3)),
+    "sgd_cls_k64": dict(gen="onehot_fields", train=dict(n_features=640, nnz=8, n_rows=300, seed=41),
+                        test=dict(n_features=640, nnz=8, n_rows=100, seed=42),
+                        cfg=dict(task="c", k0=1, k1=1, k=64, iters=3, lr=0.01, reg=(0.0, 0.0, 0.001), init_stdev=0.01, seed=1)),
+    "sgd_cls_dup": dict(gen="ragged_real", train=dict(n_features=60, n_rows=120, max_nnz=6, seed=51, duplicates=True),
+                        test=dict(n_features=60, n_rows=40, max_nnz=6, seed=52),
+                        cfg=dict(task="c", k0=1, k1=1, k=8, iters=2, lr=0.05, reg=(0.0, 0.01, 0.01), init_stdev=0.1, seed=5)),
+    "sgd_reg_k1": dict(gen="movielens_shaped", train=dict(n_users=30, n_items=20, n_rows=200, seed=61),
+                       test=dict(n_users=30, n_items=20, n_rows=50, seed=62),
+                       cfg=dict(task="r", k0=1, k1=1, k=1, iters=3, lr=0.02, reg=(0.0, 0.0, 0.0), init_stdev=0.1, seed=9)),
+    "sgd_cls_zipf_k32": dict(gen="onehot_fields", train=dict(n_features=1600, nnz=16, n_rows=500, seed=71, zipf=1.05),
+                             test=dict(n_features=1600, nnz=16, n_rows=100, seed=72, zipf=1.05),
+                             cfg=dict(task="c", k0=1, k1=1, k=32, iters=2, lr=0.01, reg=(0.0, 0.0, 0.001), init_stdev=0.01, seed=2)),
+}
+
+
+def main():
+    O.build()
+    for name, case in CASES.items():
+        gen = getattr(datagen, case["gen"])
+        tr = O.Data(*gen(**case["train"]))
+        te = O.Data(*gen(**case["test"]))
+        cfg = case["cfg"]
+        with tempfile.TemporaryDirectory() as td:
+            trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
+            tr.write_libsvm(trf)
+            te.write_libsvm(tef)
+            O.run_ref_harness(["sgd", trf, tef, cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"], repr(cfg["lr"]),
+                               repr(cfg["reg"][0]), repr(cfg["reg"][1]), repr(cfg["reg"][2]), repr(cfg["init_stdev"]),
+                               cfg["seed"], pre])
+            init = O.Model.from_dump(pre + ".init.bin")
+            final = O.Model.from_dump(pre + ".final.bin")
+            pred_raw = np.fromfile(pre + ".pred_raw.bin", dtype=np.float64)
+            pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+            ev = np.loadtxt(pre + ".eval.txt", ndmin=2)
+        # what the reference parser saw: targets as parsed floats; for task c they become +-1 (libfm.cpp:302-306)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            train_entries=tr.entries, train_row_ptr=tr.row_ptr, train_target=tr.target,
+            test_entries=te.entries, test_row_ptr=te.row_ptr, test_target=te.target,
+            task=cfg["task"], k0=cfg["k0"], k1=cfg["k1"], k=cfg["k"], iters=cfg["iters"], lr=cfg["lr"],
+            reg=np.array(cfg["reg"]), init_stdev=cfg["init_stdev"], seed=cfg["seed"],
+            n=init.n, init_w0=init.w0, init_w=init.w, init_v=init.v,
+            final_w0=final.w0, final_w=final.w, final_v=final.v,
+            pred_raw=pred_raw, pred_out=pred_out, eval=ev)
+        print("%-22s n=%d k=%d rows=%d/%d  eval[-1]=%s" % (name, init.n, init.k, tr.n_rows, te.n_rows, ev[-1]))
+
+
+if __name__ == "__main__":
+    main()
