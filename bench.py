@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- SGD training throughput of the FM hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (north star): n = 1e8 features, k = 64, 32 nnz/row, one-hot field rows with uniform
+ids, values 1.0, +-1 labels, task = classification, lr 0.01, regular 0,0,0.001; synthetic rows are generated ON
+the device (fmx_synth_rows) and the parameters are filled on the device (fmx_init_params), so everything is
+resident in HBM before the timed region.  A "step" is one SGD pass over `--rows` examples.
+
+N = 1 : the whole pass runs inside the library (fmx_sgd_epoch).
+N > 1 : V/w are row-sharded by feature id (owner = id mod N); every rank sees every example restricted to its
+        own features; per minibatch ONE all-reduce (RCCL) of the [B][k+1] partial sums, then every rank
+        updates its shard (fmx_sgd_partial -> all_reduce -> fmx_sgd_finish).  Total work is fixed => "strong".
+
+The JSON line carries `roofline` (dominant kernel: algorithmic bytes / HIP-event duration vs the 8 TB/s HBM
+peak) and, at N = 1, `cpu_baseline` (the C restatement of the reference loop, one thread, bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s copy ceiling)
+
+
+def algorithmic_bytes(k, nnz, kind):
+    """SURVEY section 8(d), fp32 parameters, u32 ids, f32 values."""
+    read_step = nnz * (4 * k + 12) + 4          # ids+values, w, V rows, target
+    write_step = nnz * (4 * k + 4)              # w, V rows
+    if kind == "fused":                         # whole training step in one kernel
+        return read_step + write_step
+    if kind == "apply":                         # k_apply: ids+values, w, V, the example's S row and multiplier; writes w, V
+        return nnz * (4 * k + 12) + 4 * k + 4 + write_step
+    if kind == "rowsums":                       # k_rowsums: predict-side reads, writes S row + scalar
+        return nnz * (4 * k + 12) + 4 * k + 4
+    raise ValueError(kind)
+
+
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def cpu_baseline(n, k, nnz, rows):
+    """oracle leg: the restated reference loop (fm_model::predict + fm_SGD, fp64, factor-major V) on one core."""
+    from oracle import oracle as O
+    n_cpu = n
+    need = lambda nn: nn * k * 8 + nn * 8
+    avail = mem_available_bytes()
+    while avail and need(n_cpu) * 1.25 > avail and n_cpu > 10 ** 6:
+        n_cpu //= 2
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    sec, eps = O.time_sgd_synth(n_cpu, k, nnz, rows, seed=123, threads=min(cores, 64))
+    setup = time.time() - t0 - sec
+    sample = "%d rows of the synthetic workload at n=%d k=%d nnz=%d, fp64 reference layout, 1 epoch" % (rows, n_cpu, k, nnz)
+    if n_cpu != n:
+        sample += " (n reduced from %d: host RAM)" % n
+    return {"value": round(eps, 1), "unit": "examples/s", "cores": 1, "kind": "port", "sample": sample,
+            "seconds": round(sec, 3), "setup_seconds": round(setup, 1), "host_cores": cores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--nnz", type=int, default=32)
+    ap.add_argument("--rows", type=int, default=1 << 22, help="examples per step")
+    ap.add_argument("--mode", default="minibatch", choices=["minibatch", "hogwild"])
+    ap.add_argument("--apply", default="atomic", choices=["atomic", "store"])
+    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 65536 sharded)")
+    ap.add_argument("--w0-chunk", type=int, default=64)
+    ap.add_argument("--cpu-rows", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", type=float, default=None, help="PMC HBM bytes per launch of the dominant kernel")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from libfm_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.n, args.k, args.nnz, args.cpu_rows)
+
+    lr, regv = 0.01, 0.001
+    h = capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
+                    device=local_rank, shard_rank=rank, shard_world=world)
+    h.init_params(0.0, 0.01, 1)
+    h.synth_rows(0, 123, 0, args.rows, args.nnz)
+    info = h.info()
+    mode = capi.SGD_HOGWILD if args.mode == "hogwild" else capi.SGD_MINIBATCH
+    apply_ = capi.APPLY_ATOMIC if args.apply == "atomic" else capi.APPLY_STORE
+
+    if world == 1:
+        batch = args.batch or 16384
+        main_time, main_launches = 0.0, 0
+
+        def step(timed):
+            nonlocal main_time, main_launches
+            st = h.sgd_epoch(0, mode, apply_, batch, args.w0_chunk, capi.FLAG_TIME_MAIN_KERNEL if timed else 0)
+            if timed:
+                main_time += st.main_kernel_seconds
+                main_launches += st.main_kernel_launches
+        rows_per_launch = args.rows if args.mode == "hogwild" else min(batch, args.rows)
+        kind = "fused" if args.mode == "hogwild" else "apply"
+    else:
+        batch = args.batch or 65536
+        kp1 = info.k_padded + 1
+        buf = torch.empty(batch * kp1, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def step(timed):
+            for row0 in range(0, args.rows, batch):
+                nb = min(batch, args.rows - row0)
+                view = buf[: nb * kp1]
+                h.sgd_partial(0, row0, nb, view.data_ptr(), stream)
+                dist.all_reduce(view)
+                h.sgd_finish(0, row0, nb, view.data_ptr(), apply_, args.w0_chunk, stream)
+        rows_per_launch = min(batch, args.rows)
+        kind = "apply"
+        main_time, main_launches = 0.0, 0
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    h.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    h.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = args.steps * args.rows / elapsed
+        roof = None
+        if main_launches:
+            # the shard sees nnz/world entries per example; k_apply / k_fused bytes scale with them
+            per_ex = algorithmic_bytes(args.k, args.nnz, kind)
+            avg = main_time / main_launches
+            achieved = per_ex * rows_per_launch / avg / 1e9
+            roof = {"bound": "hbm", "kernel": "k_fused" if kind == "fused" else "k_apply",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic,
+                    "bytes_per_example": per_ex, "examples_per_launch": rows_per_launch,
+                    "avg_launch_ms": round(avg * 1e3, 4), "launches": main_launches}
+        out = {
+            "metric": "SGD training examples/sec at k=%d, nnz=%d, %.0e feat" % (args.k, args.nnz, args.n),
+            "value": round(value, 1), "unit": "examples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
+                                   % (args.n, args.k, args.nnz, args.rows, lr, regv),
+                       "mode": args.mode, "apply": args.apply, "batch": batch if args.mode == "minibatch" or world > 1 else None,
+                       "w0_chunk": args.w0_chunk, "sharding": "features mod %d" % world if world > 1 else "none",
+                       "device": info.device_name.decode(), "arch": info.arch.decode()},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+/*
+ * fmx.h -- C-ABI of the MI355X-native Factorization Machine hot path (libfmx.so).
+ *
+ * This is the drop-in boundary for srendle/libfm's learner interface.  libFM has no plugin/FFI API;
+ * its de-facto operator interface is `class fm_learn` (/root/reference/src/libfm/src/fm_learn.h:31-60)
+ * driven by main() (/root/reference/src/libfm/libfm.cpp:271-434).  Each entry point below names the
+ * reference interface it replaces.  The reference-side binding (an fm_learn subclass calling these
+ * functions) is shown in INTEGRATION.md and lives in adapter/fm_learn_gpu.h.
+ *
+ * Conventions
+ *   - plain C: opaque handle, POD structs, raw pointers and sizes; no C++/torch types cross the boundary.
+ *   - every call returns FMX_OK (0) or a negative FMX_E_* code; fmx_last_error(h) gives the text.
+ *     (The reference throws std::string / const char* caught in main, libfm.cpp:436-440; the adapter
+ *      re-throws the text so that behaviour is preserved.)
+ *   - host parameter layout is the reference's: w0 double, w[n] double, v[k][n] double FACTOR-major
+ *     (fm_model.h:46-48, matrix.h:165-170: fm->v.value[0] is one contiguous k*n block).
+ *   - host row layout is the reference's: one contiguous array of sparse_entry<float> {uint32 id; float value}
+ *     in row order (fmatrix.h:34-42; Data.h:237-270 allocates exactly this) plus row offsets.
+ *   - device layout (inside the library): V is FEATURE-major fp32, rows padded to a power of two,
+ *     so one gathered row is one coalesced segment (256 B at k=64).  See DESIGN.md section 2.
+ *   - single calling thread per handle (the reference is single threaded).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with FMX_E_HIP.
+ */
+#ifndef FMX_H_
+#define FMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMX_ABI_VERSION 1
+
+enum {
+  FMX_OK = 0,
+  FMX_E_ARG = -1,       /* bad argument */
+  FMX_E_HIP = -2,       /* HIP runtime error (no device, out of memory, launch failure) */
+  FMX_E_STATE = -3,     /* call order violated (e.g. slot not uploaded) */
+  FMX_E_UNSUPPORTED = -4
+};
+
+enum { FMX_TASK_REGRESSION = 0, FMX_TASK_CLASSIFICATION = 1 };   /* fm_learn.h:45-47 */
+
+/* SGD update modes */
+enum {
+  FMX_SGD_SEQUENTIAL = 0,  /* batch = 1, rows in storage order: the reference trajectory
+                              (fm_learn_sgd_element.h:56-67), for parity; one wavefront, slow */
+  FMX_SGD_MINIBATCH = 1,   /* restated batch rule (oracle/fm_oracle.h fmo_sgd_epoch_minibatch):
+                              partial sums -> [all-reduce] -> w0 micro-chunks + multipliers -> scatter-add */
+  FMX_SGD_HOGWILD = 2      /* fused single pass per example (gather, predict, update in registers);
+                              asynchronous between wavefronts; single device only */
+};
+
+enum {
+  FMX_APPLY_ATOMIC = 0,    /* fp32 atomic scatter-add of the per-occurrence deltas */
+  FMX_APPLY_STORE = 1      /* plain read-modify-write stores (colliding ids in a batch lose updates) */
+};
+
+typedef struct fmx_context_s *fmx_handle;
+
+/* replaces the fields main() writes into fm_model / fm_learn (libfm.cpp:245-256, 294-309, 366-404) */
+typedef struct fmx_config {
+  uint64_t num_attribute;   /* fm_model::num_attribute (global n)            fm_model.h:51 */
+  int32_t  num_factor;      /* fm_model::num_factor (k)                      fm_model.h:54 */
+  int32_t  k0;              /* use bias                                       fm_model.h:53 */
+  int32_t  k1;              /* use 1-way interactions                         fm_model.h:53 */
+  int32_t  task;            /* fm_learn::task                                 fm_learn.h:45 */
+  double   reg0, regw, regv;/* fm_model::reg0/regw/regv                       fm_model.h:56-57 */
+  double   learn_rate;      /* fm_learn_sgd::learn_rate                       fm_learn_sgd.h:42 */
+  double   min_target;      /* fm_learn::min_target (of the TRAIN set)        libfm.cpp:295-296 */
+  double   max_target;
+  int32_t  device;          /* HIP device ordinal; -1 = current device */
+  int32_t  shard_rank;      /* feature sharding: this handle owns the features j with            */
+  int32_t  shard_world;     /*   j % shard_world == shard_rank  (1 = unsharded)                  */
+  int32_t  reserved;
+} fmx_config;
+
+typedef struct fmx_sgd_opts {
+  int32_t  mode;            /* FMX_SGD_* */
+  int32_t  apply;           /* FMX_APPLY_* (MINIBATCH and HOGWILD) */
+  uint32_t batch;           /* rows per minibatch (MINIBATCH); 0 = library default (16384) */
+  uint32_t w0_chunk;        /* w0 micro-chunk (MINIBATCH); 0 = library default (64) */
+  uint32_t flags;           /* FMX_FLAG_* */
+  uint32_t reserved;
+} fmx_sgd_opts;
+
+#define FMX_FLAG_TIME_MAIN_KERNEL 1u  /* bracket every launch of the dominant kernel with HIP events */
+
+typedef struct fmx_epoch_stats {
+  uint64_t rows;            /* examples processed */
+  uint64_t batches;
+  double   device_seconds;  /* HIP-event time of the epoch's kernels on the handle's stream */
+  double   main_kernel_seconds; /* HIP-event time summed over launches of the dominant kernel only */
+  uint64_t main_kernel_launches;
+} fmx_epoch_stats;
+
+/* what fm_learn::evaluate_regression / evaluate_classification compute (fm_learn.h:113-153) */
+typedef struct fmx_eval {
+  double   rmse;            /* regression: sqrt(sum err^2 / N) with clamped predictions */
+  double   mae;             /* regression */
+  double   accuracy;        /* classification: sign agreement (p>=0 vs y>=0) */
+  double   device_seconds;
+  uint64_t rows;
+} fmx_eval;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* replaces: fm_model fm; fm.init() allocation (fm_model.h:91-99) + new fm_learn_* (libfm.cpp:271-293) */
+int fmx_create(const fmx_config *cfg, fmx_handle *out);
+int fmx_destroy(fmx_handle h);
+/* text of the last error on this handle (h may be NULL: last creation error). Never NULL. */
+const char *fmx_last_error(fmx_handle h);
+int fmx_abi_version(void);
+/* number of visible HIP devices (0 when none / no driver) */
+int fmx_device_count(void);
+
+/* ---- parameters: the fm_model block (fm_model.h:46-48) -------------------------------------- */
+/* host -> device. w may be NULL when k1 == 0, v may be NULL when k == 0.  In sharded mode the FULL
+ * arrays are passed and the handle keeps its own features. */
+int fmx_set_params(fmx_handle h, double w0, const double *w, const double *v);
+/* device -> host, same layout; after learn() the host fm_model must hold the result (libfm.cpp:431-434).
+ * Sharded mode: only this shard's features are written, the rest of w / v is left untouched. */
+int fmx_get_params(fmx_handle h, double *w0, double *w, double *v);
+/* device-side fill for workloads too large to stage through the host (bench.py):
+ * w0 = 0, w = 0, v[f][j] = mean + fmo_init_value(seed, j, f, stdev) -- a counter-hash uniform with unit
+ * variance (same definition as oracle/fm_oracle.c), NOT the reference's rand() stream (fm_model.h:96). */
+int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t seed);
+/* the scalar bias alone (cheap; used between minibatches by multi-process drivers) */
+int fmx_get_w0(fmx_handle h, double *w0);
+
+/* ---- rows: what Data::load produces (Data.h:237-270) ---------------------------------------- */
+/* uploads a data set into `slot` (0..FMX_MAX_SLOTS-1).  entries: {uint32 id; float value}[nnz] in row
+ * order (the buffer Data::load allocates), row_ptr: uint64[n_rows+1] prefix sums of sparse_row::size,
+ * target: float[n_rows] (already rewritten to +-1 for classification, libfm.cpp:302-306); may be NULL
+ * for predict-only slots.  ids must be < num_attribute (asserted by the reference, fm_model.h:112). */
+#define FMX_MAX_SLOTS 8
+int fmx_upload_rows(fmx_handle h, int slot, const void *entries, const uint64_t *row_ptr,
+                    const float *target, uint32_t n_rows, uint64_t nnz);
+/* synthetic one-hot field rows generated on the device (bench workload; same
+ * definition as oracle/fm_oracle.c fmo_synth_rows): rows row0 .. row0+n_rows-1 */
+int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz);
+int fmx_free_rows(fmx_handle h, int slot);
+/* copies a slot back to the host (tests / debugging): sizes via fmx_rows_info first.  Sharded handles return
+ * their LOCAL rows (kept entries only, ids = global id / shard_world). Any pointer may be NULL. */
+int fmx_rows_info(fmx_handle h, int slot, uint32_t *n_rows, uint64_t *nnz);
+int fmx_download_rows(fmx_handle h, int slot, void *entries, uint64_t *row_ptr, float *target);
+
+/* ---- fm_model::predict over a data set (fm_model.h:105-127 via fm_learn.h:63-65) -------------- */
+/* raw y-hat per row (no clamp / sigmoid: fm_learn_sgd::predict applies those on the host,
+ * fm_learn_sgd.h:80-87).  out: double[n_rows]. Sharded handles return the PARTIAL sums only. */
+int fmx_predict(fmx_handle h, int slot, double *out);
+/* fm_learn::evaluate (fm_learn.h:93-153) fused on the device */
+int fmx_evaluate(fmx_handle h, int slot, fmx_eval *out);
+
+/* ---- fm_learn_sgd_element::learn, one epoch (fm_learn_sgd_element.h:56-67) -------------------- */
+int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_epoch_stats *stats);
+
+/* ---- minibatch step split at the exchange point, for one-process-per-GPU drivers --------------
+ * partial: floats per batch = fmx_partial_floats(h, batch): [batch][KP] partial factor sums followed by
+ *          [batch] scalars (linear term - 0.5*sum of squares).  d_partial is DEVICE memory.
+ * The driver all-reduces (sum) d_partial across the feature shards (RCCL), then calls finish on every
+ * rank: multipliers + w0 micro-chunks (identical on all ranks) and the scatter-add into the local shard.
+ * `stream` is a hipStream_t (NULL = the handle's own stream). */
+int fmx_partial_floats(fmx_handle h, uint32_t batch, uint64_t *n_floats);
+int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, float *d_partial, void *stream);
+int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const float *d_partial,
+                   const fmx_sgd_opts *opts, void *stream);
+/* sharded predict: finish a partial buffer into y-hat (device float[n_rows]) */
+int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float *d_partial, float *d_yhat, void *stream);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+typedef struct fmx_info {
+  uint64_t n_local;         /* features held by this handle */
+  int32_t  k_padded;        /* device row length in floats (power of two >= k) */
+  int32_t  device;
+  uint64_t bytes_params;    /* device bytes of w + V */
+  char     device_name[64];
+  char     arch[32];        /* e.g. "gfx950" */
+} fmx_info;
+int fmx_get_info(fmx_handle h, fmx_info *out);
+int fmx_synchronize(fmx_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMX_H_ */

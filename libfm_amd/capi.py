@@ -1,0 +1,228 @@
+"""ctypes binding of the C-ABI in include/fmx.h (libfm_amd/libfmx.so).
+
+This is the only way Python reaches the HIP kernels; there is no Python/CPU fallback: if the shared library is
+missing or no HIP device is present, the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfmx.so")
+
+FMX_OK = 0
+TASK_REGRESSION, TASK_CLASSIFICATION = 0, 1
+SGD_SEQUENTIAL, SGD_MINIBATCH, SGD_HOGWILD = 0, 1, 2
+APPLY_ATOMIC, APPLY_STORE = 0, 1
+FLAG_TIME_MAIN_KERNEL = 1
+MAX_SLOTS = 8
+
+ENTRY_DTYPE = np.dtype([("id", np.uint32), ("value", np.float32)])   # sparse_entry<float>, fmatrix.h:34-37
+
+
+class FmxError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libfmx error %d: %s" % (code, text))
+        self.code = code
+        self.text = text
+
+
+class Config(C.Structure):
+    _fields_ = [("num_attribute", C.c_uint64), ("num_factor", C.c_int32), ("k0", C.c_int32), ("k1", C.c_int32),
+                ("task", C.c_int32), ("reg0", C.c_double), ("regw", C.c_double), ("regv", C.c_double),
+                ("learn_rate", C.c_double), ("min_target", C.c_double), ("max_target", C.c_double),
+                ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SgdOpts(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("apply", C.c_int32), ("batch", C.c_uint32), ("w0_chunk", C.c_uint32),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class EpochStats(C.Structure):
+    _fields_ = [("rows", C.c_uint64), ("batches", C.c_uint64), ("device_seconds", C.c_double),
+                ("main_kernel_seconds", C.c_double), ("main_kernel_launches", C.c_uint64)]
+
+
+class Eval(C.Structure):
+    _fields_ = [("rmse", C.c_double), ("mae", C.c_double), ("accuracy", C.c_double),
+                ("device_seconds", C.c_double), ("rows", C.c_uint64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("n_local", C.c_uint64), ("k_padded", C.c_int32), ("device", C.c_int32),
+                ("bytes_params", C.c_uint64), ("device_name", C.c_char * 64), ("arch", C.c_char * 32)]
+
+
+# every symbol include/fmx.h declares: (name, restype, argtypes)
+H = C.c_void_p
+SYMBOLS = [
+    ("fmx_create", C.c_int, [C.POINTER(Config), C.POINTER(H)]),
+    ("fmx_destroy", C.c_int, [H]),
+    ("fmx_last_error", C.c_char_p, [H]),
+    ("fmx_abi_version", C.c_int, []),
+    ("fmx_device_count", C.c_int, []),
+    ("fmx_set_params", C.c_int, [H, C.c_double, C.c_void_p, C.c_void_p]),
+    ("fmx_get_params", C.c_int, [H, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
+    ("fmx_init_params", C.c_int, [H, C.c_double, C.c_double, C.c_uint64]),
+    ("fmx_get_w0", C.c_int, [H, C.POINTER(C.c_double)]),
+    ("fmx_upload_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
+    ("fmx_synth_rows", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+    ("fmx_free_rows", C.c_int, [H, C.c_int]),
+    ("fmx_rows_info", C.c_int, [H, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("fmx_download_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("fmx_predict", C.c_int, [H, C.c_int, C.c_void_p]),
+    ("fmx_evaluate", C.c_int, [H, C.c_int, C.POINTER(Eval)]),
+    ("fmx_sgd_epoch", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(EpochStats)]),
+    ("fmx_partial_floats", C.c_int, [H, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("fmx_sgd_partial", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("fmx_sgd_finish", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(SgdOpts), C.c_void_p]),
+    ("fmx_predict_finish", C.c_int, [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("fmx_get_info", C.c_int, [H, C.POINTER(Info)]),
+    ("fmx_synchronize", C.c_int, [H]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libfmx.so and bind every declared symbol.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libfm_amd/libfmx.so is not built: run `python -m libfm_amd.build` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)          # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Handle:
+    """Thin OO wrapper over an fmx_handle; every method is one C-ABI call."""
+
+    def __init__(self, num_attribute, num_factor, k0=True, k1=True, task=TASK_REGRESSION, reg0=0.0, regw=0.0, regv=0.0,
+                 learn_rate=0.0, min_target=0.0, max_target=0.0, device=-1, shard_rank=0, shard_world=1):
+        self.lib = load()
+        self.cfg = Config(int(num_attribute), int(num_factor), int(bool(k0)), int(bool(k1)), int(task),
+                          float(reg0), float(regw), float(regv), float(learn_rate), float(min_target),
+                          float(max_target), int(device), int(shard_rank), int(shard_world), 0)
+        self.h = H()
+        rc = self.lib.fmx_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != FMX_OK:
+            raise FmxError(rc, self.lib.fmx_last_error(None).decode())
+        self.n, self.k = int(num_attribute), int(num_factor)
+
+    def _chk(self, rc):
+        if rc != FMX_OK:
+            raise FmxError(rc, self.lib.fmx_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.fmx_destroy(self.h)
+            self.h = H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # parameters ------------------------------------------------------------------------------
+    def set_params(self, w0, w, v):
+        w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        v = None if v is None else np.ascontiguousarray(v, dtype=np.float64)
+        if w is not None:
+            assert w.shape == (self.n,)
+        if v is not None:
+            assert v.shape == (self.k, self.n)
+        self._chk(self.lib.fmx_set_params(self.h, float(w0), _ptr(w), _ptr(v)))
+
+    def get_params(self, w=None, v=None):
+        w0 = C.c_double(0)
+        if w is None:
+            w = np.zeros(self.n, dtype=np.float64)
+        if v is None:
+            v = np.zeros((self.k, self.n), dtype=np.float64)
+        self._chk(self.lib.fmx_get_params(self.h, C.byref(w0), _ptr(w), _ptr(v) if self.k > 0 else None))
+        return w0.value, w, v
+
+    def init_params(self, mean, stdev, seed):
+        self._chk(self.lib.fmx_init_params(self.h, float(mean), float(stdev), int(seed)))
+
+    def get_w0(self):
+        w0 = C.c_double(0)
+        self._chk(self.lib.fmx_get_w0(self.h, C.byref(w0)))
+        return w0.value
+
+    # rows ------------------------------------------------------------------------------------
+    def upload_rows(self, slot, entries, row_ptr, target):
+        entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        target = None if target is None else np.ascontiguousarray(target, dtype=np.float32)
+        n_rows = len(row_ptr) - 1
+        self._chk(self.lib.fmx_upload_rows(self.h, slot, _ptr(entries) if len(entries) else None, _ptr(row_ptr),
+                                           _ptr(target), n_rows, len(entries)))
+        return n_rows
+
+    def synth_rows(self, slot, seed, row0, n_rows, nnz):
+        self._chk(self.lib.fmx_synth_rows(self.h, slot, int(seed), int(row0), int(n_rows), int(nnz)))
+
+    def download_rows(self, slot):
+        n_rows, nnz = C.c_uint32(0), C.c_uint64(0)
+        self._chk(self.lib.fmx_rows_info(self.h, slot, C.byref(n_rows), C.byref(nnz)))
+        ent = np.zeros(nnz.value, dtype=ENTRY_DTYPE)
+        rp = np.zeros(n_rows.value + 1, dtype=np.uint64)
+        y = np.zeros(n_rows.value, dtype=np.float32)
+        self._chk(self.lib.fmx_download_rows(self.h, slot, _ptr(ent) if nnz.value else None, _ptr(rp), _ptr(y)))
+        return ent, rp, y
+
+    def free_rows(self, slot):
+        self._chk(self.lib.fmx_free_rows(self.h, slot))
+
+    # compute ---------------------------------------------------------------------------------
+    def predict(self, slot, n_rows):
+        out = np.zeros(n_rows, dtype=np.float64)
+        self._chk(self.lib.fmx_predict(self.h, slot, _ptr(out)))
+        return out
+
+    def evaluate(self, slot):
+        ev = Eval()
+        self._chk(self.lib.fmx_evaluate(self.h, slot, C.byref(ev)))
+        return ev
+
+    def sgd_epoch(self, slot, mode, apply=APPLY_ATOMIC, batch=0, w0_chunk=0, flags=0):
+        opts = SgdOpts(mode, apply, batch, w0_chunk, flags, 0)
+        st = EpochStats()
+        self._chk(self.lib.fmx_sgd_epoch(self.h, slot, C.byref(opts), C.byref(st)))
+        return st
+
+    def partial_floats(self, batch):
+        n = C.c_uint64(0)
+        self._chk(self.lib.fmx_partial_floats(self.h, batch, C.byref(n)))
+        return n.value
+
+    def sgd_partial(self, slot, row0, n_rows, d_partial_ptr, stream=None):
+        self._chk(self.lib.fmx_sgd_partial(self.h, slot, row0, n_rows, d_partial_ptr, stream))
+
+    def sgd_finish(self, slot, row0, n_rows, d_partial_ptr, apply=APPLY_ATOMIC, w0_chunk=0, stream=None):
+        opts = SgdOpts(SGD_MINIBATCH, apply, n_rows, w0_chunk, 0, 0)
+        self._chk(self.lib.fmx_sgd_finish(self.h, slot, row0, n_rows, d_partial_ptr, C.byref(opts), stream))
+
+    def predict_finish(self, n_rows, d_partial_ptr, d_yhat_ptr, stream=None):
+        self._chk(self.lib.fmx_predict_finish(self.h, n_rows, d_partial_ptr, d_yhat_ptr, stream))
+
+    def info(self):
+        inf = Info()
+        self._chk(self.lib.fmx_get_info(self.h, C.byref(inf)))
+        return inf
+
+    def synchronize(self):
+        self._chk(self.lib.fmx_synchronize(self.h))

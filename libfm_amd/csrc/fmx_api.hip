@@ -1,0 +1,713 @@
+// fmx_api.hip -- C-ABI implementation (include/fmx.h) over the gfx950 kernels in fmx_kernels.h.
+// Build: python -m libfm_amd.build   (hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -shared -fPIC)
+//
+// No CPU fallback lives here: every compute entry point needs a HIP device and fails with FMX_E_HIP
+// otherwise.  Nothing in this library links or calls oracle/.
+#include "../../include/fmx.h"
+#include "fmx_kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fmx;
+
+namespace {
+
+struct Slot {
+  Entry*    ent = nullptr;
+  uint64_t* row_ptr = nullptr;
+  float*    target = nullptr;
+  uint32_t  n_rows = 0;
+  uint64_t  nnz = 0;
+  uint32_t  max_row = 0;
+  bool      used = false;
+};
+
+thread_local std::string g_create_error = "";
+
+}  // namespace
+
+struct fmx_context_s {
+  fmx_config cfg;
+  int        KP = 1;
+  uint64_t   n_local = 0;
+  int        device = 0;
+  hipStream_t stream = nullptr;
+  float*     V = nullptr;
+  float*     w = nullptr;
+  double*    w0 = nullptr;       // device scalar
+  double*    acc = nullptr;      // 4 doubles of reduction scratch
+  Slot       slots[FMX_MAX_SLOTS];
+  float*     partial = nullptr;  // [cap][KP] + [cap]
+  float*     mult = nullptr;     // [cap]
+  float*     rest = nullptr;     // [cap_rest]
+  size_t     cap = 0, cap_rest = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  std::string err;
+  hipDeviceProp_t prop;
+};
+
+namespace {
+
+int fail(fmx_handle h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                         \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return fail((h), FMX_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+int next_pow2(int k) { int p = 1; while (p < k) p <<= 1; return p; }
+
+Hyper make_hyper(const fmx_config& c) {
+  Hyper h;
+  h.lr = (float)c.learn_rate; h.reg0 = (float)c.reg0; h.regw = (float)c.regw; h.regv = (float)c.regv;
+  h.min_target = (float)c.min_target; h.max_target = (float)c.max_target;
+  h.task = c.task; h.k0 = c.k0; h.k1 = c.k1;
+  h.lr_d = c.learn_rate; h.reg0_d = c.reg0; h.regw_d = c.regw; h.regv_d = c.regv;
+  h.min_d = c.min_target; h.max_d = c.max_target;
+  return h;
+}
+
+// wave-per-example grids: 4 waves per 256-thread block, capped so that the launch is >> 256 workgroups
+// but grid-strides the rest (guide: memory-bound ops, 256 CUs x 8 blocks).
+inline uint32_t wave_grid(uint64_t n_waves_wanted) {
+  uint64_t blocks = (n_waves_wanted + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  return (uint32_t)blocks;
+}
+
+#define KP_SWITCH(KPV, ...)                                            \
+  switch (KPV) {                                                       \
+    case 1:   { constexpr int KP = 1;   __VA_ARGS__; } break;          \
+    case 2:   { constexpr int KP = 2;   __VA_ARGS__; } break;          \
+    case 4:   { constexpr int KP = 4;   __VA_ARGS__; } break;          \
+    case 8:   { constexpr int KP = 8;   __VA_ARGS__; } break;          \
+    case 16:  { constexpr int KP = 16;  __VA_ARGS__; } break;          \
+    case 32:  { constexpr int KP = 32;  __VA_ARGS__; } break;          \
+    case 64:  { constexpr int KP = 64;  __VA_ARGS__; } break;          \
+    case 128: { constexpr int KP = 128; __VA_ARGS__; } break;          \
+    case 256: { constexpr int KP = 256; __VA_ARGS__; } break;          \
+    default: return fail(h, FMX_E_UNSUPPORTED, "num_factor > 256 is not supported yet");   \
+  }
+
+int ensure_scratch(fmx_handle h, size_t batch_cap, size_t rest_cap) {
+  if (batch_cap > h->cap) {
+    if (h->partial) hipFree(h->partial);
+    if (h->mult) hipFree(h->mult);
+    h->partial = nullptr; h->mult = nullptr; h->cap = 0;
+    HIPCHK(h, hipMalloc(&h->partial, batch_cap * (size_t)(h->KP + 1) * sizeof(float)));
+    HIPCHK(h, hipMalloc(&h->mult, batch_cap * sizeof(float)));
+    h->cap = batch_cap;
+  }
+  if (rest_cap > h->cap_rest) {
+    if (h->rest) hipFree(h->rest);
+    h->rest = nullptr; h->cap_rest = 0;
+    HIPCHK(h, hipMalloc(&h->rest, rest_cap * sizeof(float)));
+    h->cap_rest = rest_cap;
+  }
+  return FMX_OK;
+}
+
+int check_slot(fmx_handle h, int slot, bool need_target) {
+  if (!h) return FMX_E_ARG;
+  if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  if (!h->slots[slot].used) return fail(h, FMX_E_STATE, "slot %d holds no rows (call fmx_upload_rows first)", slot);
+  if (need_target && !h->slots[slot].target) return fail(h, FMX_E_STATE, "slot %d was uploaded without targets", slot);
+  return FMX_OK;
+}
+
+void free_slot(Slot& s) {
+  if (s.ent) hipFree(s.ent);
+  if (s.row_ptr) hipFree(s.row_ptr);
+  if (s.target) hipFree(s.target);
+  s = Slot();
+}
+
+// rest[e] (= y-hat - w0) for rows [row0,row0+n) of a slot, single device
+int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st) {
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rowsums<KP, false, true>), dim3(wave_grid(n)), dim3(256), 0, st,
+                                        s.ent, s.row_ptr, row0, n, h->V, h->w, h->cfg.k1, (float*)nullptr, rest));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+template <int KP, bool ATOMIC>
+int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint32_t n_rows, hipStream_t st) {
+  constexpr int VEC = Map<KP>::VEC, EPI = Map<KP>::EPI;
+  const uint32_t need = (s.max_row + EPI - 1) / EPI;      // row slots per lane to keep a whole row in registers
+  const dim3 grid(wave_grid(n_rows)), block(256);
+#define FMX_LAUNCH_ZR(ZRV)                                                                                  \
+  hipLaunchKernelGGL((k_fused<KP, ZRV, ATOMIC>), grid, block, 0, st, s.ent, s.row_ptr, s.target, (uint64_t)0, \
+                     n_rows, h->V, h->w, hy, h->w0)
+  if constexpr (VEC * 8 <= 128) { if (need <= 8) { FMX_LAUNCH_ZR(8); return FMX_OK; } }
+  if constexpr (VEC * 16 <= 128) { if (need <= 16) { FMX_LAUNCH_ZR(16); return FMX_OK; } }
+  if constexpr (VEC * 32 <= 128) { if (need <= 32) { FMX_LAUNCH_ZR(32); return FMX_OK; } }
+  if constexpr (VEC * 64 <= 128) { if (need <= 64) { FMX_LAUNCH_ZR(64); return FMX_OK; } }
+  // rows too long for the register file: the kernel's two-pass branch handles them (ZR = 8 instance)
+  FMX_LAUNCH_ZR(8);
+#undef FMX_LAUNCH_ZR
+  return FMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fmx_abi_version(void) { return FMX_ABI_VERSION; }
+
+int fmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* fmx_last_error(fmx_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fmx_create(const fmx_config* cfg, fmx_handle* out) {
+  if (!cfg || !out) return fail(nullptr, FMX_E_ARG, "fmx_create: null argument");
+  *out = nullptr;
+  if (cfg->num_attribute == 0) return fail(nullptr, FMX_E_ARG, "num_attribute must be > 0");
+  if (cfg->num_attribute > 0xFFFFFFFFull) return fail(nullptr, FMX_E_ARG, "num_attribute must fit uint32 (fm_model.h:51)");
+  if (cfg->num_factor < 0) return fail(nullptr, FMX_E_ARG, "num_factor must be >= 0");
+  if (cfg->num_factor > 256) return fail(nullptr, FMX_E_UNSUPPORTED, "num_factor > 256 is not supported yet");
+  if (cfg->task != FMX_TASK_REGRESSION && cfg->task != FMX_TASK_CLASSIFICATION)
+    return fail(nullptr, FMX_E_ARG, "unknown task");                       // fm_learn.h:81 "unknown task"
+  if (cfg->shard_world < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_world)
+    return fail(nullptr, FMX_E_ARG, "bad shard_rank/shard_world");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, FMX_E_HIP, "no HIP device available (%s); libfmx has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  int dev = cfg->device;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= ndev) return fail(nullptr, FMX_E_ARG, "device %d out of range (%d devices)", dev, ndev);
+
+  fmx_handle h = new fmx_context_s();
+  h->cfg = *cfg;
+  h->device = dev;
+  h->KP = next_pow2(std::max(cfg->num_factor, 1));
+  const uint64_t n = cfg->num_attribute, W = (uint64_t)cfg->shard_world, R = (uint64_t)cfg->shard_rank;
+  h->n_local = (n > R) ? (n - R + W - 1) / W : 0;
+  if (h->n_local == 0) h->n_local = 1;
+#define CREATE_CHK(expr)                                                                     \
+  do { hipError_t _e = (expr); if (_e != hipSuccess) {                                       \
+      fail(nullptr, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));               \
+      fmx_destroy(h); return FMX_E_HIP; } } while (0)
+  CREATE_CHK(hipSetDevice(dev));
+  CREATE_CHK(hipGetDeviceProperties(&h->prop, dev));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_CHK(hipEventCreate(&h->ev0));
+  CREATE_CHK(hipEventCreate(&h->ev1));
+  CREATE_CHK(hipMalloc(&h->V, h->n_local * (size_t)h->KP * sizeof(float)));
+  CREATE_CHK(hipMalloc(&h->w, h->n_local * sizeof(float)));
+  CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
+  CREATE_CHK(hipMalloc(&h->acc, 4 * sizeof(double)));
+  CREATE_CHK(hipMemsetAsync(h->V, 0, h->n_local * (size_t)h->KP * sizeof(float), h->stream));
+  CREATE_CHK(hipMemsetAsync(h->w, 0, h->n_local * sizeof(float), h->stream));
+  CREATE_CHK(hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
+  CREATE_CHK(hipStreamSynchronize(h->stream));
+#undef CREATE_CHK
+  *out = h;
+  return FMX_OK;
+}
+
+int fmx_destroy(fmx_handle h) {
+  if (!h) return FMX_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (auto& s : h->slots) free_slot(s);
+  if (h->V) hipFree(h->V);
+  if (h->w) hipFree(h->w);
+  if (h->w0) hipFree(h->w0);
+  if (h->acc) hipFree(h->acc);
+  if (h->partial) hipFree(h->partial);
+  if (h->mult) hipFree(h->mult);
+  if (h->rest) hipFree(h->rest);
+  for (auto ev : h->ev_pool) hipEventDestroy(ev);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return FMX_OK;
+}
+
+int fmx_get_info(fmx_handle h, fmx_info* out) {
+  if (!h || !out) return FMX_E_ARG;
+  memset(out, 0, sizeof(*out));
+  out->n_local = h->n_local;
+  out->k_padded = h->KP;
+  out->device = h->device;
+  out->bytes_params = h->n_local * (size_t)(h->KP + 1) * sizeof(float);
+  snprintf(out->device_name, sizeof(out->device_name), "%s", h->prop.name);
+  snprintf(out->arch, sizeof(out->arch), "%s", h->prop.gcnArchName);
+  return FMX_OK;
+}
+
+int fmx_synchronize(fmx_handle h) {
+  if (!h) return FMX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------------
+static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, double* v) {
+  HIPCHK(h, hipSetDevice(h->device));
+  const uint64_t n = h->cfg.num_attribute;
+  const int k = h->cfg.num_factor, KP = h->KP;
+  const int R = h->cfg.shard_rank, W = h->cfg.shard_world;
+  if (to_device) {
+    HIPCHK(h, hipMemcpyAsync(h->w0, w0, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIPCHK(h, hipMemcpyAsync(w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  const uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 1u << 18);
+  double* stage = nullptr;
+  HIPCHK(h, hipMalloc(&stage, (size_t)chunk * (size_t)std::max(k, 1) * sizeof(double)));
+  int rc = FMX_OK;
+#define STAGE_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    rc = fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); goto done; } } while (0)
+  for (uint64_t j0 = 0; j0 < n; j0 += chunk) {
+    const uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, n - j0);
+    if (w) {
+      if (to_device) {
+        STAGE_CHK(hipMemcpyAsync(stage, w + j0, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_w_in, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->w);
+      } else {
+        if (W > 1) STAGE_CHK(hipMemcpyAsync(stage, w + j0, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_w_out, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->w);
+        STAGE_CHK(hipMemcpyAsync(w + j0, stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      }
+      STAGE_CHK(hipStreamSynchronize(h->stream));
+    }
+    if (v && k > 0) {
+      if (to_device) {
+        for (int f = 0; f < k; f++)
+          STAGE_CHK(hipMemcpyAsync(stage + (size_t)f * cnt, v + (size_t)f * n + j0, cnt * sizeof(double),
+                                   hipMemcpyHostToDevice, h->stream));
+        const uint64_t total = (uint64_t)cnt * KP;
+        hipLaunchKernelGGL(k_stage_in, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream,
+                           stage, j0, cnt, k, KP, R, W, h->V);
+      } else {
+        if (W > 1)
+          for (int f = 0; f < k; f++)
+            STAGE_CHK(hipMemcpyAsync(stage + (size_t)f * cnt, v + (size_t)f * n + j0, cnt * sizeof(double),
+                                     hipMemcpyHostToDevice, h->stream));
+        const uint64_t total = (uint64_t)cnt * k;
+        hipLaunchKernelGGL(k_stage_out, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream,
+                           stage, j0, cnt, k, KP, R, W, h->V);
+        for (int f = 0; f < k; f++)
+          STAGE_CHK(hipMemcpyAsync(v + (size_t)f * n + j0, stage + (size_t)f * cnt, cnt * sizeof(double),
+                                   hipMemcpyDeviceToHost, h->stream));
+      }
+      STAGE_CHK(hipStreamSynchronize(h->stream));
+    }
+  }
+  STAGE_CHK(hipGetLastError());
+  STAGE_CHK(hipStreamSynchronize(h->stream));
+done:
+#undef STAGE_CHK
+  hipFree(stage);
+  return rc;
+}
+
+int fmx_set_params(fmx_handle h, double w0, const double* w, const double* v) {
+  if (!h) return FMX_E_ARG;
+  if (h->cfg.num_factor > 0 && !v) return fail(h, FMX_E_ARG, "fmx_set_params: v is NULL but num_factor > 0");
+  double w0c = w0;
+  return stage_params(h, true, &w0c, const_cast<double*>(w), const_cast<double*>(v));
+}
+
+int fmx_get_params(fmx_handle h, double* w0, double* w, double* v) {
+  if (!h || !w0) return FMX_E_ARG;
+  return stage_params(h, false, w0, w, v);
+}
+
+int fmx_get_w0(fmx_handle h, double* w0) {
+  if (!h || !w0) return FMX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t seed) {
+  if (!h) return FMX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_init_params, dim3(256 * 8), dim3(256), 0, h->stream, h->V, h->w, h->n_local,
+                     h->cfg.num_factor, h->KP, h->cfg.shard_rank, h->cfg.shard_world, (float)init_mean, init_stdev, seed);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows
+// ---------------------------------------------------------------------------------------------
+int fmx_free_rows(fmx_handle h, int slot) {
+  if (!h || slot < 0 || slot >= FMX_MAX_SLOTS) return FMX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_slot(h->slots[slot]);
+  return FMX_OK;
+}
+
+int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t* row_ptr, const float* target,
+                    uint32_t n_rows, uint64_t nnz) {
+  if (!h) return FMX_E_ARG;
+  if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  if (!row_ptr || (nnz > 0 && !entries)) return fail(h, FMX_E_ARG, "fmx_upload_rows: null entries/row_ptr");
+  if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return fail(h, FMX_E_ARG, "row_ptr[0] must be 0 and row_ptr[n_rows] == nnz");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_slot(h->slots[slot]);
+  const Entry* src = static_cast<const Entry*>(entries);
+  const uint64_t n = h->cfg.num_attribute;
+  const uint32_t W = (uint32_t)h->cfg.shard_world, R = (uint32_t)h->cfg.shard_rank;
+  std::vector<Entry> local_ent;
+  std::vector<uint64_t> local_ptr;
+  const Entry* up_ent = src;
+  const uint64_t* up_ptr = row_ptr;
+  uint64_t up_nnz = nnz;
+  uint32_t max_row = 0;
+  // bound check: the reference asserts id < num_attribute (fm_model.h:112)
+  for (uint64_t i = 0; i < nnz; i++)
+    if (src[i].id >= n) return fail(h, FMX_E_ARG, "feature id %u >= num_attribute %llu (row entry %llu)", src[i].id,
+                                    (unsigned long long)n, (unsigned long long)i);
+  if (W > 1) {   // keep this shard's features, ids become local rows (j / world)
+    local_ptr.resize((size_t)n_rows + 1);
+    local_ent.reserve((size_t)(nnz / W + n_rows));
+    for (uint32_t r = 0; r < n_rows; r++) {
+      local_ptr[r] = local_ent.size();
+      for (uint64_t i = row_ptr[r]; i < row_ptr[r + 1]; i++)
+        if (src[i].id % W == R) { Entry e; e.id = src[i].id / W; e.value = src[i].value; local_ent.push_back(e); }
+    }
+    local_ptr[n_rows] = local_ent.size();
+    up_ent = local_ent.data(); up_ptr = local_ptr.data(); up_nnz = local_ent.size();
+  }
+  for (uint32_t r = 0; r < n_rows; r++) max_row = std::max<uint32_t>(max_row, (uint32_t)(up_ptr[r + 1] - up_ptr[r]));
+  Slot s;
+  HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(up_nnz, 1) * sizeof(Entry)));
+  HIPCHK(h, hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  if (up_nnz) HIPCHK(h, hipMemcpy(s.ent, up_ent, up_nnz * sizeof(Entry), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(s.row_ptr, up_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (target) {
+    HIPCHK(h, hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float)));
+    if (n_rows) HIPCHK(h, hipMemcpy(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice));
+  }
+  s.n_rows = n_rows; s.nnz = up_nnz; s.max_row = max_row; s.used = true;
+  h->slots[slot] = s;
+  return FMX_OK;
+}
+
+int fmx_rows_info(fmx_handle h, int slot, uint32_t* n_rows, uint64_t* nnz) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  if (n_rows) *n_rows = h->slots[slot].n_rows;
+  if (nnz) *nnz = h->slots[slot].nnz;
+  return FMX_OK;
+}
+
+int fmx_download_rows(fmx_handle h, int slot, void* entries, uint64_t* row_ptr, float* target) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const Slot& s = h->slots[slot];
+  if (entries && s.nnz) HIPCHK(h, hipMemcpy(entries, s.ent, s.nnz * sizeof(Entry), hipMemcpyDeviceToHost));
+  if (row_ptr) HIPCHK(h, hipMemcpy(row_ptr, s.row_ptr, ((size_t)s.n_rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (target && s.target && s.n_rows) HIPCHK(h, hipMemcpy(target, s.target, (size_t)s.n_rows * sizeof(float), hipMemcpyDeviceToHost));
+  return FMX_OK;
+}
+
+int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz) {
+  if (!h) return FMX_E_ARG;
+  if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  if (nnz == 0 || n_rows == 0) return fail(h, FMX_E_ARG, "fmx_synth_rows: empty workload");
+  const uint64_t n = h->cfg.num_attribute;
+  const uint32_t fs = (uint32_t)(n / nnz);
+  if (fs == 0) return fail(h, FMX_E_ARG, "fmx_synth_rows: num_attribute < nnz");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_slot(h->slots[slot]);
+  const int R = h->cfg.shard_rank, W = h->cfg.shard_world;
+  Slot s;
+  uint32_t* cnt = nullptr;
+  HIPCHK(h, hipMalloc(&cnt, ((size_t)n_rows + 1) * sizeof(uint32_t)));
+  HIPCHK(h, hipMemsetAsync(cnt, 0, ((size_t)n_rows + 1) * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  HIPCHK(h, hipMalloc(&s.target, (size_t)n_rows * sizeof(float)));
+  const dim3 grid((n_rows + 255) / 256), block(256);
+  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, R, W, cnt,
+                     (const uint64_t*)nullptr, (Entry*)nullptr, s.target);
+  HIPCHK(h, hipGetLastError());
+  {  // exclusive prefix sum u32 -> u64 over n_rows+1 items (last = total)
+    void* tmp = nullptr; size_t tmp_bytes = 0;
+    auto conv = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, uint32_t*>(cnt, hipcub::CastOp<uint64_t>());
+    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
+    HIPCHK(h, hipMalloc(&tmp, tmp_bytes));
+    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(tmp);
+  }
+  uint64_t total = 0;
+  HIPCHK(h, hipMemcpy(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
+  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, R, W, (uint32_t*)nullptr,
+                     (const uint64_t*)s.row_ptr, s.ent, (float*)nullptr);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  hipFree(cnt);
+  s.n_rows = n_rows; s.nnz = total; s.max_row = nnz; s.used = true;
+  h->slots[slot] = s;
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// predict / evaluate
+// ---------------------------------------------------------------------------------------------
+int fmx_predict(fmx_handle h, int slot, double* out) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  if (!out) return fail(h, FMX_E_ARG, "fmx_predict: out is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[slot];
+  if (s.n_rows == 0) return FMX_OK;
+  rc = ensure_scratch(h, 0, (size_t)s.n_rows * 2);
+  if (rc) return rc;
+  rc = launch_rest(h, s, 0, s.n_rows, h->rest, h->stream);
+  if (rc) return rc;
+  float* yhat = h->rest + s.n_rows;
+  const int k0 = (h->cfg.shard_world > 1) ? (h->cfg.shard_rank == 0 ? h->cfg.k0 : 0) : h->cfg.k0;
+  hipLaunchKernelGGL(k_yhat, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, h->stream,
+                     h->rest, s.n_rows, k0, h->w0, yhat);
+  HIPCHK(h, hipGetLastError());
+  std::vector<float> tmp(s.n_rows);
+  HIPCHK(h, hipMemcpyAsync(tmp.data(), yhat, (size_t)s.n_rows * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (uint32_t r = 0; r < s.n_rows; r++) out[r] = (double)tmp[r];
+  return FMX_OK;
+}
+
+int fmx_evaluate(fmx_handle h, int slot, fmx_eval* out) {
+  int rc = check_slot(h, slot, true);
+  if (rc) return rc;
+  if (!out) return fail(h, FMX_E_ARG, "fmx_evaluate: out is NULL");
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "fmx_evaluate on a feature shard: use fmx_sgd_partial + all-reduce + fmx_predict_finish");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[slot];
+  memset(out, 0, sizeof(*out));
+  out->rows = s.n_rows;
+  if (s.n_rows == 0) return FMX_OK;
+  rc = ensure_scratch(h, 0, (size_t)s.n_rows * 2);
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  rc = launch_rest(h, s, 0, s.n_rows, h->rest, h->stream);
+  if (rc) return rc;
+  HIPCHK(h, hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
+  hipLaunchKernelGGL(k_eval, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, h->stream,
+                     h->rest, s.target, s.n_rows, make_hyper(h->cfg), h->w0, h->acc);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  double acc[4];
+  HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  out->device_seconds = ms * 1e-3;
+  out->rmse = std::sqrt(acc[0] / s.n_rows);          // fm_learn.h:152
+  out->mae = acc[1] / s.n_rows;                      // fm_learn.h:148
+  out->accuracy = acc[2] / s.n_rows;                 // fm_learn.h:129
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SGD
+// ---------------------------------------------------------------------------------------------
+int fmx_partial_floats(fmx_handle h, uint32_t batch, uint64_t* n_floats) {
+  if (!h || !n_floats) return FMX_E_ARG;
+  *n_floats = (uint64_t)batch * (uint64_t)(h->KP + 1);
+  return FMX_OK;
+}
+
+// partial buffer layout: [n_rows][KP] factor sums, then [n_rows] scalars
+int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, float* d_partial, void* stream) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  const Slot& s = h->slots[slot];
+  if (row0 + n_rows > s.n_rows) return fail(h, FMX_E_ARG, "fmx_sgd_partial: rows [%llu,+%u) outside slot (%u rows)",
+                                            (unsigned long long)row0, n_rows, s.n_rows);
+  if (!d_partial) return fail(h, FMX_E_ARG, "fmx_sgd_partial: d_partial is NULL");
+  if (n_rows == 0) return FMX_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  float* S = d_partial;
+  float* c = d_partial + (size_t)n_rows * h->KP;
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rowsums<KP, true, false>), dim3(wave_grid(n_rows)), dim3(256), 0, st,
+                                        s.ent, s.row_ptr, row0, n_rows, h->V, h->w, h->cfg.k1, S, c));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, const float* S,
+                           const float* rest, const fmx_sgd_opts* opts, hipStream_t st,
+                           hipEvent_t ev_a, hipEvent_t ev_b) {
+  const Hyper hy = make_hyper(h->cfg);
+  const uint32_t chunk = (opts && opts->w0_chunk) ? opts->w0_chunk : 64u;
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(64), 0, st, rest, s.target + row0, n_rows, chunk, hy, h->w0, h->mult);
+  const bool atomic = !(opts && opts->apply == FMX_APPLY_STORE);
+  if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
+  if (atomic) {
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply<KP, true>), dim3(wave_grid(n_rows)), dim3(256), 0, st,
+                                          s.ent, s.row_ptr, row0, n_rows, h->V, h->w, hy, S, h->mult));
+  } else {
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply<KP, false>), dim3(wave_grid(n_rows)), dim3(256), 0, st,
+                                          s.ent, s.row_ptr, row0, n_rows, h->V, h->w, hy, S, h->mult));
+  }
+  if (ev_b) HIPCHK(h, hipEventRecord(ev_b, st));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const float* d_partial,
+                   const fmx_sgd_opts* opts, void* stream) {
+  int rc = check_slot(h, slot, true);
+  if (rc) return rc;
+  const Slot& s = h->slots[slot];
+  if (row0 + n_rows > s.n_rows) return fail(h, FMX_E_ARG, "fmx_sgd_finish: rows outside slot");
+  if (!d_partial) return fail(h, FMX_E_ARG, "fmx_sgd_finish: d_partial is NULL");
+  if (n_rows == 0) return FMX_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  rc = ensure_scratch(h, n_rows, n_rows);
+  if (rc) return rc;
+  const float* S = d_partial;
+  const float* c = d_partial + (size_t)n_rows * h->KP;
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n_rows + Map<KP>::EPI - 1) / Map<KP>::EPI)),
+                                        dim3(256), 0, st, S, c, n_rows, h->rest));
+  HIPCHK(h, hipGetLastError());
+  return sgd_finish_impl(h, s, row0, n_rows, S, h->rest, opts, st, nullptr, nullptr);
+}
+
+int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, float* d_yhat, void* stream) {
+  if (!h || !d_partial || !d_yhat) return FMX_E_ARG;
+  if (n_rows == 0) return FMX_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  int rc = ensure_scratch(h, 0, n_rows);
+  if (rc) return rc;
+  const float* S = d_partial;
+  const float* c = d_partial + (size_t)n_rows * h->KP;
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n_rows + Map<KP>::EPI - 1) / Map<KP>::EPI)),
+                                        dim3(256), 0, st, S, c, n_rows, h->rest));
+  hipLaunchKernelGGL(k_yhat, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st,
+                     h->rest, n_rows, h->cfg.k0, h->w0, d_yhat);
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats) {
+  int rc = check_slot(h, slot, true);
+  if (rc) return rc;
+  if (!opts) return fail(h, FMX_E_ARG, "fmx_sgd_epoch: opts is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[slot];
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (s.n_rows == 0) return FMX_OK;
+  if (h->cfg.shard_world > 1 && opts->mode != FMX_SGD_MINIBATCH)
+    return fail(h, FMX_E_UNSUPPORTED, "feature-sharded handles train through fmx_sgd_partial / fmx_sgd_finish");
+  if (h->cfg.shard_world > 1)
+    return fail(h, FMX_E_UNSUPPORTED, "fmx_sgd_epoch on a feature shard: drive fmx_sgd_partial + all-reduce + fmx_sgd_finish");
+  const Hyper hy = make_hyper(h->cfg);
+  const bool timed = (opts->flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
+  uint64_t batches = 0, main_launches = 0;
+  size_t ev_used = 0;
+  auto get_event = [&](hipEvent_t* ev) -> hipError_t {
+    if (ev_used == h->ev_pool.size()) { hipEvent_t e; hipError_t er = hipEventCreate(&e); if (er != hipSuccess) return er; h->ev_pool.push_back(e); }
+    *ev = h->ev_pool[ev_used++];
+    return hipSuccess;
+  };
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  if (opts->mode == FMX_SGD_SEQUENTIAL) {
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr,
+                                          s.target, s.n_rows, h->V, h->w, hy, h->w0));
+    HIPCHK(h, hipGetLastError());
+    batches = s.n_rows; main_launches = 1;
+  } else if (opts->mode == FMX_SGD_HOGWILD) {
+    if (opts->apply == FMX_APPLY_STORE) {
+      KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, s.n_rows, h->stream); });
+    } else {
+      KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, s.n_rows, h->stream); });
+    }
+    if (rc) return rc;
+    HIPCHK(h, hipGetLastError());
+    batches = 1; main_launches = 1;
+  } else if (opts->mode == FMX_SGD_MINIBATCH) {
+    const uint32_t B = opts->batch ? opts->batch : 16384u;
+    rc = ensure_scratch(h, std::min<uint32_t>(B, s.n_rows), 0);
+    if (rc) return rc;
+    for (uint64_t row0 = 0; row0 < s.n_rows; row0 += B) {
+      const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
+      float* S = h->partial;
+      float* rest = h->partial + (size_t)nb * h->KP;
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rowsums<KP, true, true>), dim3(wave_grid(nb)), dim3(256), 0, h->stream,
+                                            s.ent, s.row_ptr, row0, nb, h->V, h->w, h->cfg.k1, S, rest));
+      hipEvent_t ea = nullptr, eb = nullptr;
+      if (timed) { HIPCHK(h, get_event(&ea)); HIPCHK(h, get_event(&eb)); main_launches++; }
+      rc = sgd_finish_impl(h, s, row0, nb, S, rest, opts, h->stream, ea, eb);
+      if (rc) return rc;
+      batches++;
+    }
+  } else {
+    return fail(h, FMX_E_ARG, "unknown SGD mode %d", opts->mode);
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  if (stats) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    stats->rows = s.n_rows;
+    stats->batches = batches;
+    stats->device_seconds = ms * 1e-3;
+    if (opts->mode == FMX_SGD_MINIBATCH && timed) {
+      double tot = 0;
+      for (size_t i = 0; i + 1 < ev_used; i += 2) {
+        float m2 = 0;
+        HIPCHK(h, hipEventElapsedTime(&m2, h->ev_pool[i], h->ev_pool[i + 1]));
+        tot += m2 * 1e-3;
+      }
+      stats->main_kernel_seconds = tot;
+      stats->main_kernel_launches = main_launches;
+    } else {
+      stats->main_kernel_seconds = stats->device_seconds;
+      stats->main_kernel_launches = main_launches;
+    }
+  }
+  return FMX_OK;
+}
+
+}  // extern "C"

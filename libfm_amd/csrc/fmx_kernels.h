@@ -1,0 +1,619 @@
+// fmx_kernels.h -- hand-written CDNA4 (gfx950) kernels of the FM hot path.
+//
+// Reference algorithms (restated, never copied):
+//   fm_model::predict   /root/reference/src/fm_core/fm_model.h:105-127   (sum / sum-of-squares trick)
+//   fm_SGD              /root/reference/src/fm_core/fm_sgd.h:33-51
+//   loss multiplier     /root/reference/src/libfm/src/fm_learn_sgd_element.h:58-65
+//   evaluate            /root/reference/src/libfm/src/fm_learn.h:113-153
+//
+// Device layout: V is FEATURE-major fp32, V[j*KP + f], KP = power of two >= k (padding factors are 0 and
+// stay 0 under the update), so the k factors of one feature are ONE coalesced segment (256 B at k=64).
+// w is fp32 [n].  w0 is one fp64 scalar.  Rows are the reference's AoS {u32 id; f32 value} CSR.
+//
+// Wavefront mapping (64 lanes, no 32-wide assumptions): one wavefront per example.
+//   VEC = max(1, KP/64) floats per lane, LPR = KP/VEC lanes cover one V row, EPI = 64/LPR rows are
+//   fetched by ONE wave-wide load instruction (k=64: 1 row = 256 B; k=32: 2 rows; k=8: 8 rows).
+//   Lane (g, f) = (lane / LPR, lane % LPR) owns factors [f*VEC, f*VEC+VEC) of the entries i == g (mod EPI);
+//   sum_f needs no cross-lane traffic until the final EPI-way butterfly + one 64-lane reduction.
+// All kernels are HBM-bandwidth bound random gathers/scatters: no MFMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmx {
+
+struct Entry { uint32_t id; float value; };   // sparse_entry<float>, fmatrix.h:34-37
+
+template <int KP> struct Map {
+  static constexpr int VEC = (KP >= 64) ? KP / 64 : 1;
+  static constexpr int LPR = KP / VEC;
+  static constexpr int EPI = 64 / LPR;
+};
+
+struct Hyper {            // per-launch scalars (fm_model.h:56-57, fm_learn_sgd.h:42, fm_learn.h:41-45)
+  float lr, reg0, regw, regv;
+  float min_target, max_target;
+  int   task, k0, k1;
+  double lr_d, reg0_d, regw_d, regv_d, min_d, max_d;   // unrounded copies for the fp64 sequential kernel
+};
+
+// ----------------------------------------------------------------------------------------------
+// small device helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+// all-reduce over the EPI sub-groups that hold the same factor (lane bits >= log2(LPR))
+template <int LPR> __device__ __forceinline__ float subgroup_allsum(float x) {
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) x += __shfl_xor(x, o);
+  return x;
+}
+template <int EPI> __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, uint32_t idx) {
+  if constexpr (EPI == 1) return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx);   // idx is wave-uniform
+  else return (uint32_t)__shfl((int)v, (int)idx);
+}
+template <int EPI> __device__ __forceinline__ float bcast_f32(float v, uint32_t idx) {
+  return __uint_as_float(bcast_u32<EPI>(__float_as_uint(v), idx));
+}
+template <int VEC> __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&out)[VEC]) {
+  if constexpr (VEC == 1) { out[0] = p[0]; }
+  else if constexpr (VEC == 2) { float2 t = *reinterpret_cast<const float2*>(p); out[0] = t.x; out[1] = t.y; }
+  else {
+#pragma unroll
+    for (int c = 0; c < VEC / 4; c++) {
+      float4 t = reinterpret_cast<const float4*>(p)[c];
+      out[4 * c] = t.x; out[4 * c + 1] = t.y; out[4 * c + 2] = t.z; out[4 * c + 3] = t.w;
+    }
+  }
+}
+template <int VEC> __device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&in)[VEC]) {
+  if constexpr (VEC == 1) { p[0] = in[0]; }
+  else if constexpr (VEC == 2) { *reinterpret_cast<float2*>(p) = make_float2(in[0], in[1]); }
+  else {
+#pragma unroll
+    for (int c = 0; c < VEC / 4; c++)
+      reinterpret_cast<float4*>(p)[c] = make_float4(in[4 * c], in[4 * c + 1], in[4 * c + 2], in[4 * c + 3]);
+  }
+}
+// loss multiplier, fm_learn_sgd_element.h:58-65
+__device__ __forceinline__ float multiplier(const Hyper& h, float p, float y) {
+  if (h.task == 0) {
+    p = fminf(h.max_target, p);
+    p = fmaxf(h.min_target, p);
+    return -(y - p);
+  }
+  return -y * (1.0f - 1.0f / (1.0f + __expf(-y * p)));
+}
+
+// ----------------------------------------------------------------------------------------------
+// pass 1 of a row: the sums of fm_model.h:110-125.
+//   sum[v]  : sum_f for the lane's factors (complete over the row only AFTER subgroup_allsum when EPI>1)
+//   sq      : this lane's share of  sum_f sum_i (v x)^2
+//   lin     : this lane's share of  sum_i w[id_i] x_i
+// ----------------------------------------------------------------------------------------------
+template <int KP, int U>
+__device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t size,
+                                         const float* __restrict__ V, const float* __restrict__ w, int k1,
+                                         float (&sum)[Map<KP>::VEC], float& sq, float& lin) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane / LPR, f = lane % LPR;
+#pragma unroll
+  for (int v = 0; v < VEC; v++) sum[v] = 0.f;
+  sq = 0.f; lin = 0.f;
+  for (uint32_t base = 0; base < size; base += 64) {
+    const uint32_t cnt = min(64u, size - base);
+    Entry e; e.id = 0; e.value = 0.f;
+    if (lane < cnt) {
+      e = ent[base + lane];
+      if (k1) lin += w[e.id] * e.value;
+    }
+    for (uint32_t i = 0; i < cnt; i += EPI * U) {
+      float vr[U][VEC]; float xs[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t idx = i + u * EPI + g;
+        const uint32_t id = bcast_u32<EPI>(e.id, idx & 63u);
+        xs[u] = bcast_f32<EPI>(e.value, idx & 63u);
+        if (idx < cnt) {
+          load_vec<VEC>(V + (size_t)id * KP + f * VEC, vr[u]);
+        } else {
+          xs[u] = 0.f;
+#pragma unroll
+          for (int v = 0; v < VEC; v++) vr[u][v] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const float d = vr[u][v] * xs[u];
+          sum[v] += d;
+          sq = fmaf(d, d, sq);
+        }
+    }
+  }
+}
+
+// pass 2 of a row: fm_sgd.h:38-50 with sum_f (complete) and the multiplier given.
+//   ATOMIC: scatter-add of the delta (fp32 atomics execute at L2); else read-modify-write store.
+template <int KP, int U, bool ATOMIC>
+__device__ __forceinline__ void row_apply(const Entry* __restrict__ ent, uint32_t size,
+                                          float* __restrict__ V, float* __restrict__ w, const Hyper& h,
+                                          const float (&sum)[Map<KP>::VEC], float mult) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane / LPR, f = lane % LPR;
+  for (uint32_t base = 0; base < size; base += 64) {
+    const uint32_t cnt = min(64u, size - base);
+    Entry e; e.id = 0; e.value = 0.f;
+    if (lane < cnt) {
+      e = ent[base + lane];
+      if (h.k1) {                                           // fm_sgd.h:38-43
+        const float wv = w[e.id];
+        const float dw = -h.lr * (mult * e.value + h.regw * wv);
+        if (ATOMIC) unsafeAtomicAdd(w + e.id, dw); else w[e.id] = wv + dw;
+      }
+    }
+    for (uint32_t i = 0; i < cnt; i += EPI * U) {
+      float vr[U][VEC]; float xs[U]; uint32_t ids[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t idx = i + u * EPI + g;
+        ids[u] = bcast_u32<EPI>(e.id, idx & 63u);
+        xs[u] = bcast_f32<EPI>(e.value, idx & 63u);
+        if (idx < cnt) load_vec<VEC>(V + (size_t)ids[u] * KP + f * VEC, vr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t idx = i + u * EPI + g;
+        if (idx < cnt) {
+          float* p = V + (size_t)ids[u] * KP + f * VEC;
+          const float x = xs[u];
+          float nv[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {                   // fm_sgd.h:44-50
+            const float vv = vr[u][v];
+            const float grad = sum[v] * x - vv * x * x;
+            const float dv = -h.lr * (mult * grad + h.regv * vv);
+            if (ATOMIC) unsafeAtomicAdd(p + v, dv); else nv[v] = vv + dv;
+          }
+          if (!ATOMIC) store_vec<VEC>(p, nv);
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_rowsums: one wavefront per example.  Writes
+//   S[e][0..KP)           (WRITE_S)  the (partial) factor sums
+//   scal[e]               FINISH ? rest_e = lin + 0.5*(sum_f S_ef^2 - Q_e)   (single device)
+//                                : c_e    = lin - 0.5*Q_e                    (feature shard; all-reduced later)
+// Used by predict / evaluate (WRITE_S = false, FINISH = true) and by the minibatch step.
+// ----------------------------------------------------------------------------------------------
+template <int KP, bool WRITE_S, bool FINISH>
+__global__ void __launch_bounds__(256)
+k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t n_rows,
+          const float* __restrict__ V, const float* __restrict__ w, int k1,
+          float* __restrict__ S, float* __restrict__ scal) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t e = wave0; e < n_rows; e += nwaves) {
+    const uint64_t a = row_ptr[row0 + e];
+    const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
+    float sum[VEC], sq, lin;
+    row_sums<KP, 8>(ent + a, size, V, w, k1, sum, sq, lin);
+#pragma unroll
+    for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
+    if (WRITE_S && lane < LPR) store_vec<VEC>(S + (size_t)e * KP + lane * VEC, sum);
+    float part = lin - 0.5f * sq;
+    if (FINISH && lane < LPR) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+    }
+    part = wave_sum(part);
+    if (lane == 0) scal[e] = part;
+  }
+}
+
+// after the all-reduce of a feature-sharded partial buffer: rest_e = c_e + 0.5 * sum_f S_ef^2
+template <int KP>
+__global__ void __launch_bounds__(256)
+k_rest_from_partial(const float* __restrict__ S, const float* __restrict__ c, uint32_t n_rows, float* __restrict__ rest) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
+  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t e0 = wave0 * EPI; e0 < n_rows; e0 += nwaves * EPI) {
+    const uint32_t e = e0 + g;
+    float part = 0.f;
+    if (e < n_rows) {
+      float s[VEC];
+      load_vec<VEC>(S + (size_t)e * KP + f * VEC, s);
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part = fmaf(0.5f * s[v], s[v], part);
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) part += __shfl_xor(part, o);
+    if (e < n_rows && f == 0) rest[e] = part + c[e];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_scan: ONE wavefront.  Step 2 of the minibatch rule (oracle/fm_oracle.h): w0 advances in
+// micro-chunks of `chunk` consecutive examples; mult_e is computed with the w0 of its chunk.
+//   fm_learn_sgd_element.h:57-65 (p, multiplier) + fm_sgd.h:34-37 (w0) per example.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
+       Hyper h, double* __restrict__ w0_ptr, float* __restrict__ mult) {
+  const uint32_t lane = threadIdx.x;
+  double w0 = *w0_ptr;
+  for (uint32_t c0 = 0; c0 < n_rows; c0 += chunk) {
+    const uint32_t nc = min(chunk, n_rows - c0);
+    const float w0s = h.k0 ? (float)w0 : 0.f;
+    float acc = 0.f;
+    for (uint32_t t = lane; t < nc; t += 64) {
+      const float m = multiplier(h, w0s + rest[c0 + t], target[c0 + t]);
+      mult[c0 + t] = m;
+      acc += m;
+    }
+    acc = wave_sum(acc);
+    if (h.k0) w0 -= (double)h.lr * ((double)acc + (double)nc * (double)h.reg0 * (double)w0s);
+  }
+  if (lane == 0) *w0_ptr = w0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_apply: step 3 of the minibatch rule -- one wavefront per example scatters its deltas.
+// ----------------------------------------------------------------------------------------------
+template <int KP, bool ATOMIC>
+__global__ void __launch_bounds__(256)
+k_apply(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t n_rows,
+        float* __restrict__ V, float* __restrict__ w, Hyper h,
+        const float* __restrict__ S, const float* __restrict__ mult) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  const uint32_t lane = threadIdx.x & 63u, f = lane % LPR;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t e = wave0; e < n_rows; e += nwaves) {
+    const uint64_t a = row_ptr[row0 + e];
+    const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
+    float sum[VEC];
+    load_vec<VEC>(S + (size_t)e * KP + f * VEC, sum);
+    const float m = mult[e];
+    row_apply<KP, 8, ATOMIC>(ent + a, size, V, w, h, sum, m);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_fused: HOGWILD mode.  One wavefront per example, ONE pass over HBM: the gathered V rows stay in
+// registers (ZR row-slots x VEC floats per lane), the prediction, multiplier and fm_SGD update are
+// computed in-register and the rows are written straight back.  V is read once and written once --
+// the algorithmic minimum of a training step.  Rows longer than ZR*EPI take the
+// two-pass path (row_sums + row_apply; the second read is an L2 hit).
+// w0: each wavefront reads the current w0, accumulates its own delta and publishes it with one fp64
+// atomic every FLUSH examples.
+// ----------------------------------------------------------------------------------------------
+template <int KP, int ZR, bool ATOMIC>
+__global__ void __launch_bounds__(256)
+k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
+        uint64_t row0, uint32_t n_rows, float* __restrict__ V, float* __restrict__ w, Hyper h,
+        double* __restrict__ w0_ptr) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  constexpr int FLUSH = 8;
+  const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  double w0_pending = 0.0;
+  int since_flush = 0;
+  for (uint32_t e = wave0; e < n_rows; e += nwaves) {
+    const uint64_t a = row_ptr[row0 + e];
+    const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
+    const Entry* __restrict__ row = ent + a;
+    const float y = target[row0 + e];
+    const float w0s = h.k0 ? (float)(__hip_atomic_load(w0_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + w0_pending) : 0.f;
+    float mult;
+    if (size <= (uint32_t)(ZR * EPI) && size <= 64u) {
+      Entry en; en.id = 0; en.value = 0.f;
+      float wv = 0.f;
+      if (lane < size) {
+        en = row[lane];
+        if (h.k1) wv = w[en.id];
+      }
+      // phase A: issue every gather of the row back-to-back (ids / values are re-broadcast later instead of
+      // being kept: with EPI == 1 they are wave-uniform and live in SGPRs for the duration of one use)
+      float vr[ZR][VEC];
+#pragma unroll
+      for (int t = 0; t < ZR; t++) {
+        const uint32_t idx = t * EPI + g;
+        const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
+        if (idx < size) {
+          load_vec<VEC>(V + (size_t)id * KP + f * VEC, vr[t]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
+        }
+      }
+      // phase B: sums (fm_model.h:116-125)
+      float sum[VEC]; float sq = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; v++) sum[v] = 0.f;
+#pragma unroll
+      for (int t = 0; t < ZR; t++) {
+        const uint32_t idx = t * EPI + g;
+        const float x = (idx < size) ? bcast_f32<EPI>(en.value, idx & 63u) : 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const float d = vr[t][v] * x;
+          sum[v] += d;
+          sq = fmaf(d, d, sq);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
+      float part = wv * en.value - 0.5f * sq;
+      if (lane < LPR) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      }
+      const float p = w0s + wave_sum(part);
+      mult = multiplier(h, p, y);
+      if (h.k1 && lane < size) {                             // fm_sgd.h:38-43
+        const float dw = -h.lr * (mult * en.value + h.regw * wv);
+        if (ATOMIC) unsafeAtomicAdd(w + en.id, dw); else w[en.id] = wv + dw;
+      }
+      // phase C: fm_sgd.h:44-50 on the register-resident rows, written straight back
+#pragma unroll
+      for (int t = 0; t < ZR; t++) {
+        const uint32_t idx = t * EPI + g;
+        if (idx < size) {
+          const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
+          const float x = bcast_f32<EPI>(en.value, idx & 63u);
+          float* pv = V + (size_t)id * KP + f * VEC;
+          float nv[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const float vv = vr[t][v];
+            const float grad = sum[v] * x - vv * x * x;
+            const float dv = -h.lr * (mult * grad + h.regv * vv);
+            if (ATOMIC) unsafeAtomicAdd(pv + v, dv); else nv[v] = vv + dv;
+          }
+          if (!ATOMIC) store_vec<VEC>(pv, nv);
+        }
+      }
+    } else {
+      float sum[VEC], sq, lin;
+      row_sums<KP, 8>(row, size, V, w, h.k1, sum, sq, lin);
+#pragma unroll
+      for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
+      float part = lin - 0.5f * sq;
+      if (lane < LPR) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      }
+      const float p = w0s + wave_sum(part);
+      mult = multiplier(h, p, y);
+      row_apply<KP, 8, ATOMIC>(row, size, V, w, h, sum, mult);
+    }
+    if (h.k0) {                                              // fm_sgd.h:34-37
+      w0_pending -= (double)h.lr * ((double)mult + (double)h.reg0 * (double)w0s);
+      if (++since_flush == FLUSH) {
+        if (lane == 0) unsafeAtomicAdd(w0_ptr, w0_pending);
+        w0_pending = 0.0; since_flush = 0;
+      }
+    }
+  }
+  if (h.k0 && since_flush && lane == 0) unsafeAtomicAdd(w0_ptr, w0_pending);
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_sequential: the reference trajectory (batch = 1, storage order) on ONE wavefront, for parity.
+// Loads bypass the per-CU L1 (agent-scope relaxed atomics -> sc1) and every row ends with a drain of
+// the store queue, so row r+1 sees row r's update exactly like fm_learn_sgd_element.h:56-67.
+// Entries are updated one at a time in row order, so a repeated id inside a row sees its own earlier
+// update (fm_sgd.h:44-50 semantics).  Sums are accumulated in fp64; parameters are stored fp32.
+// ----------------------------------------------------------------------------------------------
+template <int KP>
+__global__ void __launch_bounds__(64)
+k_sequential(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
+             uint32_t n_rows, float* V, float* w, Hyper h, double* w0_ptr) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  const uint32_t lane = threadIdx.x;
+  const bool act = lane < LPR;
+  double w0 = *w0_ptr;
+  for (uint32_t r = 0; r < n_rows; r++) {
+    const uint64_t a = row_ptr[r];
+    const uint32_t size = (uint32_t)(row_ptr[r + 1] - a);
+    double sum[VEC]; double sq = 0.0, lin = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) sum[v] = 0.0;
+    for (uint32_t i = 0; i < size; i++) {
+      const Entry e = ent[a + i];
+      if (h.k1 && lane == 0)
+        lin += (double)__hip_atomic_load(w + e.id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (double)e.value;
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const float vv = __hip_atomic_load(V + (size_t)e.id * KP + lane * VEC + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double d = (double)vv * (double)e.value;
+          sum[v] += d;
+          sq += d * d;
+        }
+      }
+    }
+    double part = lin - 0.5 * sq;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+    }
+    double p = (h.k0 ? w0 : 0.0) + wave_sum_d(part);
+    const double y = (double)target[r];
+    double mult;
+    if (h.task == 0) {
+      p = fmin(h.max_d, p);
+      p = fmax(h.min_d, p);
+      mult = -(y - p);
+    } else {
+      mult = -y * (1.0 - 1.0 / (1.0 + exp(-y * p)));
+    }
+    if (h.k0) w0 -= h.lr_d * (mult + h.reg0_d * w0);
+    for (uint32_t i = 0; i < size; i++) {
+      const Entry e = ent[a + i];
+      const double x = (double)e.value;
+      if (h.k1 && lane == 0) {
+        const double wv = (double)__hip_atomic_load(w + e.id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(w + e.id, (float)(wv - h.lr_d * (mult * x + h.regw_d * wv)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          float* pv = V + (size_t)e.id * KP + lane * VEC + v;
+          const double vv = (double)__hip_atomic_load(pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double grad = sum[v] * x - vv * x * x;
+          __hip_atomic_store(pv, (float)(vv - h.lr_d * (mult * grad + h.regv_d * vv)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // a later entry of this row (repeated id) and the next row must observe these stores
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  if (lane == 0) *w0_ptr = w0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// evaluation: y-hat = w0 + rest, then the reductions of fm_learn.h:113-153
+// acc[0] = sum err^2 (clamped), acc[1] = sum |err|, acc[2] = #correct sign
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_eval(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, Hyper h,
+       const double* __restrict__ w0_ptr, double* __restrict__ acc) {
+  const float w0 = h.k0 ? (float)(*w0_ptr) : 0.f;
+  double se = 0, ae = 0, nc = 0;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_rows; e += gridDim.x * blockDim.x) {
+    const float p = w0 + rest[e];
+    const float y = target[e];
+    if (h.task == 0) {
+      const float pc = fmaxf(h.min_target, fminf(h.max_target, p));
+      const double err = (double)pc - (double)y;
+      se += err * err; ae += fabs(err);
+    } else {
+      if (((p >= 0) && (y >= 0)) || ((p < 0) && (y < 0))) nc += 1;
+    }
+  }
+  se = wave_sum_d(se); ae = wave_sum_d(ae); nc = wave_sum_d(nc);
+  if ((threadIdx.x & 63) == 0) {
+    unsafeAtomicAdd(acc + 0, se); unsafeAtomicAdd(acc + 1, ae); unsafeAtomicAdd(acc + 2, nc);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_yhat(const float* __restrict__ rest, uint32_t n_rows, int k0, const double* __restrict__ w0_ptr, float* __restrict__ yhat) {
+  const float w0 = k0 ? (float)(*w0_ptr) : 0.f;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_rows; e += gridDim.x * blockDim.x)
+    yhat[e] = w0 + rest[e];
+}
+
+// ----------------------------------------------------------------------------------------------
+// parameter staging: reference layout (fp64, factor-major v[f][j]) <-> device (fp32, V[jl*KP+f]).
+// stage holds `cnt` consecutive GLOBAL features j0.. of factor rows: stage[f*cnt + (j-j0)].
+// feature j belongs to this shard iff j % world == rank; its local row is j / world.
+// ----------------------------------------------------------------------------------------------
+__global__ void k_stage_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
+                           int rank, int world, float* __restrict__ V) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = (uint64_t)cnt * KP;
+  if (t >= total) return;
+  const uint32_t jj = (uint32_t)(t / KP); const int f = (int)(t % KP);
+  const uint64_t j = j0 + jj;
+  if ((int)(j % world) != rank) return;
+  V[(j / world) * KP + f] = (f < k) ? (float)stage[(size_t)f * cnt + jj] : 0.f;
+}
+__global__ void k_stage_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
+                            int rank, int world, const float* __restrict__ V) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = (uint64_t)cnt * k;
+  if (t >= total) return;
+  const int f = (int)(t / cnt); const uint32_t jj = (uint32_t)(t % cnt);
+  const uint64_t j = j0 + jj;
+  if ((int)(j % world) != rank) return;
+  stage[(size_t)f * cnt + jj] = (double)V[(j / world) * KP + f];
+}
+__global__ void k_w_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, float* __restrict__ w) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cnt) return;
+  const uint64_t j = j0 + t;
+  if ((int)(j % world) == rank) w[j / world] = (float)stage[t];
+}
+__global__ void k_w_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, const float* __restrict__ w) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cnt) return;
+  const uint64_t j = j0 + t;
+  if ((int)(j % world) == rank) stage[t] = (double)w[j / world];
+}
+
+// counter-hash helpers: identical definitions in oracle/fm_oracle.c (fmo_mix64, fmo_synth_id, ...)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+  x ^= x >> 31;
+  return x;
+}
+__host__ __device__ __forceinline__ uint64_t synth_key(uint64_t seed, uint64_t row, uint32_t field) {
+  return mix64(seed + 0x9E3779B97F4A7C15ULL * (row + 1) + 0xC2B2AE3D27D4EB4FULL * ((uint64_t)field + 1));
+}
+
+__global__ void k_init_params(float* __restrict__ V, float* __restrict__ w, uint64_t n_local, int k, int KP,
+                              int rank, int world, float mean, double stdev, uint64_t seed) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = t; i < n_local * (uint64_t)KP; i += stride) {
+    const uint64_t jl = i / KP; const int f = (int)(i % KP);
+    const uint64_t j = jl * world + rank;
+    float val = 0.f;
+    if (f < k) {
+      const uint64_t hsh = mix64(seed ^ (j * 0x9E3779B97F4A7C15ULL + (uint64_t)f * 0xD6E8FEB86659FD93ULL + 0x1234567ULL));
+      const double u = (double)(hsh >> 11) * (1.0 / 9007199254740992.0);
+      val = mean + (float)(stdev * (2.0 * u - 1.0) * 1.7320508075688772);
+    }
+    V[i] = val;
+  }
+  for (uint64_t i = t; i < n_local; i += stride) w[i] = 0.f;
+}
+
+// synthetic rows: field t owns ids [t*fs,(t+1)*fs); this shard keeps id % world == rank
+// pass 1 (count==true): row_cnt[r] = #kept entries; pass 2: fill at row_ptr[r]
+__global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t fs, int rank, int world,
+                        uint32_t* __restrict__ row_cnt, const uint64_t* __restrict__ row_ptr,
+                        Entry* __restrict__ ent, float* __restrict__ target) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  uint64_t pos = row_ptr ? row_ptr[r] : 0;
+  uint32_t c = 0;
+  for (uint32_t t = 0; t < nnz; t++) {
+    const uint64_t hsh = synth_key(seed, row0 + r, t);
+    const uint32_t id = t * fs + (uint32_t)(((hsh >> 32) * (uint64_t)fs) >> 32);
+    if ((int)(id % (uint32_t)world) == rank) {
+      if (ent) { ent[pos].id = id / (uint32_t)world; ent[pos].value = 1.0f; pos++; }
+      c++;
+    }
+  }
+  if (row_cnt) row_cnt[r] = c;
+  if (target) target[r] = (synth_key(seed, row0 + r, 0xFFFFFFFFu) & 1) ? 1.0f : -1.0f;
+}
+
+}  // namespace fmx

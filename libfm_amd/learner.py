@@ -1,0 +1,153 @@
+"""Host-side mirror of the reference's learner interface on top of the C-ABI (include/fmx.h).
+
+The names, fields, argument meaning and error behaviour follow the reference so that the parity tests read like
+the reference's own driver (there are no reference tests to imitate):
+
+    FMModel      <-> class fm_model            /root/reference/src/fm_core/fm_model.h:36-66
+    Data         <-> class Data                /root/reference/src/libfm/src/Data.h:49-73   (rows + target only)
+    FMLearnSGD   <-> fm_learn_sgd_element      /root/reference/src/libfm/src/fm_learn_sgd_element.h:34-78
+                     (+ fm_learn_sgd.h:34-90, fm_learn.h:31-153)
+
+All arithmetic happens in libfmx.so on the GPU; this file only moves buffers and applies the host-side
+clamp / sigmoid of fm_learn_sgd::predict (fm_learn_sgd.h:80-87).  No CPU fallback exists.
+"""
+import sys
+
+import numpy as np
+
+from . import capi
+
+TASK_REGRESSION = capi.TASK_REGRESSION        # fm_learn.h:46
+TASK_CLASSIFICATION = capi.TASK_CLASSIFICATION  # fm_learn.h:47
+
+
+class Data:
+    """Rows in the reference's layout: AoS entries {u32 id; f32 value} + row offsets + float targets."""
+
+    def __init__(self, entries, row_ptr, target):
+        self.entries = np.ascontiguousarray(entries, dtype=capi.ENTRY_DTYPE)
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        self.target = np.ascontiguousarray(target, dtype=np.float32)
+        self.num_cases = len(self.target)                       # Data.h:60
+        self.num_feature = int(self.entries["id"].max()) + 1 if len(self.entries) else 0   # Data.h:59
+        self.min_target = float(self.target.min()) if self.num_cases else 0.0   # Data.h:62-63
+        self.max_target = float(self.target.max()) if self.num_cases else 0.0
+
+
+class FMModel:
+    """fm_model: parameters in the reference layout (w0, w[n], v[k][n] fp64) and its hyper-parameters."""
+
+    def __init__(self):
+        self.num_attribute = 0
+        self.num_factor = 0
+        self.k0, self.k1 = True, True
+        self.reg0 = self.regw = self.regv = 0.0
+        self.init_stdev, self.init_mean = 0.01, 0.0             # fm_model.h:69-78
+        self.w0 = 0.0
+        self.w = None
+        self.v = None
+
+    def init(self, rng=None):
+        """fm_model::init (fm_model.h:91-99): w0 = 0, w = 0, v ~ N(init_mean, init_stdev).
+        The reference draws from libc rand(); here a numpy Generator is used (pass the reference's own
+        initial parameters for trajectory parity, as the tests do)."""
+        rng = rng if rng is not None else np.random.default_rng(0)
+        self.w0 = 0.0
+        self.w = np.zeros(self.num_attribute, dtype=np.float64)
+        if self.init_stdev == 0:
+            self.v = np.full((self.num_factor, self.num_attribute), self.init_mean, dtype=np.float64)
+        else:
+            self.v = self.init_mean + self.init_stdev * rng.standard_normal((self.num_factor, self.num_attribute))
+
+
+class FMLearnSGD:
+    """fm_learn_sgd_element on the GPU.
+
+    Public knobs are plain fields set by the driver, like libfm.cpp:271-309, 387-403 does by direct writes:
+    fm, min_target, max_target, task, num_iter, learn_rate.  GPU-only knobs: mode ('sequential' | 'minibatch' |
+    'hogwild'), batch, w0_chunk, apply ('atomic' | 'store'), device."""
+
+    MODES = {"sequential": capi.SGD_SEQUENTIAL, "minibatch": capi.SGD_MINIBATCH, "hogwild": capi.SGD_HOGWILD}
+    APPLY = {"atomic": capi.APPLY_ATOMIC, "store": capi.APPLY_STORE}
+
+    def __init__(self):
+        self.fm = None
+        self.min_target = 0.0
+        self.max_target = 0.0
+        self.task = TASK_REGRESSION
+        self.num_iter = 100                                     # libfm.cpp:274 default
+        self.learn_rate = None                                  # no default in the reference (libfm.cpp:391-392)
+        self.mode = "minibatch"
+        self.batch = 0
+        self.w0_chunk = 0
+        self.apply = "atomic"
+        self.device = -1
+        self.log = []                                           # one dict per iteration (rlog fields)
+        self.out = sys.stdout
+        self._h = None
+        self._slots = {}
+
+    # fm_learn::init (fm_learn.h:73-91): here it creates the device context and uploads the parameters
+    def init(self):
+        if self.task not in (TASK_REGRESSION, TASK_CLASSIFICATION):
+            raise ValueError("unknown task")                    # fm_learn.h:81
+        if self.learn_rate is None:
+            raise ValueError("learn_rate must be set")          # the reference asserts (libfm.cpp:391-392)
+        fm = self.fm
+        self._h = capi.Handle(fm.num_attribute, fm.num_factor, fm.k0, fm.k1, self.task, fm.reg0, fm.regw, fm.regv,
+                              self.learn_rate, self.min_target, self.max_target, device=self.device)
+        self._h.set_params(fm.w0, fm.w, fm.v)
+
+    def _slot(self, data):
+        key = id(data)
+        if key not in self._slots:
+            slot = len(self._slots)
+            if slot >= capi.MAX_SLOTS:
+                raise RuntimeError("too many data sets")
+            self._h.upload_rows(slot, data.entries, data.row_ptr, data.target)
+            self._slots[key] = slot
+        return self._slots[key]
+
+    # fm_learn_sgd_element::learn (fm_learn_sgd_element.h:48-78)
+    def learn(self, train, test):
+        print("learnrate=%g" % self.learn_rate, file=self.out)   # fm_learn_sgd.h:57-59
+        print("#iterations=%d" % self.num_iter, file=self.out)
+        print("SGD: DON'T FORGET TO SHUFFLE THE ROWS IN TRAINING DATA TO GET THE BEST RESULTS.", file=self.out)
+        st = self._slot(train)
+        for i in range(self.num_iter):
+            stats = self._h.sgd_epoch(st, self.MODES[self.mode], self.APPLY[self.apply], self.batch, self.w0_chunk)
+            rmse_train = self.evaluate(train)
+            rmse_test = self.evaluate(test)
+            print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, rmse_train, rmse_test), file=self.out)   # :71
+            self.log.append({"rmse_train": rmse_train, "time_learn": stats.device_seconds})
+        self.sync_model()
+
+    def sync_model(self):
+        """after learn() the host fm_model holds the learned parameters (main reads it, libfm.cpp:431-434)."""
+        self.fm.w0, self.fm.w, self.fm.v = self._h.get_params(self.fm.w, self.fm.v)
+
+    # fm_learn::evaluate (fm_learn.h:93-153): rmse for regression, accuracy for classification
+    def evaluate(self, data):
+        ev = self._h.evaluate(self._slot(data))
+        return ev.rmse if self.task == TASK_REGRESSION else ev.accuracy
+
+    def predict_raw(self, data):
+        """fm_learn::predict_case over the data set (fm_learn.h:63-65)."""
+        return self._h.predict(self._slot(data), data.num_cases)
+
+    # fm_learn_sgd::predict (fm_learn_sgd.h:76-90)
+    def predict(self, data):
+        p = self.predict_raw(data)
+        if self.task == TASK_REGRESSION:
+            p = np.minimum(self.max_target, p)
+            p = np.maximum(self.min_target, p)
+        elif self.task == TASK_CLASSIFICATION:
+            p = 1.0 / (1.0 + np.exp(-p))
+        else:
+            raise ValueError("task not supported")              # fm_learn_sgd.h:85
+        return p
+
+    def close(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None

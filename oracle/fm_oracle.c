@@ -6,8 +6,10 @@
 #include "fm_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define V(m, f, j) ((m)->v[(size_t)(f) * (size_t)(m)->n + (size_t)(j)])
 
@@ -280,4 +282,44 @@ double fmo_init_value(uint64_t seed, uint64_t j, uint32_t f, double stdev) {
   uint64_t h = fmo_mix64(seed ^ (j * 0x9E3779B97F4A7C15ULL + (uint64_t)f * 0xD6E8FEB86659FD93ULL + 0x1234567ULL));
   double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);   /* [0,1) */
   return stdev * (2.0 * u - 1.0) * 1.7320508075688772;
+}
+
+typedef struct { fmo_model *m; uint64_t seed; double stdev; int tid, nt; } fill_arg;
+
+static void *fill_worker(void *p) {
+  fill_arg *a = (fill_arg *)p;
+  const size_t n = (size_t)a->m->n;
+  const size_t lo = n * (size_t)a->tid / (size_t)a->nt, hi = n * (size_t)(a->tid + 1) / (size_t)a->nt;
+  for (int f = 0; f < a->m->k; f++)
+    for (size_t j = lo; j < hi; j++) V(a->m, f, j) = fmo_init_value(a->seed, j, (uint32_t)f, a->stdev);
+  for (size_t j = lo; j < hi; j++) a->m->w[j] = 0.0;
+  return NULL;
+}
+
+void fmo_fill_params(fmo_model *m, uint64_t seed, double stdev, int threads) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  pthread_t th[256];
+  fill_arg args[256];
+  for (int t = 0; t < threads; t++) {
+    args[t].m = m; args[t].seed = seed; args[t].stdev = stdev; args[t].tid = t; args[t].nt = threads;
+    pthread_create(&th[t], NULL, fill_worker, &args[t]);
+  }
+  for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+  m->w0 = 0.0;
+}
+
+double fmo_time_sgd_synth(fmo_model *m, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz,
+                          int task, double learn_rate) {
+  fmo_entry *ent = (fmo_entry *)malloc(sizeof(fmo_entry) * (size_t)n_rows * nnz);
+  uint64_t *rp = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n_rows + 1));
+  float *y = (float *)malloc(sizeof(float) * n_rows);
+  fmo_synth_rows(seed, row0, n_rows, nnz, m->n, ent, rp, y);
+  fmo_data d; d.entries = ent; d.row_ptr = rp; d.target = y; d.n_rows = n_rows;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  fmo_sgd_epoch_online(m, &d, task, learn_rate, -1.0, 1.0);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  free(ent); free(rp); free(y);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

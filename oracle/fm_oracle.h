@@ -146,6 +146,13 @@ void     fmo_synth_rows(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t 
 /* deterministic cheap parameter fill used by bench.py for BOTH legs (not the reference RNG):
  * v[f][j] = stdev * u(seed, j, f) with u uniform in [-sqrt3, sqrt3) (unit variance). */
 double fmo_init_value(uint64_t seed, uint64_t j, uint32_t f, double stdev);
+/* fills m->v with fmo_init_value (and w, w0 with 0) using `threads` host threads (untimed set-up of the
+ * cpu_baseline leg: 6.4e9 values at the north-star size) */
+void fmo_fill_params(fmo_model *m, uint64_t seed, double stdev, int threads);
+/* cpu_baseline: generates rows [row0,row0+n_rows) of the synthetic workload and runs ONE pass of the
+ * online loop (fmo_sgd_epoch_online) over them on ONE thread; returns the seconds of the loop alone. */
+double fmo_time_sgd_synth(fmo_model *m, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz,
+                          int task, double learn_rate);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,9 @@ def lib():
         L.fmo_synth_id.restype = C.c_uint32
         L.fmo_init_value.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double]
         L.fmo_init_value.restype = C.c_double
+        L.fmo_fill_params.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_double, C.c_int]
+        L.fmo_time_sgd_synth.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_double]
+        L.fmo_time_sgd_synth.restype = C.c_double
         _lib = L
     return _lib
 
@@ -224,3 +227,18 @@ def run_ref_harness(args, cwd=None):
         raise FileNotFoundError("oracle/_ref/ref_harness not built (needs /root/reference); run make -C oracle")
     return subprocess.run([REF_HARNESS] + [str(a) for a in args], cwd=cwd, check=True,
                           capture_output=True, text=True)
+
+
+def time_sgd_synth(n, k, nnz, n_rows, seed=123, stdev=0.01, lr=0.01, regv=0.001, threads=8, row0=0):
+    """cpu_baseline leg of bench.py: the restated reference loop (1 thread) on a bounded sample of the synthetic
+    workload.  Parameters are np.empty + a threaded fill (untimed).  Returns (seconds, examples_per_sec)."""
+    m = Model.__new__(Model)
+    m.n, m.k, m.k0, m.k1 = int(n), int(k), True, True
+    m.reg0, m.regw, m.regv = 0.0, 0.0, float(regv)
+    m.w0 = 0.0
+    m.w = np.empty(m.n, dtype=np.float64)
+    m.v = np.empty((m.k, m.n), dtype=np.float64)
+    cm = m._c()
+    lib().fmo_fill_params(C.byref(cm), seed, stdev, threads)
+    sec = lib().fmo_time_sgd_synth(C.byref(cm), seed, row0, n_rows, nnz, TASK_CLASSIFICATION, lr)
+    return sec, n_rows / sec

@@ -1,0 +1,316 @@
+"""GPU: parity of the HIP path (through the C-ABI) with the oracle and the golden fixtures.
+
+Tolerance: north_star asks for predictions within 1e-4 relative of the CPU reference.  The device keeps the
+parameters in fp32 (reference: fp64), so every comparison below is
+    |gpu - ref| <= 1e-4 * |ref| + ATOL
+with ATOL a small absolute floor for values near zero (stated per test)."""
+import numpy as np
+import pytest
+
+import datagen
+from common import Golden
+from conftest import golden_cases
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+CASES = [c for c in golden_cases() if c.startswith("sgd_")]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from libfm_amd import build, capi
+    build.build()
+    if capi.load().fmx_device_count() == 0:
+        pytest.fail("gpu-marked test without a HIP device")
+    return capi
+
+
+def make_handle(capi, g, **kw):
+    return capi.Handle(g.n, g.k, g.k0, g.k1, g.task, g.reg[0], g.reg[1], g.reg[2], g.lr,
+                       g.min_target, g.max_target, **kw)
+
+
+def upload(h, slot, d):
+    h.upload_rows(slot, d.entries, d.row_ptr, d.target)
+    return d.n_rows
+
+
+# ---------------------------------------------------------------------------------------------
+# A5: parameter block round trip (reference layout fp64 factor-major <-> device fp32 feature-major)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_params_round_trip(capi, oracle, name):
+    g = Golden(name)
+    m = g.model(oracle, "final")
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    w0, w, v = h.get_params()
+    assert w0 == m.w0
+    assert np.array_equal(w, m.w.astype(np.float32).astype(np.float64))
+    assert np.array_equal(v, m.v.astype(np.float32).astype(np.float64))
+    h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# A1/A4: fm_model::predict on fixed parameters, against the REAL reference's outputs (golden)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_predict_matches_reference(capi, oracle, name):
+    g = Golden(name)
+    m = g.model(oracle, "final")
+    te = g.data(oracle, "test")
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    n = upload(h, 0, te)
+    p = h.predict(0, n)
+    np.testing.assert_allclose(p, g.z["pred_raw"], rtol=RTOL, atol=2e-5)
+    h.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_evaluate_matches_reference(capi, oracle, name):
+    g = Golden(name)
+    m = g.model(oracle, "final")
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    for slot, which, col in ((0, "train", 0), (1, "test", 1)):
+        d = g.data(oracle, which)
+        upload(h, slot, d)
+        ev = h.evaluate(slot)
+        ref = float(g.z["eval"][-1, col])
+        if g.task == 0:
+            assert abs(ev.rmse - ref) <= RTOL * ref + 1e-6
+            _, mae = oracle.evaluate(m, d, g.task, g.min_target, g.max_target)
+            assert abs(ev.mae - mae) <= RTOL * mae + 1e-6
+        else:
+            # accuracy is a count: allow rows whose raw prediction is within fp32 noise of 0 to flip
+            raw = oracle.predict_raw(m, d)
+            near = int((np.abs(raw) < 1e-5).sum())
+            assert abs(ev.accuracy - ref) * d.n_rows <= near + 1e-9
+    h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# A2/A3: the reference trajectory (sequential mode) against the REAL reference's final parameters
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_sequential_sgd_matches_reference_trajectory(capi, oracle, name):
+    g = Golden(name)
+    m = g.model(oracle, "init")
+    tr, te = g.data(oracle, "train"), g.data(oracle, "test")
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    upload(h, 0, tr)
+    nte = upload(h, 1, te)
+    for _ in range(g.iters):
+        h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
+    w0, w, v = h.get_params()
+    # parameters are stored in fp32 after every update: a few e-7 relative per step, accumulated
+    assert abs(w0 - float(g.z["final_w0"])) <= RTOL * abs(float(g.z["final_w0"])) + 1e-5
+    np.testing.assert_allclose(w, g.z["final_w"], rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, g.z["final_v"], rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(h.predict(1, nte), g.z["pred_raw"], rtol=RTOL, atol=5e-5)
+    h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# minibatch mode against the restated batch rule (oracle), several batch / chunk sizes, both apply forms
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,batch,chunk", [
+    ("sgd_reg_ml", 1, 1), ("sgd_reg_ml", 7, 1), ("sgd_reg_ml", 64, 16), ("sgd_reg_ml", 600, 64),
+    ("sgd_cls_ragged", 32, 8), ("sgd_cls_k64", 50, 64), ("sgd_reg_ragged_nolin", 16, 4),
+    ("sgd_reg_k1", 25, 5), ("sgd_cls_zipf_k32", 100, 10), ("sgd_cls_dup", 10, 3),
+])
+def test_minibatch_matches_restated_rule(capi, oracle, name, batch, chunk):
+    g = Golden(name)
+    m = g.model(oracle, "init")
+    tr = g.data(oracle, "train")
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    upload(h, 0, tr)
+    for _ in range(g.iters):
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_ATOMIC, batch, chunk)
+        oracle.sgd_epoch_minibatch(m, tr, g.task, g.lr, g.min_target, g.max_target, batch, chunk)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    h.close()
+
+
+def collision_free(n_rows, nnz, seed):
+    """every feature occurs at most once in the whole data set."""
+    rng = np.random.default_rng(seed)
+    n = n_rows * nnz
+    ids = rng.permutation(n).astype(np.uint32)
+    ent = np.zeros(n, dtype=datagen.ENTRY_DTYPE)
+    ent["id"] = ids
+    ent["value"] = np.round(rng.uniform(0.5, 1.5, n), 3)
+    row_ptr = np.arange(n_rows + 1, dtype=np.uint64) * np.uint64(nnz)
+    y = np.where(rng.random(n_rows) < 0.5, -1.0, 1.0).astype(np.float32)
+    return n, ent, row_ptr, y
+
+
+@pytest.mark.parametrize("k,nnz,apply", [(64, 32, "atomic"), (64, 32, "store"), (32, 16, "store"), (8, 5, "atomic"),
+                                        (128, 7, "store"), (256, 3, "atomic"), (64, 39, "store"), (16, 70, "store")])
+def test_hogwild_and_store_are_exact_without_collisions(capi, oracle, k, nnz, apply):
+    """With no shared feature and no bias the update of a row is independent of every other row, so the
+    asynchronous fused kernel, the minibatch kernels and the online reference loop must all agree."""
+    n_rows = 300
+    n, ent, row_ptr, y = collision_free(n_rows, nnz, seed=k * 1000 + nnz)
+    d = oracle.Data(ent, row_ptr, y)
+    m = oracle.Model(n, k, k0=False, k1=True, reg0=0.0, regw=0.01, regv=0.02)
+    m.v[:] = oracle.init_values(5, n, k, 0.1)
+    m.w[:] = oracle.init_values(6, n, 1, 0.1)[0]
+    lr = 0.05
+    ap = capi.APPLY_ATOMIC if apply == "atomic" else capi.APPLY_STORE
+    ref = m.copy()
+    oracle.sgd_epoch_online(ref, d, 1, lr, -1.0, 1.0)
+    for mode, batch in ((capi.SGD_HOGWILD, 0), (capi.SGD_MINIBATCH, 64)):
+        h = capi.Handle(n, k, False, True, 1, 0.0, 0.01, 0.02, lr, -1.0, 1.0)
+        h.set_params(m.w0, m.w, m.v)
+        h.upload_rows(0, ent, row_ptr, y)
+        h.sgd_epoch(0, mode, ap, batch, 8)
+        w0, w, v = h.get_params()
+        np.testing.assert_allclose(w, ref.w, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(v, ref.v, rtol=RTOL, atol=1e-6)
+        h.close()
+
+
+def test_hogwild_converges_like_the_reference(capi, oracle):
+    """asynchronous mode is not trajectory-identical; hold it to the reference's final metric."""
+    g = Golden("sgd_reg_ml")
+    m = g.model(oracle, "init")
+    tr = g.data(oracle, "train")
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    upload(h, 0, tr)
+    for _ in range(g.iters):
+        h.sgd_epoch(0, capi.SGD_HOGWILD, capi.APPLY_ATOMIC)
+    rmse = h.evaluate(0).rmse
+    ref = float(g.z["eval"][-1, 0])
+    assert abs(rmse - ref) < 0.05 * ref
+    h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# long ragged rows (> 64 entries: more than one wavefront-wide chunk), k not a power of two
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [0, 3, 10, 20, 100])
+def test_odd_k_and_long_rows(capi, oracle, k):
+    n = 500
+    ent, row_ptr, y = datagen.ragged_real(n, 120, 150, seed=77 + k, classification=False)
+    d = oracle.Data(ent, row_ptr, y)
+    m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.003)
+    if k:
+        m.v[:] = oracle.init_values(1, n, k, 0.05)
+    m.w[:] = oracle.init_values(2, n, 1, 0.05)[0]
+    m.w0 = 0.1
+    lo, hi = float(y.min()), float(y.max())
+    h = capi.Handle(n, k, True, True, 0, 0.001, 0.002, 0.003, 0.002, lo, hi)
+    h.set_params(m.w0, m.w, m.v if k else None)
+    h.upload_rows(0, ent, row_ptr, y)
+    np.testing.assert_allclose(h.predict(0, d.n_rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5)
+    h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
+    oracle.sgd_epoch_online(m, d, 0, 0.002, lo, hi)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    if k:
+        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+    h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_ATOMIC, 16, 4)
+    oracle.sgd_epoch_minibatch(m, d, 0, 0.002, lo, hi, 16, 4)
+    w0, w, v = h.get_params()
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    if k:
+        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+    h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic workload + device init: integer work is bit-exact against the oracle's definition
+# ---------------------------------------------------------------------------------------------
+def test_synth_rows_bit_exact(capi, oracle):
+    n, nnz, rows = 6400, 32, 1000
+    h = capi.Handle(n, 8, task=1)
+    h.synth_rows(0, 123, 17, rows, nnz)
+    ent, rp, y = h.download_rows(0)
+    d = oracle.synth_rows(123, 17, rows, nnz, n)
+    assert np.array_equal(ent, d.entries)
+    assert np.array_equal(rp, d.row_ptr)
+    assert np.array_equal(y, d.target)
+    h.close()
+
+
+def test_init_params_matches_oracle_definition(capi, oracle):
+    n, k = 1000, 16
+    h = capi.Handle(n, k)
+    h.init_params(0.0, 0.1, 99)
+    w0, w, v = h.get_params()
+    ref = oracle.init_values(99, n, k, 0.1).astype(np.float32).astype(np.float64)
+    assert w0 == 0 and not w.any()
+    assert np.array_equal(v, ref)
+    h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# feature sharding on ONE device (loopback): two shard handles + host-side sum == unsharded handle
+# ---------------------------------------------------------------------------------------------
+def test_sharded_partials_sum_to_unsharded(capi, oracle):
+    import torch
+    g = Golden("sgd_cls_k64")
+    m = g.model(oracle, "init")
+    tr = g.data(oracle, "train")
+    B = 128
+    full = make_handle(capi, g)
+    full.set_params(m.w0, m.w, m.v)
+    upload(full, 0, tr)
+    nf = full.partial_floats(B)
+    world = 2
+    shards = [make_handle(capi, g, shard_rank=r, shard_world=world) for r in range(world)]
+    for s in shards:
+        s.set_params(m.w0, m.w, m.v)
+        upload(s, 0, tr)
+    dev = torch.device("cuda:0")
+    for epoch in range(2):
+        for row0 in range(0, tr.n_rows, B):
+            nb = min(B, tr.n_rows - row0)
+            bufs = []
+            for s in shards:
+                buf = torch.zeros(nf, dtype=torch.float32, device=dev)
+                torch.cuda.synchronize()
+                s.sgd_partial(0, row0, nb, buf.data_ptr())
+                s.synchronize()
+                bufs.append(buf)
+            tot = bufs[0] + bufs[1]                       # what the RCCL all-reduce computes
+            torch.cuda.synchronize()
+            for s in shards:
+                s.sgd_finish(0, row0, nb, tot.data_ptr(), w0_chunk=16)
+                s.synchronize()
+        full.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_ATOMIC, B, 16)
+    w0f, wf, vf = full.get_params()
+    w = np.zeros_like(wf)
+    v = np.zeros_like(vf)
+    for s in shards:
+        w0s, _, _ = s.get_params(w, v)                    # each shard fills only its own features
+        assert abs(w0s - w0f) <= 1e-6 * max(1.0, abs(w0f))
+    np.testing.assert_allclose(w, wf, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(v, vf, rtol=1e-5, atol=1e-7)
+    for s in shards:
+        s.close()
+    full.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# error behaviour at the boundary
+# ---------------------------------------------------------------------------------------------
+def test_errors(capi, oracle):
+    h = capi.Handle(10, 4)
+    with pytest.raises(capi.FmxError):
+        h.predict(0, 1)                                    # slot not uploaded
+    ent = np.zeros(1, dtype=capi.ENTRY_DTYPE)
+    ent["id"] = 10                                         # id >= num_attribute (reference asserts, fm_model.h:112)
+    with pytest.raises(capi.FmxError):
+        h.upload_rows(0, ent, np.array([0, 1], dtype=np.uint64), np.zeros(1, dtype=np.float32))
+    h.close()
