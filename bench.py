@@ -83,9 +83,9 @@ def main():
     ap.add_argument("--nnz", type=int, default=32)
     ap.add_argument("--rows", type=int, default=1 << 22, help="examples per step")
     ap.add_argument("--mode", default="minibatch", choices=["minibatch", "hogwild"])
-    ap.add_argument("--apply", default="atomic", choices=["atomic", "store"])
-    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 65536 sharded)")
-    ap.add_argument("--w0-chunk", type=int, default=64)
+    ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
+    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 65536 sharded); hogwild: rows per launch (0: 262144)")
+    ap.add_argument("--w0-chunk", type=int, default=256)
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None, help="PMC HBM bytes per launch of the dominant kernel")
@@ -118,10 +118,11 @@ def main():
     h.synth_rows(0, 123, 0, args.rows, args.nnz)
     info = h.info()
     mode = capi.SGD_HOGWILD if args.mode == "hogwild" else capi.SGD_MINIBATCH
-    apply_ = capi.APPLY_ATOMIC if args.apply == "atomic" else capi.APPLY_STORE
+    apply_ = {"default": capi.APPLY_DEFAULT, "segmented": capi.APPLY_SEGMENTED, "atomic": capi.APPLY_ATOMIC,
+              "store": capi.APPLY_STORE}[args.apply]
 
     if world == 1:
-        batch = args.batch or 16384
+        batch = args.batch or (262144 if args.mode == "hogwild" else 16384)
         main_time, main_launches = 0.0, 0
 
         def step(timed):
@@ -130,7 +131,7 @@ def main():
             if timed:
                 main_time += st.main_kernel_seconds
                 main_launches += st.main_kernel_launches
-        rows_per_launch = args.rows if args.mode == "hogwild" else min(batch, args.rows)
+        rows_per_launch = min(batch, args.rows)
         kind = "fused" if args.mode == "hogwild" else "apply"
     else:
         batch = args.batch or 65536
@@ -144,7 +145,7 @@ def main():
                 view = buf[: nb * kp1]
                 h.sgd_partial(0, row0, nb, view.data_ptr(), stream)
                 dist.all_reduce(view)
-                h.sgd_finish(0, row0, nb, view.data_ptr(), apply_, args.w0_chunk, stream)
+                h.sgd_finish(0, row0, nb, view.data_ptr(), apply_, args.w0_chunk, stream, batch)
         rows_per_launch = min(batch, args.rows)
         kind = "apply"
         main_time, main_launches = 0.0, 0
@@ -176,7 +177,7 @@ def main():
             per_ex = algorithmic_bytes(args.k, args.nnz, kind)
             avg = main_time / main_launches
             achieved = per_ex * rows_per_launch / avg / 1e9
-            roof = {"bound": "hbm", "kernel": "k_fused" if kind == "fused" else "k_apply",
+            roof = {"bound": "hbm", "kernel": "k_fused" if kind == "fused" else ("k_apply_seg" if args.apply in ("default", "segmented") else "k_apply"),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic,
                     "bytes_per_example": per_ex, "examples_per_launch": rows_per_launch,
@@ -189,7 +190,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
-                       "mode": args.mode, "apply": args.apply, "batch": batch if args.mode == "minibatch" or world > 1 else None,
+                       "mode": args.mode, "apply": args.apply, "batch": batch,
                        "w0_chunk": args.w0_chunk, "sharding": "features mod %d" % world if world > 1 else "none",
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,

@@ -54,8 +54,13 @@ enum {
 };
 
 enum {
-  FMX_APPLY_ATOMIC = 0,    /* fp32 atomic scatter-add of the per-occurrence deltas */
-  FMX_APPLY_STORE = 1      /* plain read-modify-write stores (colliding ids in a batch lose updates) */
+  FMX_APPLY_DEFAULT = 0,   /* MINIBATCH: SEGMENTED, HOGWILD: STORE */
+  FMX_APPLY_ATOMIC = 1,    /* one wavefront per example, fp32 atomic scatter-add of the per-occurrence deltas
+                              (reads of a feature that collides inside the batch may see a partial update) */
+  FMX_APPLY_STORE = 2,     /* one wavefront per example, plain read-modify-write stores (colliding ids in a
+                              batch lose updates; exact when a batch has no repeated feature) */
+  FMX_APPLY_SEGMENTED = 3  /* MINIBATCH only: entries pre-bucketed per (batch, feature); one owner per touched
+                              row, no atomics, exactly the batch rule of oracle/fm_oracle.h (deterministic) */
 };
 
 typedef struct fmx_context_s *fmx_handle;
@@ -80,8 +85,9 @@ typedef struct fmx_config {
 typedef struct fmx_sgd_opts {
   int32_t  mode;            /* FMX_SGD_* */
   int32_t  apply;           /* FMX_APPLY_* (MINIBATCH and HOGWILD) */
-  uint32_t batch;           /* rows per minibatch (MINIBATCH); 0 = library default (16384) */
-  uint32_t w0_chunk;        /* w0 micro-chunk (MINIBATCH); 0 = library default (64) */
+  uint32_t batch;           /* MINIBATCH: rows per minibatch, 0 = 16384.  HOGWILD: rows per launch during which
+                               w0 is frozen (macro-batch), 0 = 262144 */
+  uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default (256) */
   uint32_t flags;           /* FMX_FLAG_* */
   uint32_t reserved;
 } fmx_sgd_opts;

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libfmx.so")
 FMX_OK = 0
 TASK_REGRESSION, TASK_CLASSIFICATION = 0, 1
 SGD_SEQUENTIAL, SGD_MINIBATCH, SGD_HOGWILD = 0, 1, 2
-APPLY_ATOMIC, APPLY_STORE = 0, 1
+APPLY_DEFAULT, APPLY_ATOMIC, APPLY_STORE, APPLY_SEGMENTED = 0, 1, 2, 3
 FLAG_TIME_MAIN_KERNEL = 1
 MAX_SLOTS = 8
 
@@ -89,6 +89,10 @@ def load():
     """dlopen libfmx.so and bind every declared symbol.  Raises (never falls back) when it is missing."""
     global _lib
     if _lib is None:
+        try:                       # torch bundles its own HIP runtime: when both live in one process torch's
+            import torch  # noqa: F401   # must be loaded first, or torch.cuda finds no device afterwards
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise ImportError("libfm_amd/libfmx.so is not built: run `python -m libfm_amd.build` "
                               "(there is no CPU fallback)")
@@ -198,7 +202,7 @@ class Handle:
         self._chk(self.lib.fmx_evaluate(self.h, slot, C.byref(ev)))
         return ev
 
-    def sgd_epoch(self, slot, mode, apply=APPLY_ATOMIC, batch=0, w0_chunk=0, flags=0):
+    def sgd_epoch(self, slot, mode, apply=APPLY_DEFAULT, batch=0, w0_chunk=0, flags=0):
         opts = SgdOpts(mode, apply, batch, w0_chunk, flags, 0)
         st = EpochStats()
         self._chk(self.lib.fmx_sgd_epoch(self.h, slot, C.byref(opts), C.byref(st)))
@@ -212,8 +216,8 @@ class Handle:
     def sgd_partial(self, slot, row0, n_rows, d_partial_ptr, stream=None):
         self._chk(self.lib.fmx_sgd_partial(self.h, slot, row0, n_rows, d_partial_ptr, stream))
 
-    def sgd_finish(self, slot, row0, n_rows, d_partial_ptr, apply=APPLY_ATOMIC, w0_chunk=0, stream=None):
-        opts = SgdOpts(SGD_MINIBATCH, apply, n_rows, w0_chunk, 0, 0)
+    def sgd_finish(self, slot, row0, n_rows, d_partial_ptr, apply=APPLY_DEFAULT, w0_chunk=0, stream=None, batch=0):
+        opts = SgdOpts(SGD_MINIBATCH, apply, batch or n_rows, w0_chunk, 0, 0)
         self._chk(self.lib.fmx_sgd_finish(self.h, slot, row0, n_rows, d_partial_ptr, C.byref(opts), stream))
 
     def predict_finish(self, n_rows, d_partial_ptr, d_yhat_ptr, stream=None):

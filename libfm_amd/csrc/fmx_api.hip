@@ -28,6 +28,14 @@ struct Slot {
   uint64_t  nnz = 0;
   uint32_t  max_row = 0;
   bool      used = false;
+  // per-batch transposed rows for FMX_APPLY_SEGMENTED (built lazily for one batch size)
+  uint32_t  seg_B = 0;
+  TEntry*   t_ent = nullptr;
+  uint32_t* seg_feat = nullptr;
+  uint32_t* seg_rel = nullptr;
+  uint32_t  nseg = 0;
+  std::vector<uint32_t> batch_seg;   // [n_batches+1] first segment of every batch
+  std::vector<uint64_t> batch_base;  // [n_batches+1] first entry of every batch
 };
 
 thread_local std::string g_create_error = "";
@@ -135,7 +143,16 @@ int check_slot(fmx_handle h, int slot, bool need_target) {
   return FMX_OK;
 }
 
+void free_segments(Slot& s) {
+  if (s.t_ent) hipFree(s.t_ent);
+  if (s.seg_feat) hipFree(s.seg_feat);
+  if (s.seg_rel) hipFree(s.seg_rel);
+  s.t_ent = nullptr; s.seg_feat = nullptr; s.seg_rel = nullptr; s.seg_B = 0; s.nseg = 0;
+  s.batch_seg.clear(); s.batch_base.clear();
+}
+
 void free_slot(Slot& s) {
+  free_segments(s);
   if (s.ent) hipFree(s.ent);
   if (s.row_ptr) hipFree(s.row_ptr);
   if (s.target) hipFree(s.target);
@@ -151,13 +168,13 @@ int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* r
 }
 
 template <int KP, bool ATOMIC>
-int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint32_t n_rows, hipStream_t st) {
+int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st) {
   constexpr int VEC = Map<KP>::VEC, EPI = Map<KP>::EPI;
   const uint32_t need = (s.max_row + EPI - 1) / EPI;      // row slots per lane to keep a whole row in registers
   const dim3 grid(wave_grid(n_rows)), block(256);
 #define FMX_LAUNCH_ZR(ZRV)                                                                                  \
-  hipLaunchKernelGGL((k_fused<KP, ZRV, ATOMIC>), grid, block, 0, st, s.ent, s.row_ptr, s.target, (uint64_t)0, \
-                     n_rows, h->V, h->w, hy, h->w0)
+  hipLaunchKernelGGL((k_fused<KP, ZRV, ATOMIC>), grid, block, 0, st, s.ent, s.row_ptr, s.target, row0, \
+                     n_rows, h->V, h->w, hy, h->w0, h->rest)
   if constexpr (VEC * 8 <= 128) { if (need <= 8) { FMX_LAUNCH_ZR(8); return FMX_OK; } }
   if constexpr (VEC * 16 <= 128) { if (need <= 16) { FMX_LAUNCH_ZR(16); return FMX_OK; } }
   if constexpr (VEC * 32 <= 128) { if (need <= 32) { FMX_LAUNCH_ZR(32); return FMX_OK; } }
@@ -572,20 +589,120 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
   return FMX_OK;
 }
 
+// builds the (batch, feature) segments of a slot for batch size B (device radix sort; once per data set)
+static int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
+  if (s.seg_B == B && s.t_ent) return FMX_OK;
+  free_segments(s);
+  const uint64_t nnz = s.nnz;
+  const uint32_t n_batches = (s.n_rows + B - 1) / B;
+  if (nnz >= (1ull << 31)) return fail(h, FMX_E_UNSUPPORTED, "segmented apply: nnz >= 2^31 in one slot (split the data set)");
+  hipStream_t st = h->stream;
+  uint64_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr;
+  void* tmp = nullptr;
+  int rc = FMX_OK;
+  const size_t cnt = (size_t)std::max<uint64_t>(nnz, 1);
+#define SEG_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    rc = fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); goto done; } } while (0)
+  SEG_CHK(hipMalloc(&keys_a, cnt * 8)); SEG_CHK(hipMalloc(&keys_b, cnt * 8));
+  SEG_CHK(hipMalloc(&vals_a, cnt * 8)); SEG_CHK(hipMalloc(&vals_b, cnt * 8));
+  SEG_CHK(hipMalloc(&flags, cnt * 4)); SEG_CHK(hipMalloc(&pos, cnt * 4));
+  SEG_CHK(hipMalloc(&d_batch_seg, ((size_t)n_batches + 1) * 4));
+  if (nnz) {
+    hipLaunchKernelGGL(k_seg_keys, dim3(wave_grid(s.n_rows)), dim3(256), 0, st, s.ent, s.row_ptr, s.n_rows, B, keys_a, vals_a);
+    int bits_batch = 1; while ((1ull << bits_batch) < n_batches) bits_batch++;
+    size_t tmp_bytes = 0;
+    SEG_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (int)nnz, 0, 32 + bits_batch, st));
+    SEG_CHK(hipMalloc(&tmp, tmp_bytes));
+    SEG_CHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (int)nnz, 0, 32 + bits_batch, st));
+    hipLaunchKernelGGL(k_seg_heads, dim3(2048), dim3(256), 0, st, keys_b, nnz, flags);
+    SEG_CHK(hipStreamSynchronize(st));
+    hipFree(tmp); tmp = nullptr; tmp_bytes = 0;
+    SEG_CHK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, flags, pos, (int)nnz, st));
+    SEG_CHK(hipMalloc(&tmp, tmp_bytes));
+    SEG_CHK(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, flags, pos, (int)nnz, st));
+    uint32_t nseg = 0;
+    SEG_CHK(hipMemcpyAsync(&nseg, pos + (nnz - 1), 4, hipMemcpyDeviceToHost, st));
+    SEG_CHK(hipStreamSynchronize(st));
+    s.nseg = nseg;
+    SEG_CHK(hipMalloc(&s.seg_feat, (size_t)nseg * 4));
+    SEG_CHK(hipMalloc(&s.seg_rel, (size_t)nseg * 4));
+    hipLaunchKernelGGL(k_seg_fill, dim3(2048), dim3(256), 0, st, keys_b, flags, pos, nnz, s.row_ptr, B, s.seg_feat, s.seg_rel);
+    hipLaunchKernelGGL(k_seg_batches, dim3((n_batches + 256) / 256), dim3(256), 0, st, pos, nnz, nseg, s.row_ptr,
+                       s.n_rows, B, n_batches, d_batch_seg);
+    SEG_CHK(hipGetLastError());
+    s.batch_seg.resize((size_t)n_batches + 1);
+    SEG_CHK(hipMemcpyAsync(s.batch_seg.data(), d_batch_seg, ((size_t)n_batches + 1) * 4, hipMemcpyDeviceToHost, st));
+    SEG_CHK(hipStreamSynchronize(st));
+    s.t_ent = reinterpret_cast<TEntry*>(vals_b); vals_b = nullptr;      // payload layout == TEntry
+  } else {
+    s.nseg = 0;
+    s.batch_seg.assign((size_t)n_batches + 1, 0);
+    SEG_CHK(hipMalloc(&s.t_ent, 8));
+  }
+  {  // first entry of every batch (row_ptr sampled at multiples of B)
+    std::vector<uint64_t> rp((size_t)s.n_rows + 1);
+    SEG_CHK(hipMemcpy(rp.data(), s.row_ptr, rp.size() * 8, hipMemcpyDeviceToHost));
+    s.batch_base.resize((size_t)n_batches + 1);
+    for (uint32_t b = 0; b <= n_batches; b++) s.batch_base[b] = rp[std::min<uint64_t>((uint64_t)b * B, s.n_rows)];
+  }
+  s.seg_B = B;
+done:
+#undef SEG_CHK
+  if (keys_a) hipFree(keys_a);
+  if (keys_b) hipFree(keys_b);
+  if (vals_a) hipFree(vals_a);
+  if (vals_b) hipFree(vals_b);
+  if (flags) hipFree(flags);
+  if (pos) hipFree(pos);
+  if (d_batch_seg) hipFree(d_batch_seg);
+  if (tmp) hipFree(tmp);
+  if (rc) free_segments(s);
+  return rc;
+}
+
+static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
+                       const Hyper& hy, float* mult, hipStream_t st) {
+  if (hy.k0) {
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, rest, target, n_rows, chunk, hy, h->w0, mult);
+  } else if (mult) {
+    hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy, mult);
+  }
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+// steps 2 and 3 of the minibatch rule for rows [row0,row0+n_rows); `seg_batch` = batch index when the rows are
+// exactly one batch of the slot's segment structure (else -1: per-example apply only)
 static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, const float* S,
                            const float* rest, const fmx_sgd_opts* opts, hipStream_t st,
-                           hipEvent_t ev_a, hipEvent_t ev_b) {
+                           hipEvent_t ev_a, hipEvent_t ev_b, int64_t seg_batch) {
   const Hyper hy = make_hyper(h->cfg);
-  const uint32_t chunk = (opts && opts->w0_chunk) ? opts->w0_chunk : 64u;
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(64), 0, st, rest, s.target + row0, n_rows, chunk, hy, h->w0, h->mult);
-  const bool atomic = !(opts && opts->apply == FMX_APPLY_STORE);
+  const uint32_t chunk = (opts && opts->w0_chunk) ? opts->w0_chunk : 256u;
+  int rc = launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
+  if (rc) return rc;
+  int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
+  if (apply == FMX_APPLY_DEFAULT) apply = FMX_APPLY_SEGMENTED;
+  if (apply == FMX_APPLY_SEGMENTED && seg_batch < 0) return fail(h, FMX_E_STATE, "segmented apply needs batch-aligned rows");
   if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
-  if (atomic) {
+  if (apply == FMX_APPLY_SEGMENTED) {
+    const uint32_t s0 = s.batch_seg[(size_t)seg_batch], s1 = s.batch_seg[(size_t)seg_batch + 1];
+    const uint64_t base = s.batch_base[(size_t)seg_batch];
+    const uint32_t bnnz = (uint32_t)(s.batch_base[(size_t)seg_batch + 1] - base);
+    const uint32_t nseg = s1 - s0;
+    if (nseg) {
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply_seg<KP, 4>), dim3(wave_grid(((uint64_t)nseg + Map<KP>::EPI * 4 - 1) / (Map<KP>::EPI * 4))),
+                                          dim3(256), 0, st, s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nseg, bnnz,
+                                          h->V, h->w, hy, S, h->mult));
+    }
+  } else if (apply == FMX_APPLY_ATOMIC) {
     KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply<KP, true>), dim3(wave_grid(n_rows)), dim3(256), 0, st,
                                           s.ent, s.row_ptr, row0, n_rows, h->V, h->w, hy, S, h->mult));
-  } else {
+  } else if (apply == FMX_APPLY_STORE) {
     KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply<KP, false>), dim3(wave_grid(n_rows)), dim3(256), 0, st,
                                           s.ent, s.row_ptr, row0, n_rows, h->V, h->w, hy, S, h->mult));
+  } else {
+    return fail(h, FMX_E_ARG, "unknown apply mode %d", apply);
   }
   if (ev_b) HIPCHK(h, hipEventRecord(ev_b, st));
   HIPCHK(h, hipGetLastError());
@@ -596,7 +713,7 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
                    const fmx_sgd_opts* opts, void* stream) {
   int rc = check_slot(h, slot, true);
   if (rc) return rc;
-  const Slot& s = h->slots[slot];
+  Slot& s = h->slots[slot];
   if (row0 + n_rows > s.n_rows) return fail(h, FMX_E_ARG, "fmx_sgd_finish: rows outside slot");
   if (!d_partial) return fail(h, FMX_E_ARG, "fmx_sgd_finish: d_partial is NULL");
   if (n_rows == 0) return FMX_OK;
@@ -609,7 +726,18 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n_rows + Map<KP>::EPI - 1) / Map<KP>::EPI)),
                                         dim3(256), 0, st, S, c, n_rows, h->rest));
   HIPCHK(h, hipGetLastError());
-  return sgd_finish_impl(h, s, row0, n_rows, S, h->rest, opts, st, nullptr, nullptr);
+  int64_t seg_batch = -1;
+  const int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
+  if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_SEGMENTED) {
+    // the driver walks the slot in batches of opts->batch rows (the last one may be short)
+    const uint32_t B = (opts && opts->batch) ? opts->batch : n_rows;
+    if (row0 % B != 0 || (n_rows != B && row0 + n_rows != s.n_rows))
+      return fail(h, FMX_E_ARG, "fmx_sgd_finish: rows [%llu,+%u) are not batch %u of the slot", (unsigned long long)row0, n_rows, B);
+    rc = ensure_segments(h, h->slots[slot], B);
+    if (rc) return rc;
+    seg_batch = (int64_t)(row0 / B);
+  }
+  return sgd_finish_impl(h, s, row0, n_rows, S, h->rest, opts, st, nullptr, nullptr, seg_batch);
 }
 
 int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, float* d_yhat, void* stream) {
@@ -634,7 +762,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   if (rc) return rc;
   if (!opts) return fail(h, FMX_E_ARG, "fmx_sgd_epoch: opts is NULL");
   HIPCHK(h, hipSetDevice(h->device));
-  const Slot& s = h->slots[slot];
+  Slot& s = h->slots[slot];
   if (stats) memset(stats, 0, sizeof(*stats));
   if (s.n_rows == 0) return FMX_OK;
   if (h->cfg.shard_world > 1 && opts->mode != FMX_SGD_MINIBATCH)
@@ -657,18 +785,37 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     HIPCHK(h, hipGetLastError());
     batches = s.n_rows; main_launches = 1;
   } else if (opts->mode == FMX_SGD_HOGWILD) {
-    if (opts->apply == FMX_APPLY_STORE) {
-      KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, s.n_rows, h->stream); });
-    } else {
-      KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, s.n_rows, h->stream); });
-    }
+    if (opts->apply == FMX_APPLY_SEGMENTED) return fail(h, FMX_E_ARG, "HOGWILD has no segmented apply");
+    const uint32_t M = opts->batch ? opts->batch : 262144u;       // rows per launch; w0 frozen inside
+    const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : 256u;
+    rc = ensure_scratch(h, 0, std::min<uint32_t>(M, s.n_rows));
     if (rc) return rc;
-    HIPCHK(h, hipGetLastError());
-    batches = 1; main_launches = 1;
+    for (uint64_t row0 = 0; row0 < s.n_rows; row0 += M) {
+      const uint32_t nb = (uint32_t)std::min<uint64_t>(M, s.n_rows - row0);
+      hipEvent_t ea = nullptr, eb = nullptr;
+      if (timed) { HIPCHK(h, get_event(&ea)); HIPCHK(h, get_event(&eb)); main_launches++; HIPCHK(h, hipEventRecord(ea, h->stream)); }
+      if (opts->apply == FMX_APPLY_ATOMIC) {
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, row0, nb, h->stream); });
+      } else {
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, row0, nb, h->stream); });
+      }
+      if (rc) return rc;
+      if (timed) HIPCHK(h, hipEventRecord(eb, h->stream));
+      HIPCHK(h, hipGetLastError());
+      rc = launch_scan(h, h->rest, s.target + row0, nb, chunk, hy, nullptr, h->stream);   // advances w0 only
+      if (rc) return rc;
+      batches++;
+    }
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
     const uint32_t B = opts->batch ? opts->batch : 16384u;
     rc = ensure_scratch(h, std::min<uint32_t>(B, s.n_rows), 0);
     if (rc) return rc;
+    const bool segmented = (opts->apply == FMX_APPLY_DEFAULT || opts->apply == FMX_APPLY_SEGMENTED);
+    if (segmented) {
+      rc = ensure_segments(h, h->slots[slot], B);
+      if (rc) return rc;
+      HIPCHK(h, hipEventRecord(h->ev0, h->stream));           // do not bill the one-time bucketing to the epoch
+    }
     for (uint64_t row0 = 0; row0 < s.n_rows; row0 += B) {
       const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
       float* S = h->partial;
@@ -677,7 +824,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
                                             s.ent, s.row_ptr, row0, nb, h->V, h->w, h->cfg.k1, S, rest));
       hipEvent_t ea = nullptr, eb = nullptr;
       if (timed) { HIPCHK(h, get_event(&ea)); HIPCHK(h, get_event(&eb)); main_launches++; }
-      rc = sgd_finish_impl(h, s, row0, nb, S, rest, opts, h->stream, ea, eb);
+      rc = sgd_finish_impl(h, s, row0, nb, S, rest, opts, h->stream, ea, eb, segmented ? (int64_t)(row0 / B) : -1);
       if (rc) return rc;
       batches++;
     }
@@ -693,7 +840,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     stats->rows = s.n_rows;
     stats->batches = batches;
     stats->device_seconds = ms * 1e-3;
-    if (opts->mode == FMX_SGD_MINIBATCH && timed) {
+    if ((opts->mode == FMX_SGD_MINIBATCH || opts->mode == FMX_SGD_HOGWILD) && timed) {
       double tot = 0;
       for (size_t i = 0; i + 1 < ev_used; i += 2) {
         float m2 = 0;

@@ -51,6 +51,20 @@ __device__ __forceinline__ double wave_sum_d(double x) {
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
   return x;
 }
+// 64-lane sum through DPP (no LDS crossbar traffic): two quad_perm butterflies, two row rotates, then the
+// gfx9 row_bcast15 / row_bcast31 steps leave the total in lane 63; returned wave-uniform.
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+#define FMX_DPP_ADD(ctrl, rmask)                                                                        \
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false))
+  FMX_DPP_ADD(0xB1, 0xf);    // quad_perm(1,0,3,2)
+  FMX_DPP_ADD(0x4E, 0xf);    // quad_perm(2,3,0,1)
+  FMX_DPP_ADD(0x124, 0xf);   // row_ror:4
+  FMX_DPP_ADD(0x128, 0xf);   // row_ror:8
+  FMX_DPP_ADD(0x142, 0xa);   // row_bcast:15 -> rows 1,3
+  FMX_DPP_ADD(0x143, 0xc);   // row_bcast:31 -> rows 2,3
+#undef FMX_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
 // all-reduce over the EPI sub-groups that hold the same factor (lane bits >= log2(LPR))
 template <int LPR> __device__ __forceinline__ float subgroup_allsum(float x) {
 #pragma unroll
@@ -223,7 +237,7 @@ k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, u
 #pragma unroll
       for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
     }
-    part = wave_sum(part);
+    part = wave_sum_dpp(part);
     if (lane == 0) scal[e] = part;
   }
 }
@@ -252,28 +266,58 @@ k_rest_from_partial(const float* __restrict__ S, const float* __restrict__ c, ui
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_scan: ONE wavefront.  Step 2 of the minibatch rule (oracle/fm_oracle.h): w0 advances in
-// micro-chunks of `chunk` consecutive examples; mult_e is computed with the w0 of its chunk.
+// k_scan: step 2 of the minibatch rule (oracle/fm_oracle.h): w0 advances in micro-chunks of `chunk`
+// consecutive examples; mult_e is computed with the w0 of its chunk.
 //   fm_learn_sgd_element.h:57-65 (p, multiplier) + fm_sgd.h:34-37 (w0) per example.
+// ONE workgroup: 1024 threads stage rest/target tiles through LDS (the recurrence itself is serial, so
+// its loads must not be HBM round trips); wavefront 0 runs the recurrence out of LDS with a DPP reduction
+// per chunk; the multipliers go back to HBM in coalesced tiles.
 // ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
+constexpr int SCAN_TILE = 8192;
+__global__ void __launch_bounds__(1024)
 k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
        Hyper h, double* __restrict__ w0_ptr, float* __restrict__ mult) {
-  const uint32_t lane = threadIdx.x;
+  __shared__ float s_rest[SCAN_TILE];
+  __shared__ float s_y[SCAN_TILE];
+  __shared__ float s_m[SCAN_TILE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
   double w0 = *w0_ptr;
-  for (uint32_t c0 = 0; c0 < n_rows; c0 += chunk) {
-    const uint32_t nc = min(chunk, n_rows - c0);
-    const float w0s = h.k0 ? (float)w0 : 0.f;
-    float acc = 0.f;
-    for (uint32_t t = lane; t < nc; t += 64) {
-      const float m = multiplier(h, w0s + rest[c0 + t], target[c0 + t]);
-      mult[c0 + t] = m;
-      acc += m;
+  uint32_t chunk_pos = 0;
+  float acc = 0.f;
+  for (uint32_t t0 = 0; t0 < n_rows; t0 += SCAN_TILE) {
+    const uint32_t tn = min((uint32_t)SCAN_TILE, n_rows - t0);
+    for (uint32_t i = tid; i < tn; i += 1024) { s_rest[i] = rest[t0 + i]; s_y[i] = target[t0 + i]; }
+    __syncthreads();
+    if (tid < 64) {
+      uint32_t i = 0;
+      while (i < tn) {
+        const uint32_t take = min(chunk - chunk_pos, tn - i);
+        const float w0s = h.k0 ? (float)w0 : 0.f;
+        for (uint32_t t = lane; t < take; t += 64) {
+          const float m = multiplier(h, w0s + s_rest[i + t], s_y[i + t]);
+          s_m[i + t] = m;
+          acc += m;
+        }
+        i += take; chunk_pos += take;
+        if (chunk_pos == chunk || t0 + i == n_rows) {
+          const float tot = wave_sum_dpp(acc);
+          if (h.k0) w0 -= (double)h.lr * ((double)tot + (double)chunk_pos * (double)h.reg0 * (double)w0s);
+          acc = 0.f; chunk_pos = 0;
+        }
+      }
     }
-    acc = wave_sum(acc);
-    if (h.k0) w0 -= (double)h.lr * ((double)acc + (double)nc * (double)h.reg0 * (double)w0s);
+    __syncthreads();
+    if (mult) for (uint32_t i = tid; i < tn; i += 1024) mult[t0 + i] = s_m[i];
+    __syncthreads();
   }
-  if (lane == 0) *w0_ptr = w0;
+  if (tid == 0) *w0_ptr = w0;
+}
+
+// no bias: the multipliers are independent of each other
+__global__ void __launch_bounds__(256)
+k_mult(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, Hyper h, float* __restrict__ mult) {
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_rows; e += gridDim.x * blockDim.x)
+    mult[e] = multiplier(h, rest[e], target[e]);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -299,33 +343,161 @@ k_apply(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uin
 }
 
 // ----------------------------------------------------------------------------------------------
+// Per-batch transposed rows ("segments"): libFM never shuffles (fm_learn_sgd_element.h:56), so the batches
+// are static and their entries can be bucketed ONCE by (batch, feature).  A segment = all occurrences of
+// one feature inside one batch, in example order.  k_apply_seg then owns each touched V row exclusively:
+// no atomics, no lost updates, and exactly the batch-start-parameter rule of the oracle:
+//   v_new = v0 - lr*( sum_e mult_e*x_e*S_ef  -  v0*sum_e mult_e*x_e^2  +  n_occ*regv*v0 )   (fm_sgd.h:44-50 per occurrence)
+//   w_new = w0 - lr*( sum_e mult_e*x_e + n_occ*regw*w0 )                                     (fm_sgd.h:38-43)
+// ----------------------------------------------------------------------------------------------
+struct TEntry { uint32_t e; float x; };     // (example index inside its batch, value)
+
+// sort keys: (batch << 32) | feature id ; payload: (value bits << 32) | example-in-batch  (== TEntry in memory)
+__global__ void __launch_bounds__(256)
+k_seg_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint32_t B,
+           uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t r = wave0; r < n_rows; r += nwaves) {
+    const uint64_t a = row_ptr[r], b = row_ptr[r + 1];
+    const uint64_t hi = (uint64_t)(r / B) << 32;
+    const uint32_t eb = r % B;
+    for (uint64_t i = a + lane; i < b; i += 64) {
+      const Entry e = ent[i];
+      keys[i] = hi | e.id;
+      vals[i] = ((uint64_t)__float_as_uint(e.value) << 32) | eb;
+    }
+  }
+}
+__global__ void __launch_bounds__(256)
+k_seg_heads(const uint64_t* __restrict__ keys, uint64_t nnz, uint32_t* __restrict__ flags) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x)
+    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// pos = inclusive scan of flags (1-based segment number of every entry)
+__global__ void __launch_bounds__(256)
+k_seg_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
+           uint64_t nnz, const uint64_t* __restrict__ row_ptr, uint32_t B,
+           uint32_t* __restrict__ seg_feat, uint32_t* __restrict__ seg_rel) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x)
+    if (flags[i]) {
+      const uint32_t s = pos[i] - 1;
+      const uint64_t key = keys[i];
+      seg_feat[s] = (uint32_t)key;
+      seg_rel[s] = (uint32_t)(i - row_ptr[(uint64_t)(key >> 32) * B]);   // offset inside the batch's entries
+    }
+}
+__global__ void __launch_bounds__(256)
+k_seg_batches(const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t nseg, const uint64_t* __restrict__ row_ptr,
+              uint32_t n_rows, uint32_t B, uint32_t n_batches, uint32_t* __restrict__ batch_seg) {
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= n_batches; b += gridDim.x * blockDim.x) {
+    const uint64_t r = min((uint64_t)b * B, (uint64_t)n_rows);
+    const uint64_t p = row_ptr[r];
+    batch_seg[b] = (p < nnz) ? pos[p] - 1 : nseg;
+  }
+}
+
+template <int KP, int UNR>
+__global__ void __launch_bounds__(256)
+k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
+            uint32_t nseg, uint32_t batch_nnz, float* __restrict__ V, float* __restrict__ w, Hyper h,
+            const float* __restrict__ S, const float* __restrict__ mult) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t sg0 = wave0 * (EPI * UNR); sg0 < nseg; sg0 += nwaves * (EPI * UNR)) {
+    uint32_t j[UNR], a[UNR], b[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {                       // segment descriptors
+      const uint32_t s = sg0 + u * EPI + g;
+      ok[u] = s < nseg;
+      j[u] = 0; a[u] = 0; b[u] = 0;
+      if (ok[u]) {
+        j[u] = seg_feat[s];
+        a[u] = seg_rel[s];
+        b[u] = (s + 1 < nseg) ? seg_rel[s + 1] : batch_nnz;
+      }
+    }
+    float v0[UNR][VEC]; TEntry te[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {                       // owned V rows + first occurrence
+      te[u].e = 0; te[u].x = 0.f;
+      if (ok[u]) {
+        load_vec<VEC>(V + (size_t)j[u] * KP + f * VEC, v0[u]);
+        te[u] = t_ent[a[u]];
+      }
+    }
+    float m[UNR]; float sef[UNR][VEC];
+#pragma unroll
+    for (int u = 0; u < UNR; u++)
+      if (ok[u]) {
+        m[u] = mult[te[u].e];
+        load_vec<VEC>(S + (size_t)te[u].e * KP + f * VEC, sef[u]);
+      }
+#pragma unroll
+    for (int u = 0; u < UNR; u++)
+      if (ok[u]) {
+        float G[VEC]; float A, Gw;
+        {
+          const float mx = m[u] * te[u].x;
+#pragma unroll
+          for (int v = 0; v < VEC; v++) G[v] = mx * sef[u][v];
+          A = mx * te[u].x; Gw = mx;
+        }
+        for (uint32_t i = a[u] + 1; i < b[u]; i++) {      // further occurrences of the feature in this batch
+          const TEntry t2 = t_ent[i];
+          const float mx = mult[t2.e] * t2.x;
+          float s2[VEC];
+          load_vec<VEC>(S + (size_t)t2.e * KP + f * VEC, s2);
+#pragma unroll
+          for (int v = 0; v < VEC; v++) G[v] = fmaf(mx, s2[v], G[v]);
+          A = fmaf(mx, t2.x, A); Gw += mx;
+        }
+        const float nocc = (float)(b[u] - a[u]);
+        float nv[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const float vv = v0[u][v];
+          nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
+        }
+        store_vec<VEC>(V + (size_t)j[u] * KP + f * VEC, nv);
+        if (h.k1 && f == 0) {
+          const float wv = w[j[u]];
+          w[j[u]] = wv - h.lr * (Gw + nocc * h.regw * wv);
+        }
+      }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // k_fused: HOGWILD mode.  One wavefront per example, ONE pass over HBM: the gathered V rows stay in
 // registers (ZR row-slots x VEC floats per lane), the prediction, multiplier and fm_SGD update are
 // computed in-register and the rows are written straight back.  V is read once and written once --
-// the algorithmic minimum of a training step.  Rows longer than ZR*EPI take the
-// two-pass path (row_sums + row_apply; the second read is an L2 hit).
-// w0: each wavefront reads the current w0, accumulates its own delta and publishes it with one fp64
-// atomic every FLUSH examples.
+// the algorithmic minimum of a training step.  Rows longer than ZR*EPI (or 64)
+// take the two-pass path (row_sums + row_apply; the second read is an L2 hit).
+// w0 is FROZEN for the launch (one macro-batch): a per-example read-modify-write of one scalar from
+// ~6000 resident wavefronts is a single-address hot spot and, worse, an unstable recurrence at that
+// staleness.  The kernel writes rest_e = y-hat_e - w0 and k_scan advances w0 afterwards with the exact
+// micro-chunk recurrence (fm_sgd.h:34-37), see DESIGN.md section 3.
 // ----------------------------------------------------------------------------------------------
 template <int KP, int ZR, bool ATOMIC>
 __global__ void __launch_bounds__(256)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
         uint64_t row0, uint32_t n_rows, float* __restrict__ V, float* __restrict__ w, Hyper h,
-        double* __restrict__ w0_ptr) {
+        const double* __restrict__ w0_ptr, float* __restrict__ rest_out) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
-  constexpr int FLUSH = 8;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  double w0_pending = 0.0;
-  int since_flush = 0;
+  const float w0s = h.k0 ? (float)(*w0_ptr) : 0.f;
   for (uint32_t e = wave0; e < n_rows; e += nwaves) {
     const uint64_t a = row_ptr[row0 + e];
     const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
     const Entry* __restrict__ row = ent + a;
     const float y = target[row0 + e];
-    const float w0s = h.k0 ? (float)(__hip_atomic_load(w0_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + w0_pending) : 0.f;
-    float mult;
     if (size <= (uint32_t)(ZR * EPI) && size <= 64u) {
       Entry en; en.id = 0; en.value = 0.f;
       float wv = 0.f;
@@ -369,8 +541,9 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
 #pragma unroll
         for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
       }
-      const float p = w0s + wave_sum(part);
-      mult = multiplier(h, p, y);
+      const float rest = wave_sum_dpp(part);
+      if (lane == 0) rest_out[e] = rest;
+      const float mult = multiplier(h, w0s + rest, y);
       if (h.k1 && lane < size) {                             // fm_sgd.h:38-43
         const float dw = -h.lr * (mult * en.value + h.regw * wv);
         if (ATOMIC) unsafeAtomicAdd(w + en.id, dw); else w[en.id] = wv + dw;
@@ -404,19 +577,12 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
 #pragma unroll
         for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
       }
-      const float p = w0s + wave_sum(part);
-      mult = multiplier(h, p, y);
+      const float rest = wave_sum_dpp(part);
+      if (lane == 0) rest_out[e] = rest;
+      const float mult = multiplier(h, w0s + rest, y);
       row_apply<KP, 8, ATOMIC>(row, size, V, w, h, sum, mult);
     }
-    if (h.k0) {                                              // fm_sgd.h:34-37
-      w0_pending -= (double)h.lr * ((double)mult + (double)h.reg0 * (double)w0s);
-      if (++since_flush == FLUSH) {
-        if (lane == 0) unsafeAtomicAdd(w0_ptr, w0_pending);
-        w0_pending = 0.0; since_flush = 0;
-      }
-    }
   }
-  if (h.k0 && since_flush && lane == 0) unsafeAtomicAdd(w0_ptr, w0_pending);
 }
 
 // ----------------------------------------------------------------------------------------------

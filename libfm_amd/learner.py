@@ -65,10 +65,11 @@ class FMLearnSGD:
 
     Public knobs are plain fields set by the driver, like libfm.cpp:271-309, 387-403 does by direct writes:
     fm, min_target, max_target, task, num_iter, learn_rate.  GPU-only knobs: mode ('sequential' | 'minibatch' |
-    'hogwild'), batch, w0_chunk, apply ('atomic' | 'store'), device."""
+    'hogwild'), batch, w0_chunk, apply ('default' | 'segmented' | 'atomic' | 'store'), device."""
 
     MODES = {"sequential": capi.SGD_SEQUENTIAL, "minibatch": capi.SGD_MINIBATCH, "hogwild": capi.SGD_HOGWILD}
-    APPLY = {"atomic": capi.APPLY_ATOMIC, "store": capi.APPLY_STORE}
+    APPLY = {"default": capi.APPLY_DEFAULT, "atomic": capi.APPLY_ATOMIC, "store": capi.APPLY_STORE,
+             "segmented": capi.APPLY_SEGMENTED}
 
     def __init__(self):
         self.fm = None
@@ -80,7 +81,7 @@ class FMLearnSGD:
         self.mode = "minibatch"
         self.batch = 0
         self.w0_chunk = 0
-        self.apply = "atomic"
+        self.apply = "default"
         self.device = -1
         self.log = []                                           # one dict per iteration (rlog fields)
         self.out = sys.stdout

@@ -130,7 +130,7 @@ def test_minibatch_matches_restated_rule(capi, oracle, name, batch, chunk):
     h.set_params(m.w0, m.w, m.v)
     upload(h, 0, tr)
     for _ in range(g.iters):
-        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_ATOMIC, batch, chunk)
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, chunk)
         oracle.sgd_epoch_minibatch(m, tr, g.task, g.lr, g.min_target, g.max_target, batch, chunk)
     w0, w, v = h.get_params()
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
@@ -178,19 +178,28 @@ def test_hogwild_and_store_are_exact_without_collisions(capi, oracle, k, nnz, ap
         h.close()
 
 
-def test_hogwild_converges_like_the_reference(capi, oracle):
-    """asynchronous mode is not trajectory-identical; hold it to the reference's final metric."""
-    g = Golden("sgd_reg_ml")
-    m = g.model(oracle, "init")
-    tr = g.data(oracle, "train")
-    h = make_handle(capi, g)
+@pytest.mark.parametrize("apply", ["atomic", "store"])
+def test_hogwild_converges_like_the_reference(capi, oracle, apply):
+    """asynchronous mode is not trajectory-identical (features shared by in-flight rows race); hold it to the
+    online reference loop's metric on an ML-shaped problem with a bias, 5 epochs."""
+    nu, ni, rows = 3000, 2000, 30000
+    ent, rp, y = datagen.movielens_shaped(nu, ni, rows, seed=5)
+    d = oracle.Data(ent, rp, y)
+    n, k, lr = nu + ni, 8, 0.01
+    m = oracle.Model(n, k, True, True, 0.0, 0.0, 0.01)
+    m.v[:] = oracle.init_values(3, n, k, 0.1)
+    lo, hi = float(y.min()), float(y.max())
+    h = capi.Handle(n, k, True, True, 0, 0.0, 0.0, 0.01, lr, lo, hi)
     h.set_params(m.w0, m.w, m.v)
-    upload(h, 0, tr)
-    for _ in range(g.iters):
-        h.sgd_epoch(0, capi.SGD_HOGWILD, capi.APPLY_ATOMIC)
+    h.upload_rows(0, ent, rp, y)
+    ap = capi.APPLY_ATOMIC if apply == "atomic" else capi.APPLY_STORE
+    for _ in range(5):
+        h.sgd_epoch(0, capi.SGD_HOGWILD, ap, 512, 16)
+        oracle.sgd_epoch_online(m, d, 0, lr, lo, hi)
     rmse = h.evaluate(0).rmse
-    ref = float(g.z["eval"][-1, 0])
-    assert abs(rmse - ref) < 0.05 * ref
+    ref, _ = oracle.evaluate(m, d, 0, lo, hi)
+    assert abs(rmse - ref) < 0.03 * ref
+    assert abs(h.get_w0() - m.w0) < 0.05 * abs(m.w0) + 0.02
     h.close()
 
 
@@ -219,7 +228,7 @@ def test_odd_k_and_long_rows(capi, oracle, k):
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
     if k:
         np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
-    h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_ATOMIC, 16, 4)
+    h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 16, 4)
     oracle.sgd_epoch_minibatch(m, d, 0, 0.002, lo, hi, 16, 4)
     w0, w, v = h.get_params()
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
@@ -286,9 +295,9 @@ def test_sharded_partials_sum_to_unsharded(capi, oracle):
             tot = bufs[0] + bufs[1]                       # what the RCCL all-reduce computes
             torch.cuda.synchronize()
             for s in shards:
-                s.sgd_finish(0, row0, nb, tot.data_ptr(), w0_chunk=16)
+                s.sgd_finish(0, row0, nb, tot.data_ptr(), w0_chunk=16, batch=B)
                 s.synchronize()
-        full.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_ATOMIC, B, 16)
+        full.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, B, 16)
     w0f, wf, vf = full.get_params()
     w = np.zeros_like(wf)
     v = np.zeros_like(vf)
