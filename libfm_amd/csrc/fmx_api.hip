@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace fmx;
@@ -48,9 +49,12 @@ struct fmx_context_s {
   uint64_t   n_local = 0;
   int        device = 0;
   hipStream_t stream = nullptr;
-  float*     V = nullptr;
-  float*     w = nullptr;
+  Tab        tb = {nullptr, nullptr, 0, 0};   // V rows (+ co-located w), see fmx_kernels.h
+  float*     w_sep = nullptr;    // separate w[] array (only when FMX_WPAD=0)
   double*    w0 = nullptr;       // device scalar
+  double*    w0_pp = nullptr;    // 2 doubles: ping-pong copies of w0 for the overlapped hogwild bias scan
+  hipStream_t stream2 = nullptr; // side stream of the hogwild bias scan
+  int        num_cu = 256;
   double*    acc = nullptr;      // 4 doubles of reduction scratch
   Slot       slots[FMX_MAX_SLOTS];
   float*     partial = nullptr;  // [cap][KP] + [cap]
@@ -59,6 +63,7 @@ struct fmx_context_s {
   size_t     cap = 0, cap_rest = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> ev_sync;   // untimed events ordering the two hogwild streams
   std::string err;
   hipDeviceProp_t prop;
 };
@@ -102,6 +107,33 @@ inline uint32_t wave_grid(uint64_t n_waves_wanted) {
   if (blocks > 256 * 8) blocks = 256 * 8;
   return (uint32_t)blocks;
 }
+
+// persistent sizing: never launch more workgroups than can be resident (a second, partially filled round of
+// equally long grid-stride workgroups is pure tail), never more than the work needs.
+uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted) {
+  static std::unordered_map<const void*, int> cache;
+  auto it = cache.find(kernel);
+  int occ;
+  if (it == cache.end()) {
+    occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 4;
+    if (occ > 8) occ = 8;
+    cache[kernel] = occ;
+  } else {
+    occ = it->second;
+  }
+  uint64_t blocks = (n_waves_wanted + 3) / 4;
+  // over-subscribe: more (shorter) workgroups than can be resident let the dispatcher balance the tail;
+  // measured better than an exactly-resident persistent grid for these gather kernels
+  int over = 2;
+  if (const char* e = getenv("FMX_GRID_OVER")) over = atoi(e) > 0 ? atoi(e) : 1;
+  const uint64_t cap = (uint64_t)occ * (uint64_t)h->num_cu * (uint64_t)over;
+  if (blocks < 1) blocks = 1;
+  if (blocks > cap) blocks = cap;
+  return (uint32_t)blocks;
+}
+#define FMX_LAUNCH_WAVES(kfn, waves, st, ...)                                                        \
+  do { auto _k = kfn; hipLaunchKernelGGL(_k, dim3(resident_grid(h, (const void*)_k, (waves))), dim3(256), 0, st, __VA_ARGS__); } while (0)
 
 #define KP_SWITCH(KPV, ...)                                            \
   switch (KPV) {                                                       \
@@ -161,20 +193,20 @@ void free_slot(Slot& s) {
 
 // rest[e] (= y-hat - w0) for rows [row0,row0+n) of a slot, single device
 int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st) {
-  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rowsums<KP, false, true>), dim3(wave_grid(n)), dim3(256), 0, st,
-                                        s.ent, s.row_ptr, row0, n, h->V, h->w, h->cfg.k1, (float*)nullptr, rest));
+  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, false, true>), n, st,
+                                     s.ent, s.row_ptr, row0, n, h->tb, h->cfg.k1, (float*)nullptr, rest));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
 }
 
 template <int KP, bool ATOMIC>
-int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st) {
+int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
+                    const double* w0_in, float* rest_out) {
   constexpr int VEC = Map<KP>::VEC, EPI = Map<KP>::EPI;
   const uint32_t need = (s.max_row + EPI - 1) / EPI;      // row slots per lane to keep a whole row in registers
-  const dim3 grid(wave_grid(n_rows)), block(256);
 #define FMX_LAUNCH_ZR(ZRV)                                                                                  \
-  hipLaunchKernelGGL((k_fused<KP, ZRV, ATOMIC>), grid, block, 0, st, s.ent, s.row_ptr, s.target, row0, \
-                     n_rows, h->V, h->w, hy, h->w0, h->rest)
+  FMX_LAUNCH_WAVES((k_fused<KP, ZRV, ATOMIC>), n_rows, st, s.ent, s.row_ptr, s.target, row0, \
+                   n_rows, h->tb, hy, w0_in, rest_out)
   if constexpr (VEC * 8 <= 128) { if (need <= 8) { FMX_LAUNCH_ZR(8); return FMX_OK; } }
   if constexpr (VEC * 16 <= 128) { if (need <= 16) { FMX_LAUNCH_ZR(16); return FMX_OK; } }
   if constexpr (VEC * 32 <= 128) { if (need <= 32) { FMX_LAUNCH_ZR(32); return FMX_OK; } }
@@ -235,12 +267,29 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_CHK(hipEventCreate(&h->ev0));
   CREATE_CHK(hipEventCreate(&h->ev1));
-  CREATE_CHK(hipMalloc(&h->V, h->n_local * (size_t)h->KP * sizeof(float)));
-  CREATE_CHK(hipMalloc(&h->w, h->n_local * sizeof(float)));
+  {
+    // row layout: default = separate w[] array (FMX_WPAD=0).  FMX_WPAD=<floats> co-locates w behind the factors
+    // ([KP factors | w | padding]); measured on MI355X it does NOT pay: HBM fetches 64-B sectors, so a 4-B w
+    // costs one sector wherever it lives, and the unaligned rows cost more.
+    int wpad = 0;
+    if (const char* e = getenv("FMX_WPAD")) wpad = atoi(e);
+    if (wpad < 0 || (wpad % 4) != 0) wpad = 0;
+    h->tb.rs = (uint32_t)(h->KP + wpad);
+    CREATE_CHK(hipMalloc(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float)));
+    CREATE_CHK(hipMemsetAsync(h->tb.V, 0, h->n_local * (size_t)h->tb.rs * sizeof(float), h->stream));
+    if (wpad == 0) {
+      CREATE_CHK(hipMalloc(&h->w_sep, h->n_local * sizeof(float)));
+      CREATE_CHK(hipMemsetAsync(h->w_sep, 0, h->n_local * sizeof(float), h->stream));
+      h->tb.w = h->w_sep; h->tb.ws = 1;
+    } else {
+      h->tb.w = h->tb.V + h->KP; h->tb.ws = h->tb.rs;
+    }
+  }
   CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
+  CREATE_CHK(hipMalloc(&h->w0_pp, 2 * sizeof(double)));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  h->num_cu = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
   CREATE_CHK(hipMalloc(&h->acc, 4 * sizeof(double)));
-  CREATE_CHK(hipMemsetAsync(h->V, 0, h->n_local * (size_t)h->KP * sizeof(float), h->stream));
-  CREATE_CHK(hipMemsetAsync(h->w, 0, h->n_local * sizeof(float), h->stream));
   CREATE_CHK(hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
   CREATE_CHK(hipStreamSynchronize(h->stream));
 #undef CREATE_CHK
@@ -253,14 +302,17 @@ int fmx_destroy(fmx_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (auto& s : h->slots) free_slot(s);
-  if (h->V) hipFree(h->V);
-  if (h->w) hipFree(h->w);
+  if (h->tb.V) hipFree(h->tb.V);
+  if (h->w_sep) hipFree(h->w_sep);
   if (h->w0) hipFree(h->w0);
+  if (h->w0_pp) hipFree(h->w0_pp);
+  if (h->stream2) hipStreamDestroy(h->stream2);
   if (h->acc) hipFree(h->acc);
   if (h->partial) hipFree(h->partial);
   if (h->mult) hipFree(h->mult);
   if (h->rest) hipFree(h->rest);
   for (auto ev : h->ev_pool) hipEventDestroy(ev);
+  for (auto ev : h->ev_sync) hipEventDestroy(ev);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -274,7 +326,7 @@ int fmx_get_info(fmx_handle h, fmx_info* out) {
   out->n_local = h->n_local;
   out->k_padded = h->KP;
   out->device = h->device;
-  out->bytes_params = h->n_local * (size_t)(h->KP + 1) * sizeof(float);
+  out->bytes_params = h->n_local * (size_t)(h->tb.rs + (h->w_sep ? 1 : 0)) * sizeof(float);
   snprintf(out->device_name, sizeof(out->device_name), "%s", h->prop.name);
   snprintf(out->arch, sizeof(out->arch), "%s", h->prop.gcnArchName);
   return FMX_OK;
@@ -311,10 +363,10 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
     if (w) {
       if (to_device) {
         STAGE_CHK(hipMemcpyAsync(stage, w + j0, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_w_in, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->w);
+        hipLaunchKernelGGL(k_w_in, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->tb);
       } else {
         if (W > 1) STAGE_CHK(hipMemcpyAsync(stage, w + j0, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_w_out, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->w);
+        hipLaunchKernelGGL(k_w_out, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->tb);
         STAGE_CHK(hipMemcpyAsync(w + j0, stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       }
       STAGE_CHK(hipStreamSynchronize(h->stream));
@@ -326,7 +378,7 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
                                    hipMemcpyHostToDevice, h->stream));
         const uint64_t total = (uint64_t)cnt * KP;
         hipLaunchKernelGGL(k_stage_in, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream,
-                           stage, j0, cnt, k, KP, R, W, h->V);
+                           stage, j0, cnt, k, KP, R, W, h->tb);
       } else {
         if (W > 1)
           for (int f = 0; f < k; f++)
@@ -334,7 +386,7 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
                                      hipMemcpyHostToDevice, h->stream));
         const uint64_t total = (uint64_t)cnt * k;
         hipLaunchKernelGGL(k_stage_out, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream,
-                           stage, j0, cnt, k, KP, R, W, h->V);
+                           stage, j0, cnt, k, KP, R, W, h->tb);
         for (int f = 0; f < k; f++)
           STAGE_CHK(hipMemcpyAsync(v + (size_t)f * n + j0, stage + (size_t)f * cnt, cnt * sizeof(double),
                                    hipMemcpyDeviceToHost, h->stream));
@@ -373,7 +425,7 @@ int fmx_get_w0(fmx_handle h, double* w0) {
 int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t seed) {
   if (!h) return FMX_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(k_init_params, dim3(256 * 8), dim3(256), 0, h->stream, h->V, h->w, h->n_local,
+  hipLaunchKernelGGL(k_init_params, dim3(256 * 8), dim3(256), 0, h->stream, h->tb, h->n_local,
                      h->cfg.num_factor, h->KP, h->cfg.shard_rank, h->cfg.shard_world, (float)init_mean, init_stdev, seed);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
@@ -583,8 +635,8 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   float* S = d_partial;
   float* c = d_partial + (size_t)n_rows * h->KP;
-  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rowsums<KP, true, false>), dim3(wave_grid(n_rows)), dim3(256), 0, st,
-                                        s.ent, s.row_ptr, row0, n_rows, h->V, h->w, h->cfg.k1, S, c));
+  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st,
+                                     s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
 }
@@ -662,9 +714,10 @@ done:
 }
 
 static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
-                       const Hyper& hy, float* mult, hipStream_t st) {
+                       const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr) {
   if (hy.k0) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, rest, target, n_rows, chunk, hy, h->w0, mult);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, rest, target, n_rows, chunk, hy,
+                       w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
   } else if (mult) {
     hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy, mult);
   }
@@ -691,16 +744,15 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
     const uint32_t bnnz = (uint32_t)(s.batch_base[(size_t)seg_batch + 1] - base);
     const uint32_t nseg = s1 - s0;
     if (nseg) {
-      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply_seg<KP, 4>), dim3(wave_grid(((uint64_t)nseg + Map<KP>::EPI * 4 - 1) / (Map<KP>::EPI * 4))),
-                                          dim3(256), 0, st, s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nseg, bnnz,
-                                          h->V, h->w, hy, S, h->mult));
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)nseg + 63) / 64, st,
+                                         s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nseg, bnnz, h->tb, hy, S, h->mult));
     }
   } else if (apply == FMX_APPLY_ATOMIC) {
-    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply<KP, true>), dim3(wave_grid(n_rows)), dim3(256), 0, st,
-                                          s.ent, s.row_ptr, row0, n_rows, h->V, h->w, hy, S, h->mult));
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, true>), n_rows, st,
+                                       s.ent, s.row_ptr, row0, n_rows, h->tb, hy, S, h->mult));
   } else if (apply == FMX_APPLY_STORE) {
-    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply<KP, false>), dim3(wave_grid(n_rows)), dim3(256), 0, st,
-                                          s.ent, s.row_ptr, row0, n_rows, h->V, h->w, hy, S, h->mult));
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, false>), n_rows, st,
+                                       s.ent, s.row_ptr, row0, n_rows, h->tb, hy, S, h->mult));
   } else {
     return fail(h, FMX_E_ARG, "unknown apply mode %d", apply);
   }
@@ -781,31 +833,48 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   if (opts->mode == FMX_SGD_SEQUENTIAL) {
     KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr,
-                                          s.target, s.n_rows, h->V, h->w, hy, h->w0));
+                                          s.target, s.n_rows, h->tb, hy, h->w0));
     HIPCHK(h, hipGetLastError());
     batches = s.n_rows; main_launches = 1;
   } else if (opts->mode == FMX_SGD_HOGWILD) {
     if (opts->apply == FMX_APPLY_SEGMENTED) return fail(h, FMX_E_ARG, "HOGWILD has no segmented apply");
-    const uint32_t M = opts->batch ? opts->batch : 262144u;       // rows per launch; w0 frozen inside
+    // rows per launch M: w0 is frozen inside a launch.  The bias recurrence of launch i (k_scan, one CU) runs
+    // on a side stream WHILE launch i+1 streams; launch i reads the w0 produced by scan i-2 (ping-pong slots,
+    // so the result does not depend on timing).
+    const uint32_t M = opts->batch ? opts->batch : 262144u;
     const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : 256u;
-    rc = ensure_scratch(h, 0, std::min<uint32_t>(M, s.n_rows));
+    const uint32_t cap = std::min<uint32_t>(M, s.n_rows);
+    rc = ensure_scratch(h, 0, (size_t)cap * 2);
     if (rc) return rc;
-    for (uint64_t row0 = 0; row0 < s.n_rows; row0 += M) {
+    const uint64_t n_launch = ((uint64_t)s.n_rows + M - 1) / M;
+    while (h->ev_sync.size() < 2 * n_launch) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+    HIPCHK(h, hipMemcpyAsync(h->w0_pp, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->w0_pp + 1, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    for (uint64_t i = 0; i < n_launch; i++) {
+      const uint64_t row0 = i * M;
       const uint32_t nb = (uint32_t)std::min<uint64_t>(M, s.n_rows - row0);
+      float* rest = h->rest + (size_t)(i & 1) * cap;
+      if (i >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync[2 * (i - 2) + 1], 0));   // scan i-2 done
       hipEvent_t ea = nullptr, eb = nullptr;
       if (timed) { HIPCHK(h, get_event(&ea)); HIPCHK(h, get_event(&eb)); main_launches++; HIPCHK(h, hipEventRecord(ea, h->stream)); }
+      const double* w0_in = h->w0_pp + ((i + 1) & 1);      // slot written by scan i-2 (initial value for i < 2)
       if (opts->apply == FMX_APPLY_ATOMIC) {
-        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, row0, nb, h->stream); });
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, row0, nb, h->stream, w0_in, rest); });
       } else {
-        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, row0, nb, h->stream); });
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, row0, nb, h->stream, w0_in, rest); });
       }
       if (rc) return rc;
       if (timed) HIPCHK(h, hipEventRecord(eb, h->stream));
       HIPCHK(h, hipGetLastError());
-      rc = launch_scan(h, h->rest, s.target + row0, nb, chunk, hy, nullptr, h->stream);   // advances w0 only
+      HIPCHK(h, hipEventRecord(h->ev_sync[2 * i], h->stream));
+      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * i], 0));
+      rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (i & 1), h->w0_pp + ((i + 1) & 1));
       if (rc) return rc;
+      HIPCHK(h, hipEventRecord(h->ev_sync[2 * i + 1], h->stream2));
       batches++;
     }
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync[2 * (n_launch - 1) + 1], 0));
+    if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_launch & 1), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
     const uint32_t B = opts->batch ? opts->batch : 16384u;
     rc = ensure_scratch(h, std::min<uint32_t>(B, s.n_rows), 0);
@@ -820,8 +889,8 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
       const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
       float* S = h->partial;
       float* rest = h->partial + (size_t)nb * h->KP;
-      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rowsums<KP, true, true>), dim3(wave_grid(nb)), dim3(256), 0, h->stream,
-                                            s.ent, s.row_ptr, row0, nb, h->V, h->w, h->cfg.k1, S, rest));
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, h->stream,
+                                         s.ent, s.row_ptr, row0, nb, h->tb, h->cfg.k1, S, rest));
       hipEvent_t ea = nullptr, eb = nullptr;
       if (timed) { HIPCHK(h, get_event(&ea)); HIPCHK(h, get_event(&eb)); main_launches++; }
       rc = sgd_finish_impl(h, s, row0, nb, S, rest, opts, h->stream, ea, eb, segmented ? (int64_t)(row0 / B) : -1);

@@ -31,6 +31,11 @@ template <int KP> struct Map {
   static constexpr int EPI = 64 / LPR;
 };
 
+// parameter table: V rows of `rs` floats (rs >= KP); w(j) lives at w[j*ws].  In the co-located layout
+// w = V + KP and ws = rs: the linear weight sits in the same DRAM page as its factor row, so one feature
+// costs ONE row activation instead of two (measured: the separate w[] gather cost 35-50 % of the step).
+struct Tab { float* V; float* w; uint32_t rs; uint32_t ws; };
+
 struct Hyper {            // per-launch scalars (fm_model.h:56-57, fm_learn_sgd.h:42, fm_learn.h:41-45)
   float lr, reg0, regw, regv;
   float min_target, max_target;
@@ -108,6 +113,17 @@ __device__ __forceinline__ float multiplier(const Hyper& h, float p, float y) {
   return -y * (1.0f - 1.0f / (1.0f + __expf(-y * p)));
 }
 
+// same multiplier with the hardware reciprocal (1 ulp) -- used on the serial w0 recurrence where the IEEE
+// division sequence sits on the critical path
+__device__ __forceinline__ float multiplier_fast(const Hyper& h, float p, float y) {
+  if (h.task == 0) {
+    p = fminf(h.max_target, p);
+    p = fmaxf(h.min_target, p);
+    return -(y - p);
+  }
+  return -y * (1.0f - __builtin_amdgcn_rcpf(1.0f + __expf(-y * p)));
+}
+
 // ----------------------------------------------------------------------------------------------
 // pass 1 of a row: the sums of fm_model.h:110-125.
 //   sum[v]  : sum_f for the lane's factors (complete over the row only AFTER subgroup_allsum when EPI>1)
@@ -116,7 +132,7 @@ __device__ __forceinline__ float multiplier(const Hyper& h, float p, float y) {
 // ----------------------------------------------------------------------------------------------
 template <int KP, int U>
 __device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t size,
-                                         const float* __restrict__ V, const float* __restrict__ w, int k1,
+                                         const Tab tb, int k1,
                                          float (&sum)[Map<KP>::VEC], float& sq, float& lin) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u;
@@ -129,7 +145,7 @@ __device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t
     Entry e; e.id = 0; e.value = 0.f;
     if (lane < cnt) {
       e = ent[base + lane];
-      if (k1) lin += w[e.id] * e.value;
+      if (k1) lin += tb.w[(size_t)e.id * tb.ws] * e.value;
     }
     for (uint32_t i = 0; i < cnt; i += EPI * U) {
       float vr[U][VEC]; float xs[U];
@@ -139,7 +155,7 @@ __device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t
         const uint32_t id = bcast_u32<EPI>(e.id, idx & 63u);
         xs[u] = bcast_f32<EPI>(e.value, idx & 63u);
         if (idx < cnt) {
-          load_vec<VEC>(V + (size_t)id * KP + f * VEC, vr[u]);
+          load_vec<VEC>(tb.V + (size_t)id * tb.rs + f * VEC, vr[u]);
         } else {
           xs[u] = 0.f;
 #pragma unroll
@@ -162,7 +178,7 @@ __device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t
 //   ATOMIC: scatter-add of the delta (fp32 atomics execute at L2); else read-modify-write store.
 template <int KP, int U, bool ATOMIC>
 __device__ __forceinline__ void row_apply(const Entry* __restrict__ ent, uint32_t size,
-                                          float* __restrict__ V, float* __restrict__ w, const Hyper& h,
+                                          const Tab tb, const Hyper& h,
                                           const float (&sum)[Map<KP>::VEC], float mult) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u;
@@ -173,9 +189,9 @@ __device__ __forceinline__ void row_apply(const Entry* __restrict__ ent, uint32_
     if (lane < cnt) {
       e = ent[base + lane];
       if (h.k1) {                                           // fm_sgd.h:38-43
-        const float wv = w[e.id];
+        const float wv = tb.w[(size_t)e.id * tb.ws];
         const float dw = -h.lr * (mult * e.value + h.regw * wv);
-        if (ATOMIC) unsafeAtomicAdd(w + e.id, dw); else w[e.id] = wv + dw;
+        if (ATOMIC) unsafeAtomicAdd(tb.w + (size_t)e.id * tb.ws, dw); else tb.w[(size_t)e.id * tb.ws] = wv + dw;
       }
     }
     for (uint32_t i = 0; i < cnt; i += EPI * U) {
@@ -185,13 +201,13 @@ __device__ __forceinline__ void row_apply(const Entry* __restrict__ ent, uint32_
         const uint32_t idx = i + u * EPI + g;
         ids[u] = bcast_u32<EPI>(e.id, idx & 63u);
         xs[u] = bcast_f32<EPI>(e.value, idx & 63u);
-        if (idx < cnt) load_vec<VEC>(V + (size_t)ids[u] * KP + f * VEC, vr[u]);
+        if (idx < cnt) load_vec<VEC>(tb.V + (size_t)ids[u] * tb.rs + f * VEC, vr[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const uint32_t idx = i + u * EPI + g;
         if (idx < cnt) {
-          float* p = V + (size_t)ids[u] * KP + f * VEC;
+          float* p = tb.V + (size_t)ids[u] * tb.rs + f * VEC;
           const float x = xs[u];
           float nv[VEC];
 #pragma unroll
@@ -218,7 +234,7 @@ __device__ __forceinline__ void row_apply(const Entry* __restrict__ ent, uint32_
 template <int KP, bool WRITE_S, bool FINISH>
 __global__ void __launch_bounds__(256)
 k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t n_rows,
-          const float* __restrict__ V, const float* __restrict__ w, int k1,
+          const Tab tb, int k1,
           float* __restrict__ S, float* __restrict__ scal) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x & 63u;
@@ -228,7 +244,7 @@ k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, u
     const uint64_t a = row_ptr[row0 + e];
     const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
     float sum[VEC], sq, lin;
-    row_sums<KP, 8>(ent + a, size, V, w, k1, sum, sq, lin);
+    row_sums<KP, 8>(ent + a, size, tb, k1, sum, sq, lin);
 #pragma unroll
     for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
     if (WRITE_S && lane < LPR) store_vec<VEC>(S + (size_t)e * KP + lane * VEC, sum);
@@ -276,12 +292,12 @@ k_rest_from_partial(const float* __restrict__ S, const float* __restrict__ c, ui
 constexpr int SCAN_TILE = 8192;
 __global__ void __launch_bounds__(1024)
 k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
-       Hyper h, double* __restrict__ w0_ptr, float* __restrict__ mult) {
+       Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
   __shared__ float s_rest[SCAN_TILE];
   __shared__ float s_y[SCAN_TILE];
   __shared__ float s_m[SCAN_TILE];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  double w0 = *w0_ptr;
+  double w0 = *w0_in;
   uint32_t chunk_pos = 0;
   float acc = 0.f;
   for (uint32_t t0 = 0; t0 < n_rows; t0 += SCAN_TILE) {
@@ -293,8 +309,18 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
       while (i < tn) {
         const uint32_t take = min(chunk - chunk_pos, tn - i);
         const float w0s = h.k0 ? (float)w0 : 0.f;
-        for (uint32_t t = lane; t < take; t += 64) {
-          const float m = multiplier(h, w0s + s_rest[i + t], s_y[i + t]);
+        uint32_t t = 0;
+        for (; t + 256 <= take; t += 256) {                   // 4 independent elements per lane: LDS reads overlap
+          const uint32_t q = i + t + lane;
+          const float r0 = s_rest[q], r1 = s_rest[q + 64], r2 = s_rest[q + 128], r3 = s_rest[q + 192];
+          const float y0 = s_y[q], y1 = s_y[q + 64], y2 = s_y[q + 128], y3 = s_y[q + 192];
+          const float m0 = multiplier_fast(h, w0s + r0, y0), m1 = multiplier_fast(h, w0s + r1, y1);
+          const float m2 = multiplier_fast(h, w0s + r2, y2), m3 = multiplier_fast(h, w0s + r3, y3);
+          s_m[q] = m0; s_m[q + 64] = m1; s_m[q + 128] = m2; s_m[q + 192] = m3;
+          acc += (m0 + m1) + (m2 + m3);
+        }
+        for (t += lane; t < take; t += 64) {
+          const float m = multiplier_fast(h, w0s + s_rest[i + t], s_y[i + t]);
           s_m[i + t] = m;
           acc += m;
         }
@@ -310,7 +336,7 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
     if (mult) for (uint32_t i = tid; i < tn; i += 1024) mult[t0 + i] = s_m[i];
     __syncthreads();
   }
-  if (tid == 0) *w0_ptr = w0;
+  if (tid == 0) *w0_out = w0;
 }
 
 // no bias: the multipliers are independent of each other
@@ -326,7 +352,7 @@ k_mult(const float* __restrict__ rest, const float* __restrict__ target, uint32_
 template <int KP, bool ATOMIC>
 __global__ void __launch_bounds__(256)
 k_apply(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t n_rows,
-        float* __restrict__ V, float* __restrict__ w, Hyper h,
+        const Tab tb, Hyper h,
         const float* __restrict__ S, const float* __restrict__ mult) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x & 63u, f = lane % LPR;
@@ -338,7 +364,7 @@ k_apply(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uin
     float sum[VEC];
     load_vec<VEC>(S + (size_t)e * KP + f * VEC, sum);
     const float m = mult[e];
-    row_apply<KP, 8, ATOMIC>(ent + a, size, V, w, h, sum, m);
+    row_apply<KP, 8, ATOMIC>(ent + a, size, tb, h, sum, m);
   }
 }
 
@@ -398,77 +424,81 @@ k_seg_batches(const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t nseg, con
   }
 }
 
-template <int KP, int UNR>
+// One wavefront owns blocks of 64 consecutive segments: the descriptors, first occurrences and their
+// multipliers are fetched lane-parallel (coalesced), then U segment groups at a time are broadcast and their
+// V rows + S rows gathered together (2*U row loads in flight per wavefront).
+template <int KP, int U>
 __global__ void __launch_bounds__(256)
 k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
-            uint32_t nseg, uint32_t batch_nnz, float* __restrict__ V, float* __restrict__ w, Hyper h,
+            uint32_t nseg, uint32_t batch_nnz, const Tab tb, Hyper h,
             const float* __restrict__ S, const float* __restrict__ mult) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t sg0 = wave0 * (EPI * UNR); sg0 < nseg; sg0 += nwaves * (EPI * UNR)) {
-    uint32_t j[UNR], a[UNR], b[UNR];
-    bool ok[UNR];
+  for (uint32_t blk = wave0 * 64u; blk < nseg; blk += nwaves * 64u) {
+    const uint32_t cnt = min(64u, nseg - blk);
+    uint32_t jl = 0, al = 0, bl = 0, el = 0; float xl = 0.f, ml = 0.f;
+    if (lane < cnt) {
+      const uint32_t s = blk + lane;
+      jl = seg_feat[s];
+      al = seg_rel[s];
+      bl = (s + 1 < nseg) ? seg_rel[s + 1] : batch_nnz;
+      const TEntry te = t_ent[al];
+      el = te.e; xl = te.x;
+      ml = mult[el];
+    }
+    for (uint32_t i = 0; i < cnt; i += EPI * U) {
+      float v0[U][VEC], sf[U][VEC];
 #pragma unroll
-    for (int u = 0; u < UNR; u++) {                       // segment descriptors
-      const uint32_t s = sg0 + u * EPI + g;
-      ok[u] = s < nseg;
-      j[u] = 0; a[u] = 0; b[u] = 0;
-      if (ok[u]) {
-        j[u] = seg_feat[s];
-        a[u] = seg_rel[s];
-        b[u] = (s + 1 < nseg) ? seg_rel[s + 1] : batch_nnz;
+      for (int u = 0; u < U; u++) {
+        const uint32_t idx = i + u * EPI + g;
+        const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
+        const uint32_t e = bcast_u32<EPI>(el, idx & 63u);
+        if (idx < cnt) {
+          load_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, v0[u]);
+          load_vec<VEC>(S + (size_t)e * KP + f * VEC, sf[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t idx = i + u * EPI + g;
+        const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
+        const uint32_t a = bcast_u32<EPI>(al, idx & 63u);
+        const uint32_t b = bcast_u32<EPI>(bl, idx & 63u);
+        const float x = bcast_f32<EPI>(xl, idx & 63u);
+        const float m = bcast_f32<EPI>(ml, idx & 63u);
+        if (idx < cnt) {
+          float G[VEC]; float A, Gw;
+          const float mx = m * x;
+#pragma unroll
+          for (int v = 0; v < VEC; v++) G[v] = mx * sf[u][v];
+          A = mx * x; Gw = mx;
+          for (uint32_t i2 = a + 1; i2 < b; i2++) {             // further occurrences of the feature in this batch
+            const TEntry t2 = t_ent[i2];
+            const float mx2 = mult[t2.e] * t2.x;
+            float s2[VEC];
+            load_vec<VEC>(S + (size_t)t2.e * KP + f * VEC, s2);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[v], G[v]);
+            A = fmaf(mx2, t2.x, A); Gw += mx2;
+          }
+          const float nocc = (float)(b - a);
+          float nv[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const float vv = v0[u][v];
+            nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
+          }
+          store_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
+          if (h.k1 && f == 0) {
+            float* pw = tb.w + (size_t)j * tb.ws;
+            const float wv = *pw;
+            *pw = wv - h.lr * (Gw + nocc * h.regw * wv);
+          }
+        }
       }
     }
-    float v0[UNR][VEC]; TEntry te[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; u++) {                       // owned V rows + first occurrence
-      te[u].e = 0; te[u].x = 0.f;
-      if (ok[u]) {
-        load_vec<VEC>(V + (size_t)j[u] * KP + f * VEC, v0[u]);
-        te[u] = t_ent[a[u]];
-      }
-    }
-    float m[UNR]; float sef[UNR][VEC];
-#pragma unroll
-    for (int u = 0; u < UNR; u++)
-      if (ok[u]) {
-        m[u] = mult[te[u].e];
-        load_vec<VEC>(S + (size_t)te[u].e * KP + f * VEC, sef[u]);
-      }
-#pragma unroll
-    for (int u = 0; u < UNR; u++)
-      if (ok[u]) {
-        float G[VEC]; float A, Gw;
-        {
-          const float mx = m[u] * te[u].x;
-#pragma unroll
-          for (int v = 0; v < VEC; v++) G[v] = mx * sef[u][v];
-          A = mx * te[u].x; Gw = mx;
-        }
-        for (uint32_t i = a[u] + 1; i < b[u]; i++) {      // further occurrences of the feature in this batch
-          const TEntry t2 = t_ent[i];
-          const float mx = mult[t2.e] * t2.x;
-          float s2[VEC];
-          load_vec<VEC>(S + (size_t)t2.e * KP + f * VEC, s2);
-#pragma unroll
-          for (int v = 0; v < VEC; v++) G[v] = fmaf(mx, s2[v], G[v]);
-          A = fmaf(mx, t2.x, A); Gw += mx;
-        }
-        const float nocc = (float)(b[u] - a[u]);
-        float nv[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; v++) {
-          const float vv = v0[u][v];
-          nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
-        }
-        store_vec<VEC>(V + (size_t)j[u] * KP + f * VEC, nv);
-        if (h.k1 && f == 0) {
-          const float wv = w[j[u]];
-          w[j[u]] = wv - h.lr * (Gw + nocc * h.regw * wv);
-        }
-      }
   }
 }
 
@@ -486,7 +516,7 @@ k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_f
 template <int KP, int ZR, bool ATOMIC>
 __global__ void __launch_bounds__(256)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
-        uint64_t row0, uint32_t n_rows, float* __restrict__ V, float* __restrict__ w, Hyper h,
+        uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
@@ -503,7 +533,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       float wv = 0.f;
       if (lane < size) {
         en = row[lane];
-        if (h.k1) wv = w[en.id];
+        if (h.k1) wv = tb.w[(size_t)en.id * tb.ws];
       }
       // phase A: issue every gather of the row back-to-back (ids / values are re-broadcast later instead of
       // being kept: with EPI == 1 they are wave-uniform and live in SGPRs for the duration of one use)
@@ -513,7 +543,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         const uint32_t idx = t * EPI + g;
         const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
         if (idx < size) {
-          load_vec<VEC>(V + (size_t)id * KP + f * VEC, vr[t]);
+          load_vec<VEC>(tb.V + (size_t)id * tb.rs + f * VEC, vr[t]);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
@@ -546,7 +576,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       const float mult = multiplier(h, w0s + rest, y);
       if (h.k1 && lane < size) {                             // fm_sgd.h:38-43
         const float dw = -h.lr * (mult * en.value + h.regw * wv);
-        if (ATOMIC) unsafeAtomicAdd(w + en.id, dw); else w[en.id] = wv + dw;
+        if (ATOMIC) unsafeAtomicAdd(tb.w + (size_t)en.id * tb.ws, dw); else tb.w[(size_t)en.id * tb.ws] = wv + dw;
       }
       // phase C: fm_sgd.h:44-50 on the register-resident rows, written straight back
 #pragma unroll
@@ -555,7 +585,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         if (idx < size) {
           const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
           const float x = bcast_f32<EPI>(en.value, idx & 63u);
-          float* pv = V + (size_t)id * KP + f * VEC;
+          float* pv = tb.V + (size_t)id * tb.rs + f * VEC;
           float nv[VEC];
 #pragma unroll
           for (int v = 0; v < VEC; v++) {
@@ -569,7 +599,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       }
     } else {
       float sum[VEC], sq, lin;
-      row_sums<KP, 8>(row, size, V, w, h.k1, sum, sq, lin);
+      row_sums<KP, 8>(row, size, tb, h.k1, sum, sq, lin);
 #pragma unroll
       for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
       float part = lin - 0.5f * sq;
@@ -580,7 +610,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       const float rest = wave_sum_dpp(part);
       if (lane == 0) rest_out[e] = rest;
       const float mult = multiplier(h, w0s + rest, y);
-      row_apply<KP, 8, ATOMIC>(row, size, V, w, h, sum, mult);
+      row_apply<KP, 8, ATOMIC>(row, size, tb, h, sum, mult);
     }
   }
 }
@@ -595,7 +625,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
 template <int KP>
 __global__ void __launch_bounds__(64)
 k_sequential(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
-             uint32_t n_rows, float* V, float* w, Hyper h, double* w0_ptr) {
+             uint32_t n_rows, const Tab tb, Hyper h, double* w0_ptr) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x;
   const bool act = lane < LPR;
@@ -609,11 +639,11 @@ k_sequential(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
     for (uint32_t i = 0; i < size; i++) {
       const Entry e = ent[a + i];
       if (h.k1 && lane == 0)
-        lin += (double)__hip_atomic_load(w + e.id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (double)e.value;
+        lin += (double)__hip_atomic_load(tb.w + (size_t)e.id * tb.ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (double)e.value;
       if (act) {
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
-          const float vv = __hip_atomic_load(V + (size_t)e.id * KP + lane * VEC + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float vv = __hip_atomic_load(tb.V + (size_t)e.id * tb.rs + lane * VEC + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const double d = (double)vv * (double)e.value;
           sum[v] += d;
           sq += d * d;
@@ -640,14 +670,14 @@ k_sequential(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
       const Entry e = ent[a + i];
       const double x = (double)e.value;
       if (h.k1 && lane == 0) {
-        const double wv = (double)__hip_atomic_load(w + e.id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(w + e.id, (float)(wv - h.lr_d * (mult * x + h.regw_d * wv)),
+        const double wv = (double)__hip_atomic_load(tb.w + (size_t)e.id * tb.ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tb.w + (size_t)e.id * tb.ws, (float)(wv - h.lr_d * (mult * x + h.regw_d * wv)),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (act) {
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
-          float* pv = V + (size_t)e.id * KP + lane * VEC + v;
+          float* pv = tb.V + (size_t)e.id * tb.rs + lane * VEC + v;
           const double vv = (double)__hip_atomic_load(pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const double grad = sum[v] * x - vv * x * x;
           __hip_atomic_store(pv, (float)(vv - h.lr_d * (mult * grad + h.regv_d * vv)),
@@ -700,36 +730,36 @@ k_yhat(const float* __restrict__ rest, uint32_t n_rows, int k0, const double* __
 // feature j belongs to this shard iff j % world == rank; its local row is j / world.
 // ----------------------------------------------------------------------------------------------
 __global__ void k_stage_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
-                           int rank, int world, float* __restrict__ V) {
+                           int rank, int world, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = (uint64_t)cnt * KP;
   if (t >= total) return;
   const uint32_t jj = (uint32_t)(t / KP); const int f = (int)(t % KP);
   const uint64_t j = j0 + jj;
   if ((int)(j % world) != rank) return;
-  V[(j / world) * KP + f] = (f < k) ? (float)stage[(size_t)f * cnt + jj] : 0.f;
+  tb.V[(j / world) * tb.rs + f] = (f < k) ? (float)stage[(size_t)f * cnt + jj] : 0.f;
 }
 __global__ void k_stage_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
-                            int rank, int world, const float* __restrict__ V) {
+                            int rank, int world, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = (uint64_t)cnt * k;
   if (t >= total) return;
   const int f = (int)(t / cnt); const uint32_t jj = (uint32_t)(t % cnt);
   const uint64_t j = j0 + jj;
   if ((int)(j % world) != rank) return;
-  stage[(size_t)f * cnt + jj] = (double)V[(j / world) * KP + f];
+  stage[(size_t)f * cnt + jj] = (double)tb.V[(j / world) * tb.rs + f];
 }
-__global__ void k_w_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, float* __restrict__ w) {
+__global__ void k_w_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cnt) return;
   const uint64_t j = j0 + t;
-  if ((int)(j % world) == rank) w[j / world] = (float)stage[t];
+  if ((int)(j % world) == rank) tb.w[(j / world) * tb.ws] = (float)stage[t];
 }
-__global__ void k_w_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, const float* __restrict__ w) {
+__global__ void k_w_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cnt) return;
   const uint64_t j = j0 + t;
-  if ((int)(j % world) == rank) stage[t] = (double)w[j / world];
+  if ((int)(j % world) == rank) stage[t] = (double)tb.w[(j / world) * tb.ws];
 }
 
 // counter-hash helpers: identical definitions in oracle/fm_oracle.c (fmo_mix64, fmo_synth_id, ...)
@@ -743,12 +773,12 @@ __host__ __device__ __forceinline__ uint64_t synth_key(uint64_t seed, uint64_t r
   return mix64(seed + 0x9E3779B97F4A7C15ULL * (row + 1) + 0xC2B2AE3D27D4EB4FULL * ((uint64_t)field + 1));
 }
 
-__global__ void k_init_params(float* __restrict__ V, float* __restrict__ w, uint64_t n_local, int k, int KP,
+__global__ void k_init_params(Tab tb, uint64_t n_local, int k, int KP,
                               int rank, int world, float mean, double stdev, uint64_t seed) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = t; i < n_local * (uint64_t)KP; i += stride) {
-    const uint64_t jl = i / KP; const int f = (int)(i % KP);
+  for (uint64_t i = t; i < n_local * (uint64_t)tb.rs; i += stride) {    // whole row incl. padding (and w if co-located)
+    const uint64_t jl = i / tb.rs; const int f = (int)(i % tb.rs);
     const uint64_t j = jl * world + rank;
     float val = 0.f;
     if (f < k) {
@@ -756,9 +786,9 @@ __global__ void k_init_params(float* __restrict__ V, float* __restrict__ w, uint
       const double u = (double)(hsh >> 11) * (1.0 / 9007199254740992.0);
       val = mean + (float)(stdev * (2.0 * u - 1.0) * 1.7320508075688772);
     }
-    V[i] = val;
+    tb.V[i] = val;
   }
-  for (uint64_t i = t; i < n_local; i += stride) w[i] = 0.f;
+  if (tb.ws == 1) for (uint64_t i = t; i < n_local; i += stride) tb.w[i] = 0.f;
 }
 
 // synthetic rows: field t owns ids [t*fs,(t+1)*fs); this shard keeps id % world == rank
