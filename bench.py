@@ -78,11 +78,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=100_000_000)
-    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--features", dest="n", type=int, default=100_000_000, help="number of features n")
+    ap.add_argument("--factors", dest="k", type=int, default=64, help="number of factors k")
     ap.add_argument("--nnz", type=int, default=32)
     ap.add_argument("--rows", type=int, default=1 << 22, help="examples per step")
-    ap.add_argument("--mode", default="minibatch", choices=["minibatch", "hogwild"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "minibatch", "hogwild"],
+                    help="auto: hogwild (fused single pass) on one GPU, minibatch (feature-sharded) on several")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo stages the all-reduce through the host (testing the N>1 path without RCCL)")
+    ap.add_argument("--same-device", action="store_true", help="testing: all ranks use cuda:0")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 65536 sharded); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=256)
@@ -103,9 +107,18 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    if args.mode == "auto":
+        args.mode = "hogwild" if world == 1 else "minibatch"
+    if world > 1 and args.mode != "minibatch":
+        raise SystemExit("several GPUs: only --mode minibatch (feature-sharded) exists")
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -144,7 +157,12 @@ def main():
                 nb = min(batch, args.rows - row0)
                 view = buf[: nb * kp1]
                 h.sgd_partial(0, row0, nb, view.data_ptr(), stream)
-                dist.all_reduce(view)
+                if args.backend == "nccl":
+                    dist.all_reduce(view)
+                else:
+                    host = view.cpu()
+                    dist.all_reduce(host)
+                    view.copy_(host)
                 h.sgd_finish(0, row0, nb, view.data_ptr(), apply_, args.w0_chunk, stream, batch)
         rows_per_launch = min(batch, args.rows)
         kind = "apply"
@@ -165,7 +183,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfmx.so")
+LIB_PATH = os.environ.get("FMX_LIB", os.path.join(HERE, "libfmx.so"))   # FMX_LIB: experiment builds only
 
 FMX_OK = 0
 TASK_REGRESSION, TASK_CLASSIFICATION = 0, 1

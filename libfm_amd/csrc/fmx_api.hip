@@ -54,6 +54,7 @@ struct fmx_context_s {
   double*    w0 = nullptr;       // device scalar
   double*    w0_pp = nullptr;    // 2 doubles: ping-pong copies of w0 for the overlapped hogwild bias scan
   hipStream_t stream2 = nullptr; // side stream of the hogwild bias scan
+  hipStream_t stream3 = nullptr; // second launch stream of the hogwild macro-batches (odd launches)
   int        num_cu = 256;
   double*    acc = nullptr;      // 4 doubles of reduction scratch
   Slot       slots[FMX_MAX_SLOTS];
@@ -288,6 +289,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
   CREATE_CHK(hipMalloc(&h->w0_pp, 2 * sizeof(double)));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   h->num_cu = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
   CREATE_CHK(hipMalloc(&h->acc, 4 * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
@@ -307,6 +309,7 @@ int fmx_destroy(fmx_handle h) {
   if (h->w0) hipFree(h->w0);
   if (h->w0_pp) hipFree(h->w0_pp);
   if (h->stream2) hipStreamDestroy(h->stream2);
+  if (h->stream3) hipStreamDestroy(h->stream3);
   if (h->acc) hipFree(h->acc);
   if (h->partial) hipFree(h->partial);
   if (h->mult) hipFree(h->mult);
@@ -847,32 +850,41 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     rc = ensure_scratch(h, 0, (size_t)cap * 2);
     if (rc) return rc;
     const uint64_t n_launch = ((uint64_t)s.n_rows + M - 1) / M;
-    while (h->ev_sync.size() < 2 * n_launch) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+    while (h->ev_sync.size() < 2 * n_launch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
     HIPCHK(h, hipMemcpyAsync(h->w0_pp, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->w0_pp + 1, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    // even launches go to `stream`, odd ones to `stream3`: the drain of one macro-batch overlaps the ramp-up of
+    // the next (rows of different launches are as independent as rows of one launch)
+    const bool two_streams = getenv("FMX_HOGWILD_TWO_STREAMS") != nullptr;   // +6 % but launches overlap (timing per launch blurs)
+    hipEvent_t ev_start = h->ev_sync[2 * n_launch];
+    HIPCHK(h, hipEventRecord(ev_start, h->stream));
+    if (two_streams) HIPCHK(h, hipStreamWaitEvent(h->stream3, ev_start, 0));
     for (uint64_t i = 0; i < n_launch; i++) {
       const uint64_t row0 = i * M;
       const uint32_t nb = (uint32_t)std::min<uint64_t>(M, s.n_rows - row0);
       float* rest = h->rest + (size_t)(i & 1) * cap;
-      if (i >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync[2 * (i - 2) + 1], 0));   // scan i-2 done
+      hipStream_t fs = (two_streams && (i & 1)) ? h->stream3 : h->stream;
+      if (i >= 2) HIPCHK(h, hipStreamWaitEvent(fs, h->ev_sync[2 * (i - 2) + 1], 0));   // scan i-2 done
       hipEvent_t ea = nullptr, eb = nullptr;
-      if (timed) { HIPCHK(h, get_event(&ea)); HIPCHK(h, get_event(&eb)); main_launches++; HIPCHK(h, hipEventRecord(ea, h->stream)); }
+      // (no per-launch events here: a timing event between two launches costs ~13 % on this path; the epoch is
+      //  bracketed by ev0/ev1 on the launch stream and the average launch time is epoch time / launches)
+      main_launches++;
       const double* w0_in = h->w0_pp + ((i + 1) & 1);      // slot written by scan i-2 (initial value for i < 2)
       if (opts->apply == FMX_APPLY_ATOMIC) {
-        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, row0, nb, h->stream, w0_in, rest); });
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, row0, nb, fs, w0_in, rest); });
       } else {
-        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, row0, nb, h->stream, w0_in, rest); });
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, row0, nb, fs, w0_in, rest); });
       }
       if (rc) return rc;
-      if (timed) HIPCHK(h, hipEventRecord(eb, h->stream));
       HIPCHK(h, hipGetLastError());
-      HIPCHK(h, hipEventRecord(h->ev_sync[2 * i], h->stream));
+      HIPCHK(h, hipEventRecord(h->ev_sync[2 * i], fs));
       HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * i], 0));
       rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (i & 1), h->w0_pp + ((i + 1) & 1));
       if (rc) return rc;
       HIPCHK(h, hipEventRecord(h->ev_sync[2 * i + 1], h->stream2));
       batches++;
     }
+    // stream2 is in order: its last event covers every scan, and scan i waited for launch i
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync[2 * (n_launch - 1) + 1], 0));
     if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_launch & 1), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
@@ -909,7 +921,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     stats->rows = s.n_rows;
     stats->batches = batches;
     stats->device_seconds = ms * 1e-3;
-    if ((opts->mode == FMX_SGD_MINIBATCH || opts->mode == FMX_SGD_HOGWILD) && timed) {
+    if (opts->mode == FMX_SGD_MINIBATCH && timed) {
       double tot = 0;
       for (size_t i = 0; i + 1 < ev_used; i += 2) {
         float m2 = 0;

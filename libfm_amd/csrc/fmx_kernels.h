@@ -103,6 +103,20 @@ template <int VEC> __device__ __forceinline__ void store_vec(float* __restrict__
       reinterpret_cast<float4*>(p)[c] = make_float4(in[4 * c], in[4 * c + 1], in[4 * c + 2], in[4 * c + 3]);
   }
 }
+// load of one linear weight w[j] (a 4-byte gather).  FMX_W_LOAD selects the cache policy for experiments:
+// 0 plain, 1 non-temporal, 2 sc1 (agent-scope relaxed atomic load).
+#ifndef FMX_W_LOAD
+#define FMX_W_LOAD 0
+#endif
+__device__ __forceinline__ float load_w(const float* p) {
+#if FMX_W_LOAD == 1
+  return __builtin_nontemporal_load(p);
+#elif FMX_W_LOAD == 2
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *p;
+#endif
+}
 // loss multiplier, fm_learn_sgd_element.h:58-65
 __device__ __forceinline__ float multiplier(const Hyper& h, float p, float y) {
   if (h.task == 0) {
@@ -145,7 +159,7 @@ __device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t
     Entry e; e.id = 0; e.value = 0.f;
     if (lane < cnt) {
       e = ent[base + lane];
-      if (k1) lin += tb.w[(size_t)e.id * tb.ws] * e.value;
+      if (k1) lin += load_w(tb.w + (size_t)e.id * tb.ws) * e.value;
     }
     for (uint32_t i = 0; i < cnt; i += EPI * U) {
       float vr[U][VEC]; float xs[U];
@@ -533,7 +547,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       float wv = 0.f;
       if (lane < size) {
         en = row[lane];
-        if (h.k1) wv = tb.w[(size_t)en.id * tb.ws];
+        if (h.k1) wv = load_w(tb.w + (size_t)en.id * tb.ws);
       }
       // phase A: issue every gather of the row back-to-back (ids / values are re-broadcast later instead of
       // being kept: with EPI == 1 they are wave-uniform and live in SGPRs for the duration of one use)

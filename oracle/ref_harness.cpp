@@ -10,6 +10,8 @@
 //
 // usage:
 //   ref_harness sgd  <train> <test> <task r|c> <k0> <k1> <k> <iters> <lr> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
+//   ref_harness sgd_gpu <same arguments as sgd> [mode 0|1|2] [batch] [w0_chunk]
+//                    (same driver, but the learner is adapter/fm_learn_sgd_gpu.h -> libfmx.so; needs a GPU)
 //   ref_harness als  <train> <test> <task r|c> <k0> <k1> <k> <iters> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
 //   ref_harness mcmc <train> <test> <task r|c> <k0> <k1> <k> <iters> <init_stdev> <seed> <out_prefix>
 //   ref_harness time_sgd <n> <k> <nnz> <rows> <seed>        (CPU baseline: reference fm_model::predict + fm_SGD on
@@ -40,6 +42,9 @@
 #include "libfm/src/fm_learn_mcmc_simultaneous.h"
 
 #include "fm_oracle.h"   // only for the synthetic-row generator used by time_sgd
+#ifdef FMX_WITH_GPU_ADAPTER
+#include "../adapter/fm_learn_sgd_gpu.h"   // the reference-side binding of libfmx, exercised by mode sgd_gpu
+#endif
 
 static void dump_params(const std::string& path, fm_model& fm) {
   FILE* f = fopen(path.c_str(), "wb");
@@ -121,14 +126,14 @@ int main(int argc, char** argv) {
     int k0 = atoi(argv[a++]), k1 = atoi(argv[a++]), k = atoi(argv[a++]);
     int iters = atoi(argv[a++]);
     double lr = 0, reg0 = 0, regw = 0, regv = 0;
-    if (mode == "sgd") lr = atof(argv[a++]);
+    if (mode == "sgd" || mode == "sgd_gpu") lr = atof(argv[a++]);
     if (mode != "mcmc") { reg0 = atof(argv[a++]); regw = atof(argv[a++]); regv = atof(argv[a++]); }
     double init_stdev = atof(argv[a++]);
     long seed = atol(argv[a++]);
     std::string prefix = argv[a++];
 
     srand(seed);                                               // libfm.cpp:115-116
-    const bool is_sgd = (mode == "sgd");
+    const bool is_sgd = (mode == "sgd" || mode == "sgd_gpu");
     Data train(0, is_sgd, !is_sgd);                            // libfm.cpp:143-148
     train.load(train_file);
     Data test(0, is_sgd, !is_sgd);
@@ -145,6 +150,28 @@ int main(int argc, char** argv) {
     fm.init();
 
     FILE* ev = fopen((prefix + ".eval.txt").c_str(), "w");
+#ifdef FMX_WITH_GPU_ADAPTER
+    if (mode == "sgd_gpu") {
+      fm_learn_sgd_gpu* fml = new fm_learn_sgd_gpu();
+      if (argc > a) fml->gpu_mode = atoi(argv[a++]);
+      if (argc > a) fml->gpu_batch = atoi(argv[a++]);
+      if (argc > a) fml->gpu_w0_chunk = atoi(argv[a++]);
+      fml->num_iter = iters;
+      fml->fm = &fm; fml->max_target = train.max_target; fml->min_target = train.min_target; fml->meta = &meta;
+      set_task(fml, task, train, test);
+      fml->log = NULL;
+      fml->init();
+      fm.reg0 = reg0; fm.regw = regw; fm.regv = regv;
+      fml->learn_rate = lr; fml->learn_rates.init(lr);
+      dump_params(prefix + ".init.bin", fm);
+      fml->learn(train, test);
+      fprintf(ev, "%.17g %.17g\n", fml->evaluate(train), fml->evaluate(test));
+      dump_params(prefix + ".final.bin", fm);
+      DVector<double> pred; pred.setSize(test.num_cases);
+      fml->predict(test, pred);
+      dump_vec(prefix + ".pred_out.bin", pred.value, pred.dim);
+    } else
+#endif
     if (is_sgd) {
       Open<fm_learn_sgd_element>* fml = new Open<fm_learn_sgd_element>();
       fml->num_iter = 1;

@@ -1,0 +1,52 @@
+"""GPU: the reference-side binding (adapter/fm_learn_sgd_gpu.h) driven by the REAL reference classes.
+
+oracle/_ref/ref_harness_gpu is the reference's own Data / fm_model / fm_learn machinery (compiled from
+/root/reference in the build container; the binary travels with the snapshot) with the learner swapped for the
+fm_learn subclass that calls libfmx.so.  Run in SEQUENTIAL mode it must land on the reference's own trajectory
+(the golden fixture produced by the stock fm_learn_sgd_element)."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from common import Golden
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness_gpu")
+
+
+@pytest.mark.parametrize("name", ["sgd_reg_ml", "sgd_cls_ragged", "sgd_cls_k64"])
+def test_reference_driver_with_gpu_learner(oracle, name):
+    if not os.path.exists(HARNESS):
+        pytest.skip("oracle/_ref/ref_harness_gpu not built (needs /root/reference at build time)")
+    O = oracle
+    g = Golden(name)
+    z = g.z
+    with tempfile.TemporaryDirectory() as td:
+        trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
+        # the harness parses the files with the reference's own loader and rewrites the targets itself
+        O.Data(z["train_entries"], z["train_row_ptr"], z["train_target"]).write_libsvm(trf)
+        O.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(tef)
+        cfg = ["sgd_gpu", trf, tef, str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]),
+               repr(float(z["lr"])), repr(g.reg[0]), repr(g.reg[1]), repr(g.reg[2]), repr(float(z["init_stdev"])),
+               int(z["seed"]), pre, 0]                       # trailing 0 = FMX_SGD_SEQUENTIAL
+        r = subprocess.run([HARNESS] + [str(c) for c in cfg], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "#Iter=" in r.stdout                          # the reference's progress line format
+        init = O.Model.from_dump(pre + ".init.bin")
+        final = O.Model.from_dump(pre + ".final.bin")
+        pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+        ev = np.loadtxt(pre + ".eval.txt", ndmin=2)
+    # same seed => the reference's rand() stream gives the same initial model as in the fixture
+    assert np.array_equal(init.v, z["init_v"])
+    np.testing.assert_allclose(final.v, z["final_v"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(final.w, z["final_w"], rtol=1e-4, atol=1e-5)
+    assert abs(final.w0 - float(z["final_w0"])) <= 1e-4 * abs(float(z["final_w0"])) + 1e-5
+    np.testing.assert_allclose(pred_out, z["pred_out"], rtol=1e-4, atol=5e-5)
+    if g.task == 0:
+        np.testing.assert_allclose(ev[-1], z["eval"][-1], rtol=1e-4)
+    else:
+        assert np.abs(ev[-1] - z["eval"][-1]).max() <= 2.0 / 100
