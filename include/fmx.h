@@ -175,6 +175,41 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
 /* sharded predict: finish a partial buffer into y-hat (device float[n_rows]) */
 int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float *d_partial, float *d_yhat, void *stream);
 
+/* ---- fm_learn_mcmc (ALS = MCMC without sampling, libfm.cpp:135-139) ---------------------------------
+ * The learner keeps e(c) = y-hat(c) - target(c) and q_f(c) per training row (e_q_term, fm_learn_mcmc.h:46-49)
+ * and sweeps the coordinates through X^T (built on the device from the slot's rows, Data.h:292-341).
+ *   fmx_als_begin : fm_learn_mcmc::learn set-up (:1160-1172) + _learn's first prediction and e -= target
+ *                   (fm_learn_mcmc_simultaneous.h:69-86).
+ *   fmx_als_sweep : one iteration of _learn (:88-196): draw_all (fm_learn_mcmc.h:430-641: draw_w0, draw_w per
+ *                   feature, per factor add_main_q + draw_v), full re-prediction of the train rows, train metric,
+ *                   new residuals.  Test predictions of the iteration = fmx_predict on the test slot.
+ *   fmx_als_end   : frees the caches (:1192-1200).
+ * do_sample = 0 is ALS (alpha = 1, mu = 0, lambdas from -regular: reg0 -> w0, w_lambda, v_lambda; libfm.cpp:326-365).
+ * do_sample = 1 draws every coordinate from its posterior N(mean, sigma^2) with a counter-based generator (NOT the
+ * reference's libc rand() stream: statistical, not bitwise, parity); alpha and the prior means/precisions are
+ * supplied per sweep by the caller (the hyper-prior draws of :911-1097 are scalar work that stays on the host).
+ * One attribute group; no relations (block structure) -- those are out of scope. */
+typedef struct fmx_als_opts {
+  double   alpha;           /* fm_learn_mcmc::alpha (1 for ALS) */
+  double   w_mu, w_lambda;  /* prior of the linear weights */
+  double   v_mu, v_lambda;  /* prior of the factors */
+  int32_t  do_sample;       /* 0 = ALS, 1 = Gibbs draws */
+  int32_t  reserved;
+  uint64_t seed;
+} fmx_als_opts;
+
+typedef struct fmx_als_stats {
+  double   train_metric;    /* rmse_train (regression, clamped) or acc_train (classification) of this iteration */
+  double   device_seconds;
+  uint32_t levels;          /* dependency levels of the sweep (1 launch per level and coordinate family) */
+  uint32_t reserved;
+  double   sum_e_sqr;       /* sum over train rows of e^2 BEFORE the sweep (draw_alpha's statistic, :918-920) */
+} fmx_als_stats;
+
+int fmx_als_begin(fmx_handle h, int train_slot);
+int fmx_als_sweep(fmx_handle h, const fmx_als_opts *opts, fmx_als_stats *stats);
+int fmx_als_end(fmx_handle h);
+
 /* ---- introspection --------------------------------------------------------------------------- */
 typedef struct fmx_info {
   uint64_t n_local;         /* features held by this handle */

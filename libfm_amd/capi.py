@@ -49,6 +49,16 @@ class Eval(C.Structure):
                 ("device_seconds", C.c_double), ("rows", C.c_uint64)]
 
 
+class AlsOpts(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("w_mu", C.c_double), ("w_lambda", C.c_double), ("v_mu", C.c_double),
+                ("v_lambda", C.c_double), ("do_sample", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64)]
+
+
+class AlsStats(C.Structure):
+    _fields_ = [("train_metric", C.c_double), ("device_seconds", C.c_double), ("levels", C.c_uint32),
+                ("reserved", C.c_uint32), ("sum_e_sqr", C.c_double)]
+
+
 class Info(C.Structure):
     _fields_ = [("n_local", C.c_uint64), ("k_padded", C.c_int32), ("device", C.c_int32),
                 ("bytes_params", C.c_uint64), ("device_name", C.c_char * 64), ("arch", C.c_char * 32)]
@@ -78,6 +88,9 @@ SYMBOLS = [
     ("fmx_sgd_partial", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_sgd_finish", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(SgdOpts), C.c_void_p]),
     ("fmx_predict_finish", C.c_int, [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("fmx_als_begin", C.c_int, [H, C.c_int]),
+    ("fmx_als_sweep", C.c_int, [H, C.POINTER(AlsOpts), C.POINTER(AlsStats)]),
+    ("fmx_als_end", C.c_int, [H]),
     ("fmx_get_info", C.c_int, [H, C.POINTER(Info)]),
     ("fmx_synchronize", C.c_int, [H]),
 ]
@@ -222,6 +235,19 @@ class Handle:
 
     def predict_finish(self, n_rows, d_partial_ptr, d_yhat_ptr, stream=None):
         self._chk(self.lib.fmx_predict_finish(self.h, n_rows, d_partial_ptr, d_yhat_ptr, stream))
+
+    # ALS / MCMC ----------------------------------------------------------------------------
+    def als_begin(self, train_slot):
+        self._chk(self.lib.fmx_als_begin(self.h, train_slot))
+
+    def als_sweep(self, w_lambda, v_lambda, alpha=1.0, w_mu=0.0, v_mu=0.0, do_sample=False, seed=0):
+        opts = AlsOpts(alpha, w_mu, w_lambda, v_mu, v_lambda, int(do_sample), 0, seed)
+        st = AlsStats()
+        self._chk(self.lib.fmx_als_sweep(self.h, C.byref(opts), C.byref(st)))
+        return st
+
+    def als_end(self):
+        self._chk(self.lib.fmx_als_end(self.h))
 
     def info(self):
         inf = Info()

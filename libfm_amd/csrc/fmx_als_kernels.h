@@ -1,0 +1,232 @@
+// fmx_als_kernels.h -- gfx950 kernels of the ALS / MCMC learner (coordinate-wise Gauss-Seidel over X^T).
+//
+// Reference (restated, never copied):
+//   fm_learn_mcmc::predict_data_and_write_to_eterms  /root/reference/src/libfm/src/fm_learn_mcmc.h:148-378
+//   add_main_q :406-428, draw_all :430-641, draw_w0 :643-683, draw_w :685-732, draw_v :792-847
+//   fm_learn_mcmc_simultaneous::_learn               /root/reference/src/libfm/src/fm_learn_mcmc_simultaneous.h:56-270
+//
+// State on the device: e[c] = y-hat(c) - target(c) and q[f][c] = sum_j v_fj x_cj in fp64 (the reference keeps
+// both in fp64: e_q_term, fm_learn_mcmc.h:46-49); parameters stay in the fp32 table shared with the SGD path,
+// every new value is rounded to fp32 BEFORE its delta is pushed into e/q, so the caches always describe the
+// stored parameters.
+//
+// Parallelism: two coordinates conflict iff their columns share a row.  The host assigns every feature a
+// LEVEL = 1 + max level of the earlier (smaller id) features it shares a row with; features of one level are
+// mutually independent and all their predecessors are in lower levels, so "level by level, all features of a
+// level in parallel" performs EXACTLY the reference's sequential sweep (one-hot field data: level = field).
+#pragma once
+
+#include "fmx_kernels.h"
+
+namespace fmx {
+
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+// reference's erf polynomial / cdf_gaussian (random.h:45-67), needed bit-compatibly for the probit target
+__device__ __forceinline__ double ref_erf(double x) {
+  const double t = (x >= 0) ? 1.0 / (1.0 + 0.3275911 * x) : 1.0 / (1.0 - 0.3275911 * x);
+  const double r = 1.0 - (t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429))))) * exp(-x * x);
+  return (x >= 0) ? r : -r;
+}
+__device__ __forceinline__ double ref_cdf_gaussian(double x) { return 0.5 + 0.5 * ref_erf(0.707106781 * x); }
+
+// ----------------------------------------------------------------------------------------------
+// k_als_eterms: one wavefront per row.  e[c] = y-hat(c) (fp64 accumulation, fm_model.h:105-127 arithmetic; the
+// reference's 2k+1 passes over X^T, fm_learn_mcmc.h:176-368, compute the same number) and q[f][c] for the
+// coming sweep (add_main_q :406-428 evaluated for every factor at once: v_f does not change before its own
+// sweep, so the value is the one the reference would compute later).
+// ----------------------------------------------------------------------------------------------
+template <int KP>
+__global__ void __launch_bounds__(256)
+k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, const Tab tb,
+             int k0, int k1, const double* __restrict__ w0_ptr, double* __restrict__ e, double* __restrict__ q /* [KP][n_rows] or null */) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool act = lane < LPR;
+  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  const double w0 = k0 ? *w0_ptr : 0.0;
+  for (uint32_t c = wave0; c < n_rows; c += nwaves) {
+    const uint64_t a = row_ptr[c];
+    const uint32_t size = (uint32_t)(row_ptr[c + 1] - a);
+    double sum[VEC]; double sq = 0.0, lin = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) sum[v] = 0.0;
+    for (uint32_t i = 0; i < size; i++) {
+      const Entry en = ent[a + i];
+      const double x = (double)en.value;
+      if (k1 && lane == 0) lin += (double)tb.w[(size_t)en.id * tb.ws] * x;
+      if (act) {
+        float vv[VEC];
+        load_vec<VEC>(tb.V + (size_t)en.id * tb.rs + lane * VEC, vv);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const double d = (double)vv[v] * x;
+          sum[v] += d;
+          sq += d * d;
+        }
+      }
+    }
+    double part = lin - 0.5 * sq;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+      if (q) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) q[(size_t)(lane * VEC + v) * n_rows + c] = sum[v];
+      }
+    }
+    part = wave_sum_f64(part);
+    if (lane == 0) e[c] = w0 + part;
+  }
+}
+
+// e[c] -= target[c] (initialisation, _learn :70-86)
+__global__ void k_als_sub_target(double* __restrict__ e, const float* __restrict__ target, uint32_t n) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) e[c] -= (double)target[c];
+}
+
+// after a sweep, e holds y-hat: accumulate the train metric and turn e back into the residual
+//   regression    (_learn :139-150): rmse over clamped predictions, e -= y
+//   classification(_learn :163-196): accuracy of cdf_gaussian(e) vs sign, e -= E[truncated normal] (do_sample = 0)
+// acc[0] = sum err^2 / #correct
+__global__ void __launch_bounds__(256)
+k_als_targets(double* __restrict__ e, const float* __restrict__ target, uint32_t n, int task,
+              double min_target, double max_target, double* __restrict__ acc) {
+  double s = 0.0;
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    const double yh = e[c];
+    const double y = (double)target[c];
+    if (task == 0) {
+      double p = fmin(max_target, yh);
+      p = fmax(min_target, p);
+      const double err = p - y;
+      s += err * err;
+      e[c] = yh - y;
+    } else {
+      const double p = ref_cdf_gaussian(yh);
+      if (((p >= 0.5) && (y > 0.0)) || ((p < 0.5) && (y < 0.0))) s += 1.0;
+      const double phi_minus_mu = exp(-yh * yh / 2.0) / sqrt(3.141 * 2);       // sic: 3.141 (:179,:189)
+      const double Phi_minus_mu = ref_cdf_gaussian(-yh);
+      const double st = (y >= 0.0) ? yh + phi_minus_mu / (1 - Phi_minus_mu) : yh - phi_minus_mu / Phi_minus_mu;
+      e[c] = yh - st;
+    }
+  }
+  s = wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(acc, s);
+}
+
+// sum_c e[c] (draw_w0's numerator, :650-652: sum (e - w0) = sum e - N w0) and sum e^2 (draw_alpha :918-920)
+__global__ void __launch_bounds__(256)
+k_als_sum_e(const double* __restrict__ e, uint32_t n, double* __restrict__ acc) {
+  double s = 0.0, s2 = 0.0;
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) { const double v = e[c]; s += v; s2 += v * v; }
+  s = wave_sum_f64(s); s2 = wave_sum_f64(s2);
+  if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(acc, s); unsafeAtomicAdd(acc + 1, s2); }
+}
+__global__ void k_als_add_const(double* __restrict__ e, uint32_t n, double d) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) e[c] += d;
+}
+
+// counter-based N(0,1) for the sampling variant (MCMC): Box-Muller on two splitmix64 hashes of (seed, stream, index)
+__device__ __forceinline__ double gauss_hash(uint64_t seed, uint64_t stream, uint64_t idx) {
+  const uint64_t h1 = mix64(seed ^ (stream * 0x9E3779B97F4A7C15ULL) ^ (idx * 0xD6E8FEB86659FD93ULL + 0x632BE59BD9B4E019ULL));
+  const uint64_t h2 = mix64(h1 + 0x9E3779B97F4A7C15ULL);
+  const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740992.0);    // (0,1]
+  const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_als_draw: one wavefront per feature of the current level.
+//   IS_V = false: draw_w (:685-732)    theta = w_j,    h = x
+//   IS_V = true : draw_v (:792-847)    theta = v_fj,   h = x (q_c - x theta)
+// posterior: sigma^2 = 1/(lambda + alpha sum h^2), mean = -sigma^2 (alpha (sum h e - theta sum h^2) - mu lambda);
+// new theta = mean (ALS) or mean + sigma N(0,1) (MCMC); NaN/Inf sigma^2 -> 0, NaN/Inf theta -> keep (:704-724).
+// then e_c -= h (theta_old - theta), q_c -= x (theta_old - theta).
+// seg_list: the level's segments; a segment = one feature's column inside t_ent (sorted by feature).
+// ----------------------------------------------------------------------------------------------
+template <bool IS_V>
+__global__ void __launch_bounds__(256)
+k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
+           uint32_t nseg_total, uint32_t nnz, const uint32_t* __restrict__ seg_list, uint32_t n_list,
+           float* __restrict__ param, uint32_t pstride, double* __restrict__ e, double* __restrict__ q,
+           double alpha, double lambda, double mu, int do_sample, uint64_t seed, uint64_t stream) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t li = wave0; li < n_list; li += nwaves) {
+    const uint32_t s = seg_list[li];
+    const uint32_t j = seg_feat[s];
+    const uint32_t a = seg_rel[s];
+    const uint32_t b = (s + 1 < nseg_total) ? seg_rel[s + 1] : nnz;
+    float* pt = param + (size_t)j * pstride;
+    const double th = (double)(*pt);
+    double t_he = 0.0, t_hh = 0.0;
+    for (uint32_t i = a + lane; i < b; i += 64) {
+      const TEntry te = t_ent[i];
+      const double x = (double)te.x;
+      double h;
+      if (IS_V) h = x * (q[te.e] - x * th); else h = x;
+      if (IS_V) { t_he += h * e[te.e]; } else { t_he += x * (e[te.e] - th * x); }
+      t_hh += h * h;
+    }
+    t_he = wave_sum_f64(t_he);
+    t_hh = wave_sum_f64(t_hh);
+    if (IS_V) t_he -= th * t_hh;                                   // :803
+    const double sigma_sqr = 1.0 / (lambda + alpha * t_hh);
+    double mean = -sigma_sqr * (alpha * t_he - mu * lambda);
+    double nt;
+    if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
+    else nt = do_sample ? mean + sqrt(sigma_sqr) * gauss_hash(seed, stream, j) : mean;
+    if (isnan(nt) || isinf(nt)) continue;                          // keep the old value, caches untouched
+    const float ntf = (float)nt;
+    const double d = th - (double)ntf;                             // theta_old - theta (of the STORED value)
+    if (lane == 0) *pt = ntf;
+    if (d != 0.0) {
+      for (uint32_t i = a + lane; i < b; i += 64) {
+        const TEntry te = t_ent[i];
+        const double x = (double)te.x;
+        if (IS_V) {
+          // a row that holds this feature more than once (entries adjacent: the sort is stable in row order):
+          // the reference updates q between the occurrences (:839-846), so the later one sees q - x_prev * d
+          double qc = q[te.e];
+          for (uint32_t ib = i; ib > a && t_ent[ib - 1].e == te.e; ib--) qc -= (double)t_ent[ib - 1].x * d;
+          const double h = x * (qc - x * th);
+          unsafeAtomicAdd(e + te.e, -h * d);                     // atomics: two lanes may hit the same row
+        } else {
+          unsafeAtomicAdd(e + te.e, -x * d);
+        }
+      }
+      if (IS_V) {
+        // q must be updated after every lane has read it for h (same wavefront: the loop above has completed)
+        for (uint32_t i = a + lane; i < b; i += 64) {
+          const TEntry te = t_ent[i];
+          unsafeAtomicAdd(q + te.e, -(double)te.x * d);
+        }
+      }
+    }
+  }
+}
+
+// features without a training column: the empty-row draw (:467-476, :586-595): theta = prior mean mu = 0
+// (sigma^2 = 1/lambda; lambda = 0 -> sigma^2 = inf -> theta = 0); MCMC: mu + N(0,1)/sqrt(lambda)
+__global__ void __launch_bounds__(256)
+k_als_unseen(const uint8_t* __restrict__ seen, uint64_t n_local, float* __restrict__ param, uint32_t pstride,
+             double lambda, double mu, int do_sample, uint64_t seed, uint64_t stream) {
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_local; j += (uint64_t)gridDim.x * blockDim.x)
+    if (!seen[j]) {
+      const double sigma_sqr = 1.0 / lambda;
+      double nt;
+      if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
+      else nt = do_sample ? mu + sqrt(sigma_sqr) * gauss_hash(seed, stream, j) : mu;
+      if (isnan(nt) || isinf(nt)) continue;
+      param[(size_t)j * pstride] = (float)nt;
+    }
+}
+
+}  // namespace fmx

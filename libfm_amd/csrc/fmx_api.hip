@@ -5,6 +5,7 @@
 // otherwise.  Nothing in this library links or calls oracle/.
 #include "../../include/fmx.h"
 #include "fmx_kernels.h"
+#include "fmx_als_kernels.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -13,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <random>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -43,8 +45,19 @@ thread_local std::string g_create_error = "";
 
 }  // namespace
 
+struct AlsState {
+  int       slot = -1;
+  double*   e = nullptr;          // [N] residuals
+  double*   q = nullptr;          // [KP][N]
+  uint8_t*  seen = nullptr;       // [n_local] feature has a training column
+  uint32_t* level_list = nullptr; // segments ordered by level
+  std::vector<uint32_t> level_ptr;
+  uint64_t  iter = 0;
+};
+
 struct fmx_context_s {
   fmx_config cfg;
+  AlsState   als;
   int        KP = 1;
   uint64_t   n_local = 0;
   int        device = 0;
@@ -220,6 +233,8 @@ int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0,
 
 }  // namespace
 
+static void als_free(fmx_handle h);
+
 extern "C" {
 
 int fmx_abi_version(void) { return FMX_ABI_VERSION; }
@@ -303,6 +318,7 @@ int fmx_destroy(fmx_handle h) {
   if (!h) return FMX_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  als_free(h);
   for (auto& s : h->slots) free_slot(s);
   if (h->tb.V) hipFree(h->tb.V);
   if (h->w_sep) hipFree(h->w_sep);
@@ -934,6 +950,166 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
       stats->main_kernel_seconds = stats->device_seconds;
       stats->main_kernel_launches = main_launches;
     }
+  }
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ALS / MCMC
+// ---------------------------------------------------------------------------------------------
+static void als_free(fmx_handle h) {
+  AlsState& a = h->als;
+  if (a.e) hipFree(a.e);
+  if (a.q) hipFree(a.q);
+  if (a.seen) hipFree(a.seen);
+  if (a.level_list) hipFree(a.level_list);
+  a = AlsState();
+}
+
+int fmx_als_end(fmx_handle h) {
+  if (!h) return FMX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  als_free(h);
+  return FMX_OK;
+}
+
+static int als_eterms(fmx_handle h, const Slot& s, double* e, double* q) {
+  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), s.n_rows, h->stream, s.ent, s.row_ptr, s.n_rows, h->tb,
+                                     h->cfg.k0, h->cfg.k1, h->w0, e, q));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+int fmx_als_begin(fmx_handle h, int train_slot) {
+  int rc = check_slot(h, train_slot, true);
+  if (rc) return rc;
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "ALS on a feature shard is not implemented");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  als_free(h);
+  Slot& s = h->slots[train_slot];
+  if (s.n_rows == 0) return fail(h, FMX_E_ARG, "fmx_als_begin: empty training set");
+  rc = ensure_segments(h, s, s.n_rows);          // one "batch" = the whole data set: X^T with columns in id order
+  if (rc) return rc;
+  AlsState& a = h->als;
+  a.slot = train_slot;
+  const uint32_t N = s.n_rows, nseg = s.nseg;
+  // ---- dependency levels (host, O(nnz)): level(j) = 1 + max level of earlier features sharing a row with j
+  std::vector<uint32_t> seg_feat(nseg), seg_rel(nseg + 1), lvl(nseg), rowlevel(N, 0);
+  std::vector<TEntry> tent((size_t)s.nnz);
+  if (nseg) {
+    HIPCHK(h, hipMemcpy(seg_feat.data(), s.seg_feat, (size_t)nseg * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(seg_rel.data(), s.seg_rel, (size_t)nseg * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(tent.data(), s.t_ent, (size_t)s.nnz * sizeof(TEntry), hipMemcpyDeviceToHost));
+  }
+  seg_rel[nseg] = (uint32_t)s.nnz;
+  uint32_t n_levels = 0;
+  for (uint32_t sg = 0; sg < nseg; sg++) {
+    uint32_t l = 0;
+    for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) l = std::max(l, rowlevel[tent[i].e]);
+    l += 1;
+    for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) rowlevel[tent[i].e] = l;
+    lvl[sg] = l - 1;
+    n_levels = std::max(n_levels, l);
+  }
+  a.level_ptr.assign((size_t)n_levels + 1, 0);
+  for (uint32_t sg = 0; sg < nseg; sg++) a.level_ptr[lvl[sg] + 1]++;
+  for (uint32_t l = 0; l < n_levels; l++) a.level_ptr[l + 1] += a.level_ptr[l];
+  std::vector<uint32_t> list(std::max<uint32_t>(nseg, 1)), fill(a.level_ptr.begin(), a.level_ptr.end());
+  for (uint32_t sg = 0; sg < nseg; sg++) list[fill[lvl[sg]]++] = sg;
+  std::vector<uint8_t> seen((size_t)h->n_local, 0);
+  for (uint32_t sg = 0; sg < nseg; sg++) seen[seg_feat[sg]] = 1;
+  HIPCHK(h, hipMalloc(&a.level_list, list.size() * 4));
+  HIPCHK(h, hipMemcpy(a.level_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMalloc(&a.seen, seen.size()));
+  HIPCHK(h, hipMemcpy(a.seen, seen.data(), seen.size(), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMalloc(&a.e, (size_t)N * sizeof(double)));
+  HIPCHK(h, hipMalloc(&a.q, (size_t)N * (size_t)h->KP * sizeof(double)));
+  // ---- first prediction and e -= target (fm_learn_mcmc_simultaneous.h:69-86)
+  rc = als_eterms(h, s, a.e, a.q);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_als_sub_target, dim3(std::min<uint32_t>((N + 255) / 256, 2048)), dim3(256), 0, h->stream, a.e, s.target, N);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) {
+  if (!h || !opts) return FMX_E_ARG;
+  AlsState& a = h->als;
+  if (a.slot < 0) return fail(h, FMX_E_STATE, "fmx_als_sweep before fmx_als_begin");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[a.slot];
+  const uint32_t N = s.n_rows;
+  const uint32_t n_levels = (uint32_t)a.level_ptr.size() - 1;
+  hipStream_t st = h->stream;
+  const dim3 g1(std::min<uint32_t>((N + 255) / 256, 2048)), b1(256);
+  HIPCHK(h, hipEventRecord(h->ev0, st));
+  double acc[4] = {0, 0, 0, 0};
+  // sum e, sum e^2 (draw_w0's numerator; draw_alpha's statistic for the caller)
+  HIPCHK(h, hipMemsetAsync(h->acc, 0, 4 * sizeof(double), st));
+  hipLaunchKernelGGL(k_als_sum_e, g1, b1, 0, st, a.e, N, h->acc);
+  HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+  double w0 = 0;
+  HIPCHK(h, hipMemcpyAsync(&w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (stats) stats->sum_e_sqr = acc[1];
+  std::mt19937_64 rng(opts->seed * 0x9E3779B97F4A7C15ull + a.iter + 1);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  if (h->cfg.k0) {                                         // draw_w0, fm_learn_mcmc.h:643-683 (w0_mean_0 = 0)
+    double mean = acc[0] - (double)N * w0;
+    const double sigma_sqr = 1.0 / (h->cfg.reg0 + opts->alpha * (double)N);
+    mean = -sigma_sqr * (opts->alpha * mean - 0.0 * h->cfg.reg0);
+    double nw0 = opts->do_sample ? mean + std::sqrt(sigma_sqr) * nd(rng) : mean;
+    if (!(std::isnan(nw0) || std::isinf(nw0))) {
+      HIPCHK(h, hipMemcpyAsync(h->w0, &nw0, sizeof(double), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_als_add_const, g1, b1, 0, st, a.e, N, nw0 - w0);
+      HIPCHK(h, hipStreamSynchronize(st));                 // nw0 lives on this stack frame
+    }
+  }
+  const uint32_t nseg = s.nseg, nnz = (uint32_t)s.nnz;
+  const dim3 gu((uint32_t)std::min<uint64_t>((h->n_local + 255) / 256, 2048));
+  if (h->cfg.k1) {                                         // draw_w per level, :454-476
+    for (uint32_t l = 0; l < n_levels; l++) {
+      const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
+      if (!cnt) continue;
+      FMX_LAUNCH_WAVES((k_als_draw<false>), cnt, st, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                       h->tb.w, h->tb.ws, a.e, (double*)nullptr, opts->alpha, opts->w_lambda, opts->w_mu, opts->do_sample,
+                       opts->seed, (uint64_t)(a.iter * 1024 + 1000));
+    }
+    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.w, h->tb.ws, opts->w_lambda, opts->w_mu,
+                       opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 1001));
+  }
+  for (int f = 0; f < h->cfg.num_factor; f++) {            // per factor: q_f is ready (k_als_eterms), draw_v per level :528-595
+    double* qf = a.q + (size_t)f * N;
+    for (uint32_t l = 0; l < n_levels; l++) {
+      const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
+      if (!cnt) continue;
+      FMX_LAUNCH_WAVES((k_als_draw<true>), cnt, st, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                       h->tb.V + f, h->tb.rs, a.e, qf, opts->alpha, opts->v_lambda, opts->v_mu, opts->do_sample,
+                       opts->seed, (uint64_t)(a.iter * 1024 + f));
+    }
+    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.V + f, h->tb.rs, opts->v_lambda, opts->v_mu,
+                       opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 512 + f));
+  }
+  HIPCHK(h, hipGetLastError());
+  // full re-prediction (fm_learn_mcmc_simultaneous.h:122), train metric and new residuals (:139-196)
+  int rc = als_eterms(h, s, a.e, a.q);
+  if (rc) return rc;
+  HIPCHK(h, hipMemsetAsync(h->acc, 0, 4 * sizeof(double), st));
+  hipLaunchKernelGGL(k_als_targets, g1, b1, 0, st, a.e, s.target, N, h->cfg.task, h->cfg.min_target, h->cfg.max_target, h->acc);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, st));
+  HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  a.iter++;
+  if (stats) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    stats->device_seconds = ms * 1e-3;
+    stats->levels = n_levels;
+    stats->train_metric = (h->cfg.task == FMX_TASK_REGRESSION) ? std::sqrt(acc[0] / N) : acc[0] / N;
   }
   return FMX_OK;
 }

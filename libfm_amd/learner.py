@@ -152,3 +152,81 @@ class FMLearnSGD:
         if self._h is not None:
             self._h.close()
             self._h = None
+
+
+def _ref_erf(x):
+    """the reference's 5-term erf polynomial (random.h:45-59), vectorised."""
+    x = np.asarray(x, dtype=np.float64)
+    t = np.where(x >= 0, 1.0 / (1.0 + 0.3275911 * x), 1.0 / (1.0 - 0.3275911 * x))
+    r = 1.0 - (t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429))))) * np.exp(-x * x)
+    return np.where(x >= 0, r, -r)
+
+
+def cdf_gaussian(x):
+    """random.h:65-67"""
+    return 0.5 + 0.5 * _ref_erf(0.707106781 * np.asarray(x, dtype=np.float64))
+
+
+class FMLearnALS:
+    """fm_learn_mcmc_simultaneous with do_sample = 0, do_multilevel = 0 -- what `-method als` runs
+    (libfm.cpp:135-139, 283-290) -- on the GPU.  Fields follow fm_learn_mcmc (fm_learn_mcmc.h:60-88):
+    fm, min_target, max_target, task, num_iter; w_lambda / v_lambda are set from -regular like libfm.cpp:326-365
+    (one attribute group)."""
+
+    def __init__(self):
+        self.fm = None
+        self.min_target = self.max_target = 0.0
+        self.task = TASK_REGRESSION
+        self.num_iter = 100
+        self.w_lambda = 0.0
+        self.v_lambda = 0.0
+        self.do_sample = False
+        self.seed = 0
+        self.device = -1
+        self.out = sys.stdout
+        self.pred_this = None          # fm_learn_mcmc.h:116
+        self.pred_sum_all = None       # fm_learn_mcmc.h:114
+        self.log = []
+        self._h = None
+
+    def init(self):
+        fm = self.fm
+        self._h = capi.Handle(fm.num_attribute, fm.num_factor, fm.k0, fm.k1, self.task, fm.reg0, fm.regw, fm.regv,
+                              0.0, self.min_target, self.max_target, device=self.device)
+        self._h.set_params(fm.w0, fm.w, fm.v)
+
+    # fm_learn_mcmc::learn + _learn (fm_learn_mcmc.h:1160-1201, fm_learn_mcmc_simultaneous.h:56-270)
+    def learn(self, train, test):
+        h = self._h
+        h.upload_rows(0, train.entries, train.row_ptr, train.target)
+        h.upload_rows(1, test.entries, test.row_ptr, test.target)
+        self.pred_sum_all = np.zeros(test.num_cases)
+        h.als_begin(0)
+        for i in range(self.num_iter):
+            st = h.als_sweep(self.w_lambda, self.v_lambda, 1.0, 0.0, 0.0, self.do_sample, self.seed)
+            p = h.predict(1, test.num_cases)
+            if self.task == TASK_REGRESSION:                  # :127-138
+                self.pred_this = p
+                self.pred_sum_all += np.maximum(self.min_target, np.minimum(self.max_target, p))
+                rmse_test = float(np.sqrt(np.mean((self.pred_sum_all / (i + 1) - test.target) ** 2)))
+                print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, st.train_metric, rmse_test), file=self.out)
+            else:                                             # :151-161
+                self.pred_this = cdf_gaussian(p)
+                self.pred_sum_all += self.pred_this
+                acc = float(np.mean(((self.pred_sum_all / (i + 1)) >= 0.5) == (test.target >= 0)))
+                print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, st.train_metric, acc), file=self.out)
+            self.log.append({"train": st.train_metric, "time_learn": st.device_seconds, "levels": st.levels})
+        h.als_end()
+        self.fm.w0, self.fm.w, self.fm.v = h.get_params(self.fm.w, self.fm.v)
+
+    # fm_learn_mcmc::predict (fm_learn_mcmc.h:380-404)
+    def predict(self, data):
+        out = self.pred_sum_all / self.num_iter if self.do_sample else self.pred_this.copy()
+        if self.task == TASK_REGRESSION:
+            return np.maximum(self.min_target, np.minimum(self.max_target, out))
+        return np.maximum(0.0, np.minimum(1.0, out))
+
+    def close(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None

@@ -116,22 +116,30 @@ typedef struct { double e, q; } fmo_eq;   /* e_q_term, fm_learn_mcmc.h:46-49 */
 /* build X^T from X (Data::create_data_t, Data.h:292-341); caller frees *entries_t, *col_ptr */
 void fmo_transpose(const fmo_data *d, uint64_t n, fmo_entry **entries_t, uint64_t **col_ptr);
 
-/* predict_data_and_write_to_eterms, non-relational part (fm_learn_mcmc.h:148-378): cache[c].e = y-hat(c) */
+/* predict_data_and_write_to_eterms, non-relational part (fm_learn_mcmc.h:148-378): cache[c].e = y-hat(c),
+ * cache[c].q = 0, computed through X^T in the reference's pass order (k passes of q, k passes of -0.5 v^2 x^2,
+ * one linear pass, then + w0).  dt may describe fewer features than the model (a test set). */
 void fmo_als_predict_eterms(const fmo_model *m, const fmo_data_t *dt, fmo_eq *cache);
 
-/* one ALS sweep = draw_all with do_sample=0, do_multilevel=0 (fm_learn_mcmc.h:430-641):
- * draw_w0 (:643-683), draw_w (:685-732) for every feature, then per factor add_main_q (:406-428)
- * + draw_v (:792-847).  cache[c].e must hold (y-hat - y) on entry and holds it on exit.
- * alpha=1, mu=0, lambdas = reg (fm_learn_mcmc.h:1099-1125 with libfm.cpp:326-365). */
-void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache,
-                   double w0_lambda_unused, double w_lambda, double v_lambda);
+/* one sweep = draw_all with do_sample = 0, do_multilevel = 0 (fm_learn_mcmc.h:430-641): alpha = alpha_0 = 1,
+ * mu = mu_0 = 0; draw_w0 (:643-683) with reg = m->reg0; draw_w (:685-732) for every feature in X^T row order
+ * with lambda = w_lambda, features without a training column get the empty-row draw (:467-476); per factor
+ * add_main_q (:406-428) then draw_v (:792-847) with lambda = v_lambda.  cache[c].e holds (y-hat - target). */
+void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, double w_lambda, double v_lambda);
 
-/* full ALS iteration loop of fm_learn_mcmc_simultaneous::_learn for task regression with
- * do_sample = 0 (fm_learn_mcmc_simultaneous.h:56-150): returns after num_iter sweeps with the
- * model updated; test predictions (last iterate, clamped) written to test_pred if non-NULL. */
-void fmo_als_learn(fmo_model *m, const fmo_data *train, const fmo_data *test, int num_iter,
+/* fm_learn_mcmc::learn + fm_learn_mcmc_simultaneous::_learn with do_sample = 0 (fm_learn_mcmc.h:1160-1201,
+ * fm_learn_mcmc_simultaneous.h:56-270): num_iter sweeps, e recomputed after each.  task regression: e -= y;
+ * classification: e -= E[truncated normal] (:172-194, with the reference's 3.141 and its erf polynomial,
+ * random.h:45-67).  Outputs (any may be NULL): test_pred_this[n_test] = pred_this of the last iteration
+ * (unclamped y-hat for regression, cdf_gaussian(y-hat) for classification), train_metric[num_iter] =
+ * rmse_train / acc_train per iteration. */
+void fmo_als_learn(fmo_model *m, const fmo_data *train, const fmo_data *test, int task, int num_iter,
                    double w_lambda, double v_lambda, double min_target, double max_target,
-                   double *test_pred);
+                   double *test_pred_this, double *train_metric);
+
+/* the reference's 5-term erf polynomial and cdf_gaussian (random.h:45-67) */
+double fmo_erf(double x);
+double fmo_cdf_gaussian(double x);
 
 /* ---------------- synthetic workload (shared definition with the HIP generator) ---------------- */
 

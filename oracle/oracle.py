@@ -65,6 +65,8 @@ def lib():
         L.fmo_synth_id.restype = C.c_uint32
         L.fmo_init_value.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double]
         L.fmo_init_value.restype = C.c_double
+        L.fmo_als_learn.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.POINTER(_Data), C.c_int, C.c_int, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.fmo_fill_params.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_double, C.c_int]
         L.fmo_time_sgd_synth.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_double]
         L.fmo_time_sgd_synth.restype = C.c_double
@@ -242,3 +244,14 @@ def time_sgd_synth(n, k, nnz, n_rows, seed=123, stdev=0.01, lr=0.01, regv=0.001,
     lib().fmo_fill_params(C.byref(cm), seed, stdev, threads)
     sec = lib().fmo_time_sgd_synth(C.byref(cm), seed, row0, n_rows, nnz, TASK_CLASSIFICATION, lr)
     return sec, n_rows / sec
+
+
+def als_learn(m, train, test, task, num_iter, w_lambda, v_lambda, min_target, max_target):
+    """fm_learn_mcmc with do_sample = 0 (ALS).  Returns (pred_this on test of the last iteration, train metric per iteration)."""
+    pred = np.zeros(test.n_rows, dtype=np.float64)
+    metric = np.zeros(num_iter, dtype=np.float64)
+    cm, ctr, cte = m._c(), train._c(), test._c()
+    lib().fmo_als_learn(C.byref(cm), C.byref(ctr), C.byref(cte), task, num_iter, w_lambda, v_lambda, min_target, max_target,
+                        pred.ctypes.data, metric.ctypes.data)
+    m.w0 = cm.w0
+    return pred, metric

@@ -49,8 +49,52 @@ CASES = {
 }
 
 
+ALS_CASES = {
+    "als_reg_ml": dict(gen="movielens_shaped", train=dict(n_users=120, n_items=80, n_rows=600, seed=11),
+                       test=dict(n_users=120, n_items=80, n_rows=150, seed=12),
+                       cfg=dict(task="r", k0=1, k1=1, k=8, iters=4, reg=(0.0, 1.0, 5.0), init_stdev=0.1, seed=42)),
+    "als_cls_ragged": dict(gen="ragged_real", train=dict(n_features=150, n_rows=300, max_nnz=8, seed=21, empty_every=50),
+                           test=dict(n_features=160, n_rows=80, max_nnz=8, seed=22),
+                           cfg=dict(task="c", k0=1, k1=1, k=4, iters=3, reg=(0.5, 2.0, 8.0), init_stdev=0.05, seed=7)),
+    "als_reg_fields_k16": dict(gen="onehot_fields", train=dict(n_features=480, nnz=6, n_rows=400, seed=41, classification=False),
+                               test=dict(n_features=480, nnz=6, n_rows=100, seed=42, classification=False),
+                               cfg=dict(task="r", k0=1, k1=1, k=16, iters=3, reg=(0.0, 0.5, 10.0), init_stdev=0.1, seed=1)),
+    "als_reg_nolin_dup": dict(gen="ragged_real", train=dict(n_features=60, n_rows=150, max_nnz=6, seed=51, duplicates=True, classification=False),
+                              test=dict(n_features=60, n_rows=40, max_nnz=6, seed=52, classification=False),
+                              cfg=dict(task="r", k0=0, k1=0, k=3, iters=2, reg=(0.0, 0.0, 2.0), init_stdev=0.1, seed=5)),
+}
+
+
+def make_als():
+    for name, case in ALS_CASES.items():
+        gen = getattr(datagen, case["gen"])
+        tr = O.Data(*gen(**case["train"]))
+        te = O.Data(*gen(**case["test"]))
+        cfg = case["cfg"]
+        with tempfile.TemporaryDirectory() as td:
+            trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
+            tr.write_libsvm(trf)
+            te.write_libsvm(tef)
+            O.run_ref_harness(["als", trf, tef, cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"],
+                               repr(cfg["reg"][0]), repr(cfg["reg"][1]), repr(cfg["reg"][2]), repr(cfg["init_stdev"]),
+                               cfg["seed"], pre])
+            init = O.Model.from_dump(pre + ".init.bin")
+            final = O.Model.from_dump(pre + ".final.bin")
+            pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            train_entries=tr.entries, train_row_ptr=tr.row_ptr, train_target=tr.target,
+            test_entries=te.entries, test_row_ptr=te.row_ptr, test_target=te.target,
+            task=cfg["task"], k0=cfg["k0"], k1=cfg["k1"], k=cfg["k"], iters=cfg["iters"], lr=0.0,
+            reg=np.array(cfg["reg"]), init_stdev=cfg["init_stdev"], seed=cfg["seed"],
+            n=init.n, init_w0=init.w0, init_w=init.w, init_v=init.v,
+            final_w0=final.w0, final_w=final.w, final_v=final.v, pred_out=pred_out)
+        print("%-22s n=%d k=%d rows=%d/%d  pred_out[:3]=%s" % (name, init.n, init.k, tr.n_rows, te.n_rows, pred_out[:3]))
+
+
 def main():
     O.build()
+    make_als()
     for name, case in CASES.items():
         gen = getattr(datagen, case["gen"])
         tr = O.Data(*gen(**case["train"]))
