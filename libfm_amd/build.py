@@ -9,7 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "fmx_api.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "fmx_kernels.h"), os.path.join(ROOT, "include", "fmx.h")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "fmx_kernels.h"), os.path.join(HERE, "csrc", "fmx_als_kernels.h"),
+              os.path.join(ROOT, "include", "fmx.h")]
 OUT = os.path.join(HERE, "libfmx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",

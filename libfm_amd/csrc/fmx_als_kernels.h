@@ -188,26 +188,33 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
     const double d = th - (double)ntf;                             // theta_old - theta (of the STORED value)
     if (lane == 0) *pt = ntf;
     if (d != 0.0) {
+      // update e (and q): one lane per (row, run of occurrences).  A row holding this feature more than once has its
+      // occurrences adjacent (the sort is stable in row order); the first one walks the run sequentially exactly
+      // like the reference loop (:839-846: q is updated between the occurrences), the others skip.  Rows are
+      // disjoint between lanes and between the wavefronts of a level, so plain read-modify-writes suffice.
       for (uint32_t i = a + lane; i < b; i += 64) {
         const TEntry te = t_ent[i];
-        const double x = (double)te.x;
+        if (i > a && t_ent[i - 1].e == te.e) continue;
+        double ec = e[te.e];
         if (IS_V) {
-          // a row that holds this feature more than once (entries adjacent: the sort is stable in row order):
-          // the reference updates q between the occurrences (:839-846), so the later one sees q - x_prev * d
           double qc = q[te.e];
-          for (uint32_t ib = i; ib > a && t_ent[ib - 1].e == te.e; ib--) qc -= (double)t_ent[ib - 1].x * d;
-          const double h = x * (qc - x * th);
-          unsafeAtomicAdd(e + te.e, -h * d);                     // atomics: two lanes may hit the same row
+          for (uint32_t i2 = i; i2 < b; i2++) {
+            const TEntry t2 = t_ent[i2];
+            if (t2.e != te.e) break;
+            const double x = (double)t2.x;
+            const double h = x * (qc - x * th);
+            qc -= x * d;
+            ec -= h * d;
+          }
+          q[te.e] = qc;
         } else {
-          unsafeAtomicAdd(e + te.e, -x * d);
+          for (uint32_t i2 = i; i2 < b; i2++) {
+            const TEntry t2 = t_ent[i2];
+            if (t2.e != te.e) break;
+            ec -= (double)t2.x * d;
+          }
         }
-      }
-      if (IS_V) {
-        // q must be updated after every lane has read it for h (same wavefront: the loop above has completed)
-        for (uint32_t i = a + lane; i < b; i += 64) {
-          const TEntry te = t_ent[i];
-          unsafeAtomicAdd(q + te.e, -(double)te.x * d);
-        }
+        e[te.e] = ec;
       }
     }
   }

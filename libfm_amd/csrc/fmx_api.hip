@@ -1009,6 +1009,7 @@ int fmx_als_begin(fmx_handle h, int train_slot) {
     uint32_t l = 0;
     for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) l = std::max(l, rowlevel[tent[i].e]);
     l += 1;
+    if (getenv("FMX_ALS_SEQUENTIAL")) l = sg + 1;      // debugging aid: one feature per level (the reference's order, serial)
     for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) rowlevel[tent[i].e] = l;
     lvl[sg] = l - 1;
     n_levels = std::max(n_levels, l);
