@@ -196,6 +196,8 @@ typedef struct fmx_als_opts {
   int32_t  do_sample;       /* 0 = ALS, 1 = Gibbs draws */
   int32_t  reserved;
   uint64_t seed;
+  const double *v_mu_f;     /* optional per-factor prior means v_mu(g=0,f) [num_factor]  (fm_learn_mcmc.h:76); NULL = v_mu */
+  const double *v_lambda_f; /* optional per-factor prior precisions v_lambda(g=0,f);              NULL = v_lambda */
 } fmx_als_opts;
 
 typedef struct fmx_als_stats {
@@ -207,6 +209,12 @@ typedef struct fmx_als_stats {
 } fmx_als_stats;
 
 int fmx_als_begin(fmx_handle h, int train_slot);
+/* statistics the hyper-prior draws need (draw_alpha :911-939, draw_w_mu/_lambda :941-1017, draw_v_mu/_lambda
+ * :1019-1097), reduced on the device in fp64:
+ *   out[0] = sum_c e_c^2 over the train rows (current residuals), out[1] = sum_c e_c,
+ *   out[2] = sum_j w_j, out[3] = sum_j w_j^2, then for f = 0..k-1: out[4+2f] = sum_j v_fj, out[5+2f] = sum_j v_fj^2.
+ * out must hold 4 + 2*num_factor doubles. */
+int fmx_als_moments(fmx_handle h, double *out);
 int fmx_als_sweep(fmx_handle h, const fmx_als_opts *opts, fmx_als_stats *stats);
 int fmx_als_end(fmx_handle h);
 

@@ -51,7 +51,8 @@ class Eval(C.Structure):
 
 class AlsOpts(C.Structure):
     _fields_ = [("alpha", C.c_double), ("w_mu", C.c_double), ("w_lambda", C.c_double), ("v_mu", C.c_double),
-                ("v_lambda", C.c_double), ("do_sample", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64)]
+                ("v_lambda", C.c_double), ("do_sample", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
+                ("v_mu_f", C.c_void_p), ("v_lambda_f", C.c_void_p)]
 
 
 class AlsStats(C.Structure):
@@ -89,6 +90,7 @@ SYMBOLS = [
     ("fmx_sgd_finish", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(SgdOpts), C.c_void_p]),
     ("fmx_predict_finish", C.c_int, [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("fmx_als_begin", C.c_int, [H, C.c_int]),
+    ("fmx_als_moments", C.c_int, [H, C.c_void_p]),
     ("fmx_als_sweep", C.c_int, [H, C.POINTER(AlsOpts), C.POINTER(AlsStats)]),
     ("fmx_als_end", C.c_int, [H]),
     ("fmx_get_info", C.c_int, [H, C.POINTER(Info)]),
@@ -240,8 +242,16 @@ class Handle:
     def als_begin(self, train_slot):
         self._chk(self.lib.fmx_als_begin(self.h, train_slot))
 
+    def als_moments(self):
+        out = np.zeros(4 + 2 * self.k, dtype=np.float64)
+        self._chk(self.lib.fmx_als_moments(self.h, _ptr(out)))
+        return out
+
     def als_sweep(self, w_lambda, v_lambda, alpha=1.0, w_mu=0.0, v_mu=0.0, do_sample=False, seed=0):
-        opts = AlsOpts(alpha, w_mu, w_lambda, v_mu, v_lambda, int(do_sample), 0, seed)
+        """v_lambda / v_mu may be scalars or per-factor arrays (fm_learn_mcmc.h:76)."""
+        vl = np.ascontiguousarray(np.broadcast_to(np.asarray(v_lambda, dtype=np.float64), (max(self.k, 1),)))
+        vm = np.ascontiguousarray(np.broadcast_to(np.asarray(v_mu, dtype=np.float64), (max(self.k, 1),)))
+        opts = AlsOpts(alpha, w_mu, w_lambda, float(vm[0]), float(vl[0]), int(do_sample), 0, seed, _ptr(vm), _ptr(vl))
         st = AlsStats()
         self._chk(self.lib.fmx_als_sweep(self.h, C.byref(opts), C.byref(st)))
         return st

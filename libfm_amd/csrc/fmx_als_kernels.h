@@ -90,13 +90,42 @@ __global__ void k_als_sub_target(double* __restrict__ e, const float* __restrict
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) e[c] -= (double)target[c];
 }
 
+// counter-based uniforms / normals for the Gibbs variant (statistical, not bitwise, parity with libc rand())
+__device__ __forceinline__ double unif_hash(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t attempt) {
+  const uint64_t hh = mix64(seed ^ (stream * 0x9E3779B97F4A7C15ULL) ^ (idx * 0xD6E8FEB86659FD93ULL + attempt * 0xA24BAED4963EE407ULL + 0x9FB21C651E98DF25ULL));
+  return ((double)(hh >> 11) + 0.5) * (1.0 / 9007199254740992.0);     // (0,1)
+}
+__device__ __forceinline__ double gauss_hash2(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t attempt) {
+  const double u1 = unif_hash(seed, stream, idx, 2 * attempt), u2 = unif_hash(seed, stream, idx, 2 * attempt + 1);
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+// ran_left_tgaussian(left): standard normal conditioned on z >= left (random.h:70-101): naive rejection for
+// left <= 0, Robert's translated-exponential rejection otherwise.  Bounded loops (64 attempts) for safety.
+__device__ __forceinline__ double left_tgauss(double left, uint64_t seed, uint64_t stream, uint64_t idx) {
+  if (left <= 0.0) {
+    double r = 0.0;
+    for (uint32_t a = 0; a < 64; a++) { r = gauss_hash2(seed, stream, idx, a); if (r >= left) return r; }
+    return fmax(r, left);
+  }
+  const double alpha_star = 0.5 * (left + sqrt(left * left + 4.0));
+  double zz = left;
+  for (uint32_t a = 0; a < 64; a++) {
+    zz = -log(1.0 - unif_hash(seed, stream, idx, 2 * a)) / alpha_star + left;
+    double d = zz - alpha_star;
+    d = exp(-(d * d) / 2);
+    if (unif_hash(seed, stream, idx, 2 * a + 1) < d) return zz;
+  }
+  return zz;
+}
+
 // after a sweep, e holds y-hat: accumulate the train metric and turn e back into the residual
 //   regression    (_learn :139-150): rmse over clamped predictions, e -= y
 //   classification(_learn :163-196): accuracy of cdf_gaussian(e) vs sign, e -= E[truncated normal] (do_sample = 0)
 // acc[0] = sum err^2 / #correct
 __global__ void __launch_bounds__(256)
 k_als_targets(double* __restrict__ e, const float* __restrict__ target, uint32_t n, int task,
-              double min_target, double max_target, double* __restrict__ acc) {
+              double min_target, double max_target, double* __restrict__ acc,
+              int do_sample, uint64_t seed, uint64_t stream) {
   double s = 0.0;
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
     const double yh = e[c];
@@ -110,9 +139,15 @@ k_als_targets(double* __restrict__ e, const float* __restrict__ target, uint32_t
     } else {
       const double p = ref_cdf_gaussian(yh);
       if (((p >= 0.5) && (y > 0.0)) || ((p < 0.5) && (y < 0.0))) s += 1.0;
-      const double phi_minus_mu = exp(-yh * yh / 2.0) / sqrt(3.141 * 2);       // sic: 3.141 (:179,:189)
-      const double Phi_minus_mu = ref_cdf_gaussian(-yh);
-      const double st = (y >= 0.0) ? yh + phi_minus_mu / (1 - Phi_minus_mu) : yh - phi_minus_mu / Phi_minus_mu;
+      double st;
+      if (do_sample) {                                                        // :172-175, :184-186
+        // ran_left_tgaussian(0, mu, 1) = mu + ltg(-mu);  ran_right_tgaussian(0, mu, 1) = mu - ltg(mu)   (random.h:99-112)
+        st = (y >= 0.0) ? yh + left_tgauss(-yh, seed, stream, c) : yh - left_tgauss(yh, seed, stream, c);
+      } else {
+        const double phi_minus_mu = exp(-yh * yh / 2.0) / sqrt(3.141 * 2);     // sic: 3.141 (:179,:189)
+        const double Phi_minus_mu = ref_cdf_gaussian(-yh);
+        st = (y >= 0.0) ? yh + phi_minus_mu / (1 - Phi_minus_mu) : yh - phi_minus_mu / Phi_minus_mu;
+      }
       e[c] = yh - st;
     }
   }
@@ -130,6 +165,18 @@ k_als_sum_e(const double* __restrict__ e, uint32_t n, double* __restrict__ acc) 
 }
 __global__ void k_als_add_const(double* __restrict__ e, uint32_t n, double d) {
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) e[c] += d;
+}
+
+// sum_j theta_j and sum_j theta_j^2 of one coordinate family (w: param = tb.w, stride ws; v_f: param = tb.V + f, stride rs)
+__global__ void __launch_bounds__(256)
+k_param_moments(const float* __restrict__ param, uint32_t pstride, uint64_t n_local, double* __restrict__ out2) {
+  double s = 0.0, s2 = 0.0;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_local; j += (uint64_t)gridDim.x * blockDim.x) {
+    const double t = (double)param[(size_t)j * pstride];
+    s += t; s2 += t * t;
+  }
+  s = wave_sum_f64(s); s2 = wave_sum_f64(s2);
+  if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(out2, s); unsafeAtomicAdd(out2 + 1, s2); }
 }
 
 // counter-based N(0,1) for the sampling variant (MCMC): Box-Muller on two splitmix64 hashes of (seed, stream, index)

@@ -1036,6 +1036,31 @@ int fmx_als_begin(fmx_handle h, int train_slot) {
   return FMX_OK;
 }
 
+int fmx_als_moments(fmx_handle h, double* out) {
+  if (!h || !out) return FMX_E_ARG;
+  AlsState& a = h->als;
+  if (a.slot < 0) return fail(h, FMX_E_STATE, "fmx_als_moments before fmx_als_begin");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[a.slot];
+  const int k = h->cfg.num_factor;
+  const size_t cnt = 4 + 2 * (size_t)k;
+  double* d = nullptr;
+  HIPCHK(h, hipMalloc(&d, cnt * sizeof(double)));
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipMemsetAsync(d, 0, cnt * sizeof(double), st));
+  const dim3 b1(256), ge(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), gp((uint32_t)std::min<uint64_t>((h->n_local + 255) / 256, 2048));
+  hipLaunchKernelGGL(k_als_sum_e, ge, b1, 0, st, a.e, s.n_rows, d);            // d[0] = sum e, d[1] = sum e^2
+  hipLaunchKernelGGL(k_param_moments, gp, b1, 0, st, h->tb.w, h->tb.ws, h->n_local, d + 2);
+  for (int f = 0; f < k; f++) hipLaunchKernelGGL(k_param_moments, gp, b1, 0, st, h->tb.V + f, h->tb.rs, h->n_local, d + 4 + 2 * f);
+  hipError_t er = hipGetLastError();
+  if (er == hipSuccess) er = hipMemcpyAsync(out, d, cnt * sizeof(double), hipMemcpyDeviceToHost, st);
+  if (er == hipSuccess) er = hipStreamSynchronize(st);
+  hipFree(d);
+  if (er != hipSuccess) return fail(h, FMX_E_HIP, "fmx_als_moments: %s", hipGetErrorString(er));
+  std::swap(out[0], out[1]);                                                   // documented order: sum e^2 first
+  return FMX_OK;
+}
+
 int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) {
   if (!h || !opts) return FMX_E_ARG;
   AlsState& a = h->als;
@@ -1084,14 +1109,16 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
   }
   for (int f = 0; f < h->cfg.num_factor; f++) {            // per factor: q_f is ready (k_als_eterms), draw_v per level :528-595
     double* qf = a.q + (size_t)f * N;
+    const double v_lambda = opts->v_lambda_f ? opts->v_lambda_f[f] : opts->v_lambda;
+    const double v_mu = opts->v_mu_f ? opts->v_mu_f[f] : opts->v_mu;
     for (uint32_t l = 0; l < n_levels; l++) {
       const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
       if (!cnt) continue;
       FMX_LAUNCH_WAVES((k_als_draw<true>), cnt, st, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                       h->tb.V + f, h->tb.rs, a.e, qf, opts->alpha, opts->v_lambda, opts->v_mu, opts->do_sample,
+                       h->tb.V + f, h->tb.rs, a.e, qf, opts->alpha, v_lambda, v_mu, opts->do_sample,
                        opts->seed, (uint64_t)(a.iter * 1024 + f));
     }
-    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.V + f, h->tb.rs, opts->v_lambda, opts->v_mu,
+    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.V + f, h->tb.rs, v_lambda, v_mu,
                        opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 512 + f));
   }
   HIPCHK(h, hipGetLastError());
@@ -1099,7 +1126,8 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
   int rc = als_eterms(h, s, a.e, a.q);
   if (rc) return rc;
   HIPCHK(h, hipMemsetAsync(h->acc, 0, 4 * sizeof(double), st));
-  hipLaunchKernelGGL(k_als_targets, g1, b1, 0, st, a.e, s.target, N, h->cfg.task, h->cfg.min_target, h->cfg.max_target, h->acc);
+  hipLaunchKernelGGL(k_als_targets, g1, b1, 0, st, a.e, s.target, N, h->cfg.task, h->cfg.min_target, h->cfg.max_target, h->acc,
+                     opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 1002));
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, st));
   HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, st));

@@ -230,3 +230,69 @@ class FMLearnALS:
         if self._h is not None:
             self._h.close()
             self._h = None
+
+
+class FMLearnMCMC(FMLearnALS):
+    """fm_learn_mcmc_simultaneous with do_sample = 1, do_multilevel = 1 -- `-method mcmc` (libfm.cpp:283-290).
+
+    The coordinate draws run on the GPU (fmx_als_sweep with do_sample = 1); the hyper-prior draws are scalar work
+    and stay on the host, in the reference's order (draw_all, fm_learn_mcmc.h:430-527): alpha (:911-939), w_lambda
+    (:985-1017), w_mu (:941-983), v_lambda (:1061-1097), v_mu (:1019-1059), from statistics reduced on the device
+    (fmx_als_moments).  Hyper-priors alpha_0 = gamma_0 = beta_0 = 1, mu_0 = 0 (:1106-1109).  Random numbers come
+    from numpy / a counter hash, not libc rand(): parity with the reference is statistical."""
+
+    def __init__(self):
+        super().__init__()
+        self.do_sample = True
+        self.do_multilevel = True
+        self.alpha_0 = self.gamma_0 = self.beta_0 = 1.0
+        self.mu_0 = 0.0
+
+    def learn(self, train, test):
+        h = self._h
+        rng = np.random.default_rng(self.seed)
+        k, n = self.fm.num_factor, self.fm.num_attribute
+        h.upload_rows(0, train.entries, train.row_ptr, train.target)
+        h.upload_rows(1, test.entries, test.row_ptr, test.target)
+        self.pred_sum_all = np.zeros(test.num_cases)
+        N = train.num_cases
+        alpha, w_mu, w_lambda = 1.0, 0.0, float(self.w_lambda)
+        v_mu, v_lambda = np.zeros(max(k, 1)), np.full(max(k, 1), float(self.v_lambda))
+        a0, g0, b0, m0 = self.alpha_0, self.gamma_0, self.beta_0, self.mu_0
+        h.als_begin(0)
+        for i in range(self.num_iter):
+            if self.do_multilevel:
+                mom = h.als_moments()
+                alpha = rng.gamma((a0 + N) / 2.0) / ((g0 + mom[0]) / 2.0)                      # draw_alpha :911-922
+                if self.fm.k1:
+                    sw, sw2 = mom[2], mom[3]
+                    gam = b0 * (w_mu - m0) ** 2 + g0 + (sw2 - 2 * w_mu * sw + n * w_mu * w_mu)   # draw_w_lambda :990-997
+                    w_lambda = rng.gamma((a0 + n + 1) / 2.0) / (gam / 2.0)
+                    mean = (sw + b0 * m0) / (n + b0)                                            # draw_w_mu :946-959
+                    w_mu = mean + rng.standard_normal() * np.sqrt(1.0 / ((n + b0) * w_lambda))
+                for f in range(k):
+                    sv, sv2 = mom[4 + 2 * f], mom[5 + 2 * f]
+                    gam = b0 * (v_mu[f] - m0) ** 2 + g0 + (sv2 - 2 * v_mu[f] * sv + n * v_mu[f] ** 2)   # :1066-1075
+                    v_lambda[f] = rng.gamma((a0 + n + 1) / 2.0) / (gam / 2.0)
+                for f in range(k):
+                    mean = (sv_f(mom, f) + b0 * m0) / (n + b0)                                   # :1024-1037
+                    v_mu[f] = mean + rng.standard_normal() * np.sqrt(1.0 / ((n + b0) * v_lambda[f]))
+            st = h.als_sweep(w_lambda, v_lambda, alpha, w_mu, v_mu, self.do_sample, self.seed * 7919 + 13)
+            p = h.predict(1, test.num_cases)
+            if self.task == TASK_REGRESSION:
+                self.pred_this = p
+                self.pred_sum_all += np.maximum(self.min_target, np.minimum(self.max_target, p))
+                metric = float(np.sqrt(np.mean((self.pred_sum_all / (i + 1) - test.target) ** 2)))
+            else:
+                self.pred_this = cdf_gaussian(p)
+                self.pred_sum_all += self.pred_this
+                metric = float(np.mean(((self.pred_sum_all / (i + 1)) >= 0.5) == (test.target >= 0)))
+            print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, st.train_metric, metric), file=self.out)
+            self.log.append({"train": st.train_metric, "test": metric, "alpha": alpha, "w_lambda": w_lambda,
+                             "time_learn": st.device_seconds})
+        h.als_end()
+        self.fm.w0, self.fm.w, self.fm.v = h.get_params(self.fm.w, self.fm.v)
+
+
+def sv_f(mom, f):
+    return mom[4 + 2 * f]

@@ -92,8 +92,53 @@ def make_als():
         print("%-22s n=%d k=%d rows=%d/%d  pred_out[:3]=%s" % (name, init.n, init.k, tr.n_rows, te.n_rows, pred_out[:3]))
 
 
+MCMC_CASES = {
+    "mcmc_reg_ml": dict(gen="movielens_shaped", train=dict(n_users=300, n_items=200, n_rows=6000, seed=11),
+                        test=dict(n_users=300, n_items=200, n_rows=1500, seed=11, _skip=6000),
+                        cfg=dict(task="r", k0=1, k1=1, k=8, iters=40, init_stdev=0.1, seed=42)),
+    "mcmc_cls_fields": dict(gen="onehot_fields", train=dict(n_features=600, nnz=6, n_rows=4000, seed=41),
+                            test=dict(n_features=600, nnz=6, n_rows=1000, seed=41, _skip=4000),
+                            cfg=dict(task="c", k0=1, k1=1, k=4, iters=40, init_stdev=0.1, seed=1)),
+}
+
+
+def make_mcmc():
+    """statistical fixtures: the reference's MCMC (libc rand() stream) on a train/test split of ONE planted model."""
+    for name, case in MCMC_CASES.items():
+        gen = getattr(datagen, case["gen"])
+        kw = dict(case["train"])
+        n_tr, n_te = kw["n_rows"], case["test"]["n_rows"]
+        kw["n_rows"] = n_tr + n_te
+        ent, rp, y = gen(**kw)
+        rp = rp.astype(np.int64)
+        tr = O.Data(ent[:rp[n_tr]], rp[:n_tr + 1], y[:n_tr])
+        te = O.Data(ent[rp[n_tr]:], rp[n_tr:] - rp[n_tr], y[n_tr:])
+        cfg = case["cfg"]
+        with tempfile.TemporaryDirectory() as td:
+            trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
+            tr.write_libsvm(trf)
+            te.write_libsvm(tef)
+            O.run_ref_harness(["mcmc", trf, tef, cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"],
+                               repr(cfg["init_stdev"]), cfg["seed"], pre])
+            init = O.Model.from_dump(pre + ".init.bin")
+            pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            train_entries=tr.entries, train_row_ptr=tr.row_ptr, train_target=tr.target,
+            test_entries=te.entries, test_row_ptr=te.row_ptr, test_target=te.target,
+            task=cfg["task"], k0=cfg["k0"], k1=cfg["k1"], k=cfg["k"], iters=cfg["iters"], lr=0.0,
+            reg=np.zeros(3), init_stdev=cfg["init_stdev"], seed=cfg["seed"],
+            n=init.n, init_w0=init.w0, init_w=init.w, init_v=init.v, pred_out=pred_out)
+        if cfg["task"] == "r":
+            print("%-22s n=%d rows=%d/%d test rmse of the reference's posterior mean: %.4f" % (name, init.n, tr.n_rows, te.n_rows, np.sqrt(np.mean((pred_out - te.target) ** 2))))
+        else:
+            yy = np.where(te.target > 0, 1, 0)
+            print("%-22s n=%d rows=%d/%d test accuracy of the reference's posterior mean: %.4f" % (name, init.n, tr.n_rows, te.n_rows, np.mean((pred_out >= 0.5) == (yy == 1))))
+
+
 def main():
     O.build()
+    make_mcmc()
     make_als()
     for name, case in CASES.items():
         gen = getattr(datagen, case["gen"])
