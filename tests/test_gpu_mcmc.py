@@ -3,7 +3,9 @@
 The reference draws from one sequential libc rand() stream with rejection loops (random.h); no parallel sampler
 can reproduce it bit-for-bit, so the bar is: same model, same hyper-priors, same data -> the posterior-mean test
 predictions of our chain agree with those of the reference's chain (fixtures produced by oracle/_ref/ref_harness
-mcmc, 40 iterations): test RMSE / accuracy within 3 % and prediction correlation >= 0.97."""
+mcmc, 40 iterations): test RMSE / accuracy within 3 % and a prediction correlation inside the band the REFERENCE
+shows against itself when only its -seed changes (measured with three other seeds: regression 0.986-0.990, rms
+difference 0.09-0.11; classification 0.967-0.972, rms difference 0.075-0.082)."""
 import io
 
 import numpy as np
@@ -42,8 +44,8 @@ def test_mcmc_regression_posterior_mean(oracle):
     rmse_ref = np.sqrt(np.mean((ref - y) ** 2))
     rmse = np.sqrt(np.mean((p - y) ** 2))
     assert abs(rmse - rmse_ref) < 0.03 * rmse_ref, (rmse, rmse_ref)
-    assert np.corrcoef(p, ref)[0, 1] > 0.97
-    assert np.sqrt(np.mean((p - ref) ** 2)) < 0.35 * rmse_ref      # chains differ by MC noise, well below the error
+    assert np.corrcoef(p, ref)[0, 1] > 0.975                 # reference vs reference (other seeds): 0.986-0.990
+    assert np.sqrt(np.mean((p - ref) ** 2)) < 0.14           # reference vs reference: 0.093-0.112
     assert all(np.isfinite(x["alpha"]) and x["alpha"] > 0 for x in l.log)
 
 
@@ -55,7 +57,8 @@ def test_mcmc_classification_posterior_mean(oracle):
     acc_ref = np.mean((ref >= 0.5) == (y > 0))
     acc = np.mean((p >= 0.5) == (y > 0))
     assert abs(acc - acc_ref) < 0.03, (acc, acc_ref)
-    assert np.corrcoef(p, ref)[0, 1] > 0.97
+    assert np.corrcoef(p, ref)[0, 1] > 0.955                 # reference vs reference (other seeds): 0.967-0.972
+    assert np.sqrt(np.mean((p - ref) ** 2)) < 0.10           # reference vs reference: 0.075-0.082
     assert (p >= 0).all() and (p <= 1).all()
 
 
