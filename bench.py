@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 65536 sharded); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=256)
+    ap.add_argument("--no-bias-lag", action="store_true", help="minibatch: keep the w0 recurrence on the critical path (exact chunk coupling)")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None, help="PMC HBM bytes per launch of the dominant kernel")
@@ -134,13 +135,14 @@ def main():
     apply_ = {"default": capi.APPLY_DEFAULT, "segmented": capi.APPLY_SEGMENTED, "atomic": capi.APPLY_ATOMIC,
               "store": capi.APPLY_STORE}[args.apply]
 
+    lagf = 0 if (args.no_bias_lag or args.mode == "hogwild") else capi.FLAG_BIAS_LAG
     if world == 1:
         batch = args.batch or (262144 if args.mode == "hogwild" else 16384)
         main_time, main_launches = 0.0, 0
 
         def step(timed):
             nonlocal main_time, main_launches
-            st = h.sgd_epoch(0, mode, apply_, batch, args.w0_chunk, capi.FLAG_TIME_MAIN_KERNEL if timed else 0)
+            st = h.sgd_epoch(0, mode, apply_, batch, args.w0_chunk, (capi.FLAG_TIME_MAIN_KERNEL if timed else 0) | lagf)
             if timed:
                 main_time += st.main_kernel_seconds
                 main_launches += st.main_kernel_launches
@@ -163,7 +165,7 @@ def main():
                     host = view.cpu()
                     dist.all_reduce(host)
                     view.copy_(host)
-                h.sgd_finish(0, row0, nb, view.data_ptr(), apply_, args.w0_chunk, stream, batch)
+                h.sgd_finish(0, row0, nb, view.data_ptr(), apply_, args.w0_chunk, stream, batch, lagf)
         rows_per_launch = min(batch, args.rows)
         kind = "apply"
         main_time, main_launches = 0.0, 0
@@ -209,7 +211,7 @@ def main():
             "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
-                       "w0_chunk": args.w0_chunk, "sharding": "features mod %d" % world if world > 1 else "none",
+                       "w0_chunk": args.w0_chunk, "bias_lag": bool(lagf), "sharding": "features mod %d" % world if world > 1 else "none",
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -93,6 +93,9 @@ typedef struct fmx_sgd_opts {
 } fmx_sgd_opts;
 
 #define FMX_FLAG_TIME_MAIN_KERNEL 1u  /* bracket every launch of the dominant kernel with HIP events */
+#define FMX_FLAG_BIAS_LAG 2u          /* MINIBATCH: the multipliers of a batch use the w0 of the batch START; w0 itself still
+                                         advances through the micro-chunk recurrence, which then runs on a side stream
+                                         overlapped with the next batch (oracle: fmo_sgd_epoch_minibatch_ex, bias_lag = 1) */
 
 typedef struct fmx_epoch_stats {
   uint64_t rows;            /* examples processed */

@@ -15,6 +15,7 @@ TASK_REGRESSION, TASK_CLASSIFICATION = 0, 1
 SGD_SEQUENTIAL, SGD_MINIBATCH, SGD_HOGWILD = 0, 1, 2
 APPLY_DEFAULT, APPLY_ATOMIC, APPLY_STORE, APPLY_SEGMENTED = 0, 1, 2, 3
 FLAG_TIME_MAIN_KERNEL = 1
+FLAG_BIAS_LAG = 2
 MAX_SLOTS = 8
 
 ENTRY_DTYPE = np.dtype([("id", np.uint32), ("value", np.float32)])   # sparse_entry<float>, fmatrix.h:34-37
@@ -231,8 +232,8 @@ class Handle:
     def sgd_partial(self, slot, row0, n_rows, d_partial_ptr, stream=None):
         self._chk(self.lib.fmx_sgd_partial(self.h, slot, row0, n_rows, d_partial_ptr, stream))
 
-    def sgd_finish(self, slot, row0, n_rows, d_partial_ptr, apply=APPLY_DEFAULT, w0_chunk=0, stream=None, batch=0):
-        opts = SgdOpts(SGD_MINIBATCH, apply, batch or n_rows, w0_chunk, 0, 0)
+    def sgd_finish(self, slot, row0, n_rows, d_partial_ptr, apply=APPLY_DEFAULT, w0_chunk=0, stream=None, batch=0, flags=0):
+        opts = SgdOpts(SGD_MINIBATCH, apply, batch or n_rows, w0_chunk, flags, 0)
         self._chk(self.lib.fmx_sgd_finish(self.h, slot, row0, n_rows, d_partial_ptr, C.byref(opts), stream))
 
     def predict_finish(self, n_rows, d_partial_ptr, d_yhat_ptr, stream=None):

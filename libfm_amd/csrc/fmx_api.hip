@@ -55,9 +55,16 @@ struct AlsState {
   uint64_t  iter = 0;
 };
 
+struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping: w0 lives in w0_pp[step & 1] while active
+  bool       active = false;
+  uint64_t   step = 0;
+  hipEvent_t ev_rest = nullptr, ev_scan[2] = {nullptr, nullptr};
+};
+
 struct fmx_context_s {
   fmx_config cfg;
   AlsState   als;
+  LagState   lag;
   int        KP = 1;
   uint64_t   n_local = 0;
   int        device = 0;
@@ -234,6 +241,7 @@ int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0,
 }  // namespace
 
 static void als_free(fmx_handle h);
+static int lag_flush(fmx_handle h);
 
 extern "C" {
 
@@ -332,6 +340,9 @@ int fmx_destroy(fmx_handle h) {
   if (h->rest) hipFree(h->rest);
   for (auto ev : h->ev_pool) hipEventDestroy(ev);
   for (auto ev : h->ev_sync) hipEventDestroy(ev);
+  if (h->lag.ev_rest) hipEventDestroy(h->lag.ev_rest);
+  if (h->lag.ev_scan[0]) hipEventDestroy(h->lag.ev_scan[0]);
+  if (h->lag.ev_scan[1]) hipEventDestroy(h->lag.ev_scan[1]);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -353,6 +364,7 @@ int fmx_get_info(fmx_handle h, fmx_info* out) {
 
 int fmx_synchronize(fmx_handle h) {
   if (!h) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return FMX_OK;
@@ -423,6 +435,7 @@ done:
 
 int fmx_set_params(fmx_handle h, double w0, const double* w, const double* v) {
   if (!h) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   if (h->cfg.num_factor > 0 && !v) return fail(h, FMX_E_ARG, "fmx_set_params: v is NULL but num_factor > 0");
   double w0c = w0;
   return stage_params(h, true, &w0c, const_cast<double*>(w), const_cast<double*>(v));
@@ -430,11 +443,13 @@ int fmx_set_params(fmx_handle h, double w0, const double* w, const double* v) {
 
 int fmx_get_params(fmx_handle h, double* w0, double* w, double* v) {
   if (!h || !w0) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   return stage_params(h, false, w0, w, v);
 }
 
 int fmx_get_w0(fmx_handle h, double* w0) {
   if (!h || !w0) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -443,6 +458,7 @@ int fmx_get_w0(fmx_handle h, double* w0) {
 
 int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t seed) {
   if (!h) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(k_init_params, dim3(256 * 8), dim3(256), 0, h->stream, h->tb, h->n_local,
                      h->cfg.num_factor, h->KP, h->cfg.shard_rank, h->cfg.shard_world, (float)init_mean, init_stdev, seed);
@@ -580,6 +596,7 @@ int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_
 int fmx_predict(fmx_handle h, int slot, double* out) {
   int rc = check_slot(h, slot, false);
   if (rc) return rc;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   if (!out) return fail(h, FMX_E_ARG, "fmx_predict: out is NULL");
   HIPCHK(h, hipSetDevice(h->device));
   const Slot& s = h->slots[slot];
@@ -603,6 +620,7 @@ int fmx_predict(fmx_handle h, int slot, double* out) {
 int fmx_evaluate(fmx_handle h, int slot, fmx_eval* out) {
   int rc = check_slot(h, slot, true);
   if (rc) return rc;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   if (!out) return fail(h, FMX_E_ARG, "fmx_evaluate: out is NULL");
   if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "fmx_evaluate on a feature shard: use fmx_sgd_partial + all-reduce + fmx_predict_finish");
   HIPCHK(h, hipSetDevice(h->device));
@@ -738,9 +756,58 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, rest, target, n_rows, chunk, hy,
                        w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
   } else if (mult) {
-    hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy, mult);
+    hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
+                       (const double*)nullptr, mult);
   }
   HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+// ---- FMX_FLAG_BIAS_LAG: the w0 recurrence of batch b runs on stream2 while the main stream goes on ------------
+static int lag_flush(fmx_handle h) {                      // make h->w0 the current bias again
+  LagState& L = h->lag;
+  if (!L.active) return FMX_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream2));
+  HIPCHK(h, hipMemcpy(h->w0, h->w0_pp + (L.step & 1), sizeof(double), hipMemcpyDeviceToDevice));
+  L.active = false; L.step = 0;
+  return FMX_OK;
+}
+// call BEFORE producing the rest buffer of this step on `st`; returns which of the two rest buffers to use
+static int lag_prepare(fmx_handle h, hipStream_t st, int* slot) {
+  LagState& L = h->lag;
+  if (!L.ev_rest) {
+    HIPCHK(h, hipEventCreateWithFlags(&L.ev_rest, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&L.ev_scan[0], hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&L.ev_scan[1], hipEventDisableTiming));
+  }
+  if (!L.active) {
+    HIPCHK(h, hipMemcpyAsync(h->w0_pp, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->w0_pp + 1, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+    L.active = true; L.step = 0;
+  } else {
+    HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[L.step & 1], 0));      // scan(step-2) is done with this buffer
+  }
+  *slot = (int)(L.step & 1);
+  return FMX_OK;
+}
+// call AFTER `rest` is complete on `st`: starts the recurrence on the side stream and leaves the multipliers of
+// this batch (batch-start bias) in h->mult on `st`
+static int lag_step(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
+                    const Hyper& hy, hipStream_t st) {
+  LagState& L = h->lag;
+  const uint64_t b = L.step;
+  if (hy.k0) {
+    HIPCHK(h, hipEventRecord(L.ev_rest, st));
+    HIPCHK(h, hipStreamWaitEvent(h->stream2, L.ev_rest, 0));
+    int rc = launch_scan(h, rest, target, n_rows, chunk, hy, nullptr, h->stream2, h->w0_pp + (b & 1), h->w0_pp + ((b + 1) & 1));
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(L.ev_scan[b & 1], h->stream2));
+    if (b >= 1) HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[(b + 1) & 1], 0));   // scan(b-1) wrote w0_pp[b & 1]
+  }
+  hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
+                     (const double*)(h->w0_pp + (b & 1)), h->mult);
+  HIPCHK(h, hipGetLastError());
+  L.step++;
   return FMX_OK;
 }
 
@@ -751,7 +818,9 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
                            hipEvent_t ev_a, hipEvent_t ev_b, int64_t seg_batch) {
   const Hyper hy = make_hyper(h->cfg);
   const uint32_t chunk = (opts && opts->w0_chunk) ? opts->w0_chunk : 256u;
-  int rc = launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
+  const bool lag = opts && (opts->flags & FMX_FLAG_BIAS_LAG);
+  int rc = lag ? lag_step(h, rest, s.target + row0, n_rows, chunk, hy, st)
+               : launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
   if (rc) return rc;
   int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
   if (apply == FMX_APPLY_DEFAULT) apply = FMX_APPLY_SEGMENTED;
@@ -790,12 +859,17 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   if (n_rows == 0) return FMX_OK;
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  rc = ensure_scratch(h, n_rows, n_rows);
+  const bool lag = opts && (opts->flags & FMX_FLAG_BIAS_LAG);
+  const uint32_t Bcap = (opts && opts->batch) ? std::max(opts->batch, n_rows) : n_rows;
+  rc = ensure_scratch(h, n_rows, (size_t)Bcap * 2);
   if (rc) return rc;
+  int rslot = 0;
+  if (lag) { rc = lag_prepare(h, st, &rslot); if (rc) return rc; } else { rc = lag_flush(h); if (rc) return rc; }
+  float* rest_buf = h->rest + (size_t)rslot * Bcap;
   const float* S = d_partial;
   const float* c = d_partial + (size_t)n_rows * h->KP;
   KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n_rows + Map<KP>::EPI - 1) / Map<KP>::EPI)),
-                                        dim3(256), 0, st, S, c, n_rows, h->rest));
+                                        dim3(256), 0, st, S, c, n_rows, rest_buf));
   HIPCHK(h, hipGetLastError());
   int64_t seg_batch = -1;
   const int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
@@ -808,11 +882,12 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
     if (rc) return rc;
     seg_batch = (int64_t)(row0 / B);
   }
-  return sgd_finish_impl(h, s, row0, n_rows, S, h->rest, opts, st, nullptr, nullptr, seg_batch);
+  return sgd_finish_impl(h, s, row0, n_rows, S, rest_buf, opts, st, nullptr, nullptr, seg_batch);
 }
 
 int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, float* d_yhat, void* stream) {
   if (!h || !d_partial || !d_yhat) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   if (n_rows == 0) return FMX_OK;
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
@@ -831,6 +906,7 @@ int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, fl
 int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats) {
   int rc = check_slot(h, slot, true);
   if (rc) return rc;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   if (!opts) return fail(h, FMX_E_ARG, "fmx_sgd_epoch: opts is NULL");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[slot];
@@ -905,7 +981,9 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_launch & 1), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
     const uint32_t B = opts->batch ? opts->batch : 16384u;
-    rc = ensure_scratch(h, std::min<uint32_t>(B, s.n_rows), 0);
+    const bool lag = (opts->flags & FMX_FLAG_BIAS_LAG) != 0;
+    const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
+    rc = ensure_scratch(h, (size_t)Bc * (lag ? 2 : 1), 0);
     if (rc) return rc;
     const bool segmented = (opts->apply == FMX_APPLY_DEFAULT || opts->apply == FMX_APPLY_SEGMENTED);
     if (segmented) {
@@ -915,8 +993,10 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     }
     for (uint64_t row0 = 0; row0 < s.n_rows; row0 += B) {
       const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
-      float* S = h->partial;
-      float* rest = h->partial + (size_t)nb * h->KP;
+      int pslot = 0;
+      if (lag) { rc = lag_prepare(h, h->stream, &pslot); if (rc) return rc; }
+      float* S = h->partial + (size_t)pslot * Bc * (size_t)(h->KP + 1);
+      float* rest = S + (size_t)nb * h->KP;
       KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, h->stream,
                                          s.ent, s.row_ptr, row0, nb, h->tb, h->cfg.k1, S, rest));
       hipEvent_t ea = nullptr, eb = nullptr;
@@ -928,9 +1008,14 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   } else {
     return fail(h, FMX_E_ARG, "unknown SGD mode %d", opts->mode);
   }
+  if (h->lag.active) {     // the last recurrence must finish inside the timed region; then w0 returns to h->w0
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->lag.ev_scan[(h->lag.step + 1) & 1], 0));
+  }
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
+  rc = lag_flush(h);
+  if (rc) return rc;
   if (stats) {
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -984,6 +1069,7 @@ static int als_eterms(fmx_handle h, const Slot& s, double* e, double* q) {
 int fmx_als_begin(fmx_handle h, int train_slot) {
   int rc = check_slot(h, train_slot, true);
   if (rc) return rc;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
   if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "ALS on a feature shard is not implemented");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -355,9 +355,11 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
 
 // no bias: the multipliers are independent of each other
 __global__ void __launch_bounds__(256)
-k_mult(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, Hyper h, float* __restrict__ mult) {
+k_mult(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, Hyper h,
+       const double* __restrict__ w0_ptr, float* __restrict__ mult) {
+  const float w0 = (h.k0 && w0_ptr) ? (float)(*w0_ptr) : 0.f;
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_rows; e += gridDim.x * blockDim.x)
-    mult[e] = multiplier(h, rest[e], target[e]);
+    mult[e] = multiplier(h, w0 + rest[e], target[e]);
 }
 
 // ----------------------------------------------------------------------------------------------

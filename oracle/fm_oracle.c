@@ -158,6 +158,12 @@ double fmo_evaluate(const fmo_model *m, const fmo_data *d, int task,
 void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                              double min_target, double max_target,
                              uint32_t batch, uint32_t w0_chunk) {
+  fmo_sgd_epoch_minibatch_ex(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, 0);
+}
+
+void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                                double min_target, double max_target,
+                                uint32_t batch, uint32_t w0_chunk, int bias_lag) {
   const int k = m->k;
   const size_t n = (size_t)m->n;
   if (batch == 0 || batch > d->n_rows) batch = d->n_rows;
@@ -192,20 +198,23 @@ void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double l
       }
       rest[e] = res;
     }
-    /* step 2: w0 micro-chunks (fm_learn_sgd_element.h:57-65 + fm_sgd.h:34-37) */
+    /* step 2: w0 micro-chunks (fm_learn_sgd_element.h:57-65 + fm_sgd.h:34-37).
+     * bias_lag: the multipliers handed to step 3 use the w0 of the BATCH start (frozen), while w0 itself still
+     * advances through the micro-chunks with its own multipliers -- this takes the serial recurrence off the
+     * critical path of the step (it overlaps the next batch's gather).  Identical to the plain rule at batch 1. */
+    const double w0_batch = m->k0 ? m->w0 : 0.0;
     for (uint32_t c0 = 0; c0 < nb; c0 += w0_chunk) {
       uint32_t nc = (nb - c0 < w0_chunk) ? (nb - c0) : w0_chunk;
       double w0s = m->k0 ? m->w0 : 0.0;
       double acc = 0;
       for (uint32_t e = c0; e < c0 + nc; e++) {
         double p = w0s + rest[e];
-        mult[e] = fmo_multiplier(task, p, (double)d->target[r0 + e], min_target, max_target);
-        acc += mult[e] + m->reg0 * w0s;
+        double me = fmo_multiplier(task, p, (double)d->target[r0 + e], min_target, max_target);
+        mult[e] = bias_lag ? fmo_multiplier(task, w0_batch + rest[e], (double)d->target[r0 + e], min_target, max_target) : me;
+        acc += me + m->reg0 * w0s;
+        if (nc == 1 && m->k0) m->w0 -= learn_rate * (me + m->reg0 * m->w0);  /* literal form at chunk 1 */
       }
-      if (m->k0) {
-        if (nc == 1) m->w0 -= learn_rate * (mult[c0] + m->reg0 * m->w0);  /* literal form at chunk 1 */
-        else         m->w0 -= learn_rate * acc;
-      }
+      if (m->k0 && nc != 1) m->w0 -= learn_rate * acc;
     }
     /* step 3: per-occurrence deltas from batch-start w, v (fm_sgd.h:38-50) */
     for (uint32_t e = 0; e < nb; e++) {

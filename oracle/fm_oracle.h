@@ -101,6 +101,11 @@ double fmo_evaluate(const fmo_model *m, const fmo_data *d, int task,
 void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                              double min_target, double max_target,
                              uint32_t batch, uint32_t w0_chunk);
+/* same with bias_lag != 0: step 3 uses mult_e = multiplier(w0 at BATCH start + rest_e) while step 2's recurrence
+ * still advances w0 chunk by chunk (GPU flag FMX_FLAG_BIAS_LAG: the recurrence leaves the critical path). */
+void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                                double min_target, double max_target,
+                                uint32_t batch, uint32_t w0_chunk, int bias_lag);
 
 /* ---------------- ALS (coordinate descent; "MCMC without sampling", libfm.cpp:135-139) ---------------- */
 

@@ -9,6 +9,8 @@ run --mode minibatch --apply segmented
 run --mode minibatch --apply store
 run --mode minibatch --apply segmented --batch 8192
 run --mode minibatch --apply segmented --batch 65536
+run --mode minibatch --apply segmented --no-bias-lag
+run --mode minibatch --apply segmented --batch 65536 --no-bias-lag
 python - <<'PY'
 import json
 for line in open('gpurun_out/bench_variants.log'):

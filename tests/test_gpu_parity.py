@@ -139,6 +139,26 @@ def test_minibatch_matches_restated_rule(capi, oracle, name, batch, chunk):
     h.close()
 
 
+@pytest.mark.parametrize("name,batch,chunk", [("sgd_reg_ml", 64, 16), ("sgd_cls_ragged", 32, 8), ("sgd_cls_zipf_k32", 100, 10),
+                                              ("sgd_reg_ml", 1, 1), ("sgd_cls_k64", 300, 64)])
+def test_minibatch_bias_lag_matches_restated_rule(capi, oracle, name, batch, chunk):
+    """FMX_FLAG_BIAS_LAG: multipliers from the batch-start bias, recurrence overlapped on the side stream."""
+    g = Golden(name)
+    m = g.model(oracle, "init")
+    tr = g.data(oracle, "train")
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    upload(h, 0, tr)
+    for _ in range(g.iters):
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, chunk, capi.FLAG_BIAS_LAG)
+        oracle.sgd_epoch_minibatch(m, tr, g.task, g.lr, g.min_target, g.max_target, batch, chunk, bias_lag=True)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    h.close()
+
+
 def collision_free(n_rows, nnz, seed):
     """every feature occurs at most once in the whole data set."""
     rng = np.random.default_rng(seed)
@@ -266,8 +286,10 @@ def test_init_params_matches_oracle_definition(capi, oracle):
 # ---------------------------------------------------------------------------------------------
 # feature sharding on ONE device (loopback): two shard handles + host-side sum == unsharded handle
 # ---------------------------------------------------------------------------------------------
-def test_sharded_partials_sum_to_unsharded(capi, oracle):
+@pytest.mark.parametrize("lag", [False, True])
+def test_sharded_partials_sum_to_unsharded(capi, oracle, lag):
     import torch
+    flags = capi.FLAG_BIAS_LAG if lag else 0
     g = Golden("sgd_cls_k64")
     m = g.model(oracle, "init")
     tr = g.data(oracle, "train")
@@ -295,9 +317,12 @@ def test_sharded_partials_sum_to_unsharded(capi, oracle):
             tot = bufs[0] + bufs[1]                       # what the RCCL all-reduce computes
             torch.cuda.synchronize()
             for s in shards:
-                s.sgd_finish(0, row0, nb, tot.data_ptr(), w0_chunk=16, batch=B)
-                s.synchronize()
-        full.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, B, 16)
+                s.sgd_finish(0, row0, nb, tot.data_ptr(), w0_chunk=16, batch=B, flags=flags)
+                if not lag:
+                    s.synchronize()
+        for s in shards:
+            s.synchronize()
+        full.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, B, 16, flags)
     w0f, wf, vf = full.get_params()
     w = np.zeros_like(wf)
     v = np.zeros_like(vf)
