@@ -73,6 +73,35 @@ def cpu_baseline(n, k, nnz, rows):
             "seconds": round(sec, 3), "setup_seconds": round(setup, 1), "host_cores": cores}
 
 
+def cpu_reference(n, k, nnz, rows):
+    """the reference's own fm_model::predict + fm_SGD (compiled from /root/reference into oracle/_ref/ref_harness),
+    one thread.  The stock containers overflow at k*n >= 2^32 (matrix.h:167-169), so n is capped accordingly."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(exe):
+        return None
+    n_ref = min(n, (2 ** 32 - 1) // k // 1_000_000 * 1_000_000)
+    r = subprocess.run([exe, "time_sgd", str(n_ref), str(k), str(nnz), str(rows), "123"], capture_output=True, text=True)
+    if r.returncode != 0:
+        return {"error": r.stderr[-200:]}
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": round(d["examples_per_sec"], 1), "unit": "examples/s", "cores": 1, "kind": "reference",
+            "sample": "%d rows of the synthetic workload at n=%d (largest the stock containers allocate; bench n=%d) k=%d nnz=%d"
+                      % (rows, n_ref, n, k, nnz), "seconds": round(d["seconds"], 3)}
+
+
+def committed_traffic(kernel, examples_per_launch, k, nnz):
+    """HBM bytes per launch from the committed PMC profile (profiles/traffic.json), if it is for this kernel/shape."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        e = t.get(kernel)
+        if e and e["examples_per_launch"] == examples_per_launch and e["k"] == k and e["nnz"] == nnz:
+            return e["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +122,10 @@ def main():
     ap.add_argument("--no-bias-lag", action="store_true", help="minibatch: keep the w0 recurrence on the critical path (exact chunk coupling)")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic", type=float, default=None, help="PMC HBM bytes per launch of the dominant kernel")
+    ap.add_argument("--traffic", type=float, default=None,
+                    help="PMC HBM bytes per launch of the dominant kernel (default: profiles/traffic.json if it matches)")
+    ap.add_argument("--cpu-reference", action="store_true",
+                    help="also time the REAL reference code (oracle/_ref/ref_harness time_sgd) at the largest n it can allocate")
     args = ap.parse_args()
 
     import torch
@@ -121,9 +153,11 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    cpu = None
+    cpu, cpu_ref = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.n, args.k, args.nnz, args.cpu_rows)
+        if args.cpu_reference:
+            cpu_ref = cpu_reference(args.n, args.k, args.nnz, args.cpu_rows)
 
     lr, regv = 0.01, 0.001
     h = capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
@@ -197,9 +231,11 @@ def main():
             per_ex = algorithmic_bytes(args.k, args.nnz, kind)
             avg = main_time / main_launches
             achieved = per_ex * rows_per_launch / avg / 1e9
-            roof = {"bound": "hbm", "kernel": "k_fused" if kind == "fused" else ("k_apply_seg" if args.apply in ("default", "segmented") else "k_apply"),
+            kname = "k_fused" if kind == "fused" else ("k_apply_seg" if args.apply in ("default", "segmented") else "k_apply")
+            traffic = args.traffic if args.traffic is not None else committed_traffic(kname, rows_per_launch, args.k, args.nnz)
+            roof = {"bound": "hbm", "kernel": kname,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_example": per_ex, "examples_per_launch": rows_per_launch,
                     "avg_launch_ms": round(avg * 1e3, 4), "launches": main_launches}
         out = {
@@ -216,6 +252,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if cpu_ref is not None:
+            out["cpu_reference"] = cpu_ref
         print(json.dumps(out), flush=True)
     h.close()
     if world > 1:

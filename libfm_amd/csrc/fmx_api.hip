@@ -311,7 +311,12 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   }
   CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
   CREATE_CHK(hipMalloc(&h->w0_pp, 2 * sizeof(double)));
-  CREATE_CHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  {  // the side stream runs the one-workgroup bias recurrence next to chip-filling gathers: give it priority so
+     // that its workgroup is placed as soon as any CU has room
+    int lo = 0, hi = 0;
+    CREATE_CHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CREATE_CHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+  }
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   h->num_cu = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
   CREATE_CHK(hipMalloc(&h->acc, 4 * sizeof(double)));
@@ -753,7 +758,7 @@ done:
 static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
                        const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr) {
   if (hy.k0) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, rest, target, n_rows, chunk, hy,
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy,
                        w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
   } else if (mult) {
     hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,

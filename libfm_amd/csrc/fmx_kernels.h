@@ -303,54 +303,71 @@ k_rest_from_partial(const float* __restrict__ S, const float* __restrict__ c, ui
 // its loads must not be HBM round trips); wavefront 0 runs the recurrence out of LDS with a DPP reduction
 // per chunk; the multipliers go back to HBM in coalesced tiles.
 // ----------------------------------------------------------------------------------------------
-constexpr int SCAN_TILE = 8192;
-__global__ void __launch_bounds__(1024)
+constexpr int SCAN_TILE = 4096;
+// ONE wavefront, <= 32 VGPRs, 64 KiB LDS: it must be placeable on a CU whose SIMDs are already full of gather
+// wavefronts (the hogwild launch it overlaps leaves 32 free VGPRs per lane), otherwise it only starts when that
+// launch drains and the next one stalls behind it (measured: +35 % per launch with a 4-wavefront, 72-VGPR version).
+// Tiles arrive by LDS-DMA (global_load_lds: no VGPR round trip), tile t+1 in flight while tile t is scanned.
+__device__ __forceinline__ void scan_fetch_tile(const float* __restrict__ g_rest, const float* __restrict__ g_y,
+                                                uint32_t cnt, float* s_r, float* s_t, uint32_t lane) {
+  for (uint32_t base = 0; base < cnt; base += 64) {
+    if (base + lane < cnt) {
+      __builtin_amdgcn_global_load_lds(g_rest + base + lane, s_r + base, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(g_y + base + lane, s_t + base, 4, 0, 0);
+    }
+  }
+}
+__global__ void __launch_bounds__(64)
 k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
        Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
-  __shared__ float s_rest[SCAN_TILE];
-  __shared__ float s_y[SCAN_TILE];
-  __shared__ float s_m[SCAN_TILE];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  __shared__ float s_rest[2][SCAN_TILE];
+  __shared__ float s_y[2][SCAN_TILE];
+  // as the youngest wavefront on its SIMD it would only get leftover issue slots: raise the priority
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t lane = threadIdx.x;
+  const uint32_t n_tiles = (n_rows + SCAN_TILE - 1) / SCAN_TILE;
   double w0 = *w0_in;
   uint32_t chunk_pos = 0;
   float acc = 0.f;
-  for (uint32_t t0 = 0; t0 < n_rows; t0 += SCAN_TILE) {
+  scan_fetch_tile(rest, target, min((uint32_t)SCAN_TILE, n_rows), s_rest[0], s_y[0], lane);
+  for (uint32_t t = 0; t < n_tiles; t++) {
+    const uint32_t t0 = t * SCAN_TILE;
     const uint32_t tn = min((uint32_t)SCAN_TILE, n_rows - t0);
-    for (uint32_t i = tid; i < tn; i += 1024) { s_rest[i] = rest[t0 + i]; s_y[i] = target[t0 + i]; }
-    __syncthreads();
-    if (tid < 64) {
-      uint32_t i = 0;
-      while (i < tn) {
-        const uint32_t take = min(chunk - chunk_pos, tn - i);
-        const float w0s = h.k0 ? (float)w0 : 0.f;
-        uint32_t t = 0;
-        for (; t + 256 <= take; t += 256) {                   // 4 independent elements per lane: LDS reads overlap
-          const uint32_t q = i + t + lane;
-          const float r0 = s_rest[q], r1 = s_rest[q + 64], r2 = s_rest[q + 128], r3 = s_rest[q + 192];
-          const float y0 = s_y[q], y1 = s_y[q + 64], y2 = s_y[q + 128], y3 = s_y[q + 192];
-          const float m0 = multiplier_fast(h, w0s + r0, y0), m1 = multiplier_fast(h, w0s + r1, y1);
-          const float m2 = multiplier_fast(h, w0s + r2, y2), m3 = multiplier_fast(h, w0s + r3, y3);
-          s_m[q] = m0; s_m[q + 64] = m1; s_m[q + 128] = m2; s_m[q + 192] = m3;
-          acc += (m0 + m1) + (m2 + m3);
-        }
-        for (t += lane; t < take; t += 64) {
-          const float m = multiplier_fast(h, w0s + s_rest[i + t], s_y[i + t]);
-          s_m[i + t] = m;
-          acc += m;
-        }
-        i += take; chunk_pos += take;
-        if (chunk_pos == chunk || t0 + i == n_rows) {
-          const float tot = wave_sum_dpp(acc);
-          if (h.k0) w0 -= (double)h.lr * ((double)tot + (double)chunk_pos * (double)h.reg0 * (double)w0s);
-          acc = 0.f; chunk_pos = 0;
-        }
+    const uint32_t cur = t & 1u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tile t has landed in LDS (issued one tile ago)
+    __builtin_amdgcn_s_barrier();                              // single wavefront: orders the DMA writes before the reads
+    if (t + 1 < n_tiles) {
+      const uint32_t u0 = t0 + SCAN_TILE;
+      scan_fetch_tile(rest + u0, target + u0, min((uint32_t)SCAN_TILE, n_rows - u0), s_rest[cur ^ 1u], s_y[cur ^ 1u], lane);
+    }
+    const float* sr = s_rest[cur];
+    const float* sy = s_y[cur];
+    uint32_t i = 0;
+    while (i < tn) {
+      const uint32_t take = min(chunk - chunk_pos, tn - i);
+      const float w0s = h.k0 ? (float)w0 : 0.f;
+      uint32_t tt = 0;
+      for (; tt + 128 <= take; tt += 128) {                   // 2 independent elements per lane
+        const uint32_t q = i + tt + lane;
+        const float m0 = multiplier_fast(h, w0s + sr[q], sy[q]);
+        const float m1 = multiplier_fast(h, w0s + sr[q + 64], sy[q + 64]);
+        if (mult) { mult[t0 + q] = m0; mult[t0 + q + 64] = m1; }
+        acc += m0 + m1;
+      }
+      for (tt += lane; tt < take; tt += 64) {
+        const float m = multiplier_fast(h, w0s + sr[i + tt], sy[i + tt]);
+        if (mult) mult[t0 + i + tt] = m;
+        acc += m;
+      }
+      i += take; chunk_pos += take;
+      if (chunk_pos == chunk || t0 + i == n_rows) {
+        const float tot = wave_sum_dpp(acc);
+        if (h.k0) w0 -= (double)h.lr * ((double)tot + (double)chunk_pos * (double)h.reg0 * (double)w0s);
+        acc = 0.f; chunk_pos = 0;
       }
     }
-    __syncthreads();
-    if (mult) for (uint32_t i = tid; i < tn; i += 1024) mult[t0 + i] = s_m[i];
-    __syncthreads();
   }
-  if (tid == 0) *w0_out = w0;
+  if (lane == 0) *w0_out = w0;
 }
 
 // no bias: the multipliers are independent of each other
