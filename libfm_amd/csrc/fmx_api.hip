@@ -310,7 +310,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     }
   }
   CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
-  CREATE_CHK(hipMalloc(&h->w0_pp, 2 * sizeof(double)));
+  CREATE_CHK(hipMalloc(&h->w0_pp, 4 * sizeof(double)));
   {  // the side stream runs the one-workgroup bias recurrence next to chip-filling gathers: give it priority so
      // that its workgroup is placed as soon as any CU has room
     int lo = 0, hi = 0;
@@ -758,8 +758,10 @@ done:
 static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
                        const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr) {
   if (hy.k0) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy,
-                       w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
+    if (mult) hipLaunchKernelGGL(k_scan<true>, dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy,
+                                 w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
+    else      hipLaunchKernelGGL(k_scan<false>, dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy,
+                                 w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
   } else if (mult) {
     hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
                        (const double*)nullptr, mult);
@@ -938,18 +940,17 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     batches = s.n_rows; main_launches = 1;
   } else if (opts->mode == FMX_SGD_HOGWILD) {
     if (opts->apply == FMX_APPLY_SEGMENTED) return fail(h, FMX_E_ARG, "HOGWILD has no segmented apply");
-    // rows per launch M: w0 is frozen inside a launch.  The bias recurrence of launch i (k_scan, one CU) runs
-    // on a side stream WHILE launch i+1 streams; launch i reads the w0 produced by scan i-2 (ping-pong slots,
-    // so the result does not depend on timing).
+    // rows per launch M: w0 is frozen inside a launch.  The bias recurrence of launch i (k_scan, one wavefront) runs
+    // on a side stream WHILE launches i+1, i+2 stream; launch i reads the w0 produced by scan i-3 (a ring of 3
+    // slots / rest buffers, so the result does not depend on timing and a slow scan has two launches of slack).
     const uint32_t M = opts->batch ? opts->batch : 262144u;
     const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : 256u;
     const uint32_t cap = std::min<uint32_t>(M, s.n_rows);
-    rc = ensure_scratch(h, 0, (size_t)cap * 2);
+    rc = ensure_scratch(h, 0, (size_t)cap * 3);
     if (rc) return rc;
     const uint64_t n_launch = ((uint64_t)s.n_rows + M - 1) / M;
     while (h->ev_sync.size() < 2 * n_launch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
-    HIPCHK(h, hipMemcpyAsync(h->w0_pp, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->w0_pp + 1, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    for (int r = 0; r < 3; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     // even launches go to `stream`, odd ones to `stream3`: the drain of one macro-batch overlaps the ramp-up of
     // the next (rows of different launches are as independent as rows of one launch)
     const bool two_streams = getenv("FMX_HOGWILD_TWO_STREAMS") != nullptr;   // +6 % but launches overlap (timing per launch blurs)
@@ -959,14 +960,14 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     for (uint64_t i = 0; i < n_launch; i++) {
       const uint64_t row0 = i * M;
       const uint32_t nb = (uint32_t)std::min<uint64_t>(M, s.n_rows - row0);
-      float* rest = h->rest + (size_t)(i & 1) * cap;
+      float* rest = h->rest + (size_t)(i % 3) * cap;
       hipStream_t fs = (two_streams && (i & 1)) ? h->stream3 : h->stream;
-      if (i >= 2) HIPCHK(h, hipStreamWaitEvent(fs, h->ev_sync[2 * (i - 2) + 1], 0));   // scan i-2 done
+      if (i >= 3) HIPCHK(h, hipStreamWaitEvent(fs, h->ev_sync[2 * (i - 3) + 1], 0));   // scan i-3 done
       hipEvent_t ea = nullptr, eb = nullptr;
       // (no per-launch events here: a timing event between two launches costs ~13 % on this path; the epoch is
       //  bracketed by ev0/ev1 on the launch stream and the average launch time is epoch time / launches)
       main_launches++;
-      const double* w0_in = h->w0_pp + ((i + 1) & 1);      // slot written by scan i-2 (initial value for i < 2)
+      const double* w0_in = h->w0_pp + ((i + 1) % 3);      // slot written by scan i-3 (initial value for i < 3)
       if (opts->apply == FMX_APPLY_ATOMIC) {
         KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, row0, nb, fs, w0_in, rest); });
       } else {
@@ -976,14 +977,14 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipEventRecord(h->ev_sync[2 * i], fs));
       HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * i], 0));
-      rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (i & 1), h->w0_pp + ((i + 1) & 1));
+      rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (i % 3), h->w0_pp + ((i + 1) % 3));
       if (rc) return rc;
       HIPCHK(h, hipEventRecord(h->ev_sync[2 * i + 1], h->stream2));
       batches++;
     }
     // stream2 is in order: its last event covers every scan, and scan i waited for launch i
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync[2 * (n_launch - 1) + 1], 0));
-    if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_launch & 1), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_launch % 3), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
     const uint32_t B = opts->batch ? opts->batch : 16384u;
     const bool lag = (opts->flags & FMX_FLAG_BIAS_LAG) != 0;

@@ -308,15 +308,21 @@ constexpr int SCAN_TILE = 4096;
 // wavefronts (the hogwild launch it overlaps leaves 32 free VGPRs per lane), otherwise it only starts when that
 // launch drains and the next one stalls behind it (measured: +35 % per launch with a 4-wavefront, 72-VGPR version).
 // Tiles arrive by LDS-DMA (global_load_lds: no VGPR round trip), tile t+1 in flight while tile t is scanned.
-__device__ __forceinline__ void scan_fetch_tile(const float* __restrict__ g_rest, const float* __restrict__ g_y,
-                                                uint32_t cnt, float* s_r, float* s_t, uint32_t lane) {
-  for (uint32_t base = 0; base < cnt; base += 64) {
-    if (base + lane < cnt) {
-      __builtin_amdgcn_global_load_lds(g_rest + base + lane, s_r + base, 4, 0, 0);
-      __builtin_amdgcn_global_load_lds(g_y + base + lane, s_t + base, 4, 0, 0);
-    }
+__device__ __forceinline__ void scan_fetch_array(const float* __restrict__ g, uint32_t cnt, float* s, uint32_t lane) {
+  if ((((uintptr_t)g) & 15u) == 0) {                           // 16-byte pieces: 1 KiB per wave instruction
+    for (uint32_t base = 0; base < cnt; base += 256)
+      if (base + 4 * lane < cnt) __builtin_amdgcn_global_load_lds(g + base + 4 * lane, s + base, 16, 0, 0);
+  } else {                                                     // unaligned start (row0 not a multiple of 4): dwords
+    for (uint32_t base = 0; base < cnt; base += 64)
+      if (base + lane < cnt) __builtin_amdgcn_global_load_lds(g + base + lane, s + base, 4, 0, 0);
   }
 }
+__device__ __forceinline__ void scan_fetch_tile(const float* __restrict__ g_rest, const float* __restrict__ g_y,
+                                                uint32_t cnt, float* s_r, float* s_t, uint32_t lane) {
+  scan_fetch_array(g_rest, cnt, s_r, lane);
+  scan_fetch_array(g_y, cnt, s_t, lane);
+}
+template <bool WRITE_MULT>
 __global__ void __launch_bounds__(64)
 k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
        Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
@@ -347,16 +353,18 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
       const uint32_t take = min(chunk - chunk_pos, tn - i);
       const float w0s = h.k0 ? (float)w0 : 0.f;
       uint32_t tt = 0;
-      for (; tt + 128 <= take; tt += 128) {                   // 2 independent elements per lane
+      for (; tt + 256 <= take; tt += 256) {                   // 4 independent elements per lane: LDS reads overlap
         const uint32_t q = i + tt + lane;
         const float m0 = multiplier_fast(h, w0s + sr[q], sy[q]);
         const float m1 = multiplier_fast(h, w0s + sr[q + 64], sy[q + 64]);
-        if (mult) { mult[t0 + q] = m0; mult[t0 + q + 64] = m1; }
-        acc += m0 + m1;
+        const float m2 = multiplier_fast(h, w0s + sr[q + 128], sy[q + 128]);
+        const float m3 = multiplier_fast(h, w0s + sr[q + 192], sy[q + 192]);
+        if (WRITE_MULT) { mult[t0 + q] = m0; mult[t0 + q + 64] = m1; mult[t0 + q + 128] = m2; mult[t0 + q + 192] = m3; }
+        acc += (m0 + m1) + (m2 + m3);
       }
       for (tt += lane; tt < take; tt += 64) {
         const float m = multiplier_fast(h, w0s + sr[i + tt], sy[i + tt]);
-        if (mult) mult[t0 + i + tt] = m;
+        if (WRITE_MULT) mult[t0 + i + tt] = m;
         acc += m;
       }
       i += take; chunk_pos += take;
