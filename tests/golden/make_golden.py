@@ -136,8 +136,45 @@ def make_mcmc():
             print("%-22s n=%d rows=%d/%d test accuracy of the reference's posterior mean: %.4f" % (name, init.n, tr.n_rows, te.n_rows, np.mean((pred_out >= 0.5) == (yy == 1))))
 
 
+def make_c1():
+    """BASELINE.json configs[0]: MovieLens-100K-shaped plumbing case run through the STOCK reference binary
+    (oracle/_ref/libFM, the reference's own main + CLI + text parser + -out / -save_model writers)."""
+    import subprocess
+    ent, rp, y = datagen.movielens_shaped(943, 1682, 100000, seed=100)
+    rp = rp.astype(np.int64)
+    ntr = 80000
+    tr = O.Data(ent[:rp[ntr]], rp[:ntr + 1], y[:ntr])
+    te = O.Data(ent[rp[ntr]:], rp[ntr:] - rp[ntr], y[ntr:])
+    with tempfile.TemporaryDirectory() as td:
+        trf, tef = os.path.join(td, "ml.train.libfm"), os.path.join(td, "ml.test.libfm")
+        tr.write_libsvm(trf)
+        te.write_libsvm(tef)
+        cmd = [O.REF_LIBFM, "-task", "r", "-train", trf, "-test", tef, "-dim", "1,1,8", "-iter", "20", "-method", "sgd",
+               "-learn_rate", "0.01", "-regular", "0,0,0.01", "-init_stdev", "0.1", "-seed", "42",
+               "-out", os.path.join(td, "pred"), "-save_model", os.path.join(td, "model")]
+        r = subprocess.run(cmd, capture_output=True, text=True, check=True)
+        iters = [[float(x.split("=")[1]) for x in line.split("\t")[1:3]] for line in r.stdout.splitlines() if line.startswith("#Iter=")]
+        pred = np.loadtxt(os.path.join(td, "pred"))
+        lines = open(os.path.join(td, "model")).read().splitlines()
+        n = 943 + 1682
+        w0 = float(lines[1]); w = np.array([float(x) for x in lines[3:3 + n]])
+        v = np.array([[float(x) for x in ln.split()] for ln in lines[4 + n:4 + 2 * n]]).T     # file is feature-major
+        # the same seed through the harness gives the full-precision initial model (same srand/init order)
+        pre = os.path.join(td, "h")
+        O.run_ref_harness(["sgd", trf, tef, "r", 1, 1, 8, 0, "0.01", "0", "0", "0.01", "0.1", 42, pre])
+        init = O.Model.from_dump(pre + ".init.bin")
+    np.savez_compressed(os.path.join(HERE, "c1_ml100k_shaped.npz"),
+                        train_entries=tr.entries, train_row_ptr=tr.row_ptr.astype(np.uint32), train_target=tr.target,
+                        test_entries=te.entries, test_row_ptr=te.row_ptr.astype(np.uint32), test_target=te.target,
+                        stdout_iters=np.array(iters), out_pred=pred, model_w0=w0, model_w=w, model_v=v,
+                        init_w0=init.w0, init_w=init.w, init_v=init.v, cmdline=" ".join(cmd[1:]))
+    print("c1_ml100k_shaped       stock libFM: last #Iter line Train=%g Test=%g" % tuple(iters[-1]))
+
+
 def main():
     O.build()
+    if "--c1" in sys.argv or not os.path.exists(os.path.join(HERE, "c1_ml100k_shaped.npz")):
+        make_c1()
     make_mcmc()
     make_als()
     for name, case in CASES.items():
