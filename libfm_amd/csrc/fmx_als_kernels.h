@@ -20,6 +20,10 @@
 
 namespace fmx {
 
+// e_q_term (fm_learn_mcmc.h:46-49): the residual and the CURRENT factor's q of one training row side by side,
+// so that a coordinate update touches ONE 16-byte slot per entry (one cache line instead of two)
+struct __attribute__((aligned(16))) EQ { double e, q; };
+
 __device__ __forceinline__ double wave_sum_f64(double x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -43,7 +47,7 @@ __device__ __forceinline__ double ref_cdf_gaussian(double x) { return 0.5 + 0.5 
 template <int KP>
 __global__ void __launch_bounds__(256)
 k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, const Tab tb,
-             int k0, int k1, const double* __restrict__ w0_ptr, double* __restrict__ e, double* __restrict__ q /* [KP][n_rows] or null */) {
+             int k0, int k1, const double* __restrict__ w0_ptr, EQ* __restrict__ eq, double* __restrict__ q /* [KP][n_rows] or null */) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x & 63u;
   const bool act = lane < LPR;
@@ -81,13 +85,17 @@ k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
       }
     }
     part = wave_sum_f64(part);
-    if (lane == 0) e[c] = w0 + part;
+    if (lane == 0) eq[c].e = w0 + part;
   }
 }
 
 // e[c] -= target[c] (initialisation, _learn :70-86)
-__global__ void k_als_sub_target(double* __restrict__ e, const float* __restrict__ target, uint32_t n) {
-  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) e[c] -= (double)target[c];
+__global__ void k_als_sub_target(EQ* __restrict__ eq, const float* __restrict__ target, uint32_t n) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].e -= (double)target[c];
+}
+// add_main_q (:406-428) for factor f was evaluated by k_als_eterms; move it next to e for the coming sweep
+__global__ void k_als_load_q(EQ* __restrict__ eq, const double* __restrict__ qf, uint32_t n) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].q = qf[c];
 }
 
 // counter-based uniforms / normals for the Gibbs variant (statistical, not bitwise, parity with libc rand())
@@ -123,19 +131,19 @@ __device__ __forceinline__ double left_tgauss(double left, uint64_t seed, uint64
 //   classification(_learn :163-196): accuracy of cdf_gaussian(e) vs sign, e -= E[truncated normal] (do_sample = 0)
 // acc[0] = sum err^2 / #correct
 __global__ void __launch_bounds__(256)
-k_als_targets(double* __restrict__ e, const float* __restrict__ target, uint32_t n, int task,
+k_als_targets(EQ* __restrict__ eq, const float* __restrict__ target, uint32_t n, int task,
               double min_target, double max_target, double* __restrict__ acc,
               int do_sample, uint64_t seed, uint64_t stream) {
   double s = 0.0;
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-    const double yh = e[c];
+    const double yh = eq[c].e;
     const double y = (double)target[c];
     if (task == 0) {
       double p = fmin(max_target, yh);
       p = fmax(min_target, p);
       const double err = p - y;
       s += err * err;
-      e[c] = yh - y;
+      eq[c].e = yh - y;
     } else {
       const double p = ref_cdf_gaussian(yh);
       if (((p >= 0.5) && (y > 0.0)) || ((p < 0.5) && (y < 0.0))) s += 1.0;
@@ -148,7 +156,7 @@ k_als_targets(double* __restrict__ e, const float* __restrict__ target, uint32_t
         const double Phi_minus_mu = ref_cdf_gaussian(-yh);
         st = (y >= 0.0) ? yh + phi_minus_mu / (1 - Phi_minus_mu) : yh - phi_minus_mu / Phi_minus_mu;
       }
-      e[c] = yh - st;
+      eq[c].e = yh - st;
     }
   }
   s = wave_sum_f64(s);
@@ -157,14 +165,14 @@ k_als_targets(double* __restrict__ e, const float* __restrict__ target, uint32_t
 
 // sum_c e[c] (draw_w0's numerator, :650-652: sum (e - w0) = sum e - N w0) and sum e^2 (draw_alpha :918-920)
 __global__ void __launch_bounds__(256)
-k_als_sum_e(const double* __restrict__ e, uint32_t n, double* __restrict__ acc) {
+k_als_sum_e(const EQ* __restrict__ eq, uint32_t n, double* __restrict__ acc) {
   double s = 0.0, s2 = 0.0;
-  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) { const double v = e[c]; s += v; s2 += v * v; }
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) { const double v = eq[c].e; s += v; s2 += v * v; }
   s = wave_sum_f64(s); s2 = wave_sum_f64(s2);
   if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(acc, s); unsafeAtomicAdd(acc + 1, s2); }
 }
-__global__ void k_als_add_const(double* __restrict__ e, uint32_t n, double d) {
-  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) e[c] += d;
+__global__ void k_als_add_const(EQ* __restrict__ eq, uint32_t n, double d) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].e += d;
 }
 
 // sum_j theta_j and sum_j theta_j^2 of one coordinate family (w: param = tb.w, stride ws; v_f: param = tb.V + f, stride rs)
@@ -197,33 +205,47 @@ __device__ __forceinline__ double gauss_hash(uint64_t seed, uint64_t stream, uin
 // then e_c -= h (theta_old - theta), q_c -= x (theta_old - theta).
 // seg_list: the level's segments; a segment = one feature's column inside t_ent (sorted by feature).
 // ----------------------------------------------------------------------------------------------
-template <bool IS_V>
+// G lanes cooperate on one feature (G = 64: one wavefront per column; smaller G: 64/G columns per wavefront, chosen on
+// the host from the mean column length -- sparse one-hot data has columns of a handful of rows)
+template <int G> __device__ __forceinline__ double group_sum_f64(double x) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+template <bool IS_V, int G>
 __global__ void __launch_bounds__(256)
 k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
            uint32_t nseg_total, uint32_t nnz, const uint32_t* __restrict__ seg_list, uint32_t n_list,
-           float* __restrict__ param, uint32_t pstride, double* __restrict__ e, double* __restrict__ q,
+           float* __restrict__ param, uint32_t pstride, EQ* __restrict__ eq,
            double alpha, double lambda, double mu, int do_sample, uint64_t seed, uint64_t stream) {
-  const uint32_t lane = threadIdx.x & 63u;
+  constexpr uint32_t GPW = 64 / G;                      // feature groups per wavefront
+  const uint32_t lane = (threadIdx.x & 63u) % G;         // lane inside its group
+  const uint32_t grp = (threadIdx.x & 63u) / G;
   const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t li = wave0; li < n_list; li += nwaves) {
-    const uint32_t s = seg_list[li];
+  for (uint32_t lw = wave0 * GPW; lw < n_list; lw += nwaves * GPW) {
+    const uint32_t li = lw + grp;
+    const bool have = li < n_list;                       // idle groups still take part in the shuffles
+    const uint32_t s = seg_list[have ? li : n_list - 1];
     const uint32_t j = seg_feat[s];
     const uint32_t a = seg_rel[s];
-    const uint32_t b = (s + 1 < nseg_total) ? seg_rel[s + 1] : nnz;
+    const uint32_t b = have ? ((s + 1 < nseg_total) ? seg_rel[s + 1] : nnz) : a;
     float* pt = param + (size_t)j * pstride;
     const double th = (double)(*pt);
     double t_he = 0.0, t_hh = 0.0;
-    for (uint32_t i = a + lane; i < b; i += 64) {
+    for (uint32_t i = a + lane; i < b; i += G) {
       const TEntry te = t_ent[i];
       const double x = (double)te.x;
+      const EQ c = eq[te.e];                                       // one 16-byte gather: e and q of the row
       double h;
-      if (IS_V) h = x * (q[te.e] - x * th); else h = x;
-      if (IS_V) { t_he += h * e[te.e]; } else { t_he += x * (e[te.e] - th * x); }
+      if (IS_V) h = x * (c.q - x * th); else h = x;
+      if (IS_V) { t_he += h * c.e; } else { t_he += x * (c.e - th * x); }
       t_hh += h * h;
     }
-    t_he = wave_sum_f64(t_he);
-    t_hh = wave_sum_f64(t_hh);
+    t_he = group_sum_f64<G>(t_he);
+    t_hh = group_sum_f64<G>(t_hh);
+    if (!have) continue;
     if (IS_V) t_he -= th * t_hh;                                   // :803
     const double sigma_sqr = 1.0 / (lambda + alpha * t_hh);
     double mean = -sigma_sqr * (alpha * t_he - mu * lambda);
@@ -239,12 +261,13 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
       // occurrences adjacent (the sort is stable in row order); the first one walks the run sequentially exactly
       // like the reference loop (:839-846: q is updated between the occurrences), the others skip.  Rows are
       // disjoint between lanes and between the wavefronts of a level, so plain read-modify-writes suffice.
-      for (uint32_t i = a + lane; i < b; i += 64) {
+      for (uint32_t i = a + lane; i < b; i += G) {
         const TEntry te = t_ent[i];
         if (i > a && t_ent[i - 1].e == te.e) continue;
-        double ec = e[te.e];
+        EQ c = eq[te.e];
+        double ec = c.e;
         if (IS_V) {
-          double qc = q[te.e];
+          double qc = c.q;
           for (uint32_t i2 = i; i2 < b; i2++) {
             const TEntry t2 = t_ent[i2];
             if (t2.e != te.e) break;
@@ -253,7 +276,7 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
             qc -= x * d;
             ec -= h * d;
           }
-          q[te.e] = qc;
+          c.q = qc;
         } else {
           for (uint32_t i2 = i; i2 < b; i2++) {
             const TEntry t2 = t_ent[i2];
@@ -261,7 +284,8 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
             ec -= (double)t2.x * d;
           }
         }
-        e[te.e] = ec;
+        c.e = ec;
+        eq[te.e] = c;                                              // one 16-byte store
       }
     }
   }

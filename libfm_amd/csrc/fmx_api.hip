@@ -47,7 +47,7 @@ thread_local std::string g_create_error = "";
 
 struct AlsState {
   int       slot = -1;
-  double*   e = nullptr;          // [N] residuals
+  EQ*       e = nullptr;          // [N] {residual, current factor's q}
   double*   q = nullptr;          // [KP][N]
   uint8_t*  seen = nullptr;       // [n_local] feature has a training column
   uint32_t* level_list = nullptr; // segments ordered by level
@@ -1065,7 +1065,7 @@ int fmx_als_end(fmx_handle h) {
   return FMX_OK;
 }
 
-static int als_eterms(fmx_handle h, const Slot& s, double* e, double* q) {
+static int als_eterms(fmx_handle h, const Slot& s, EQ* e, double* q) {
   KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), s.n_rows, h->stream, s.ent, s.row_ptr, s.n_rows, h->tb,
                                      h->cfg.k0, h->cfg.k1, h->w0, e, q));
   HIPCHK(h, hipGetLastError());
@@ -1117,7 +1117,7 @@ int fmx_als_begin(fmx_handle h, int train_slot) {
   HIPCHK(h, hipMemcpy(a.level_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMalloc(&a.seen, seen.size()));
   HIPCHK(h, hipMemcpy(a.seen, seen.data(), seen.size(), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMalloc(&a.e, (size_t)N * sizeof(double)));
+  HIPCHK(h, hipMalloc(&a.e, (size_t)N * sizeof(EQ)));
   HIPCHK(h, hipMalloc(&a.q, (size_t)N * (size_t)h->KP * sizeof(double)));
   // ---- first prediction and e -= target (fm_learn_mcmc_simultaneous.h:69-86)
   rc = als_eterms(h, s, a.e, a.q);
@@ -1188,13 +1188,23 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
   }
   const uint32_t nseg = s.nseg, nnz = (uint32_t)s.nnz;
   const dim3 gu((uint32_t)std::min<uint64_t>((h->n_local + 255) / 256, 2048));
+  // lanes per column from the mean column length (one-hot data: a handful of rows per feature)
+  const double avg_col = nseg ? (double)nnz / (double)nseg : 0.0;
+  const int G = avg_col <= 5.0 ? 4 : (avg_col <= 12.0 ? 8 : (avg_col <= 40.0 ? 16 : 64));
+#define FMX_ALS_DRAW(ISV, cnt, ...)                                                                          \
+  do {                                                                                                        \
+    if (G == 4)       FMX_LAUNCH_WAVES((k_als_draw<ISV, 4>), ((uint64_t)(cnt) + 15) / 16, st, __VA_ARGS__);    \
+    else if (G == 8)  FMX_LAUNCH_WAVES((k_als_draw<ISV, 8>), ((uint64_t)(cnt) + 7) / 8, st, __VA_ARGS__);      \
+    else if (G == 16) FMX_LAUNCH_WAVES((k_als_draw<ISV, 16>), ((uint64_t)(cnt) + 3) / 4, st, __VA_ARGS__);     \
+    else              FMX_LAUNCH_WAVES((k_als_draw<ISV, 64>), (uint64_t)(cnt), st, __VA_ARGS__);               \
+  } while (0)
   if (h->cfg.k1) {                                         // draw_w per level, :454-476
     for (uint32_t l = 0; l < n_levels; l++) {
       const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
       if (!cnt) continue;
-      FMX_LAUNCH_WAVES((k_als_draw<false>), cnt, st, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                       h->tb.w, h->tb.ws, a.e, (double*)nullptr, opts->alpha, opts->w_lambda, opts->w_mu, opts->do_sample,
-                       opts->seed, (uint64_t)(a.iter * 1024 + 1000));
+      FMX_ALS_DRAW(false, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                   h->tb.w, h->tb.ws, a.e, opts->alpha, opts->w_lambda, opts->w_mu, opts->do_sample,
+                   opts->seed, (uint64_t)(a.iter * 1024 + 1000));
     }
     hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.w, h->tb.ws, opts->w_lambda, opts->w_mu,
                        opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 1001));
@@ -1203,12 +1213,13 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
     double* qf = a.q + (size_t)f * N;
     const double v_lambda = opts->v_lambda_f ? opts->v_lambda_f[f] : opts->v_lambda;
     const double v_mu = opts->v_mu_f ? opts->v_mu_f[f] : opts->v_mu;
+    hipLaunchKernelGGL(k_als_load_q, g1, b1, 0, st, a.e, qf, N);
     for (uint32_t l = 0; l < n_levels; l++) {
       const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
       if (!cnt) continue;
-      FMX_LAUNCH_WAVES((k_als_draw<true>), cnt, st, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                       h->tb.V + f, h->tb.rs, a.e, qf, opts->alpha, v_lambda, v_mu, opts->do_sample,
-                       opts->seed, (uint64_t)(a.iter * 1024 + f));
+      FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                   h->tb.V + f, h->tb.rs, a.e, opts->alpha, v_lambda, v_mu, opts->do_sample,
+                   opts->seed, (uint64_t)(a.iter * 1024 + f));
     }
     hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.V + f, h->tb.rs, v_lambda, v_mu,
                        opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 512 + f));
