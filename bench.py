@@ -117,7 +117,7 @@ def main():
                     help="gloo stages the all-reduce through the host (testing the N>1 path without RCCL)")
     ap.add_argument("--same-device", action="store_true", help="testing: all ranks use cuda:0")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
-    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 65536 sharded); hogwild: rows per launch (0: 262144)")
+    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 131072 sharded); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=256)
     ap.add_argument("--no-bias-lag", action="store_true", help="minibatch: keep the w0 recurrence on the critical path (exact chunk coupling)")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
@@ -183,23 +183,12 @@ def main():
         rows_per_launch = min(batch, args.rows)
         kind = "fused" if args.mode == "hogwild" else "apply"
     else:
-        batch = args.batch or 65536
-        kp1 = info.k_padded + 1
-        buf = torch.empty(batch * kp1, dtype=torch.float32, device="cuda")
-        stream = torch.cuda.current_stream().cuda_stream
+        from libfm_amd.distributed import ShardedSGD
+        batch = args.batch or 131072
+        drv = ShardedSGD(h, 0, args.rows, batch, args.w0_chunk, apply_, lagf, args.backend)
 
         def step(timed):
-            for row0 in range(0, args.rows, batch):
-                nb = min(batch, args.rows - row0)
-                view = buf[: nb * kp1]
-                h.sgd_partial(0, row0, nb, view.data_ptr(), stream)
-                if args.backend == "nccl":
-                    dist.all_reduce(view)
-                else:
-                    host = view.cpu()
-                    dist.all_reduce(host)
-                    view.copy_(host)
-                h.sgd_finish(0, row0, nb, view.data_ptr(), apply_, args.w0_chunk, stream, batch, lagf)
+            drv.epoch()
         rows_per_launch = min(batch, args.rows)
         kind = "apply"
         main_time, main_launches = 0.0, 0
@@ -207,12 +196,15 @@ def main():
     for _ in range(args.warmup):
         step(False)
     if world > 1:
+        drv.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     h.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    if world > 1:
+        drv.synchronize()
     h.synchronize()
     torch.cuda.synchronize()
     if world > 1:
