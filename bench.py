@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the all-reduce through the host (testing the N>1 path without RCCL)")
     ap.add_argument("--same-device", action="store_true", help="testing: all ranks use cuda:0")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="testing: drive the multi-GPU code path (ShardedSGD + all-reduce) even with one rank")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 131072 sharded); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=256)
@@ -143,15 +145,19 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    sharded = world > 1 or args.force_sharded
     if args.mode == "auto":
-        args.mode = "hogwild" if world == 1 else "minibatch"
+        args.mode = "minibatch" if sharded else "hogwild"
     if world > 1 and args.mode != "minibatch":
         raise SystemExit("several GPUs: only --mode minibatch (feature-sharded) exists")
-    if world > 1:
+    if sharded:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cpu, cpu_ref = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -170,7 +176,7 @@ def main():
               "store": capi.APPLY_STORE}[args.apply]
 
     lagf = 0 if (args.no_bias_lag or args.mode == "hogwild") else capi.FLAG_BIAS_LAG
-    if world == 1:
+    if not sharded:
         batch = args.batch or (262144 if args.mode == "hogwild" else 16384)
         main_time, main_launches = 0.0, 0
 
@@ -195,7 +201,7 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if sharded:
         drv.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
@@ -203,14 +209,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    if world > 1:
+    if sharded:
         drv.synchronize()
     h.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -246,10 +252,17 @@ def main():
         }
         if cpu_ref is not None:
             out["cpu_reference"] = cpu_ref
-        print(json.dumps(out), flush=True)
     h.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION): flush it first so that the JSON
+        # line is the LAST line on stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
