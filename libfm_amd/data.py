@@ -1,0 +1,102 @@
+"""Readers / writers of libFM's data formats (host side, numpy).  They produce exactly the buffers the C-ABI takes.
+
+  text   : libsvm lines "target id:value id:value ..."; blank lines and lines starting with '#' are skipped,
+           leading blanks/tabs allowed                                (Data::load, src/libfm/src/Data.h:180-285)
+  binary : <prefix>.x = file_header {u32 id = 2; u32 float_size = 4; u64 num_values; u32 num_rows; u32 num_cols}
+           (24 bytes with the compiler's padding) then per row {u32 size; sparse_entry<float>[size]}
+                                                                      (src/util/fmatrix.h:44-50, 124-143)
+           <prefix>.y = {u32 file_version = 1; u32 data_size = 4; u32 num_rows} then float32[num_rows]
+                                                                      (src/util/matrix.h:344-358)
+           <prefix>.xt = the transpose in the same .x format          (tools/transpose.cpp)
+  Data::load picks binary when <name>.x (and <name>.y) exist, else text (Data.h:119-125); load() does the same.
+"""
+import os
+
+import numpy as np
+
+from .capi import ENTRY_DTYPE
+
+FMATRIX_FILE_ID = 2          # fmatrix.h:32
+DVECTOR_FILE_ID = 1          # matrix.h:32
+_HDR = np.dtype([("id", "<u4"), ("float_size", "<u4"), ("num_values", "<u8"), ("num_rows", "<u4"), ("num_cols", "<u4")])
+
+
+def read_libsvm(path):
+    ids, vals, sizes, ys = [], [], [], []
+    with open(path) as f:
+        for line in f:
+            line = line.lstrip(" \t").rstrip("\r\n")
+            if not line or line[0] == "#":
+                continue
+            toks = line.split()
+            ys.append(float(toks[0]))
+            n = 0
+            for t in toks[1:]:
+                if t[0] == "#":
+                    break
+                a, b = t.split(":")
+                ids.append(int(a))
+                vals.append(float(b))
+                n += 1
+            sizes.append(n)
+    ent = np.zeros(len(ids), dtype=ENTRY_DTYPE)
+    ent["id"] = np.asarray(ids, dtype=np.uint32)
+    ent["value"] = np.asarray(vals, dtype=np.float32)
+    row_ptr = np.concatenate([[0], np.cumsum(np.asarray(sizes, dtype=np.uint64))]).astype(np.uint64)
+    return ent, row_ptr, np.asarray(ys, dtype=np.float32)
+
+
+def read_binary_x(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    hdr = raw[:_HDR.itemsize].view(_HDR)[0]
+    if int(hdr["id"]) != FMATRIX_FILE_ID or int(hdr["float_size"]) != 4:
+        raise ValueError("%s: not a libFM binary matrix (id %d, float_size %d)" % (path, hdr["id"], hdr["float_size"]))
+    n_rows, nnz = int(hdr["num_rows"]), int(hdr["num_values"])
+    body = raw[_HDR.itemsize:]
+    if len(body) != 4 * n_rows + 8 * nnz:
+        raise ValueError("%s: size does not match its header" % path)
+    words = body.view("<u4")
+    ent = np.zeros(nnz, dtype=ENTRY_DTYPE)
+    row_ptr = np.zeros(n_rows + 1, dtype=np.uint64)
+    pos, out = 0, 0
+    for r in range(n_rows):                      # rows are variable length: walk the size words
+        sz = int(words[pos]); pos += 1
+        ent[out:out + sz] = words[pos:pos + 2 * sz].view(ENTRY_DTYPE)
+        pos += 2 * sz; out += sz
+        row_ptr[r + 1] = out
+    return ent, row_ptr, int(hdr["num_cols"])
+
+
+def read_binary_y(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    ver, size, n = raw[:12].view("<u4")
+    if int(ver) != DVECTOR_FILE_ID or int(size) != 4:
+        raise ValueError("%s: not a libFM binary float vector" % path)
+    return raw[12:12 + 4 * int(n)].view("<f4").copy()
+
+
+def write_binary(prefix, entries, row_ptr, target, num_cols=None):
+    """what tools/convert.cpp writes: <prefix>.x and <prefix>.y"""
+    entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    n_rows = len(row_ptr) - 1
+    hdr = np.zeros(1, dtype=_HDR)
+    hdr["id"], hdr["float_size"], hdr["num_values"], hdr["num_rows"] = FMATRIX_FILE_ID, 4, len(entries), n_rows
+    hdr["num_cols"] = num_cols if num_cols is not None else (int(entries["id"].max()) + 1 if len(entries) else 0)
+    with open(prefix + ".x", "wb") as f:
+        f.write(hdr.tobytes())
+        for r in range(n_rows):
+            a, b = row_ptr[r], row_ptr[r + 1]
+            f.write(np.uint32(b - a).tobytes())
+            f.write(entries[a:b].tobytes())
+    with open(prefix + ".y", "wb") as f:
+        f.write(np.array([DVECTOR_FILE_ID, 4, n_rows], dtype="<u4").tobytes())
+        f.write(np.ascontiguousarray(target, dtype="<f4").tobytes())
+
+
+def load(name):
+    """Data::load auto-detection (Data.h:113-125): binary <name>.x/.y if present, else libsvm text <name>."""
+    if os.path.exists(name + ".x") and os.path.exists(name + ".y"):
+        ent, row_ptr, _ = read_binary_x(name + ".x")
+        return ent, row_ptr, read_binary_y(name + ".y")
+    return read_libsvm(name)

@@ -60,6 +60,41 @@ class FMModel:
             self.v = self.init_mean + self.init_stdev * rng.standard_normal((self.num_factor, self.num_attribute))
 
 
+    # fm_model::saveModel (fm_model.h:132-154): text, ostream default precision (= printf %g)
+    def save_model(self, path):
+        with open(path, "w") as f:
+            if self.k0:
+                f.write("#global bias W0\n%g\n" % self.w0)
+            if self.k1:
+                f.write("#unary interactions Wj\n")
+                f.write("".join("%g\n" % x for x in self.w))
+            f.write("#pairwise interactions Vj,f\n")
+            for j in range(self.num_attribute):
+                f.write(" ".join("%g" % x for x in self.v[:, j]) + "\n")
+
+    # fm_model::loadModel (fm_model.h:160-190); returns False on a malformed file like the reference returns 0.
+    # (The reference's splitString yields no token for a line without a blank, so k = 1 models fail to load there,
+    #  fm_model.h:195-205; this reader accepts them.)
+    def load_model(self, path):
+        try:
+            lines = open(path).read().splitlines()
+            pos = 0
+            if self.k0:
+                self.w0 = float(lines[pos + 1]); pos += 2
+            if self.k1:
+                pos += 1
+                self.w = np.array([float(x) for x in lines[pos:pos + self.num_attribute]], dtype=np.float64)
+                pos += self.num_attribute
+            pos += 1
+            rows = [[float(x) for x in ln.split(" ")] for ln in lines[pos:pos + self.num_attribute]]
+            if len(rows) != self.num_attribute or any(len(r) != self.num_factor for r in rows):
+                return False
+            self.v = np.ascontiguousarray(np.array(rows, dtype=np.float64).T)
+            return True
+        except (OSError, ValueError, IndexError):
+            return False
+
+
 class FMLearnSGD:
     """fm_learn_sgd_element on the GPU.
 

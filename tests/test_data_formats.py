@@ -1,0 +1,76 @@
+"""CPU: the host-side readers of libFM's data formats against files written by the REFERENCE's own convert tool
+(oracle/_ref/convert, compiled from /root/reference/src/libfm/tools/convert.cpp when the reference is present) and
+against the documented sizes (.x = 24 + 4N + 8 nnz bytes, .y = 12 + 4N bytes)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import datagen
+from conftest import ROOT
+
+CONVERT = os.path.join(ROOT, "oracle", "_ref", "convert")
+
+
+def test_binary_round_trip_and_sizes(tmp_path):
+    from libfm_amd import data as D
+    ent, rp, y = datagen.ragged_real(97, 60, 9, seed=3, empty_every=7)
+    pre = str(tmp_path / "t")
+    D.write_binary(pre, ent, rp, y)
+    assert os.path.getsize(pre + ".x") == 24 + 4 * 60 + 8 * len(ent)
+    assert os.path.getsize(pre + ".y") == 12 + 4 * 60
+    e2, r2, y2 = D.load(pre)
+    assert np.array_equal(e2, ent) and np.array_equal(r2, rp) and np.array_equal(y2, y)
+
+
+def test_text_reader_matches_reference_parser_rules(tmp_path, oracle):
+    from libfm_amd import data as D
+    p = str(tmp_path / "a.libfm")
+    with open(p, "w") as f:
+        f.write("# comment\n\n  1 0:1 5:0.5\n\t-1 3:2\n0\n2.5 1:1 2:1 # trailing comment\n")
+    ent, rp, y = D.read_libsvm(p)
+    assert list(y) == [1.0, -1.0, 0.0, 2.5]
+    assert list(np.diff(rp.astype(int))) == [2, 1, 0, 2]
+    assert list(ent["id"]) == [0, 5, 3, 1, 2]
+
+
+@pytest.mark.skipif(not os.path.exists(CONVERT), reason="oracle/_ref/convert not built (needs /root/reference)")
+def test_reads_what_the_reference_convert_tool_writes(tmp_path, oracle):
+    from libfm_amd import data as D
+    ent, rp, y = datagen.movielens_shaped(50, 40, 300, seed=1)
+    txt = str(tmp_path / "d.libfm")
+    oracle.Data(ent, rp, y).write_libsvm(txt)
+    pre = str(tmp_path / "d")
+    subprocess.run([CONVERT, "--ifile", txt, "--ofilex", pre + ".x", "--ofiley", pre + ".y"], check=True, capture_output=True)
+    e2, r2, y2 = D.load(pre)
+    assert np.array_equal(e2, ent) and np.array_equal(r2, rp) and np.array_equal(y2, y)
+    # and our writer produces byte-identical files
+    D.write_binary(str(tmp_path / "w"), ent, rp, y)
+    assert open(pre + ".x", "rb").read() == open(str(tmp_path / "w") + ".x", "rb").read()
+    assert open(pre + ".y", "rb").read() == open(str(tmp_path / "w") + ".y", "rb").read()
+
+
+LIBFM = os.path.join(ROOT, "oracle", "_ref", "libFM")
+
+
+@pytest.mark.skipif(not os.path.exists(LIBFM), reason="oracle/_ref/libFM not built (needs /root/reference)")
+def test_model_file_round_trip_is_byte_identical_to_the_reference_writer(tmp_path, oracle):
+    """-save_model text format (fm_model.h:132-154): read the stock binary's file, write it again, same bytes."""
+    from libfm_amd import learner as L
+    ent, rp, y = datagen.movielens_shaped(30, 20, 200, seed=2)
+    txt = str(tmp_path / "d.libfm")
+    oracle.Data(ent, rp, y).write_libsvm(txt)
+    mf = str(tmp_path / "model")
+    subprocess.run([LIBFM, "-task", "r", "-train", txt, "-test", txt, "-dim", "1,1,4", "-iter", "3", "-method", "sgd",
+                    "-learn_rate", "0.01", "-init_stdev", "0.1", "-seed", "7", "-save_model", mf],
+                   check=True, capture_output=True)
+    fm = L.FMModel()
+    fm.num_attribute, fm.num_factor = 50, 4
+    assert fm.load_model(mf)
+    out = str(tmp_path / "model2")
+    fm.save_model(out)
+    assert open(mf).read() == open(out).read()
+    fm2 = L.FMModel()
+    fm2.num_attribute, fm2.num_factor = 50, 5
+    assert not fm2.load_model(mf)                      # wrong k: "malformed model file" (libfm.cpp:264-267)
