@@ -221,6 +221,18 @@ int fmx_als_moments(fmx_handle h, double *out);
 int fmx_als_sweep(fmx_handle h, const fmx_als_opts *opts, fmx_als_stats *stats);
 int fmx_als_end(fmx_handle h);
 
+/* ---- fm_learn_sgd_element_adapt_reg (`-method sgda`; src/libfm/src/fm_learn_sgd_element_adapt_reg.h) -------------
+ * Self-adaptive regularisation: theta steps on the train rows alternate with lambda steps on the validation rows,
+ * strictly online, so this learner exists in the reference-order (one wavefront) form only.  One attribute group.
+ *   fmx_sgda_begin : the learner's start of learn() (:256-262): w := 0, reg_w := 0, reg_v := 0, shadow gradients := 0
+ *   fmx_sgda_epoch : one iteration of the epoch loop (:262-279); do_lambda_steps = 0 in the first iteration (:269)
+ *   fmx_sgda_get_reg : reg[0] = reg_w, reg[1+f] = reg_v[f]  (what -rlog reports as regw[0], regv[0,f])
+ */
+int fmx_sgda_begin(fmx_handle h);
+int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, fmx_epoch_stats *stats);
+int fmx_sgda_get_reg(fmx_handle h, double *reg /* [1 + num_factor] */);
+int fmx_sgda_end(fmx_handle h);
+
 /* ---- introspection --------------------------------------------------------------------------- */
 typedef struct fmx_info {
   uint64_t n_local;         /* features held by this handle */

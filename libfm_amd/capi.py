@@ -90,6 +90,10 @@ SYMBOLS = [
     ("fmx_sgd_partial", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_sgd_finish", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(SgdOpts), C.c_void_p]),
     ("fmx_predict_finish", C.c_int, [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("fmx_sgda_begin", C.c_int, [H]),
+    ("fmx_sgda_epoch", C.c_int, [H, C.c_int, C.c_int, C.c_int, C.POINTER(EpochStats)]),
+    ("fmx_sgda_get_reg", C.c_int, [H, C.c_void_p]),
+    ("fmx_sgda_end", C.c_int, [H]),
     ("fmx_als_begin", C.c_int, [H, C.c_int]),
     ("fmx_als_moments", C.c_int, [H, C.c_void_p]),
     ("fmx_als_sweep", C.c_int, [H, C.POINTER(AlsOpts), C.POINTER(AlsStats)]),
@@ -238,6 +242,23 @@ class Handle:
 
     def predict_finish(self, n_rows, d_partial_ptr, d_yhat_ptr, stream=None):
         self._chk(self.lib.fmx_predict_finish(self.h, n_rows, d_partial_ptr, d_yhat_ptr, stream))
+
+    # SGDA ------------------------------------------------------------------------------------
+    def sgda_begin(self):
+        self._chk(self.lib.fmx_sgda_begin(self.h))
+
+    def sgda_epoch(self, train_slot, val_slot, do_lambda):
+        st = EpochStats()
+        self._chk(self.lib.fmx_sgda_epoch(self.h, train_slot, val_slot, int(do_lambda), C.byref(st)))
+        return st
+
+    def sgda_get_reg(self):
+        out = np.zeros(1 + self.k, dtype=np.float64)
+        self._chk(self.lib.fmx_sgda_get_reg(self.h, _ptr(out)))
+        return out
+
+    def sgda_end(self):
+        self._chk(self.lib.fmx_sgda_end(self.h))
 
     # ALS / MCMC ----------------------------------------------------------------------------
     def als_begin(self, train_slot):

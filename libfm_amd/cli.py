@@ -9,7 +9,7 @@ auto-detection (Data.h:113-125), `-seed` reproducing the reference's initial mod
 targets rewritten to +-1 for `-task c` (:298-306), regularisation / learning-rate parsing (:326-404), the
 `#Iter=...` progress lines, `-out` (:423-428), `-save_model` / `-load_model` (:262-268, :431-434), and the
 reference's error convention: "ERROR: ..." on stderr and exit status 0 (:436-441).
-Not mirrored: `-method sgda`, `-relation`, `-meta` groups, `-cache_size` (out of scope).
+Not mirrored: `-relation`, `-meta` groups, `-cache_size` (out of scope).
 GPU-only additions: -gpu_mode sequential|minibatch|hogwild (default minibatch), -batch, -w0_chunk, -device.
 """
 import sys
@@ -83,7 +83,7 @@ def _main(argv):
     if method == "mcmc" and ("save_model" in a or "load_model" in a):
         print("WARNING: -save_model / -load_model enabled only for SGD and ALS.")      # libfm.cpp:123-133
         return 0
-    if method not in ("sgd", "als", "mcmc"):
+    if method not in ("sgd", "sgda", "als", "mcmc"):
         raise ValueError("unknown method")
     for need in ("task", "train", "test"):
         if need not in a:
@@ -129,8 +129,15 @@ def _main(argv):
     fm.reg0, fm.regw, fm.regv = reg
     num_iter = int(a.get("iter", "100"))
 
-    if method == "sgd":
-        l = L.FMLearnSGD()
+    if method in ("sgd", "sgda"):
+        l = L.FMLearnSGD() if method == "sgd" else L.FMLearnSGDA()
+        if method == "sgda":
+            if "validation" not in a:
+                raise ValueError("sgda needs -validation")
+            print("Loading validation set...\t")
+            l.validation = L.Data(*D.load(a["validation"]))
+            if task == "c":
+                l.validation.target[:] = np.where(l.validation.target <= 0.0, -1.0, 1.0)
         lrs = [float(x) for x in split_list(a.get("learn_rate", ""))]
         if len(lrs) not in (1, 3):
             raise ValueError("-learn_rate needs 1 or 3 values")                     # the reference asserts (libfm.cpp:391-392)
@@ -151,7 +158,7 @@ def _main(argv):
     l.device = int(a.get("device", "-1"))
     l.init()
     l.learn(train, test)
-    if method == "sgd":
+    if method in ("sgd", "sgda"):
         print("Final\tTrain=%g\tTest=%g" % (l.evaluate(train), l.evaluate(test)))   # libfm.cpp:418-420
     if "rlog" in a and a["rlog"]:
         with open(a["rlog"], "w") as f:                                              # rlog.h:60-103: TSV with a header

@@ -61,9 +61,12 @@ struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping: w0 lives in 
   hipEvent_t ev_rest = nullptr, ev_scan[2] = {nullptr, nullptr};
 };
 
+struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; };
+
 struct fmx_context_s {
   fmx_config cfg;
   AlsState   als;
+  SgdaState  sgda;
   LagState   lag;
   int        KP = 1;
   uint64_t   n_local = 0;
@@ -241,6 +244,7 @@ int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0,
 }  // namespace
 
 static void als_free(fmx_handle h);
+static void sgda_free(fmx_handle h);
 static int lag_flush(fmx_handle h);
 
 extern "C" {
@@ -332,6 +336,7 @@ int fmx_destroy(fmx_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   als_free(h);
+  sgda_free(h);
   for (auto& s : h->slots) free_slot(s);
   if (h->tb.V) hipFree(h->tb.V);
   if (h->w_sep) hipFree(h->w_sep);
@@ -1041,6 +1046,82 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
       stats->main_kernel_seconds = stats->device_seconds;
       stats->main_kernel_launches = main_launches;
     }
+  }
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SGDA
+// ---------------------------------------------------------------------------------------------
+static void sgda_free(fmx_handle h) {
+  if (h->sgda.gw) hipFree(h->sgda.gw);
+  if (h->sgda.gv) hipFree(h->sgda.gv);
+  if (h->sgda.reg) hipFree(h->sgda.reg);
+  h->sgda = SgdaState();
+}
+
+int fmx_sgda_end(fmx_handle h) {
+  if (!h) return FMX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  sgda_free(h);
+  return FMX_OK;
+}
+
+int fmx_sgda_begin(fmx_handle h) {
+  if (!h) return FMX_E_ARG;
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "SGDA on a feature shard is not implemented");
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  sgda_free(h);
+  const size_t nv = h->n_local * (size_t)h->tb.rs, nreg = 1 + (size_t)h->KP;
+  HIPCHK(h, hipMalloc(&h->sgda.gw, h->n_local * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->sgda.gv, nv * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->sgda.reg, nreg * sizeof(double)));
+  HIPCHK(h, hipMemsetAsync(h->sgda.gw, 0, h->n_local * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->sgda.gv, 0, nv * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->sgda.reg, 0, nreg * sizeof(double), h->stream));
+  // fm->w.init(0) (:256): the linear weights restart from zero
+  if (h->tb.ws == 1) HIPCHK(h, hipMemsetAsync(h->tb.w, 0, h->n_local * sizeof(float), h->stream));
+  else HIPCHK(h, hipMemset2DAsync(h->tb.w, (size_t)h->tb.ws * sizeof(float), 0, sizeof(float), h->n_local, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+int fmx_sgda_get_reg(fmx_handle h, double* reg) {
+  if (!h || !reg) return FMX_E_ARG;
+  if (!h->sgda.reg) return fail(h, FMX_E_STATE, "fmx_sgda_get_reg before fmx_sgda_begin");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(reg, h->sgda.reg, (1 + (size_t)h->cfg.num_factor) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, fmx_epoch_stats* stats) {
+  int rc = check_slot(h, train_slot, true);
+  if (rc) return rc;
+  rc = check_slot(h, validation_slot, true);
+  if (rc) return rc;
+  if (!h->sgda.reg) return fail(h, FMX_E_STATE, "fmx_sgda_epoch before fmx_sgda_begin");
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[train_slot];
+  const Slot& v = h->slots[validation_slot];
+  const Hyper hy = make_hyper(h->cfg);
+  if (stats) memset(stats, 0, sizeof(*stats));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows,
+                                        v.ent, v.row_ptr, v.target, v.n_rows, h->tb, h->sgda.gw, h->sgda.gv, hy, h->w0,
+                                        h->sgda.reg, do_lambda_steps));
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (stats) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    stats->rows = s.n_rows; stats->batches = s.n_rows; stats->device_seconds = ms * 1e-3;
+    stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = 1;
   }
   return FMX_OK;
 }

@@ -733,6 +733,145 @@ k_sequential(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
 }
 
 // ----------------------------------------------------------------------------------------------
+// k_sgda: fm_learn_sgd_element_adapt_reg (`-method sgda`, src/libfm/src/fm_learn_sgd_element_adapt_reg.h), ONE
+// wavefront, the reference's strictly online interleaving: for every train row a theta step (:136-169: like fm_SGD
+// but mult = 2(p-y), regularisation 2*reg*theta with the LEARNED reg_w / reg_v[f], and the gradient of every
+// touched parameter remembered in grad_w / grad_v), then (from the 2nd epoch on) a lambda step on the next
+// validation row (:201-248 through predict_scaled :171-199).  One attribute group.  Sums in fp64, parameters and
+// shadow gradients stored fp32.  reg: [0] = reg_w, [1+f] = reg_v[f].
+// ----------------------------------------------------------------------------------------------
+template <int KP>
+__global__ void __launch_bounds__(64)
+k_sgda(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint32_t n_rows,
+       const Entry* __restrict__ vent, const uint64_t* __restrict__ vrow_ptr, const float* __restrict__ vtarget, uint32_t v_rows,
+       const Tab tb, float* gw, float* gv, Hyper h, double* w0_ptr, double* reg, int do_lambda) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  const uint32_t lane = threadIdx.x;
+  const bool act = lane < LPR;
+  double w0 = *w0_ptr;
+  double reg_w = reg[0];
+  double reg_v[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; v++) reg_v[v] = act ? reg[1 + lane * VEC + v] : 0.0;
+  uint32_t vpos = 0;                                                        // validation->data->begin() (:266)
+#define LD(p) ((double)__hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#define ST(p, val) __hip_atomic_store((p), (float)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+  for (uint32_t r = 0; r < n_rows; r++) {
+    // ---------------- theta step (:136-169)
+    const uint64_t a = row_ptr[r];
+    const uint32_t size = (uint32_t)(row_ptr[r + 1] - a);
+    double sum[VEC]; double sq = 0.0, lin = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) sum[v] = 0.0;
+    for (uint32_t i = 0; i < size; i++) {
+      const Entry e = ent[a + i];
+      if (h.k1 && lane == 0) lin += LD(tb.w + (size_t)e.id * tb.ws) * (double)e.value;
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const double d = LD(tb.V + (size_t)e.id * tb.rs + lane * VEC + v) * (double)e.value;
+          sum[v] += d; sq += d * d;
+        }
+      }
+    }
+    double part = lin - 0.5 * sq;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+    }
+    double p = (h.k0 ? w0 : 0.0) + wave_sum_d(part);
+    const double y = (double)target[r];
+    double mult;
+    if (h.task == 0) { p = fmin(h.max_d, p); p = fmax(h.min_d, p); mult = 2 * (p - y); }
+    else mult = y * ((1.0 / (1.0 + exp(-y * p))) - 1.0);
+    if (h.k0) w0 -= h.lr_d * (mult + 2 * 0.0 * w0);                          // reg_0 = 0 (:100)
+    for (uint32_t i = 0; i < size; i++) {
+      const Entry e = ent[a + i];
+      const double x = (double)e.value;
+      if (h.k1 && lane == 0) {
+        float* pw = tb.w + (size_t)e.id * tb.ws;
+        const double wv = LD(pw);
+        const double g = mult * x;
+        ST(gw + e.id, g);
+        ST(pw, wv - h.lr_d * ((double)(float)g + 2 * reg_w * wv));
+      }
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          float* pv = tb.V + (size_t)e.id * tb.rs + lane * VEC + v;
+          const double vv = LD(pv);
+          const double g = mult * (x * (sum[v] - vv * x));
+          ST(gv + (size_t)e.id * tb.rs + lane * VEC + v, g);
+          ST(pv, vv - h.lr_d * ((double)(float)g + 2 * reg_v[v] * vv));
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (!do_lambda || v_rows == 0) continue;
+    // ---------------- lambda step on the next validation row (:271-276, :201-248)
+    if (vpos >= v_rows) vpos = 0;
+    const uint64_t va = vrow_ptr[vpos];
+    const uint32_t vsize = (uint32_t)(vrow_ptr[vpos + 1] - va);
+    const double vy = (double)vtarget[vpos];
+    vpos++;
+    double lw = 0.0, plin = 0.0;
+    double s_dash[VEC], s_f[VEC], s_df[VEC]; double q_dash = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) { s_dash[v] = 0.0; s_f[v] = 0.0; s_df[v] = 0.0; }
+    for (uint32_t i = 0; i < vsize; i++) {
+      const Entry e = vent[va + i];
+      const double x = (double)e.value;
+      if (h.k1 && lane == 0) {
+        const double wv = LD(tb.w + (size_t)e.id * tb.ws);
+        const double w_dash = wv - h.lr_d * (LD(gw + e.id) + 2 * reg_w * wv);   // predict_scaled :178-184
+        plin += w_dash * x;
+        lw += x * wv;                                                            // :215-218
+      }
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const double vv = LD(tb.V + (size_t)e.id * tb.rs + lane * VEC + v);
+          const double v_dash = vv - h.lr_d * (LD(gv + (size_t)e.id * tb.rs + lane * VEC + v) + 2 * reg_v[v] * vv);
+          const double d = v_dash * x;
+          s_dash[v] += d; q_dash += d * d;                                       // :186-196
+          s_f[v] += vv * x;                                                      // :233-238
+          s_df[v] += d * vv * x;
+        }
+      }
+    }
+    double vpart = plin - 0.5 * q_dash;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) vpart += 0.5 * s_dash[v] * s_dash[v];
+    }
+    double vp = (h.k0 ? w0 : 0.0) + wave_sum_d(vpart);
+    double grad_loss;
+    if (h.task == 0) { vp = fmin(h.max_d, vp); vp = fmax(h.min_d, vp); grad_loss = 2 * (vp - vy); }
+    else grad_loss = vy * ((1.0 / (1.0 + exp(-vy * vp))) - 1.0);
+    if (h.k1) {                                                                  // :213-224
+      const double lwt = -2 * h.lr_d * wave_sum_d(lw);
+      reg_w -= h.lr_d * grad_loss * lwt;
+      reg_w = fmax(0.0, reg_w);
+    }
+    if (act) {                                                                   // :240-246
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        const double lambda_v_grad = -2 * h.lr_d * (s_dash[v] * s_f[v] - s_df[v]);
+        reg_v[v] -= h.lr_d * grad_loss * lambda_v_grad;
+        reg_v[v] = fmax(0.0, reg_v[v]);
+      }
+    }
+  }
+#undef LD
+#undef ST
+  if (lane == 0) { *w0_ptr = w0; reg[0] = reg_w; }
+  if (act) {
+#pragma unroll
+    for (int v = 0; v < VEC; v++) reg[1 + lane * VEC + v] = reg_v[v];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // evaluation: y-hat = w0 + rest, then the reductions of fm_learn.h:113-153
 // acc[0] = sum err^2 (clamped), acc[1] = sum |err|, acc[2] = #correct sign
 // ----------------------------------------------------------------------------------------------

@@ -331,3 +331,35 @@ class FMLearnMCMC(FMLearnALS):
 
 def sv_f(mom, f):
     return mom[4 + 2 * f]
+
+
+class FMLearnSGDA(FMLearnSGD):
+    """fm_learn_sgd_element_adapt_reg (`-method sgda`, fm_learn_sgd_element_adapt_reg.h:44-93) on the GPU: theta steps
+    on the train rows alternate with lambda steps on `validation` (libfm.cpp:276-279).  Reference-order only."""
+
+    def __init__(self):
+        super().__init__()
+        self.validation = None
+        self.reg_w = 0.0
+        self.reg_v = None
+
+    def learn(self, train, test):
+        if self.validation is None:
+            raise ValueError("sgda needs a validation set")              # the reference asserts (libfm.cpp:277)
+        print("Training using self-adaptive-regularization SGD.", file=self.out)
+        h = self._h
+        st, sv = self._slot(train), self._slot(self.validation)
+        self.fm.reg0 = self.fm.regw = self.fm.regv = 0.0                  # :257-259
+        h.sgda_begin()
+        for i in range(self.num_iter):
+            stats = h.sgda_epoch(st, sv, i > 0)
+            rmse_val = self.evaluate(self.validation)
+            rmse_train = self.evaluate(train)
+            rmse_test = self.evaluate(test)
+            print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, rmse_train, rmse_test), file=self.out)
+            reg = h.sgda_get_reg()
+            self.reg_w, self.reg_v = float(reg[0]), reg[1:].copy()
+            self.log.append({"rmse_train": rmse_train, "rmse_val": rmse_val, "time_learn": stats.device_seconds,
+                             "regw[0]": self.reg_w})
+        h.sgda_end()
+        self.sync_model()

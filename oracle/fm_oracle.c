@@ -250,6 +250,109 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
   free(S); free(rest); free(mult); free(sum_sqr); free(dw); free(dv);
 }
 
+/* ------------------------------- SGDA ------------------------------- */
+/* sgd_theta_step                    /root/reference/src/libfm/src/fm_learn_sgd_element_adapt_reg.h:136-169 */
+static void sgda_theta_step(fmo_model *m, fmo_sgda_state *st, const fmo_entry *row, uint32_t size, double target,
+                            int task, double lr, double min_target, double max_target, double *sum, double *sum_sqr) {
+  double p = fmo_predict_row(m, row, size, sum, sum_sqr);
+  double mult = 0;
+  if (task == 0) {
+    p = (max_target < p) ? max_target : p;
+    p = (min_target > p) ? min_target : p;
+    mult = 2 * (p - target);                                   /* :142 (note the factor 2, unlike plain SGD) */
+  } else if (task == 1) {
+    mult = target * ((1.0 / (1.0 + exp(-target * p))) - 1.0);  /* :144 */
+  }
+  const size_t n = (size_t)m->n;
+  if (m->k0) m->w0 -= lr * (mult + 2 * 0.0 * m->w0);           /* reg_0 = 0 (:100,:149) */
+  if (m->k1)
+    for (uint32_t i = 0; i < size; i++) {
+      double *w = &m->w[row[i].id];
+      st->grad_w[row[i].id] = mult * row[i].value;
+      *w -= lr * (st->grad_w[row[i].id] + 2 * st->reg_w * (*w));
+    }
+  for (int f = 0; f < m->k; f++)
+    for (uint32_t i = 0; i < size; i++) {
+      double *v = &V(m, f, row[i].id);
+      double *g = &st->grad_v[(size_t)f * n + row[i].id];
+      *g = mult * (row[i].value * (sum[f] - (*v) * row[i].value));
+      *v -= lr * (*g + 2 * st->reg_v[f] * (*v));
+    }
+}
+
+/* predict_scaled (:171-199) + sgd_lambda_step (:201-248), one attribute group */
+static void sgda_lambda_step(fmo_model *m, fmo_sgda_state *st, const fmo_entry *row, uint32_t size, double target,
+                             int task, double lr, double min_target, double max_target) {
+  const size_t n = (size_t)m->n;
+  double p = 0.0;
+  if (m->k0) p += m->w0;
+  if (m->k1)
+    for (uint32_t i = 0; i < size; i++) {
+      double w = m->w[row[i].id];
+      double w_dash = w - lr * (st->grad_w[row[i].id] + 2 * st->reg_w * w);
+      p += w_dash * row[i].value;
+    }
+  for (int f = 0; f < m->k; f++) {
+    double s = 0.0, q = 0.0;
+    for (uint32_t i = 0; i < size; i++) {
+      double v = V(m, f, row[i].id);
+      double v_dash = v - lr * (st->grad_v[(size_t)f * n + row[i].id] + 2 * st->reg_v[f] * v);
+      double d = v_dash * row[i].value;
+      s += d; q += d * d;
+    }
+    p += 0.5 * (s * s - q);
+  }
+  double grad_loss = 0;
+  if (task == 0) {
+    p = (max_target < p) ? max_target : p;
+    p = (min_target > p) ? min_target : p;
+    grad_loss = 2 * (p - target);
+  } else if (task == 1) {
+    grad_loss = target * ((1.0 / (1.0 + exp(-target * p))) - 1.0);
+  }
+  if (m->k1) {                                                 /* :213-224 */
+    double lw = 0.0;
+    for (uint32_t i = 0; i < size; i++) lw += row[i].value * m->w[row[i].id];
+    lw = -2 * lr * lw;
+    st->reg_w -= lr * grad_loss * lw;
+    st->reg_w = (0.0 > st->reg_w) ? 0.0 : st->reg_w;
+  }
+  for (int f = 0; f < m->k; f++) {                             /* :225-247 */
+    double sum_f_dash = 0.0, sum_f = 0.0, sum_f_dash_f = 0.0;
+    for (uint32_t i = 0; i < size; i++) {
+      double v = V(m, f, row[i].id);
+      double v_dash = v - lr * (st->grad_v[(size_t)f * n + row[i].id] + 2 * st->reg_v[f] * v);
+      sum_f_dash += v_dash * row[i].value;
+      sum_f += v * row[i].value;
+      sum_f_dash_f += v_dash * row[i].value * v * row[i].value;
+    }
+    double lambda_v_grad = -2 * lr * (sum_f_dash * sum_f - sum_f_dash_f);
+    st->reg_v[f] -= lr * grad_loss * lambda_v_grad;
+    st->reg_v[f] = (0.0 > st->reg_v[f]) ? 0.0 : st->reg_v[f];
+  }
+}
+
+/* one iteration of fm_learn_sgd_element_adapt_reg::learn (:262-279) */
+void fmo_sgda_epoch(fmo_model *m, fmo_sgda_state *st, const fmo_data *train, const fmo_data *val, int task,
+                    double learn_rate, double min_target, double max_target, int do_lambda_steps) {
+  double *sum = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  double *sum_sqr = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  st->val_pos = 0;                                             /* validation->data->begin() (:266) */
+  for (uint32_t r = 0; r < train->n_rows; r++) {
+    const fmo_entry *row = train->entries + train->row_ptr[r];
+    uint32_t size = (uint32_t)(train->row_ptr[r + 1] - train->row_ptr[r]);
+    sgda_theta_step(m, st, row, size, (double)train->target[r], task, learn_rate, min_target, max_target, sum, sum_sqr);
+    if (do_lambda_steps) {
+      if (st->val_pos >= val->n_rows) st->val_pos = 0;         /* :271-274 */
+      const fmo_entry *vrow = val->entries + val->row_ptr[st->val_pos];
+      uint32_t vsize = (uint32_t)(val->row_ptr[st->val_pos + 1] - val->row_ptr[st->val_pos]);
+      sgda_lambda_step(m, st, vrow, vsize, (double)val->target[st->val_pos], task, learn_rate, min_target, max_target);
+      st->val_pos++;
+    }
+  }
+  free(sum); free(sum_sqr);
+}
+
 /* ------------------------------- synthetic workload ------------------------------- */
 
 uint64_t fmo_mix64(uint64_t x) {          /* splitmix64 finaliser */

@@ -107,6 +107,22 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
                                 double min_target, double max_target,
                                 uint32_t batch, uint32_t w0_chunk, int bias_lag);
 
+/* ---------------- SGDA (adaptive regularisation, Rendle WSDM'12) ---------------------------------------------
+ * fm_learn_sgd_element_adapt_reg (src/libfm/src/fm_learn_sgd_element_adapt_reg.h): one attribute group.
+ * state: reg_w (scalar), reg_v[k], and the shadow gradients grad_w[n], grad_v[k][n] of the last theta step that
+ * touched each parameter (:84-95).  One epoch (:262-279): for every train row a theta step (:136-169); from the
+ * second epoch on, each theta step is followed by a lambda step (:201-248, through predict_scaled :171-199) on the
+ * next validation row (cyclic).  The learner zeroes w and the model's reg values at the start of learn (:256-262). */
+typedef struct {
+  double  reg_w;
+  double *reg_v;     /* [k] */
+  double *grad_w;    /* [n] */
+  double *grad_v;    /* [k][n] factor-major */
+  uint32_t val_pos;  /* next validation row */
+} fmo_sgda_state;
+void fmo_sgda_epoch(fmo_model *m, fmo_sgda_state *st, const fmo_data *train, const fmo_data *val, int task,
+                    double learn_rate, double min_target, double max_target, int do_lambda_steps);
+
 /* ---------------- ALS (coordinate descent; "MCMC without sampling", libfm.cpp:135-139) ---------------- */
 
 typedef struct {

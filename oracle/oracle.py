@@ -44,6 +44,11 @@ class _Data(C.Structure):
                 ("n_rows", C.c_uint32)]
 
 
+class _SgdaState(C.Structure):
+    _fields_ = [("reg_w", C.c_double), ("reg_v", C.c_void_p), ("grad_w", C.c_void_p), ("grad_v", C.c_void_p),
+                ("val_pos", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -68,6 +73,8 @@ def lib():
         L.fmo_init_value.restype = C.c_double
         L.fmo_als_learn.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.POINTER(_Data), C.c_int, C.c_int, C.c_double, C.c_double,
                                     C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.fmo_sgda_epoch.argtypes = [C.POINTER(_Model), C.POINTER(_SgdaState), C.POINTER(_Data), C.POINTER(_Data), C.c_int,
+                                     C.c_double, C.c_double, C.c_double, C.c_int]
         L.fmo_fill_params.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_double, C.c_int]
         L.fmo_time_sgd_synth.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_double]
         L.fmo_time_sgd_synth.restype = C.c_double
@@ -256,3 +263,26 @@ def als_learn(m, train, test, task, num_iter, w_lambda, v_lambda, min_target, ma
                         pred.ctypes.data, metric.ctypes.data)
     m.w0 = cm.w0
     return pred, metric
+
+
+class SgdaState:
+    """reg_w, reg_v[k] and the shadow gradients of fm_learn_sgd_element_adapt_reg (one attribute group)."""
+
+    def __init__(self, n, k):
+        self.reg_w = 0.0
+        self.reg_v = np.zeros(max(k, 1), dtype=np.float64)
+        self.grad_w = np.zeros(n, dtype=np.float64)
+        self.grad_v = np.zeros((max(k, 1), n), dtype=np.float64)
+
+
+def sgda_learn(m, train, val, task, lr, min_target, max_target, num_iter):
+    """fm_learn_sgd_element_adapt_reg::learn (:250-279): w := 0, regs := 0, then num_iter epochs (lambda steps from the 2nd)."""
+    st = SgdaState(m.n, m.k)
+    m.w[:] = 0.0
+    for i in range(num_iter):
+        cm, ctr, cv = m._c(), train._c(), val._c()
+        cs = _SgdaState(st.reg_w, st.reg_v.ctypes.data, st.grad_w.ctypes.data, st.grad_v.ctypes.data, 0)
+        lib().fmo_sgda_epoch(C.byref(cm), C.byref(cs), C.byref(ctr), C.byref(cv), task, lr, min_target, max_target, int(i > 0))
+        m.w0 = cm.w0
+        st.reg_w = cs.reg_w
+    return st

@@ -12,6 +12,7 @@
 //   ref_harness sgd  <train> <test> <task r|c> <k0> <k1> <k> <iters> <lr> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
 //   ref_harness sgd_gpu <same arguments as sgd> [mode 0|1|2] [batch] [w0_chunk]
 //                    (same driver, but the learner is adapter/fm_learn_sgd_gpu.h -> libfmx.so; needs a GPU)
+//   ref_harness sgda <same arguments as sgd> <validation>   (fm_learn_sgd_element_adapt_reg; also dumps .reg.txt: reg_w, reg_v[f])
 //   ref_harness als  <train> <test> <task r|c> <k0> <k1> <k> <iters> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
 //   ref_harness mcmc <train> <test> <task r|c> <k0> <k1> <k> <iters> <init_stdev> <seed> <out_prefix>
 //   ref_harness time_sgd <n> <k> <nnz> <rows> <seed>        (CPU baseline: reference fm_model::predict + fm_SGD on
@@ -126,14 +127,14 @@ int main(int argc, char** argv) {
     int k0 = atoi(argv[a++]), k1 = atoi(argv[a++]), k = atoi(argv[a++]);
     int iters = atoi(argv[a++]);
     double lr = 0, reg0 = 0, regw = 0, regv = 0;
-    if (mode == "sgd" || mode == "sgd_gpu") lr = atof(argv[a++]);
+    if (mode == "sgd" || mode == "sgd_gpu" || mode == "sgda") lr = atof(argv[a++]);
     if (mode != "mcmc") { reg0 = atof(argv[a++]); regw = atof(argv[a++]); regv = atof(argv[a++]); }
     double init_stdev = atof(argv[a++]);
     long seed = atol(argv[a++]);
     std::string prefix = argv[a++];
 
     srand(seed);                                               // libfm.cpp:115-116
-    const bool is_sgd = (mode == "sgd" || mode == "sgd_gpu");
+    const bool is_sgd = (mode == "sgd" || mode == "sgd_gpu" || mode == "sgda");
     Data train(0, is_sgd, !is_sgd);                            // libfm.cpp:143-148
     train.load(train_file);
     Data test(0, is_sgd, !is_sgd);
@@ -172,6 +173,33 @@ int main(int argc, char** argv) {
       dump_vec(prefix + ".pred_out.bin", pred.value, pred.dim);
     } else
 #endif
+    if (mode == "sgda") {
+      std::string val_file = argv[a++];
+      Data validation(0, true, false);
+      validation.load(val_file);
+      validation.relation.setSize(0);
+      Open<fm_learn_sgd_element_adapt_reg>* fml = new Open<fm_learn_sgd_element_adapt_reg>();
+      fml->num_iter = iters;
+      fml->validation = &validation;                           // libfm.cpp:279
+      fml->fm = &fm; fml->max_target = train.max_target; fml->min_target = train.min_target; fml->meta = &meta;
+      set_task(fml, task, train, test);
+      if (task != "r") for (uint i = 0; i < validation.target.dim; i++) { if (validation.target(i) <= 0.0) { validation.target(i) = -1.0; } else { validation.target(i) = 1.0; } }
+      fml->log = NULL;
+      fml->init();
+      fm.reg0 = reg0; fm.regw = regw; fm.regv = regv;
+      fml->learn_rate = lr; fml->learn_rates.init(lr);
+      dump_params(prefix + ".init.bin", fm);
+      fml->learn(train, test);
+      fprintf(ev, "%.17g %.17g\n", fml->evaluate(train), fml->evaluate(test));
+      dump_params(prefix + ".final.bin", fm);
+      DVector<double> pred; pred.setSize(test.num_cases);
+      fml->predict(test, pred);
+      dump_vec(prefix + ".pred_out.bin", pred.value, pred.dim);
+      FILE* rf = fopen((prefix + ".reg.txt").c_str(), "w");
+      fprintf(rf, "%.17g\n", fml->reg_w(0));
+      for (int f = 0; f < k; f++) fprintf(rf, "%.17g\n", fml->reg_v(0, f));
+      fclose(rf);
+    } else
     if (is_sgd) {
       Open<fm_learn_sgd_element>* fml = new Open<fm_learn_sgd_element>();
       fml->num_iter = 1;

@@ -136,6 +136,49 @@ def make_mcmc():
             print("%-22s n=%d rows=%d/%d test accuracy of the reference's posterior mean: %.4f" % (name, init.n, tr.n_rows, te.n_rows, np.mean((pred_out >= 0.5) == (yy == 1))))
 
 
+SGDA_CASES = {
+    "sgda_reg_ml": dict(gen="movielens_shaped", n=dict(n_users=120, n_items=80, seed=11), rows=(600, 150, 200),
+                        cfg=dict(task="r", k0=1, k1=1, k=8, iters=4, lr=0.005, init_stdev=0.1, seed=42)),
+    "sgda_cls_fields": dict(gen="onehot_fields", n=dict(n_features=300, nnz=6, seed=41), rows=(500, 100, 150),
+                            cfg=dict(task="c", k0=1, k1=1, k=4, iters=3, lr=0.02, init_stdev=0.1, seed=3)),
+}
+
+
+def make_sgda():
+    for name, case in SGDA_CASES.items():
+        gen = getattr(datagen, case["gen"])
+        ntr, nte, nva = case["rows"]
+        ent, rp, y = gen(n_rows=ntr + nte + nva, **case["n"])
+        rp = rp.astype(np.int64)
+
+        def part(a, b):
+            return O.Data(ent[rp[a]:rp[b]], rp[a:b + 1] - rp[a], y[a:b])
+        tr, te, va = part(0, ntr), part(ntr, ntr + nte), part(ntr + nte, ntr + nte + nva)
+        cfg = case["cfg"]
+        with tempfile.TemporaryDirectory() as td:
+            f = [os.path.join(td, x) for x in ("train", "test", "val")]
+            for d, p in zip((tr, te, va), f):
+                d.write_libsvm(p)
+            pre = os.path.join(td, "out")
+            O.run_ref_harness(["sgda", f[0], f[1], cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"], repr(cfg["lr"]),
+                               "0", "0", "0", repr(cfg["init_stdev"]), cfg["seed"], pre, f[2]])
+            init = O.Model.from_dump(pre + ".init.bin")
+            final = O.Model.from_dump(pre + ".final.bin")
+            pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+            regs = np.loadtxt(pre + ".reg.txt")
+            ev = np.loadtxt(pre + ".eval.txt", ndmin=2)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            train_entries=tr.entries, train_row_ptr=tr.row_ptr, train_target=tr.target,
+            test_entries=te.entries, test_row_ptr=te.row_ptr, test_target=te.target,
+            val_entries=va.entries, val_row_ptr=va.row_ptr, val_target=va.target,
+            task=cfg["task"], k0=cfg["k0"], k1=cfg["k1"], k=cfg["k"], iters=cfg["iters"], lr=cfg["lr"],
+            reg=np.zeros(3), init_stdev=cfg["init_stdev"], seed=cfg["seed"],
+            n=init.n, init_w0=init.w0, init_w=init.w, init_v=init.v,
+            final_w0=final.w0, final_w=final.w, final_v=final.v, pred_out=pred_out, regs=regs, eval=ev)
+        print("%-22s n=%d k=%d rows=%d/%d/%d reg_w=%.4g reg_v[0]=%.4g" % (name, init.n, init.k, ntr, nte, nva, regs[0], regs[1]))
+
+
 def make_c1():
     """BASELINE.json configs[0]: MovieLens-100K-shaped plumbing case run through the STOCK reference binary
     (oracle/_ref/libFM, the reference's own main + CLI + text parser + -out / -save_model writers)."""
@@ -176,6 +219,7 @@ def main():
     if "--c1" in sys.argv or not os.path.exists(os.path.join(HERE, "c1_ml100k_shaped.npz")):
         make_c1()
     make_mcmc()
+    make_sgda()
     make_als()
     for name, case in CASES.items():
         gen = getattr(datagen, case["gen"])

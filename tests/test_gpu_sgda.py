@@ -1,0 +1,42 @@
+"""GPU: `-method sgda` (fm_learn_sgd_element_adapt_reg) against the REAL reference's results (fixtures produced by
+oracle/_ref/ref_harness sgda): final parameters, the LEARNED regularisation values and the -out predictions."""
+import io
+
+import numpy as np
+import pytest
+
+from common import Golden
+from conftest import golden_cases
+
+pytestmark = pytest.mark.gpu
+CASES = [c for c in golden_cases() if c.startswith("sgda_")]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sgda_matches_reference(oracle, name):
+    from libfm_amd import learner as L
+    g = Golden(name)
+    z = g.z
+    fm = L.FMModel()
+    fm.num_attribute, fm.num_factor, fm.k0, fm.k1 = g.n, g.k, bool(g.k0), bool(g.k1)
+    m = g.model(oracle, "init")
+    fm.w0, fm.w, fm.v = m.w0, m.w.copy(), m.v.copy()
+    vt = z["val_target"].copy()
+    if g.task == 1:
+        vt = np.where(vt <= 0, -1.0, 1.0).astype(np.float32)
+    l = L.FMLearnSGDA()
+    l.fm, l.task, l.num_iter, l.learn_rate = fm, g.task, g.iters, g.lr
+    l.min_target, l.max_target = g.min_target, g.max_target
+    l.validation = L.Data(z["val_entries"], z["val_row_ptr"], vt)
+    l.out = io.StringIO()
+    train = L.Data(z["train_entries"], z["train_row_ptr"], g.train_target)
+    test = L.Data(z["test_entries"], z["test_row_ptr"], g.test_target)
+    l.init()
+    l.learn(train, test)
+    np.testing.assert_allclose(fm.v, z["final_v"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(fm.w, z["final_w"], rtol=1e-4, atol=2e-5)
+    assert abs(fm.w0 - float(z["final_w0"])) <= 1e-4 * abs(float(z["final_w0"])) + 2e-5
+    np.testing.assert_allclose(l.reg_w, z["regs"][0], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(l.reg_v, z["regs"][1:], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(l.predict(test), z["pred_out"], rtol=1e-4, atol=5e-5)
+    l.close()

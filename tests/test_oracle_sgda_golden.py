@@ -1,0 +1,32 @@
+"""CPU: pins the SGDA restatement (oracle/fm_oracle.c fmo_sgda_epoch) against the REAL reference's
+fm_learn_sgd_element_adapt_reg (`-method sgda`).  Bar: bit-exact fp64 (parameters and learned regularisation)."""
+import numpy as np
+import pytest
+
+from common import Golden
+from conftest import golden_cases
+
+CASES = [c for c in golden_cases() if c.startswith("sgda_")]
+
+
+def val_data(g, O):
+    z = g.z
+    t = z["val_target"].copy()
+    if g.task == 1:
+        t = np.where(t <= 0, -1.0, 1.0).astype(np.float32)
+    return O.Data(z["val_entries"], z["val_row_ptr"], t)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sgda_bit_exact(oracle, name):
+    O = oracle
+    g = Golden(name)
+    m = g.model(O, "init")
+    m.reg0 = m.regw = m.regv = 0.0
+    st = O.sgda_learn(m, g.data(O, "train"), val_data(g, O), g.task, g.lr, g.min_target, g.max_target, g.iters)
+    assert m.w0 == float(g.z["final_w0"])
+    assert np.array_equal(m.w, g.z["final_w"])
+    assert np.array_equal(m.v, g.z["final_v"])
+    assert st.reg_w == g.z["regs"][0]
+    assert np.array_equal(st.reg_v[:g.k], g.z["regs"][1:])
+    assert np.array_equal(O.predict_out(m, g.data(O, "test"), g.task, g.min_target, g.max_target), g.z["pred_out"])
