@@ -1,0 +1,92 @@
+// adapter/fm_learn_mcmc_gpu.h -- REFERENCE-SIDE binding of the ALS learner (`-method als` = MCMC without sampling,
+// src/libfm/libfm.cpp:135-139) to libfmx.  Same rules as fm_learn_sgd_gpu.h: include it in the one translation unit
+// that includes the reference headers, after fm_learn_mcmc_simultaneous.h.
+//
+// It derives from fm_learn_mcmc so that main()'s casts and field writes keep working unchanged
+// (libfm.cpp:284-290: num_iter, num_eval_cases, do_sample, do_multilevel; :335-352: w_lambda / v_lambda from
+// -regular) and replaces the iteration loop of fm_learn_mcmc_simultaneous::_learn (fm_learn_mcmc_simultaneous.h:
+// 56-270) by fmx_als_begin / fmx_als_sweep.  Only do_sample = 0, do_multilevel = 0, one attribute group, no relations.
+#ifndef FM_LEARN_MCMC_GPU_H_
+#define FM_LEARN_MCMC_GPU_H_
+
+#include <vector>
+#include <string>
+#include "fmx.h"
+
+class fm_learn_als_gpu : public fm_learn_mcmc {
+ public:
+  int gpu_device;
+  fm_learn_als_gpu() : gpu_device(-1), h(NULL) {}
+  virtual ~fm_learn_als_gpu() { if (h) fmx_destroy(h); }
+
+  virtual void learn(Data& train, Data& test) {            // fm_learn_mcmc::learn (:1160-1201) + _learn
+    if (do_sample || do_multilevel) throw "fm_learn_als_gpu: only -method als (no sampling) is bound";
+    if (train.relation.dim > 0) throw "relations are not supported";
+    if (meta->num_attr_groups != 1) throw "attribute groups are not supported";
+    pred_sum_all.setSize(test.num_cases); pred_sum_all_but5.setSize(test.num_cases); pred_this.setSize(test.num_cases);
+    pred_sum_all.init(0.0); pred_sum_all_but5.init(0.0); pred_this.init(0.0);
+    fmx_config c;
+    c.num_attribute = fm->num_attribute; c.num_factor = fm->num_factor; c.k0 = fm->k0; c.k1 = fm->k1;
+    c.task = task; c.reg0 = fm->reg0; c.regw = fm->regw; c.regv = fm->regv; c.learn_rate = 0;
+    c.min_target = min_target; c.max_target = max_target; c.device = gpu_device;
+    c.shard_rank = 0; c.shard_world = 1; c.reserved = 0;
+    if (fmx_create(&c, &h) != FMX_OK) throw std::string(fmx_last_error(NULL));
+    check(fmx_set_params(h, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
+    upload(0, train); upload(1, test);
+    check(fmx_als_begin(h, 0));
+    fmx_als_opts o;
+    o.alpha = alpha_0; o.w_mu = mu_0; o.v_mu = mu_0;                       // draw_alpha / draw_*_mu without multilevel
+    o.w_lambda = w_lambda(0); o.v_lambda = fm->num_factor > 0 ? v_lambda(0, 0) : 0.0;
+    o.do_sample = 0; o.reserved = 0; o.seed = 0; o.v_mu_f = NULL; o.v_lambda_f = NULL;
+    std::vector<double> p(test.num_cases);
+    for (uint i = 0; i < num_iter; i++) {
+      fmx_als_stats st;
+      check(fmx_als_sweep(h, &o, &st));
+      check(fmx_predict(h, 1, p.empty() ? NULL : &p[0]));
+      double rmse_or_acc = 0;
+      for (uint c2 = 0; c2 < test.num_cases; c2++) {                       // _learn :127-138 / :151-161
+        double v = p[c2];
+        if (task == TASK_REGRESSION) {
+          pred_this(c2) = v;
+          v = std::min(max_target, v); v = std::max(min_target, v);
+          pred_sum_all(c2) += v;
+          double err = pred_sum_all(c2) / (i + 1) - test.target(c2);
+          rmse_or_acc += err * err;
+        } else {
+          v = cdf_gaussian(v);
+          pred_this(c2) = v;
+          pred_sum_all(c2) += v;
+          if (((pred_sum_all(c2) / (i + 1) >= 0.5) && (test.target(c2) >= 0)) || ((pred_sum_all(c2) / (i + 1) < 0.5) && (test.target(c2) < 0))) rmse_or_acc += 1;
+        }
+      }
+      rmse_or_acc = (task == TASK_REGRESSION) ? std::sqrt(rmse_or_acc / test.num_cases) : rmse_or_acc / test.num_cases;
+      std::cout << "#Iter=" << std::setw(3) << i << "\tTrain=" << st.train_metric << "\tTest=" << rmse_or_acc << std::endl;
+    }
+    check(fmx_als_end(h));
+    check(fmx_get_params(h, &fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
+  }
+
+ protected:
+  fmx_handle h;
+  void check(int rc) { if (rc != FMX_OK) throw std::string(fmx_last_error(h)); }
+  void upload(int slot, Data& d) {
+    // ALS data sets are loaded transposed-only by main (has_x = false, libfm.cpp:143-147): rebuild the rows from X^T
+    std::vector<uint64> row_ptr(d.num_cases + 1, 0);
+    LargeSparseMatrix<DATA_FLOAT>* xt = d.data_t;
+    for (xt->begin(); !xt->end(); xt->next()) {
+      sparse_row<DATA_FLOAT>& col = xt->getRow();
+      for (uint i = 0; i < col.size; i++) row_ptr[col.data[i].id + 1]++;
+    }
+    for (uint r = 0; r < d.num_cases; r++) row_ptr[r + 1] += row_ptr[r];
+    std::vector< sparse_entry<DATA_FLOAT> > ent(row_ptr[d.num_cases]);
+    std::vector<uint64> fill(row_ptr.begin(), row_ptr.end() - 1);
+    for (xt->begin(); !xt->end(); xt->next()) {
+      sparse_row<DATA_FLOAT>& col = xt->getRow();
+      uint j = xt->getRowIndex();
+      for (uint i = 0; i < col.size; i++) { sparse_entry<DATA_FLOAT> e; e.id = j; e.value = col.data[i].value; ent[fill[col.data[i].id]++] = e; }
+    }
+    check(fmx_upload_rows(h, slot, ent.empty() ? NULL : &ent[0], (const uint64_t*)&row_ptr[0], d.target.value, d.num_cases, ent.size()));
+  }
+};
+
+#endif /* FM_LEARN_MCMC_GPU_H_ */

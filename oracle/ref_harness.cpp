@@ -13,6 +13,7 @@
 //   ref_harness sgd_gpu <same arguments as sgd> [mode 0|1|2] [batch] [w0_chunk]
 //                    (same driver, but the learner is adapter/fm_learn_sgd_gpu.h -> libfmx.so; needs a GPU)
 //   ref_harness sgda <same arguments as sgd> <validation>   (fm_learn_sgd_element_adapt_reg; also dumps .reg.txt: reg_w, reg_v[f])
+//   ref_harness als_gpu <same arguments as als>             (the learner is adapter/fm_learn_mcmc_gpu.h -> libfmx.so; needs a GPU)
 //   ref_harness als  <train> <test> <task r|c> <k0> <k1> <k> <iters> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
 //   ref_harness mcmc <train> <test> <task r|c> <k0> <k1> <k> <iters> <init_stdev> <seed> <out_prefix>
 //   ref_harness time_sgd <n> <k> <nnz> <rows> <seed>        (CPU baseline: reference fm_model::predict + fm_SGD on
@@ -45,6 +46,7 @@
 #include "fm_oracle.h"   // only for the synthetic-row generator used by time_sgd
 #ifdef FMX_WITH_GPU_ADAPTER
 #include "../adapter/fm_learn_sgd_gpu.h"   // the reference-side binding of libfmx, exercised by mode sgd_gpu
+#include "../adapter/fm_learn_mcmc_gpu.h"  // ... and the ALS binding, exercised by mode als_gpu
 #endif
 
 static void dump_params(const std::string& path, fm_model& fm) {
@@ -129,6 +131,8 @@ int main(int argc, char** argv) {
     double lr = 0, reg0 = 0, regw = 0, regv = 0;
     if (mode == "sgd" || mode == "sgd_gpu" || mode == "sgda") lr = atof(argv[a++]);
     if (mode != "mcmc") { reg0 = atof(argv[a++]); regw = atof(argv[a++]); regv = atof(argv[a++]); }
+    const bool als_gpu = (mode == "als_gpu");
+    if (als_gpu) mode = "als";
     double init_stdev = atof(argv[a++]);
     long seed = atol(argv[a++]);
     std::string prefix = argv[a++];
@@ -224,7 +228,11 @@ int main(int argc, char** argv) {
     } else {
       const bool is_als = (mode == "als");
       fm.w.init_normal(fm.init_mean, fm.init_stdev);          // libfm.cpp:283
-      fm_learn_mcmc_simultaneous* fml = new fm_learn_mcmc_simultaneous();
+      fm_learn_mcmc* fml;
+#ifdef FMX_WITH_GPU_ADAPTER
+      if (als_gpu) fml = new fm_learn_als_gpu(); else
+#endif
+      fml = new fm_learn_mcmc_simultaneous();
       fml->validation = NULL;
       fml->num_iter = iters;
       fml->num_eval_cases = test.num_cases;

@@ -50,3 +50,30 @@ def test_reference_driver_with_gpu_learner(oracle, name):
         np.testing.assert_allclose(ev[-1], z["eval"][-1], rtol=1e-4)
     else:
         assert np.abs(ev[-1] - z["eval"][-1]).max() <= 2.0 / 100
+
+
+@pytest.mark.parametrize("name", ["als_reg_ml", "als_cls_ragged", "als_reg_fields_k16"])
+def test_reference_driver_with_gpu_als_learner(oracle, name):
+    """adapter/fm_learn_mcmc_gpu.h: the reference's loader (X^T only for als, libfm.cpp:143-147), RNG and output code
+    with the GPU ALS learner must land on the stock learner's results (golden fixture)."""
+    if not os.path.exists(HARNESS):
+        pytest.skip("oracle/_ref/ref_harness_gpu not built (needs /root/reference at build time)")
+    O = oracle
+    g = Golden(name)
+    z = g.z
+    with tempfile.TemporaryDirectory() as td:
+        trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
+        O.Data(z["train_entries"], z["train_row_ptr"], z["train_target"]).write_libsvm(trf)
+        O.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(tef)
+        cfg = ["als_gpu", trf, tef, str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]),
+               repr(g.reg[0]), repr(g.reg[1]), repr(g.reg[2]), repr(float(z["init_stdev"])), int(z["seed"]), pre]
+        r = subprocess.run([HARNESS] + [str(c) for c in cfg], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "#Iter=" in r.stdout
+        init = O.Model.from_dump(pre + ".init.bin")
+        final = O.Model.from_dump(pre + ".final.bin")
+        pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+    assert np.array_equal(init.v, z["init_v"]) and np.array_equal(init.w, z["init_w"])
+    np.testing.assert_allclose(final.v, z["final_v"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(final.w, z["final_w"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(pred_out, z["pred_out"], rtol=1e-4, atol=5e-5)
