@@ -135,6 +135,10 @@ int fmx_get_params(fmx_handle h, double *w0, double *w, double *v);
  * w0 = 0, w = 0, v[f][j] = mean + fmo_init_value(seed, j, f, stdev) -- a counter-hash uniform with unit
  * variance (same definition as oracle/fm_oracle.c), NOT the reference's rand() stream (fm_model.h:96). */
 int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t seed);
+/* selected rows of the parameter block (spot checks at sizes where the full fm_model does not fit the host):
+ * for i < count: w_out[i] = w[ids[i]], v_out[i*num_factor + f] = v[f][ids[i]].  Sharded handles accept only their
+ * own features (id % shard_world == shard_rank). */
+int fmx_get_param_rows(fmx_handle h, const uint32_t *ids, uint32_t count, double *w_out, double *v_out);
 /* the scalar bias alone (cheap; used between minibatches by multi-process drivers) */
 int fmx_get_w0(fmx_handle h, double *w0);
 

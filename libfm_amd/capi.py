@@ -77,6 +77,7 @@ SYMBOLS = [
     ("fmx_set_params", C.c_int, [H, C.c_double, C.c_void_p, C.c_void_p]),
     ("fmx_get_params", C.c_int, [H, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
     ("fmx_init_params", C.c_int, [H, C.c_double, C.c_double, C.c_uint64]),
+    ("fmx_get_param_rows", C.c_int, [H, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_get_w0", C.c_int, [H, C.POINTER(C.c_double)]),
     ("fmx_upload_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     ("fmx_synth_rows", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
@@ -180,6 +181,14 @@ class Handle:
 
     def init_params(self, mean, stdev, seed):
         self._chk(self.lib.fmx_init_params(self.h, float(mean), float(stdev), int(seed)))
+
+    def get_param_rows(self, ids):
+        """(w[ids], v[:, ids]) for spot checks when the full model does not fit the host."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        w = np.zeros(len(ids), dtype=np.float64)
+        v = np.zeros((len(ids), max(self.k, 1)), dtype=np.float64)
+        self._chk(self.lib.fmx_get_param_rows(self.h, _ptr(ids), len(ids), _ptr(w), _ptr(v) if self.k > 0 else None))
+        return w, v[:, :self.k].T.copy()
 
     def get_w0(self):
         w0 = C.c_double(0)

@@ -457,6 +457,35 @@ int fmx_get_params(fmx_handle h, double* w0, double* w, double* v) {
   return stage_params(h, false, w0, w, v);
 }
 
+int fmx_get_param_rows(fmx_handle h, const uint32_t* ids, uint32_t count, double* w_out, double* v_out) {
+  if (!h || !ids || !w_out) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  const int k = h->cfg.num_factor;
+  if (k > 0 && !v_out) return fail(h, FMX_E_ARG, "fmx_get_param_rows: v_out is NULL");
+  if (count == 0) return FMX_OK;
+  for (uint32_t i = 0; i < count; i++) {
+    if (ids[i] >= h->cfg.num_attribute) return fail(h, FMX_E_ARG, "feature id %u >= num_attribute", ids[i]);
+    if ((int)(ids[i] % (uint32_t)h->cfg.shard_world) != h->cfg.shard_rank) return fail(h, FMX_E_ARG, "feature id %u is not on this shard", ids[i]);
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  uint32_t* d_ids = nullptr; double* d_out = nullptr;
+  const size_t nout = (size_t)count * (size_t)(k + 1);
+  HIPCHK(h, hipMalloc(&d_ids, (size_t)count * 4));
+  HIPCHK(h, hipMalloc(&d_out, nout * sizeof(double)));
+  hipError_t er = hipMemcpyAsync(d_ids, ids, (size_t)count * 4, hipMemcpyHostToDevice, h->stream);
+  if (er == hipSuccess) {
+    hipLaunchKernelGGL(k_fetch_rows, dim3((uint32_t)((nout + 255) / 256)), dim3(256), 0, h->stream, d_ids, count, k,
+                       h->cfg.shard_world, h->tb, d_out, d_out + count);
+    er = hipGetLastError();
+  }
+  if (er == hipSuccess) er = hipMemcpyAsync(w_out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (er == hipSuccess && k > 0) er = hipMemcpyAsync(v_out, d_out + count, (size_t)count * k * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+  hipFree(d_ids); hipFree(d_out);
+  if (er != hipSuccess) return fail(h, FMX_E_HIP, "fmx_get_param_rows: %s", hipGetErrorString(er));
+  return FMX_OK;
+}
+
 int fmx_get_w0(fmx_handle h, double* w0) {
   if (!h || !w0) return FMX_E_ARG;
   { int _rc = lag_flush(h); if (_rc) return _rc; }

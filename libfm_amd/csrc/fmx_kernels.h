@@ -942,6 +942,16 @@ __global__ void k_w_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, i
   if ((int)(j % world) == rank) stage[t] = (double)tb.w[(j / world) * tb.ws];
 }
 
+__global__ void k_fetch_rows(const uint32_t* __restrict__ ids, uint32_t count, int k, int world, Tab tb,
+                             double* __restrict__ w_out, double* __restrict__ v_out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)count * (uint64_t)(k + 1)) return;
+  const uint32_t i = (uint32_t)(t / (k + 1)); const int f = (int)(t % (k + 1));
+  const size_t jl = ids[i] / (uint32_t)world;
+  if (f == k) w_out[i] = (double)tb.w[jl * tb.ws];
+  else v_out[(size_t)i * k + f] = (double)tb.V[jl * tb.rs + f];
+}
+
 // counter-hash helpers: identical definitions in oracle/fm_oracle.c (fmo_mix64, fmo_synth_id, ...)
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
