@@ -1,19 +1,24 @@
 """Build recipe of the HIP library: libfm_amd/libfmx.so (gfx950 only, in-tree so it travels with gpurun).
 
     python -m libfm_amd.build [--force]
+
+Three translation units (csrc/fmx_core.hip, fmx_sgd.hip, fmx_als.hip) are compiled in parallel and linked.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "fmx_api.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "fmx_kernels.h"), os.path.join(HERE, "csrc", "fmx_als_kernels.h"),
-              os.path.join(ROOT, "include", "fmx.h")]
+CSRC = os.path.join(HERE, "csrc")
+SRC = [os.path.join(CSRC, f) for f in ("fmx_core.hip", "fmx_sgd.hip", "fmx_als.hip")]
+DEPS = SRC + [os.path.join(CSRC, f) for f in ("fmx_internal.h", "fmx_kernels.h", "fmx_als_kernels.h")] + \
+    [os.path.join(ROOT, "include", "fmx.h")]
 OUT = os.path.join(HERE, "libfmx.so")
+OBJ_DIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fvisibility=hidden",
          "-Wno-unused-result", "-Wno-unused-value"]
 
 
@@ -27,7 +32,17 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    cmd = [HIPCC] + FLAGS + SRC + ["-o", OUT]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = [os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o") for s in SRC]
+
+    def cc(pair):
+        cmd = [HIPCC] + FLAGS + ["-c", pair[0], "-o", pair[1]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(len(SRC)) as ex:
+        list(ex.map(cc, zip(SRC, objs)))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

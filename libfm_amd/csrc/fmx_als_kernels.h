@@ -90,11 +90,11 @@ k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
 }
 
 // e[c] -= target[c] (initialisation, _learn :70-86)
-__global__ void k_als_sub_target(EQ* __restrict__ eq, const float* __restrict__ target, uint32_t n) {
+static __global__ void k_als_sub_target(EQ* __restrict__ eq, const float* __restrict__ target, uint32_t n) {
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].e -= (double)target[c];
 }
 // add_main_q (:406-428) for factor f was evaluated by k_als_eterms; move it next to e for the coming sweep
-__global__ void k_als_load_q(EQ* __restrict__ eq, const double* __restrict__ qf, uint32_t n) {
+static __global__ void k_als_load_q(EQ* __restrict__ eq, const double* __restrict__ qf, uint32_t n) {
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].q = qf[c];
 }
 
@@ -130,7 +130,7 @@ __device__ __forceinline__ double left_tgauss(double left, uint64_t seed, uint64
 //   regression    (_learn :139-150): rmse over clamped predictions, e -= y
 //   classification(_learn :163-196): accuracy of cdf_gaussian(e) vs sign, e -= E[truncated normal] (do_sample = 0)
 // acc[0] = sum err^2 / #correct
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_als_targets(EQ* __restrict__ eq, const float* __restrict__ target, uint32_t n, int task,
               double min_target, double max_target, double* __restrict__ acc,
               int do_sample, uint64_t seed, uint64_t stream) {
@@ -164,19 +164,19 @@ k_als_targets(EQ* __restrict__ eq, const float* __restrict__ target, uint32_t n,
 }
 
 // sum_c e[c] (draw_w0's numerator, :650-652: sum (e - w0) = sum e - N w0) and sum e^2 (draw_alpha :918-920)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_als_sum_e(const EQ* __restrict__ eq, uint32_t n, double* __restrict__ acc) {
   double s = 0.0, s2 = 0.0;
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) { const double v = eq[c].e; s += v; s2 += v * v; }
   s = wave_sum_f64(s); s2 = wave_sum_f64(s2);
   if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(acc, s); unsafeAtomicAdd(acc + 1, s2); }
 }
-__global__ void k_als_add_const(EQ* __restrict__ eq, uint32_t n, double d) {
+static __global__ void k_als_add_const(EQ* __restrict__ eq, uint32_t n, double d) {
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].e += d;
 }
 
 // sum_j theta_j and sum_j theta_j^2 of one coordinate family (w: param = tb.w, stride ws; v_f: param = tb.V + f, stride rs)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_param_moments(const float* __restrict__ param, uint32_t pstride, uint64_t n_local, double* __restrict__ out2) {
   double s = 0.0, s2 = 0.0;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_local; j += (uint64_t)gridDim.x * blockDim.x) {
@@ -293,7 +293,7 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
 
 // features without a training column: the empty-row draw (:467-476, :586-595): theta = prior mean mu = 0
 // (sigma^2 = 1/lambda; lambda = 0 -> sigma^2 = inf -> theta = 0); MCMC: mu + N(0,1)/sqrt(lambda)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_als_unseen(const uint8_t* __restrict__ seen, uint64_t n_local, float* __restrict__ param, uint32_t pstride,
              double lambda, double mu, int do_sample, uint64_t seed, uint64_t stream) {
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_local; j += (uint64_t)gridDim.x * blockDim.x)

@@ -1,0 +1,548 @@
+// fmx_core.hip -- C-ABI (include/fmx.h): lifetime, parameters, rows, predict / evaluate.
+// Build: python -m libfm_amd.build   (hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -shared -fPIC)
+//
+// No CPU fallback lives in this library: every compute entry point needs a HIP device and fails with FMX_E_HIP
+// otherwise.  Nothing here links or calls oracle/.
+#include "fmx_internal.h"
+
+static thread_local std::string g_create_error = "";
+
+int fail(fmx_handle h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+static int next_pow2(int k) { int p = 1; while (p < k) p <<= 1; return p; }
+
+Hyper make_hyper(const fmx_config& c) {
+  Hyper h;
+  h.lr = (float)c.learn_rate; h.reg0 = (float)c.reg0; h.regw = (float)c.regw; h.regv = (float)c.regv;
+  h.min_target = (float)c.min_target; h.max_target = (float)c.max_target;
+  h.task = c.task; h.k0 = c.k0; h.k1 = c.k1;
+  h.lr_d = c.learn_rate; h.reg0_d = c.reg0; h.regw_d = c.regw; h.regv_d = c.regv;
+  h.min_d = c.min_target; h.max_d = c.max_target;
+  return h;
+}
+
+// persistent sizing: never launch more workgroups than can be resident (a second, partially filled round of
+// equally long grid-stride workgroups is pure tail), never more than the work needs.
+uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted) {
+  static std::unordered_map<const void*, int> cache;
+  auto it = cache.find(kernel);
+  int occ;
+  if (it == cache.end()) {
+    occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 4;
+    if (occ > 8) occ = 8;
+    cache[kernel] = occ;
+  } else {
+    occ = it->second;
+  }
+  uint64_t blocks = (n_waves_wanted + 3) / 4;
+  // over-subscribe: more (shorter) workgroups than can be resident let the dispatcher balance the tail;
+  // measured better than an exactly-resident persistent grid for these gather kernels
+  int over = 2;
+  if (const char* e = getenv("FMX_GRID_OVER")) over = atoi(e) > 0 ? atoi(e) : 1;
+  const uint64_t cap = (uint64_t)occ * (uint64_t)h->num_cu * (uint64_t)over;
+  if (blocks < 1) blocks = 1;
+  if (blocks > cap) blocks = cap;
+  return (uint32_t)blocks;
+}
+int ensure_scratch(fmx_handle h, size_t batch_cap, size_t rest_cap) {
+  if (batch_cap > h->cap) {
+    if (h->partial) hipFree(h->partial);
+    if (h->mult) hipFree(h->mult);
+    h->partial = nullptr; h->mult = nullptr; h->cap = 0;
+    HIPCHK(h, hipMalloc(&h->partial, batch_cap * (size_t)(h->KP + 1) * sizeof(float)));
+    HIPCHK(h, hipMalloc(&h->mult, batch_cap * sizeof(float)));
+    h->cap = batch_cap;
+  }
+  if (rest_cap > h->cap_rest) {
+    if (h->rest) hipFree(h->rest);
+    h->rest = nullptr; h->cap_rest = 0;
+    HIPCHK(h, hipMalloc(&h->rest, rest_cap * sizeof(float)));
+    h->cap_rest = rest_cap;
+  }
+  return FMX_OK;
+}
+
+int check_slot(fmx_handle h, int slot, bool need_target) {
+  if (!h) return FMX_E_ARG;
+  if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  if (!h->slots[slot].used) return fail(h, FMX_E_STATE, "slot %d holds no rows (call fmx_upload_rows first)", slot);
+  if (need_target && !h->slots[slot].target) return fail(h, FMX_E_STATE, "slot %d was uploaded without targets", slot);
+  return FMX_OK;
+}
+
+void free_segments(Slot& s) {
+  if (s.t_ent) hipFree(s.t_ent);
+  if (s.seg_feat) hipFree(s.seg_feat);
+  if (s.seg_rel) hipFree(s.seg_rel);
+  s.t_ent = nullptr; s.seg_feat = nullptr; s.seg_rel = nullptr; s.seg_B = 0; s.nseg = 0;
+  s.batch_seg.clear(); s.batch_base.clear();
+}
+
+void free_slot(Slot& s) {
+  free_segments(s);
+  if (s.ent) hipFree(s.ent);
+  if (s.row_ptr) hipFree(s.row_ptr);
+  if (s.target) hipFree(s.target);
+  s = Slot();
+}
+
+// rest[e] (= y-hat - w0) for rows [row0,row0+n) of a slot, single device
+int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st) {
+  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, false, true>), n, st,
+                                     s.ent, s.row_ptr, row0, n, h->tb, h->cfg.k1, (float*)nullptr, rest));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+extern "C" {
+
+int fmx_abi_version(void) { return FMX_ABI_VERSION; }
+
+int fmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* fmx_last_error(fmx_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fmx_create(const fmx_config* cfg, fmx_handle* out) {
+  if (!cfg || !out) return fail(nullptr, FMX_E_ARG, "fmx_create: null argument");
+  *out = nullptr;
+  if (cfg->num_attribute == 0) return fail(nullptr, FMX_E_ARG, "num_attribute must be > 0");
+  if (cfg->num_attribute > 0xFFFFFFFFull) return fail(nullptr, FMX_E_ARG, "num_attribute must fit uint32 (fm_model.h:51)");
+  if (cfg->num_factor < 0) return fail(nullptr, FMX_E_ARG, "num_factor must be >= 0");
+  if (cfg->num_factor > 256) return fail(nullptr, FMX_E_UNSUPPORTED, "num_factor > 256 is not supported yet");
+  if (cfg->task != FMX_TASK_REGRESSION && cfg->task != FMX_TASK_CLASSIFICATION)
+    return fail(nullptr, FMX_E_ARG, "unknown task");                       // fm_learn.h:81 "unknown task"
+  if (cfg->shard_world < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_world)
+    return fail(nullptr, FMX_E_ARG, "bad shard_rank/shard_world");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, FMX_E_HIP, "no HIP device available (%s); libfmx has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  int dev = cfg->device;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= ndev) return fail(nullptr, FMX_E_ARG, "device %d out of range (%d devices)", dev, ndev);
+
+  fmx_handle h = new fmx_context_s();
+  h->cfg = *cfg;
+  h->device = dev;
+  h->KP = next_pow2(std::max(cfg->num_factor, 1));
+  const uint64_t n = cfg->num_attribute, W = (uint64_t)cfg->shard_world, R = (uint64_t)cfg->shard_rank;
+  h->n_local = (n > R) ? (n - R + W - 1) / W : 0;
+  if (h->n_local == 0) h->n_local = 1;
+#define CREATE_CHK(expr)                                                                     \
+  do { hipError_t _e = (expr); if (_e != hipSuccess) {                                       \
+      fail(nullptr, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));               \
+      fmx_destroy(h); return FMX_E_HIP; } } while (0)
+  CREATE_CHK(hipSetDevice(dev));
+  CREATE_CHK(hipGetDeviceProperties(&h->prop, dev));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_CHK(hipEventCreate(&h->ev0));
+  CREATE_CHK(hipEventCreate(&h->ev1));
+  {
+    // row layout: default = separate w[] array (FMX_WPAD=0).  FMX_WPAD=<floats> co-locates w behind the factors
+    // ([KP factors | w | padding]); measured on MI355X it does NOT pay: HBM fetches 64-B sectors, so a 4-B w
+    // costs one sector wherever it lives, and the unaligned rows cost more.
+    int wpad = 0;
+    if (const char* e = getenv("FMX_WPAD")) wpad = atoi(e);
+    if (wpad < 0 || (wpad % 4) != 0) wpad = 0;
+    h->tb.rs = (uint32_t)(h->KP + wpad);
+    CREATE_CHK(hipMalloc(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float)));
+    CREATE_CHK(hipMemsetAsync(h->tb.V, 0, h->n_local * (size_t)h->tb.rs * sizeof(float), h->stream));
+    if (wpad == 0) {
+      CREATE_CHK(hipMalloc(&h->w_sep, h->n_local * sizeof(float)));
+      CREATE_CHK(hipMemsetAsync(h->w_sep, 0, h->n_local * sizeof(float), h->stream));
+      h->tb.w = h->w_sep; h->tb.ws = 1;
+    } else {
+      h->tb.w = h->tb.V + h->KP; h->tb.ws = h->tb.rs;
+    }
+  }
+  CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
+  CREATE_CHK(hipMalloc(&h->w0_pp, 4 * sizeof(double)));
+  {  // the side stream runs the one-workgroup bias recurrence next to chip-filling gathers: give it priority so
+     // that its workgroup is placed as soon as any CU has room
+    int lo = 0, hi = 0;
+    CREATE_CHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CREATE_CHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+  }
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+  h->num_cu = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
+  CREATE_CHK(hipMalloc(&h->acc, 4 * sizeof(double)));
+  CREATE_CHK(hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
+  CREATE_CHK(hipStreamSynchronize(h->stream));
+#undef CREATE_CHK
+  *out = h;
+  return FMX_OK;
+}
+
+int fmx_destroy(fmx_handle h) {
+  if (!h) return FMX_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  als_free(h);
+  sgda_free(h);
+  for (auto& s : h->slots) free_slot(s);
+  if (h->tb.V) hipFree(h->tb.V);
+  if (h->w_sep) hipFree(h->w_sep);
+  if (h->w0) hipFree(h->w0);
+  if (h->w0_pp) hipFree(h->w0_pp);
+  if (h->stream2) hipStreamDestroy(h->stream2);
+  if (h->stream3) hipStreamDestroy(h->stream3);
+  if (h->acc) hipFree(h->acc);
+  if (h->partial) hipFree(h->partial);
+  if (h->mult) hipFree(h->mult);
+  if (h->rest) hipFree(h->rest);
+  for (auto ev : h->ev_pool) hipEventDestroy(ev);
+  for (auto ev : h->ev_sync) hipEventDestroy(ev);
+  if (h->lag.ev_rest) hipEventDestroy(h->lag.ev_rest);
+  if (h->lag.ev_scan[0]) hipEventDestroy(h->lag.ev_scan[0]);
+  if (h->lag.ev_scan[1]) hipEventDestroy(h->lag.ev_scan[1]);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return FMX_OK;
+}
+
+int fmx_get_info(fmx_handle h, fmx_info* out) {
+  if (!h || !out) return FMX_E_ARG;
+  memset(out, 0, sizeof(*out));
+  out->n_local = h->n_local;
+  out->k_padded = h->KP;
+  out->device = h->device;
+  out->bytes_params = h->n_local * (size_t)(h->tb.rs + (h->w_sep ? 1 : 0)) * sizeof(float);
+  snprintf(out->device_name, sizeof(out->device_name), "%s", h->prop.name);
+  snprintf(out->arch, sizeof(out->arch), "%s", h->prop.gcnArchName);
+  return FMX_OK;
+}
+
+int fmx_synchronize(fmx_handle h) {
+  if (!h) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------------
+static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, double* v) {
+  HIPCHK(h, hipSetDevice(h->device));
+  const uint64_t n = h->cfg.num_attribute;
+  const int k = h->cfg.num_factor, KP = h->KP;
+  const int R = h->cfg.shard_rank, W = h->cfg.shard_world;
+  if (to_device) {
+    HIPCHK(h, hipMemcpyAsync(h->w0, w0, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIPCHK(h, hipMemcpyAsync(w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  const uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 1u << 18);
+  double* stage = nullptr;
+  HIPCHK(h, hipMalloc(&stage, (size_t)chunk * (size_t)std::max(k, 1) * sizeof(double)));
+  int rc = FMX_OK;
+#define STAGE_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    rc = fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); goto done; } } while (0)
+  for (uint64_t j0 = 0; j0 < n; j0 += chunk) {
+    const uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, n - j0);
+    if (w) {
+      if (to_device) {
+        STAGE_CHK(hipMemcpyAsync(stage, w + j0, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_w_in, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->tb);
+      } else {
+        if (W > 1) STAGE_CHK(hipMemcpyAsync(stage, w + j0, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_w_out, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->tb);
+        STAGE_CHK(hipMemcpyAsync(w + j0, stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      }
+      STAGE_CHK(hipStreamSynchronize(h->stream));
+    }
+    if (v && k > 0) {
+      if (to_device) {
+        for (int f = 0; f < k; f++)
+          STAGE_CHK(hipMemcpyAsync(stage + (size_t)f * cnt, v + (size_t)f * n + j0, cnt * sizeof(double),
+                                   hipMemcpyHostToDevice, h->stream));
+        const uint64_t total = (uint64_t)cnt * KP;
+        hipLaunchKernelGGL(k_stage_in, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream,
+                           stage, j0, cnt, k, KP, R, W, h->tb);
+      } else {
+        if (W > 1)
+          for (int f = 0; f < k; f++)
+            STAGE_CHK(hipMemcpyAsync(stage + (size_t)f * cnt, v + (size_t)f * n + j0, cnt * sizeof(double),
+                                     hipMemcpyHostToDevice, h->stream));
+        const uint64_t total = (uint64_t)cnt * k;
+        hipLaunchKernelGGL(k_stage_out, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream,
+                           stage, j0, cnt, k, KP, R, W, h->tb);
+        for (int f = 0; f < k; f++)
+          STAGE_CHK(hipMemcpyAsync(v + (size_t)f * n + j0, stage + (size_t)f * cnt, cnt * sizeof(double),
+                                   hipMemcpyDeviceToHost, h->stream));
+      }
+      STAGE_CHK(hipStreamSynchronize(h->stream));
+    }
+  }
+  STAGE_CHK(hipGetLastError());
+  STAGE_CHK(hipStreamSynchronize(h->stream));
+done:
+#undef STAGE_CHK
+  hipFree(stage);
+  return rc;
+}
+
+int fmx_set_params(fmx_handle h, double w0, const double* w, const double* v) {
+  if (!h) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  if (h->cfg.num_factor > 0 && !v) return fail(h, FMX_E_ARG, "fmx_set_params: v is NULL but num_factor > 0");
+  double w0c = w0;
+  return stage_params(h, true, &w0c, const_cast<double*>(w), const_cast<double*>(v));
+}
+
+int fmx_get_params(fmx_handle h, double* w0, double* w, double* v) {
+  if (!h || !w0) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  return stage_params(h, false, w0, w, v);
+}
+
+int fmx_get_param_rows(fmx_handle h, const uint32_t* ids, uint32_t count, double* w_out, double* v_out) {
+  if (!h || !ids || !w_out) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  const int k = h->cfg.num_factor;
+  if (k > 0 && !v_out) return fail(h, FMX_E_ARG, "fmx_get_param_rows: v_out is NULL");
+  if (count == 0) return FMX_OK;
+  for (uint32_t i = 0; i < count; i++) {
+    if (ids[i] >= h->cfg.num_attribute) return fail(h, FMX_E_ARG, "feature id %u >= num_attribute", ids[i]);
+    if ((int)(ids[i] % (uint32_t)h->cfg.shard_world) != h->cfg.shard_rank) return fail(h, FMX_E_ARG, "feature id %u is not on this shard", ids[i]);
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  uint32_t* d_ids = nullptr; double* d_out = nullptr;
+  const size_t nout = (size_t)count * (size_t)(k + 1);
+  HIPCHK(h, hipMalloc(&d_ids, (size_t)count * 4));
+  HIPCHK(h, hipMalloc(&d_out, nout * sizeof(double)));
+  hipError_t er = hipMemcpyAsync(d_ids, ids, (size_t)count * 4, hipMemcpyHostToDevice, h->stream);
+  if (er == hipSuccess) {
+    hipLaunchKernelGGL(k_fetch_rows, dim3((uint32_t)((nout + 255) / 256)), dim3(256), 0, h->stream, d_ids, count, k,
+                       h->cfg.shard_world, h->tb, d_out, d_out + count);
+    er = hipGetLastError();
+  }
+  if (er == hipSuccess) er = hipMemcpyAsync(w_out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (er == hipSuccess && k > 0) er = hipMemcpyAsync(v_out, d_out + count, (size_t)count * k * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+  hipFree(d_ids); hipFree(d_out);
+  if (er != hipSuccess) return fail(h, FMX_E_HIP, "fmx_get_param_rows: %s", hipGetErrorString(er));
+  return FMX_OK;
+}
+
+int fmx_get_w0(fmx_handle h, double* w0) {
+  if (!h || !w0) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t seed) {
+  if (!h) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_init_params, dim3(256 * 8), dim3(256), 0, h->stream, h->tb, h->n_local,
+                     h->cfg.num_factor, h->KP, h->cfg.shard_rank, h->cfg.shard_world, (float)init_mean, init_stdev, seed);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows
+// ---------------------------------------------------------------------------------------------
+int fmx_free_rows(fmx_handle h, int slot) {
+  if (!h || slot < 0 || slot >= FMX_MAX_SLOTS) return FMX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_slot(h->slots[slot]);
+  return FMX_OK;
+}
+
+int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t* row_ptr, const float* target,
+                    uint32_t n_rows, uint64_t nnz) {
+  if (!h) return FMX_E_ARG;
+  if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  if (!row_ptr || (nnz > 0 && !entries)) return fail(h, FMX_E_ARG, "fmx_upload_rows: null entries/row_ptr");
+  if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return fail(h, FMX_E_ARG, "row_ptr[0] must be 0 and row_ptr[n_rows] == nnz");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_slot(h->slots[slot]);
+  const Entry* src = static_cast<const Entry*>(entries);
+  const uint64_t n = h->cfg.num_attribute;
+  const uint32_t W = (uint32_t)h->cfg.shard_world, R = (uint32_t)h->cfg.shard_rank;
+  std::vector<Entry> local_ent;
+  std::vector<uint64_t> local_ptr;
+  const Entry* up_ent = src;
+  const uint64_t* up_ptr = row_ptr;
+  uint64_t up_nnz = nnz;
+  uint32_t max_row = 0;
+  // bound check: the reference asserts id < num_attribute (fm_model.h:112)
+  for (uint64_t i = 0; i < nnz; i++)
+    if (src[i].id >= n) return fail(h, FMX_E_ARG, "feature id %u >= num_attribute %llu (row entry %llu)", src[i].id,
+                                    (unsigned long long)n, (unsigned long long)i);
+  if (W > 1) {   // keep this shard's features, ids become local rows (j / world)
+    local_ptr.resize((size_t)n_rows + 1);
+    local_ent.reserve((size_t)(nnz / W + n_rows));
+    for (uint32_t r = 0; r < n_rows; r++) {
+      local_ptr[r] = local_ent.size();
+      for (uint64_t i = row_ptr[r]; i < row_ptr[r + 1]; i++)
+        if (src[i].id % W == R) { Entry e; e.id = src[i].id / W; e.value = src[i].value; local_ent.push_back(e); }
+    }
+    local_ptr[n_rows] = local_ent.size();
+    up_ent = local_ent.data(); up_ptr = local_ptr.data(); up_nnz = local_ent.size();
+  }
+  for (uint32_t r = 0; r < n_rows; r++) max_row = std::max<uint32_t>(max_row, (uint32_t)(up_ptr[r + 1] - up_ptr[r]));
+  Slot s;
+  HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(up_nnz, 1) * sizeof(Entry)));
+  HIPCHK(h, hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  if (up_nnz) HIPCHK(h, hipMemcpy(s.ent, up_ent, up_nnz * sizeof(Entry), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(s.row_ptr, up_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (target) {
+    HIPCHK(h, hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float)));
+    if (n_rows) HIPCHK(h, hipMemcpy(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice));
+  }
+  s.n_rows = n_rows; s.nnz = up_nnz; s.max_row = max_row; s.used = true;
+  h->slots[slot] = s;
+  return FMX_OK;
+}
+
+int fmx_rows_info(fmx_handle h, int slot, uint32_t* n_rows, uint64_t* nnz) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  if (n_rows) *n_rows = h->slots[slot].n_rows;
+  if (nnz) *nnz = h->slots[slot].nnz;
+  return FMX_OK;
+}
+
+int fmx_download_rows(fmx_handle h, int slot, void* entries, uint64_t* row_ptr, float* target) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const Slot& s = h->slots[slot];
+  if (entries && s.nnz) HIPCHK(h, hipMemcpy(entries, s.ent, s.nnz * sizeof(Entry), hipMemcpyDeviceToHost));
+  if (row_ptr) HIPCHK(h, hipMemcpy(row_ptr, s.row_ptr, ((size_t)s.n_rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (target && s.target && s.n_rows) HIPCHK(h, hipMemcpy(target, s.target, (size_t)s.n_rows * sizeof(float), hipMemcpyDeviceToHost));
+  return FMX_OK;
+}
+
+int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz) {
+  if (!h) return FMX_E_ARG;
+  if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  if (nnz == 0 || n_rows == 0) return fail(h, FMX_E_ARG, "fmx_synth_rows: empty workload");
+  const uint64_t n = h->cfg.num_attribute;
+  const uint32_t fs = (uint32_t)(n / nnz);
+  if (fs == 0) return fail(h, FMX_E_ARG, "fmx_synth_rows: num_attribute < nnz");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_slot(h->slots[slot]);
+  const int R = h->cfg.shard_rank, W = h->cfg.shard_world;
+  Slot s;
+  uint32_t* cnt = nullptr;
+  HIPCHK(h, hipMalloc(&cnt, ((size_t)n_rows + 1) * sizeof(uint32_t)));
+  HIPCHK(h, hipMemsetAsync(cnt, 0, ((size_t)n_rows + 1) * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  HIPCHK(h, hipMalloc(&s.target, (size_t)n_rows * sizeof(float)));
+  const dim3 grid((n_rows + 255) / 256), block(256);
+  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, R, W, cnt,
+                     (const uint64_t*)nullptr, (Entry*)nullptr, s.target);
+  HIPCHK(h, hipGetLastError());
+  {  // exclusive prefix sum u32 -> u64 over n_rows+1 items (last = total)
+    void* tmp = nullptr; size_t tmp_bytes = 0;
+    auto conv = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, uint32_t*>(cnt, hipcub::CastOp<uint64_t>());
+    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
+    HIPCHK(h, hipMalloc(&tmp, tmp_bytes));
+    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(tmp);
+  }
+  uint64_t total = 0;
+  HIPCHK(h, hipMemcpy(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
+  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, R, W, (uint32_t*)nullptr,
+                     (const uint64_t*)s.row_ptr, s.ent, (float*)nullptr);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  hipFree(cnt);
+  s.n_rows = n_rows; s.nnz = total; s.max_row = nnz; s.used = true;
+  h->slots[slot] = s;
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// predict / evaluate
+// ---------------------------------------------------------------------------------------------
+int fmx_predict(fmx_handle h, int slot, double* out) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  if (!out) return fail(h, FMX_E_ARG, "fmx_predict: out is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[slot];
+  if (s.n_rows == 0) return FMX_OK;
+  rc = ensure_scratch(h, 0, (size_t)s.n_rows * 2);
+  if (rc) return rc;
+  rc = launch_rest(h, s, 0, s.n_rows, h->rest, h->stream);
+  if (rc) return rc;
+  float* yhat = h->rest + s.n_rows;
+  const int k0 = (h->cfg.shard_world > 1) ? (h->cfg.shard_rank == 0 ? h->cfg.k0 : 0) : h->cfg.k0;
+  hipLaunchKernelGGL(k_yhat, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, h->stream,
+                     h->rest, s.n_rows, k0, h->w0, yhat);
+  HIPCHK(h, hipGetLastError());
+  std::vector<float> tmp(s.n_rows);
+  HIPCHK(h, hipMemcpyAsync(tmp.data(), yhat, (size_t)s.n_rows * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (uint32_t r = 0; r < s.n_rows; r++) out[r] = (double)tmp[r];
+  return FMX_OK;
+}
+
+int fmx_evaluate(fmx_handle h, int slot, fmx_eval* out) {
+  int rc = check_slot(h, slot, true);
+  if (rc) return rc;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  if (!out) return fail(h, FMX_E_ARG, "fmx_evaluate: out is NULL");
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "fmx_evaluate on a feature shard: use fmx_sgd_partial + all-reduce + fmx_predict_finish");
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[slot];
+  memset(out, 0, sizeof(*out));
+  out->rows = s.n_rows;
+  if (s.n_rows == 0) return FMX_OK;
+  rc = ensure_scratch(h, 0, (size_t)s.n_rows * 2);
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  rc = launch_rest(h, s, 0, s.n_rows, h->rest, h->stream);
+  if (rc) return rc;
+  HIPCHK(h, hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
+  hipLaunchKernelGGL(k_eval, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, h->stream,
+                     h->rest, s.target, s.n_rows, make_hyper(h->cfg), h->w0, h->acc);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  double acc[4];
+  HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  out->device_seconds = ms * 1e-3;
+  out->rmse = std::sqrt(acc[0] / s.n_rows);          // fm_learn.h:152
+  out->mae = acc[1] / s.n_rows;                      // fm_learn.h:148
+  out->accuracy = acc[2] / s.n_rows;                 // fm_learn.h:129
+  return FMX_OK;
+}
+
+}  // extern "C"

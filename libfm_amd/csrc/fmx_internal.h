@@ -1,0 +1,135 @@
+// fmx_internal.h -- shared by the translation units of libfmx.so (fmx_core.hip, fmx_sgd.hip, fmx_als.hip).
+// The C-ABI is include/fmx.h; nothing declared here is exported.
+#pragma once
+#pragma GCC visibility push(default)      // the C-ABI is the only thing libfmx.so exports (-fvisibility=hidden)
+#include "../../include/fmx.h"
+#pragma GCC visibility pop
+#include "fmx_kernels.h"
+#include "fmx_als_kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace fmx;
+
+struct Slot {
+  Entry*    ent = nullptr;
+  uint64_t* row_ptr = nullptr;
+  float*    target = nullptr;
+  uint32_t  n_rows = 0;
+  uint64_t  nnz = 0;
+  uint32_t  max_row = 0;
+  bool      used = false;
+  // per-batch transposed rows for FMX_APPLY_SEGMENTED (built lazily for one batch size)
+  uint32_t  seg_B = 0;
+  TEntry*   t_ent = nullptr;
+  uint32_t* seg_feat = nullptr;
+  uint32_t* seg_rel = nullptr;
+  uint32_t  nseg = 0;
+  std::vector<uint32_t> batch_seg;   // [n_batches+1] first segment of every batch
+  std::vector<uint64_t> batch_base;  // [n_batches+1] first entry of every batch
+};
+
+struct AlsState {
+  int       slot = -1;
+  EQ*       e = nullptr;          // [N] {residual, current factor's q}
+  double*   q = nullptr;          // [KP][N]
+  uint8_t*  seen = nullptr;       // [n_local] feature has a training column
+  uint32_t* level_list = nullptr; // segments ordered by level
+  std::vector<uint32_t> level_ptr;
+  uint64_t  iter = 0;
+};
+
+struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping: w0 lives in w0_pp[step & 1] while active
+  bool       active = false;
+  uint64_t   step = 0;
+  hipEvent_t ev_rest = nullptr, ev_scan[2] = {nullptr, nullptr};
+};
+
+struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; };
+
+struct fmx_context_s {
+  fmx_config cfg;
+  AlsState   als;
+  SgdaState  sgda;
+  LagState   lag;
+  int        KP = 1;
+  uint64_t   n_local = 0;
+  int        device = 0;
+  hipStream_t stream = nullptr;
+  Tab        tb = {nullptr, nullptr, 0, 0};   // V rows (+ co-located w), see fmx_kernels.h
+  float*     w_sep = nullptr;    // separate w[] array (only when FMX_WPAD=0)
+  double*    w0 = nullptr;       // device scalar
+  double*    w0_pp = nullptr;    // 2 doubles: ping-pong copies of w0 for the overlapped hogwild bias scan
+  hipStream_t stream2 = nullptr; // side stream of the hogwild bias scan
+  hipStream_t stream3 = nullptr; // second launch stream of the hogwild macro-batches (odd launches)
+  int        num_cu = 256;
+  double*    acc = nullptr;      // 4 doubles of reduction scratch
+  Slot       slots[FMX_MAX_SLOTS];
+  float*     partial = nullptr;  // [cap][KP] + [cap]
+  float*     mult = nullptr;     // [cap]
+  float*     rest = nullptr;     // [cap_rest]
+  size_t     cap = 0, cap_rest = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> ev_sync;   // untimed events ordering the two hogwild streams
+  std::string err;
+  hipDeviceProp_t prop;
+};
+
+// ---- helpers shared between the translation units -------------------------------------------------------------
+int fail(fmx_handle h, int code, const char* fmt, ...);                 // fmx_core.hip
+Hyper make_hyper(const fmx_config& c);
+uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted);
+int ensure_scratch(fmx_handle h, size_t batch_cap, size_t rest_cap);
+int check_slot(fmx_handle h, int slot, bool need_target);
+void free_segments(Slot& s);
+void free_slot(Slot& s);
+int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st);
+int ensure_segments(fmx_handle h, Slot& s, uint32_t B);                 // fmx_sgd.hip
+int lag_flush(fmx_handle h);                                             // fmx_sgd.hip
+void sgda_free(fmx_handle h);                                            // fmx_sgd.hip
+void als_free(fmx_handle h);                                             // fmx_als.hip
+
+#define HIPCHK(h, expr)                                                                         \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return fail((h), FMX_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+// wave-per-example grids: 4 waves per 256-thread block, capped so that the launch is >> 256 workgroups
+// but grid-strides the rest (guide: memory-bound ops, 256 CUs x 8 blocks).
+inline uint32_t wave_grid(uint64_t n_waves_wanted) {
+  uint64_t blocks = (n_waves_wanted + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  return (uint32_t)blocks;
+}
+
+#define FMX_LAUNCH_WAVES(kfn, waves, st, ...)                                                        \
+  do { auto _k = kfn; hipLaunchKernelGGL(_k, dim3(resident_grid(h, (const void*)_k, (waves))), dim3(256), 0, st, __VA_ARGS__); } while (0)
+
+#define KP_SWITCH(KPV, ...)                                            \
+  switch (KPV) {                                                       \
+    case 1:   { constexpr int KP = 1;   __VA_ARGS__; } break;          \
+    case 2:   { constexpr int KP = 2;   __VA_ARGS__; } break;          \
+    case 4:   { constexpr int KP = 4;   __VA_ARGS__; } break;          \
+    case 8:   { constexpr int KP = 8;   __VA_ARGS__; } break;          \
+    case 16:  { constexpr int KP = 16;  __VA_ARGS__; } break;          \
+    case 32:  { constexpr int KP = 32;  __VA_ARGS__; } break;          \
+    case 64:  { constexpr int KP = 64;  __VA_ARGS__; } break;          \
+    case 128: { constexpr int KP = 128; __VA_ARGS__; } break;          \
+    case 256: { constexpr int KP = 256; __VA_ARGS__; } break;          \
+    default: return fail(h, FMX_E_UNSUPPORTED, "num_factor > 256 is not supported yet");   \
+  }
+

@@ -379,7 +379,7 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
 }
 
 // no bias: the multipliers are independent of each other
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_mult(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, Hyper h,
        const double* __restrict__ w0_ptr, float* __restrict__ mult) {
   const float w0 = (h.k0 && w0_ptr) ? (float)(*w0_ptr) : 0.f;
@@ -420,7 +420,7 @@ k_apply(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uin
 struct TEntry { uint32_t e; float x; };     // (example index inside its batch, value)
 
 // sort keys: (batch << 32) | feature id ; payload: (value bits << 32) | example-in-batch  (== TEntry in memory)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_seg_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint32_t B,
            uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -437,13 +437,13 @@ k_seg_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, 
     }
   }
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_seg_heads(const uint64_t* __restrict__ keys, uint64_t nnz, uint32_t* __restrict__ flags) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x)
     flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 }
 // pos = inclusive scan of flags (1-based segment number of every entry)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_seg_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
            uint64_t nnz, const uint64_t* __restrict__ row_ptr, uint32_t B,
            uint32_t* __restrict__ seg_feat, uint32_t* __restrict__ seg_rel) {
@@ -455,7 +455,7 @@ k_seg_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flags
       seg_rel[s] = (uint32_t)(i - row_ptr[(uint64_t)(key >> 32) * B]);   // offset inside the batch's entries
     }
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_seg_batches(const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t nseg, const uint64_t* __restrict__ row_ptr,
               uint32_t n_rows, uint32_t B, uint32_t n_batches, uint32_t* __restrict__ batch_seg) {
   for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= n_batches; b += gridDim.x * blockDim.x) {
@@ -875,7 +875,7 @@ k_sgda(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, cons
 // evaluation: y-hat = w0 + rest, then the reductions of fm_learn.h:113-153
 // acc[0] = sum err^2 (clamped), acc[1] = sum |err|, acc[2] = #correct sign
 // ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_eval(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, Hyper h,
        const double* __restrict__ w0_ptr, double* __restrict__ acc) {
   const float w0 = h.k0 ? (float)(*w0_ptr) : 0.f;
@@ -897,7 +897,7 @@ k_eval(const float* __restrict__ rest, const float* __restrict__ target, uint32_
   }
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_yhat(const float* __restrict__ rest, uint32_t n_rows, int k0, const double* __restrict__ w0_ptr, float* __restrict__ yhat) {
   const float w0 = k0 ? (float)(*w0_ptr) : 0.f;
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_rows; e += gridDim.x * blockDim.x)
@@ -909,7 +909,7 @@ k_yhat(const float* __restrict__ rest, uint32_t n_rows, int k0, const double* __
 // stage holds `cnt` consecutive GLOBAL features j0.. of factor rows: stage[f*cnt + (j-j0)].
 // feature j belongs to this shard iff j % world == rank; its local row is j / world.
 // ----------------------------------------------------------------------------------------------
-__global__ void k_stage_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
+static __global__ void k_stage_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
                            int rank, int world, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = (uint64_t)cnt * KP;
@@ -919,7 +919,7 @@ __global__ void k_stage_in(const double* __restrict__ stage, uint64_t j0, uint32
   if ((int)(j % world) != rank) return;
   tb.V[(j / world) * tb.rs + f] = (f < k) ? (float)stage[(size_t)f * cnt + jj] : 0.f;
 }
-__global__ void k_stage_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
+static __global__ void k_stage_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
                             int rank, int world, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = (uint64_t)cnt * k;
@@ -929,20 +929,20 @@ __global__ void k_stage_out(double* __restrict__ stage, uint64_t j0, uint32_t cn
   if ((int)(j % world) != rank) return;
   stage[(size_t)f * cnt + jj] = (double)tb.V[(j / world) * tb.rs + f];
 }
-__global__ void k_w_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, Tab tb) {
+static __global__ void k_w_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cnt) return;
   const uint64_t j = j0 + t;
   if ((int)(j % world) == rank) tb.w[(j / world) * tb.ws] = (float)stage[t];
 }
-__global__ void k_w_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, Tab tb) {
+static __global__ void k_w_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cnt) return;
   const uint64_t j = j0 + t;
   if ((int)(j % world) == rank) stage[t] = (double)tb.w[(j / world) * tb.ws];
 }
 
-__global__ void k_fetch_rows(const uint32_t* __restrict__ ids, uint32_t count, int k, int world, Tab tb,
+static __global__ void k_fetch_rows(const uint32_t* __restrict__ ids, uint32_t count, int k, int world, Tab tb,
                              double* __restrict__ w_out, double* __restrict__ v_out) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (uint64_t)count * (uint64_t)(k + 1)) return;
@@ -963,7 +963,7 @@ __host__ __device__ __forceinline__ uint64_t synth_key(uint64_t seed, uint64_t r
   return mix64(seed + 0x9E3779B97F4A7C15ULL * (row + 1) + 0xC2B2AE3D27D4EB4FULL * ((uint64_t)field + 1));
 }
 
-__global__ void k_init_params(Tab tb, uint64_t n_local, int k, int KP,
+static __global__ void k_init_params(Tab tb, uint64_t n_local, int k, int KP,
                               int rank, int world, float mean, double stdev, uint64_t seed) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -983,7 +983,7 @@ __global__ void k_init_params(Tab tb, uint64_t n_local, int k, int KP,
 
 // synthetic rows: field t owns ids [t*fs,(t+1)*fs); this shard keeps id % world == rank
 // pass 1 (count==true): row_cnt[r] = #kept entries; pass 2: fill at row_ptr[r]
-__global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t fs, int rank, int world,
+static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t fs, int rank, int world,
                         uint32_t* __restrict__ row_cnt, const uint64_t* __restrict__ row_ptr,
                         Entry* __restrict__ ent, float* __restrict__ target) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,494 @@
+// fmx_sgd.hip -- C-ABI (include/fmx.h): the SGD family -- sequential / minibatch / hogwild epochs, the split step of
+// the multi-GPU driver, the bias-lag bookkeeping, the (batch, feature) segment build, and SGDA.
+#include "fmx_internal.h"
+
+namespace {
+template <int KP, bool ATOMIC>
+int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
+                    const double* w0_in, float* rest_out) {
+  constexpr int VEC = Map<KP>::VEC, EPI = Map<KP>::EPI;
+  const uint32_t need = (s.max_row + EPI - 1) / EPI;      // row slots per lane to keep a whole row in registers
+#define FMX_LAUNCH_ZR(ZRV)                                                                                  \
+  FMX_LAUNCH_WAVES((k_fused<KP, ZRV, ATOMIC>), n_rows, st, s.ent, s.row_ptr, s.target, row0, \
+                   n_rows, h->tb, hy, w0_in, rest_out)
+  if constexpr (VEC * 8 <= 128) { if (need <= 8) { FMX_LAUNCH_ZR(8); return FMX_OK; } }
+  if constexpr (VEC * 16 <= 128) { if (need <= 16) { FMX_LAUNCH_ZR(16); return FMX_OK; } }
+  if constexpr (VEC * 32 <= 128) { if (need <= 32) { FMX_LAUNCH_ZR(32); return FMX_OK; } }
+  if constexpr (VEC * 64 <= 128) { if (need <= 64) { FMX_LAUNCH_ZR(64); return FMX_OK; } }
+  // rows too long for the register file: the kernel's two-pass branch handles them (ZR = 8 instance)
+  FMX_LAUNCH_ZR(8);
+#undef FMX_LAUNCH_ZR
+  return FMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// SGD
+// ---------------------------------------------------------------------------------------------
+int fmx_partial_floats(fmx_handle h, uint32_t batch, uint64_t* n_floats) {
+  if (!h || !n_floats) return FMX_E_ARG;
+  *n_floats = (uint64_t)batch * (uint64_t)(h->KP + 1);
+  return FMX_OK;
+}
+
+// partial buffer layout: [n_rows][KP] factor sums, then [n_rows] scalars
+int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, float* d_partial, void* stream) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  const Slot& s = h->slots[slot];
+  if (row0 + n_rows > s.n_rows) return fail(h, FMX_E_ARG, "fmx_sgd_partial: rows [%llu,+%u) outside slot (%u rows)",
+                                            (unsigned long long)row0, n_rows, s.n_rows);
+  if (!d_partial) return fail(h, FMX_E_ARG, "fmx_sgd_partial: d_partial is NULL");
+  if (n_rows == 0) return FMX_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  float* S = d_partial;
+  float* c = d_partial + (size_t)n_rows * h->KP;
+  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st,
+                                     s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+// builds the (batch, feature) segments of a slot for batch size B (device radix sort; once per data set)
+extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
+  if (s.seg_B == B && s.t_ent) return FMX_OK;
+  free_segments(s);
+  const uint64_t nnz = s.nnz;
+  const uint32_t n_batches = (s.n_rows + B - 1) / B;
+  if (nnz >= (1ull << 31)) return fail(h, FMX_E_UNSUPPORTED, "segmented apply: nnz >= 2^31 in one slot (split the data set)");
+  hipStream_t st = h->stream;
+  uint64_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr;
+  void* tmp = nullptr;
+  int rc = FMX_OK;
+  const size_t cnt = (size_t)std::max<uint64_t>(nnz, 1);
+#define SEG_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    rc = fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); goto done; } } while (0)
+  SEG_CHK(hipMalloc(&keys_a, cnt * 8)); SEG_CHK(hipMalloc(&keys_b, cnt * 8));
+  SEG_CHK(hipMalloc(&vals_a, cnt * 8)); SEG_CHK(hipMalloc(&vals_b, cnt * 8));
+  SEG_CHK(hipMalloc(&flags, cnt * 4)); SEG_CHK(hipMalloc(&pos, cnt * 4));
+  SEG_CHK(hipMalloc(&d_batch_seg, ((size_t)n_batches + 1) * 4));
+  if (nnz) {
+    hipLaunchKernelGGL(k_seg_keys, dim3(wave_grid(s.n_rows)), dim3(256), 0, st, s.ent, s.row_ptr, s.n_rows, B, keys_a, vals_a);
+    int bits_batch = 1; while ((1ull << bits_batch) < n_batches) bits_batch++;
+    size_t tmp_bytes = 0;
+    SEG_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (int)nnz, 0, 32 + bits_batch, st));
+    SEG_CHK(hipMalloc(&tmp, tmp_bytes));
+    SEG_CHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (int)nnz, 0, 32 + bits_batch, st));
+    hipLaunchKernelGGL(k_seg_heads, dim3(2048), dim3(256), 0, st, keys_b, nnz, flags);
+    SEG_CHK(hipStreamSynchronize(st));
+    hipFree(tmp); tmp = nullptr; tmp_bytes = 0;
+    SEG_CHK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, flags, pos, (int)nnz, st));
+    SEG_CHK(hipMalloc(&tmp, tmp_bytes));
+    SEG_CHK(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, flags, pos, (int)nnz, st));
+    uint32_t nseg = 0;
+    SEG_CHK(hipMemcpyAsync(&nseg, pos + (nnz - 1), 4, hipMemcpyDeviceToHost, st));
+    SEG_CHK(hipStreamSynchronize(st));
+    s.nseg = nseg;
+    SEG_CHK(hipMalloc(&s.seg_feat, (size_t)nseg * 4));
+    SEG_CHK(hipMalloc(&s.seg_rel, (size_t)nseg * 4));
+    hipLaunchKernelGGL(k_seg_fill, dim3(2048), dim3(256), 0, st, keys_b, flags, pos, nnz, s.row_ptr, B, s.seg_feat, s.seg_rel);
+    hipLaunchKernelGGL(k_seg_batches, dim3((n_batches + 256) / 256), dim3(256), 0, st, pos, nnz, nseg, s.row_ptr,
+                       s.n_rows, B, n_batches, d_batch_seg);
+    SEG_CHK(hipGetLastError());
+    s.batch_seg.resize((size_t)n_batches + 1);
+    SEG_CHK(hipMemcpyAsync(s.batch_seg.data(), d_batch_seg, ((size_t)n_batches + 1) * 4, hipMemcpyDeviceToHost, st));
+    SEG_CHK(hipStreamSynchronize(st));
+    s.t_ent = reinterpret_cast<TEntry*>(vals_b); vals_b = nullptr;      // payload layout == TEntry
+  } else {
+    s.nseg = 0;
+    s.batch_seg.assign((size_t)n_batches + 1, 0);
+    SEG_CHK(hipMalloc(&s.t_ent, 8));
+  }
+  {  // first entry of every batch (row_ptr sampled at multiples of B)
+    std::vector<uint64_t> rp((size_t)s.n_rows + 1);
+    SEG_CHK(hipMemcpy(rp.data(), s.row_ptr, rp.size() * 8, hipMemcpyDeviceToHost));
+    s.batch_base.resize((size_t)n_batches + 1);
+    for (uint32_t b = 0; b <= n_batches; b++) s.batch_base[b] = rp[std::min<uint64_t>((uint64_t)b * B, s.n_rows)];
+  }
+  s.seg_B = B;
+done:
+#undef SEG_CHK
+  if (keys_a) hipFree(keys_a);
+  if (keys_b) hipFree(keys_b);
+  if (vals_a) hipFree(vals_a);
+  if (vals_b) hipFree(vals_b);
+  if (flags) hipFree(flags);
+  if (pos) hipFree(pos);
+  if (d_batch_seg) hipFree(d_batch_seg);
+  if (tmp) hipFree(tmp);
+  if (rc) free_segments(s);
+  return rc;
+}
+
+static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
+                       const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr) {
+  if (hy.k0) {
+    if (mult) hipLaunchKernelGGL(k_scan<true>, dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy,
+                                 w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
+    else      hipLaunchKernelGGL(k_scan<false>, dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy,
+                                 w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
+  } else if (mult) {
+    hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
+                       (const double*)nullptr, mult);
+  }
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+// ---- FMX_FLAG_BIAS_LAG: the w0 recurrence of batch b runs on stream2 while the main stream goes on ------------
+extern "C++" int lag_flush(fmx_handle h) {                      // make h->w0 the current bias again
+  LagState& L = h->lag;
+  if (!L.active) return FMX_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream2));
+  HIPCHK(h, hipMemcpy(h->w0, h->w0_pp + (L.step & 1), sizeof(double), hipMemcpyDeviceToDevice));
+  L.active = false; L.step = 0;
+  return FMX_OK;
+}
+// call BEFORE producing the rest buffer of this step on `st`; returns which of the two rest buffers to use
+static int lag_prepare(fmx_handle h, hipStream_t st, int* slot) {
+  LagState& L = h->lag;
+  if (!L.ev_rest) {
+    HIPCHK(h, hipEventCreateWithFlags(&L.ev_rest, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&L.ev_scan[0], hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&L.ev_scan[1], hipEventDisableTiming));
+  }
+  if (!L.active) {
+    HIPCHK(h, hipMemcpyAsync(h->w0_pp, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->w0_pp + 1, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+    L.active = true; L.step = 0;
+  } else {
+    HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[L.step & 1], 0));      // scan(step-2) is done with this buffer
+  }
+  *slot = (int)(L.step & 1);
+  return FMX_OK;
+}
+// call AFTER `rest` is complete on `st`: starts the recurrence on the side stream and leaves the multipliers of
+// this batch (batch-start bias) in h->mult on `st`
+static int lag_step(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
+                    const Hyper& hy, hipStream_t st) {
+  LagState& L = h->lag;
+  const uint64_t b = L.step;
+  if (hy.k0) {
+    HIPCHK(h, hipEventRecord(L.ev_rest, st));
+    HIPCHK(h, hipStreamWaitEvent(h->stream2, L.ev_rest, 0));
+    int rc = launch_scan(h, rest, target, n_rows, chunk, hy, nullptr, h->stream2, h->w0_pp + (b & 1), h->w0_pp + ((b + 1) & 1));
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(L.ev_scan[b & 1], h->stream2));
+    if (b >= 1) HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[(b + 1) & 1], 0));   // scan(b-1) wrote w0_pp[b & 1]
+  }
+  hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
+                     (const double*)(h->w0_pp + (b & 1)), h->mult);
+  HIPCHK(h, hipGetLastError());
+  L.step++;
+  return FMX_OK;
+}
+
+// steps 2 and 3 of the minibatch rule for rows [row0,row0+n_rows); `seg_batch` = batch index when the rows are
+// exactly one batch of the slot's segment structure (else -1: per-example apply only)
+static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, const float* S,
+                           const float* rest, const fmx_sgd_opts* opts, hipStream_t st,
+                           hipEvent_t ev_a, hipEvent_t ev_b, int64_t seg_batch) {
+  const Hyper hy = make_hyper(h->cfg);
+  const uint32_t chunk = (opts && opts->w0_chunk) ? opts->w0_chunk : 256u;
+  const bool lag = opts && (opts->flags & FMX_FLAG_BIAS_LAG);
+  int rc = lag ? lag_step(h, rest, s.target + row0, n_rows, chunk, hy, st)
+               : launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
+  if (rc) return rc;
+  int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
+  if (apply == FMX_APPLY_DEFAULT) apply = FMX_APPLY_SEGMENTED;
+  if (apply == FMX_APPLY_SEGMENTED && seg_batch < 0) return fail(h, FMX_E_STATE, "segmented apply needs batch-aligned rows");
+  if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
+  if (apply == FMX_APPLY_SEGMENTED) {
+    const uint32_t s0 = s.batch_seg[(size_t)seg_batch], s1 = s.batch_seg[(size_t)seg_batch + 1];
+    const uint64_t base = s.batch_base[(size_t)seg_batch];
+    const uint32_t bnnz = (uint32_t)(s.batch_base[(size_t)seg_batch + 1] - base);
+    const uint32_t nseg = s1 - s0;
+    if (nseg) {
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)nseg + 63) / 64, st,
+                                         s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nseg, bnnz, h->tb, hy, S, h->mult));
+    }
+  } else if (apply == FMX_APPLY_ATOMIC) {
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, true>), n_rows, st,
+                                       s.ent, s.row_ptr, row0, n_rows, h->tb, hy, S, h->mult));
+  } else if (apply == FMX_APPLY_STORE) {
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, false>), n_rows, st,
+                                       s.ent, s.row_ptr, row0, n_rows, h->tb, hy, S, h->mult));
+  } else {
+    return fail(h, FMX_E_ARG, "unknown apply mode %d", apply);
+  }
+  if (ev_b) HIPCHK(h, hipEventRecord(ev_b, st));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const float* d_partial,
+                   const fmx_sgd_opts* opts, void* stream) {
+  int rc = check_slot(h, slot, true);
+  if (rc) return rc;
+  Slot& s = h->slots[slot];
+  if (row0 + n_rows > s.n_rows) return fail(h, FMX_E_ARG, "fmx_sgd_finish: rows outside slot");
+  if (!d_partial) return fail(h, FMX_E_ARG, "fmx_sgd_finish: d_partial is NULL");
+  if (n_rows == 0) return FMX_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const bool lag = opts && (opts->flags & FMX_FLAG_BIAS_LAG);
+  const uint32_t Bcap = (opts && opts->batch) ? std::max(opts->batch, n_rows) : n_rows;
+  rc = ensure_scratch(h, n_rows, (size_t)Bcap * 2);
+  if (rc) return rc;
+  int rslot = 0;
+  if (lag) { rc = lag_prepare(h, st, &rslot); if (rc) return rc; } else { rc = lag_flush(h); if (rc) return rc; }
+  float* rest_buf = h->rest + (size_t)rslot * Bcap;
+  const float* S = d_partial;
+  const float* c = d_partial + (size_t)n_rows * h->KP;
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n_rows + Map<KP>::EPI - 1) / Map<KP>::EPI)),
+                                        dim3(256), 0, st, S, c, n_rows, rest_buf));
+  HIPCHK(h, hipGetLastError());
+  int64_t seg_batch = -1;
+  const int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
+  if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_SEGMENTED) {
+    // the driver walks the slot in batches of opts->batch rows (the last one may be short)
+    const uint32_t B = (opts && opts->batch) ? opts->batch : n_rows;
+    if (row0 % B != 0 || (n_rows != B && row0 + n_rows != s.n_rows))
+      return fail(h, FMX_E_ARG, "fmx_sgd_finish: rows [%llu,+%u) are not batch %u of the slot", (unsigned long long)row0, n_rows, B);
+    rc = ensure_segments(h, h->slots[slot], B);
+    if (rc) return rc;
+    seg_batch = (int64_t)(row0 / B);
+  }
+  return sgd_finish_impl(h, s, row0, n_rows, S, rest_buf, opts, st, nullptr, nullptr, seg_batch);
+}
+
+int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, float* d_yhat, void* stream) {
+  if (!h || !d_partial || !d_yhat) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  if (n_rows == 0) return FMX_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  int rc = ensure_scratch(h, 0, n_rows);
+  if (rc) return rc;
+  const float* S = d_partial;
+  const float* c = d_partial + (size_t)n_rows * h->KP;
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n_rows + Map<KP>::EPI - 1) / Map<KP>::EPI)),
+                                        dim3(256), 0, st, S, c, n_rows, h->rest));
+  hipLaunchKernelGGL(k_yhat, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st,
+                     h->rest, n_rows, h->cfg.k0, h->w0, d_yhat);
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats) {
+  int rc = check_slot(h, slot, true);
+  if (rc) return rc;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  if (!opts) return fail(h, FMX_E_ARG, "fmx_sgd_epoch: opts is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[slot];
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (s.n_rows == 0) return FMX_OK;
+  if (h->cfg.shard_world > 1 && opts->mode != FMX_SGD_MINIBATCH)
+    return fail(h, FMX_E_UNSUPPORTED, "feature-sharded handles train through fmx_sgd_partial / fmx_sgd_finish");
+  if (h->cfg.shard_world > 1)
+    return fail(h, FMX_E_UNSUPPORTED, "fmx_sgd_epoch on a feature shard: drive fmx_sgd_partial + all-reduce + fmx_sgd_finish");
+  const Hyper hy = make_hyper(h->cfg);
+  const bool timed = (opts->flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
+  uint64_t batches = 0, main_launches = 0;
+  size_t ev_used = 0;
+  auto get_event = [&](hipEvent_t* ev) -> hipError_t {
+    if (ev_used == h->ev_pool.size()) { hipEvent_t e; hipError_t er = hipEventCreate(&e); if (er != hipSuccess) return er; h->ev_pool.push_back(e); }
+    *ev = h->ev_pool[ev_used++];
+    return hipSuccess;
+  };
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  if (opts->mode == FMX_SGD_SEQUENTIAL) {
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr,
+                                          s.target, s.n_rows, h->tb, hy, h->w0));
+    HIPCHK(h, hipGetLastError());
+    batches = s.n_rows; main_launches = 1;
+  } else if (opts->mode == FMX_SGD_HOGWILD) {
+    if (opts->apply == FMX_APPLY_SEGMENTED) return fail(h, FMX_E_ARG, "HOGWILD has no segmented apply");
+    // rows per launch M: w0 is frozen inside a launch.  The bias recurrence of launch i (k_scan, one wavefront) runs
+    // on a side stream WHILE launches i+1, i+2 stream; launch i reads the w0 produced by scan i-3 (a ring of 3
+    // slots / rest buffers, so the result does not depend on timing and a slow scan has two launches of slack).
+    const uint32_t M = opts->batch ? opts->batch : 262144u;
+    const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : 256u;
+    const uint32_t cap = std::min<uint32_t>(M, s.n_rows);
+    rc = ensure_scratch(h, 0, (size_t)cap * 3);
+    if (rc) return rc;
+    const uint64_t n_launch = ((uint64_t)s.n_rows + M - 1) / M;
+    while (h->ev_sync.size() < 2 * n_launch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+    for (int r = 0; r < 3; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    // even launches go to `stream`, odd ones to `stream3`: the drain of one macro-batch overlaps the ramp-up of
+    // the next (rows of different launches are as independent as rows of one launch)
+    const bool two_streams = getenv("FMX_HOGWILD_TWO_STREAMS") != nullptr;   // +6 % but launches overlap (timing per launch blurs)
+    hipEvent_t ev_start = h->ev_sync[2 * n_launch];
+    HIPCHK(h, hipEventRecord(ev_start, h->stream));
+    if (two_streams) HIPCHK(h, hipStreamWaitEvent(h->stream3, ev_start, 0));
+    for (uint64_t i = 0; i < n_launch; i++) {
+      const uint64_t row0 = i * M;
+      const uint32_t nb = (uint32_t)std::min<uint64_t>(M, s.n_rows - row0);
+      float* rest = h->rest + (size_t)(i % 3) * cap;
+      hipStream_t fs = (two_streams && (i & 1)) ? h->stream3 : h->stream;
+      if (i >= 3) HIPCHK(h, hipStreamWaitEvent(fs, h->ev_sync[2 * (i - 3) + 1], 0));   // scan i-3 done
+      hipEvent_t ea = nullptr, eb = nullptr;
+      // (no per-launch events here: a timing event between two launches costs ~13 % on this path; the epoch is
+      //  bracketed by ev0/ev1 on the launch stream and the average launch time is epoch time / launches)
+      main_launches++;
+      const double* w0_in = h->w0_pp + ((i + 1) % 3);      // slot written by scan i-3 (initial value for i < 3)
+      if (opts->apply == FMX_APPLY_ATOMIC) {
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, row0, nb, fs, w0_in, rest); });
+      } else {
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, row0, nb, fs, w0_in, rest); });
+      }
+      if (rc) return rc;
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipEventRecord(h->ev_sync[2 * i], fs));
+      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * i], 0));
+      rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (i % 3), h->w0_pp + ((i + 1) % 3));
+      if (rc) return rc;
+      HIPCHK(h, hipEventRecord(h->ev_sync[2 * i + 1], h->stream2));
+      batches++;
+    }
+    // stream2 is in order: its last event covers every scan, and scan i waited for launch i
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync[2 * (n_launch - 1) + 1], 0));
+    if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_launch % 3), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  } else if (opts->mode == FMX_SGD_MINIBATCH) {
+    const uint32_t B = opts->batch ? opts->batch : 16384u;
+    const bool lag = (opts->flags & FMX_FLAG_BIAS_LAG) != 0;
+    const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
+    rc = ensure_scratch(h, (size_t)Bc * (lag ? 2 : 1), 0);
+    if (rc) return rc;
+    const bool segmented = (opts->apply == FMX_APPLY_DEFAULT || opts->apply == FMX_APPLY_SEGMENTED);
+    if (segmented) {
+      rc = ensure_segments(h, h->slots[slot], B);
+      if (rc) return rc;
+      HIPCHK(h, hipEventRecord(h->ev0, h->stream));           // do not bill the one-time bucketing to the epoch
+    }
+    for (uint64_t row0 = 0; row0 < s.n_rows; row0 += B) {
+      const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
+      int pslot = 0;
+      if (lag) { rc = lag_prepare(h, h->stream, &pslot); if (rc) return rc; }
+      float* S = h->partial + (size_t)pslot * Bc * (size_t)(h->KP + 1);
+      float* rest = S + (size_t)nb * h->KP;
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, h->stream,
+                                         s.ent, s.row_ptr, row0, nb, h->tb, h->cfg.k1, S, rest));
+      hipEvent_t ea = nullptr, eb = nullptr;
+      if (timed) { HIPCHK(h, get_event(&ea)); HIPCHK(h, get_event(&eb)); main_launches++; }
+      rc = sgd_finish_impl(h, s, row0, nb, S, rest, opts, h->stream, ea, eb, segmented ? (int64_t)(row0 / B) : -1);
+      if (rc) return rc;
+      batches++;
+    }
+  } else {
+    return fail(h, FMX_E_ARG, "unknown SGD mode %d", opts->mode);
+  }
+  if (h->lag.active) {     // the last recurrence must finish inside the timed region; then w0 returns to h->w0
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->lag.ev_scan[(h->lag.step + 1) & 1], 0));
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  rc = lag_flush(h);
+  if (rc) return rc;
+  if (stats) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    stats->rows = s.n_rows;
+    stats->batches = batches;
+    stats->device_seconds = ms * 1e-3;
+    if (opts->mode == FMX_SGD_MINIBATCH && timed) {
+      double tot = 0;
+      for (size_t i = 0; i + 1 < ev_used; i += 2) {
+        float m2 = 0;
+        HIPCHK(h, hipEventElapsedTime(&m2, h->ev_pool[i], h->ev_pool[i + 1]));
+        tot += m2 * 1e-3;
+      }
+      stats->main_kernel_seconds = tot;
+      stats->main_kernel_launches = main_launches;
+    } else {
+      stats->main_kernel_seconds = stats->device_seconds;
+      stats->main_kernel_launches = main_launches;
+    }
+  }
+  return FMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SGDA
+// ---------------------------------------------------------------------------------------------
+extern "C++" void sgda_free(fmx_handle h) {
+  if (h->sgda.gw) hipFree(h->sgda.gw);
+  if (h->sgda.gv) hipFree(h->sgda.gv);
+  if (h->sgda.reg) hipFree(h->sgda.reg);
+  h->sgda = SgdaState();
+}
+
+int fmx_sgda_end(fmx_handle h) {
+  if (!h) return FMX_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  sgda_free(h);
+  return FMX_OK;
+}
+
+int fmx_sgda_begin(fmx_handle h) {
+  if (!h) return FMX_E_ARG;
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "SGDA on a feature shard is not implemented");
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  sgda_free(h);
+  const size_t nv = h->n_local * (size_t)h->tb.rs, nreg = 1 + (size_t)h->KP;
+  HIPCHK(h, hipMalloc(&h->sgda.gw, h->n_local * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->sgda.gv, nv * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->sgda.reg, nreg * sizeof(double)));
+  HIPCHK(h, hipMemsetAsync(h->sgda.gw, 0, h->n_local * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->sgda.gv, 0, nv * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->sgda.reg, 0, nreg * sizeof(double), h->stream));
+  // fm->w.init(0) (:256): the linear weights restart from zero
+  if (h->tb.ws == 1) HIPCHK(h, hipMemsetAsync(h->tb.w, 0, h->n_local * sizeof(float), h->stream));
+  else HIPCHK(h, hipMemset2DAsync(h->tb.w, (size_t)h->tb.ws * sizeof(float), 0, sizeof(float), h->n_local, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+int fmx_sgda_get_reg(fmx_handle h, double* reg) {
+  if (!h || !reg) return FMX_E_ARG;
+  if (!h->sgda.reg) return fail(h, FMX_E_STATE, "fmx_sgda_get_reg before fmx_sgda_begin");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(reg, h->sgda.reg, (1 + (size_t)h->cfg.num_factor) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, fmx_epoch_stats* stats) {
+  int rc = check_slot(h, train_slot, true);
+  if (rc) return rc;
+  rc = check_slot(h, validation_slot, true);
+  if (rc) return rc;
+  if (!h->sgda.reg) return fail(h, FMX_E_STATE, "fmx_sgda_epoch before fmx_sgda_begin");
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  const Slot& s = h->slots[train_slot];
+  const Slot& v = h->slots[validation_slot];
+  const Hyper hy = make_hyper(h->cfg);
+  if (stats) memset(stats, 0, sizeof(*stats));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows,
+                                        v.ent, v.row_ptr, v.target, v.n_rows, h->tb, h->sgda.gw, h->sgda.gv, hy, h->w0,
+                                        h->sgda.reg, do_lambda_steps));
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (stats) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    stats->rows = s.n_rows; stats->batches = s.n_rows; stats->device_seconds = ms * 1e-3;
+    stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = 1;
+  }
+  return FMX_OK;
+}
+
+}  // extern "C"
