@@ -554,8 +554,11 @@ k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_f
 // staleness.  The kernel writes rest_e = y-hat_e - w0 and k_scan advances w0 afterwards with the exact
 // micro-chunk recurrence (fm_sgd.h:34-37), see DESIGN.md section 3.
 // ----------------------------------------------------------------------------------------------
+#ifndef FMX_FUSED_MIN_WAVES
+#define FMX_FUSED_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for (A/B knob)
+#endif
 template <int KP, int ZR, bool ATOMIC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, FMX_FUSED_MIN_WAVES)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
         uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out) {
