@@ -126,8 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None,
                     help="PMC HBM bytes per launch of the dominant kernel (default: profiles/traffic.json if it matches)")
-    ap.add_argument("--cpu-reference", action="store_true",
-                    help="also time the REAL reference code (oracle/_ref/ref_harness time_sgd) at the largest n it can allocate")
+    ap.add_argument("--no-cpu-reference", dest="cpu_reference", action="store_false",
+                    help="skip timing the REAL reference code (oracle/_ref/ref_harness time_sgd, largest n it can allocate)")
     args = ap.parse_args()
 
     import torch

@@ -118,3 +118,39 @@ def test_feature_shards_sum_to_unsharded_partials_at_full_size(capi):
     torch.cuda.synchronize()
     np.testing.assert_allclose(tot.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=1e-6)
     full.close()
+
+
+def test_largest_feature_ids(capi, oracle):
+    """num_attribute at the reference's type limit (uint ids, fm_model.h:51): 2^32 - 1 features, rows touching the very
+    last ids -- every index product must be 64-bit (k = 2: 34 GB of factors + 17 GB of linear weights)."""
+    n = 2 ** 32 - 1
+    k = 2
+    h = capi.Handle(n, k, True, True, capi.TASK_REGRESSION, 0.0, 0.001, 0.002, 0.01, -5.0, 5.0)
+    h.init_params(0.0, 0.1, 13)
+    rng = np.random.default_rng(0)
+    rows, nnz = 512, 6
+    ids = np.concatenate([np.array([n - 1, n - 2, 0, 2 ** 31, 2 ** 31 + 1, 2 ** 32 - 7], dtype=np.uint64),
+                          rng.integers(0, n, rows * nnz - 6, dtype=np.uint64)]).astype(np.uint32)
+    ent = np.zeros(rows * nnz, dtype=capi.ENTRY_DTYPE)
+    ent["id"] = ids
+    ent["value"] = np.round(rng.uniform(0.5, 1.5, rows * nnz), 3)
+    rp = np.arange(rows + 1, dtype=np.uint64) * np.uint64(nnz)
+    y = rng.normal(0, 1, rows).astype(np.float32)
+    h.upload_rows(0, ent, rp, y)
+    uniq = np.unique(ids)
+    w, v = h.get_param_rows(uniq)
+    assert np.abs(v).max() > 0                                   # the fill reached the last rows
+    m = oracle.Model(len(uniq), k, True, True, 0.0, 0.001, 0.002)
+    m.w[:], m.v[:] = w, v
+    e2 = ent.copy()
+    e2["id"] = np.searchsorted(uniq, ids).astype(np.uint32)
+    d = oracle.Data(e2, rp, y)
+    np.testing.assert_allclose(h.predict(0, rows), oracle.predict_raw(m, d), rtol=1e-4, atol=2e-5)
+    h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 64, 16)
+    oracle.sgd_epoch_minibatch(m, d, 0, 0.01, -5.0, 5.0, 64, 16)
+    w2, v2 = h.get_param_rows(uniq)
+    np.testing.assert_allclose(v2, m.v, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w2, m.w, rtol=1e-4, atol=1e-6)
+    with pytest.raises(capi.FmxError):
+        capi.Handle(2 ** 32, 1)                                   # one past the reference's uint range
+    h.close()
