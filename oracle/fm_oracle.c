@@ -251,6 +251,8 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
 }
 
 /* ------------------------------- SGDA ------------------------------- */
+#define GRP(st, id) ((st)->group ? (st)->group[(id)] : 0u)      /* meta->attr_group(id), Data.h:41 */
+
 /* sgd_theta_step                    /root/reference/src/libfm/src/fm_learn_sgd_element_adapt_reg.h:136-169 */
 static void sgda_theta_step(fmo_model *m, fmo_sgda_state *st, const fmo_entry *row, uint32_t size, double target,
                             int task, double lr, double min_target, double max_target, double *sum, double *sum_sqr) {
@@ -264,39 +266,46 @@ static void sgda_theta_step(fmo_model *m, fmo_sgda_state *st, const fmo_entry *r
     mult = target * ((1.0 / (1.0 + exp(-target * p))) - 1.0);  /* :144 */
   }
   const size_t n = (size_t)m->n;
+  const int k = m->k;
   if (m->k0) m->w0 -= lr * (mult + 2 * 0.0 * m->w0);           /* reg_0 = 0 (:100,:149) */
   if (m->k1)
     for (uint32_t i = 0; i < size; i++) {
+      uint32_t g = GRP(st, row[i].id);
       double *w = &m->w[row[i].id];
       st->grad_w[row[i].id] = mult * row[i].value;
-      *w -= lr * (st->grad_w[row[i].id] + 2 * st->reg_w * (*w));
+      *w -= lr * (st->grad_w[row[i].id] + 2 * st->reg_w[g] * (*w));
     }
-  for (int f = 0; f < m->k; f++)
+  for (int f = 0; f < k; f++)
     for (uint32_t i = 0; i < size; i++) {
+      uint32_t g = GRP(st, row[i].id);
       double *v = &V(m, f, row[i].id);
-      double *g = &st->grad_v[(size_t)f * n + row[i].id];
-      *g = mult * (row[i].value * (sum[f] - (*v) * row[i].value));
-      *v -= lr * (*g + 2 * st->reg_v[f] * (*v));
+      double *gr = &st->grad_v[(size_t)f * n + row[i].id];
+      *gr = mult * (row[i].value * (sum[f] - (*v) * row[i].value));
+      *v -= lr * (*gr + 2 * st->reg_v[(size_t)g * k + f] * (*v));
     }
 }
 
-/* predict_scaled (:171-199) + sgd_lambda_step (:201-248), one attribute group */
+/* predict_scaled (:171-199) + sgd_lambda_step (:201-248) */
 static void sgda_lambda_step(fmo_model *m, fmo_sgda_state *st, const fmo_entry *row, uint32_t size, double target,
                              int task, double lr, double min_target, double max_target) {
   const size_t n = (size_t)m->n;
+  const int k = m->k;
+  const uint32_t G = st->num_groups;
   double p = 0.0;
   if (m->k0) p += m->w0;
   if (m->k1)
     for (uint32_t i = 0; i < size; i++) {
+      uint32_t g = GRP(st, row[i].id);
       double w = m->w[row[i].id];
-      double w_dash = w - lr * (st->grad_w[row[i].id] + 2 * st->reg_w * w);
+      double w_dash = w - lr * (st->grad_w[row[i].id] + 2 * st->reg_w[g] * w);
       p += w_dash * row[i].value;
     }
-  for (int f = 0; f < m->k; f++) {
+  for (int f = 0; f < k; f++) {
     double s = 0.0, q = 0.0;
     for (uint32_t i = 0; i < size; i++) {
+      uint32_t g = GRP(st, row[i].id);
       double v = V(m, f, row[i].id);
-      double v_dash = v - lr * (st->grad_v[(size_t)f * n + row[i].id] + 2 * st->reg_v[f] * v);
+      double v_dash = v - lr * (st->grad_v[(size_t)f * n + row[i].id] + 2 * st->reg_v[(size_t)g * k + f] * v);
       double d = v_dash * row[i].value;
       s += d; q += d * d;
     }
@@ -310,26 +319,35 @@ static void sgda_lambda_step(fmo_model *m, fmo_sgda_state *st, const fmo_entry *
   } else if (task == 1) {
     grad_loss = target * ((1.0 / (1.0 + exp(-target * p))) - 1.0);
   }
+  double *acc = (double *)calloc((size_t)2 * G, sizeof(double));   /* lambda_w_grad / sum_f, sum_f_dash_f (:96-98) */
   if (m->k1) {                                                 /* :213-224 */
-    double lw = 0.0;
-    for (uint32_t i = 0; i < size; i++) lw += row[i].value * m->w[row[i].id];
-    lw = -2 * lr * lw;
-    st->reg_w -= lr * grad_loss * lw;
-    st->reg_w = (0.0 > st->reg_w) ? 0.0 : st->reg_w;
-  }
-  for (int f = 0; f < m->k; f++) {                             /* :225-247 */
-    double sum_f_dash = 0.0, sum_f = 0.0, sum_f_dash_f = 0.0;
-    for (uint32_t i = 0; i < size; i++) {
-      double v = V(m, f, row[i].id);
-      double v_dash = v - lr * (st->grad_v[(size_t)f * n + row[i].id] + 2 * st->reg_v[f] * v);
-      sum_f_dash += v_dash * row[i].value;
-      sum_f += v * row[i].value;
-      sum_f_dash_f += v_dash * row[i].value * v * row[i].value;
+    for (uint32_t i = 0; i < size; i++) acc[GRP(st, row[i].id)] += row[i].value * m->w[row[i].id];
+    for (uint32_t g = 0; g < G; g++) {
+      double lw = -2 * lr * acc[g];
+      st->reg_w[g] -= lr * grad_loss * lw;
+      st->reg_w[g] = (0.0 > st->reg_w[g]) ? 0.0 : st->reg_w[g];
     }
-    double lambda_v_grad = -2 * lr * (sum_f_dash * sum_f - sum_f_dash_f);
-    st->reg_v[f] -= lr * grad_loss * lambda_v_grad;
-    st->reg_v[f] = (0.0 > st->reg_v[f]) ? 0.0 : st->reg_v[f];
   }
+  for (int f = 0; f < k; f++) {                                /* :225-247 */
+    double sum_f_dash = 0.0;
+    double *sum_f = acc, *sum_f_dash_f = acc + G;
+    for (uint32_t g = 0; g < 2 * G; g++) acc[g] = 0.0;
+    for (uint32_t i = 0; i < size; i++) {
+      uint32_t g = GRP(st, row[i].id);
+      double v = V(m, f, row[i].id);
+      double v_dash = v - lr * (st->grad_v[(size_t)f * n + row[i].id] + 2 * st->reg_v[(size_t)g * k + f] * v);
+      sum_f_dash += v_dash * row[i].value;
+      sum_f[g] += v * row[i].value;
+      sum_f_dash_f[g] += v_dash * row[i].value * v * row[i].value;
+    }
+    for (uint32_t g = 0; g < G; g++) {
+      double lambda_v_grad = -2 * lr * (sum_f_dash * sum_f[g] - sum_f_dash_f[g]);
+      double *rv = &st->reg_v[(size_t)g * k + f];
+      *rv -= lr * grad_loss * lambda_v_grad;
+      *rv = (0.0 > *rv) ? 0.0 : *rv;
+    }
+  }
+  free(acc);
 }
 
 /* one iteration of fm_learn_sgd_element_adapt_reg::learn (:262-279) */

@@ -108,17 +108,20 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
                                 uint32_t batch, uint32_t w0_chunk, int bias_lag);
 
 /* ---------------- SGDA (adaptive regularisation, Rendle WSDM'12) ---------------------------------------------
- * fm_learn_sgd_element_adapt_reg (src/libfm/src/fm_learn_sgd_element_adapt_reg.h): one attribute group.
- * state: reg_w (scalar), reg_v[k], and the shadow gradients grad_w[n], grad_v[k][n] of the last theta step that
- * touched each parameter (:84-95).  One epoch (:262-279): for every train row a theta step (:136-169); from the
- * second epoch on, each theta step is followed by a lambda step (:201-248, through predict_scaled :171-199) on the
- * next validation row (cyclic).  The learner zeroes w and the model's reg values at the start of learn (:256-262). */
+ * fm_learn_sgd_element_adapt_reg (src/libfm/src/fm_learn_sgd_element_adapt_reg.h).
+ * state: reg_w[G], reg_v[G][k] per attribute group (`-meta`, :84-85; G = 1 without a meta file), and the shadow
+ * gradients grad_w[n], grad_v[k][n] of the last theta step that touched each parameter (:90-95).  One epoch
+ * (:262-279): for every train row a theta step (:136-169); from the second epoch on, each theta step is followed by
+ * a lambda step (:201-248, through predict_scaled :171-199) on the next validation row (cyclic).  The learner
+ * zeroes w and the model's reg values at the start of learn (:256-262). */
 typedef struct {
-  double  reg_w;
-  double *reg_v;     /* [k] */
+  double *reg_w;     /* [G] */
+  double *reg_v;     /* [G][k] */
   double *grad_w;    /* [n] */
   double *grad_v;    /* [k][n] factor-major */
   uint32_t val_pos;  /* next validation row */
+  uint32_t num_groups;       /* G >= 1 */
+  const uint32_t *group;     /* [n] attribute -> group (DataMetaInfo::attr_group, Data.h:41); NULL = all 0 */
 } fmo_sgda_state;
 void fmo_sgda_epoch(fmo_model *m, fmo_sgda_state *st, const fmo_data *train, const fmo_data *val, int task,
                     double learn_rate, double min_target, double max_target, int do_lambda_steps);
@@ -148,6 +151,16 @@ void fmo_als_predict_eterms(const fmo_model *m, const fmo_data_t *dt, fmo_eq *ca
  * add_main_q (:406-428) then draw_v (:792-847) with lambda = v_lambda.  cache[c].e holds (y-hat - target). */
 void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, double w_lambda, double v_lambda);
 
+/* the same with regularisation per attribute group (`-meta` + `-regular 'r0,w_1..w_G,v_1..v_G'`, libfm.cpp:353-363):
+ * w_lambda[G], v_lambda[G][k] (the reference's DMatrix v_lambda(g,f), fm_learn_mcmc.h:1121-1122) */
+typedef struct {
+  const uint32_t *group;     /* [m->n] attribute -> group; NULL = all 0 */
+  uint32_t        num_groups;
+  const double   *w_lambda;  /* [G] */
+  const double   *v_lambda;  /* [G][k] */
+} fmo_als_reg;
+void fmo_als_sweep_groups(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, const fmo_als_reg *reg);
+
 /* fm_learn_mcmc::learn + fm_learn_mcmc_simultaneous::_learn with do_sample = 0 (fm_learn_mcmc.h:1160-1201,
  * fm_learn_mcmc_simultaneous.h:56-270): num_iter sweeps, e recomputed after each.  task regression: e -= y;
  * classification: e -= E[truncated normal] (:172-194, with the reference's 3.141 and its erf polynomial,
@@ -157,6 +170,9 @@ void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, double w_l
 void fmo_als_learn(fmo_model *m, const fmo_data *train, const fmo_data *test, int task, int num_iter,
                    double w_lambda, double v_lambda, double min_target, double max_target,
                    double *test_pred_this, double *train_metric);
+void fmo_als_learn_groups(fmo_model *m, const fmo_data *train, const fmo_data *test, int task, int num_iter,
+                          const fmo_als_reg *reg, double min_target, double max_target,
+                          double *test_pred_this, double *train_metric);
 
 /* the reference's 5-term erf polynomial and cdf_gaussian (random.h:45-67) */
 double fmo_erf(double x);

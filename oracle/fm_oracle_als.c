@@ -128,9 +128,13 @@ static void als_draw_v(double *v, double v_mu, double v_lambda, double alpha,
   }
 }
 
-void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, double w_lambda, double v_lambda) {
+/* draw_all with do_sample = 0 (fm_learn_mcmc.h:430-641); lambda per attribute group: w_lambda(g), v_lambda(g,f)
+ * (:464-466, :583-585), g = meta->attr_group(feature) */
+void fmo_als_sweep_groups(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, const fmo_als_reg *reg) {
   const double alpha = 1.0, mu = 0.0;                      /* fm_learn_mcmc.h:1106-1112, draw_alpha :912-915 */
   const uint32_t N = dt->n_rows;
+  const int k = m->k;
+#define AG(j) (reg->group ? reg->group[(j)] : 0u)
   if (m->k0) {                                             /* draw_w0 :643-683 (reg = fm->reg0, w0_mean_0 = 0) */
     double w0_mean = 0;
     for (uint32_t i = 0; i < N; i++) w0_mean += cache[i].e - m->w0;
@@ -143,10 +147,10 @@ void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, double w_l
   }
   if (m->k1) {                                             /* :441-476 */
     for (uint64_t j = 0; j < dt->n; j++)
-      als_draw_w(&m->w[j], mu, w_lambda, alpha, dt->entries + dt->col_ptr[j], dt->col_ptr[j + 1] - dt->col_ptr[j], cache);
-    for (uint64_t j = dt->n; j < m->n; j++) als_draw_w(&m->w[j], mu, w_lambda, alpha, NULL, 0, cache);
+      als_draw_w(&m->w[j], mu, reg->w_lambda[AG(j)], alpha, dt->entries + dt->col_ptr[j], dt->col_ptr[j + 1] - dt->col_ptr[j], cache);
+    for (uint64_t j = dt->n; j < m->n; j++) als_draw_w(&m->w[j], mu, reg->w_lambda[AG(j)], alpha, NULL, 0, cache);
   }
-  for (int f = 0; f < m->k; f++) {                         /* :528-595 */
+  for (int f = 0; f < k; f++) {                            /* :528-595 */
     for (uint32_t c = 0; c < N; c++) cache[c].q = 0.0;
     for (uint64_t j = 0; j < dt->n; j++) {                 /* add_main_q :406-428 */
       const double v_if = VV(m, f, j);
@@ -154,14 +158,33 @@ void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, double w_l
         cache[dt->entries[i].id].q += v_if * dt->entries[i].value;
     }
     for (uint64_t j = 0; j < dt->n; j++)
-      als_draw_v(&VV(m, f, j), mu, v_lambda, alpha, dt->entries + dt->col_ptr[j], dt->col_ptr[j + 1] - dt->col_ptr[j], cache);
-    for (uint64_t j = dt->n; j < m->n; j++) als_draw_v(&VV(m, f, j), mu, v_lambda, alpha, NULL, 0, cache);
+      als_draw_v(&VV(m, f, j), mu, reg->v_lambda[(size_t)AG(j) * k + f], alpha, dt->entries + dt->col_ptr[j], dt->col_ptr[j + 1] - dt->col_ptr[j], cache);
+    for (uint64_t j = dt->n; j < m->n; j++) als_draw_v(&VV(m, f, j), mu, reg->v_lambda[(size_t)AG(j) * k + f], alpha, NULL, 0, cache);
   }
+#undef AG
+}
+
+void fmo_als_sweep(fmo_model *m, const fmo_data_t *dt, fmo_eq *cache, double w_lambda, double v_lambda) {
+  double *vl = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  for (int f = 0; f < m->k; f++) vl[f] = v_lambda;
+  fmo_als_reg reg = { NULL, 1, &w_lambda, vl };
+  fmo_als_sweep_groups(m, dt, cache, &reg);
+  free(vl);
 }
 
 void fmo_als_learn(fmo_model *m, const fmo_data *train, const fmo_data *test, int task, int num_iter,
                    double w_lambda, double v_lambda, double min_target, double max_target,
                    double *test_pred_this, double *train_metric) {
+  double *vl = (double *)malloc(sizeof(double) * (size_t)(m->k > 0 ? m->k : 1));
+  for (int f = 0; f < m->k; f++) vl[f] = v_lambda;
+  fmo_als_reg reg = { NULL, 1, &w_lambda, vl };
+  fmo_als_learn_groups(m, train, test, task, num_iter, &reg, min_target, max_target, test_pred_this, train_metric);
+  free(vl);
+}
+
+void fmo_als_learn_groups(fmo_model *m, const fmo_data *train, const fmo_data *test, int task, int num_iter,
+                          const fmo_als_reg *reg, double min_target, double max_target,
+                          double *test_pred_this, double *train_metric) {
   /* X^T of each data set has as many rows as THAT data set has features (Data.h:300-301) */
   uint64_t n_train = 0, n_test = 0;
   for (uint64_t i = 0; i < train->row_ptr[train->n_rows]; i++) if (train->entries[i].id + 1 > n_train) n_train = train->entries[i].id + 1;
@@ -179,7 +202,7 @@ void fmo_als_learn(fmo_model *m, const fmo_data *train, const fmo_data *test, in
   for (uint32_t c = 0; c < train->n_rows; c++) cache[c].e = cache[c].e - train->target[c];   /* :70-86 */
 
   for (int it = 0; it < num_iter; it++) {                  /* :88 */
-    fmo_als_sweep(m, &dtr, cache, w_lambda, v_lambda);     /* draw_all :94 */
+    fmo_als_sweep_groups(m, &dtr, cache, reg);             /* draw_all :94 */
     fmo_als_predict_eterms(m, &dtr, cache);                /* :122 */
     fmo_als_predict_eterms(m, &dte, cache_test);
     if (task == FMO_TASK_REGRESSION) {                     /* :127-150 */

@@ -45,8 +45,12 @@ class _Data(C.Structure):
 
 
 class _SgdaState(C.Structure):
-    _fields_ = [("reg_w", C.c_double), ("reg_v", C.c_void_p), ("grad_w", C.c_void_p), ("grad_v", C.c_void_p),
-                ("val_pos", C.c_uint32)]
+    _fields_ = [("reg_w", C.c_void_p), ("reg_v", C.c_void_p), ("grad_w", C.c_void_p), ("grad_v", C.c_void_p),
+                ("val_pos", C.c_uint32), ("num_groups", C.c_uint32), ("group", C.c_void_p)]
+
+
+class _AlsReg(C.Structure):
+    _fields_ = [("group", C.c_void_p), ("num_groups", C.c_uint32), ("w_lambda", C.c_void_p), ("v_lambda", C.c_void_p)]
 
 
 _lib = None
@@ -73,6 +77,8 @@ def lib():
         L.fmo_init_value.restype = C.c_double
         L.fmo_als_learn.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.POINTER(_Data), C.c_int, C.c_int, C.c_double, C.c_double,
                                     C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.fmo_als_learn_groups.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.POINTER(_Data), C.c_int, C.c_int, C.POINTER(_AlsReg),
+                                           C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.fmo_sgda_epoch.argtypes = [C.POINTER(_Model), C.POINTER(_SgdaState), C.POINTER(_Data), C.POINTER(_Data), C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_int]
         L.fmo_fill_params.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_double, C.c_int]
@@ -231,12 +237,15 @@ def init_values(seed, n, k, stdev):
     return stdev * (2.0 * u - 1.0) * 1.7320508075688772
 
 
-def run_ref_harness(args, cwd=None):
-    """Run oracle/_ref/ref_harness (the real reference classes).  Raises if it is not built."""
+def run_ref_harness(args, cwd=None, env=None):
+    """Run oracle/_ref/ref_harness (the real reference classes).  Raises if it is not built.
+    env: extra environment (FMX_META, FMX_GROUP_REG -- see the header of ref_harness.cpp)."""
     if not os.path.exists(REF_HARNESS):
         raise FileNotFoundError("oracle/_ref/ref_harness not built (needs /root/reference); run make -C oracle")
+    e = dict(os.environ)
+    e.update(env or {})
     return subprocess.run([REF_HARNESS] + [str(a) for a in args], cwd=cwd, check=True,
-                          capture_output=True, text=True)
+                          capture_output=True, text=True, env=e)
 
 
 def time_sgd_synth(n, k, nnz, n_rows, seed=123, stdev=0.01, lr=0.01, regv=0.001, threads=8, row0=0):
@@ -265,24 +274,44 @@ def als_learn(m, train, test, task, num_iter, w_lambda, v_lambda, min_target, ma
     return pred, metric
 
 
-class SgdaState:
-    """reg_w, reg_v[k] and the shadow gradients of fm_learn_sgd_element_adapt_reg (one attribute group)."""
+def als_learn_groups(m, train, test, task, num_iter, group, w_lambda_g, v_lambda_gf, min_target, max_target):
+    """ALS with regularisation per attribute group: group[n] (uint32), w_lambda_g[G], v_lambda_gf[G][k]."""
+    group = np.ascontiguousarray(group, dtype=np.uint32)
+    wl = np.ascontiguousarray(w_lambda_g, dtype=np.float64)
+    vl = np.ascontiguousarray(v_lambda_gf, dtype=np.float64)
+    assert group.shape == (m.n,) and vl.shape == (len(wl), max(m.k, 0)) and int(group.max()) < len(wl)
+    pred = np.zeros(test.n_rows, dtype=np.float64)
+    metric = np.zeros(num_iter, dtype=np.float64)
+    cm, ctr, cte = m._c(), train._c(), test._c()
+    reg = _AlsReg(group.ctypes.data, len(wl), wl.ctypes.data, vl.ctypes.data)
+    lib().fmo_als_learn_groups(C.byref(cm), C.byref(ctr), C.byref(cte), task, num_iter, C.byref(reg), min_target, max_target,
+                               pred.ctypes.data, metric.ctypes.data)
+    m.w0 = cm.w0
+    return pred, metric
 
-    def __init__(self, n, k):
-        self.reg_w = 0.0
-        self.reg_v = np.zeros(max(k, 1), dtype=np.float64)
+
+class SgdaState:
+    """reg_w[G], reg_v[G][k] and the shadow gradients of fm_learn_sgd_element_adapt_reg (G attribute groups)."""
+
+    def __init__(self, n, k, group=None):
+        self.group = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
+        self.num_groups = 1 if group is None else int(self.group.max()) + 1
+        self.reg_w = np.zeros(self.num_groups, dtype=np.float64)
+        self.reg_v = np.zeros((self.num_groups, max(k, 1)), dtype=np.float64)
         self.grad_w = np.zeros(n, dtype=np.float64)
         self.grad_v = np.zeros((max(k, 1), n), dtype=np.float64)
 
 
-def sgda_learn(m, train, val, task, lr, min_target, max_target, num_iter):
+def sgda_learn(m, train, val, task, lr, min_target, max_target, num_iter, group=None):
     """fm_learn_sgd_element_adapt_reg::learn (:250-279): w := 0, regs := 0, then num_iter epochs (lambda steps from the 2nd)."""
-    st = SgdaState(m.n, m.k)
+    st = SgdaState(m.n, m.k, group)
+    if m.k == 0:
+        st.reg_v = np.zeros((st.num_groups, 0), dtype=np.float64)
     m.w[:] = 0.0
     for i in range(num_iter):
         cm, ctr, cv = m._c(), train._c(), val._c()
-        cs = _SgdaState(st.reg_w, st.reg_v.ctypes.data, st.grad_w.ctypes.data, st.grad_v.ctypes.data, 0)
+        cs = _SgdaState(st.reg_w.ctypes.data, st.reg_v.ctypes.data, st.grad_w.ctypes.data, st.grad_v.ctypes.data, 0,
+                        st.num_groups, None if st.group is None else st.group.ctypes.data)
         lib().fmo_sgda_epoch(C.byref(cm), C.byref(cs), C.byref(ctr), C.byref(cv), task, lr, min_target, max_target, int(i > 0))
         m.w0 = cm.w0
-        st.reg_w = cs.reg_w
     return st

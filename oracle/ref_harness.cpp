@@ -18,6 +18,8 @@
 //   ref_harness mcmc <train> <test> <task r|c> <k0> <k1> <k> <iters> <init_stdev> <seed> <out_prefix>
 //   ref_harness time_sgd <n> <k> <nnz> <rows> <seed>        (CPU baseline: reference fm_model::predict + fm_SGD on
 //                                                             the synthetic workload of oracle/fm_oracle.c, 1 thread)
+// environment: FMX_META=<file>  attribute groups (`-meta`, one group id per line, Data.h:85-97);
+//              FMX_GROUP_REG=w_1,..,w_G,v_1,..,v_G  per-group lambdas for als (the tail of `-regular`, libfm.cpp:353-363)
 // outputs (<out_prefix>.*):
 //   .init.bin / .final.bin : magic 'FMXP', u64 n, i32 k, f64 w0, f64 w[n], f64 v[k][n]  (reference layout)
 //   .pred_raw.bin          : f64[num_test]  fm_learn::predict_case per test row after training
@@ -145,6 +147,7 @@ int main(int argc, char** argv) {
     test.load(test_file);
     uint num_all_attribute = std::max(train.num_feature, test.num_feature);   // libfm.cpp:203
     DataMetaInfo meta(num_all_attribute);
+    if (getenv("FMX_META")) meta.loadGroupsFromFile(getenv("FMX_META"));   // -meta, libfm.cpp:207-210 (no relations: meta == meta_main)
     meta.num_relations = 0;
     train.relation.setSize(0); test.relation.setSize(0);
 
@@ -200,8 +203,10 @@ int main(int argc, char** argv) {
       fml->predict(test, pred);
       dump_vec(prefix + ".pred_out.bin", pred.value, pred.dim);
       FILE* rf = fopen((prefix + ".reg.txt").c_str(), "w");
-      fprintf(rf, "%.17g\n", fml->reg_w(0));
-      for (int f = 0; f < k; f++) fprintf(rf, "%.17g\n", fml->reg_v(0, f));
+      for (uint g = 0; g < meta.num_attr_groups; g++) {          // [G][1+k]: reg_w(g), reg_v(g,0..k-1)
+        fprintf(rf, "%.17g\n", fml->reg_w(g));
+        for (int f = 0; f < k; f++) fprintf(rf, "%.17g\n", fml->reg_v(g, f));
+      }
       fclose(rf);
     } else
     if (is_sgd) {
@@ -244,6 +249,14 @@ int main(int argc, char** argv) {
       fml->init();
       fm.reg0 = reg0; fm.regw = regw; fm.regv = regv;         // libfm.cpp:346-352
       fml->w_lambda.init(fm.regw); fml->v_lambda.init(fm.regv);
+      if (getenv("FMX_GROUP_REG")) {                           // -regular 'r0,w_1..w_G,v_1..v_G', libfm.cpp:353-363
+        std::vector<double> reg; { std::string t = getenv("FMX_GROUP_REG"); size_t p0 = 0; while (p0 < t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); reg.push_back(atof(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } }
+        if (reg.size() != 2 * meta.num_attr_groups) { fprintf(stderr, "FMX_GROUP_REG needs 2*G values\n"); return 2; }
+        fm.regw = 0.0; fm.regv = 0.0;
+        int j = 0;
+        for (uint g = 0; g < meta.num_attr_groups; g++) fml->w_lambda(g) = reg[j++];
+        for (uint g = 0; g < meta.num_attr_groups; g++) { for (int f = 0; f < fm.num_factor; f++) fml->v_lambda(g, f) = reg[j]; j++; }
+      }
       dump_params(prefix + ".init.bin", fm);
       fml->learn(train, test);
       dump_params(prefix + ".final.bin", fm);

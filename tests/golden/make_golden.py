@@ -49,6 +49,25 @@ CASES = {
 }
 
 
+def groups_of(case, n):
+    """attribute -> group array of a case: ('split', boundary) = ids below the boundary are group 0, the rest group 1
+    (users / items); ('fields', nnz, n_features, fields_per_group) = one-hot field blocks."""
+    spec = case.get("groups")
+    if spec is None:
+        return None
+    j = np.arange(n)
+    if spec[0] == "split":
+        return (j >= spec[1]).astype(np.uint32)
+    _, nnz, n_features, per = spec
+    return np.minimum(j // (n_features // nnz), nnz - 1).astype(np.uint32) // per
+
+
+def write_meta(path, case, n_nominal):
+    g = groups_of(case, n_nominal)
+    with open(path, "w") as f:                       # DVector<uint>::load reads `dim` whitespace-separated values (matrix.h:360-371)
+        f.write("".join("%d\n" % x for x in g))
+
+
 ALS_CASES = {
     "als_reg_ml": dict(gen="movielens_shaped", train=dict(n_users=120, n_items=80, n_rows=600, seed=11),
                        test=dict(n_users=120, n_items=80, n_rows=150, seed=12),
@@ -59,6 +78,15 @@ ALS_CASES = {
     "als_reg_fields_k16": dict(gen="onehot_fields", train=dict(n_features=480, nnz=6, n_rows=400, seed=41, classification=False),
                                test=dict(n_features=480, nnz=6, n_rows=100, seed=42, classification=False),
                                cfg=dict(task="r", k0=1, k1=1, k=16, iters=3, reg=(0.0, 0.5, 10.0), init_stdev=0.1, seed=1)),
+    # attribute groups (-meta) with per-group lambdas (-regular 'r0,w_1..w_G,v_1..v_G', libfm.cpp:353-363)
+    "als_reg_ml_groups": dict(gen="movielens_shaped", train=dict(n_users=120, n_items=80, n_rows=600, seed=11),
+                              test=dict(n_users=120, n_items=80, n_rows=150, seed=12), groups=("split", 120), n_nominal=200,
+                              group_reg=((0.5, 2.0), (3.0, 9.0)),
+                              cfg=dict(task="r", k0=1, k1=1, k=8, iters=4, reg=(0.0, 0.0, 0.0), init_stdev=0.1, seed=42)),
+    "als_cls_fields_groups": dict(gen="onehot_fields", train=dict(n_features=480, nnz=6, n_rows=400, seed=43),
+                                  test=dict(n_features=480, nnz=6, n_rows=100, seed=44), groups=("fields", 6, 480, 2), n_nominal=480,
+                                  group_reg=((0.1, 1.0, 4.0), (2.0, 6.0, 12.0)),
+                                  cfg=dict(task="c", k0=1, k1=1, k=4, iters=3, reg=(0.2, 0.0, 0.0), init_stdev=0.1, seed=8)),
     "als_reg_nolin_dup": dict(gen="ragged_real", train=dict(n_features=60, n_rows=150, max_nnz=6, seed=51, duplicates=True, classification=False),
                               test=dict(n_features=60, n_rows=40, max_nnz=6, seed=52, classification=False),
                               cfg=dict(task="r", k0=0, k1=0, k=3, iters=2, reg=(0.0, 0.0, 2.0), init_stdev=0.1, seed=5)),
@@ -75,14 +103,22 @@ def make_als():
             trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
             tr.write_libsvm(trf)
             te.write_libsvm(tef)
+            env, extra = {}, {}
+            if "groups" in case:
+                write_meta(os.path.join(td, "meta"), case, case["n_nominal"])
+                env = {"FMX_META": os.path.join(td, "meta"),
+                       "FMX_GROUP_REG": ",".join(repr(x) for x in case["group_reg"][0] + case["group_reg"][1])}
             O.run_ref_harness(["als", trf, tef, cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"],
                                repr(cfg["reg"][0]), repr(cfg["reg"][1]), repr(cfg["reg"][2]), repr(cfg["init_stdev"]),
-                               cfg["seed"], pre])
+                               cfg["seed"], pre], env=env)
             init = O.Model.from_dump(pre + ".init.bin")
             final = O.Model.from_dump(pre + ".final.bin")
             pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+            if "groups" in case:
+                extra = dict(group=groups_of(case, init.n), w_lambda_g=np.array(case["group_reg"][0]),
+                             v_lambda_g=np.array(case["group_reg"][1]))
         np.savez_compressed(
-            os.path.join(HERE, name + ".npz"),
+            os.path.join(HERE, name + ".npz"), **extra,
             train_entries=tr.entries, train_row_ptr=tr.row_ptr, train_target=tr.target,
             test_entries=te.entries, test_row_ptr=te.row_ptr, test_target=te.target,
             task=cfg["task"], k0=cfg["k0"], k1=cfg["k1"], k=cfg["k"], iters=cfg["iters"], lr=0.0,
@@ -99,6 +135,9 @@ MCMC_CASES = {
     "mcmc_cls_fields": dict(gen="onehot_fields", train=dict(n_features=600, nnz=6, n_rows=4000, seed=41),
                             test=dict(n_features=600, nnz=6, n_rows=1000, seed=41, _skip=4000),
                             cfg=dict(task="c", k0=1, k1=1, k=4, iters=40, init_stdev=0.1, seed=1)),
+    "mcmc_reg_ml_groups": dict(gen="movielens_shaped", train=dict(n_users=300, n_items=200, n_rows=6000, seed=13),
+                               test=dict(n_users=300, n_items=200, n_rows=1500, seed=13, _skip=6000), groups=("split", 300), n_nominal=500,
+                               cfg=dict(task="r", k0=1, k1=1, k=8, iters=40, init_stdev=0.1, seed=42)),
 }
 
 
@@ -118,12 +157,18 @@ def make_mcmc():
             trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
             tr.write_libsvm(trf)
             te.write_libsvm(tef)
+            env, extra = {}, {}
+            if "groups" in case:
+                write_meta(os.path.join(td, "meta"), case, case["n_nominal"])
+                env = {"FMX_META": os.path.join(td, "meta")}
             O.run_ref_harness(["mcmc", trf, tef, cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"],
-                               repr(cfg["init_stdev"]), cfg["seed"], pre])
+                               repr(cfg["init_stdev"]), cfg["seed"], pre], env=env)
             init = O.Model.from_dump(pre + ".init.bin")
             pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+            if "groups" in case:
+                extra = dict(group=groups_of(case, init.n))
         np.savez_compressed(
-            os.path.join(HERE, name + ".npz"),
+            os.path.join(HERE, name + ".npz"), **extra,
             train_entries=tr.entries, train_row_ptr=tr.row_ptr, train_target=tr.target,
             test_entries=te.entries, test_row_ptr=te.row_ptr, test_target=te.target,
             task=cfg["task"], k0=cfg["k0"], k1=cfg["k1"], k=cfg["k"], iters=cfg["iters"], lr=0.0,
@@ -141,6 +186,12 @@ SGDA_CASES = {
                         cfg=dict(task="r", k0=1, k1=1, k=8, iters=4, lr=0.005, init_stdev=0.1, seed=42)),
     "sgda_cls_fields": dict(gen="onehot_fields", n=dict(n_features=300, nnz=6, seed=41), rows=(500, 100, 150),
                             cfg=dict(task="c", k0=1, k1=1, k=4, iters=3, lr=0.02, init_stdev=0.1, seed=3)),
+    "sgda_reg_ml_groups": dict(gen="movielens_shaped", n=dict(n_users=120, n_items=80, seed=15), rows=(600, 150, 200),
+                               groups=("split", 120), n_nominal=200,
+                               cfg=dict(task="r", k0=1, k1=1, k=8, iters=4, lr=0.005, init_stdev=0.1, seed=42)),
+    "sgda_cls_fields_groups": dict(gen="onehot_fields", n=dict(n_features=300, nnz=6, seed=45), rows=(500, 100, 150),
+                                   groups=("fields", 6, 300, 1), n_nominal=300,
+                                   cfg=dict(task="c", k0=1, k1=1, k=4, iters=3, lr=0.02, init_stdev=0.1, seed=3)),
 }
 
 
@@ -160,15 +211,21 @@ def make_sgda():
             for d, p in zip((tr, te, va), f):
                 d.write_libsvm(p)
             pre = os.path.join(td, "out")
+            env, extra = {}, {}
+            if "groups" in case:
+                write_meta(os.path.join(td, "meta"), case, case["n_nominal"])
+                env = {"FMX_META": os.path.join(td, "meta")}
             O.run_ref_harness(["sgda", f[0], f[1], cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"], repr(cfg["lr"]),
-                               "0", "0", "0", repr(cfg["init_stdev"]), cfg["seed"], pre, f[2]])
+                               "0", "0", "0", repr(cfg["init_stdev"]), cfg["seed"], pre, f[2]], env=env)
             init = O.Model.from_dump(pre + ".init.bin")
             final = O.Model.from_dump(pre + ".final.bin")
             pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
             regs = np.loadtxt(pre + ".reg.txt")
             ev = np.loadtxt(pre + ".eval.txt", ndmin=2)
+            if "groups" in case:
+                extra = dict(group=groups_of(case, init.n))
         np.savez_compressed(
-            os.path.join(HERE, name + ".npz"),
+            os.path.join(HERE, name + ".npz"), **extra,
             train_entries=tr.entries, train_row_ptr=tr.row_ptr, train_target=tr.target,
             test_entries=te.entries, test_row_ptr=te.row_ptr, test_target=te.target,
             val_entries=va.entries, val_row_ptr=va.row_ptr, val_target=va.target,

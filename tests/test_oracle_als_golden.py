@@ -15,7 +15,11 @@ def test_als_bit_exact(oracle, name):
     g = Golden(name)
     m = g.model(O, "init")
     tr, te = g.data(O, "train"), g.data(O, "test")
-    pred, metric = O.als_learn(m, tr, te, g.task, g.iters, g.reg[1], g.reg[2], g.min_target, g.max_target)
+    if "group" in g.z.files:                                           # -meta + per-group lambdas (libfm.cpp:353-363)
+        vl = np.repeat(g.z["v_lambda_g"][:, None], max(g.k, 1), axis=1)[:, :g.k]
+        pred, metric = O.als_learn_groups(m, tr, te, g.task, g.iters, g.z["group"], g.z["w_lambda_g"], vl, g.min_target, g.max_target)
+    else:
+        pred, metric = O.als_learn(m, tr, te, g.task, g.iters, g.reg[1], g.reg[2], g.min_target, g.max_target)
     assert m.w0 == float(g.z["final_w0"])
     assert np.array_equal(m.w, g.z["final_w"])
     assert np.array_equal(m.v, g.z["final_v"])

@@ -23,10 +23,14 @@ def test_sgda_bit_exact(oracle, name):
     g = Golden(name)
     m = g.model(O, "init")
     m.reg0 = m.regw = m.regv = 0.0
-    st = O.sgda_learn(m, g.data(O, "train"), val_data(g, O), g.task, g.lr, g.min_target, g.max_target, g.iters)
+    group = g.z["group"] if "group" in g.z.files else None            # `-meta` attribute groups
+    st = O.sgda_learn(m, g.data(O, "train"), val_data(g, O), g.task, g.lr, g.min_target, g.max_target, g.iters, group)
     assert m.w0 == float(g.z["final_w0"])
     assert np.array_equal(m.w, g.z["final_w"])
     assert np.array_equal(m.v, g.z["final_v"])
-    assert st.reg_w == g.z["regs"][0]
-    assert np.array_equal(st.reg_v[:g.k], g.z["regs"][1:])
+    regs = g.z["regs"].reshape(st.num_groups, 1 + g.k)                # [G][1+k]: reg_w(g), reg_v(g,f)
+    assert np.array_equal(st.reg_w, regs[:, 0])
+    assert np.array_equal(st.reg_v[:, :g.k], regs[:, 1:])
+    if group is not None:
+        assert st.num_groups > 1 and np.unique(regs[:, 1:], axis=0).shape[0] > 1   # the groups really learn different values
     assert np.array_equal(O.predict_out(m, g.data(O, "test"), g.task, g.min_target, g.max_target), g.z["pred_out"])
