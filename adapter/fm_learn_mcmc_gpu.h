@@ -5,10 +5,12 @@
 // It derives from fm_learn_mcmc so that main()'s casts and field writes keep working unchanged
 // (libfm.cpp:284-290: num_iter, num_eval_cases, do_sample, do_multilevel; :335-352: w_lambda / v_lambda from
 // -regular) and replaces the iteration loop of fm_learn_mcmc_simultaneous::_learn (fm_learn_mcmc_simultaneous.h:
-// 56-270) by fmx_als_begin / fmx_als_sweep.  Only do_sample = 0, do_multilevel = 0, one attribute group, no relations.
+// 56-270) by fmx_als_begin / fmx_als_sweep.  Only do_sample = 0, do_multilevel = 0, no relations.  Attribute groups
+// (`-meta`) are passed through: meta->attr_group -> fmx_set_groups, w_lambda(g) / v_lambda(g,f) -> the opts tables.
 #ifndef FM_LEARN_MCMC_GPU_H_
 #define FM_LEARN_MCMC_GPU_H_
 
+#include <cstring>
 #include <vector>
 #include <string>
 #include "fmx.h"
@@ -22,7 +24,6 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
   virtual void learn(Data& train, Data& test) {            // fm_learn_mcmc::learn (:1160-1201) + _learn
     if (do_sample || do_multilevel) throw "fm_learn_als_gpu: only -method als (no sampling) is bound";
     if (train.relation.dim > 0) throw "relations are not supported";
-    if (meta->num_attr_groups != 1) throw "attribute groups are not supported";
     pred_sum_all.setSize(test.num_cases); pred_sum_all_but5.setSize(test.num_cases); pred_this.setSize(test.num_cases);
     pred_sum_all.init(0.0); pred_sum_all_but5.init(0.0); pred_this.init(0.0);
     fmx_config c;
@@ -33,11 +34,17 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
     if (fmx_create(&c, &h) != FMX_OK) throw std::string(fmx_last_error(NULL));
     check(fmx_set_params(h, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
     upload(0, train); upload(1, test);
+    const uint G = meta->num_attr_groups;
+    if (G > 1) check(fmx_set_groups(h, (const uint32_t*)meta->attr_group.value, G));   // DVector<uint>, Data.h:41
     check(fmx_als_begin(h, 0));
     fmx_als_opts o;
+    memset(&o, 0, sizeof(o));
     o.alpha = alpha_0; o.w_mu = mu_0; o.v_mu = mu_0;                       // draw_alpha / draw_*_mu without multilevel
     o.w_lambda = w_lambda(0); o.v_lambda = fm->num_factor > 0 ? v_lambda(0, 0) : 0.0;
-    o.do_sample = 0; o.reserved = 0; o.seed = 0; o.v_mu_f = NULL; o.v_lambda_f = NULL;
+    if (G > 1) {                                                           // w_lambda(g), v_lambda(g,f): DVector[G], DMatrix[G][k]
+      o.num_groups = G; o.w_lambda_g = w_lambda.value;
+      o.v_lambda_gf = fm->num_factor > 0 ? v_lambda.value[0] : NULL;
+    }
     std::vector<double> p(test.num_cases);
     for (uint i = 0; i < num_iter; i++) {
       fmx_als_stats st;

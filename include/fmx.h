@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 1
+#define FMX_ABI_VERSION 2
 
 enum {
   FMX_OK = 0,
@@ -142,6 +142,14 @@ int fmx_get_param_rows(fmx_handle h, const uint32_t *ids, uint32_t count, double
 /* the scalar bias alone (cheap; used between minibatches by multi-process drivers) */
 int fmx_get_w0(fmx_handle h, double *w0);
 
+/* ---- attribute groups (`-meta`): DataMetaInfo::attr_group, src/libfm/src/Data.h:39-46, loaded by
+ * loadGroupsFromFile (:85-97).  group_of_feature[n_local] (host, ids < num_groups) of this handle's features.
+ * Groups select the prior of a coordinate in ALS / MCMC (w_lambda(g), w_mu(g), v_lambda(g,f), v_mu(g,f);
+ * fm_learn_mcmc.h:464-466, :583-585) and the learned regularisation in SGDA (reg_w(g), reg_v(g,f);
+ * fm_learn_sgd_element_adapt_reg.h:155-166); plain SGD ignores them like the reference does.
+ * NULL or num_groups <= 1 goes back to one group.  Not allowed while an ALS / SGDA session is open. */
+int fmx_set_groups(fmx_handle h, const uint32_t *group_of_feature, uint32_t num_groups);
+
 /* ---- rows: what Data::load produces (Data.h:237-270) ---------------------------------------- */
 /* uploads a data set into `slot` (0..FMX_MAX_SLOTS-1).  entries: {uint32 id; float value}[nnz] in row
  * order (the buffer Data::load allocates), row_ptr: uint64[n_rows+1] prefix sums of sparse_row::size,
@@ -195,7 +203,7 @@ int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float *d_partial, fl
  * do_sample = 1 draws every coordinate from its posterior N(mean, sigma^2) with a counter-based generator (NOT the
  * reference's libc rand() stream: statistical, not bitwise, parity); alpha and the prior means/precisions are
  * supplied per sweep by the caller (the hyper-prior draws of :911-1097 are scalar work that stays on the host).
- * One attribute group; no relations (block structure) -- those are out of scope. */
+ * No relations (block structure) -- out of scope. */
 typedef struct fmx_als_opts {
   double   alpha;           /* fm_learn_mcmc::alpha (1 for ALS) */
   double   w_mu, w_lambda;  /* prior of the linear weights */
@@ -205,6 +213,13 @@ typedef struct fmx_als_opts {
   uint64_t seed;
   const double *v_mu_f;     /* optional per-factor prior means v_mu(g=0,f) [num_factor]  (fm_learn_mcmc.h:76); NULL = v_mu */
   const double *v_lambda_f; /* optional per-factor prior precisions v_lambda(g=0,f);              NULL = v_lambda */
+  /* with attribute groups (fmx_set_groups, G = num_groups > 1) the priors are per group; any table may be NULL
+   * (falls back to the fields above).  Layouts are the reference's: w_*(g) DVector[G], v_*(g,f) DMatrix[G][num_factor]
+   * (fm_learn_mcmc.h:1116-1122). num_groups must be 0 (no tables) or equal the handle's group count. */
+  uint32_t      num_groups;
+  uint32_t      reserved2;
+  const double *w_mu_g, *w_lambda_g;     /* [G] */
+  const double *v_mu_gf, *v_lambda_gf;   /* [G][num_factor] */
 } fmx_als_opts;
 
 typedef struct fmx_als_stats {
@@ -219,22 +234,26 @@ int fmx_als_begin(fmx_handle h, int train_slot);
 /* statistics the hyper-prior draws need (draw_alpha :911-939, draw_w_mu/_lambda :941-1017, draw_v_mu/_lambda
  * :1019-1097), reduced on the device in fp64:
  *   out[0] = sum_c e_c^2 over the train rows (current residuals), out[1] = sum_c e_c,
- *   out[2] = sum_j w_j, out[3] = sum_j w_j^2, then for f = 0..k-1: out[4+2f] = sum_j v_fj, out[5+2f] = sum_j v_fj^2.
- * out must hold 4 + 2*num_factor doubles. */
+ *   then a [1 + num_factor][G][2] block (G = attribute groups, 1 without fmx_set_groups): row 0 = w, row 1+f = v_f;
+ *   per group g the pair {sum_{j in g} theta_j, sum_{j in g} theta_j^2}  (the per-group loops of :946-951, :987-992,
+ *   :1026-1031, :1067-1072).  With one group: out[2] = sum w, out[3] = sum w^2, out[4+2f] = sum v_f, out[5+2f] = sum v_f^2.
+ * out must hold 2 + 2*G*(1 + num_factor) doubles. */
 int fmx_als_moments(fmx_handle h, double *out);
 int fmx_als_sweep(fmx_handle h, const fmx_als_opts *opts, fmx_als_stats *stats);
 int fmx_als_end(fmx_handle h);
 
 /* ---- fm_learn_sgd_element_adapt_reg (`-method sgda`; src/libfm/src/fm_learn_sgd_element_adapt_reg.h) -------------
  * Self-adaptive regularisation: theta steps on the train rows alternate with lambda steps on the validation rows,
- * strictly online, so this learner exists in the reference-order (one wavefront) form only.  One attribute group.
+ * strictly online, so this learner exists in the reference-order (one wavefront) form only.  Regularisation is
+ * learned per attribute group (fmx_set_groups): reg_w(g), reg_v(g,f).
  *   fmx_sgda_begin : the learner's start of learn() (:256-262): w := 0, reg_w := 0, reg_v := 0, shadow gradients := 0
  *   fmx_sgda_epoch : one iteration of the epoch loop (:262-279); do_lambda_steps = 0 in the first iteration (:269)
- *   fmx_sgda_get_reg : reg[0] = reg_w, reg[1+f] = reg_v[f]  (what -rlog reports as regw[0], regv[0,f])
+ *   fmx_sgda_get_reg : [G][1 + num_factor]: reg[g*(1+k)] = reg_w(g), reg[g*(1+k)+1+f] = reg_v(g,f)
+ *                      (what -rlog reports as regw[g], regv[g,f]; :119-132)
  */
 int fmx_sgda_begin(fmx_handle h);
 int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, fmx_epoch_stats *stats);
-int fmx_sgda_get_reg(fmx_handle h, double *reg /* [1 + num_factor] */);
+int fmx_sgda_get_reg(fmx_handle h, double *reg /* [G][1 + num_factor] */);
 int fmx_sgda_end(fmx_handle h);
 
 /* ---- introspection --------------------------------------------------------------------------- */

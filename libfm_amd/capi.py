@@ -53,7 +53,9 @@ class Eval(C.Structure):
 class AlsOpts(C.Structure):
     _fields_ = [("alpha", C.c_double), ("w_mu", C.c_double), ("w_lambda", C.c_double), ("v_mu", C.c_double),
                 ("v_lambda", C.c_double), ("do_sample", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
-                ("v_mu_f", C.c_void_p), ("v_lambda_f", C.c_void_p)]
+                ("v_mu_f", C.c_void_p), ("v_lambda_f", C.c_void_p),
+                ("num_groups", C.c_uint32), ("reserved2", C.c_uint32), ("w_mu_g", C.c_void_p), ("w_lambda_g", C.c_void_p),
+                ("v_mu_gf", C.c_void_p), ("v_lambda_gf", C.c_void_p)]
 
 
 class AlsStats(C.Structure):
@@ -79,6 +81,7 @@ SYMBOLS = [
     ("fmx_init_params", C.c_int, [H, C.c_double, C.c_double, C.c_uint64]),
     ("fmx_get_param_rows", C.c_int, [H, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_get_w0", C.c_int, [H, C.POINTER(C.c_double)]),
+    ("fmx_set_groups", C.c_int, [H, C.c_void_p, C.c_uint32]),
     ("fmx_upload_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     ("fmx_synth_rows", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     ("fmx_free_rows", C.c_int, [H, C.c_int]),
@@ -144,6 +147,8 @@ class Handle:
         if rc != FMX_OK:
             raise FmxError(rc, self.lib.fmx_last_error(None).decode())
         self.n, self.k = int(num_attribute), int(num_factor)
+        self.G = 1                                   # attribute groups (set_groups)
+        self.n_local = int(self.info().n_local)
 
     def _chk(self, rc):
         if rc != FMX_OK:
@@ -194,6 +199,19 @@ class Handle:
         w0 = C.c_double(0)
         self._chk(self.lib.fmx_get_w0(self.h, C.byref(w0)))
         return w0.value
+
+    def set_groups(self, group):
+        """attribute -> group ids (`-meta`, Data.h:85-97); None = one group."""
+        if group is None:
+            self._chk(self.lib.fmx_set_groups(self.h, None, 1))
+            self.G = 1
+            return
+        group = np.ascontiguousarray(group, dtype=np.uint32)
+        if len(group) != self.n_local:
+            raise ValueError("set_groups: need one group id per local feature (%d), got %d" % (self.n_local, len(group)))
+        G = int(group.max()) + 1 if len(group) else 1
+        self._chk(self.lib.fmx_set_groups(self.h, _ptr(group), G))
+        self.G = max(G, 1)
 
     # rows ------------------------------------------------------------------------------------
     def upload_rows(self, slot, entries, row_ptr, target):
@@ -262,7 +280,8 @@ class Handle:
         return st
 
     def sgda_get_reg(self):
-        out = np.zeros(1 + self.k, dtype=np.float64)
+        """[G][1 + k]: column 0 = reg_w(g), columns 1.. = reg_v(g, f)."""
+        out = np.zeros((self.G, 1 + self.k), dtype=np.float64)
         self._chk(self.lib.fmx_sgda_get_reg(self.h, _ptr(out)))
         return out
 
@@ -274,15 +293,30 @@ class Handle:
         self._chk(self.lib.fmx_als_begin(self.h, train_slot))
 
     def als_moments(self):
-        out = np.zeros(4 + 2 * self.k, dtype=np.float64)
+        """(sum e^2, sum e, m) with m[1 + k][G][2]: row 0 = w, row 1+f = v_f; per group {sum theta, sum theta^2}."""
+        out = np.zeros(2 + 2 * self.G * (1 + self.k), dtype=np.float64)
         self._chk(self.lib.fmx_als_moments(self.h, _ptr(out)))
-        return out
+        return out[0], out[1], out[2:].reshape(1 + self.k, self.G, 2)
 
     def als_sweep(self, w_lambda, v_lambda, alpha=1.0, w_mu=0.0, v_mu=0.0, do_sample=False, seed=0):
-        """v_lambda / v_mu may be scalars or per-factor arrays (fm_learn_mcmc.h:76)."""
-        vl = np.ascontiguousarray(np.broadcast_to(np.asarray(v_lambda, dtype=np.float64), (max(self.k, 1),)))
-        vm = np.ascontiguousarray(np.broadcast_to(np.asarray(v_mu, dtype=np.float64), (max(self.k, 1),)))
-        opts = AlsOpts(alpha, w_mu, w_lambda, float(vm[0]), float(vl[0]), int(do_sample), 0, seed, _ptr(vm), _ptr(vl))
+        """w_lambda / w_mu: scalar or [G]; v_lambda / v_mu: scalar, [k] or [G][k] (the reference's w_lambda(g),
+        v_lambda(g,f); fm_learn_mcmc.h:1116-1122)."""
+        G, k = self.G, max(self.k, 1)
+
+        def tab_w(x):
+            return np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (G,)))
+
+        def tab_v(x):
+            x = np.asarray(x, dtype=np.float64)
+            if x.ndim == 1 and G > 1 and x.shape[0] == G and G != k:
+                x = x[:, None]                       # one value per group
+            return np.ascontiguousarray(np.broadcast_to(x, (G, k)))
+        wl, wm, vl, vm = tab_w(w_lambda), tab_w(w_mu), tab_v(v_lambda), tab_v(v_mu)
+        opts = AlsOpts(alpha, float(wm[0]), float(wl[0]), float(vm[0, 0]), float(vl[0, 0]), int(do_sample), 0, seed,
+                       _ptr(vm[0]) if G == 1 else None, _ptr(vl[0]) if G == 1 else None,
+                       G if G > 1 else 0, 0, _ptr(wm), _ptr(wl), _ptr(vm), _ptr(vl))
+        if G > 1 and self.k != k:                    # k == 0: tables are [G][0]
+            opts.v_mu_gf = opts.v_lambda_gf = None
         st = AlsStats()
         self._chk(self.lib.fmx_als_sweep(self.h, C.byref(opts), C.byref(st)))
         return st

@@ -9,7 +9,8 @@ auto-detection (Data.h:113-125), `-seed` reproducing the reference's initial mod
 targets rewritten to +-1 for `-task c` (:298-306), regularisation / learning-rate parsing (:326-404), the
 `#Iter=...` progress lines, `-out` (:423-428), `-save_model` / `-load_model` (:262-268, :431-434), and the
 reference's error convention: "ERROR: ..." on stderr and exit status 0 (:436-441).
-Not mirrored: `-relation`, `-meta` groups, `-cache_size` (out of scope).
+`-meta` (attribute groups, :199-242 / Data.h:85-97) is honoured by als / mcmc / sgda, incl. `-regular 'r0,w_1..w_G,v_1..v_G'`
+(:353-363).  Not mirrored: `-relation`, `-cache_size` (out of scope).
 GPU-only additions: -gpu_mode sequential|minibatch|hogwild (default minibatch), -batch, -w0_chunk, -device.
 """
 import sys
@@ -21,7 +22,7 @@ from . import data as D
 from . import learner as L
 from . import refrand as R
 
-FLAGS = {"task": "r=regression, c=binary classification [MANDATORY]", "meta": "", "train": "filename for training data [MANDATORY]",
+FLAGS = {"task": "r=regression, c=binary classification [MANDATORY]", "meta": "filename for meta information about data set", "train": "filename for training data [MANDATORY]",
          "test": "filename for test data [MANDATORY]", "validation": "", "out": "filename for output",
          "dim": "'k0,k1,k2': k0=use bias, k1=use 1-way interactions, k2=dim of 2-way interactions; default=1,1,8",
          "regular": "'r0,r1,r2' for SGD and ALS", "init_stdev": "stdev for initialization of 2-way factors; default=0.1",
@@ -98,8 +99,17 @@ def _main(argv):
     print("num_rows=%d\tnum_values=%d\tnum_features=%d\tmin_target=%g\tmax_target=%g" %
           (test.num_cases, len(test.entries), test.num_feature, test.min_target, test.max_target))
 
+    validation = None
+    if method == "sgda":                                                             # libfm.cpp:173-194
+        if "validation" not in a:
+            raise ValueError("sgda needs -validation")
+        print("Loading validation set...\t")
+        validation = L.Data(*D.load(a["validation"]))
+
     fm = L.FMModel()
-    fm.num_attribute = max(train.num_feature, test.num_feature)                      # libfm.cpp:203
+    fm.num_attribute = max(train.num_feature, test.num_feature)                      # libfm.cpp:203-206
+    if validation is not None:
+        fm.num_attribute = max(fm.num_attribute, validation.num_feature)
     fm.k0, fm.k1, fm.num_factor = dim[0] != 0, dim[1] != 0, dim[2]
     fm.init_stdev = init_stdev
     R.srand(seed)                                                                     # libfm.cpp:115-116
@@ -111,6 +121,18 @@ def _main(argv):
         if not fm.load_model(a["load_model"]):
             print("WARNING: malformed model file. Nothing will be loaded.")
             fm.w0, fm.w[:] = 0.0, 0.0
+
+    # (1.3) meta data: attribute -> group, one id per line (DataMetaInfo::loadGroupsFromFile, Data.h:85-97;
+    # DVector::load reads num_attribute values, missing ones stay 0, matrix.h:360-371)
+    groups, num_groups = None, 1
+    if a.get("meta"):
+        print("Loading meta data...\t")
+        with open(a["meta"]) as f:
+            vals = f.read().split()[:fm.num_attribute]
+        groups = np.zeros(fm.num_attribute, dtype=np.uint32)
+        groups[:len(vals)] = [int(x) for x in vals]
+        num_groups = int(groups.max()) + 1 if len(groups) else 1
+        print("#attr=%d\t#groups=%d" % (fm.num_attribute, num_groups))
 
     task = a["task"]
     if task not in ("r", "c"):
@@ -124,18 +146,20 @@ def _main(argv):
         reg = [0.0, 0.0, 0.0]
     elif len(reg) == 1:
         reg = [reg[0]] * 3
+    group_reg = None
+    if len(reg) == 1 + 2 * num_groups and len(reg) != 3 and method in ("als", "mcmc"):      # libfm.cpp:353-363
+        group_reg = (np.array(reg[1:1 + num_groups]), np.array(reg[1 + num_groups:]))
+        reg = [reg[0], 0.0, 0.0]
     elif len(reg) != 3:
-        raise ValueError("-regular needs 0, 1 or 3 values (attribute groups are not supported)")
+        raise ValueError("-regular needs 0, 1, 3 or 1+2*#groups values")
     fm.reg0, fm.regw, fm.regv = reg
     num_iter = int(a.get("iter", "100"))
 
     if method in ("sgd", "sgda"):
         l = L.FMLearnSGD() if method == "sgd" else L.FMLearnSGDA()
         if method == "sgda":
-            if "validation" not in a:
-                raise ValueError("sgda needs -validation")
-            print("Loading validation set...\t")
-            l.validation = L.Data(*D.load(a["validation"]))
+            l.validation = validation
+            l.groups = groups
             if task == "c":
                 l.validation.target[:] = np.where(l.validation.target <= 0.0, -1.0, 1.0)
         lrs = [float(x) for x in split_list(a.get("learn_rate", ""))]
@@ -153,6 +177,9 @@ def _main(argv):
             l.seed = seed
         fm.w = R.init_w_normal(fm.num_attribute, fm.init_mean, fm.init_stdev)        # libfm.cpp:283
         l.w_lambda, l.v_lambda = fm.regw, fm.regv
+        l.groups = groups
+        if group_reg is not None:
+            l.w_lambda, l.v_lambda = group_reg
     l.fm, l.num_iter, l.task = fm, num_iter, (0 if task == "r" else 1)
     l.min_target, l.max_target = min_t, max_t
     l.device = int(a.get("device", "-1"))

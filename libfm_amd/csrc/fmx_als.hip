@@ -12,6 +12,7 @@ extern "C++" void als_free(fmx_handle h) {
   if (a.q) hipFree(a.q);
   if (a.seen) hipFree(a.seen);
   if (a.level_list) hipFree(a.level_list);
+  if (a.prior) hipFree(a.prior);
   a = AlsState();
 }
 
@@ -93,22 +94,37 @@ int fmx_als_moments(fmx_handle h, double* out) {
   HIPCHK(h, hipSetDevice(h->device));
   const Slot& s = h->slots[a.slot];
   const int k = h->cfg.num_factor;
-  const size_t cnt = 4 + 2 * (size_t)k;
+  const uint32_t G = h->num_groups;
+  const size_t cells = (size_t)(1 + h->KP) * G * 2;              // device block [1 + KP][G][2]
   double* d = nullptr;
-  HIPCHK(h, hipMalloc(&d, cnt * sizeof(double)));
+  HIPCHK(h, hipMalloc(&d, (2 + cells) * sizeof(double)));
   hipStream_t st = h->stream;
-  HIPCHK(h, hipMemsetAsync(d, 0, cnt * sizeof(double), st));
-  const dim3 b1(256), ge(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), gp((uint32_t)std::min<uint64_t>((h->n_local + 255) / 256, 2048));
+  hipError_t er = hipMemsetAsync(d, 0, (2 + cells) * sizeof(double), st);
+  const dim3 b1(256), ge(std::min<uint32_t>((s.n_rows + 255) / 256, 2048));
   hipLaunchKernelGGL(k_als_sum_e, ge, b1, 0, st, a.e, s.n_rows, d);            // d[0] = sum e, d[1] = sum e^2
-  hipLaunchKernelGGL(k_param_moments, gp, b1, 0, st, h->tb.w, h->tb.ws, h->n_local, d + 2);
-  for (int f = 0; f < k; f++) hipLaunchKernelGGL(k_param_moments, gp, b1, 0, st, h->tb.V + f, h->tb.rs, h->n_local, d + 4 + 2 * f);
-  hipError_t er = hipGetLastError();
-  if (er == hipSuccess) er = hipMemcpyAsync(out, d, cnt * sizeof(double), hipMemcpyDeviceToHost, st);
+  const bool grouped = G > 1;
+  const int lds_ok = cells * sizeof(double) <= 64 * 1024;
+  const size_t lds = (grouped && lds_ok) ? cells * sizeof(double) : 0;
+  int rc = FMX_OK;
+  do {
+    KP_SWITCH(h->KP, {
+      const uint64_t waves = (h->n_local + Map<KP>::EPI - 1) / Map<KP>::EPI;
+      if (grouped) { auto kf = k_group_moments<KP, true>;
+        hipLaunchKernelGGL(kf, dim3(resident_grid(h, (const void*)kf, waves)), b1, lds, st, h->tb, h->n_local, h->cfg.k1, h->grp, G, lds_ok, d + 2);
+      } else { auto kf = k_group_moments<KP, false>;
+        hipLaunchKernelGGL(kf, dim3(resident_grid(h, (const void*)kf, waves)), b1, 0, st, h->tb, h->n_local, h->cfg.k1, h->grp, G, 0, d + 2);
+      }
+    });
+  } while (0);
+  std::vector<double> host(2 + cells);
+  if (er == hipSuccess) er = hipGetLastError();
+  if (er == hipSuccess) er = hipMemcpyAsync(host.data(), d, (2 + cells) * sizeof(double), hipMemcpyDeviceToHost, st);
   if (er == hipSuccess) er = hipStreamSynchronize(st);
   hipFree(d);
   if (er != hipSuccess) return fail(h, FMX_E_HIP, "fmx_als_moments: %s", hipGetErrorString(er));
-  std::swap(out[0], out[1]);                                                   // documented order: sum e^2 first
-  return FMX_OK;
+  out[0] = host[1]; out[1] = host[0];                                          // documented order: sum e^2 first
+  memcpy(out + 2, host.data() + 2, (size_t)(1 + k) * G * 2 * sizeof(double)); // rows 0..k of [1 + KP][G][2]
+  return rc;
 }
 
 int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) {
@@ -144,6 +160,24 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
       HIPCHK(h, hipStreamSynchronize(st));                 // nw0 lives on this stack frame
     }
   }
+  // ---- priors per coordinate family and attribute group: [1 + k][2][NG] = lambda[NG] then mu[NG]
+  const uint32_t NG = h->num_groups;
+  const int kf = h->cfg.num_factor;
+  if (opts->num_groups != 0 && opts->num_groups != NG)
+    return fail(h, FMX_E_ARG, "fmx_als_sweep: opts->num_groups = %u but the handle has %u attribute groups", opts->num_groups, NG);
+  const bool tabs = opts->num_groups != 0;
+  a.prior_host.resize((size_t)(1 + kf) * 2 * NG);
+  for (uint32_t g = 0; g < NG; g++) {
+    a.prior_host[g] = (tabs && opts->w_lambda_g) ? opts->w_lambda_g[g] : opts->w_lambda;
+    a.prior_host[NG + g] = (tabs && opts->w_mu_g) ? opts->w_mu_g[g] : opts->w_mu;
+    for (int f = 0; f < kf; f++) {
+      double* row = a.prior_host.data() + (size_t)(1 + f) * 2 * NG;
+      row[g] = (tabs && opts->v_lambda_gf) ? opts->v_lambda_gf[(size_t)g * kf + f] : (opts->v_lambda_f ? opts->v_lambda_f[f] : opts->v_lambda);
+      row[NG + g] = (tabs && opts->v_mu_gf) ? opts->v_mu_gf[(size_t)g * kf + f] : (opts->v_mu_f ? opts->v_mu_f[f] : opts->v_mu);
+    }
+  }
+  if (!a.prior) HIPCHK(h, hipMalloc(&a.prior, a.prior_host.size() * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(a.prior, a.prior_host.data(), a.prior_host.size() * sizeof(double), hipMemcpyHostToDevice, st));
   const uint32_t nseg = s.nseg, nnz = (uint32_t)s.nnz;
   const dim3 gu((uint32_t)std::min<uint64_t>((h->n_local + 255) / 256, 2048));
   // lanes per column from the mean column length (one-hot data: a handful of rows per feature)
@@ -161,25 +195,25 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
       const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
       if (!cnt) continue;
       FMX_ALS_DRAW(false, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                   h->tb.w, h->tb.ws, a.e, opts->alpha, opts->w_lambda, opts->w_mu, opts->do_sample,
+                   h->tb.w, h->tb.ws, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
                    opts->seed, (uint64_t)(a.iter * 1024 + 1000));
     }
-    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.w, h->tb.ws, opts->w_lambda, opts->w_mu,
+    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.w, h->tb.ws, a.prior, a.prior + NG, h->grp,
                        opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 1001));
   }
   for (int f = 0; f < h->cfg.num_factor; f++) {            // per factor: q_f is ready (k_als_eterms), draw_v per level :528-595
     double* qf = a.q + (size_t)f * N;
-    const double v_lambda = opts->v_lambda_f ? opts->v_lambda_f[f] : opts->v_lambda;
-    const double v_mu = opts->v_mu_f ? opts->v_mu_f[f] : opts->v_mu;
+    const double* v_lambda = a.prior + (size_t)(1 + f) * 2 * NG;
+    const double* v_mu = v_lambda + NG;
     hipLaunchKernelGGL(k_als_load_q, g1, b1, 0, st, a.e, qf, N);
     for (uint32_t l = 0; l < n_levels; l++) {
       const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
       if (!cnt) continue;
       FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                   h->tb.V + f, h->tb.rs, a.e, opts->alpha, v_lambda, v_mu, opts->do_sample,
+                   h->tb.V + f, h->tb.rs, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
                    opts->seed, (uint64_t)(a.iter * 1024 + f));
     }
-    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.V + f, h->tb.rs, v_lambda, v_mu,
+    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.V + f, h->tb.rs, v_lambda, v_mu, h->grp,
                        opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 512 + f));
   }
   HIPCHK(h, hipGetLastError());

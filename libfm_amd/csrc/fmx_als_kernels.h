@@ -175,16 +175,69 @@ static __global__ void k_als_add_const(EQ* __restrict__ eq, uint32_t n, double d
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].e += d;
 }
 
-// sum_j theta_j and sum_j theta_j^2 of one coordinate family (w: param = tb.w, stride ws; v_f: param = tb.V + f, stride rs)
-static __global__ void __launch_bounds__(256)
-k_param_moments(const float* __restrict__ param, uint32_t pstride, uint64_t n_local, double* __restrict__ out2) {
-  double s = 0.0, s2 = 0.0;
-  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_local; j += (uint64_t)gridDim.x * blockDim.x) {
-    const double t = (double)param[(size_t)j * pstride];
-    s += t; s2 += t * t;
+// per attribute group g: sum_{j in g} theta_j and sum_{j in g} theta_j^2 of EVERY coordinate family in one pass over the
+// parameter rows (the statistics of draw_w_mu/_lambda and draw_v_mu/_lambda, fm_learn_mcmc.h:941-1097).
+// out: [1 + KP][G][2] doubles (row 0 = w, row 1+f = v_f), accumulated with atomics (zero it first).
+// One row of V per LPR lanes (coalesced 4*KP bytes); a lane owns VEC consecutive factors.
+//   GROUPED = false (G == 1): register accumulators, one atomic per (wave, factor) at the end.
+//   GROUPED = true : LDS table [1+KP][G][2] per workgroup when it fits (lds_ok), else atomics straight to `out`.
+template <int KP, bool GROUPED>
+__global__ void __launch_bounds__(256)
+k_group_moments(const Tab tb, uint64_t n_local, int k1, const uint32_t* __restrict__ grp, uint32_t G, int lds_ok,
+                double* __restrict__ out) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  extern __shared__ double mom_lds[];
+  const uint32_t lane = threadIdx.x & 63u, sub = lane / LPR, fl = lane % LPR;
+  const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const size_t cells = (size_t)(1 + KP) * G * 2;
+  if (GROUPED && lds_ok) {
+    for (size_t i = threadIdx.x; i < cells; i += blockDim.x) mom_lds[i] = 0.0;
+    __syncthreads();
   }
-  s = wave_sum_f64(s); s2 = wave_sum_f64(s2);
-  if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(out2, s); unsafeAtomicAdd(out2 + 1, s2); }
+  double sv[VEC], sv2[VEC], sw = 0.0, sw2 = 0.0;
+#pragma unroll
+  for (int v = 0; v < VEC; v++) { sv[v] = 0.0; sv2[v] = 0.0; }
+  for (uint64_t j0 = wave0 * EPI; j0 < n_local; j0 += nwaves * EPI) {
+    const uint64_t j = j0 + sub;
+    if (j >= n_local) continue;
+    double t[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) t[v] = (double)tb.V[(size_t)j * tb.rs + fl * VEC + v];
+    const double tw = (k1 && fl == 0) ? (double)tb.w[(size_t)j * tb.ws] : 0.0;
+    if (!GROUPED) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) { sv[v] += t[v]; sv2[v] += t[v] * t[v]; }
+      sw += tw; sw2 += tw * tw;
+    } else {
+      const uint32_t g = grp[j];
+      double* dst = lds_ok ? mom_lds : out;
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        double* c = dst + ((size_t)(1 + fl * VEC + v) * G + g) * 2;
+        unsafeAtomicAdd(c, t[v]); unsafeAtomicAdd(c + 1, t[v] * t[v]);
+      }
+      if (k1 && fl == 0) { unsafeAtomicAdd(dst + (size_t)g * 2, tw); unsafeAtomicAdd(dst + (size_t)g * 2 + 1, tw * tw); }
+    }
+  }
+  if (!GROUPED) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {                      // the EPI rows a wavefront handles side by side
+#pragma unroll
+      for (int v = 0; v < VEC; v++) { sv[v] += __shfl_xor(sv[v], o); sv2[v] += __shfl_xor(sv2[v], o); }
+      sw += __shfl_xor(sw, o); sw2 += __shfl_xor(sw2, o);
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        unsafeAtomicAdd(out + (size_t)(1 + fl * VEC + v) * 2, sv[v]); unsafeAtomicAdd(out + (size_t)(1 + fl * VEC + v) * 2 + 1, sv2[v]);
+      }
+      if (k1 && fl == 0) { unsafeAtomicAdd(out, sw); unsafeAtomicAdd(out + 1, sw2); }
+    }
+  } else if (lds_ok) {
+    __syncthreads();
+    for (size_t i = threadIdx.x; i < cells; i += blockDim.x) { const double x = mom_lds[i]; if (x != 0.0) unsafeAtomicAdd(out + i, x); }
+  }
 }
 
 // counter-based N(0,1) for the sampling variant (MCMC): Box-Muller on two splitmix64 hashes of (seed, stream, index)
@@ -218,7 +271,8 @@ __global__ void __launch_bounds__(256)
 k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
            uint32_t nseg_total, uint32_t nnz, const uint32_t* __restrict__ seg_list, uint32_t n_list,
            float* __restrict__ param, uint32_t pstride, EQ* __restrict__ eq,
-           double alpha, double lambda, double mu, int do_sample, uint64_t seed, uint64_t stream) {
+           double alpha, const double* __restrict__ lambda_g, const double* __restrict__ mu_g, const uint32_t* __restrict__ attr_group,
+           int do_sample, uint64_t seed, uint64_t stream) {
   constexpr uint32_t GPW = 64 / G;                      // feature groups per wavefront
   const uint32_t lane = (threadIdx.x & 63u) % G;         // lane inside its group
   const uint32_t grp = (threadIdx.x & 63u) / G;
@@ -229,6 +283,8 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
     const bool have = li < n_list;                       // idle groups still take part in the shuffles
     const uint32_t s = seg_list[have ? li : n_list - 1];
     const uint32_t j = seg_feat[s];
+    const uint32_t g = attr_group ? attr_group[j] : 0u;  // meta->attr_group(j): the prior of this coordinate (:464-466, :583-585)
+    const double lambda = lambda_g[g], mu = mu_g[g];
     const uint32_t a = seg_rel[s];
     const uint32_t b = have ? ((s + 1 < nseg_total) ? seg_rel[s + 1] : nnz) : a;
     float* pt = param + (size_t)j * pstride;
@@ -295,9 +351,12 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
 // (sigma^2 = 1/lambda; lambda = 0 -> sigma^2 = inf -> theta = 0); MCMC: mu + N(0,1)/sqrt(lambda)
 static __global__ void __launch_bounds__(256)
 k_als_unseen(const uint8_t* __restrict__ seen, uint64_t n_local, float* __restrict__ param, uint32_t pstride,
-             double lambda, double mu, int do_sample, uint64_t seed, uint64_t stream) {
+             const double* __restrict__ lambda_g, const double* __restrict__ mu_g, const uint32_t* __restrict__ grp,
+             int do_sample, uint64_t seed, uint64_t stream) {
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_local; j += (uint64_t)gridDim.x * blockDim.x)
     if (!seen[j]) {
+      const uint32_t g = grp ? grp[j] : 0u;
+      const double lambda = lambda_g[g], mu = mu_g[g];
       const double sigma_sqr = 1.0 / lambda;
       double nt;
       if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;

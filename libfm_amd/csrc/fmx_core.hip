@@ -194,6 +194,7 @@ int fmx_destroy(fmx_handle h) {
   als_free(h);
   sgda_free(h);
   for (auto& s : h->slots) free_slot(s);
+  if (h->grp) hipFree(h->grp);
   if (h->tb.V) hipFree(h->tb.V);
   if (h->w_sep) hipFree(h->w_sep);
   if (h->w0) hipFree(h->w0);
@@ -348,6 +349,24 @@ int fmx_get_w0(fmx_handle h, double* w0) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
+int fmx_set_groups(fmx_handle h, const uint32_t* group_of_feature, uint32_t num_groups) {
+  if (!h) return FMX_E_ARG;
+  if (h->als.slot >= 0 || h->sgda.reg) return fail(h, FMX_E_STATE, "fmx_set_groups while an ALS / SGDA session is open");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->grp) { hipFree(h->grp); h->grp = nullptr; }
+  h->num_groups = 1;
+  if (!group_of_feature || num_groups <= 1) return FMX_OK;
+  for (uint64_t j = 0; j < h->n_local; j++)
+    if (group_of_feature[j] >= num_groups)
+      return fail(h, FMX_E_ARG, "fmx_set_groups: feature %llu has group %u >= num_groups %u", (unsigned long long)j,
+                  group_of_feature[j], num_groups);
+  HIPCHK(h, hipMalloc(&h->grp, h->n_local * sizeof(uint32_t)));
+  HIPCHK(h, hipMemcpy(h->grp, group_of_feature, h->n_local * sizeof(uint32_t), hipMemcpyHostToDevice));
+  h->num_groups = num_groups;
   return FMX_OK;
 }
 

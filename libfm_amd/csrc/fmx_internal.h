@@ -47,6 +47,8 @@ struct AlsState {
   uint32_t* level_list = nullptr; // segments ordered by level
   std::vector<uint32_t> level_ptr;
   uint64_t  iter = 0;
+  double*   prior = nullptr;      // [1 + k][2][G]: per coordinate family (row 0 = w, 1+f = v_f) lambda[G] then mu[G]
+  std::vector<double> prior_host;
 };
 
 struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping: w0 lives in w0_pp[step & 1] while active
@@ -63,6 +65,8 @@ struct fmx_context_s {
   SgdaState  sgda;
   LagState   lag;
   int        KP = 1;
+  uint32_t*  grp = nullptr;      // [n_local] attribute -> group (fmx_set_groups); nullptr = one group
+  uint32_t   num_groups = 1;
   uint64_t   n_local = 0;
   int        device = 0;
   hipStream_t stream = nullptr;

@@ -875,6 +875,176 @@ k_sgda(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, cons
 }
 
 // ----------------------------------------------------------------------------------------------
+// k_sgda_groups: the same learner with attribute groups (`-meta`): reg_w(g), reg_v(g,f) and the per-group sums of the
+// lambda step (lambda_w_grad(g), sum_f(g), sum_f_dash_f(g); :96-98, :213-247) live in LDS:
+//   regw[G] | regv[G][KP] | lwg[G] | sfg[G][KP] | sdfg[G][KP] | stamp[G]
+// Only the groups present in a validation row are zeroed / updated: for an absent group the reference's update is
+// reg -= lr * grad_loss * (-0.0), i.e. the identity for every finite grad_loss.  Each (g, factor) cell is owned by
+// one lane; lane 0 owns the linear cells and the stamps, hence the barriers around the stamp reads.
+// reg (global): [G][1 + KP], reg[g*(1+KP)] = reg_w(g), reg[g*(1+KP)+1+f] = reg_v(g,f).
+// ----------------------------------------------------------------------------------------------
+template <int KP>
+__global__ void __launch_bounds__(64)
+k_sgda_groups(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint32_t n_rows,
+              const Entry* __restrict__ vent, const uint64_t* __restrict__ vrow_ptr, const float* __restrict__ vtarget, uint32_t v_rows,
+              const Tab tb, float* gw, float* gv, Hyper h, double* w0_ptr, double* reg, int do_lambda,
+              const uint32_t* __restrict__ grp, uint32_t G) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  extern __shared__ double sgda_lds[];
+  double* regw = sgda_lds;
+  double* regv = regw + G;
+  double* lwg = regv + (size_t)G * KP;
+  double* sfg = lwg + G;
+  double* sdfg = sfg + (size_t)G * KP;
+  uint32_t* stamp = (uint32_t*)(sdfg + (size_t)G * KP);
+  const uint32_t lane = threadIdx.x;
+  const bool act = lane < LPR;
+  for (uint32_t g = lane; g < G; g += 64) { regw[g] = reg[(size_t)g * (1 + KP)]; stamp[g] = 0; }
+  for (uint32_t i = lane; i < G * KP; i += 64) regv[i] = reg[(size_t)(i / KP) * (1 + KP) + 1 + (i % KP)];
+  __syncthreads();
+  double w0 = *w0_ptr;
+  uint32_t vpos = 0, cur = 0;
+#define LD(p) ((double)__hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#define ST(p, val) __hip_atomic_store((p), (float)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+  for (uint32_t r = 0; r < n_rows; r++) {
+    // ---------------- theta step (:136-169)
+    const uint64_t a = row_ptr[r];
+    const uint32_t size = (uint32_t)(row_ptr[r + 1] - a);
+    double sum[VEC]; double sq = 0.0, lin = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) sum[v] = 0.0;
+    for (uint32_t i = 0; i < size; i++) {
+      const Entry e = ent[a + i];
+      if (h.k1 && lane == 0) lin += LD(tb.w + (size_t)e.id * tb.ws) * (double)e.value;
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const double d = LD(tb.V + (size_t)e.id * tb.rs + lane * VEC + v) * (double)e.value;
+          sum[v] += d; sq += d * d;
+        }
+      }
+    }
+    double part = lin - 0.5 * sq;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+    }
+    double p = (h.k0 ? w0 : 0.0) + wave_sum_d(part);
+    const double y = (double)target[r];
+    double mult;
+    if (h.task == 0) { p = fmin(h.max_d, p); p = fmax(h.min_d, p); mult = 2 * (p - y); }
+    else mult = y * ((1.0 / (1.0 + exp(-y * p))) - 1.0);
+    if (h.k0) w0 -= h.lr_d * (mult + 2 * 0.0 * w0);                          // reg_0 = 0 (:100)
+    for (uint32_t i = 0; i < size; i++) {
+      const Entry e = ent[a + i];
+      const uint32_t g = grp[e.id];
+      const double x = (double)e.value;
+      if (h.k1 && lane == 0) {
+        float* pw = tb.w + (size_t)e.id * tb.ws;
+        const double wv = LD(pw);
+        const double gr = mult * x;
+        ST(gw + e.id, gr);
+        ST(pw, wv - h.lr_d * ((double)(float)gr + 2 * regw[g] * wv));
+      }
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          float* pv = tb.V + (size_t)e.id * tb.rs + lane * VEC + v;
+          const double vv = LD(pv);
+          const double gr = mult * (x * (sum[v] - vv * x));
+          ST(gv + (size_t)e.id * tb.rs + lane * VEC + v, gr);
+          ST(pv, vv - h.lr_d * ((double)(float)gr + 2 * regv[(size_t)g * KP + lane * VEC + v] * vv));
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (!do_lambda || v_rows == 0) continue;
+    // ---------------- lambda step on the next validation row (:271-276, :201-248)
+    if (vpos >= v_rows) vpos = 0;
+    const uint64_t va = vrow_ptr[vpos];
+    const uint32_t vsize = (uint32_t)(vrow_ptr[vpos + 1] - va);
+    const double vy = (double)vtarget[vpos];
+    vpos++;
+    cur += 2;                                                                    // stamp == cur: sums valid; cur+1: updated
+    double plin = 0.0, q_dash = 0.0;
+    double s_dash[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) s_dash[v] = 0.0;
+    for (uint32_t i = 0; i < vsize; i++) {
+      const Entry e = vent[va + i];
+      const uint32_t g = grp[e.id];
+      const double x = (double)e.value;
+      const bool fresh = stamp[g] != cur;
+      __syncthreads();
+      if (fresh) {
+        if (lane == 0) { lwg[g] = 0.0; stamp[g] = cur; }
+        if (act) {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) { sfg[(size_t)g * KP + lane * VEC + v] = 0.0; sdfg[(size_t)g * KP + lane * VEC + v] = 0.0; }
+        }
+      }
+      __syncthreads();
+      if (h.k1 && lane == 0) {
+        const double wv = LD(tb.w + (size_t)e.id * tb.ws);
+        const double w_dash = wv - h.lr_d * (LD(gw + e.id) + 2 * regw[g] * wv);   // predict_scaled :178-184
+        plin += w_dash * x;
+        lwg[g] += x * wv;                                                          // :215-218
+      }
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const size_t c = (size_t)g * KP + lane * VEC + v;
+          const double vv = LD(tb.V + (size_t)e.id * tb.rs + lane * VEC + v);
+          const double v_dash = vv - h.lr_d * (LD(gv + (size_t)e.id * tb.rs + lane * VEC + v) + 2 * regv[c] * vv);
+          const double d = v_dash * x;
+          s_dash[v] += d; q_dash += d * d;                                       // :186-196
+          sfg[c] += vv * x;                                                      // :233-238
+          sdfg[c] += d * vv * x;
+        }
+      }
+    }
+    double vpart = plin - 0.5 * q_dash;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) vpart += 0.5 * s_dash[v] * s_dash[v];
+    }
+    double vp = (h.k0 ? w0 : 0.0) + wave_sum_d(vpart);
+    double grad_loss;
+    if (h.task == 0) { vp = fmin(h.max_d, vp); vp = fmax(h.min_d, vp); grad_loss = 2 * (vp - vy); }
+    else grad_loss = vy * ((1.0 / (1.0 + exp(-vy * vp))) - 1.0);
+    for (uint32_t i = 0; i < vsize; i++) {                                       // every group of the row, once
+      const uint32_t g = grp[vent[va + i].id];
+      const bool todo = stamp[g] == cur;
+      __syncthreads();
+      if (todo) {
+        if (lane == 0) {
+          stamp[g] = cur + 1;
+          if (h.k1) {                                                            // :213-224
+            const double lwt = -2 * h.lr_d * lwg[g];
+            regw[g] = fmax(0.0, regw[g] - h.lr_d * grad_loss * lwt);
+          }
+        }
+        if (act) {                                                               // :240-246
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const size_t c = (size_t)g * KP + lane * VEC + v;
+            const double lambda_v_grad = -2 * h.lr_d * (s_dash[v] * sfg[c] - sdfg[c]);
+            regv[c] = fmax(0.0, regv[c] - h.lr_d * grad_loss * lambda_v_grad);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+#undef LD
+#undef ST
+  __syncthreads();
+  if (lane == 0) *w0_ptr = w0;
+  for (uint32_t g = lane; g < G; g += 64) reg[(size_t)g * (1 + KP)] = regw[g];
+  for (uint32_t i = lane; i < G * KP; i += 64) reg[(size_t)(i / KP) * (1 + KP) + 1 + (i % KP)] = regv[i];
+}
+
+// ----------------------------------------------------------------------------------------------
 // evaluation: y-hat = w0 + rest, then the reductions of fm_learn.h:113-153
 // acc[0] = sum err^2 (clamped), acc[1] = sum |err|, acc[2] = #correct sign
 // ----------------------------------------------------------------------------------------------

@@ -440,7 +440,7 @@ int fmx_sgda_begin(fmx_handle h) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   sgda_free(h);
-  const size_t nv = h->n_local * (size_t)h->tb.rs, nreg = 1 + (size_t)h->KP;
+  const size_t nv = h->n_local * (size_t)h->tb.rs, nreg = (size_t)h->num_groups * (1 + (size_t)h->KP);   // [G][1 + KP]
   HIPCHK(h, hipMalloc(&h->sgda.gw, h->n_local * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->sgda.gv, nv * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->sgda.reg, nreg * sizeof(double)));
@@ -458,8 +458,11 @@ int fmx_sgda_get_reg(fmx_handle h, double* reg) {
   if (!h || !reg) return FMX_E_ARG;
   if (!h->sgda.reg) return fail(h, FMX_E_STATE, "fmx_sgda_get_reg before fmx_sgda_begin");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(reg, h->sgda.reg, (1 + (size_t)h->cfg.num_factor) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  const size_t G = h->num_groups, k = (size_t)h->cfg.num_factor, KP = (size_t)h->KP;
+  std::vector<double> dev(G * (1 + KP));
+  HIPCHK(h, hipMemcpyAsync(dev.data(), h->sgda.reg, dev.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (size_t g = 0; g < G; g++) memcpy(reg + g * (1 + k), dev.data() + g * (1 + KP), (1 + k) * sizeof(double));
   return FMX_OK;
 }
 
@@ -476,9 +479,20 @@ int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lam
   const Hyper hy = make_hyper(h->cfg);
   if (stats) memset(stats, 0, sizeof(*stats));
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows,
-                                        v.ent, v.row_ptr, v.target, v.n_rows, h->tb, h->sgda.gw, h->sgda.gv, hy, h->w0,
-                                        h->sgda.reg, do_lambda_steps));
+  if (h->num_groups <= 1) {
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows,
+                                          v.ent, v.row_ptr, v.target, v.n_rows, h->tb, h->sgda.gw, h->sgda.gv, hy, h->w0,
+                                          h->sgda.reg, do_lambda_steps));
+  } else {
+    // LDS tables of k_sgda_groups: regw[G] regv[G][KP] lwg[G] sfg[G][KP] sdfg[G][KP] (doubles) + stamp[G] (u32)
+    const size_t G = h->num_groups, lds = (2 * G + 3 * G * (size_t)h->KP) * sizeof(double) + G * sizeof(uint32_t);
+    const size_t lds_max = h->prop.sharedMemPerBlock ? h->prop.sharedMemPerBlock : 64 * 1024;
+    if (lds > lds_max)
+      return fail(h, FMX_E_UNSUPPORTED, "SGDA: %zu attribute groups x %d factors need %zu bytes of LDS (limit %zu)", G, h->KP, lds, lds_max);
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda_groups<KP>), dim3(1), dim3(64), lds, h->stream, s.ent, s.row_ptr, s.target, s.n_rows,
+                                          v.ent, v.row_ptr, v.target, v.n_rows, h->tb, h->sgda.gw, h->sgda.gv, hy, h->w0,
+                                          h->sgda.reg, do_lambda_steps, h->grp, (uint32_t)G));
+  }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -205,8 +205,9 @@ def cdf_gaussian(x):
 class FMLearnALS:
     """fm_learn_mcmc_simultaneous with do_sample = 0, do_multilevel = 0 -- what `-method als` runs
     (libfm.cpp:135-139, 283-290) -- on the GPU.  Fields follow fm_learn_mcmc (fm_learn_mcmc.h:60-88):
-    fm, min_target, max_target, task, num_iter; w_lambda / v_lambda are set from -regular like libfm.cpp:326-365
-    (one attribute group)."""
+    fm, min_target, max_target, task, num_iter; w_lambda / v_lambda are set from -regular like libfm.cpp:326-365.
+    `groups` (attribute -> group id, the `-meta` file; fm_learn.h:40, Data.h:39-46) makes them per group:
+    w_lambda [G], v_lambda [G] or [G][k] (libfm.cpp:353-363)."""
 
     def __init__(self):
         self.fm = None
@@ -218,6 +219,7 @@ class FMLearnALS:
         self.do_sample = False
         self.seed = 0
         self.device = -1
+        self.groups = None             # DataMetaInfo::attr_group (None = one group)
         self.out = sys.stdout
         self.pred_this = None          # fm_learn_mcmc.h:116
         self.pred_sum_all = None       # fm_learn_mcmc.h:114
@@ -229,6 +231,15 @@ class FMLearnALS:
         self._h = capi.Handle(fm.num_attribute, fm.num_factor, fm.k0, fm.k1, self.task, fm.reg0, fm.regw, fm.regv,
                               0.0, self.min_target, self.max_target, device=self.device)
         self._h.set_params(fm.w0, fm.w, fm.v)
+        self._h.set_groups(self.groups)
+
+    def _v_table(self, x):
+        """v_lambda-like value -> [G][k] (scalar, one value per group, or the full table)."""
+        G, k = self._h.G, max(self.fm.num_factor, 1)
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1 and x.shape[0] == G:
+            x = x[:, None]
+        return np.ascontiguousarray(np.broadcast_to(x, (G, k)))
 
     # fm_learn_mcmc::learn + _learn (fm_learn_mcmc.h:1160-1201, fm_learn_mcmc_simultaneous.h:56-270)
     def learn(self, train, test):
@@ -238,7 +249,7 @@ class FMLearnALS:
         self.pred_sum_all = np.zeros(test.num_cases)
         h.als_begin(0)
         for i in range(self.num_iter):
-            st = h.als_sweep(self.w_lambda, self.v_lambda, 1.0, 0.0, 0.0, self.do_sample, self.seed)
+            st = h.als_sweep(self.w_lambda, self._v_table(self.v_lambda), 1.0, 0.0, 0.0, self.do_sample, self.seed)
             p = h.predict(1, test.num_cases)
             if self.task == TASK_REGRESSION:                  # :127-138
                 self.pred_this = p
@@ -286,32 +297,35 @@ class FMLearnMCMC(FMLearnALS):
     def learn(self, train, test):
         h = self._h
         rng = np.random.default_rng(self.seed)
-        k, n = self.fm.num_factor, self.fm.num_attribute
+        k, n, G = self.fm.num_factor, self.fm.num_attribute, h.G
         h.upload_rows(0, train.entries, train.row_ptr, train.target)
         h.upload_rows(1, test.entries, test.row_ptr, test.target)
         self.pred_sum_all = np.zeros(test.num_cases)
         N = train.num_cases
-        alpha, w_mu, w_lambda = 1.0, 0.0, float(self.w_lambda)
-        v_mu, v_lambda = np.zeros(max(k, 1)), np.full(max(k, 1), float(self.v_lambda))
+        # meta->num_attr_per_group (Data.h:93-95)
+        n_g = np.array([float(n)]) if self.groups is None else np.bincount(np.asarray(self.groups), minlength=G).astype(np.float64)
+        alpha = 1.0
+        w_mu, w_lambda = np.zeros(G), np.broadcast_to(np.asarray(self.w_lambda, dtype=np.float64), (G,)).copy()
+        v_mu, v_lambda = np.zeros((G, max(k, 1))), self._v_table(self.v_lambda).copy()
         a0, g0, b0, m0 = self.alpha_0, self.gamma_0, self.beta_0, self.mu_0
         h.als_begin(0)
         for i in range(self.num_iter):
             if self.do_multilevel:
-                mom = h.als_moments()
-                alpha = rng.gamma((a0 + N) / 2.0) / ((g0 + mom[0]) / 2.0)                      # draw_alpha :911-922
+                sum_e2, _, mom = h.als_moments()               # mom[1 + k][G][{sum, sum of squares}]
+                alpha = rng.gamma((a0 + N) / 2.0) / ((g0 + sum_e2) / 2.0)                        # draw_alpha :911-922
                 if self.fm.k1:
-                    sw, sw2 = mom[2], mom[3]
-                    gam = b0 * (w_mu - m0) ** 2 + g0 + (sw2 - 2 * w_mu * sw + n * w_mu * w_mu)   # draw_w_lambda :990-997
-                    w_lambda = rng.gamma((a0 + n + 1) / 2.0) / (gam / 2.0)
-                    mean = (sw + b0 * m0) / (n + b0)                                            # draw_w_mu :946-959
-                    w_mu = mean + rng.standard_normal() * np.sqrt(1.0 / ((n + b0) * w_lambda))
-                for f in range(k):
-                    sv, sv2 = mom[4 + 2 * f], mom[5 + 2 * f]
-                    gam = b0 * (v_mu[f] - m0) ** 2 + g0 + (sv2 - 2 * v_mu[f] * sv + n * v_mu[f] ** 2)   # :1066-1075
-                    v_lambda[f] = rng.gamma((a0 + n + 1) / 2.0) / (gam / 2.0)
-                for f in range(k):
-                    mean = (sv_f(mom, f) + b0 * m0) / (n + b0)                                   # :1024-1037
-                    v_mu[f] = mean + rng.standard_normal() * np.sqrt(1.0 / ((n + b0) * v_lambda[f]))
+                    sw, sw2 = mom[0, :, 0], mom[0, :, 1]
+                    gam = b0 * (w_mu - m0) ** 2 + g0 + (sw2 - 2 * w_mu * sw + n_g * w_mu * w_mu)   # draw_w_lambda :985-997
+                    w_lambda = _keep_finite(rng.gamma((a0 + n_g + 1) / 2.0) / (gam / 2.0), w_lambda)
+                    mean = (sw + b0 * m0) / (n_g + b0)                                            # draw_w_mu :946-959
+                    w_mu = _keep_finite(mean + rng.standard_normal(G) * np.sqrt(1.0 / ((n_g + b0) * w_lambda)), w_mu)
+                if k > 0:
+                    sv, sv2 = mom[1:, :, 0].T, mom[1:, :, 1].T                                    # [G][k]
+                    ng = n_g[:, None]
+                    gam = b0 * (v_mu - m0) ** 2 + g0 + (sv2 - 2 * v_mu * sv + ng * v_mu ** 2)     # draw_v_lambda :1061-1075
+                    v_lambda = _keep_finite(rng.gamma(np.broadcast_to((a0 + ng + 1) / 2.0, gam.shape)) / (gam / 2.0), v_lambda)
+                    mean = (sv + b0 * m0) / (ng + b0)                                             # draw_v_mu :1019-1037
+                    v_mu = _keep_finite(mean + rng.standard_normal(mean.shape) * np.sqrt(1.0 / ((ng + b0) * v_lambda)), v_mu)
             st = h.als_sweep(w_lambda, v_lambda, alpha, w_mu, v_mu, self.do_sample, self.seed * 7919 + 13)
             p = h.predict(1, test.num_cases)
             if self.task == TASK_REGRESSION:
@@ -323,14 +337,20 @@ class FMLearnMCMC(FMLearnALS):
                 self.pred_sum_all += self.pred_this
                 metric = float(np.mean(((self.pred_sum_all / (i + 1)) >= 0.5) == (test.target >= 0)))
             print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, st.train_metric, metric), file=self.out)
-            self.log.append({"train": st.train_metric, "test": metric, "alpha": alpha, "w_lambda": w_lambda,
-                             "time_learn": st.device_seconds})
+            row = {"train": st.train_metric, "test": metric, "alpha": alpha, "time_learn": st.device_seconds}
+            for g in range(G):                                                                    # rlog fields :1145-1157
+                row["wmu[%d]" % g], row["wlambda[%d]" % g] = float(w_mu[g]), float(w_lambda[g])
+            row["w_lambda"] = float(w_lambda[0])
+            self.log.append(row)
+        self.w_mu, self.w_lambda_last, self.v_mu, self.v_lambda_last = w_mu, w_lambda, v_mu, v_lambda
         h.als_end()
         self.fm.w0, self.fm.w, self.fm.v = h.get_params(self.fm.w, self.fm.v)
 
 
-def sv_f(mom, f):
-    return mom[4 + 2 * f]
+def _keep_finite(new, old):
+    """the reference keeps the old value of a hyper-parameter whose draw is NaN / Inf (fm_learn_mcmc.h:961-975 etc.)"""
+    new = np.asarray(new, dtype=np.float64)
+    return np.where(np.isfinite(new), new, old)
 
 
 class FMLearnSGDA(FMLearnSGD):
@@ -340,7 +360,8 @@ class FMLearnSGDA(FMLearnSGD):
     def __init__(self):
         super().__init__()
         self.validation = None
-        self.reg_w = 0.0
+        self.groups = None               # DataMetaInfo::attr_group (None = one group)
+        self.reg_w = 0.0                 # one group: scalar / [k]; with groups: [G] / [G][k]  (:84-85)
         self.reg_v = None
 
     def learn(self, train, test):
@@ -350,6 +371,7 @@ class FMLearnSGDA(FMLearnSGD):
         h = self._h
         st, sv = self._slot(train), self._slot(self.validation)
         self.fm.reg0 = self.fm.regw = self.fm.regv = 0.0                  # :257-259
+        h.set_groups(self.groups)
         h.sgda_begin()
         for i in range(self.num_iter):
             stats = h.sgda_epoch(st, sv, i > 0)
@@ -357,9 +379,16 @@ class FMLearnSGDA(FMLearnSGD):
             rmse_train = self.evaluate(train)
             rmse_test = self.evaluate(test)
             print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, rmse_train, rmse_test), file=self.out)
-            reg = h.sgda_get_reg()
-            self.reg_w, self.reg_v = float(reg[0]), reg[1:].copy()
-            self.log.append({"rmse_train": rmse_train, "rmse_val": rmse_val, "time_learn": stats.device_seconds,
-                             "regw[0]": self.reg_w})
+            reg = h.sgda_get_reg()                                           # [G][1 + k]
+            if h.G == 1:
+                self.reg_w, self.reg_v = float(reg[0, 0]), reg[0, 1:].copy()
+            else:
+                self.reg_w, self.reg_v = reg[:, 0].copy(), reg[:, 1:].copy()
+            row = {"rmse_train": rmse_train, "rmse_val": rmse_val, "time_learn": stats.device_seconds}
+            for g in range(h.G):                                             # rlog fields :119-132
+                row["regw[%d]" % g] = float(reg[g, 0])
+                for f in range(self.fm.num_factor):
+                    row["regv[%d,%d]" % (g, f)] = float(reg[g, 1 + f])
+            self.log.append(row)
         h.sgda_end()
         self.sync_model()

@@ -42,7 +42,7 @@ def test_exported_symbols_are_c_abi():
 
 
 def test_abi_version(lib):
-    assert lib.fmx_abi_version() == 1
+    assert lib.fmx_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu(lib):

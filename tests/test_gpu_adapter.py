@@ -52,7 +52,7 @@ def test_reference_driver_with_gpu_learner(oracle, name):
         assert np.abs(ev[-1] - z["eval"][-1]).max() <= 2.0 / 100
 
 
-@pytest.mark.parametrize("name", ["als_reg_ml", "als_cls_ragged", "als_reg_fields_k16"])
+@pytest.mark.parametrize("name", ["als_reg_ml", "als_cls_ragged", "als_reg_fields_k16", "als_reg_ml_groups", "als_cls_fields_groups"])
 def test_reference_driver_with_gpu_als_learner(oracle, name):
     """adapter/fm_learn_mcmc_gpu.h: the reference's loader (X^T only for als, libfm.cpp:143-147), RNG and output code
     with the GPU ALS learner must land on the stock learner's results (golden fixture)."""
@@ -67,7 +67,13 @@ def test_reference_driver_with_gpu_als_learner(oracle, name):
         O.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(tef)
         cfg = ["als_gpu", trf, tef, str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]),
                repr(g.reg[0]), repr(g.reg[1]), repr(g.reg[2]), repr(float(z["init_stdev"])), int(z["seed"]), pre]
-        r = subprocess.run([HARNESS] + [str(c) for c in cfg], capture_output=True, text=True)
+        env = dict(os.environ)
+        if "group" in z.files:            # -meta + per-group lambdas: the adapter reads the reference's own meta / w_lambda / v_lambda
+            with open(os.path.join(td, "meta"), "w") as f:
+                f.write("".join("%d\n" % x for x in z["group"]))
+            env["FMX_META"] = os.path.join(td, "meta")
+            env["FMX_GROUP_REG"] = ",".join(repr(float(x)) for x in list(z["w_lambda_g"]) + list(z["v_lambda_g"]))
+        r = subprocess.run([HARNESS] + [str(c) for c in cfg], capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "#Iter=" in r.stdout
         init = O.Model.from_dump(pre + ".init.bin")

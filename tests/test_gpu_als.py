@@ -25,6 +25,8 @@ def make_learner(g, oracle):
     l.fm, l.task, l.num_iter = fm, g.task, g.iters
     l.min_target, l.max_target = g.min_target, g.max_target
     l.w_lambda, l.v_lambda = g.reg[1], g.reg[2]
+    if "group" in g.z.files:                                   # `-meta` + per-group lambdas (libfm.cpp:353-363)
+        l.groups, l.w_lambda, l.v_lambda = g.z["group"], g.z["w_lambda_g"], g.z["v_lambda_g"]
     l.out = io.StringIO()
     return L, l
 

@@ -44,3 +44,30 @@ def test_cli_error_convention(capsys):
     assert "ERROR:" in capsys.readouterr().err            # "ERROR: ..." on stderr, exit status 0 (libfm.cpp:436-441)
     assert cli.main(["-task", "r", "-bogus", "1"]) == 0
     assert "does not exist" in capsys.readouterr().err
+
+
+def test_cli_als_with_meta_groups(tmp_path, oracle):
+    """`-method als -meta <file> -regular 'r0,w_1,w_2,v_1,v_2'` (libfm.cpp:199-242, 353-363): same seed, same data as the
+    reference run behind tests/golden/als_reg_ml_groups.npz -> the same -out file and model."""
+    from libfm_amd import cli
+    z = np.load(os.path.join(GOLDEN_DIR, "als_reg_ml_groups.npz"))
+    trf, tef, meta = str(tmp_path / "tr.libfm"), str(tmp_path / "te.libfm"), str(tmp_path / "meta")
+    oracle.Data(z["train_entries"], z["train_row_ptr"], z["train_target"]).write_libsvm(trf)
+    oracle.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(tef)
+    with open(meta, "w") as f:
+        f.write("".join("%d\n" % g for g in z["group"]))
+    reg = [float(z["reg"][0])] + [float(x) for x in z["w_lambda_g"]] + [float(x) for x in z["v_lambda_g"]]
+    out, model = str(tmp_path / "pred"), str(tmp_path / "model")
+    argv = ["-task", "r", "-train", trf, "-test", tef, "-dim", "%d,%d,%d" % (int(z["k0"]), int(z["k1"]), int(z["k"])),
+            "-iter", str(int(z["iters"])), "-method", "als", "-meta", meta, "-regular", ",".join(repr(x) for x in reg),
+            "-init_stdev", repr(float(z["init_stdev"])), "-seed", str(int(z["seed"])), "-out", out, "-save_model", model]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert cli.main(argv) == 0
+    assert "#groups=2" in buf.getvalue()
+    np.testing.assert_allclose(np.loadtxt(out), z["pred_out"], rtol=1e-4, atol=5e-5)
+    txt = open(model).read().splitlines()
+    n = int(z["n"])
+    np.testing.assert_allclose(float(txt[1]), float(z["final_w0"]), rtol=1e-4, atol=1e-5)
+    w = np.array([float(x) for x in txt[3:3 + n]])
+    np.testing.assert_allclose(w, z["final_w"], rtol=1e-4, atol=2e-5)

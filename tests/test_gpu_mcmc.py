@@ -26,6 +26,8 @@ def run_chain(g, oracle, seed):
     l.fm, l.task, l.num_iter, l.seed = fm, g.task, g.iters, seed
     l.min_target, l.max_target = g.min_target, g.max_target
     l.w_lambda = l.v_lambda = 0.0                              # libfm.cpp:329-335: no -regular -> lambdas start at 0
+    if "group" in z.files:
+        l.groups = z["group"]                                  # `-meta`: hyper-priors per attribute group
     l.out = io.StringIO()
     train = L.Data(z["train_entries"], z["train_row_ptr"], g.train_target)
     test = L.Data(z["test_entries"], z["test_row_ptr"], g.test_target)
@@ -68,3 +70,50 @@ def test_mcmc_two_seeds_differ_but_agree(oracle):
     p2, _ = run_chain(g, oracle, seed=2)
     assert not np.array_equal(p1, p2)
     assert np.corrcoef(p1, p2)[0, 1] > 0.97
+
+
+def test_mcmc_attribute_groups_posterior_mean(oracle):
+    """two attribute groups (users / items): lambda and mu are drawn per group (fm_learn_mcmc.h:941-1097)"""
+    g = Golden("mcmc_reg_ml_groups")
+    ref = g.z["pred_out"]
+    y = g.test_target.astype(np.float64)
+    p, l = run_chain(g, oracle, seed=3)
+    rmse_ref = np.sqrt(np.mean((ref - y) ** 2))
+    rmse = np.sqrt(np.mean((p - y) ** 2))
+    assert abs(rmse - rmse_ref) < 0.03 * rmse_ref, (rmse, rmse_ref)
+    assert np.corrcoef(p, ref)[0, 1] > 0.975
+    assert np.sqrt(np.mean((p - ref) ** 2)) < 0.14
+    assert l.w_lambda_last.shape == (2,) and l.v_lambda_last.shape == (2, g.k)
+    assert abs(l.w_lambda_last[0] - l.w_lambda_last[1]) > 1e-6 * abs(l.w_lambda_last[0])      # the groups got their own draws
+
+
+@pytest.mark.parametrize("n,k,G", [(5000, 64, 3), (3000, 8, 5), (2000, 64, 300), (1000, 128, 2), (4000, 3, 1)])
+def test_group_moments(n, k, G):
+    """fmx_als_moments: per-group sums of every coordinate family in one pass (LDS table, or global atomics when the
+    table does not fit: G = 300 at k = 64) against numpy."""
+    from libfm_amd import capi
+    rng = np.random.default_rng(n + k + G)
+    w, v = rng.normal(0, 0.3, n), rng.normal(0.1, 0.2, (k, n))
+    grp = rng.integers(0, G, n).astype(np.uint32)
+    grp[:G] = np.arange(G)
+    h = capi.Handle(n, k, True, True, 0)
+    h.set_params(0.25, w, v)
+    if G > 1:
+        h.set_groups(grp)
+    ent = np.zeros(4, dtype=capi.ENTRY_DTYPE)
+    ent["id"], ent["value"] = [0, 1, 2, 3], 1.0
+    h.upload_rows(0, ent, np.array([0, 2, 4], dtype=np.uint64), np.array([1.0, -1.0], dtype=np.float32))
+    h.als_begin(0)
+    se2, se, mom = h.als_moments()
+    h.als_end()
+    assert mom.shape == (1 + k, G, 2)
+    w32, v32 = w.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64)
+    for g in range(G):
+        sel = grp == g if G > 1 else slice(None)
+        np.testing.assert_allclose(mom[0, g], [w32[sel].sum(), (w32[sel] ** 2).sum()], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(mom[1:, g, 0], v32[:, sel].sum(axis=1), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(mom[1:, g, 1], (v32[:, sel] ** 2).sum(axis=1), rtol=1e-9, atol=1e-9)
+    yhat = h.predict(0, 2)
+    e = yhat - np.array([1.0, -1.0])
+    np.testing.assert_allclose([se2, se], [(e ** 2).sum(), e.sum()], rtol=1e-5)
+    h.close()

@@ -28,6 +28,9 @@ def test_sgda_matches_reference(oracle, name):
     l.fm, l.task, l.num_iter, l.learn_rate = fm, g.task, g.iters, g.lr
     l.min_target, l.max_target = g.min_target, g.max_target
     l.validation = L.Data(z["val_entries"], z["val_row_ptr"], vt)
+    grouped = "group" in z.files                                # `-meta` attribute groups: reg_w(g), reg_v(g,f)
+    if grouped:
+        l.groups = z["group"]
     l.out = io.StringIO()
     train = L.Data(z["train_entries"], z["train_row_ptr"], g.train_target)
     test = L.Data(z["test_entries"], z["test_row_ptr"], g.test_target)
@@ -36,7 +39,14 @@ def test_sgda_matches_reference(oracle, name):
     np.testing.assert_allclose(fm.v, z["final_v"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(fm.w, z["final_w"], rtol=1e-4, atol=2e-5)
     assert abs(fm.w0 - float(z["final_w0"])) <= 1e-4 * abs(float(z["final_w0"])) + 2e-5
-    np.testing.assert_allclose(l.reg_w, z["regs"][0], rtol=1e-3, atol=1e-7)
-    np.testing.assert_allclose(l.reg_v, z["regs"][1:], rtol=1e-3, atol=1e-7)
+    if grouped:
+        regs = z["regs"].reshape(-1, 1 + g.k)                   # [G][1 + k]
+        assert regs.shape[0] == int(z["group"].max()) + 1 > 1
+        np.testing.assert_allclose(l.reg_w, regs[:, 0], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(l.reg_v, regs[:, 1:], rtol=1e-3, atol=1e-7)
+        assert {"regw[1]", "regv[1,0]"} <= set(l.log[-1])
+    else:
+        np.testing.assert_allclose(l.reg_w, z["regs"][0], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(l.reg_v, z["regs"][1:], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(l.predict(test), z["pred_out"], rtol=1e-4, atol=5e-5)
     l.close()
