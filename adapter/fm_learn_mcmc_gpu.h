@@ -5,8 +5,9 @@
 // It derives from fm_learn_mcmc so that main()'s casts and field writes keep working unchanged
 // (libfm.cpp:284-290: num_iter, num_eval_cases, do_sample, do_multilevel; :335-352: w_lambda / v_lambda from
 // -regular) and replaces the iteration loop of fm_learn_mcmc_simultaneous::_learn (fm_learn_mcmc_simultaneous.h:
-// 56-270) by fmx_als_begin / fmx_als_sweep.  Only do_sample = 0, do_multilevel = 0, no relations.  Attribute groups
-// (`-meta`) are passed through: meta->attr_group -> fmx_set_groups, w_lambda(g) / v_lambda(g,f) -> the opts tables.
+// 56-270) by fmx_als_begin / fmx_als_sweep.  Only do_sample = 0, do_multilevel = 0.  Attribute groups (`-meta`) are
+// passed through: meta->attr_group -> fmx_set_groups, w_lambda(g) / v_lambda(g,f) -> the opts tables.  Relations
+// (`-relation`, Data::relation) go to fmx_upload_block_rows, which joins the blocks on the device.
 #ifndef FM_LEARN_MCMC_GPU_H_
 #define FM_LEARN_MCMC_GPU_H_
 
@@ -23,7 +24,6 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
 
   virtual void learn(Data& train, Data& test) {            // fm_learn_mcmc::learn (:1160-1201) + _learn
     if (do_sample || do_multilevel) throw "fm_learn_als_gpu: only -method als (no sampling) is bound";
-    if (train.relation.dim > 0) throw "relations are not supported";
     pred_sum_all.setSize(test.num_cases); pred_sum_all_but5.setSize(test.num_cases); pred_this.setSize(test.num_cases);
     pred_sum_all.init(0.0); pred_sum_all_but5.init(0.0); pred_this.init(0.0);
     fmx_config c;
@@ -76,23 +76,40 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
  protected:
   fmx_handle h;
   void check(int rc) { if (rc != FMX_OK) throw std::string(fmx_last_error(h)); }
-  void upload(int slot, Data& d) {
-    // ALS data sets are loaded transposed-only by main (has_x = false, libfm.cpp:143-147): rebuild the rows from X^T
-    std::vector<uint64> row_ptr(d.num_cases + 1, 0);
-    LargeSparseMatrix<DATA_FLOAT>* xt = d.data_t;
+  // ALS data sets are loaded transposed-only by main (has_x = false, libfm.cpp:143-147): rebuild rows from X^T
+  struct Rows { std::vector<uint64> row_ptr; std::vector< sparse_entry<DATA_FLOAT> > ent; };
+  static void rows_from_xt(LargeSparseMatrix<DATA_FLOAT>* xt, uint num_cases, Rows& out) {
+    out.row_ptr.assign((size_t)num_cases + 1, 0);
     for (xt->begin(); !xt->end(); xt->next()) {
       sparse_row<DATA_FLOAT>& col = xt->getRow();
-      for (uint i = 0; i < col.size; i++) row_ptr[col.data[i].id + 1]++;
+      for (uint i = 0; i < col.size; i++) out.row_ptr[col.data[i].id + 1]++;
     }
-    for (uint r = 0; r < d.num_cases; r++) row_ptr[r + 1] += row_ptr[r];
-    std::vector< sparse_entry<DATA_FLOAT> > ent(row_ptr[d.num_cases]);
-    std::vector<uint64> fill(row_ptr.begin(), row_ptr.end() - 1);
+    for (uint r = 0; r < num_cases; r++) out.row_ptr[r + 1] += out.row_ptr[r];
+    out.ent.resize(out.row_ptr[num_cases]);
+    std::vector<uint64> fill(out.row_ptr.begin(), out.row_ptr.end() - 1);
     for (xt->begin(); !xt->end(); xt->next()) {
       sparse_row<DATA_FLOAT>& col = xt->getRow();
       uint j = xt->getRowIndex();
-      for (uint i = 0; i < col.size; i++) { sparse_entry<DATA_FLOAT> e; e.id = j; e.value = col.data[i].value; ent[fill[col.data[i].id]++] = e; }
+      for (uint i = 0; i < col.size; i++) { sparse_entry<DATA_FLOAT> e; e.id = j; e.value = col.data[i].value; out.ent[fill[col.data[i].id]++] = e; }
     }
-    check(fmx_upload_rows(h, slot, ent.empty() ? NULL : &ent[0], (const uint64_t*)&row_ptr[0], d.target.value, d.num_cases, ent.size()));
+  }
+  void upload(int slot, Data& d) {
+    Rows main;
+    rows_from_xt(d.data_t, d.num_cases, main);
+    std::vector<Rows> blocks(d.relation.dim);
+    std::vector<fmx_relation> rel(d.relation.dim);
+    for (uint r = 0; r < d.relation.dim; r++) {                             // RelationJoin, relation.h:53-60
+      RelationData* rd = d.relation(r).data;
+      rows_from_xt(rd->data_t, rd->num_cases, blocks[r]);
+      memset(&rel[r], 0, sizeof(fmx_relation));
+      rel[r].entries = blocks[r].ent.empty() ? NULL : &blocks[r].ent[0];
+      rel[r].row_ptr = (const uint64_t*)&blocks[r].row_ptr[0];
+      rel[r].n_rows = rd->num_cases; rel[r].nnz = blocks[r].ent.size();
+      rel[r].data_row_to_relation_row = (const uint32_t*)d.relation(r).data_row_to_relation_row.value;
+      rel[r].attr_offset = rd->attr_offset;
+    }
+    check(fmx_upload_block_rows(h, slot, main.ent.empty() ? NULL : &main.ent[0], (const uint64_t*)&main.row_ptr[0], d.target.value,
+                                d.num_cases, main.ent.size(), rel.empty() ? NULL : &rel[0], (uint32_t)rel.size()));
   }
 };
 

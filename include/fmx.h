@@ -158,6 +158,23 @@ int fmx_set_groups(fmx_handle h, const uint32_t *group_of_feature, uint32_t num_
 #define FMX_MAX_SLOTS 8
 int fmx_upload_rows(fmx_handle h, int slot, const void *entries, const uint64_t *row_ptr,
                     const float *target, uint32_t n_rows, uint64_t nnz);
+/* block-structured data (`-relation`; RelationData / RelationJoin, src/libfm/src/relation.h:32-60, loaded at
+ * libfm.cpp:172-196): every main row c is joined with row data_row_to_relation_row[c] of each relation block, whose
+ * attribute ids start at attr_offset (libfm.cpp:213-216).  The rows are expanded ON THE DEVICE into one CSR
+ * (main entries, then the blocks in order) so that the slot behaves like any other; the learners then compute what
+ * the reference's per-block caches compute (fm_learn_mcmc.h:478-527, 734-790, 849-909) on the same design matrix.
+ * At most 8 relations; not available on sharded handles. */
+typedef struct fmx_relation {
+  const void     *entries;                    /* the block's own rows: sparse_entry<float>[nnz], ids local to the block */
+  const uint64_t *row_ptr;                    /* [n_rows + 1] */
+  uint32_t        n_rows;                     /* RelationData::num_cases */
+  uint32_t        reserved;
+  uint64_t        nnz;
+  const uint32_t *data_row_to_relation_row;   /* [n_rows of the MAIN data]; RelationJoin, relation.h:56 */
+  uint64_t        attr_offset;                /* RelationData::attr_offset */
+} fmx_relation;
+int fmx_upload_block_rows(fmx_handle h, int slot, const void *entries, const uint64_t *row_ptr, const float *target,
+                          uint32_t n_rows, uint64_t nnz, const fmx_relation *relations, uint32_t n_relations);
 /* synthetic one-hot field rows generated on the device (bench workload; same
  * definition as oracle/fm_oracle.c fmo_synth_rows): rows row0 .. row0+n_rows-1 */
 int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz);

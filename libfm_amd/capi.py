@@ -50,6 +50,11 @@ class Eval(C.Structure):
                 ("device_seconds", C.c_double), ("rows", C.c_uint64)]
 
 
+class Relation(C.Structure):
+    _fields_ = [("entries", C.c_void_p), ("row_ptr", C.c_void_p), ("n_rows", C.c_uint32), ("reserved", C.c_uint32),
+                ("nnz", C.c_uint64), ("data_row_to_relation_row", C.c_void_p), ("attr_offset", C.c_uint64)]
+
+
 class AlsOpts(C.Structure):
     _fields_ = [("alpha", C.c_double), ("w_mu", C.c_double), ("w_lambda", C.c_double), ("v_mu", C.c_double),
                 ("v_lambda", C.c_double), ("do_sample", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
@@ -83,6 +88,8 @@ SYMBOLS = [
     ("fmx_get_w0", C.c_int, [H, C.POINTER(C.c_double)]),
     ("fmx_set_groups", C.c_int, [H, C.c_void_p, C.c_uint32]),
     ("fmx_upload_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
+    ("fmx_upload_block_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                        C.POINTER(Relation), C.c_uint32]),
     ("fmx_synth_rows", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     ("fmx_free_rows", C.c_int, [H, C.c_int]),
     ("fmx_rows_info", C.c_int, [H, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
@@ -239,6 +246,26 @@ class Handle:
         self._chk(self.lib.fmx_free_rows(self.h, slot))
 
     # compute ---------------------------------------------------------------------------------
+    def upload_block_rows(self, slot, entries, row_ptr, target, relations):
+        """relations: list of (entries, row_ptr, data_row_to_relation_row, attr_offset) -- `-relation` blocks
+        (relation.h:32-60); the rows are expanded on the device."""
+        entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        target = None if target is None else np.ascontiguousarray(target, dtype=np.float32)
+        n_rows = len(row_ptr) - 1
+        keep, arr = [], (Relation * max(len(relations), 1))()
+        for i, (re, rp, mp, off) in enumerate(relations):
+            re = np.ascontiguousarray(re, dtype=ENTRY_DTYPE)
+            rp = np.ascontiguousarray(rp, dtype=np.uint64)
+            mp = np.ascontiguousarray(mp, dtype=np.uint32)
+            if len(mp) != n_rows:
+                raise ValueError("relation %d: the row mapping has %d entries for %d data rows" % (i, len(mp), n_rows))
+            keep += [re, rp, mp]
+            arr[i] = Relation(_ptr(re) if len(re) else None, _ptr(rp), len(rp) - 1, 0, len(re), _ptr(mp), int(off))
+        self._chk(self.lib.fmx_upload_block_rows(self.h, slot, _ptr(entries) if len(entries) else None, _ptr(row_ptr),
+                                                 _ptr(target), n_rows, len(entries), arr, len(relations)))
+        return n_rows
+
     def predict(self, slot, n_rows):
         out = np.zeros(n_rows, dtype=np.float64)
         self._chk(self.lib.fmx_predict(self.h, slot, _ptr(out)))

@@ -10,7 +10,9 @@ targets rewritten to +-1 for `-task c` (:298-306), regularisation / learning-rat
 `#Iter=...` progress lines, `-out` (:423-428), `-save_model` / `-load_model` (:262-268, :431-434), and the
 reference's error convention: "ERROR: ..." on stderr and exit status 0 (:436-441).
 `-meta` (attribute groups, :199-242 / Data.h:85-97) is honoured by als / mcmc / sgda, incl. `-regular 'r0,w_1..w_G,v_1..v_G'`
-(:353-363).  Not mirrored: `-relation`, `-cache_size` (out of scope).
+(:353-363).  `-relation a,b` (block structure, :172-196; als / mcmc only like the reference's learners) loads <a>.x or
+<a>.xt, <a>.train, <a>.test and optional <a>.groups; the joined rows are expanded on the device.  `-cache_size` is
+accepted and ignored (everything is resident).
 GPU-only additions: -gpu_mode sequential|minibatch|hogwild (default minibatch), -batch, -w0_chunk, -device.
 """
 import sys
@@ -28,7 +30,7 @@ FLAGS = {"task": "r=regression, c=binary classification [MANDATORY]", "meta": "f
          "regular": "'r0,r1,r2' for SGD and ALS", "init_stdev": "stdev for initialization of 2-way factors; default=0.1",
          "iter": "number of iterations; default=100", "learn_rate": "learn_rate for SGD", "method": "sgd, als, mcmc; default=mcmc",
          "verbosity": "", "rlog": "write measurements within iterations to a file", "seed": "integer value", "help": "",
-         "relation": "", "cache_size": "", "save_model": "filename for writing the FM model",
+         "relation": "BS: filenames for the relations, default=''", "cache_size": "", "save_model": "filename for writing the FM model",
          "load_model": "filename for reading the FM model",
          "gpu_mode": "sequential | minibatch | hogwild (default minibatch)", "batch": "", "w0_chunk": "", "device": ""}
 
@@ -110,6 +112,22 @@ def _main(argv):
     fm.num_attribute = max(train.num_feature, test.num_feature)                      # libfm.cpp:203-206
     if validation is not None:
         fm.num_attribute = max(fm.num_attribute, validation.num_feature)
+    # (1.2) relations (libfm.cpp:172-196): block attributes follow the main attributes (:213-216)
+    relations = []
+    if a.get("relation"):
+        if method not in ("als", "mcmc"):
+            raise ValueError("relations are not supported with SGD")            # fm_learn_sgd.h:61-63
+        rel_names = split_list(a["relation"])
+        print("#relations: %d" % len(rel_names))
+        for name in rel_names:
+            r = D.read_relation(name)
+            print("num_cases=%d\tnum_values=%d\tnum_features=%d" % (r.num_cases, len(r.entries), r.num_feature))
+            train.add_relation(r, D.read_row_mapping(name + ".train", train.num_cases), fm.num_attribute)
+            test.add_relation(r, D.read_row_mapping(name + ".test", test.num_cases), fm.num_attribute)
+            relations.append(r)
+            fm.num_attribute += r.num_feature
+    num_main_attribute = fm.num_attribute - sum(r.num_feature for r in relations)
+
     fm.k0, fm.k1, fm.num_factor = dim[0] != 0, dim[1] != 0, dim[2]
     fm.init_stdev = init_stdev
     R.srand(seed)                                                                     # libfm.cpp:115-116
@@ -125,13 +143,20 @@ def _main(argv):
     # (1.3) meta data: attribute -> group, one id per line (DataMetaInfo::loadGroupsFromFile, Data.h:85-97;
     # DVector::load reads num_attribute values, missing ones stay 0, matrix.h:360-371)
     groups, num_groups = None, 1
-    if a.get("meta"):
+    if a.get("meta") or any(r.groups is not None for r in relations):
         print("Loading meta data...\t")
-        with open(a["meta"]) as f:
-            vals = f.read().split()[:fm.num_attribute]
         groups = np.zeros(fm.num_attribute, dtype=np.uint32)
-        groups[:len(vals)] = [int(x) for x in vals]
-        num_groups = int(groups.max()) + 1 if len(groups) else 1
+        if a.get("meta"):
+            with open(a["meta"]) as f:
+                vals = f.read().split()[:num_main_attribute]
+            groups[:len(vals)] = [int(x) for x in vals]
+        num_groups = int(groups[:num_main_attribute].max()) + 1 if num_main_attribute else 1
+        at = num_main_attribute
+        for r in relations:                                                          # the joined table, :217-240
+            rg = r.groups if r.groups is not None else np.zeros(r.num_feature, dtype=np.uint32)
+            groups[at:at + r.num_feature] = num_groups + rg
+            num_groups += int(rg.max()) + 1 if r.num_feature else 1
+            at += r.num_feature
         print("#attr=%d\t#groups=%d" % (fm.num_attribute, num_groups))
 
     task = a["task"]

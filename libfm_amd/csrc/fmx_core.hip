@@ -441,6 +441,97 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
   return FMX_OK;
 }
 
+int fmx_upload_block_rows(fmx_handle h, int slot, const void* entries, const uint64_t* row_ptr, const float* target,
+                          uint32_t n_rows, uint64_t nnz, const fmx_relation* relations, uint32_t n_relations) {
+  if (!h) return FMX_E_ARG;
+  if (n_relations == 0) return fmx_upload_rows(h, slot, entries, row_ptr, target, n_rows, nnz);
+  if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  if (!relations || n_relations > FMX_MAX_RELATIONS) return fail(h, FMX_E_ARG, "fmx_upload_block_rows: 1..%d relations", FMX_MAX_RELATIONS);
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "block-structured rows on a feature shard are not implemented");
+  if (!row_ptr || (nnz > 0 && !entries)) return fail(h, FMX_E_ARG, "fmx_upload_block_rows: null entries/row_ptr");
+  if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return fail(h, FMX_E_ARG, "row_ptr[0] must be 0 and row_ptr[n_rows] == nnz");
+  const uint64_t n = h->cfg.num_attribute;
+  const Entry* src = static_cast<const Entry*>(entries);
+  for (uint64_t i = 0; i < nnz; i++)
+    if (src[i].id >= n) return fail(h, FMX_E_ARG, "feature id %u >= num_attribute %llu", src[i].id, (unsigned long long)n);
+  for (uint32_t r = 0; r < n_relations; r++) {
+    const fmx_relation& q = relations[r];
+    if (!q.row_ptr || !q.data_row_to_relation_row || (q.nnz && !q.entries) || q.row_ptr[0] != 0 || q.row_ptr[q.n_rows] != q.nnz)
+      return fail(h, FMX_E_ARG, "relation %u: malformed rows", r);
+    const Entry* qe = static_cast<const Entry*>(q.entries);
+    for (uint64_t i = 0; i < q.nnz; i++)
+      if ((uint64_t)qe[i].id + q.attr_offset >= n)
+        return fail(h, FMX_E_ARG, "relation %u: attribute %u + offset %llu >= num_attribute %llu", r, qe[i].id,
+                    (unsigned long long)q.attr_offset, (unsigned long long)n);
+    for (uint32_t c = 0; c < n_rows; c++)
+      if (q.data_row_to_relation_row[c] >= q.n_rows)
+        return fail(h, FMX_E_ARG, "relation %u: main row %u maps to block row %u >= %u", r, c, q.data_row_to_relation_row[c], q.n_rows);
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_slot(h->slots[slot]);
+  std::vector<void*> tmp;                                     // staging buffers, freed on every exit path
+  auto up = [&](const void* p, size_t bytes) -> void* {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+    tmp.push_back(d);
+    if (bytes && hipMemcpy(d, p, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+  };
+  Slot s;
+  bool committed = false;
+  auto cleanup = [&]() { for (void* d : tmp) hipFree(d); if (!committed) free_slot(s); };
+#define BLK_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+#define BLK_UP(dst, type, p, bytes) do { dst = (type)up((p), (bytes)); if (!dst) { cleanup(); return fail(h, FMX_E_HIP, "fmx_upload_block_rows: staging %s failed", #p); } } while (0)
+  const Entry* d_ent; const uint64_t* d_ptr;
+  BLK_UP(d_ent, const Entry*, entries, nnz * sizeof(Entry));
+  BLK_UP(d_ptr, const uint64_t*, row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t));
+  BlockRels rels;
+  memset(&rels, 0, sizeof(rels));
+  rels.n = n_relations;
+  for (uint32_t r = 0; r < n_relations; r++) {
+    const fmx_relation& q = relations[r];
+    BLK_UP(rels.r[r].ent, const Entry*, q.entries, q.nnz * sizeof(Entry));
+    BLK_UP(rels.r[r].row_ptr, const uint64_t*, q.row_ptr, ((size_t)q.n_rows + 1) * sizeof(uint64_t));
+    BLK_UP(rels.r[r].map, const uint32_t*, q.data_row_to_relation_row, (size_t)n_rows * sizeof(uint32_t));
+    rels.r[r].attr_offset = (uint32_t)q.attr_offset;
+  }
+  uint64_t* sizes = nullptr;
+  BLK_CHK(hipMalloc(&sizes, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  tmp.push_back(sizes);
+  BLK_CHK(hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  const dim3 g1(std::min<uint32_t>((n_rows + 256) / 256, 2048)), b1(256);
+  hipLaunchKernelGGL(k_block_sizes, g1, b1, 0, h->stream, d_ptr, n_rows, rels, sizes);
+  size_t scan_bytes = 0;
+  BLK_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, sizes, s.row_ptr, (int)(n_rows + 1), h->stream));
+  void* scan_tmp = nullptr;
+  BLK_CHK(hipMalloc(&scan_tmp, std::max<size_t>(scan_bytes, 8)));
+  tmp.push_back(scan_tmp);
+  BLK_CHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, sizes, s.row_ptr, (int)(n_rows + 1), h->stream));
+  std::vector<uint64_t> hs((size_t)n_rows + 1);
+  uint64_t total = 0;
+  BLK_CHK(hipMemcpyAsync(hs.data(), sizes, hs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  BLK_CHK(hipMemcpyAsync(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  BLK_CHK(hipStreamSynchronize(h->stream));
+  uint32_t max_row = 0;
+  for (uint32_t c = 0; c < n_rows; c++) max_row = std::max<uint32_t>(max_row, (uint32_t)hs[c]);
+  BLK_CHK(hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
+  hipLaunchKernelGGL(k_block_fill, g1, b1, 0, h->stream, d_ent, d_ptr, n_rows, rels, s.row_ptr, s.ent);
+  BLK_CHK(hipGetLastError());
+  if (target) {
+    BLK_CHK(hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float)));
+    if (n_rows) BLK_CHK(hipMemcpy(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice));
+  }
+  BLK_CHK(hipStreamSynchronize(h->stream));
+#undef BLK_CHK
+#undef BLK_UP
+  committed = true;
+  cleanup();
+  s.n_rows = n_rows; s.nnz = total; s.max_row = max_row; s.used = true;
+  h->slots[slot] = s;
+  return FMX_OK;
+}
+
 int fmx_rows_info(fmx_handle h, int slot, uint32_t* n_rows, uint64_t* nnz) {
   int rc = check_slot(h, slot, false);
   if (rc) return rc;

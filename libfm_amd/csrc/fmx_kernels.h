@@ -875,6 +875,42 @@ k_sgda(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, cons
 }
 
 // ----------------------------------------------------------------------------------------------
+// block-structured rows (`-relation`, src/libfm/src/relation.h:32-60): a main row c is followed by the row
+// data_row_to_relation_row[c] of every relation block, block attribute ids shifted by the block's attr_offset
+// (libfm.cpp:213-216).  The learner of the reference never materialises these rows (fm_learn_mcmc.h:478-527 works
+// on per-block caches); on the device the expanded CSR is built once at upload and every kernel runs unchanged.
+// ----------------------------------------------------------------------------------------------
+#define FMX_MAX_RELATIONS 8
+struct BlockRel { const Entry* ent; const uint64_t* row_ptr; const uint32_t* map; uint32_t attr_offset; uint32_t pad; };
+struct BlockRels { BlockRel r[FMX_MAX_RELATIONS]; uint32_t n; };
+
+static __global__ void __launch_bounds__(256)
+k_block_sizes(const uint64_t* __restrict__ main_ptr, uint32_t n_rows, BlockRels rels, uint64_t* __restrict__ sizes) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c <= n_rows; c += gridDim.x * blockDim.x) {
+    uint64_t s = 0;
+    if (c < n_rows) {
+      s = main_ptr[c + 1] - main_ptr[c];
+      for (uint32_t r = 0; r < rels.n; r++) { const uint32_t b = rels.r[r].map[c]; s += rels.r[r].row_ptr[b + 1] - rels.r[r].row_ptr[b]; }
+    }
+    sizes[c] = s;                                            // sizes[n_rows] = 0: the scan then yields row_ptr[n_rows] = nnz
+  }
+}
+
+static __global__ void __launch_bounds__(256)
+k_block_fill(const Entry* __restrict__ main_ent, const uint64_t* __restrict__ main_ptr, uint32_t n_rows, BlockRels rels,
+             const uint64_t* __restrict__ out_ptr, Entry* __restrict__ out) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_rows; c += gridDim.x * blockDim.x) {
+    uint64_t o = out_ptr[c];
+    for (uint64_t i = main_ptr[c]; i < main_ptr[c + 1]; i++) out[o++] = main_ent[i];
+    for (uint32_t r = 0; r < rels.n; r++) {
+      const BlockRel& b = rels.r[r];
+      const uint32_t br = b.map[c];
+      for (uint64_t i = b.row_ptr[br]; i < b.row_ptr[br + 1]; i++) { Entry e = b.ent[i]; e.id += b.attr_offset; out[o++] = e; }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // k_sgda_groups: the same learner with attribute groups (`-meta`): reg_w(g), reg_v(g,f) and the per-group sums of the
 // lambda step (lambda_w_grad(g), sum_f(g), sum_f_dash_f(g); :96-98, :213-247) live in LDS:
 //   regw[G] | regv[G][KP] | lwg[G] | sfg[G][KP] | sdfg[G][KP] | stamp[G]

@@ -75,20 +75,87 @@ def read_binary_y(path):
     return raw[12:12 + 4 * int(n)].view("<f4").copy()
 
 
-def write_binary(prefix, entries, row_ptr, target, num_cols=None):
-    """what tools/convert.cpp writes: <prefix>.x and <prefix>.y"""
+def write_binary_matrix(path, entries, row_ptr, num_cols=None):
+    """LargeSparseMatrix::saveToBinaryFile (fmatrix.h:121-140): header + per row {u32 size, entries}"""
     entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
     row_ptr = np.asarray(row_ptr, dtype=np.int64)
     n_rows = len(row_ptr) - 1
     hdr = np.zeros(1, dtype=_HDR)
     hdr["id"], hdr["float_size"], hdr["num_values"], hdr["num_rows"] = FMATRIX_FILE_ID, 4, len(entries), n_rows
     hdr["num_cols"] = num_cols if num_cols is not None else (int(entries["id"].max()) + 1 if len(entries) else 0)
-    with open(prefix + ".x", "wb") as f:
+    with open(path, "wb") as f:
         f.write(hdr.tobytes())
         for r in range(n_rows):
             a, b = row_ptr[r], row_ptr[r + 1]
             f.write(np.uint32(b - a).tobytes())
             f.write(entries[a:b].tobytes())
+
+
+def transpose(entries, row_ptr, num_cols):
+    """X -> X^T in the same CSR-with-AoS layout (tools/transpose.cpp; Data::create_data_t, Data.h:292-341): per
+    column the {row id, value} pairs in ascending row order."""
+    entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    rows = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.uint32), np.diff(row_ptr))
+    order = np.argsort(entries["id"], kind="stable")
+    t = np.zeros(len(entries), dtype=ENTRY_DTYPE)
+    t["id"], t["value"] = rows[order], entries["value"][order]
+    col_ptr = np.concatenate([[0], np.cumsum(np.bincount(entries["id"], minlength=num_cols))]).astype(np.uint64)
+    return t, col_ptr
+
+
+class Relation:
+    """RelationData (relation.h:32-51): one block of a block-structured data set -- its own design matrix
+    (<prefix>.x, or <prefix>.xt transposed back: for als/mcmc the reference loads only .xt, libfm.cpp:181-185) and
+    optional attribute groups (<prefix>.groups)."""
+
+    def __init__(self, entries, row_ptr, num_feature, groups=None):
+        self.entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        self.num_cases = len(self.row_ptr) - 1
+        self.num_feature = int(num_feature)
+        self.groups = groups                                     # None = one group
+
+
+def read_relation(prefix):
+    if os.path.exists(prefix + ".x"):
+        ent, row_ptr, ncols = read_binary_x(prefix + ".x")
+    elif os.path.exists(prefix + ".xt"):
+        ent_t, col_ptr, n_rows = read_binary_x(prefix + ".xt")        # rows of .xt = attributes, columns = cases
+        ent, row_ptr = transpose(ent_t, col_ptr, n_rows)
+        ncols = len(col_ptr) - 1
+    else:
+        raise OSError("could not open " + prefix + ".x / .xt")
+    groups = None
+    if os.path.exists(prefix + ".groups"):
+        with open(prefix + ".groups") as f:
+            vals = [int(x) for x in f.read().split()[:ncols]]
+        groups = np.zeros(ncols, dtype=np.uint32)
+        groups[:len(vals)] = vals
+    return Relation(ent, row_ptr, ncols, groups)
+
+
+def read_row_mapping(path, expected_rows):
+    """RelationJoin::load (relation.h:125-150): binary DVector<uint> or one uint per line"""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if len(raw) >= 12:
+        ver, size, n = raw[:12].view("<u4")
+        if int(ver) == DVECTOR_FILE_ID and int(size) == 4:
+            m = raw[12:12 + 4 * int(n)].view("<u4").copy()
+            if len(m) != expected_rows:
+                raise ValueError("%s: %d rows, expected %d" % (path, len(m), expected_rows))
+            return m
+    with open(path) as f:
+        vals = [int(x) for x in f.read().split()[:expected_rows]]
+    m = np.zeros(expected_rows, dtype=np.uint32)
+    m[:len(vals)] = vals
+    return m
+
+
+def write_binary(prefix, entries, row_ptr, target, num_cols=None):
+    """what tools/convert.cpp writes: <prefix>.x and <prefix>.y"""
+    write_binary_matrix(prefix + ".x", entries, row_ptr, num_cols)
+    n_rows = len(row_ptr) - 1
     with open(prefix + ".y", "wb") as f:
         f.write(np.array([DVECTOR_FILE_ID, 4, n_rows], dtype="<u4").tobytes())
         f.write(np.ascontiguousarray(target, dtype="<f4").tobytes())

@@ -32,6 +32,22 @@ class Data:
         self.num_feature = int(self.entries["id"].max()) + 1 if len(self.entries) else 0   # Data.h:59
         self.min_target = float(self.target.min()) if self.num_cases else 0.0   # Data.h:62-63
         self.max_target = float(self.target.max()) if self.num_cases else 0.0
+        self.relation = []                                       # Data.h:68: DVector<RelationJoin>
+
+    def add_relation(self, rel, data_row_to_relation_row, attr_offset):
+        """RelationJoin (relation.h:53-60): `rel` = a data.Relation (the block's own rows), the main-row -> block-row
+        mapping of THIS data set (<prefix>.train / <prefix>.test) and the block's first global attribute id
+        (RelationData::attr_offset, libfm.cpp:213-216)."""
+        m = np.ascontiguousarray(data_row_to_relation_row, dtype=np.uint32)
+        if len(m) != self.num_cases:
+            raise ValueError("relation mapping has %d rows, the data set %d" % (len(m), self.num_cases))   # relation.h:149
+        self.relation.append((rel.entries, rel.row_ptr, m, int(attr_offset)))
+
+    def upload(self, h, slot):
+        if self.relation:
+            h.upload_block_rows(slot, self.entries, self.row_ptr, self.target, self.relation)
+        else:
+            h.upload_rows(slot, self.entries, self.row_ptr, self.target)
 
 
 class FMModel:
@@ -140,7 +156,7 @@ class FMLearnSGD:
             slot = len(self._slots)
             if slot >= capi.MAX_SLOTS:
                 raise RuntimeError("too many data sets")
-            self._h.upload_rows(slot, data.entries, data.row_ptr, data.target)
+            data.upload(self._h, slot)
             self._slots[key] = slot
         return self._slots[key]
 
@@ -244,8 +260,8 @@ class FMLearnALS:
     # fm_learn_mcmc::learn + _learn (fm_learn_mcmc.h:1160-1201, fm_learn_mcmc_simultaneous.h:56-270)
     def learn(self, train, test):
         h = self._h
-        h.upload_rows(0, train.entries, train.row_ptr, train.target)
-        h.upload_rows(1, test.entries, test.row_ptr, test.target)
+        train.upload(h, 0)
+        test.upload(h, 1)
         self.pred_sum_all = np.zeros(test.num_cases)
         h.als_begin(0)
         for i in range(self.num_iter):
@@ -298,8 +314,8 @@ class FMLearnMCMC(FMLearnALS):
         h = self._h
         rng = np.random.default_rng(self.seed)
         k, n, G = self.fm.num_factor, self.fm.num_attribute, h.G
-        h.upload_rows(0, train.entries, train.row_ptr, train.target)
-        h.upload_rows(1, test.entries, test.row_ptr, test.target)
+        train.upload(h, 0)
+        test.upload(h, 1)
         self.pred_sum_all = np.zeros(test.num_cases)
         N = train.num_cases
         # meta->num_attr_per_group (Data.h:93-95)

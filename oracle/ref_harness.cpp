@@ -20,6 +20,7 @@
 //                                                             the synthetic workload of oracle/fm_oracle.c, 1 thread)
 // environment: FMX_META=<file>  attribute groups (`-meta`, one group id per line, Data.h:85-97);
 //              FMX_GROUP_REG=w_1,..,w_G,v_1,..,v_G  per-group lambdas for als (the tail of `-regular`, libfm.cpp:353-363)
+//              FMX_RELATIONS=<prefix>[,<prefix>]  block-structured data for als / mcmc (`-relation`, libfm.cpp:172-196)
 // outputs (<out_prefix>.*):
 //   .init.bin / .final.bin : magic 'FMXP', u64 n, i32 k, f64 w0, f64 w[n], f64 v[k][n]  (reference layout)
 //   .pred_raw.bin          : f64[num_test]  fm_learn::predict_case per test row after training
@@ -39,6 +40,7 @@
 #include "util/cmdline.h"
 #include "fm_core/fm_model.h"
 #include "libfm/src/Data.h"
+#include "libfm/src/relation.h"
 #include "libfm/src/fm_learn.h"
 #include "libfm/src/fm_learn_sgd.h"
 #include "libfm/src/fm_learn_sgd_element.h"
@@ -145,11 +147,44 @@ int main(int argc, char** argv) {
     train.load(train_file);
     Data test(0, is_sgd, !is_sgd);
     test.load(test_file);
+    // relations (block structure, `-relation a,b`; libfm.cpp:172-196): FMX_RELATIONS=<prefix>[,<prefix>...]; every
+    // prefix names <prefix>.x / .xt (binary design matrix of the block), <prefix>.train / .test (main row -> block row)
+    // and optionally <prefix>.groups
+    std::vector<std::string> rel;
+    if (getenv("FMX_RELATIONS")) { std::string t = getenv("FMX_RELATIONS"); size_t p0 = 0; while (p0 < t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); rel.push_back(t.substr(p0, p1 - p0)); p0 = p1 + 1; } }
+    DVector<RelationData*> relation;
+    relation.setSize(rel.size());
+    train.relation.setSize(rel.size()); test.relation.setSize(rel.size());
+    for (uint i = 0; i < rel.size(); i++) {
+      relation(i) = new RelationData(0, is_sgd, !is_sgd);
+      relation(i)->load(rel[i]);
+      train.relation(i).data = relation(i);
+      test.relation(i).data = relation(i);
+      train.relation(i).load(rel[i] + ".train", train.num_cases);
+      test.relation(i).load(rel[i] + ".test", test.num_cases);
+    }
     uint num_all_attribute = std::max(train.num_feature, test.num_feature);   // libfm.cpp:203
-    DataMetaInfo meta(num_all_attribute);
-    if (getenv("FMX_META")) meta.loadGroupsFromFile(getenv("FMX_META"));   // -meta, libfm.cpp:207-210 (no relations: meta == meta_main)
-    meta.num_relations = 0;
-    train.relation.setSize(0); test.relation.setSize(0);
+    DataMetaInfo meta_main(num_all_attribute);
+    if (getenv("FMX_META")) meta_main.loadGroupsFromFile(getenv("FMX_META"));  // -meta, libfm.cpp:207-210
+    for (uint r = 0; r < train.relation.dim; r++) {                            // block attributes follow the main ones (:213-216)
+      train.relation(r).data->attr_offset = num_all_attribute;
+      num_all_attribute += train.relation(r).data->num_feature;
+    }
+    DataMetaInfo meta(num_all_attribute);                                      // the joined table (:217-242)
+    {
+      meta.num_attr_groups = meta_main.num_attr_groups;
+      for (uint r = 0; r < relation.dim; r++) meta.num_attr_groups += relation(r)->meta->num_attr_groups;
+      meta.num_attr_per_group.setSize(meta.num_attr_groups);
+      meta.num_attr_per_group.init(0);
+      uint at = 0, gr = 0;
+      for (uint i = 0; i < meta_main.attr_group.dim; i++, at++) { meta.attr_group(at) = meta_main.attr_group(i); meta.num_attr_per_group(meta.attr_group(at))++; }
+      gr = meta_main.num_attr_groups;
+      for (uint r = 0; r < relation.dim; r++) {
+        for (uint i = 0; i < relation(r)->meta->attr_group.dim; i++, at++) { meta.attr_group(at) = gr + relation(r)->meta->attr_group(i); meta.num_attr_per_group(meta.attr_group(at))++; }
+        gr += relation(r)->meta->num_attr_groups;
+      }
+    }
+    meta.num_relations = train.relation.dim;
 
     fm_model fm;                                               // libfm.cpp:245-258
     fm.num_attribute = num_all_attribute;

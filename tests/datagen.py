@@ -73,3 +73,48 @@ def onehot_fields(n_features, nnz, n_rows, seed, zipf=0.0, classification=True):
     s = wtrue[idm].sum(1) / np.sqrt(nnz) + rng.normal(0, 0.3, n_rows)
     y = np.where(s > 0, 1.0, -1.0) if classification else np.round(s, 3)
     return ent, row_ptr, y.astype(np.float32)
+
+
+def block_structured(n_users, n_items, n_rows, seed, n_ctx=7, k_true=3, noise=0.2, classification=False):
+    """Block-structured ("relational", Rendle VLDB'13) rating data: a main table with one context attribute per row
+    (one-hot of n_ctx) and two relation blocks, USERS (user one-hot + 2 real attributes) and ITEMS (item one-hot +
+    3 binary genre flags, ragged).  Returns (main rows, [block rows...], [row mapping...]); block attribute ids are
+    local to the block.  The flat design matrix is expand_blocks(...)."""
+    rng = np.random.default_rng(seed)
+    u, it, cx = rng.integers(0, n_users, n_rows), rng.integers(0, n_items, n_rows), rng.integers(0, n_ctx, n_rows)
+    uattr = rng.normal(0, 1, (n_users, 2)).astype(np.float32)
+    genre = rng.random((n_items, 3)) < 0.4
+    users = _pack([[a, n_users, n_users + 1] for a in range(n_users)],
+                  [[1.0, float(uattr[a, 0]), float(uattr[a, 1])] for a in range(n_users)], np.zeros(n_users))
+    items = _pack([[b] + [n_items + g for g in range(3) if genre[b, g]] for b in range(n_items)],
+                  [[1.0] + [1.0 for g in range(3) if genre[b, g]] for b in range(n_items)], np.zeros(n_items))
+    bu, bi, bc = rng.normal(0, 0.5, n_users), rng.normal(0, 0.5, n_items), rng.normal(0, 0.3, n_ctx)
+    pu, qi = rng.normal(0, 0.5, (n_users, k_true)), rng.normal(0, 0.5, (n_items, k_true))
+    wg = rng.normal(0, 0.4, 3)
+    y = 3.5 + bu[u] + bi[it] + bc[cx] + (pu[u] * qi[it]).sum(1) + genre[it] @ wg + 0.3 * uattr[u, 0] + rng.normal(0, noise, n_rows)
+    y = np.where(y > 3.5, 1.0, -1.0) if classification else np.clip(np.rint(y), 1, 5)
+    main = _pack([[int(c)] for c in cx], [[1.0]] * n_rows, y)
+    blocks = [(users[0], users[1], n_users + 2), (items[0], items[1], n_items + 3)]      # (entries, row_ptr, num_feature)
+    return main, blocks, [u.astype(np.uint32), it.astype(np.uint32)]
+
+
+def expand_blocks(main_entries, main_row_ptr, blocks, maps, num_main_attr):
+    """the flat rows a block-structured data set stands for: main entries, then each block's mapped row with its ids
+    shifted by the block's attr_offset (libfm.cpp:213-216).  Returns (entries, row_ptr, attr_offsets)."""
+    offs, o = [], num_main_attr
+    for _, _, nf in blocks:
+        offs.append(o)
+        o += nf
+    mrp = np.asarray(main_row_ptr, dtype=np.int64)
+    ids, vals = [], []
+    for c in range(len(mrp) - 1):
+        ri, rv = list(main_entries["id"][mrp[c]:mrp[c + 1]]), list(main_entries["value"][mrp[c]:mrp[c + 1]])
+        for (be, bp, _), mp, off in zip(blocks, maps, offs):
+            bp = np.asarray(bp, dtype=np.int64)
+            a, b = bp[mp[c]], bp[mp[c] + 1]
+            ri += list(be["id"][a:b].astype(np.int64) + off)
+            rv += list(be["value"][a:b])
+        ids.append(ri)
+        vals.append(rv)
+    ent, rp, _ = _pack(ids, vals, np.zeros(len(ids)))
+    return ent, rp, offs

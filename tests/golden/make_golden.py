@@ -236,6 +236,79 @@ def make_sgda():
         print("%-22s n=%d k=%d rows=%d/%d/%d reg_w=%.4g reg_v[0]=%.4g" % (name, init.n, init.k, ntr, nte, nva, regs[0], regs[1]))
 
 
+REL_CASES = {
+    # block-structured data (`-relation`, relation.h): users block + items block, main table = one context attribute
+    "rel_als_reg": dict(gen=dict(n_users=60, n_items=40, n_rows=700, seed=81), split=550, rel_groups=False,
+                        cfg=dict(task="r", k0=1, k1=1, k=4, iters=4, reg=(0.0, 1.0, 6.0), init_stdev=0.1, seed=11)),
+    # ... with <prefix>.groups files: joined meta = main(1) + users(2: ids | attributes) + items(2: ids | genres)
+    "rel_als_cls_groups": dict(gen=dict(n_users=50, n_items=30, n_rows=600, seed=83, classification=True), split=480, rel_groups=True,
+                               group_reg=((0.5, 1.0, 2.0, 1.5, 3.0), (4.0, 6.0, 9.0, 5.0, 12.0)),
+                               cfg=dict(task="c", k0=1, k1=1, k=3, iters=3, reg=(0.1, 0.0, 0.0), init_stdev=0.1, seed=12)),
+}
+
+
+def make_rel():
+    from libfm_amd import data as D                            # host-side file formats only (no GPU involved)
+    for name, case in REL_CASES.items():
+        (ent, rp, y), blocks, maps = datagen.block_structured(**case["gen"])
+        rp = rp.astype(np.int64)
+        ntr = case["split"]
+        tr = O.Data(ent[:rp[ntr]], rp[:ntr + 1], y[:ntr])
+        te = O.Data(ent[rp[ntr]:], rp[ntr:] - rp[ntr], y[ntr:])
+        cfg = case["cfg"]
+        n_main = 7
+        with tempfile.TemporaryDirectory() as td:
+            trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
+            tr.write_libsvm(trf)
+            te.write_libsvm(tef)
+            prefixes, rgroups = [], []
+            for bi, ((be, bp, nf), mp) in enumerate(zip(blocks, maps)):
+                px = os.path.join(td, "rel%d" % bi)
+                et, cp = D.transpose(be, bp, nf)
+                D.write_binary_matrix(px + ".xt", et, cp, num_cols=len(bp) - 1)     # als/mcmc read only .xt (libfm.cpp:181-185)
+                np.savetxt(px + ".train", mp[:ntr], fmt="%d")
+                np.savetxt(px + ".test", mp[ntr:], fmt="%d")
+                g = None
+                if case["rel_groups"]:
+                    n_ids = nf - (2 if bi == 0 else 3)
+                    g = (np.arange(nf) >= n_ids).astype(np.uint32)
+                    np.savetxt(px + ".groups", g, fmt="%d")
+                rgroups.append(g)
+                prefixes.append(px)
+            env = {"FMX_RELATIONS": ",".join(prefixes)}
+            if "group_reg" in case:
+                env["FMX_GROUP_REG"] = ",".join(repr(x) for x in case["group_reg"][0] + case["group_reg"][1])
+            O.run_ref_harness(["als", trf, tef, cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"],
+                               repr(cfg["reg"][0]), repr(cfg["reg"][1]), repr(cfg["reg"][2]), repr(cfg["init_stdev"]),
+                               cfg["seed"], pre], env=env)
+            init = O.Model.from_dump(pre + ".init.bin")
+            final = O.Model.from_dump(pre + ".final.bin")
+            pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+        extra = {}
+        for bi, ((be, bp, nf), mp) in enumerate(zip(blocks, maps)):
+            extra.update({"rel%d_entries" % bi: be, "rel%d_row_ptr" % bi: bp, "rel%d_num_feature" % bi: nf,
+                          "rel%d_train" % bi: mp[:ntr], "rel%d_test" % bi: mp[ntr:]})
+            if rgroups[bi] is not None:
+                extra["rel%d_groups" % bi] = rgroups[bi]
+        if "group_reg" in case:                                  # joined meta (libfm.cpp:217-240): main group 0, then the blocks' groups
+            grp, nxt = [np.zeros(n_main, dtype=np.uint32)], 1
+            for g in rgroups:
+                grp.append(g + nxt)
+                nxt += int(g.max()) + 1
+            extra.update(group=np.concatenate(grp).astype(np.uint32), w_lambda_g=np.array(case["group_reg"][0]),
+                         v_lambda_g=np.array(case["group_reg"][1]))
+        assert init.n == n_main + sum(nf for _, _, nf in blocks), (init.n, n_main)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"), **extra, n_relations=len(blocks), n_main=n_main,
+            train_entries=tr.entries, train_row_ptr=tr.row_ptr, train_target=tr.target,
+            test_entries=te.entries, test_row_ptr=te.row_ptr, test_target=te.target,
+            task=cfg["task"], k0=cfg["k0"], k1=cfg["k1"], k=cfg["k"], iters=cfg["iters"], lr=0.0,
+            reg=np.array(cfg["reg"]), init_stdev=cfg["init_stdev"], seed=cfg["seed"],
+            n=init.n, init_w0=init.w0, init_w=init.w, init_v=init.v,
+            final_w0=final.w0, final_w=final.w, final_v=final.v, pred_out=pred_out)
+        print("%-22s n=%d k=%d rows=%d/%d relations=%d pred_out[:3]=%s" % (name, init.n, init.k, tr.n_rows, te.n_rows, len(blocks), pred_out[:3]))
+
+
 def make_c1():
     """BASELINE.json configs[0]: MovieLens-100K-shaped plumbing case run through the STOCK reference binary
     (oracle/_ref/libFM, the reference's own main + CLI + text parser + -out / -save_model writers)."""
@@ -275,6 +348,7 @@ def main():
     O.build()
     if "--c1" in sys.argv or not os.path.exists(os.path.join(HERE, "c1_ml100k_shaped.npz")):
         make_c1()
+    make_rel()
     make_mcmc()
     make_sgda()
     make_als()

@@ -83,3 +83,40 @@ def test_reference_driver_with_gpu_als_learner(oracle, name):
     np.testing.assert_allclose(final.v, z["final_v"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(final.w, z["final_w"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(pred_out, z["pred_out"], rtol=1e-4, atol=5e-5)
+
+
+def test_reference_driver_with_gpu_als_learner_on_relations(oracle, tmp_path):
+    """block-structured data through the reference's own RelationData / RelationJoin loaders (FMX_RELATIONS = `-relation`)
+    into adapter/fm_learn_mcmc_gpu.h -> fmx_upload_block_rows; result = the stock block-structured learner's (fixture)."""
+    if not os.path.exists(HARNESS):
+        pytest.skip("oracle/_ref/ref_harness_gpu not built (needs /root/reference at build time)")
+    from libfm_amd import data as D
+    O = oracle
+    g = Golden("rel_als_cls_groups")
+    z = g.z
+    td = str(tmp_path)
+    trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
+    O.Data(z["train_entries"], z["train_row_ptr"], z["train_target"]).write_libsvm(trf)
+    O.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(tef)
+    names = []
+    for i in range(int(z["n_relations"])):
+        px = os.path.join(td, "rel%d" % i)
+        be, bp, nf = z["rel%d_entries" % i], z["rel%d_row_ptr" % i], int(z["rel%d_num_feature" % i])
+        et, cp = D.transpose(be, bp, nf)
+        D.write_binary_matrix(px + ".xt", et, cp, num_cols=len(bp) - 1)
+        np.savetxt(px + ".train", z["rel%d_train" % i], fmt="%d")
+        np.savetxt(px + ".test", z["rel%d_test" % i], fmt="%d")
+        np.savetxt(px + ".groups", z["rel%d_groups" % i], fmt="%d")
+        names.append(px)
+    env = dict(os.environ)
+    env["FMX_RELATIONS"] = ",".join(names)
+    env["FMX_GROUP_REG"] = ",".join(repr(float(x)) for x in list(z["w_lambda_g"]) + list(z["v_lambda_g"]))
+    cfg = ["als_gpu", trf, tef, str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]),
+           repr(g.reg[0]), repr(g.reg[1]), repr(g.reg[2]), repr(float(z["init_stdev"])), int(z["seed"]), pre]
+    r = subprocess.run([HARNESS] + [str(c) for c in cfg], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    final = O.Model.from_dump(pre + ".final.bin")
+    pred_out = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+    np.testing.assert_allclose(final.v, z["final_v"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(final.w, z["final_w"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(pred_out, z["pred_out"], rtol=1e-4, atol=5e-5)

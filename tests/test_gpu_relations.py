@@ -1,0 +1,104 @@
+"""GPU: block-structured data (`-relation`): fmx_upload_block_rows expands the joined rows on the device; ALS on them
+must land on the REAL reference's block-structured run (fixtures rel_als_*; the reference sweeps per-block caches,
+fm_learn_mcmc.h:478-527, 734-790, 849-909).  Tolerance 1e-4 as for every ALS test."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+from common import Golden
+from conftest import golden_cases
+
+pytestmark = pytest.mark.gpu
+CASES = [c for c in golden_cases() if c.startswith("rel_als_")]
+
+
+def blocks_of(z):
+    return [(z["rel%d_entries" % i], z["rel%d_row_ptr" % i], int(z["rel%d_num_feature" % i])) for i in range(int(z["n_relations"]))]
+
+
+def test_device_expansion_is_the_flat_design_matrix():
+    from libfm_amd import capi
+    (ent, rp, y), blocks, maps = datagen.block_structured(40, 25, 300, seed=5)
+    n_main = 7
+    flat_ent, flat_rp, offs = datagen.expand_blocks(ent, rp, blocks, maps, n_main)
+    n = offs[-1] + blocks[-1][2]
+    h = capi.Handle(n, 4)
+    h.upload_block_rows(0, ent, rp, y, [(be, bp, mp, off) for (be, bp, _), mp, off in zip(blocks, maps, offs)])
+    got_ent, got_rp, got_y = h.download_rows(0)
+    assert len(got_y) == 300 and len(got_ent) == len(flat_ent)
+    assert np.array_equal(got_rp, flat_rp) and np.array_equal(got_ent, flat_ent) and np.array_equal(got_y, y)
+    # malformed mapping -> loud error
+    bad = maps[0].copy(); bad[3] = 10 ** 6
+    with pytest.raises(capi.FmxError):
+        h.upload_block_rows(1, ent, rp, y, [(blocks[0][0], blocks[0][1], bad, offs[0])])
+    h.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_als_on_relations_matches_reference(oracle, name):
+    from libfm_amd import data as D
+    from libfm_amd import learner as L
+    g = Golden(name)
+    z = g.z
+    fm = L.FMModel()
+    fm.num_attribute, fm.num_factor, fm.k0, fm.k1 = g.n, g.k, bool(g.k0), bool(g.k1)
+    fm.reg0, fm.regw, fm.regv = g.reg
+    m = g.model(oracle, "init")
+    fm.w0, fm.w, fm.v = m.w0, m.w.copy(), m.v.copy()
+    l = L.FMLearnALS()
+    l.fm, l.task, l.num_iter, l.min_target, l.max_target = fm, g.task, g.iters, g.min_target, g.max_target
+    l.w_lambda, l.v_lambda = g.reg[1], g.reg[2]
+    if "group" in z.files:
+        l.groups, l.w_lambda, l.v_lambda = z["group"], z["w_lambda_g"], z["v_lambda_g"]
+    l.out = io.StringIO()
+    train = L.Data(z["train_entries"], z["train_row_ptr"], g.train_target)
+    test = L.Data(z["test_entries"], z["test_row_ptr"], g.test_target)
+    off = int(z["n_main"])
+    for i, (be, bp, nf) in enumerate(blocks_of(z)):
+        rel = D.Relation(be, bp, nf)
+        train.add_relation(rel, z["rel%d_train" % i], off)
+        test.add_relation(rel, z["rel%d_test" % i], off)
+        off += nf
+    l.init()
+    l.learn(train, test)
+    assert abs(l.fm.w0 - float(z["final_w0"])) <= 1e-4 * abs(float(z["final_w0"])) + 2e-5
+    np.testing.assert_allclose(l.fm.w, z["final_w"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(l.fm.v, z["final_v"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(l.predict(test), z["pred_out"], rtol=1e-4, atol=5e-5)
+    l.close()
+
+
+def test_cli_relation_flag(tmp_path, oracle):
+    """`-method als -relation a,b` with the reference's file set (<a>.xt, <a>.train, <a>.test, <a>.groups) and the same
+    seed as the reference run behind the fixture -> the same -out predictions."""
+    from libfm_amd import cli
+    from libfm_amd import data as D
+    g = Golden("rel_als_cls_groups")
+    z = g.z
+    trf, tef = str(tmp_path / "tr.libfm"), str(tmp_path / "te.libfm")
+    oracle.Data(z["train_entries"], z["train_row_ptr"], z["train_target"]).write_libsvm(trf)
+    oracle.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(tef)
+    names = []
+    for i, (be, bp, nf) in enumerate(blocks_of(z)):
+        px = str(tmp_path / ("rel%d" % i))
+        et, cp = D.transpose(be, bp, nf)
+        D.write_binary_matrix(px + ".xt", et, cp, num_cols=len(bp) - 1)
+        np.savetxt(px + ".train", z["rel%d_train" % i], fmt="%d")
+        np.savetxt(px + ".test", z["rel%d_test" % i], fmt="%d")
+        np.savetxt(px + ".groups", z["rel%d_groups" % i], fmt="%d")
+        names.append(px)
+    reg = [float(z["reg"][0])] + [float(x) for x in z["w_lambda_g"]] + [float(x) for x in z["v_lambda_g"]]
+    out = str(tmp_path / "pred")
+    argv = ["-task", "c", "-train", trf, "-test", tef, "-dim", "%d,%d,%d" % (g.k0, g.k1, g.k), "-iter", str(g.iters),
+            "-method", "als", "-relation", ",".join(names), "-regular", ",".join(repr(x) for x in reg),
+            "-init_stdev", repr(float(z["init_stdev"])), "-seed", str(int(z["seed"])), "-out", out]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert cli.main(argv) == 0
+    assert "#relations: 2" in buf.getvalue() and "#groups=5" in buf.getvalue()
+    np.testing.assert_allclose(np.loadtxt(out), z["pred_out"], rtol=1e-4, atol=5e-5)
+    assert os.path.exists(out)
