@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 131072 sharded); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=256)
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="sharded: do not overlap the all-reduce of batch b+1 with the update of batch b (exact batch rule instead of "
+                         "the one-batch-stale pipelined rule; libfm_amd/distributed.py)")
     ap.add_argument("--no-bias-lag", action="store_true", help="minibatch: keep the w0 recurrence on the critical path (exact chunk coupling)")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -191,7 +194,7 @@ def main():
     else:
         from libfm_amd.distributed import ShardedSGD
         batch = args.batch or 131072
-        drv = ShardedSGD(h, 0, args.rows, batch, args.w0_chunk, apply_, lagf, args.backend)
+        drv = ShardedSGD(h, 0, args.rows, batch, args.w0_chunk, apply_, lagf, args.backend, pipeline=args.pipeline)
 
         def step(timed):
             drv.epoch()
@@ -236,6 +239,20 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_example": per_ex, "examples_per_launch": rows_per_launch,
                     "avg_launch_ms": round(avg * 1e3, 4), "launches": main_launches}
+        exchange = None
+        if sharded:
+            # no per-launch timing in the multi-process driver (it would serialise the overlap): whole-step accounting.
+            # HBM side, per GPU: the step's two passes over the LOCAL entries (gather + segmented update).
+            per_ex = algorithmic_bytes(args.k, args.nnz, "rowsums") + algorithmic_bytes(args.k, args.nnz, "apply")
+            achieved = value * per_ex / world / 1e9
+            roof = {"bound": "hbm", "kernel": "k_rowsums + k_apply_seg (whole step, per GPU)", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_example": per_ex, "examples_per_launch": rows_per_launch}
+            # wire side: ONE all-reduce of [batch][KP + 1] fp32 per batch; algbw = payload bytes reduced per second
+            wire = 4 * (info.k_padded + 1)
+            exchange = {"collective": "all_reduce(sum) fp32, one per batch", "bytes_per_example": wire,
+                        "payload_MB_per_batch": round(wire * rows_per_launch / 1e6, 2),
+                        "algbw_GBps": round(value * wire / 1e9, 2), "pipelined": bool(args.pipeline), "backend": args.backend}
         out = {
             "metric": "SGD training examples/sec at k=%d, nnz=%d, %.0e feat" % (args.k, args.nnz, args.n),
             "value": round(value, 1), "unit": "examples/s", "n_gpus": world, "steps": args.steps,
@@ -245,13 +262,15 @@ def main():
             "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
-                       "w0_chunk": args.w0_chunk, "bias_lag": bool(lagf), "sharding": "features mod %d" % world if world > 1 else "none",
+                       "w0_chunk": args.w0_chunk, "bias_lag": bool(lagf), "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
         if cpu_ref is not None:
             out["cpu_reference"] = cpu_ref
+        if exchange is not None:
+            out["exchange"] = exchange
     h.close()
     if sharded:
         dist.destroy_process_group()

@@ -161,9 +161,28 @@ void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double l
   fmo_sgd_epoch_minibatch_ex(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, 0);
 }
 
+static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double learn_rate, double min_target, double max_target,
+                           uint32_t batch, uint32_t w0_chunk, int bias_lag, int stale);
+
 void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                                 double min_target, double max_target,
                                 uint32_t batch, uint32_t w0_chunk, int bias_lag) {
+  minibatch_impl(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, bias_lag, 0);
+}
+
+/* the pipelined multi-GPU schedule (libfm_amd/distributed.py, pipeline=True): the sums of batch b+1 are gathered
+ * BEFORE the update of batch b is applied (their all-reduce overlaps that update), so step 1 of batch b reads the
+ * parameters as they were before the update of batch b-1 was applied ("one batch stale"); steps 2 and 3 are
+ * unchanged (current w0, current w / v in the gradient and the regulariser).  Stale by one only inside an epoch:
+ * the epoch drains, the next one starts from the final parameters. */
+void fmo_sgd_epoch_minibatch_pipelined(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                                       double min_target, double max_target,
+                                       uint32_t batch, uint32_t w0_chunk, int bias_lag) {
+  minibatch_impl(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, bias_lag, 1);
+}
+
+static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double learn_rate, double min_target, double max_target,
+                           uint32_t batch, uint32_t w0_chunk, int bias_lag, int stale) {
   const int k = m->k;
   const size_t n = (size_t)m->n;
   if (batch == 0 || batch > d->n_rows) batch = d->n_rows;
@@ -175,20 +194,25 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
   double *sum_sqr = (double *)malloc(sizeof(double) * kk);
   double *dw = (double *)calloc(n, sizeof(double));
   double *dv = (double *)calloc(n * kk, sizeof(double));
+  /* stale: the parameters before the latest update (what the early gather of the next batch sees) */
+  double *w_prev = stale ? (double *)malloc(sizeof(double) * (n ? n : 1)) : NULL;
+  double *v_prev = stale ? (double *)malloc(sizeof(double) * ((n * kk) > 0 ? n * kk : 1)) : NULL;
 
   for (uint32_t r0 = 0; r0 < d->n_rows; r0 += batch) {
     uint32_t nb = (d->n_rows - r0 < batch) ? (d->n_rows - r0) : batch;
+    const double *w_src = (stale && r0 > 0) ? w_prev : m->w;
+    const double *v_src = (stale && r0 > 0) ? v_prev : m->v;
     /* step 1: sums from batch-start parameters (fm_model.h:110-126 without the bias) */
     for (uint32_t e = 0; e < nb; e++) {
       const fmo_entry *row = d->entries + d->row_ptr[r0 + e];
       uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
       double res = 0;
       if (m->k1)
-        for (uint32_t i = 0; i < size; i++) res += m->w[row[i].id] * row[i].value;
+        for (uint32_t i = 0; i < size; i++) res += w_src[row[i].id] * row[i].value;
       for (int f = 0; f < k; f++) {
         double s = 0, q = 0;
         for (uint32_t i = 0; i < size; i++) {
-          double dd = V(m, f, row[i].id) * row[i].value;
+          double dd = v_src[(size_t)f * n + row[i].id] * row[i].value;
           s += dd;
           q += dd * dd;
         }
@@ -215,6 +239,10 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
         if (nc == 1 && m->k0) m->w0 -= learn_rate * (me + m->reg0 * m->w0);  /* literal form at chunk 1 */
       }
       if (m->k0 && nc != 1) m->w0 -= learn_rate * acc;
+    }
+    if (stale) {                                               /* what batch b+1's early gather will see */
+      memcpy(w_prev, m->w, sizeof(double) * n);
+      memcpy(v_prev, m->v, sizeof(double) * n * (size_t)k);
     }
     /* step 3: per-occurrence deltas from batch-start w, v (fm_sgd.h:38-50) */
     for (uint32_t e = 0; e < nb; e++) {
@@ -247,7 +275,7 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
       }
     }
   }
-  free(S); free(rest); free(mult); free(sum_sqr); free(dw); free(dv);
+  free(S); free(rest); free(mult); free(sum_sqr); free(dw); free(dv); free(w_prev); free(v_prev);
 }
 
 /* ------------------------------- SGDA ------------------------------- */

@@ -106,6 +106,11 @@ void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double l
 void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                                 double min_target, double max_target,
                                 uint32_t batch, uint32_t w0_chunk, int bias_lag);
+/* the pipelined multi-GPU schedule: step 1 of batch b reads the parameters as they were BEFORE the update of batch
+ * b-1 was applied (the gather of batch b overlaps the exchange / update of batch b-1); everything else as above. */
+void fmo_sgd_epoch_minibatch_pipelined(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                                       double min_target, double max_target,
+                                       uint32_t batch, uint32_t w0_chunk, int bias_lag);
 
 /* ---------------- SGDA (adaptive regularisation, Rendle WSDM'12) ---------------------------------------------
  * fm_learn_sgd_element_adapt_reg (src/libfm/src/fm_learn_sgd_element_adapt_reg.h).

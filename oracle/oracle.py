@@ -68,6 +68,7 @@ def lib():
         L.fmo_sgd_epoch_online.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double]
         L.fmo_sgd_epoch_minibatch.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32]
         L.fmo_sgd_epoch_minibatch_ex.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_int]
+        L.fmo_sgd_epoch_minibatch_pipelined.argtypes = L.fmo_sgd_epoch_minibatch_ex.argtypes
         L.fmo_multiplier.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.fmo_multiplier.restype = C.c_double
         L.fmo_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -210,9 +211,11 @@ def sgd_epoch_online(m, d, task, lr, min_target, max_target):
     m.w0 = cm.w0
 
 
-def sgd_epoch_minibatch(m, d, task, lr, min_target, max_target, batch, w0_chunk, bias_lag=False):
+def sgd_epoch_minibatch(m, d, task, lr, min_target, max_target, batch, w0_chunk, bias_lag=False, pipelined=False):
+    """pipelined: the multi-GPU overlap schedule -- the sums of a batch are gathered one update early (fm_oracle.h)"""
     cm, cd = m._c(), d._c()
-    lib().fmo_sgd_epoch_minibatch_ex(C.byref(cm), C.byref(cd), task, lr, min_target, max_target, batch, w0_chunk, int(bias_lag))
+    fn = lib().fmo_sgd_epoch_minibatch_pipelined if pipelined else lib().fmo_sgd_epoch_minibatch_ex
+    fn(C.byref(cm), C.byref(cd), task, lr, min_target, max_target, batch, w0_chunk, int(bias_lag))
     m.w0 = cm.w0
 
 
