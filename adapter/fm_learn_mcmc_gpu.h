@@ -1,13 +1,19 @@
-// adapter/fm_learn_mcmc_gpu.h -- REFERENCE-SIDE binding of the ALS learner (`-method als` = MCMC without sampling,
-// src/libfm/libfm.cpp:135-139) to libfmx.  Same rules as fm_learn_sgd_gpu.h: include it in the one translation unit
-// that includes the reference headers, after fm_learn_mcmc_simultaneous.h.
+// adapter/fm_learn_mcmc_gpu.h -- REFERENCE-SIDE binding of the ALS / MCMC learner (`-method als` = MCMC without
+// sampling, src/libfm/libfm.cpp:135-139; `-method mcmc` = Gibbs sampling with hyper-priors) to libfmx.  Same rules as
+// fm_learn_sgd_gpu.h: include it in the one translation unit that includes the reference headers, after
+// fm_learn_mcmc_simultaneous.h.
 //
 // It derives from fm_learn_mcmc so that main()'s casts and field writes keep working unchanged
 // (libfm.cpp:284-290: num_iter, num_eval_cases, do_sample, do_multilevel; :335-352: w_lambda / v_lambda from
 // -regular) and replaces the iteration loop of fm_learn_mcmc_simultaneous::_learn (fm_learn_mcmc_simultaneous.h:
-// 56-270) by fmx_als_begin / fmx_als_sweep.  Only do_sample = 0, do_multilevel = 0.  Attribute groups (`-meta`) are
-// passed through: meta->attr_group -> fmx_set_groups, w_lambda(g) / v_lambda(g,f) -> the opts tables.  Relations
-// (`-relation`, Data::relation) go to fmx_upload_block_rows, which joins the blocks on the device.
+// 56-270) by fmx_als_begin / fmx_als_sweep.  Attribute groups (`-meta`) are passed through: meta->attr_group ->
+// fmx_set_groups, w_lambda(g) / v_lambda(g,f) / w_mu(g) / v_mu(g,f) -> the opts tables.  Relations (`-relation`,
+// Data::relation) go to fmx_upload_block_rows, which joins the blocks on the device.
+// With do_multilevel the hyper-prior draws (draw_alpha :911-939, draw_w_lambda / draw_w_mu :941-1017, draw_v_lambda /
+// draw_v_mu :1019-1097) stay on the host, in the reference's order and with the reference's own ran_gamma /
+// ran_gaussian (src/util/random.h), fed by the per-group statistics fmx_als_moments reduces on the device; with
+// do_sample the coordinate draws happen on the device from a counter-based generator (statistical, not bitwise,
+// agreement with the stock sampler -- a parallel sampler cannot replay one sequential libc rand() stream).
 #ifndef FM_LEARN_MCMC_GPU_H_
 #define FM_LEARN_MCMC_GPU_H_
 
@@ -19,11 +25,11 @@
 class fm_learn_als_gpu : public fm_learn_mcmc {
  public:
   int gpu_device;
-  fm_learn_als_gpu() : gpu_device(-1), h(NULL) {}
+  unsigned long long gpu_seed;                             // seed of the device-side coordinate draws (do_sample); 0 = derive
+  fm_learn_als_gpu() : gpu_device(-1), gpu_seed(0), h(NULL) {}   // it from libc rand(), i.e. from main's -seed (libfm.cpp:115-116)
   virtual ~fm_learn_als_gpu() { if (h) fmx_destroy(h); }
 
   virtual void learn(Data& train, Data& test) {            // fm_learn_mcmc::learn (:1160-1201) + _learn
-    if (do_sample || do_multilevel) throw "fm_learn_als_gpu: only -method als (no sampling) is bound";
     pred_sum_all.setSize(test.num_cases); pred_sum_all_but5.setSize(test.num_cases); pred_this.setSize(test.num_cases);
     pred_sum_all.init(0.0); pred_sum_all_but5.init(0.0); pred_this.init(0.0);
     fmx_config c;
@@ -39,14 +45,26 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
     check(fmx_als_begin(h, 0));
     fmx_als_opts o;
     memset(&o, 0, sizeof(o));
-    o.alpha = alpha_0; o.w_mu = mu_0; o.v_mu = mu_0;                       // draw_alpha / draw_*_mu without multilevel
-    o.w_lambda = w_lambda(0); o.v_lambda = fm->num_factor > 0 ? v_lambda(0, 0) : 0.0;
-    if (G > 1) {                                                           // w_lambda(g), v_lambda(g,f): DVector[G], DMatrix[G][k]
-      o.num_groups = G; o.w_lambda_g = w_lambda.value;
-      o.v_lambda_gf = fm->num_factor > 0 ? v_lambda.value[0] : NULL;
-    }
+    const int k = fm->num_factor;
+    if (do_sample && gpu_seed == 0) gpu_seed = (((unsigned long long)rand()) << 31) ^ (unsigned long long)rand() ^ 0x9E3779B97F4A7C15ULL;
+    std::vector<double> mom(2 + (size_t)2 * G * (1 + k));
     std::vector<double> p(test.num_cases);
     for (uint i = 0; i < num_iter; i++) {
+      if (do_multilevel) {                                                   // the prior draws of draw_all (:433-452, :519-527)
+        check(fmx_als_moments(h, &mom[0]));
+        draw_priors_from_moments(mom, train.num_cases);
+      } else {
+        alpha = alpha_0; w_mu.init(mu_0); if (k > 0) v_mu.init(mu_0);        // draw_alpha / draw_*_mu without multilevel
+      }
+      o.alpha = alpha; o.do_sample = do_sample ? 1 : 0; o.seed = (uint64_t)gpu_seed;
+      o.w_mu = w_mu(0); o.w_lambda = w_lambda(0);
+      o.v_mu = k > 0 ? v_mu(0, 0) : 0.0; o.v_lambda = k > 0 ? v_lambda(0, 0) : 0.0;
+      if (G > 1) {                                                           // DVector[G], DMatrix[G][k]: the reference's own storage
+        o.num_groups = G; o.w_lambda_g = w_lambda.value; o.w_mu_g = w_mu.value;
+        o.v_lambda_gf = k > 0 ? v_lambda.value[0] : NULL; o.v_mu_gf = k > 0 ? v_mu.value[0] : NULL;
+      } else {
+        o.v_lambda_f = k > 0 ? v_lambda.value[0] : NULL; o.v_mu_f = k > 0 ? v_mu.value[0] : NULL;
+      }
       fmx_als_stats st;
       check(fmx_als_sweep(h, &o, &st));
       check(fmx_predict(h, 1, p.empty() ? NULL : &p[0]));
@@ -76,6 +94,40 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
  protected:
   fmx_handle h;
   void check(int rc) { if (rc != FMX_OK) throw std::string(fmx_last_error(h)); }
+
+  // mom = fmx_als_moments: {sum e^2, sum e} then [1 + k][G][2] = per coordinate family and group {sum theta, sum theta^2}
+  void draw_priors_from_moments(const std::vector<double>& mom, uint num_train_total) {
+    const uint G = meta->num_attr_groups;
+    const int k = fm->num_factor;
+    {                                                                        // draw_alpha :911-939
+      const double alpha_n = alpha_0 + num_train_total, gamma_n = gamma_0 + mom[0];
+      const double a = ran_gamma(alpha_n / 2.0, gamma_n / 2.0);
+      if (!(std::isnan(a) || std::isinf(a))) alpha = a;
+    }
+    for (int fam = 0; fam <= k; fam++) {                                     // family 0 = w (:941-1017), 1+f = v_f (:1019-1097)
+      if (fam == 0 && !fm->k1) continue;
+      const double* m = &mom[2 + (size_t)fam * G * 2];
+      // all lambdas of the family first, then all mus -- and for v: draw_v_lambda() over every f, THEN draw_v_mu()
+      // (:519-521); both orders agree here because lambda(g,f) only needs mu(g,f) of the previous iteration
+      for (uint g = 0; g < G; g++) {
+        double& lam = (fam == 0) ? w_lambda(g) : v_lambda(g, fam - 1);
+        const double mu = (fam == 0) ? w_mu(g) : v_mu(g, fam - 1);
+        const double n_g = meta->num_attr_per_group(g);
+        // sum_j (theta_j - mu)^2 = sum theta^2 - 2 mu sum theta + n_g mu^2  (:987-992, :1067-1072)
+        const double gam = beta_0 * (mu - mu_0) * (mu - mu_0) + gamma_0 + (m[2 * g + 1] - 2 * mu * m[2 * g] + n_g * mu * mu);
+        const double l = ran_gamma((alpha_0 + n_g + 1) / 2.0, gam / 2.0);
+        if (!(std::isnan(l) || std::isinf(l))) lam = l;
+      }
+      for (uint g = 0; g < G; g++) {
+        double& mu = (fam == 0) ? w_mu(g) : v_mu(g, fam - 1);
+        const double lam = (fam == 0) ? w_lambda(g) : v_lambda(g, fam - 1);
+        const double n_g = meta->num_attr_per_group(g);
+        const double mean = (m[2 * g] + beta_0 * mu_0) / (n_g + beta_0);   // :946-953, :1026-1033
+        const double x = ran_gaussian(mean, std::sqrt(1.0 / ((n_g + beta_0) * lam)));
+        if (!(std::isnan(x) || std::isinf(x))) mu = x;
+      }
+    }
+  }
   // ALS data sets are loaded transposed-only by main (has_x = false, libfm.cpp:143-147): rebuild rows from X^T
   struct Rows { std::vector<uint64> row_ptr; std::vector< sparse_entry<DATA_FLOAT> > ent; };
   static void rows_from_xt(LargeSparseMatrix<DATA_FLOAT>* xt, uint num_cases, Rows& out) {

@@ -213,8 +213,11 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
                    h->tb.V + f, h->tb.rs, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
                    opts->seed, (uint64_t)(a.iter * 1024 + f));
     }
-    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.V + f, h->tb.rs, v_lambda, v_mu, h->grp,
-                       opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 512 + f));
+  }
+  if (h->cfg.num_factor > 0) {                             // empty-row draws of every factor (:586-595) in one pass
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_unseen_v<KP>), (h->n_local + Map<KP>::EPI - 1) / Map<KP>::EPI, st, a.seen, h->n_local,
+                                       h->tb, h->cfg.num_factor, a.prior, NG, h->grp, opts->do_sample, opts->seed,
+                                       (uint64_t)(a.iter * 1024 + 512)));
   }
   HIPCHK(h, hipGetLastError());
   // full re-prediction (fm_learn_mcmc_simultaneous.h:122), train metric and new residuals (:139-196)

@@ -366,4 +366,37 @@ k_als_unseen(const uint8_t* __restrict__ seen, uint64_t n_local, float* __restri
     }
 }
 
+// the same for ALL factors of the unseen features in one pass over the parameter rows (one launch per sweep instead of
+// one per factor: at n = 1e8 the per-factor form re-reads seen[] and scatters 4-byte writes k times).  Legal because an
+// unseen feature's draw depends on nothing but its prior (no data rows), and the priors of a sweep are fixed before
+// the sweep starts (the hyper-prior statistics are taken at sweep start).  prior: [1 + k][2][G] (row 1+f: lambda, mu).
+// Random stream of (f, j) = the per-factor kernel's: stream0 + f.
+template <int KP>
+__global__ void __launch_bounds__(256)
+k_als_unseen_v(const uint8_t* __restrict__ seen, uint64_t n_local, const Tab tb, int k, const double* __restrict__ prior, uint32_t G,
+               const uint32_t* __restrict__ grp, int do_sample, uint64_t seed, uint64_t stream0) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  const uint32_t lane = threadIdx.x & 63u, sub = lane / LPR, fl = lane % LPR;
+  const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  for (uint64_t j0 = wave0 * EPI; j0 < n_local; j0 += nwaves * EPI) {
+    const uint64_t j = j0 + sub;
+    if (j >= n_local || seen[j]) continue;
+    const uint32_t g = grp ? grp[j] : 0u;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+      const int f = (int)fl * VEC + v;
+      if (f >= k) continue;
+      const double* row = prior + (size_t)(1 + f) * 2 * G;
+      const double lambda = row[g], mu = row[G + g];
+      const double sigma_sqr = 1.0 / lambda;
+      double nt;
+      if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
+      else nt = do_sample ? mu + sqrt(sigma_sqr) * gauss_hash(seed, stream0 + (uint64_t)f, j) : mu;
+      if (isnan(nt) || isinf(nt)) continue;
+      tb.V[(size_t)j * tb.rs + f] = (float)nt;
+    }
+  }
+}
+
 }  // namespace fmx

@@ -13,6 +13,8 @@
 //   ref_harness sgd_gpu <same arguments as sgd> [mode 0|1|2] [batch] [w0_chunk]
 //                    (same driver, but the learner is adapter/fm_learn_sgd_gpu.h -> libfmx.so; needs a GPU)
 //   ref_harness sgda <same arguments as sgd> <validation>   (fm_learn_sgd_element_adapt_reg; also dumps .reg.txt: reg_w, reg_v[f])
+//   ref_harness sgda_gpu <same arguments as sgda>           (the learner is fm_learn_sgda_gpu of adapter/fm_learn_sgd_gpu.h; needs a GPU)
+//   ref_harness mcmc_gpu <same arguments as mcmc>           (Gibbs sampling through adapter/fm_learn_mcmc_gpu.h; needs a GPU)
 //   ref_harness als_gpu <same arguments as als>             (the learner is adapter/fm_learn_mcmc_gpu.h -> libfmx.so; needs a GPU)
 //   ref_harness als  <train> <test> <task r|c> <k0> <k1> <k> <iters> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
 //   ref_harness mcmc <train> <test> <task r|c> <k0> <k1> <k> <iters> <init_stdev> <seed> <out_prefix>
@@ -133,10 +135,13 @@ int main(int argc, char** argv) {
     int k0 = atoi(argv[a++]), k1 = atoi(argv[a++]), k = atoi(argv[a++]);
     int iters = atoi(argv[a++]);
     double lr = 0, reg0 = 0, regw = 0, regv = 0;
-    if (mode == "sgd" || mode == "sgd_gpu" || mode == "sgda") lr = atof(argv[a++]);
-    if (mode != "mcmc") { reg0 = atof(argv[a++]); regw = atof(argv[a++]); regv = atof(argv[a++]); }
-    const bool als_gpu = (mode == "als_gpu");
-    if (als_gpu) mode = "als";
+    if (mode == "sgd" || mode == "sgd_gpu" || mode == "sgda" || mode == "sgda_gpu") lr = atof(argv[a++]);
+    if (mode != "mcmc" && mode != "mcmc_gpu") { reg0 = atof(argv[a++]); regw = atof(argv[a++]); regv = atof(argv[a++]); }
+    const bool als_gpu = (mode == "als_gpu") || (mode == "mcmc_gpu");     // both through adapter/fm_learn_mcmc_gpu.h
+    if (mode == "als_gpu") mode = "als";
+    if (mode == "mcmc_gpu") mode = "mcmc";
+    const bool sgda_gpu = (mode == "sgda_gpu");
+    if (sgda_gpu) mode = "sgda";
     double init_stdev = atof(argv[a++]);
     long seed = atol(argv[a++]);
     std::string prefix = argv[a++];
@@ -220,7 +225,11 @@ int main(int argc, char** argv) {
       Data validation(0, true, false);
       validation.load(val_file);
       validation.relation.setSize(0);
-      Open<fm_learn_sgd_element_adapt_reg>* fml = new Open<fm_learn_sgd_element_adapt_reg>();
+      fm_learn_sgd_element_adapt_reg* fml;
+#ifdef FMX_WITH_GPU_ADAPTER
+      if (sgda_gpu) fml = new fm_learn_sgda_gpu(); else
+#endif
+      fml = new fm_learn_sgd_element_adapt_reg();
       fml->num_iter = iters;
       fml->validation = &validation;                           // libfm.cpp:279
       fml->fm = &fm; fml->max_target = train.max_target; fml->min_target = train.min_target; fml->meta = &meta;

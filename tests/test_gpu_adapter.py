@@ -120,3 +120,68 @@ def test_reference_driver_with_gpu_als_learner_on_relations(oracle, tmp_path):
     np.testing.assert_allclose(final.v, z["final_v"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(final.w, z["final_w"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(pred_out, z["pred_out"], rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("name", ["sgda_reg_ml", "sgda_cls_fields_groups"])
+def test_reference_driver_with_gpu_sgda_learner(oracle, name, tmp_path):
+    """adapter fm_learn_sgda_gpu (`-method sgda`): the reference's loaders / init / output code with the device learner
+    must land on the stock fm_learn_sgd_element_adapt_reg results, incl. the learned reg_w(g), reg_v(g,f)."""
+    if not os.path.exists(HARNESS):
+        pytest.skip("oracle/_ref/ref_harness_gpu not built (needs /root/reference at build time)")
+    O = oracle
+    g = Golden(name)
+    z = g.z
+    td = str(tmp_path)
+    f = [os.path.join(td, x) for x in ("train", "test", "val")]
+    O.Data(z["train_entries"], z["train_row_ptr"], z["train_target"]).write_libsvm(f[0])
+    O.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(f[1])
+    O.Data(z["val_entries"], z["val_row_ptr"], z["val_target"]).write_libsvm(f[2])
+    env = dict(os.environ)
+    if "group" in z.files:
+        with open(os.path.join(td, "meta"), "w") as fh:
+            fh.write("".join("%d\n" % x for x in z["group"]))
+        env["FMX_META"] = os.path.join(td, "meta")
+    pre = os.path.join(td, "out")
+    cfg = ["sgda_gpu", f[0], f[1], str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]), repr(g.lr),
+           "0", "0", "0", repr(float(z["init_stdev"])), int(z["seed"]), pre, f[2]]
+    r = subprocess.run([HARNESS] + [str(c) for c in cfg], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Training using self-adaptive-regularization SGD." in r.stdout and "#Iter=" in r.stdout
+    final = O.Model.from_dump(pre + ".final.bin")
+    np.testing.assert_allclose(final.v, z["final_v"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(final.w, z["final_w"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(np.loadtxt(pre + ".reg.txt"), z["regs"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(np.fromfile(pre + ".pred_out.bin", dtype=np.float64), z["pred_out"], rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("name,min_corr,max_rms", [("mcmc_reg_ml", 0.975, 0.14), ("mcmc_reg_ml_groups", 0.970, 0.155)])
+def test_reference_driver_with_gpu_mcmc_learner(oracle, name, min_corr, max_rms, tmp_path):
+    """`-method mcmc` through adapter/fm_learn_mcmc_gpu.h: hyper-prior draws on the host with the reference's own
+    ran_gamma / ran_gaussian from device-reduced per-group moments, coordinate draws on the device.  Statistical bar =
+    the reference's own seed-to-seed band against the fixture (tests/dev_mcmc_band.py and the same loop over the stock
+    harness): mcmc_reg_ml reference 0.988-0.990 / rms 0.093-0.101, ours 0.986-0.990 / 0.092-0.111; mcmc_reg_ml_groups
+    reference 0.980-0.983 / rms 0.120-0.130, ours 0.979-0.984 / 0.115-0.133 (and ours against ours 0.122-0.130)."""
+    if not os.path.exists(HARNESS):
+        pytest.skip("oracle/_ref/ref_harness_gpu not built (needs /root/reference at build time)")
+    O = oracle
+    g = Golden(name)
+    z = g.z
+    td = str(tmp_path)
+    trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, "out")
+    O.Data(z["train_entries"], z["train_row_ptr"], z["train_target"]).write_libsvm(trf)
+    O.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(tef)
+    env = dict(os.environ)
+    if "group" in z.files:
+        with open(os.path.join(td, "meta"), "w") as fh:
+            fh.write("".join("%d\n" % x for x in z["group"]))
+        env["FMX_META"] = os.path.join(td, "meta")
+    cfg = ["mcmc_gpu", trf, tef, str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]),
+           repr(float(z["init_stdev"])), int(z["seed"]), pre]
+    r = subprocess.run([HARNESS] + [str(c) for c in cfg], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    p = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+    ref, y = z["pred_out"], g.test_target.astype(np.float64)
+    rmse_ref, rmse = np.sqrt(np.mean((ref - y) ** 2)), np.sqrt(np.mean((p - y) ** 2))
+    assert abs(rmse - rmse_ref) < 0.03 * rmse_ref, (rmse, rmse_ref)
+    assert np.corrcoef(p, ref)[0, 1] > min_corr
+    assert np.sqrt(np.mean((p - ref) ** 2)) < max_rms
