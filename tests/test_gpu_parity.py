@@ -226,7 +226,7 @@ def test_hogwild_converges_like_the_reference(capi, oracle, apply):
 # ---------------------------------------------------------------------------------------------
 # long ragged rows (> 64 entries: more than one wavefront-wide chunk), k not a power of two
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k", [0, 3, 10, 20, 100])
+@pytest.mark.parametrize("k", [0, 3, 10, 20, 100, 200, 256])
 def test_odd_k_and_long_rows(capi, oracle, k):
     n = 500
     ent, row_ptr, y = datagen.ragged_real(n, 120, 150, seed=77 + k, classification=False)
