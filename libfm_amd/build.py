@@ -15,8 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 SRC = [os.path.join(CSRC, f) for f in ("fmx_core.hip", "fmx_sgd.hip", "fmx_als.hip")]
 DEPS = SRC + [os.path.join(CSRC, f) for f in ("fmx_internal.h", "fmx_kernels.h", "fmx_als_kernels.h")] + \
     [os.path.join(ROOT, "include", "fmx.h")]
-OUT = os.path.join(HERE, "libfmx.so")
-OBJ_DIR = os.path.join(HERE, "build")
+# experiments: FMX_DEFS="-DFMX_V_NT=1" FMX_OUT=libfmx_nt.so python -m libfm_amd.build --force ; run with FMX_LIB=<that file>
+EXTRA = os.environ.get("FMX_DEFS", "").split()
+OUT = os.path.join(HERE, os.environ.get("FMX_OUT", "libfmx.so"))
+OBJ_DIR = os.path.join(HERE, "build" + ("_" + os.environ["FMX_OUT"].replace(".", "_") if "FMX_OUT" in os.environ else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fvisibility=hidden",
          "-Wno-unused-result", "-Wno-unused-value"]
@@ -36,7 +38,7 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o") for s in SRC]
 
     def cc(pair):
-        cmd = [HIPCC] + FLAGS + ["-c", pair[0], "-o", pair[1]]
+        cmd = [HIPCC] + FLAGS + EXTRA + ["-c", pair[0], "-o", pair[1]]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
