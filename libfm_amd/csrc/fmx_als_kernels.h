@@ -266,6 +266,35 @@ template <int G> __device__ __forceinline__ double group_sum_f64(double x) {
   return x;
 }
 
+// cache policy of the sweep (FMX_ALS_NT bits; measured at n=1e7, k=64: bit 2 alone 0.257 -> 0.244 s per sweep, bit 1 hurts): 1 = the X^T entries are a stream (read once per
+// (factor, level) launch), 2 = the parameter scalars are one 4-byte touch per 128-B line of a table far larger than
+// any cache; both evict the e/q cache (16 B per row, the only data with reuse across launches) unless hinted away.
+#ifndef FMX_ALS_NT
+#define FMX_ALS_NT 2
+#endif
+__device__ __forceinline__ TEntry als_stream8(const TEntry* p) {
+#if (FMX_ALS_NT & 1)
+  const uint64_t u = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(p));
+  TEntry t; __builtin_memcpy(&t, &u, 8); return t;
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ float als_param_load(const float* p) {
+#if (FMX_ALS_NT & 2)
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void als_param_store(float* p, float v) {
+#if (FMX_ALS_NT & 2)
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <bool IS_V, int G>
 __global__ void __launch_bounds__(256)
 k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
@@ -288,10 +317,10 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
     const uint32_t a = seg_rel[s];
     const uint32_t b = have ? ((s + 1 < nseg_total) ? seg_rel[s + 1] : nnz) : a;
     float* pt = param + (size_t)j * pstride;
-    const double th = (double)(*pt);
+    const double th = (double)als_param_load(pt);
     double t_he = 0.0, t_hh = 0.0;
     for (uint32_t i = a + lane; i < b; i += G) {
-      const TEntry te = t_ent[i];
+      const TEntry te = als_stream8(t_ent + i);
       const double x = (double)te.x;
       const EQ c = eq[te.e];                                       // one 16-byte gather: e and q of the row
       double h;
@@ -311,21 +340,21 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
     if (isnan(nt) || isinf(nt)) continue;                          // keep the old value, caches untouched
     const float ntf = (float)nt;
     const double d = th - (double)ntf;                             // theta_old - theta (of the STORED value)
-    if (lane == 0) *pt = ntf;
+    if (lane == 0) als_param_store(pt, ntf);
     if (d != 0.0) {
       // update e (and q): one lane per (row, run of occurrences).  A row holding this feature more than once has its
       // occurrences adjacent (the sort is stable in row order); the first one walks the run sequentially exactly
       // like the reference loop (:839-846: q is updated between the occurrences), the others skip.  Rows are
       // disjoint between lanes and between the wavefronts of a level, so plain read-modify-writes suffice.
       for (uint32_t i = a + lane; i < b; i += G) {
-        const TEntry te = t_ent[i];
+        const TEntry te = als_stream8(t_ent + i);
         if (i > a && t_ent[i - 1].e == te.e) continue;
         EQ c = eq[te.e];
         double ec = c.e;
         if (IS_V) {
           double qc = c.q;
           for (uint32_t i2 = i; i2 < b; i2++) {
-            const TEntry t2 = t_ent[i2];
+            const TEntry t2 = als_stream8(t_ent + i2);
             if (t2.e != te.e) break;
             const double x = (double)t2.x;
             const double h = x * (qc - x * th);
@@ -335,7 +364,7 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
           c.q = qc;
         } else {
           for (uint32_t i2 = i; i2 < b; i2++) {
-            const TEntry t2 = t_ent[i2];
+            const TEntry t2 = als_stream8(t_ent + i2);
             if (t2.e != te.e) break;
             ec -= (double)t2.x * d;
           }
