@@ -14,6 +14,7 @@ int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0,
   if constexpr (VEC * 8 <= 128) { if (need <= 8) { FMX_LAUNCH_ZR(8); return FMX_OK; } }
   if constexpr (VEC * 16 <= 128) { if (need <= 16) { FMX_LAUNCH_ZR(16); return FMX_OK; } }
   if constexpr (VEC * 32 <= 128) { if (need <= 32) { FMX_LAUNCH_ZR(32); return FMX_OK; } }
+  if constexpr (VEC * 40 <= 128) { if (need <= 40) { FMX_LAUNCH_ZR(40); return FMX_OK; } }   // Criteo-shaped rows (39 fields)
   if constexpr (VEC * 64 <= 128) { if (need <= 64) { FMX_LAUNCH_ZR(64); return FMX_OK; } }
   // rows too long for the register file: the kernel's two-pass branch handles them (ZR = 8 instance)
   FMX_LAUNCH_ZR(8);
