@@ -120,7 +120,7 @@ def main():
                     help="testing: drive the multi-GPU code path (ShardedSGD + all-reduce) even with one rank")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 131072 sharded); hogwild: rows per launch (0: 262144)")
-    ap.add_argument("--w0-chunk", type=int, default=256)
+    ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default, 256 / hogwild 1024)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="sharded: do not overlap the all-reduce of batch b+1 with the update of batch b (exact batch rule instead of "
                          "the one-batch-stale pipelined rule; libfm_amd/distributed.py)")
@@ -262,7 +262,7 @@ def main():
             "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
-                       "w0_chunk": args.w0_chunk, "bias_lag": bool(lagf), "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
+                       "w0_chunk": args.w0_chunk or (1024 if args.mode == "hogwild" else 256), "bias_lag": bool(lagf), "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -87,7 +87,7 @@ typedef struct fmx_sgd_opts {
   int32_t  apply;           /* FMX_APPLY_* (MINIBATCH and HOGWILD) */
   uint32_t batch;           /* MINIBATCH: rows per minibatch, 0 = 16384.  HOGWILD: rows per launch during which
                                w0 is frozen (macro-batch), 0 = 262144 */
-  uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default (256) */
+  uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default (256; HOGWILD: 1024) */
   uint32_t flags;           /* FMX_FLAG_* */
   uint32_t reserved;
 } fmx_sgd_opts;
