@@ -194,7 +194,9 @@ def main():
     else:
         from libfm_amd.distributed import ShardedSGD
         batch = args.batch or 131072
-        drv = ShardedSGD(h, 0, args.rows, batch, args.w0_chunk, apply_, lagf, args.backend, pipeline=args.pipeline)
+        # 1024-example micro-chunks: the one-wavefront bias recurrence must stay clear of the 150-200 us a rank spends
+        # on a 131 072-example batch at P = 8 (scripts/gpu_shard_probe.py: 610 -> 684 M examples/s per rank)
+        drv = ShardedSGD(h, 0, args.rows, batch, args.w0_chunk or 1024, apply_, lagf, args.backend, pipeline=args.pipeline)
 
         def step(timed):
             drv.epoch()
@@ -262,7 +264,7 @@ def main():
             "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
-                       "w0_chunk": args.w0_chunk or (1024 if args.mode == "hogwild" else 256), "bias_lag": bool(lagf), "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
+                       "w0_chunk": args.w0_chunk or (1024 if (args.mode == "hogwild" or sharded) else 256), "bias_lag": bool(lagf), "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -190,6 +190,17 @@ __device__ __forceinline__ float multiplier(const Hyper& h, float p, float y) {
 
 // same multiplier with the hardware reciprocal (1 ulp) -- used on the serial w0 recurrence where the IEEE
 // division sequence sits on the critical path
+// the same with the task resolved at compile time: no branch between the elements of an unrolled block, so their LDS
+// reads and transcendentals overlap (k_scan)
+template <int TASK> __device__ __forceinline__ float multiplier_task(const Hyper& h, float p, float y) {
+  if constexpr (TASK == 0) {
+    p = fminf(h.max_target, p);
+    p = fmaxf(h.min_target, p);
+    return -(y - p);
+  } else {
+    return -y * (1.0f - __builtin_amdgcn_rcpf(1.0f + __expf(-y * p)));
+  }
+}
 __device__ __forceinline__ float multiplier_fast(const Hyper& h, float p, float y) {
   if (h.task == 0) {
     p = fminf(h.max_target, p);
@@ -383,7 +394,7 @@ __device__ __forceinline__ void scan_fetch_tile(const float* __restrict__ g_rest
   scan_fetch_array(g_rest, cnt, s_r, lane);
   scan_fetch_array(g_y, cnt, s_t, lane);
 }
-template <bool WRITE_MULT>
+template <bool WRITE_MULT, int TASK>
 __global__ void __launch_bounds__(64)
 k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
        Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
@@ -414,17 +425,19 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
       const uint32_t take = min(chunk - chunk_pos, tn - i);
       const float w0s = h.k0 ? (float)w0 : 0.f;
       uint32_t tt = 0;
-      for (; tt + 256 <= take; tt += 256) {                   // 4 independent elements per lane: LDS reads overlap
-        const uint32_t q = i + tt + lane;
-        const float m0 = multiplier_fast(h, w0s + sr[q], sy[q]);
-        const float m1 = multiplier_fast(h, w0s + sr[q + 64], sy[q + 64]);
-        const float m2 = multiplier_fast(h, w0s + sr[q + 128], sy[q + 128]);
-        const float m3 = multiplier_fast(h, w0s + sr[q + 192], sy[q + 192]);
+      for (; tt + 256 <= take; tt += 256) {                   // 4 independent elements per lane: reads first, then math
+        const uint32_t q = i + tt + lane;                     // (kept to 32 VGPRs: the wavefront must fit next to a
+        float m0 = sr[q], m1 = sr[q + 64], m2 = sr[q + 128], m3 = sr[q + 192];   // chip-filling gather)
+        const float y0 = sy[q], y1 = sy[q + 64], y2 = sy[q + 128], y3 = sy[q + 192];
+        m0 = multiplier_task<TASK>(h, w0s + m0, y0);
+        m1 = multiplier_task<TASK>(h, w0s + m1, y1);
+        m2 = multiplier_task<TASK>(h, w0s + m2, y2);
+        m3 = multiplier_task<TASK>(h, w0s + m3, y3);
         if (WRITE_MULT) { mult[t0 + q] = m0; mult[t0 + q + 64] = m1; mult[t0 + q + 128] = m2; mult[t0 + q + 192] = m3; }
         acc += (m0 + m1) + (m2 + m3);
       }
       for (tt += lane; tt < take; tt += 64) {
-        const float m = multiplier_fast(h, w0s + sr[i + tt], sy[i + tt]);
+        const float m = multiplier_task<TASK>(h, w0s + sr[i + tt], sy[i + tt]);
         if (WRITE_MULT) mult[t0 + i + tt] = m;
         acc += m;
       }

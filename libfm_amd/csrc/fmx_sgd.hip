@@ -129,10 +129,12 @@ done:
 static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
                        const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr) {
   if (hy.k0) {
-    if (mult) hipLaunchKernelGGL(k_scan<true>, dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy,
-                                 w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
-    else      hipLaunchKernelGGL(k_scan<false>, dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy,
-                                 w0_in ? w0_in : h->w0, w0_out ? w0_out : h->w0, mult);
+    const double* wi = w0_in ? w0_in : h->w0;
+    double* wo = w0_out ? w0_out : h->w0;
+#define FMX_SCAN(WM, TK) hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult)
+    if (hy.task == 0) { if (mult) FMX_SCAN(true, 0); else FMX_SCAN(false, 0); }
+    else              { if (mult) FMX_SCAN(true, 1); else FMX_SCAN(false, 1); }
+#undef FMX_SCAN
   } else if (mult) {
     hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
                        (const double*)nullptr, mult);
