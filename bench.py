@@ -226,6 +226,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    exact = None
+    if rank == 0 and not sharded and args.mode == "hogwild" and not args.no_cpu_baseline:
+        # secondary figure (not `value`): the deterministic MINIBATCH rule -- the mode the GPU parity tests hold to the
+        # oracle at 1e-4 -- on the same rows
+        eb = 131072
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, eb, 1024, capi.FLAG_BIAS_LAG)
+        h.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, eb, 1024, capi.FLAG_BIAS_LAG)
+        h.synchronize()
+        exact = {"mode": "minibatch (restated batch rule, segmented deterministic update, bias-lag)", "batch": eb, "w0_chunk": 1024,
+                 "value": round(3 * args.rows / (time.perf_counter() - t1), 1), "unit": "examples/s", "steps": 3}
+
     if rank == 0:
         value = args.steps * args.rows / elapsed
         roof = None
@@ -273,6 +287,8 @@ def main():
             out["cpu_reference"] = cpu_ref
         if exchange is not None:
             out["exchange"] = exchange
+        if exact is not None:
+            out["minibatch_exact"] = exact
     h.close()
     if sharded:
         dist.destroy_process_group()
