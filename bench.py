@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="testing: drive the multi-GPU code path (ShardedSGD + all-reduce) even with one rank")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
-    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 131072 sharded); hogwild: rows per launch (0: 262144)")
+    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 262144 sharded); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default, 256 / hogwild 1024)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="sharded: do not overlap the all-reduce of batch b+1 with the update of batch b (exact batch rule instead of "
@@ -193,7 +193,7 @@ def main():
         kind = "fused" if args.mode == "hogwild" else "apply"
     else:
         from libfm_amd.distributed import ShardedSGD
-        batch = args.batch or 131072
+        batch = args.batch or 262144                 # per-rank compute side: 691 (131 072) -> 765 M examples/s (262 144) at P = 8
         # 1024-example micro-chunks: the one-wavefront bias recurrence must stay clear of the 150-200 us a rank spends
         # on a 131 072-example batch at P = 8 (scripts/gpu_shard_probe.py: 610 -> 684 M examples/s per rank)
         drv = ShardedSGD(h, 0, args.rows, batch, args.w0_chunk or 1024, apply_, lagf, args.backend, pipeline=args.pipeline)

@@ -8,7 +8,9 @@ from libfm_amd import capi
 
 n, k, nnz, rows, B = 100_000_000, 64, 32, 1 << 22, 131072
 if len(sys.argv) > 3:
-    k = int(sys.argv[3])          # a factor slice of a 2-D shard grid: k / P_f factors per rank
+    k = int(sys.argv[3])
+if len(sys.argv) > 4:
+    B = int(sys.argv[4])          # a factor slice of a 2-D shard grid: k / P_f factors per rank
 chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 worlds = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8, 4, 2, 1]
 for world in worlds:
@@ -32,6 +34,6 @@ for world in worlds:
     for which in ("both", "partial", "finish"):
         epoch(which); st.synchronize(); h.synchronize()
         t0 = time.perf_counter(); epoch(which); st.synchronize(); h.synchronize(); res[which] = time.perf_counter() - t0
-    print("k=%d chunk=%d " % (k, chunk) + "world=%d: gather+update %.1f Mex/s (gather alone %.1f, update alone %.1f) per rank"
+    print("k=%d B=%d chunk=%d " % (k, B, chunk) + "world=%d: gather+update %.1f Mex/s (gather alone %.1f, update alone %.1f) per rank"
           % (world, rows / res["both"] / 1e6, rows / res["partial"] / 1e6, rows / res["finish"] / 1e6), flush=True)
     h.close()
