@@ -452,6 +452,71 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
   if (lane == 0) *w0_out = w0;
 }
 
+// k_scan4: the same recurrence with FOUR wavefronts (one per SIMD of a CU, each <= 32 VGPRs so that they still fit next
+// to a chip-filling gather) for micro-chunks that are multiples of 1024 examples: inside a chunk every multiplier
+// uses the same bias, so the four wavefronts evaluate 256 examples each in parallel and only the chunk sum crosses
+// wavefronts (LDS, one barrier per 1024 examples).  A single wavefront is VALU-bound at ~1.1 ns per example
+// (8 quarter-rate transcendentals per 256 examples), which capped a P = 8 rank at ~0.9 G examples/s.
+// Summation order: per wavefront as in k_scan, then the four partial sums in wavefront order (deterministic).
+template <bool WRITE_MULT, int TASK>
+__global__ void __launch_bounds__(256)
+k_scan4(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
+        Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
+  __shared__ float s_rest[2][SCAN_TILE];
+  __shared__ float s_y[2][SCAN_TILE];
+  __shared__ float s_part[2][4];
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the tile arithmetic in SGPRs
+  constexpr uint32_t QT = SCAN_TILE / 4;                         // every wavefront fetches its quarter of a tile
+  const uint32_t n_tiles = (n_rows + SCAN_TILE - 1) / SCAN_TILE;
+  double w0 = *w0_in;
+  float w0s = h.k0 ? (float)w0 : 0.f;
+  float chunk_acc = 0.f;
+  uint32_t chunk_pos = 0, pb = 0;
+  auto fetch = [&](uint32_t t, uint32_t buf) {
+    const uint32_t t0 = t * SCAN_TILE;
+    const uint32_t tn = min((uint32_t)SCAN_TILE, n_rows - t0);
+    const uint32_t q0 = wv * QT;
+    if (q0 < tn) scan_fetch_tile(rest + t0 + q0, target + t0 + q0, min(QT, tn - q0), s_rest[buf] + q0, s_y[buf] + q0, lane);
+  };
+  fetch(0, 0);
+  for (uint32_t t = 0; t < n_tiles; t++) {
+    const uint32_t t0 = t * SCAN_TILE;
+    const uint32_t tn = min((uint32_t)SCAN_TILE, n_rows - t0);
+    const uint32_t cur = t & 1u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's quarter of tile t has landed
+    __syncthreads();                                             // ... and everybody else's; tile t-1 is no longer read
+    if (t + 1 < n_tiles) fetch(t + 1, cur ^ 1u);
+    const float* sr = s_rest[cur];
+    const float* sy = s_y[cur];
+    for (uint32_t c0 = 0; c0 < tn; c0 += 1024) {
+      const uint32_t n_here = min(1024u, tn - c0);
+      const uint32_t q = c0 + wv * 256 + lane;
+      float acc = 0.f;                                        // two pairs, not four at once: <= 32 VGPRs (placement, see k_scan)
+#pragma unroll 1
+      for (uint32_t u = 0; u < 256; u += 128) {
+        float m0 = 0.f, m1 = 0.f;
+        if (q + u < tn)      { m0 = multiplier_task<TASK>(h, w0s + sr[q + u], sy[q + u]);           if (WRITE_MULT) mult[t0 + q + u] = m0; }
+        if (q + u + 64 < tn) { m1 = multiplier_task<TASK>(h, w0s + sr[q + u + 64], sy[q + u + 64]); if (WRITE_MULT) mult[t0 + q + u + 64] = m1; }
+        acc += m0 + m1;
+      }
+      const float part = wave_sum_dpp(acc);
+      if (lane == 0) s_part[pb][wv] = part;
+      __syncthreads();
+      chunk_acc += (s_part[pb][0] + s_part[pb][1]) + (s_part[pb][2] + s_part[pb][3]);
+      pb ^= 1u;
+      chunk_pos += n_here;
+      if (chunk_pos == chunk || t0 + c0 + n_here == n_rows) {
+        if (h.k0) w0 -= (double)h.lr * ((double)chunk_acc + (double)chunk_pos * (double)h.reg0 * (double)w0s);
+        w0s = h.k0 ? (float)w0 : 0.f;
+        chunk_acc = 0.f; chunk_pos = 0;
+      }
+    }
+  }
+  if (threadIdx.x == 0) *w0_out = w0;
+}
+
 // no bias: the multipliers are independent of each other
 static __global__ void __launch_bounds__(256)
 k_mult(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, Hyper h,

@@ -139,6 +139,33 @@ def test_minibatch_matches_restated_rule(capi, oracle, name, batch, chunk):
     h.close()
 
 
+@pytest.mark.parametrize("task,batch,chunk,lag", [(1, 5000, 1024, False), (1, 3000, 2048, True), (0, 4096, 1024, True),
+                                                  (0, 9001, 4096, False), (1, 1500, 1024, True)])
+def test_minibatch_kilo_chunks(capi, oracle, task, batch, chunk, lag):
+    """micro-chunks that are multiples of 1024 examples take the four-wavefront recurrence kernel (k_scan4): ragged
+    batch tails, batches that are not multiples of the tile (4096) or of the chunk, both tasks, with / without bias-lag."""
+    n, nnz, rows, k = 4000, 6, 9001, 8
+    ent, row_ptr, y = datagen.onehot_fields(n - n % nnz, nnz, rows, seed=17 + batch, classification=(task == 1))
+    if task == 0:
+        y = (y * 0.5 + 0.1).astype(np.float32)
+    d = oracle.Data(ent, row_ptr, y)
+    m = oracle.Model(n, k, True, True, 0.002, 0.001, 0.003)
+    m.v[:] = oracle.init_values(3, n, k, 0.05)
+    m.w0 = 0.05
+    lo, hi = float(y.min()), float(y.max())
+    h = capi.Handle(n, k, True, True, task, 0.002, 0.001, 0.003, 0.01, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, row_ptr, y)
+    for _ in range(2):
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, chunk, capi.FLAG_BIAS_LAG if lag else 0)
+        oracle.sgd_epoch_minibatch(m, d, task, 0.01, lo, hi, batch, chunk, lag)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    h.close()
+
+
 @pytest.mark.parametrize("name,batch,chunk", [("sgd_reg_ml", 64, 16), ("sgd_cls_ragged", 32, 8), ("sgd_cls_zipf_k32", 100, 10),
                                               ("sgd_reg_ml", 1, 1), ("sgd_cls_k64", 300, 64)])
 def test_minibatch_bias_lag_matches_restated_rule(capi, oracle, name, batch, chunk):
