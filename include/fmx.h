@@ -196,7 +196,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_epoch_st
 
 /* ---- minibatch step split at the exchange point, for one-process-per-GPU drivers --------------
  * partial: floats per batch = fmx_partial_floats(h, batch): [batch][KP] partial factor sums followed by
- *          [batch] scalars (linear term - 0.5*sum of squares).  d_partial is DEVICE memory.
+ *          [batch] scalars (linear term - 0.5*sum of squares).  d_partial is DEVICE memory, 16-byte aligned.
  * The driver all-reduces (sum) d_partial across the feature shards (RCCL), then calls finish on every
  * rank: multipliers + w0 micro-chunks (identical on all ranks) and the scatter-add into the local shard.
  * `stream` is a hipStream_t (NULL = the handle's own stream). */

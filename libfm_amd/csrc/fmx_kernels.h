@@ -348,22 +348,46 @@ k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, u
 template <int KP>
 __global__ void __launch_bounds__(256)
 k_rest_from_partial(const float* __restrict__ S, const float* __restrict__ c, uint32_t n_rows, float* __restrict__ rest) {
-  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
-  const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
+  const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t e0 = wave0 * EPI; e0 < n_rows; e0 += nwaves * EPI) {
-    const uint32_t e = e0 + g;
-    float part = 0.f;
-    if (e < n_rows) {
-      float s[VEC];
-      load_vec<VEC>(S + (size_t)e * KP + f * VEC, s);
+  if constexpr (KP >= 4) {
+    // S is a dense [n_rows][KP] stream: 16-byte loads, KP/4 lanes per example, 4 loads in flight per lane
+    constexpr uint32_t L4 = (KP / 4 < 64) ? KP / 4 : 64;          // lanes that share one example
+    constexpr uint32_t R = KP / 4 / L4;                           // float4 per lane and example (KP > 256: not reached)
+    constexpr uint32_t EPW = 64 / L4;                             // examples per wave-wide load
+    constexpr uint32_t U = 4;
+    const uint32_t g = lane / L4, f = lane % L4;
+    for (uint32_t e0 = wave0 * EPW * U; e0 < n_rows; e0 += nwaves * EPW * U) {
+      float4 t[U][R];
 #pragma unroll
-      for (int v = 0; v < VEC; v++) part = fmaf(0.5f * s[v], s[v], part);
+      for (uint32_t u = 0; u < U; u++) {
+        const uint32_t e = e0 + u * EPW + g;
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++)
+          t[u][r] = (e < n_rows) ? reinterpret_cast<const float4*>(S + (size_t)e * KP)[f * R + r] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < U; u++) {
+        const uint32_t e = e0 + u * EPW + g;
+        float part = 0.f;
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++) {
+          part = fmaf(0.5f * t[u][r].x, t[u][r].x, part); part = fmaf(0.5f * t[u][r].y, t[u][r].y, part);
+          part = fmaf(0.5f * t[u][r].z, t[u][r].z, part); part = fmaf(0.5f * t[u][r].w, t[u][r].w, part);
+        }
+#pragma unroll
+        for (uint32_t o = 1; o < L4; o <<= 1) part += __shfl_xor(part, o);
+        if (e < n_rows && f == 0) rest[e] = part + c[e];
+      }
     }
+  } else {
+    for (uint32_t e = wave0 * 64 + lane; e < n_rows; e += nwaves * 64) {
+      float part = 0.f;
 #pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) part += __shfl_xor(part, o);
-    if (e < n_rows && f == 0) rest[e] = part + c[e];
+      for (int v = 0; v < KP; v++) { const float x = S[(size_t)e * KP + v]; part = fmaf(0.5f * x, x, part); }
+      rest[e] = part + c[e];
+    }
   }
 }
 

@@ -239,6 +239,7 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   Slot& s = h->slots[slot];
   if (row0 + n_rows > s.n_rows) return fail(h, FMX_E_ARG, "fmx_sgd_finish: rows outside slot");
   if (!d_partial) return fail(h, FMX_E_ARG, "fmx_sgd_finish: d_partial is NULL");
+  if (((uintptr_t)d_partial & 15u) != 0) return fail(h, FMX_E_ARG, "fmx_sgd_finish: d_partial must be 16-byte aligned");
   if (n_rows == 0) return FMX_OK;
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
@@ -270,6 +271,7 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
 
 int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, float* d_yhat, void* stream) {
   if (!h || !d_partial || !d_yhat) return FMX_E_ARG;
+  if (((uintptr_t)d_partial & 15u) != 0) return fail(h, FMX_E_ARG, "fmx_predict_finish: d_partial must be 16-byte aligned");
   { int _rc = lag_flush(h); if (_rc) return _rc; }
   if (n_rows == 0) return FMX_OK;
   HIPCHK(h, hipSetDevice(h->device));
