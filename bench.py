@@ -120,7 +120,7 @@ def main():
                     help="testing: drive the multi-GPU code path (ShardedSGD + all-reduce) even with one rank")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 262144 sharded); hogwild: rows per launch (0: 262144)")
-    ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default, 256 / hogwild 1024)")
+    ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default = 256 at lr 0.01, classification)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="sharded: do not overlap the all-reduce of batch b+1 with the update of batch b (exact batch rule instead of "
                          "the one-batch-stale pipelined rule; libfm_amd/distributed.py)")
@@ -194,9 +194,7 @@ def main():
     else:
         from libfm_amd.distributed import ShardedSGD
         batch = args.batch or 262144                 # per-rank compute side: 691 (131 072) -> 765 M examples/s (262 144) at P = 8
-        # 1024-example micro-chunks: the one-wavefront bias recurrence must stay clear of the 150-200 us a rank spends
-        # on a 131 072-example batch at P = 8 (scripts/gpu_shard_probe.py: 610 -> 684 M examples/s per rank)
-        drv = ShardedSGD(h, 0, args.rows, batch, args.w0_chunk or 1024, apply_, lagf, args.backend, pipeline=args.pipeline)
+        drv = ShardedSGD(h, 0, args.rows, batch, args.w0_chunk, apply_, lagf, args.backend, pipeline=args.pipeline)
 
         def step(timed):
             drv.epoch()
@@ -231,13 +229,13 @@ def main():
         # secondary figure (not `value`): the deterministic MINIBATCH rule -- the mode the GPU parity tests hold to the
         # oracle at 1e-4 -- on the same rows
         eb = 131072
-        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, eb, 1024, capi.FLAG_BIAS_LAG)
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, eb, 0, capi.FLAG_BIAS_LAG)
         h.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
-            h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, eb, 1024, capi.FLAG_BIAS_LAG)
+            h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, eb, 0, capi.FLAG_BIAS_LAG)
         h.synchronize()
-        exact = {"mode": "minibatch (restated batch rule, segmented deterministic update, bias-lag)", "batch": eb, "w0_chunk": 1024,
+        exact = {"mode": "minibatch (restated batch rule, segmented deterministic update, bias-lag)", "batch": eb, "w0_chunk": 256,
                  "value": round(3 * args.rows / (time.perf_counter() - t1), 1), "unit": "examples/s", "steps": 3}
 
     if rank == 0:
@@ -278,7 +276,7 @@ def main():
             "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
-                       "w0_chunk": args.w0_chunk or (1024 if (args.mode == "hogwild" or sharded) else 256), "bias_lag": bool(lagf), "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
+                       "w0_chunk": args.w0_chunk or 256, "bias_lag": bool(lagf), "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -87,7 +87,10 @@ typedef struct fmx_sgd_opts {
   int32_t  apply;           /* FMX_APPLY_* (MINIBATCH and HOGWILD) */
   uint32_t batch;           /* MINIBATCH: rows per minibatch, 0 = 16384.  HOGWILD: rows per launch during which
                                w0 is frozen (macro-batch), 0 = 262144 */
-  uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default (256; HOGWILD: 1024) */
+  uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default: the largest power of two <= 256
+                             * with learn_rate * chunk * curvature <= 1 (curvature 1 for regression, 1/4 for classification).
+                             * The reference moves w0 after every example (fm_sgd.h:34-37); a chunk is one batch step of
+                             * size learn_rate * chunk on the bias and oscillates when that product exceeds 2 / curvature. */
   uint32_t flags;           /* FMX_FLAG_* */
   uint32_t reserved;
 } fmx_sgd_opts;

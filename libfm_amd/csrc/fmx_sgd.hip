@@ -3,6 +3,19 @@
 #include "fmx_internal.h"
 
 namespace {
+// default micro-chunk of the bias recurrence.  The reference moves w0 after EVERY example (fm_sgd.h:34-37); summing the
+// multipliers of a chunk and applying them at once is a batch step of size lr * chunk on a coordinate whose curvature is
+// up to 1 (regression) or 1/4 (logistic) PER EXAMPLE, so lr * chunk * curvature must stay below 2 or the bias
+// oscillates with growing amplitude (observed: classification, lr = 0.02, chunk = 1024 -> w0 = +-3..6, accuracy 0.50).
+// Default: the largest power of two with lr * chunk * curvature <= 1, capped at 256.  An explicit w0_chunk is honoured.
+uint32_t default_w0_chunk(const fmx_config& c) {
+  const double curv = (c.task == FMX_TASK_REGRESSION) ? 1.0 : 0.25;
+  const double lim = (c.learn_rate > 0) ? 1.0 / (c.learn_rate * curv) : 256.0;
+  uint32_t chunk = 1;
+  while (chunk < 256u && (double)(chunk * 2) <= lim) chunk *= 2;
+  return chunk;
+}
+
 template <int KP, bool ATOMIC>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
                     const double* w0_in, float* rest_out) {
@@ -200,7 +213,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
                            const float* rest, const fmx_sgd_opts* opts, hipStream_t st,
                            hipEvent_t ev_a, hipEvent_t ev_b, int64_t seg_batch) {
   const Hyper hy = make_hyper(h->cfg);
-  const uint32_t chunk = (opts && opts->w0_chunk) ? opts->w0_chunk : 256u;
+  const uint32_t chunk = (opts && opts->w0_chunk) ? opts->w0_chunk : default_w0_chunk(h->cfg);
   const bool lag = opts && (opts->flags & FMX_FLAG_BIAS_LAG);
   int rc = lag ? lag_step(h, rest, s.target + row0, n_rows, chunk, hy, st)
                : launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
@@ -322,9 +335,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     // on a side stream WHILE launches i+1, i+2 stream; launch i reads the w0 produced by scan i-3 (a ring of 3
     // slots / rest buffers, so the result does not depend on timing and a slow scan has two launches of slack).
     const uint32_t M = opts->batch ? opts->batch : 262144u;
-    // the recurrence is one wavefront: 1024-example micro-chunks keep it clear of the launch time of short rows
-    // (k = 32, 16 entries: 466 -> 559 M examples/s); the multipliers of a launch use the frozen bias anyway
-    const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : 1024u;
+    const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : default_w0_chunk(h->cfg);
     const uint32_t cap = std::min<uint32_t>(M, s.n_rows);
     rc = ensure_scratch(h, 0, (size_t)cap * 3);
     if (rc) return rc;

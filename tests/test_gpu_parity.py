@@ -375,3 +375,25 @@ def test_errors(capi, oracle):
     with pytest.raises(capi.FmxError):
         h.upload_rows(0, ent, np.array([0, 1], dtype=np.uint64), np.zeros(1, dtype=np.float32))
     h.close()
+
+
+@pytest.mark.parametrize("task,lr", [(1, 0.05), (1, 0.2), (0, 0.02), (0, 0.1)])
+def test_default_bias_chunk_is_stable(capi, task, lr):
+    """w0_chunk = 0: the library picks the micro-chunk of the bias recurrence from learn_rate and the task's curvature
+    (lr * chunk * curvature <= 1).  A fixed large chunk makes the bias oscillate with growing amplitude (classification,
+    lr = 0.02, chunk = 1024: w0 = +-3..6, accuracy 0.50); the default must learn in every mode."""
+    n, k, nnz, rows = 64000, 8, 8, 60000
+    for mode, batch in ((capi.SGD_HOGWILD, 0), (capi.SGD_MINIBATCH, 8192)):
+        h = capi.Handle(n, k, True, True, task, 0.0, 0.0, 0.001, lr, -1.0, 1.0)
+        h.init_params(0.0, 0.05, 1)
+        h.synth_rows(0, 123, 0, rows, nnz)                    # targets +-1: learnable by memorising the features
+        for _ in range(4):
+            h.sgd_epoch(0, mode, capi.APPLY_DEFAULT, batch, 0)
+        ev = h.evaluate(0)
+        w0 = h.get_w0()
+        assert abs(w0) < 1.0, (mode, w0)
+        if task == 1:
+            assert ev.accuracy > 0.6, (mode, ev.accuracy)     # random-hash targets: slow to memorise, but far from the 0.50 of a runaway bias
+        else:
+            assert ev.rmse < 0.99, (mode, ev.rmse)
+        h.close()
