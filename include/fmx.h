@@ -106,6 +106,12 @@ typedef struct fmx_epoch_stats {
   double   device_seconds;  /* HIP-event time of the epoch's kernels on the handle's stream */
   double   main_kernel_seconds; /* HIP-event time summed over launches of the dominant kernel only */
   uint64_t main_kernel_launches;
+  uint32_t max_feature_count; /* MINIBATCH with the segmented update: occurrences of the most frequent feature inside one
+                               * batch.  The batch rule applies them at once (a step of learn_rate * count on that feature,
+                               * where the reference takes `count` small steps), so keep learn_rate * count * curvature
+                               * well below 1 (curvature: x^2 for regression, x^2 / 4 for classification) -- pick the batch
+                               * size accordingly, or use SEQUENTIAL / HOGWILD for data with very frequent features. */
+  uint32_t reserved;
 } fmx_epoch_stats;
 
 /* what fm_learn::evaluate_regression / evaluate_classification compute (fm_learn.h:113-153) */

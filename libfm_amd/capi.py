@@ -42,7 +42,8 @@ class SgdOpts(C.Structure):
 
 class EpochStats(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("batches", C.c_uint64), ("device_seconds", C.c_double),
-                ("main_kernel_seconds", C.c_double), ("main_kernel_launches", C.c_uint64)]
+                ("main_kernel_seconds", C.c_double), ("main_kernel_launches", C.c_uint64),
+                ("max_feature_count", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Eval(C.Structure):

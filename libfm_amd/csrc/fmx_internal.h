@@ -35,6 +35,7 @@ struct Slot {
   uint32_t* seg_feat = nullptr;
   uint32_t* seg_rel = nullptr;
   uint32_t  nseg = 0;
+  uint32_t  max_seg_count = 0;       // occurrences of the most frequent feature inside one batch
   std::vector<uint32_t> batch_seg;   // [n_batches+1] first segment of every batch
   std::vector<uint64_t> batch_base;  // [n_batches+1] first entry of every batch
 };

@@ -628,6 +628,24 @@ k_seg_batches(const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t nseg, con
   }
 }
 
+// the longest segment = how often the most frequent feature occurs inside ONE batch: the batch rule applies that many
+// contributions to the feature at once (a step of lr * count on it), which the caller should keep well below the
+// curvature bound (fmx_epoch_stats::max_feature_count).  head[s] = sorted position of the segment's first entry.
+static __global__ void __launch_bounds__(256)
+k_seg_head_pos(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t nseg, uint32_t* __restrict__ head) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nnz; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (i == nnz) head[nseg] = (uint32_t)nnz;
+    else if (flags[i]) head[pos[i] - 1] = (uint32_t)i;
+  }
+}
+static __global__ void __launch_bounds__(256)
+k_seg_max_count(const uint32_t* __restrict__ head, uint32_t nseg, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) m = max(m, head[s + 1] - head[s]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
+}
+
 // One wavefront owns blocks of 64 consecutive segments: the descriptors, first occurrences and their
 // multipliers are fetched lane-parallel (coalesced), then U segment groups at a time are broadcast and their
 // V rows + S rows gathered together (2*U row loads in flight per wavefront).

@@ -112,6 +112,14 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
     s.batch_seg.resize((size_t)n_batches + 1);
     SEG_CHK(hipMemcpyAsync(s.batch_seg.data(), d_batch_seg, ((size_t)n_batches + 1) * 4, hipMemcpyDeviceToHost, st));
     SEG_CHK(hipStreamSynchronize(st));
+    {  // longest segment (reported through fmx_epoch_stats::max_feature_count); keys_a is free after the sort
+      uint32_t* head = reinterpret_cast<uint32_t*>(keys_a);            // [nseg + 1] <= 8 bytes per entry
+      SEG_CHK(hipMemsetAsync(d_batch_seg, 0, 4, st));
+      hipLaunchKernelGGL(k_seg_head_pos, dim3(2048), dim3(256), 0, st, flags, pos, nnz, nseg, head);
+      hipLaunchKernelGGL(k_seg_max_count, dim3(2048), dim3(256), 0, st, head, nseg, d_batch_seg);
+      SEG_CHK(hipMemcpyAsync(&s.max_seg_count, d_batch_seg, 4, hipMemcpyDeviceToHost, st));
+      SEG_CHK(hipStreamSynchronize(st));
+    }
     s.t_ent = reinterpret_cast<TEntry*>(vals_b); vals_b = nullptr;      // payload layout == TEntry
   } else {
     s.nseg = 0;
@@ -419,6 +427,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     stats->rows = s.n_rows;
     stats->batches = batches;
     stats->device_seconds = ms * 1e-3;
+    if (opts->mode == FMX_SGD_MINIBATCH && s.seg_B) stats->max_feature_count = s.max_seg_count;
     if (opts->mode == FMX_SGD_MINIBATCH && timed) {
       double tot = 0;
       for (size_t i = 0; i + 1 < ev_used; i += 2) {

@@ -168,6 +168,11 @@ class FMLearnSGD:
         st = self._slot(train)
         for i in range(self.num_iter):
             stats = self._h.sgd_epoch(st, self.MODES[self.mode], self.APPLY[self.apply], self.batch, self.w0_chunk)
+            if i == 0 and stats.max_feature_count * self.learn_rate > 1.0:
+                # the batch rule applies all occurrences of a feature inside one batch at once (include/fmx.h)
+                print("WARNING: a feature occurs %d times per batch: learn_rate * count = %g; use a smaller -batch, or "
+                      "-gpu_mode sequential / hogwild" % (stats.max_feature_count, stats.max_feature_count * self.learn_rate),
+                      file=self.out)
             rmse_train = self.evaluate(train)
             rmse_test = self.evaluate(test)
             print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, rmse_train, rmse_test), file=self.out)   # :71

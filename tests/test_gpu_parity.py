@@ -397,3 +397,23 @@ def test_default_bias_chunk_is_stable(capi, task, lr):
         else:
             assert ev.rmse < 0.99, (mode, ev.rmse)
         h.close()
+
+
+def test_max_feature_count_is_reported(capi):
+    """fmx_epoch_stats::max_feature_count = occurrences of the most frequent feature inside one batch."""
+    n_rows, nnz = 1000, 3
+    ent = np.zeros(n_rows * nnz, dtype=datagen.ENTRY_DTYPE)
+    rng = np.random.default_rng(1)
+    ids = rng.integers(10, 5000, (n_rows, nnz)).astype(np.uint32)
+    ids[:, 0] = np.where(np.arange(n_rows) % 4 == 0, 7, ids[:, 0])        # feature 7 in every 4th row
+    ent["id"], ent["value"] = ids.reshape(-1), 1.0
+    row_ptr = np.arange(n_rows + 1, dtype=np.uint64) * np.uint64(nnz)
+    y = np.ones(n_rows, dtype=np.float32)
+    h = capi.Handle(5000, 4, True, True, 0, 0, 0, 0, 0.001, 0.0, 1.0)
+    h.upload_rows(0, ent, row_ptr, y)
+    st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 200, 16)
+    batch_ids = ids[:200].reshape(-1)
+    expect = max(int(np.bincount(ids[b:b + 200].reshape(-1)).max()) for b in range(0, n_rows, 200))
+    assert st.max_feature_count == expect >= 50
+    assert h.sgd_epoch(0, capi.SGD_HOGWILD, capi.APPLY_DEFAULT, 0, 16).max_feature_count == 0
+    h.close()
