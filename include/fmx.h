@@ -193,6 +193,23 @@ int fmx_free_rows(fmx_handle h, int slot);
 int fmx_rows_info(fmx_handle h, int slot, uint32_t *n_rows, uint64_t *nnz);
 int fmx_download_rows(fmx_handle h, int slot, void *entries, uint64_t *row_ptr, float *target);
 
+/* ---- host-side reader of libFM's text format (no device, no handle) ----------------------------------------
+ * Data::load, text branch (src/libfm/src/Data.h:180-285): lines "target id:value id:value ...", blank lines and lines
+ * starting with '#' skipped, leading / trailing blanks and tabs allowed, anything else rejected with the reference's
+ * message ("cannot parse line ..." / "unable to open ...") in `err`.  The buffers are malloc'ed; release them with
+ * fmx_free_host_rows.  They are exactly what fmx_upload_rows takes. */
+typedef struct fmx_host_rows {
+  void     *entries;        /* sparse_entry<float>[nnz] */
+  uint64_t *row_ptr;        /* [n_rows + 1] */
+  float    *target;         /* [n_rows] */
+  uint32_t  n_rows;
+  uint32_t  num_feature;    /* largest id + 1 (Data.h:226-228) */
+  uint64_t  nnz;
+  float     min_target, max_target;   /* Data.h:205-206 */
+} fmx_host_rows;
+int  fmx_read_libsvm(const char *path, fmx_host_rows *out, char *err, size_t err_len);
+void fmx_free_host_rows(fmx_host_rows *rows);
+
 /* ---- fm_model::predict over a data set (fm_model.h:105-127 via fm_learn.h:63-65) -------------- */
 /* raw y-hat per row (no clamp / sigmoid: fm_learn_sgd::predict applies those on the host,
  * fm_learn_sgd.h:80-87).  out: double[n_rows]. Sharded handles return the PARTIAL sums only. */

@@ -56,6 +56,11 @@ class Relation(C.Structure):
                 ("nnz", C.c_uint64), ("data_row_to_relation_row", C.c_void_p), ("attr_offset", C.c_uint64)]
 
 
+class HostRows(C.Structure):
+    _fields_ = [("entries", C.c_void_p), ("row_ptr", C.c_void_p), ("target", C.c_void_p), ("n_rows", C.c_uint32),
+                ("num_feature", C.c_uint32), ("nnz", C.c_uint64), ("min_target", C.c_float), ("max_target", C.c_float)]
+
+
 class AlsOpts(C.Structure):
     _fields_ = [("alpha", C.c_double), ("w_mu", C.c_double), ("w_lambda", C.c_double), ("v_mu", C.c_double),
                 ("v_lambda", C.c_double), ("do_sample", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
@@ -91,6 +96,8 @@ SYMBOLS = [
     ("fmx_upload_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     ("fmx_upload_block_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                         C.POINTER(Relation), C.c_uint32]),
+    ("fmx_read_libsvm", C.c_int, [C.c_char_p, C.POINTER(HostRows), C.c_char_p, C.c_size_t]),
+    ("fmx_free_host_rows", None, [C.POINTER(HostRows)]),
     ("fmx_synth_rows", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     ("fmx_free_rows", C.c_int, [H, C.c_int]),
     ("fmx_rows_info", C.c_int, [H, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),

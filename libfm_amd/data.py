@@ -22,6 +22,27 @@ _HDR = np.dtype([("id", "<u4"), ("float_size", "<u4"), ("num_values", "<u8"), ("
 
 
 def read_libsvm(path):
+    """Data::load's text branch through the native reader of the C-ABI (fmx_read_libsvm: same accepted tokens, same
+    rejected lines, the reference's error texts).  Returns (entries, row_ptr, target)."""
+    import ctypes as C
+    from . import capi
+    lib = capi.load()
+    rows, err = capi.HostRows(), C.create_string_buffer(512)
+    rc = lib.fmx_read_libsvm(os.fsencode(path), C.byref(rows), err, len(err))
+    if rc != capi.FMX_OK:
+        msg = err.value.decode(errors="replace")
+        raise (OSError if msg.startswith("unable to open") else ValueError)(msg)
+    try:
+        ent = np.ctypeslib.as_array(C.cast(rows.entries, C.POINTER(C.c_uint64)), (max(rows.nnz, 1),))[:rows.nnz].view(ENTRY_DTYPE).copy()
+        row_ptr = np.ctypeslib.as_array(C.cast(rows.row_ptr, C.POINTER(C.c_uint64)), (rows.n_rows + 1,)).copy()
+        y = np.ctypeslib.as_array(C.cast(rows.target, C.POINTER(C.c_float)), (max(rows.n_rows, 1),))[:rows.n_rows].copy()
+    finally:
+        lib.fmx_free_host_rows(C.byref(rows))
+    return ent, row_ptr, y
+
+
+def read_libsvm_py(path):
+    """the same format in pure Python (slow; kept as an independent cross-check of the native reader in the tests)"""
     ids, vals, sizes, ys = [], [], [], []
     with open(path) as f:
         for line in f:

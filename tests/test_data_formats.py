@@ -35,6 +35,34 @@ def test_text_reader_matches_reference_parser_rules(tmp_path, oracle):
     assert list(ent["id"]) == [0, 5, 3, 1, 2]
 
 
+def test_native_text_reader_against_python_and_reference_errors(tmp_path, oracle):
+    """fmx_read_libsvm (C-ABI, host side) == the pure-Python reader on a seeded file, and it rejects what Data::load
+    throws on (Data.h:214-221) with the reference's message; odd-but-legal tokens ("+3:1e-2", "7: 2", tabs) parse."""
+    from libfm_amd import data as D
+    import datagen
+    ent, rp, y = datagen.ragged_real(500, 300, 14, seed=5, empty_every=17)
+    p = str(tmp_path / "big.libfm")
+    oracle.Data(ent, rp, y).write_libsvm(p)
+    a, b = D.read_libsvm(p), D.read_libsvm_py(p)
+    for x, z in zip(a, b):
+        assert np.array_equal(x, z)
+    assert np.array_equal(a[0]["id"], ent["id"]) and np.array_equal(a[1], rp)
+    q = str(tmp_path / "odd.libfm")
+    with open(q, "w") as f:
+        f.write("1e0\t+3:1e-2 7: 2\t\n  -0.5 4294967295:1   # note\n")
+    e2, r2, y2 = D.read_libsvm(q)
+    assert list(y2) == [1.0, -0.5] and list(e2["id"]) == [3, 7, 4294967295] and list(r2) == [0, 2, 3]
+    assert np.allclose(e2["value"], [0.01, 2.0, 1.0])
+    for bad, needle in (("1 3:1 x\n", "cannot parse line"), ("abc\n", "cannot parse line"), ("1 3:1\r\n", "cannot parse line"),
+                        ("1 2:\n", "cannot parse line")):
+        with open(q, "w") as f:
+            f.write(bad)
+        with pytest.raises(ValueError, match=needle):
+            D.read_libsvm(q)
+    with pytest.raises(OSError, match="unable to open"):
+        D.read_libsvm(str(tmp_path / "missing"))
+
+
 @pytest.mark.skipif(not os.path.exists(CONVERT), reason="oracle/_ref/convert not built (needs /root/reference)")
 def test_reads_what_the_reference_convert_tool_writes(tmp_path, oracle):
     from libfm_amd import data as D
