@@ -74,3 +74,29 @@ def test_als_field_data_bigger_than_fixture(oracle):
     assert l.log[-1]["levels"] == nnz
     np.testing.assert_allclose([x["train"] for x in l.log], metric, rtol=1e-4)
     l.close()
+
+
+def test_als_mid_size_against_oracle(oracle):
+    """50 000 rows x 16 one-hot fields over 200 000 features, k = 16, classification (probit targets): thousands of
+    columns per level and G = 4 lanes per column -- a different launch regime from the small fixtures."""
+    from libfm_amd import learner as L
+    n, nnz, k = 200000, 16, 16
+    ent, rp, y = datagen.onehot_fields(n, nnz, 50000, seed=21)
+    ent2, rp2, y2 = datagen.onehot_fields(n, nnz, 5000, seed=22)
+    m = oracle.Model(n, k, True, True, 0.2, 2.0, 8.0)
+    m.v[:] = oracle.init_values(6, n, k, 0.1)
+    m.w[:] = oracle.init_values(7, n, 1, 0.1)[0]
+    fm = L.FMModel()
+    fm.num_attribute, fm.num_factor, fm.reg0, fm.regw, fm.regv = n, k, 0.2, 2.0, 8.0
+    fm.w0, fm.w, fm.v = m.w0, m.w.copy(), m.v.copy()
+    l = L.FMLearnALS()
+    l.fm, l.task, l.num_iter, l.min_target, l.max_target, l.w_lambda, l.v_lambda = fm, 1, 2, -1.0, 1.0, 2.0, 8.0
+    l.out = io.StringIO()
+    l.init()
+    l.learn(L.Data(ent, rp, y), L.Data(ent2, rp2, y2))
+    pred, metric = oracle.als_learn(m, oracle.Data(ent, rp, y), oracle.Data(ent2, rp2, y2), 1, 2, 2.0, 8.0, -1.0, 1.0)
+    np.testing.assert_allclose(l.fm.v, m.v, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(l.fm.w, m.w, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(l.pred_this, pred, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose([x["train"] for x in l.log], metric, rtol=1e-4)
+    l.close()
