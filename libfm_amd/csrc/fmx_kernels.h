@@ -477,12 +477,14 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
 }
 
 // k_scan4: the same recurrence with FOUR wavefronts (one per SIMD of a CU, each <= 32 VGPRs so that they still fit next
-// to a chip-filling gather) for micro-chunks that are multiples of 1024 examples: inside a chunk every multiplier
-// uses the same bias, so the four wavefronts evaluate 256 examples each in parallel and only the chunk sum crosses
-// wavefronts (LDS, one barrier per 1024 examples).  A single wavefront is VALU-bound at ~1.1 ns per example
-// (8 quarter-rate transcendentals per 256 examples), which capped a P = 8 rank at ~0.9 G examples/s.
+// to a chip-filling gather).  Inside a micro-chunk every multiplier uses the same bias, so the wavefronts evaluate a
+// PART-example piece of the chunk in parallel (PART / 4 examples each) and only the piece's sum crosses wavefronts
+// (LDS, one barrier per piece).  PART = 1024 for chunks that are multiples of 1024 (4 examples per lane), PART = 256 for
+// the other multiples of 256 -- the default chunk -- (1 example per lane: the per-chunk chain LDS read -> exp -> rcp ->
+// DPP reduction is a quarter as long as in one wavefront, paid for with one LDS exchange).  A single wavefront is
+// VALU-bound at ~1.1 ns per example, which capped a P = 8 rank and short-row shapes at ~0.9 G examples/s.
 // Summation order: per wavefront as in k_scan, then the four partial sums in wavefront order (deterministic).
-template <bool WRITE_MULT, int TASK>
+template <bool WRITE_MULT, int TASK, int PART>
 __global__ void __launch_bounds__(256)
 k_scan4(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
         Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
@@ -514,16 +516,20 @@ k_scan4(const float* __restrict__ rest, const float* __restrict__ target, uint32
     if (t + 1 < n_tiles) fetch(t + 1, cur ^ 1u);
     const float* sr = s_rest[cur];
     const float* sy = s_y[cur];
-    for (uint32_t c0 = 0; c0 < tn; c0 += 1024) {
-      const uint32_t n_here = min(1024u, tn - c0);
-      const uint32_t q = c0 + wv * 256 + lane;
-      float acc = 0.f;                                        // two pairs, not four at once: <= 32 VGPRs (placement, see k_scan)
+    for (uint32_t c0 = 0; c0 < tn; c0 += PART) {
+      const uint32_t n_here = min((uint32_t)PART, tn - c0);
+      const uint32_t q = c0 + wv * (PART / 4) + lane;
+      float acc = 0.f;
+      if constexpr (PART == 1024) {                           // two pairs, not four at once: <= 32 VGPRs (placement, see k_scan)
 #pragma unroll 1
-      for (uint32_t u = 0; u < 256; u += 128) {
-        float m0 = 0.f, m1 = 0.f;
-        if (q + u < tn)      { m0 = multiplier_task<TASK>(h, w0s + sr[q + u], sy[q + u]);           if (WRITE_MULT) mult[t0 + q + u] = m0; }
-        if (q + u + 64 < tn) { m1 = multiplier_task<TASK>(h, w0s + sr[q + u + 64], sy[q + u + 64]); if (WRITE_MULT) mult[t0 + q + u + 64] = m1; }
-        acc += m0 + m1;
+        for (uint32_t u = 0; u < 256; u += 128) {
+          float m0 = 0.f, m1 = 0.f;
+          if (q + u < tn)      { m0 = multiplier_task<TASK>(h, w0s + sr[q + u], sy[q + u]);           if (WRITE_MULT) mult[t0 + q + u] = m0; }
+          if (q + u + 64 < tn) { m1 = multiplier_task<TASK>(h, w0s + sr[q + u + 64], sy[q + u + 64]); if (WRITE_MULT) mult[t0 + q + u + 64] = m1; }
+          acc += m0 + m1;
+        }
+      } else {
+        if (q < tn) { acc = multiplier_task<TASK>(h, w0s + sr[q], sy[q]); if (WRITE_MULT) mult[t0 + q] = acc; }
       }
       const float part = wave_sum_dpp(acc);
       if (lane == 0) s_part[pb][wv] = part;

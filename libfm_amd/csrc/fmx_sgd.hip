@@ -152,10 +152,13 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
   if (hy.k0) {
     const double* wi = w0_in ? w0_in : h->w0;
     double* wo = w0_out ? w0_out : h->w0;
-    // micro-chunks that are multiples of 1024 examples: four wavefronts share a chunk (k_scan4), else one wavefront
-    const bool four = (chunk % 1024u) == 0 && !getenv("FMX_SCAN_ONE_WAVE");
-#define FMX_SCAN(WM, TK) do { if (four) hipLaunchKernelGGL((k_scan4<WM, TK>), dim3(1), dim3(256), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); \
-                              else hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
+    // micro-chunks that are multiples of 256 examples: four wavefronts share a chunk (k_scan4, pieces of 1024 or 256
+    // examples), else one wavefront
+    const int part = (getenv("FMX_SCAN_ONE_WAVE") || (chunk % 256u) != 0) ? 0 : ((chunk % 1024u) == 0 ? 1024 : 256);
+#define FMX_SCAN(WM, TK) do { \
+      if (part == 1024)     hipLaunchKernelGGL((k_scan4<WM, TK, 1024>), dim3(1), dim3(256), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); \
+      else if (part == 256) hipLaunchKernelGGL((k_scan4<WM, TK, 256>), dim3(1), dim3(256), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); \
+      else                  hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
     if (hy.task == 0) { if (mult) FMX_SCAN(true, 0); else FMX_SCAN(false, 0); }
     else              { if (mult) FMX_SCAN(true, 1); else FMX_SCAN(false, 1); }
 #undef FMX_SCAN

@@ -27,12 +27,14 @@ for name in sys.argv[1:] or ["mcmc_reg_ml_groups", "mcmc_reg_ml"]:
         if "group" in z.files:
             open(os.path.join(td, "meta"), "w").write("".join("%d\n" % x for x in z["group"]))
             env["FMX_META"] = os.path.join(td, "meta")
-        for seed in (101, 102, 103, 104, 105, 106):
+        for seed in range(201, 213):
             pre = os.path.join(td, "o%d" % seed)
             subprocess.run([HARNESS, "mcmc_gpu", trf, tef, str(z["task"]), "1", "1", str(int(z["k"])), str(int(z["iters"])),
                             repr(float(z["init_stdev"])), str(seed), pre], check=True, capture_output=True, env=env)
             p = np.fromfile(pre + ".pred_out.bin")
             preds.append(p)
-            print(name, seed, "ours vs ref: corr %.4f rms %.4f" % (np.corrcoef(p, ref)[0, 1], np.sqrt(np.mean((p - ref) ** 2))), flush=True)
+            y = g.test_target.astype(np.float64)
+            print(name, seed, "ours vs ref: corr %.4f rms %.4f | test rmse ours %.4f (fixture %.4f)" % (
+                np.corrcoef(p, ref)[0, 1], np.sqrt(np.mean((p - ref) ** 2)), np.sqrt(np.mean((p - y) ** 2)), np.sqrt(np.mean((ref - y) ** 2))), flush=True)
     for i in range(1, len(preds)):
         print(name, "ours vs ours: corr %.4f rms %.4f" % (np.corrcoef(preds[0], preds[i])[0, 1], np.sqrt(np.mean((preds[0] - preds[i]) ** 2))))

@@ -140,10 +140,12 @@ def test_minibatch_matches_restated_rule(capi, oracle, name, batch, chunk):
 
 
 @pytest.mark.parametrize("task,batch,chunk,lag", [(1, 5000, 1024, False), (1, 3000, 2048, True), (0, 4096, 1024, True),
-                                                  (0, 9001, 4096, False), (1, 1500, 1024, True)])
+                                                  (0, 9001, 4096, False), (1, 1500, 1024, True),
+                                                  (1, 5000, 256, False), (0, 3000, 768, True), (1, 9001, 256, True), (0, 700, 512, False)])
 def test_minibatch_kilo_chunks(capi, oracle, task, batch, chunk, lag):
-    """micro-chunks that are multiples of 1024 examples take the four-wavefront recurrence kernel (k_scan4): ragged
-    batch tails, batches that are not multiples of the tile (4096) or of the chunk, both tasks, with / without bias-lag."""
+    """micro-chunks that are multiples of 256 examples take the four-wavefront recurrence kernel (k_scan4, pieces of
+    1024 or 256 examples): ragged batch tails, batches that are not multiples of the tile (4096) or of the chunk, both
+    tasks, with / without bias-lag."""
     n, nnz, rows, k = 4000, 6, 9001, 8
     ent, row_ptr, y = datagen.onehot_fields(n - n % nnz, nnz, rows, seed=17 + batch, classification=(task == 1))
     if task == 0:
@@ -153,12 +155,13 @@ def test_minibatch_kilo_chunks(capi, oracle, task, batch, chunk, lag):
     m.v[:] = oracle.init_values(3, n, k, 0.05)
     m.w0 = 0.05
     lo, hi = float(y.min()), float(y.max())
-    h = capi.Handle(n, k, True, True, task, 0.002, 0.001, 0.003, 0.01, lo, hi)
+    lr = min(0.01, 0.9 / (chunk * (1.0 if task == 0 else 0.25)))     # keep the bias recurrence in its stable regime (include/fmx.h)
+    h = capi.Handle(n, k, True, True, task, 0.002, 0.001, 0.003, lr, lo, hi)
     h.set_params(m.w0, m.w, m.v)
     h.upload_rows(0, ent, row_ptr, y)
     for _ in range(2):
         h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, chunk, capi.FLAG_BIAS_LAG if lag else 0)
-        oracle.sgd_epoch_minibatch(m, d, task, 0.01, lo, hi, batch, chunk, lag)
+        oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, lag)
     w0, w, v = h.get_params()
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
