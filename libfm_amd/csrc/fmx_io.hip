@@ -2,13 +2,24 @@
 // produce exactly the buffers fmx_upload_rows takes.  Behaviour follows Data::load (src/libfm/src/Data.h:180-285):
 // the same tokens are accepted (sscanf "%f" for the target, "%d:%f" pairs), the same lines are skipped (blank, '#'),
 // and a line the reference would throw on is rejected with the reference's message.
-#include "fmx_internal.h"
+#pragma GCC visibility push(default)      // the C-ABI is the only thing libfmx.so exports (-fvisibility=hidden)
+#include "../../include/fmx.h"
+#pragma GCC visibility pop
 
+#include <algorithm>
 #include <cctype>
 #include <cerrno>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
 
 namespace {
+
+struct Entry { uint32_t id; float value; };                 // sparse_entry<float>, src/util/fmatrix.h:34-37
+static_assert(sizeof(Entry) == 8, "AoS entry layout");
 
 // what sscanf("%d", ...) consumes: optional white space, optional sign, decimal digits
 bool scan_int(const char*& p, long& out) {
