@@ -4,8 +4,9 @@
  * This is the drop-in boundary for srendle/libfm's learner interface.  libFM has no plugin/FFI API;
  * its de-facto operator interface is `class fm_learn` (/root/reference/src/libfm/src/fm_learn.h:31-60)
  * driven by main() (/root/reference/src/libfm/libfm.cpp:271-434).  Each entry point below names the
- * reference interface it replaces.  The reference-side binding (an fm_learn subclass calling these
- * functions) is shown in INTEGRATION.md and lives in adapter/fm_learn_gpu.h.
+ * reference interface it replaces.  The reference-side bindings (fm_learn subclasses calling these
+ * functions) are shown in INTEGRATION.md and live in adapter/fm_learn_sgd_gpu.h (-method sgd, sgda) and
+ * adapter/fm_learn_mcmc_gpu.h (-method als, mcmc); examples/fmx_demo.c uses the library from plain C.
  *
  * Conventions
  *   - plain C: opaque handle, POD structs, raw pointers and sizes; no C++/torch types cross the boundary.
