@@ -109,10 +109,10 @@ template <int VEC> __device__ __forceinline__ void store_vec(float* __restrict__
 #define FMX_W_LOAD 0
 #endif
 // V-row accesses with a non-temporal hint.  The 4*KP-byte rows stream through (every row is touched once per example
-// and the table is far larger than any cache), while the 4-byte w_j they travel with costs a whole 128-B line each:
-// with plain loads the rows evict those lines from the memory-side cache (Infinity Cache, 256 MB) before the next
-// example that shares the line arrives; with `nt` on the rows the w lines (and the row / S streams) survive.
-// Measured on MI355X, north-star shape: fused step 211 -> 270 M examples/s.
+// and the table is far larger than any cache): without the hint they are allocated in -- and later evicted from -- the
+// L2 / Infinity Cache path for nothing, and push out the lines that do have reuse (the 128-B lines holding w_j, the
+// S buffer of the minibatch step).  Measured on MI355X, north-star shape: fused step 211 -> 270 M examples/s, and
+// still 251 M examples/s with a 205 GB table.
 // FMX_V_NT bits (default all on): 1 fused loads, 2 fused stores, 4 gather (row_sums) loads, 8 update (row_apply /
 // k_apply_seg) loads + stores.
 #ifndef FMX_V_NT
