@@ -406,8 +406,10 @@ constexpr int SCAN_TILE = 4096;
 // Tiles arrive by LDS-DMA (global_load_lds: no VGPR round trip), tile t+1 in flight while tile t is scanned.
 __device__ __forceinline__ void scan_fetch_array(const float* __restrict__ g, uint32_t cnt, float* s, uint32_t lane) {
   if ((((uintptr_t)g) & 15u) == 0) {                           // 16-byte pieces: 1 KiB per wave instruction
-    for (uint32_t base = 0; base < cnt; base += 256)
-      if (base + 4 * lane < cnt) __builtin_amdgcn_global_load_lds(g + base + 4 * lane, s + base, 16, 0, 0);
+    const uint32_t full = cnt & ~3u;                           // whole 16-byte groups only: never read past g[cnt - 1]
+    for (uint32_t base = 0; base < full; base += 256)
+      if (base + 4 * lane < full) __builtin_amdgcn_global_load_lds(g + base + 4 * lane, s + base, 16, 0, 0);
+    if (full + lane < cnt) __builtin_amdgcn_global_load_lds(g + full + lane, s + full, 4, 0, 0);   // ragged tail (< 4 floats)
   } else {                                                     // unaligned start (row0 not a multiple of 4): dwords
     for (uint32_t base = 0; base < cnt; base += 64)
       if (base + lane < cnt) __builtin_amdgcn_global_load_lds(g + base + lane, s + base, 4, 0, 0);
