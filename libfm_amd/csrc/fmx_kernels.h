@@ -486,38 +486,53 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
 // DPP reduction is a quarter as long as in one wavefront, paid for with one LDS exchange).  A single wavefront is
 // VALU-bound at ~1.1 ns per example, which capped a P = 8 rank and short-row shapes at ~0.9 G examples/s.
 // Summation order: per wavefront as in k_scan, then the four partial sums in wavefront order (deterministic).
+constexpr int SCAN4_BUFS = 4;                                   // tile buffers of k_scan4: tiles t+1 .. t+3 in flight while t is scanned
+constexpr size_t SCAN4_LDS_BYTES = (size_t)(SCAN4_BUFS * 2 * SCAN_TILE + 8) * sizeof(float);   // 128 KiB + the partial sums
 template <bool WRITE_MULT, int TASK, int PART>
 __global__ void __launch_bounds__(256)
 k_scan4(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
         Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
-  __shared__ float s_rest[2][SCAN_TILE];
-  __shared__ float s_y[2][SCAN_TILE];
-  __shared__ float s_part[2][4];
+  // Under a chip-filling gather an LDS-DMA tile takes ~10-15 us to land while 4096 examples are scanned in ~4 us, so one
+  // tile of prefetch left the recurrence DMA-latency-bound (its kernel time tracked the gather's, ~1 ms per 262 144
+  // examples against 0.3 ms alone).  Four buffers of the 160 KiB LDS keep three tiles in flight.
+  extern __shared__ float scan_lds[];
+  float* const s_part = scan_lds + SCAN4_BUFS * 2 * SCAN_TILE;   // [2][4]
   __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the tile arithmetic in SGPRs
   constexpr uint32_t QT = SCAN_TILE / 4;                         // every wavefront fetches its quarter of a tile
+  constexpr uint32_t D = SCAN4_BUFS - 1;                         // prefetch distance in tiles
   const uint32_t n_tiles = (n_rows + SCAN_TILE - 1) / SCAN_TILE;
+  // a full tile whose arrays are 16-byte aligned costs exactly 8 DMA instructions per wavefront (4 per array): only
+  // then can "tile t has landed" be expressed as an s_waitcnt with the later tiles still in flight
+  const bool aligned = ((((uintptr_t)rest) | ((uintptr_t)target)) & 15u) == 0;
   double w0 = *w0_in;
   float w0s = h.k0 ? (float)w0 : 0.f;
   float chunk_acc = 0.f;
   uint32_t chunk_pos = 0, pb = 0;
-  auto fetch = [&](uint32_t t, uint32_t buf) {
+  auto fetch = [&](uint32_t t) {
+    const uint32_t buf = t % SCAN4_BUFS;
     const uint32_t t0 = t * SCAN_TILE;
     const uint32_t tn = min((uint32_t)SCAN_TILE, n_rows - t0);
     const uint32_t q0 = wv * QT;
-    if (q0 < tn) scan_fetch_tile(rest + t0 + q0, target + t0 + q0, min(QT, tn - q0), s_rest[buf] + q0, s_y[buf] + q0, lane);
+    float* sr = scan_lds + buf * 2 * SCAN_TILE;
+    if (q0 < tn) scan_fetch_tile(rest + t0 + q0, target + t0 + q0, min(QT, tn - q0), sr + q0, sr + SCAN_TILE + q0, lane);
   };
-  fetch(0, 0);
+  for (uint32_t t = 0; t < D && t < n_tiles; t++) fetch(t);
   for (uint32_t t = 0; t < n_tiles; t++) {
     const uint32_t t0 = t * SCAN_TILE;
     const uint32_t tn = min((uint32_t)SCAN_TILE, n_rows - t0);
-    const uint32_t cur = t & 1u;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's quarter of tile t has landed
+    // tiles t+1 .. last_issued are in flight behind tile t; all of them standard (full + aligned) -> counted wait
+    const uint32_t last_issued = min(t + D - 1, n_tiles - 1);
+    const uint32_t later = last_issued - t;
+    const bool counted = !WRITE_MULT && aligned && ((uint64_t)(last_issued + 1) * SCAN_TILE <= n_rows);
+    if (counted && later == 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (counted && later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's quarter of tile t has landed
     __syncthreads();                                             // ... and everybody else's; tile t-1 is no longer read
-    if (t + 1 < n_tiles) fetch(t + 1, cur ^ 1u);
-    const float* sr = s_rest[cur];
-    const float* sy = s_y[cur];
+    if (t + D < n_tiles) fetch(t + D);                           // into the buffer of tile t-1
+    const float* sr = scan_lds + (t % SCAN4_BUFS) * 2 * SCAN_TILE;
+    const float* sy = sr + SCAN_TILE;
     for (uint32_t c0 = 0; c0 < tn; c0 += PART) {
       const uint32_t n_here = min((uint32_t)PART, tn - c0);
       const uint32_t q = c0 + wv * (PART / 4) + lane;
@@ -534,9 +549,9 @@ k_scan4(const float* __restrict__ rest, const float* __restrict__ target, uint32
         if (q < tn) { acc = multiplier_task<TASK>(h, w0s + sr[q], sy[q]); if (WRITE_MULT) mult[t0 + q] = acc; }
       }
       const float part = wave_sum_dpp(acc);
-      if (lane == 0) s_part[pb][wv] = part;
+      if (lane == 0) s_part[pb * 4 + wv] = part;
       __syncthreads();
-      chunk_acc += (s_part[pb][0] + s_part[pb][1]) + (s_part[pb][2] + s_part[pb][3]);
+      chunk_acc += (s_part[pb * 4] + s_part[pb * 4 + 1]) + (s_part[pb * 4 + 2] + s_part[pb * 4 + 3]);
       pb ^= 1u;
       chunk_pos += n_here;
       if (chunk_pos == chunk || t0 + c0 + n_here == n_rows) {

@@ -155,13 +155,17 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     // micro-chunks that are multiples of 256 examples: four wavefronts share a chunk (k_scan4, pieces of 1024 or 256
     // examples), else one wavefront
     const int part = (getenv("FMX_SCAN_ONE_WAVE") || (chunk % 256u) != 0) ? 0 : ((chunk % 1024u) == 0 ? 1024 : 256);
+#define FMX_SCAN4(WM, TK, PT) do { auto kf = k_scan4<WM, TK, PT>; static bool raised = false;                                   \
+      if (!raised) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCAN4_LDS_BYTES)); raised = true; } \
+      hipLaunchKernelGGL(kf, dim3(1), dim3(256), SCAN4_LDS_BYTES, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
 #define FMX_SCAN(WM, TK) do { \
-      if (part == 1024)     hipLaunchKernelGGL((k_scan4<WM, TK, 1024>), dim3(1), dim3(256), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); \
-      else if (part == 256) hipLaunchKernelGGL((k_scan4<WM, TK, 256>), dim3(1), dim3(256), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); \
+      if (part == 1024)     FMX_SCAN4(WM, TK, 1024); \
+      else if (part == 256) FMX_SCAN4(WM, TK, 256); \
       else                  hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
     if (hy.task == 0) { if (mult) FMX_SCAN(true, 0); else FMX_SCAN(false, 0); }
     else              { if (mult) FMX_SCAN(true, 1); else FMX_SCAN(false, 1); }
 #undef FMX_SCAN
+#undef FMX_SCAN4
   } else if (mult) {
     hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
                        (const double*)nullptr, mult);
