@@ -80,13 +80,14 @@ def _pipe_worker(rank, world, port, out_dir, backend):
     import torch.distributed as dist
     from libfm_amd import capi
     from libfm_amd.distributed import ShardedSGD
-    torch.cuda.set_device(0)
+    dev = rank if (backend == "nccl" and world > 1) else 0      # RCCL needs one GPU per rank; gloo shards share cuda:0
+    torch.cuda.set_device(dev)
     if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=rank, world_size=world)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev), rank=rank, world_size=world)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     tr, w, v = _pipe_inputs()
-    h = capi.Handle(PN, PK, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.05, -1.0, 1.0, device=0,
+    h = capi.Handle(PN, PK, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.05, -1.0, 1.0, device=dev,
                     shard_rank=rank, shard_world=world)
     h.set_params(0.1, w, v)
     h.upload_rows(0, tr.entries, tr.row_ptr, tr.target)
@@ -100,8 +101,11 @@ def _pipe_worker(rank, world, port, out_dir, backend):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1), ("nccl", 2), ("nccl", 4)])
 def test_pipelined_schedule_matches_its_oracle(tmp_path, oracle, backend, world):
+    import torch
+    if backend == "nccl" and world > torch.cuda.device_count():
+        pytest.skip("needs %d GPUs (RCCL refuses two ranks on one device)" % world)
     """gloo x 2 shards: the order of operations of the pipelined driver; nccl x 1: the same with the asynchronous RCCL
     all-reduce and its stream dependencies.  Both must equal oracle fmo_sgd_epoch_minibatch_pipelined, and must differ
     from the unpipelined rule (otherwise the test would not see the schedule)."""
