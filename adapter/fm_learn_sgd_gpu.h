@@ -110,9 +110,9 @@ class fm_learn_sgd_gpu : public fmx_sgd_binding<fm_learn_sgd> {
   // GPU-only knobs (defaults = library defaults); everything else is inherited and set by main() as before
   int gpu_mode;          // FMX_SGD_SEQUENTIAL | FMX_SGD_MINIBATCH | FMX_SGD_HOGWILD
   int gpu_apply;         // FMX_APPLY_*
-  uint gpu_batch, gpu_w0_chunk;
+  uint gpu_batch, gpu_w0_chunk, gpu_flags, gpu_bias_lag;   // fmx_sgd_opts::flags / ::bias_lag
 
-  fm_learn_sgd_gpu() : gpu_mode(FMX_SGD_MINIBATCH), gpu_apply(FMX_APPLY_DEFAULT), gpu_batch(0), gpu_w0_chunk(0) {}
+  fm_learn_sgd_gpu() : gpu_mode(FMX_SGD_MINIBATCH), gpu_apply(FMX_APPLY_DEFAULT), gpu_batch(0), gpu_w0_chunk(0), gpu_flags(0), gpu_bias_lag(0) {}
 
   virtual void init() {                                   // fm_learn_sgd_element::init (:40-46)
     fm_learn_sgd::init();
@@ -125,7 +125,7 @@ class fm_learn_sgd_gpu : public fmx_sgd_binding<fm_learn_sgd> {
     open();
     const int s_train = slot_of(train), s_test = slot_of(test);
     fmx_sgd_opts opts; opts.mode = gpu_mode; opts.apply = gpu_apply; opts.batch = gpu_batch;
-    opts.w0_chunk = gpu_w0_chunk; opts.flags = 0; opts.reserved = 0;
+    opts.w0_chunk = gpu_w0_chunk; opts.flags = gpu_flags; opts.bias_lag = gpu_bias_lag;
     for (int i = 0; i < num_iter; i++) {
       fmx_epoch_stats st;
       check(fmx_sgd_epoch(h, s_train, &opts, &st));

@@ -10,13 +10,19 @@ ids, values 1.0, +-1 labels, task = classification, lr 0.01, regular 0,0,0.001; 
 the device (fmx_synth_rows) and the parameters are filled on the device (fmx_init_params), so everything is
 resident in HBM before the timed region.  A "step" is one SGD pass over `--rows` examples.
 
-N = 1 : the whole pass runs inside the library (fmx_sgd_epoch).
-N > 1 : V/w are row-sharded by feature id (owner = id mod N); every rank sees every example restricted to its
-        own features; per minibatch ONE all-reduce (RCCL) of the [B][k+1] partial sums, then every rank
-        updates its shard (fmx_sgd_partial -> all_reduce -> fmx_sgd_finish).  Total work is fixed => "strong".
+The update rule is the SAME at every N: the restated minibatch rule of oracle/fm_oracle.h (batch 262 144, bias lag),
+the rule tests/test_gpu_parity.py and tests/test_gpu_fullsize.py hold to the oracle at 1e-4.
+N = 1 : FMX_APPLY_FUSED -- the rule in ONE pass over HBM (features that occur once in their batch are gathered, used and
+        written back by their example's wavefront; the few that occur more than once go through the segmented kernel);
+        the whole pass runs inside the library (fmx_sgd_epoch).
+N > 1 : V/w are row-sharded by feature id; every rank sees every example restricted to its own features; per
+        minibatch ONE all-reduce (RCCL) of the [B][k+1] partial sums, then every rank updates its shard
+        (fmx_sgd_partial -> all_reduce -> fmx_sgd_finish).  Total work is fixed => "strong".
+`--mode hogwild` (asynchronous, metric-level parity only) is printed as an extra key, never as `value`.
 
-The JSON line carries `roofline` (dominant kernel: algorithmic bytes / HIP-event duration vs the 8 TB/s HBM
-peak) and, at N = 1, `cpu_baseline` (the C restatement of the reference loop, one thread, bounded sample).
+The JSON line carries `roofline` (dominant kernel: algorithmic bytes / HIP-event duration vs the 8 TB/s HBM peak, and
+the V-gather read fraction next to the total) and, at N = 1, `cpu_baseline` (the REAL reference's fm_model::predict +
+fm_SGD compiled from its own sources, one thread, bounded sample; the C restatement is the extra key `cpu_port`).
 """
 import argparse
 import ctypes
@@ -73,6 +79,11 @@ def cpu_baseline(n, k, nnz, rows):
             "seconds": round(sec, 3), "setup_seconds": round(setup, 1), "host_cores": cores}
 
 
+def v_read_fraction(value, k, nnz, world=1):
+    """SURVEY section 8(d) fraction (1): examples/s x z*k*4 bytes of gathered V rows per GPU / HBM peak."""
+    return round(value * nnz * k * 4 / world / 1e9 / HBM_PEAK_GBS, 4)
+
+
 def cpu_reference(n, k, nnz, rows):
     """the reference's own fm_model::predict + fm_SGD (compiled from /root/reference into oracle/_ref/ref_harness),
     one thread.  The stock containers overflow at k*n >= 2^32 (matrix.h:167-169), so n is capped accordingly."""
@@ -86,8 +97,9 @@ def cpu_reference(n, k, nnz, rows):
         return {"error": r.stderr[-200:]}
     d = json.loads(r.stdout.strip().splitlines()[-1])
     return {"value": round(d["examples_per_sec"], 1), "unit": "examples/s", "cores": 1, "kind": "reference",
-            "sample": "%d rows of the synthetic workload at n=%d (largest the stock containers allocate; bench n=%d) k=%d nnz=%d"
-                      % (rows, n_ref, n, k, nnz), "seconds": round(d["seconds"], 3)}
+            "sample": "%d rows of the synthetic workload through the reference's own fm_model::predict + fm_SGD (oracle/_ref/ref_harness "
+                      "time_sgd), n=%d (largest k*n the stock containers allocate, matrix.h:167-169; bench n=%d) k=%d nnz=%d, 1 epoch"
+                      % (rows, n_ref, n, k, nnz), "seconds": round(d["seconds"], 3), "host_cores": os.cpu_count() or 1}
 
 
 def committed_traffic(kernel, examples_per_launch, k, nnz):
@@ -96,10 +108,10 @@ def committed_traffic(kernel, examples_per_launch, k, nnz):
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         e = t.get(kernel)
         if e and e["examples_per_launch"] == examples_per_launch and e["k"] == k and e["nnz"] == nnz:
-            return e["hbm_bytes_per_launch"]
+            return e["hbm_bytes_per_launch"], "committed profile: " + e.get("source", "profiles/traffic.json")
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -111,8 +123,11 @@ def main():
     ap.add_argument("--factors", dest="k", type=int, default=64, help="number of factors k")
     ap.add_argument("--nnz", type=int, default=32)
     ap.add_argument("--rows", type=int, default=1 << 22, help="examples per step")
-    ap.add_argument("--mode", default="auto", choices=["auto", "minibatch", "hogwild"],
-                    help="auto: hogwild (fused single pass) on one GPU, minibatch (feature-sharded) on several")
+    ap.add_argument("--mode", default="auto", choices=["auto", "fused", "minibatch", "hogwild"],
+                    help="auto: the minibatch rule everywhere -- `fused` (FMX_APPLY_FUSED, one pass) on one GPU, the split step "
+                         "(feature-sharded) on several; minibatch: the two-pass segmented form; hogwild: asynchronous")
+    ap.add_argument("--bias-lag", type=int, default=2, help="fused: batches the multipliers' bias lags behind (1..4)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (hogwild, two-pass minibatch)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the all-reduce through the host (testing the N>1 path without RCCL)")
     ap.add_argument("--same-device", action="store_true", help="testing: all ranks use cuda:0")
@@ -150,9 +165,9 @@ def main():
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_sharded
     if args.mode == "auto":
-        args.mode = "minibatch" if sharded else "hogwild"
+        args.mode = "minibatch" if sharded else "fused"
     if world > 1 and args.mode != "minibatch":
-        raise SystemExit("several GPUs: only --mode minibatch (feature-sharded) exists")
+        raise SystemExit("several GPUs: only --mode minibatch (the split step over feature shards) exists")
     if sharded:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -177,20 +192,25 @@ def main():
     mode = capi.SGD_HOGWILD if args.mode == "hogwild" else capi.SGD_MINIBATCH
     apply_ = {"default": capi.APPLY_DEFAULT, "segmented": capi.APPLY_SEGMENTED, "atomic": capi.APPLY_ATOMIC,
               "store": capi.APPLY_STORE}[args.apply]
+    if args.mode == "fused":
+        apply_ = capi.APPLY_FUSED
 
     lagf = 0 if (args.no_bias_lag or args.mode == "hogwild") else capi.FLAG_BIAS_LAG
+    bias_lag = args.bias_lag if args.mode == "fused" else (1 if lagf else 0)
+    deferred = 0
     if not sharded:
-        batch = args.batch or (262144 if args.mode == "hogwild" else 16384)
+        batch = args.batch or (16384 if args.mode == "minibatch" else 262144)
         main_time, main_launches = 0.0, 0
 
         def step(timed):
-            nonlocal main_time, main_launches
-            st = h.sgd_epoch(0, mode, apply_, batch, args.w0_chunk, (capi.FLAG_TIME_MAIN_KERNEL if timed else 0) | lagf)
+            nonlocal main_time, main_launches, deferred
+            st = h.sgd_epoch(0, mode, apply_, batch, args.w0_chunk, (capi.FLAG_TIME_MAIN_KERNEL if timed else 0) | lagf, bias_lag)
             if timed:
                 main_time += st.main_kernel_seconds
                 main_launches += st.main_kernel_launches
+                deferred += st.deferred_features
         rows_per_launch = min(batch, args.rows)
-        kind = "fused" if args.mode == "hogwild" else "apply"
+        kind = "fused" if args.mode in ("hogwild", "fused") else "apply"
     else:
         from libfm_amd.distributed import ShardedSGD
         batch = args.batch or 262144                 # per-rank compute side: 691 (131 072) -> 765 M examples/s (262 144) at P = 8
@@ -224,19 +244,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    exact = None
-    if rank == 0 and not sharded and args.mode == "hogwild" and not args.no_cpu_baseline:
-        # secondary figure (not `value`): the deterministic MINIBATCH rule -- the mode the GPU parity tests hold to the
-        # oracle at 1e-4 -- on the same rows
-        eb = 131072
-        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, eb, 0, capi.FLAG_BIAS_LAG)
-        h.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, eb, 0, capi.FLAG_BIAS_LAG)
-        h.synchronize()
-        exact = {"mode": "minibatch (restated batch rule, segmented deterministic update, bias-lag)", "batch": eb, "w0_chunk": 256,
-                 "value": round(3 * args.rows / (time.perf_counter() - t1), 1), "unit": "examples/s", "steps": 3}
+    extras = {}
+    if rank == 0 and not sharded and not args.no_extras and not args.no_cpu_baseline:
+        # secondary figures, never `value`: the asynchronous mode (metric-level parity only) and the two-pass form of the rule
+        def timed_epochs(n, *a):
+            h.sgd_epoch(0, *a)
+            h.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                h.sgd_epoch(0, *a)
+            h.synchronize()
+            return round(n * args.rows / (time.perf_counter() - t1), 1)
+        if args.mode != "hogwild":
+            extras["hogwild"] = {"mode": "hogwild (asynchronous one-pass step; parity only metric-level -- NOT the headline)",
+                                 "batch": 262144, "value": timed_epochs(5, capi.SGD_HOGWILD, capi.APPLY_DEFAULT, 262144, args.w0_chunk, 0),
+                                 "unit": "examples/s", "steps": 5}
+        if args.mode != "minibatch":
+            extras["minibatch_two_pass"] = {"mode": "minibatch rule, two passes (k_rowsums + k_apply_seg), bias lag 1", "batch": 131072,
+                                            "value": timed_epochs(3, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 131072, args.w0_chunk, capi.FLAG_BIAS_LAG),
+                                            "unit": "examples/s", "steps": 3}
 
     if rank == 0:
         value = args.steps * args.rows / elapsed
@@ -246,13 +272,21 @@ def main():
             per_ex = algorithmic_bytes(args.k, args.nnz, kind)
             avg = main_time / main_launches
             achieved = per_ex * rows_per_launch / avg / 1e9
-            kname = "k_fused" if kind == "fused" else ("k_apply_seg" if args.apply in ("default", "segmented") else "k_apply")
-            traffic = args.traffic if args.traffic is not None else committed_traffic(kname, rows_per_launch, args.k, args.nnz)
+            kname = {"fused": "k_fused<EXACT>", "hogwild": "k_fused"}.get(args.mode) or \
+                ("k_apply_seg" if args.apply in ("default", "segmented") else "k_apply")
+            traffic, tsrc = (args.traffic, "--traffic") if args.traffic is not None else \
+                committed_traffic(kname, rows_per_launch, args.k, args.nnz)
             roof = {"bound": "hbm", "kernel": kname,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "v_read_frac": v_read_fraction(rows_per_launch / avg, args.k, args.nnz),
+                    "traffic": traffic, "traffic_source": tsrc,
                     "bytes_per_example": per_ex, "examples_per_launch": rows_per_launch,
-                    "avg_launch_ms": round(avg * 1e3, 4), "launches": main_launches}
+                    "avg_launch_ms": round(avg * 1e3, 4), "launches": main_launches,
+                    "launch_time": "epoch HIP-event time / launches: the launch of one batch incl. its collision pass and gaps"
+                                   if kind == "fused" else "HIP events around every launch"}
+            if args.mode == "fused":
+                roof["deferred_features_per_example"] = round(deferred / (args.steps * args.rows), 4)
         exchange = None
         if sharded:
             # no per-launch timing in the multi-process driver (it would serialise the overlap): whole-step accounting.
@@ -260,7 +294,8 @@ def main():
             per_ex = algorithmic_bytes(args.k, args.nnz, "rowsums") + algorithmic_bytes(args.k, args.nnz, "apply")
             achieved = value * per_ex / world / 1e9
             roof = {"bound": "hbm", "kernel": "k_rowsums + k_apply_seg (whole step, per GPU)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "v_read_frac": v_read_fraction(value, args.k, args.nnz, world), "traffic": None,
                     "bytes_per_example": per_ex, "examples_per_launch": rows_per_launch}
             # wire side: ONE all-reduce of [batch][KP + 1] fp32 per batch; algbw = payload bytes reduced per second
             wire = 4 * (info.k_padded + 1)
@@ -276,17 +311,16 @@ def main():
             "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
-                       "w0_chunk": args.w0_chunk or 256, "bias_lag": bool(lagf), "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
+                       "w0_chunk": args.w0_chunk or 256, "bias_lag": bias_lag, "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu_ref if (cpu_ref and "value" in cpu_ref) else cpu,
         }
-        if cpu_ref is not None:
-            out["cpu_reference"] = cpu_ref
+        if cpu_ref and "value" in cpu_ref and cpu is not None:
+            out["cpu_port"] = cpu
         if exchange is not None:
             out["exchange"] = exchange
-        if exact is not None:
-            out["minibatch_exact"] = exact
+        out.update(extras)
     h.close()
     if sharded:
         dist.destroy_process_group()

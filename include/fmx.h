@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 2
+#define FMX_ABI_VERSION 3
 
 enum {
   FMX_OK = 0,
@@ -47,7 +47,9 @@ enum { FMX_TASK_REGRESSION = 0, FMX_TASK_CLASSIFICATION = 1 };   /* fm_learn.h:4
 /* SGD update modes */
 enum {
   FMX_SGD_SEQUENTIAL = 0,  /* batch = 1, rows in storage order: the reference trajectory
-                              (fm_learn_sgd_element.h:56-67), for parity; one wavefront, slow */
+                              (fm_learn_sgd_element.h:56-67).  A PARITY mode, not a production mode: ONE wavefront,
+                              latency-bound, ~40x SLOWER than the reference on its own CPU (5.8 s vs 0.14 s on
+                              configs[0]).  Never make it a default; the adapters default to MINIBATCH. */
   FMX_SGD_MINIBATCH = 1,   /* restated batch rule (oracle/fm_oracle.h fmo_sgd_epoch_minibatch):
                               partial sums -> [all-reduce] -> w0 micro-chunks + multipliers -> scatter-add */
   FMX_SGD_HOGWILD = 2      /* fused single pass per example (gather, predict, update in registers);
@@ -60,8 +62,14 @@ enum {
                               (reads of a feature that collides inside the batch may see a partial update) */
   FMX_APPLY_STORE = 2,     /* one wavefront per example, plain read-modify-write stores (colliding ids in a
                               batch lose updates; exact when a batch has no repeated feature) */
-  FMX_APPLY_SEGMENTED = 3  /* MINIBATCH only: entries pre-bucketed per (batch, feature); one owner per touched
+  FMX_APPLY_SEGMENTED = 3, /* MINIBATCH only: entries pre-bucketed per (batch, feature); one owner per touched
                               row, no atomics, exactly the batch rule of oracle/fm_oracle.h (deterministic) */
+  FMX_APPLY_FUSED = 4      /* MINIBATCH only, implies FMX_FLAG_BIAS_LAG: the SAME batch rule in one pass over HBM.  The rule
+                              takes every sum and gradient from batch-start parameters, so a feature that occurs once in its
+                              batch is gathered, used and written back by its own example's wavefront (V read once, written
+                              once -- the algorithmic minimum); the features that occur more than once in the batch are
+                              finished by the segmented kernel from the factor sums their examples leave behind.
+                              Deterministic, bit-for-bit the result of FMX_APPLY_SEGMENTED with the same bias_lag. */
 };
 
 typedef struct fmx_context_s *fmx_handle;
@@ -93,7 +101,12 @@ typedef struct fmx_sgd_opts {
                              * The reference moves w0 after every example (fm_sgd.h:34-37); a chunk is one batch step of
                              * size learn_rate * chunk on the bias and oscillates when that product exceeds 2 / curvature. */
   uint32_t flags;           /* FMX_FLAG_* */
-  uint32_t reserved;
+  uint32_t bias_lag;        /* with FMX_FLAG_BIAS_LAG / FMX_APPLY_FUSED: the multipliers of batch b use the bias as it was after
+                               the recurrence of batch b - bias_lag (0 = 1 = the bias of the batch start).  fmx_sgd_epoch with
+                               FMX_APPLY_FUSED honours 1..4: with bias_lag >= 2 the one-workgroup recurrence of a batch hides
+                               under the next launches instead of sitting between them.  The split step
+                               (fmx_sgd_partial / fmx_sgd_finish) implements 1 only.
+                               Oracle: fmo_sgd_epoch_minibatch_ex(..., bias_lag). */
 } fmx_sgd_opts;
 
 #define FMX_FLAG_TIME_MAIN_KERNEL 1u  /* bracket every launch of the dominant kernel with HIP events */
@@ -113,6 +126,8 @@ typedef struct fmx_epoch_stats {
                                * well below 1 (curvature: x^2 for regression, x^2 / 4 for classification) -- pick the batch
                                * size accordingly, or use SEQUENTIAL / HOGWILD for data with very frequent features. */
   uint32_t reserved;
+  uint64_t deferred_features; /* FMX_APPLY_FUSED: (batch, feature) pairs finished by the segmented kernel, summed over the
+                               * epoch's batches (features occurring more than once in their batch; the rest was one pass) */
 } fmx_epoch_stats;
 
 /* what fm_learn::evaluate_regression / evaluate_classification compute (fm_learn.h:113-153) */

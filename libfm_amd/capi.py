@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("FMX_LIB", os.path.join(HERE, "libfmx.so"))   # FMX_LI
 FMX_OK = 0
 TASK_REGRESSION, TASK_CLASSIFICATION = 0, 1
 SGD_SEQUENTIAL, SGD_MINIBATCH, SGD_HOGWILD = 0, 1, 2
-APPLY_DEFAULT, APPLY_ATOMIC, APPLY_STORE, APPLY_SEGMENTED = 0, 1, 2, 3
+APPLY_DEFAULT, APPLY_ATOMIC, APPLY_STORE, APPLY_SEGMENTED, APPLY_FUSED = 0, 1, 2, 3, 4
 FLAG_TIME_MAIN_KERNEL = 1
 FLAG_BIAS_LAG = 2
 MAX_SLOTS = 8
@@ -37,13 +37,13 @@ class Config(C.Structure):
 
 class SgdOpts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("apply", C.c_int32), ("batch", C.c_uint32), ("w0_chunk", C.c_uint32),
-                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("bias_lag", C.c_uint32)]
 
 
 class EpochStats(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("batches", C.c_uint64), ("device_seconds", C.c_double),
                 ("main_kernel_seconds", C.c_double), ("main_kernel_launches", C.c_uint64),
-                ("max_feature_count", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_feature_count", C.c_uint32), ("reserved", C.c_uint32), ("deferred_features", C.c_uint64)]
 
 
 class Eval(C.Structure):
@@ -284,8 +284,8 @@ class Handle:
         self._chk(self.lib.fmx_evaluate(self.h, slot, C.byref(ev)))
         return ev
 
-    def sgd_epoch(self, slot, mode, apply=APPLY_DEFAULT, batch=0, w0_chunk=0, flags=0):
-        opts = SgdOpts(mode, apply, batch, w0_chunk, flags, 0)
+    def sgd_epoch(self, slot, mode, apply=APPLY_DEFAULT, batch=0, w0_chunk=0, flags=0, bias_lag=0):
+        opts = SgdOpts(mode, apply, batch, w0_chunk, flags, bias_lag)
         st = EpochStats()
         self._chk(self.lib.fmx_sgd_epoch(self.h, slot, C.byref(opts), C.byref(st)))
         return st

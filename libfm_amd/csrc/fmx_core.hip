@@ -83,8 +83,11 @@ void free_segments(Slot& s) {
   if (s.t_ent) hipFree(s.t_ent);
   if (s.seg_feat) hipFree(s.seg_feat);
   if (s.seg_rel) hipFree(s.seg_rel);
+  if (s.cmask) hipFree(s.cmask);
+  if (s.cseg) hipFree(s.cseg);
   s.t_ent = nullptr; s.seg_feat = nullptr; s.seg_rel = nullptr; s.seg_B = 0; s.nseg = 0;
-  s.batch_seg.clear(); s.batch_base.clear();
+  s.cmask = nullptr; s.cseg = nullptr; s.ncseg = 0; s.fused_cap = 0;
+  s.batch_seg.clear(); s.batch_base.clear(); s.cbatch.clear();
 }
 
 void free_slot(Slot& s) {
@@ -148,7 +151,14 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
       fmx_destroy(h); return FMX_E_HIP; } } while (0)
   CREATE_CHK(hipSetDevice(dev));
   CREATE_CHK(hipGetDeviceProperties(&h->prop, dev));
-  CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  // FMX_SCAN_CU=1 (experiment): reserve one CU for the side stream of the bias recurrence (stream2) and keep the launch
+  // streams off it -- the one-workgroup recurrence then does not share its SIMDs / LDS with gather wavefronts
+  const bool scan_cu = getenv("FMX_SCAN_CU") && atoi(getenv("FMX_SCAN_CU")) > 0;
+  uint32_t mask_main[8], mask_scan[8];
+  for (int i = 0; i < 8; i++) { mask_main[i] = 0xFFFFFFFFu; mask_scan[i] = 0u; }
+  mask_main[0] &= ~1u; mask_scan[0] = 1u;
+  if (scan_cu) CREATE_CHK(hipExtStreamCreateWithCUMask(&h->stream, 8, mask_main));
+  else CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_CHK(hipEventCreate(&h->ev0));
   CREATE_CHK(hipEventCreate(&h->ev1));
   {
@@ -162,7 +172,11 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     CREATE_CHK(hipMalloc(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float)));
     CREATE_CHK(hipMemsetAsync(h->tb.V, 0, h->n_local * (size_t)h->tb.rs * sizeof(float), h->stream));
     if (wpad == 0) {
-      CREATE_CHK(hipMalloc(&h->w_sep, h->n_local * sizeof(float)));
+      // FMX_W_ALLOC (experiment, scripts/ubench/w_gather.hip): 1 = uncached, 2 = fine-grained allocation of the w array
+      const int walloc = getenv("FMX_W_ALLOC") ? atoi(getenv("FMX_W_ALLOC")) : 0;
+      if (walloc == 1)      CREATE_CHK(hipExtMallocWithFlags((void**)&h->w_sep, h->n_local * sizeof(float), hipDeviceMallocUncached));
+      else if (walloc == 2) CREATE_CHK(hipExtMallocWithFlags((void**)&h->w_sep, h->n_local * sizeof(float), hipDeviceMallocFinegrained));
+      else                  CREATE_CHK(hipMalloc(&h->w_sep, h->n_local * sizeof(float)));
       CREATE_CHK(hipMemsetAsync(h->w_sep, 0, h->n_local * sizeof(float), h->stream));
       h->tb.w = h->w_sep; h->tb.ws = 1;
     } else {
@@ -175,9 +189,11 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
      // that its workgroup is placed as soon as any CU has room
     int lo = 0, hi = 0;
     CREATE_CHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CREATE_CHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+    if (scan_cu) CREATE_CHK(hipExtStreamCreateWithCUMask(&h->stream2, 8, mask_scan));
+    else CREATE_CHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
   }
-  CREATE_CHK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+  if (scan_cu) CREATE_CHK(hipExtStreamCreateWithCUMask(&h->stream3, 8, mask_main));
+  else CREATE_CHK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   h->num_cu = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
   CREATE_CHK(hipMalloc(&h->acc, 4 * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));

@@ -38,6 +38,12 @@ struct Slot {
   uint32_t  max_seg_count = 0;       // occurrences of the most frequent feature inside one batch
   std::vector<uint32_t> batch_seg;   // [n_batches+1] first segment of every batch
   std::vector<uint64_t> batch_base;  // [n_batches+1] first entry of every batch
+  // FMX_APPLY_FUSED (k_fused<FUSED_EXACT>): which entries the one-pass kernel must leave to k_apply_seg
+  uint64_t* cmask = nullptr;         // [n_rows] bit i: entry i's feature occurs more than once in the row's batch
+  uint32_t* cseg = nullptr;          // [ncseg] batch-local indices of the segments k_apply_seg finishes
+  uint32_t  ncseg = 0;
+  uint32_t  fused_cap = 0;           // longest row the k_fused instance of this slot keeps in registers
+  std::vector<uint32_t> cbatch;      // [n_batches+1] first cseg entry of every batch
 };
 
 struct AlsState {
@@ -52,7 +58,7 @@ struct AlsState {
   std::vector<double> prior_host;
 };
 
-struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping: w0 lives in w0_pp[step & 1] while active
+struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping (split step): w0 lives in w0_pp[step & 1] while active
   bool       active = false;
   uint64_t   step = 0;
   hipEvent_t ev_rest = nullptr, ev_scan[2] = {nullptr, nullptr};

@@ -669,14 +669,69 @@ k_seg_max_count(const uint32_t* __restrict__ head, uint32_t nseg, uint32_t* __re
   if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
 }
 
+// ---- what FUSED_EXACT needs to know about a batch (built once with the segments) ----------------------------------
+// rows that do not fit the register path of k_fused are deferred as a whole
+static __global__ void __launch_bounds__(256)
+k_seg_slow_rows(const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint32_t cap, uint64_t* __restrict__ cmask) {
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x)
+    cmask[r] = ((uint32_t)(row_ptr[r + 1] - row_ptr[r]) > cap) ? ~0ull : 0ull;
+}
+// one thread per segment: cflag[s] = the feature occurs more than once in its batch, or its (only) example is a deferred
+// row; for multi-occurrence features the bit of every occurrence is set in its row's mask (the row is searched for the
+// id: <= 64 entries, one-time cost).  keys / vals are the sorted (batch, feature) keys and {example, value} payloads.
+static __global__ void __launch_bounds__(256)
+k_seg_mark(const uint64_t* __restrict__ keys, const TEntry* __restrict__ vals, const uint32_t* __restrict__ head, uint32_t nseg,
+           const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t B, uint32_t cap,
+           uint64_t* __restrict__ cmask, uint32_t* __restrict__ cflag) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
+    const uint32_t a = head[s], b = head[s + 1];
+    const uint64_t key = keys[a];
+    const uint64_t rbase = (uint64_t)(key >> 32) * B;
+    const uint32_t feat = (uint32_t)key;
+    bool coll = (b - a) > 1;
+    if (!coll) {
+      const uint64_t r = rbase + vals[a].e;
+      coll = (uint32_t)(row_ptr[r + 1] - row_ptr[r]) > cap;
+    } else {
+      for (uint32_t i = a; i < b; i++) {
+        const uint64_t r = rbase + vals[i].e;
+        const uint64_t ra = row_ptr[r];
+        const uint32_t size = (uint32_t)(row_ptr[r + 1] - ra);
+        if (size > cap) continue;                              // deferred row: mask is all ones already
+        uint64_t bits = 0;
+        for (uint32_t q = 0; q < size; q++) if (ent[ra + q].id == feat) bits |= 1ull << q;
+        atomicOr((unsigned long long*)(cmask + r), (unsigned long long)bits);
+      }
+    }
+    cflag[s] = coll ? 1u : 0u;
+  }
+}
+// compaction: cseg[cpos[s]] = batch-local index of the flagged segment s (cpos = exclusive scan of cflag)
+static __global__ void __launch_bounds__(256)
+k_seg_compact(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head, const uint32_t* __restrict__ cflag,
+              const uint32_t* __restrict__ cpos, uint32_t nseg, const uint32_t* __restrict__ batch_seg, uint32_t* __restrict__ cseg) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x)
+    if (cflag[s]) cseg[cpos[s]] = s - batch_seg[(uint32_t)(keys[head[s]] >> 32)];
+}
+static __global__ void __launch_bounds__(256)
+k_seg_cbatch(const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ cflag, uint32_t nseg,
+             const uint32_t* __restrict__ batch_seg, uint32_t n_batches, uint32_t* __restrict__ cbatch) {
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= n_batches; b += gridDim.x * blockDim.x) {
+    const uint32_t s = batch_seg[b];
+    cbatch[b] = (s < nseg) ? cpos[s] : (nseg ? cpos[nseg - 1] + cflag[nseg - 1] : 0u);
+  }
+}
+
 // One wavefront owns blocks of 64 consecutive segments: the descriptors, first occurrences and their
 // multipliers are fetched lane-parallel (coalesced), then U segment groups at a time are broadcast and their
 // V rows + S rows gathered together (2*U row loads in flight per wavefront).
 template <int KP, int U>
 __global__ void __launch_bounds__(256)
 k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
-            uint32_t nseg, uint32_t batch_nnz, const Tab tb, Hyper h,
+            const uint32_t* __restrict__ seg_idx, uint32_t nseg, uint32_t nseg_batch, uint32_t batch_nnz, const Tab tb, Hyper h,
             const float* __restrict__ S, const float* __restrict__ mult) {
+  // seg_idx == nullptr: all nseg (== nseg_batch) segments of the batch; else the nseg listed ones (the features that
+  // occur more than once in the batch: what FUSED_EXACT leaves behind)
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -685,10 +740,10 @@ k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_f
     const uint32_t cnt = min(64u, nseg - blk);
     uint32_t jl = 0, al = 0, bl = 0, el = 0; float xl = 0.f, ml = 0.f;
     if (lane < cnt) {
-      const uint32_t s = blk + lane;
+      const uint32_t s = seg_idx ? seg_idx[blk + lane] : blk + lane;
       jl = seg_feat[s];
       al = seg_rel[s];
-      bl = (s + 1 < nseg) ? seg_rel[s + 1] : batch_nnz;
+      bl = (s + 1 < nseg_batch) ? seg_rel[s + 1] : batch_nnz;
       const TEntry te = load_stream8(t_ent + al);
       el = te.e; xl = te.x;
       ml = mult[el];
@@ -748,25 +803,37 @@ k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_f
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_fused: HOGWILD mode.  One wavefront per example, ONE pass over HBM: the gathered V rows stay in
-// registers (ZR row-slots x VEC floats per lane), the prediction, multiplier and fm_SGD update are
-// computed in-register and the rows are written straight back.  V is read once and written once --
-// the algorithmic minimum of a training step.  Rows longer than ZR*EPI (or 64)
-// take the two-pass path (row_sums + row_apply; the second read is an L2 hit).
-// w0 is FROZEN for the launch (one macro-batch): a per-example read-modify-write of one scalar from
-// ~6000 resident wavefronts is a single-address hot spot and, worse, an unstable recurrence at that
-// staleness.  The kernel writes rest_e = y-hat_e - w0 and k_scan advances w0 afterwards with the exact
-// micro-chunk recurrence (fm_sgd.h:34-37), see DESIGN.md section 3.
+// k_fused: one wavefront per example, ONE pass over HBM: the gathered V rows stay in registers (ZR row-slots x VEC
+// floats per lane), the prediction, multiplier and fm_SGD update are computed in-register and the rows are written
+// straight back.  V is read once and written once -- the algorithmic minimum of a training step.
+// Rows longer than ZR*EPI (or 64) take the two-pass path (row_sums + row_apply; the second read is an L2 hit).
+// w0 is FROZEN for the launch: a per-example read-modify-write of one scalar from ~6000 resident wavefronts is a
+// single-address hot spot and, worse, an unstable recurrence at that staleness.  The kernel writes
+// rest_e = y-hat_e - w0 and k_scan advances w0 afterwards with the exact micro-chunk recurrence (fm_sgd.h:34-37).
+//
+// Variants:
+//   FUSED_STORE / FUSED_ATOMIC : HOGWILD -- every entry is written back (plain stores / fp32 atomic adds); rows in
+//       flight race on shared features.
+//   FUSED_EXACT : the MINIBATCH rule (oracle fmo_sgd_epoch_minibatch_ex, bias_lag >= 1) in one pass.  The rule takes
+//       every sum and every gradient from BATCH-START parameters, so an entry whose feature occurs ONCE in the batch
+//       can be updated by its own example's wavefront right away -- nobody else reads or writes that row in this
+//       launch.  cmask[row] has bit i set when entry i's feature occurs more than once in the batch (or the row does
+//       not fit the register path): those entries are NOT written here (their rows keep the batch-start value for
+//       every reader); the example leaves its factor sums S_e and multiplier behind and k_apply_seg finishes exactly
+//       those features afterwards (one owner per feature, all occurrences summed).  Bit-for-bit the batch rule.
 // ----------------------------------------------------------------------------------------------
 #ifndef FMX_FUSED_MIN_WAVES
 #define FMX_FUSED_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
-template <int KP, int ZR, bool ATOMIC>
+enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2 };
+template <int KP, int ZR, int VAR>
 __global__ void __launch_bounds__(256, FMX_FUSED_MIN_WAVES)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
         uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
-        const double* __restrict__ w0_ptr, float* __restrict__ rest_out) {
+        const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
+        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), EXACT = (VAR == FUSED_EXACT);
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
@@ -776,6 +843,8 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
     const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
     const Entry* __restrict__ row = ent + a;
     const float y = target[row0 + e];
+    uint64_t cm = 0;
+    if constexpr (EXACT) cm = cmask[row0 + e];
     if (size <= (uint32_t)(ZR * EPI) && size <= 64u) {
       Entry en; en.id = 0; en.value = 0.f;
       float wv = 0.f;
@@ -784,7 +853,10 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         if (h.k1) wv = load_w(tb.w + (size_t)en.id * tb.ws);
       }
       // phase A: issue every gather of the row back-to-back (ids / values are re-broadcast later instead of
-      // being kept: with EPI == 1 they are wave-uniform and live in SGPRs for the duration of one use)
+      // being kept: with EPI == 1 they are wave-uniform and live in SGPRs for the duration of one use).
+      // Every cross-lane broadcast below runs with ALL lanes active (outside the idx < size guards): a ds_bpermute
+      // from a lane that is masked off returns 0, and with EPI > 1 the source lane t*EPI+g of a short row's last
+      // entries can belong to a lane whose own idx is >= size.
       float vr[ZR][VEC];
 #pragma unroll
       for (int t = 0; t < ZR; t++) {
@@ -797,14 +869,15 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
           for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
         }
       }
-      // phase B: sums (fm_model.h:116-125)
+      // phase B: sums (fm_model.h:116-125); lanes >= size hold value 0, so no guard is needed on x
       float sum[VEC]; float sq = 0.f;
 #pragma unroll
       for (int v = 0; v < VEC; v++) sum[v] = 0.f;
 #pragma unroll
       for (int t = 0; t < ZR; t++) {
         const uint32_t idx = t * EPI + g;
-        const float x = (idx < size) ? bcast_f32<EPI>(en.value, idx & 63u) : 0.f;
+        float x = bcast_f32<EPI>(en.value, idx & 63u);
+        if (idx >= size) x = 0.f;
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
           const float d = vr[t][v] * x;
@@ -822,7 +895,13 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       const float rest = wave_sum_dpp(part);
       if (lane == 0) rest_out[e] = rest;
       const float mult = multiplier(h, w0s + rest, y);
-      if (h.k1 && lane < size) {                             // fm_sgd.h:38-43
+      if constexpr (EXACT) {
+        if (cm != 0) {                                         // some feature of this example is finished by k_apply_seg
+          if (lane < LPR) store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
+          if (lane == 0) mult_out[e] = mult;
+        }
+      }
+      if (h.k1 && lane < size && !(EXACT && ((cm >> lane) & 1ull))) {             // fm_sgd.h:38-43
         const float dw = -h.lr * (mult * en.value + h.regw * wv);
         if (ATOMIC) unsafeAtomicAdd(tb.w + (size_t)en.id * tb.ws, dw); else tb.w[(size_t)en.id * tb.ws] = wv + dw;
       }
@@ -830,9 +909,9 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
 #pragma unroll
       for (int t = 0; t < ZR; t++) {
         const uint32_t idx = t * EPI + g;
-        if (idx < size) {
-          const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
-          const float x = bcast_f32<EPI>(en.value, idx & 63u);
+        const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
+        const float x = bcast_f32<EPI>(en.value, idx & 63u);
+        if (idx < size && !(EXACT && ((cm >> (idx & 63u)) & 1ull))) {
           float* pv = tb.V + (size_t)id * tb.rs + f * VEC;
           float nv[VEC];
 #pragma unroll
@@ -858,7 +937,12 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       const float rest = wave_sum_dpp(part);
       if (lane == 0) rest_out[e] = rest;
       const float mult = multiplier(h, w0s + rest, y);
-      row_apply<KP, 8, ATOMIC>(row, size, tb, h, sum, mult);
+      if constexpr (EXACT) {                                   // the whole row is deferred (cmask = all ones)
+        if (lane < LPR) store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
+        if (lane == 0) mult_out[e] = mult;
+      } else {
+        row_apply<KP, 8, ATOMIC>(row, size, tb, h, sum, mult);
+      }
     }
   }
 }

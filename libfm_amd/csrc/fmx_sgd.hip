@@ -16,21 +16,35 @@ uint32_t default_w0_chunk(const fmx_config& c) {
   return chunk;
 }
 
-template <int KP, bool ATOMIC>
+// row slots (ZR) of the k_fused instance used for a slot: the smallest instance whose registers hold the longest row
+template <int KP> constexpr bool fused_zr_ok(int zr) { return Map<KP>::VEC * zr <= 128; }
+template <int KP> int fused_zr_select(uint32_t max_row) {
+  constexpr int EPI = Map<KP>::EPI;
+  const uint32_t need = (max_row + EPI - 1) / EPI;         // row slots per lane to keep a whole row in registers
+  for (int zr : {8, 16, 32, 40, 64})                       // 40: Criteo-shaped rows (39 fields)
+    if (fused_zr_ok<KP>(zr) && need <= (uint32_t)zr) return zr;
+  return 8;                                                // rows too long for the register file: the kernel's two-pass branch
+}
+// longest row the selected instance keeps in registers (longer rows take its two-pass branch; FUSED_EXACT defers them)
+template <int KP> uint32_t fused_row_cap_kp(uint32_t max_row) {
+  return std::min<uint32_t>(64u, (uint32_t)fused_zr_select<KP>(max_row) * (uint32_t)Map<KP>::EPI);
+}
+
+template <int KP, int VAR>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
-                    const double* w0_in, float* rest_out) {
-  constexpr int VEC = Map<KP>::VEC, EPI = Map<KP>::EPI;
-  const uint32_t need = (s.max_row + EPI - 1) / EPI;      // row slots per lane to keep a whole row in registers
+                    const double* w0_in, float* rest_out, const uint64_t* cmask = nullptr, float* S_out = nullptr,
+                    float* mult_out = nullptr) {
 #define FMX_LAUNCH_ZR(ZRV)                                                                                  \
-  FMX_LAUNCH_WAVES((k_fused<KP, ZRV, ATOMIC>), n_rows, st, s.ent, s.row_ptr, s.target, row0, \
-                   n_rows, h->tb, hy, w0_in, rest_out)
-  if constexpr (VEC * 8 <= 128) { if (need <= 8) { FMX_LAUNCH_ZR(8); return FMX_OK; } }
-  if constexpr (VEC * 16 <= 128) { if (need <= 16) { FMX_LAUNCH_ZR(16); return FMX_OK; } }
-  if constexpr (VEC * 32 <= 128) { if (need <= 32) { FMX_LAUNCH_ZR(32); return FMX_OK; } }
-  if constexpr (VEC * 40 <= 128) { if (need <= 40) { FMX_LAUNCH_ZR(40); return FMX_OK; } }   // Criteo-shaped rows (39 fields)
-  if constexpr (VEC * 64 <= 128) { if (need <= 64) { FMX_LAUNCH_ZR(64); return FMX_OK; } }
-  // rows too long for the register file: the kernel's two-pass branch handles them (ZR = 8 instance)
-  FMX_LAUNCH_ZR(8);
+  if constexpr (fused_zr_ok<KP>(ZRV)) {                                                                     \
+    FMX_LAUNCH_WAVES((k_fused<KP, ZRV, VAR>), n_rows, st, s.ent, s.row_ptr, s.target, row0,                 \
+                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out); }
+  switch (fused_zr_select<KP>(s.max_row)) {
+    case 8:  FMX_LAUNCH_ZR(8);  break;
+    case 16: FMX_LAUNCH_ZR(16); break;
+    case 32: FMX_LAUNCH_ZR(32); break;
+    case 40: FMX_LAUNCH_ZR(40); break;
+    case 64: FMX_LAUNCH_ZR(64); break;
+  }
 #undef FMX_LAUNCH_ZR
   return FMX_OK;
 }
@@ -76,7 +90,9 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   if (nnz >= (1ull << 31)) return fail(h, FMX_E_UNSUPPORTED, "segmented apply: nnz >= 2^31 in one slot (split the data set)");
   hipStream_t st = h->stream;
   uint64_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr;
+  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr, *d_cbatch = nullptr;
+  uint32_t cap = 64;
+  KP_SWITCH(h->KP, cap = fused_row_cap_kp<KP>(s.max_row));
   void* tmp = nullptr;
   int rc = FMX_OK;
   const size_t cnt = (size_t)std::max<uint64_t>(nnz, 1);
@@ -85,7 +101,11 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   SEG_CHK(hipMalloc(&keys_a, cnt * 8)); SEG_CHK(hipMalloc(&keys_b, cnt * 8));
   SEG_CHK(hipMalloc(&vals_a, cnt * 8)); SEG_CHK(hipMalloc(&vals_b, cnt * 8));
   SEG_CHK(hipMalloc(&flags, cnt * 4)); SEG_CHK(hipMalloc(&pos, cnt * 4));
-  SEG_CHK(hipMalloc(&d_batch_seg, ((size_t)n_batches + 1) * 4));
+  SEG_CHK(hipMalloc(&d_batch_seg, ((size_t)n_batches + 2) * 4));          // [n_batches + 1] is the max-count cell
+  SEG_CHK(hipMalloc(&d_cbatch, ((size_t)n_batches + 1) * 4));
+  SEG_CHK(hipMalloc(&s.cmask, (size_t)std::max<uint32_t>(s.n_rows, 1) * 8));
+  hipLaunchKernelGGL(k_seg_slow_rows, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, st, s.row_ptr, s.n_rows, cap, s.cmask);
+  s.fused_cap = cap;
   if (nnz) {
     hipLaunchKernelGGL(k_seg_keys, dim3(wave_grid(s.n_rows)), dim3(256), 0, st, s.ent, s.row_ptr, s.n_rows, B, keys_a, vals_a);
     int bits_batch = 1; while ((1ull << bits_batch) < n_batches) bits_batch++;
@@ -114,17 +134,43 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
     SEG_CHK(hipStreamSynchronize(st));
     {  // longest segment (reported through fmx_epoch_stats::max_feature_count); keys_a is free after the sort
       uint32_t* head = reinterpret_cast<uint32_t*>(keys_a);            // [nseg + 1] <= 8 bytes per entry
-      SEG_CHK(hipMemsetAsync(d_batch_seg, 0, 4, st));
+      uint32_t* d_max = d_batch_seg + n_batches + 1;
+      SEG_CHK(hipMemsetAsync(d_max, 0, 4, st));
       hipLaunchKernelGGL(k_seg_head_pos, dim3(2048), dim3(256), 0, st, flags, pos, nnz, nseg, head);
-      hipLaunchKernelGGL(k_seg_max_count, dim3(2048), dim3(256), 0, st, head, nseg, d_batch_seg);
-      SEG_CHK(hipMemcpyAsync(&s.max_seg_count, d_batch_seg, 4, hipMemcpyDeviceToHost, st));
+      hipLaunchKernelGGL(k_seg_max_count, dim3(2048), dim3(256), 0, st, head, nseg, d_max);
+      SEG_CHK(hipMemcpyAsync(&s.max_seg_count, d_max, 4, hipMemcpyDeviceToHost, st));
+      SEG_CHK(hipStreamSynchronize(st));
+      // what the one-pass kernel (FMX_APPLY_FUSED) must leave to k_apply_seg: features occurring more than once in
+      // their batch + rows too long for its registers.  flags / pos are free now: cflag = flags, cpos = pos.
+      uint32_t *cflag = flags, *cpos = pos;
+      hipLaunchKernelGGL(k_seg_mark, dim3(2048), dim3(256), 0, st, keys_b, reinterpret_cast<const TEntry*>(vals_b), head, nseg,
+                         s.ent, s.row_ptr, B, cap, s.cmask, cflag);
+      SEG_CHK(hipGetLastError());
+      hipFree(tmp); tmp = nullptr; tmp_bytes = 0;
+      SEG_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cflag, cpos, (int)nseg, st));
+      SEG_CHK(hipMalloc(&tmp, tmp_bytes));
+      SEG_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cflag, cpos, (int)nseg, st));
+      uint32_t last_pos = 0, last_flag = 0;
+      SEG_CHK(hipMemcpyAsync(&last_pos, cpos + (nseg - 1), 4, hipMemcpyDeviceToHost, st));
+      SEG_CHK(hipMemcpyAsync(&last_flag, cflag + (nseg - 1), 4, hipMemcpyDeviceToHost, st));
+      SEG_CHK(hipStreamSynchronize(st));
+      s.ncseg = last_pos + last_flag;
+      SEG_CHK(hipMalloc(&s.cseg, (size_t)std::max<uint32_t>(s.ncseg, 1) * 4));
+      hipLaunchKernelGGL(k_seg_compact, dim3(2048), dim3(256), 0, st, keys_b, head, cflag, cpos, nseg, d_batch_seg, s.cseg);
+      hipLaunchKernelGGL(k_seg_cbatch, dim3((n_batches + 256) / 256), dim3(256), 0, st, cpos, cflag, nseg, d_batch_seg, n_batches, d_cbatch);
+      SEG_CHK(hipGetLastError());
+      s.cbatch.resize((size_t)n_batches + 1);
+      SEG_CHK(hipMemcpyAsync(s.cbatch.data(), d_cbatch, ((size_t)n_batches + 1) * 4, hipMemcpyDeviceToHost, st));
       SEG_CHK(hipStreamSynchronize(st));
     }
     s.t_ent = reinterpret_cast<TEntry*>(vals_b); vals_b = nullptr;      // payload layout == TEntry
   } else {
-    s.nseg = 0;
+    s.nseg = 0; s.ncseg = 0;
     s.batch_seg.assign((size_t)n_batches + 1, 0);
+    s.cbatch.assign((size_t)n_batches + 1, 0);
     SEG_CHK(hipMalloc(&s.t_ent, 8));
+    SEG_CHK(hipMalloc(&s.cseg, 4));
+    SEG_CHK(hipStreamSynchronize(st));
   }
   {  // first entry of every batch (row_ptr sampled at multiples of B)
     std::vector<uint64_t> rp((size_t)s.n_rows + 1);
@@ -142,6 +188,7 @@ done:
   if (flags) hipFree(flags);
   if (pos) hipFree(pos);
   if (d_batch_seg) hipFree(d_batch_seg);
+  if (d_cbatch) hipFree(d_cbatch);
   if (tmp) hipFree(tmp);
   if (rc) free_segments(s);
   return rc;
@@ -234,7 +281,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
                : launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
   if (rc) return rc;
   int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
-  if (apply == FMX_APPLY_DEFAULT) apply = FMX_APPLY_SEGMENTED;
+  if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) apply = FMX_APPLY_SEGMENTED;   // split step: same rule, two passes
   if (apply == FMX_APPLY_SEGMENTED && seg_batch < 0) return fail(h, FMX_E_STATE, "segmented apply needs batch-aligned rows");
   if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
   if (apply == FMX_APPLY_SEGMENTED) {
@@ -244,7 +291,8 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
     const uint32_t nseg = s1 - s0;
     if (nseg) {
       KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)nseg + 63) / 64, st,
-                                         s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nseg, bnnz, h->tb, hy, S, h->mult));
+                                         s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, (const uint32_t*)nullptr, nseg, nseg, bnnz,
+                                         h->tb, hy, S, h->mult));
     }
   } else if (apply == FMX_APPLY_ATOMIC) {
     KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, true>), n_rows, st,
@@ -285,7 +333,7 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   HIPCHK(h, hipGetLastError());
   int64_t seg_batch = -1;
   const int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
-  if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_SEGMENTED) {
+  if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_SEGMENTED || apply == FMX_APPLY_FUSED) {
     // the driver walks the slot in batches of opts->batch rows (the last one may be short)
     const uint32_t B = (opts && opts->batch) ? opts->batch : n_rows;
     if (row0 % B != 0 || (n_rows != B && row0 + n_rows != s.n_rows))
@@ -316,6 +364,61 @@ int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, fl
   return FMX_OK;
 }
 
+// MINIBATCH rule, FMX_APPLY_FUSED: per batch ONE pass over the examples (k_fused<FUSED_EXACT>: gather, predict, multiplier,
+// write-back of every feature that occurs once in the batch) + k_apply_seg over the features that occur more than once.
+// The multipliers of batch b use the bias as it was after the recurrence of batch b - d (d = opts->bias_lag >= 1; oracle
+// fmo_sgd_epoch_minibatch_ex with bias_lag = d): the recurrence of batch b (k_scan, one workgroup) runs on the side stream
+// under the launches of batches b+1 .. b+d-1 and only the launch of batch b+d waits for it.
+static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, const Hyper& hy, uint64_t* batches,
+                           uint64_t* launches, uint64_t* deferred) {
+  const uint32_t B = opts->batch ? opts->batch : 131072u;
+  const uint32_t d = opts->bias_lag ? opts->bias_lag : 1u;
+  if (d > 4) return fail(h, FMX_E_ARG, "bias_lag %u: at most 4 batches", d);
+  const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : default_w0_chunk(h->cfg);
+  int rc = ensure_segments(h, s, B);
+  if (rc) return rc;
+  const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
+  rc = ensure_scratch(h, Bc, (size_t)Bc * d);
+  if (rc) return rc;
+  const uint64_t n_batch = ((uint64_t)s.n_rows + B - 1) / B;
+  while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipEventRecord(h->ev0, st));                    // do not bill the one-time bucketing to the epoch
+  for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+  float* S = h->partial;
+  float* mult = h->mult;
+  for (uint64_t b = 0; b < n_batch; b++) {
+    const uint64_t row0 = b * B;
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
+    float* rest = h->rest + (size_t)(b % d) * Bc;
+    if (b >= d) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (b - d) + 1], 0));   // recurrence of batch b - d is done
+    const double* w0_in = h->w0_pp + ((b + 1) % d);         // written by the recurrence of batch b - d (initial bias for b < d)
+    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult); });
+    if (rc) return rc;
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
+    const uint32_t c0 = s.cbatch[(size_t)b], c1 = s.cbatch[(size_t)b + 1];
+    if (c1 > c0) {
+      const uint32_t s0 = s.batch_seg[(size_t)b], s1 = s.batch_seg[(size_t)b + 1];
+      const uint64_t base = s.batch_base[(size_t)b];
+      const uint32_t bnnz = (uint32_t)(s.batch_base[(size_t)b + 1] - base);
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)(c1 - c0) + 63) / 64, st,
+                                         s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, (const uint32_t*)(s.cseg + c0), c1 - c0, s1 - s0, bnnz,
+                                         h->tb, hy, (const float*)S, (const float*)mult));
+      HIPCHK(h, hipGetLastError());
+      *deferred += c1 - c0;
+    }
+    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * b], 0));
+    rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d));
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_sync[2 * b + 1], h->stream2));
+    (*batches)++; (*launches)++;
+  }
+  HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (n_batch - 1) + 1], 0));
+  if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_batch % d), sizeof(double), hipMemcpyDeviceToDevice, st));
+  return FMX_OK;
+}
+
 int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats) {
   int rc = check_slot(h, slot, true);
   if (rc) return rc;
@@ -331,7 +434,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     return fail(h, FMX_E_UNSUPPORTED, "fmx_sgd_epoch on a feature shard: drive fmx_sgd_partial + all-reduce + fmx_sgd_finish");
   const Hyper hy = make_hyper(h->cfg);
   const bool timed = (opts->flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
-  uint64_t batches = 0, main_launches = 0;
+  uint64_t batches = 0, main_launches = 0, deferred = 0;
   size_t ev_used = 0;
   auto get_event = [&](hipEvent_t* ev) -> hipError_t {
     if (ev_used == h->ev_pool.size()) { hipEvent_t e; hipError_t er = hipEventCreate(&e); if (er != hipSuccess) return er; h->ev_pool.push_back(e); }
@@ -375,9 +478,9 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
       main_launches++;
       const double* w0_in = h->w0_pp + ((i + 1) % 3);      // slot written by scan i-3 (initial value for i < 3)
       if (opts->apply == FMX_APPLY_ATOMIC) {
-        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, true>(h, s, hy, row0, nb, fs, w0_in, rest); });
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_ATOMIC>(h, s, hy, row0, nb, fs, w0_in, rest); });
       } else {
-        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, false>(h, s, hy, row0, nb, fs, w0_in, rest); });
+        KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_STORE>(h, s, hy, row0, nb, fs, w0_in, rest); });
       }
       if (rc) return rc;
       HIPCHK(h, hipGetLastError());
@@ -391,6 +494,9 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     // stream2 is in order: its last event covers every scan, and scan i waited for launch i
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync[2 * (n_launch - 1) + 1], 0));
     if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_launch % 3), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  } else if (opts->mode == FMX_SGD_MINIBATCH && opts->apply == FMX_APPLY_FUSED) {
+    rc = sgd_epoch_fused(h, s, opts, hy, &batches, &main_launches, &deferred);
+    if (rc) return rc;
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
     const uint32_t B = opts->batch ? opts->batch : 16384u;
     const bool lag = (opts->flags & FMX_FLAG_BIAS_LAG) != 0;
@@ -435,7 +541,8 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     stats->batches = batches;
     stats->device_seconds = ms * 1e-3;
     if (opts->mode == FMX_SGD_MINIBATCH && s.seg_B) stats->max_feature_count = s.max_seg_count;
-    if (opts->mode == FMX_SGD_MINIBATCH && timed) {
+    stats->deferred_features = deferred;
+    if (opts->mode == FMX_SGD_MINIBATCH && timed && opts->apply != FMX_APPLY_FUSED) {
       double tot = 0;
       for (size_t i = 0; i + 1 < ev_used; i += 2) {
         float m2 = 0;

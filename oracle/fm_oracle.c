@@ -197,6 +197,12 @@ static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double lea
   /* stale: the parameters before the latest update (what the early gather of the next batch sees) */
   double *w_prev = stale ? (double *)malloc(sizeof(double) * (n ? n : 1)) : NULL;
   double *v_prev = stale ? (double *)malloc(sizeof(double) * ((n * kk) > 0 ? n * kk : 1)) : NULL;
+  /* bias_lag = d >= 1: the multipliers handed to step 3 of batch b use the bias as it was BEFORE the recurrence of batch
+   * b - d + 1, i.e. after the recurrence of batch b - d (d = 1: the bias of the batch start).  w0_hist[i % 8] = bias at
+   * the start of batch i. */
+  double w0_hist[8];
+  uint32_t bno = 0;
+  if (bias_lag > 8) bias_lag = 8;
 
   for (uint32_t r0 = 0; r0 < d->n_rows; r0 += batch) {
     uint32_t nb = (d->n_rows - r0 < batch) ? (d->n_rows - r0) : batch;
@@ -226,7 +232,10 @@ static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double lea
      * bias_lag: the multipliers handed to step 3 use the w0 of the BATCH start (frozen), while w0 itself still
      * advances through the micro-chunks with its own multipliers -- this takes the serial recurrence off the
      * critical path of the step (it overlaps the next batch's gather).  Identical to the plain rule at batch 1. */
-    const double w0_batch = m->k0 ? m->w0 : 0.0;
+    w0_hist[bno % 8] = m->k0 ? m->w0 : 0.0;
+    const uint32_t lag_b = (bias_lag > 0 && bno + 1 >= (uint32_t)bias_lag) ? bno + 1 - (uint32_t)bias_lag : 0;
+    const double w0_batch = w0_hist[lag_b % 8];
+    bno++;
     for (uint32_t c0 = 0; c0 < nb; c0 += w0_chunk) {
       uint32_t nc = (nb - c0 < w0_chunk) ? (nb - c0) : w0_chunk;
       double w0s = m->k0 ? m->w0 : 0.0;

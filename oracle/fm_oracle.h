@@ -101,8 +101,10 @@ double fmo_evaluate(const fmo_model *m, const fmo_data *d, int task,
 void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                              double min_target, double max_target,
                              uint32_t batch, uint32_t w0_chunk);
-/* same with bias_lag != 0: step 3 uses mult_e = multiplier(w0 at BATCH start + rest_e) while step 2's recurrence
- * still advances w0 chunk by chunk (GPU flag FMX_FLAG_BIAS_LAG: the recurrence leaves the critical path). */
+/* same with bias_lag = d >= 1: step 3 of batch b uses mult_e = multiplier(w0 + rest_e) with the w0 of the START of batch
+ * b - d + 1 (d = 1: the start of the batch itself; the first d - 1 batches use the initial bias) while step 2's recurrence
+ * still advances w0 chunk by chunk (GPU: FMX_FLAG_BIAS_LAG / fmx_sgd_opts::bias_lag -- the one-workgroup recurrence
+ * leaves the critical path and, for d >= 2, hides completely under the next launches). */
 void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                                 double min_target, double max_target,
                                 uint32_t batch, uint32_t w0_chunk, int bias_lag);

@@ -64,6 +64,70 @@ def test_training_step_spot_check_against_oracle(capi, oracle):
         h.close()
 
 
+def submodel_minibatch(capi, oracle, h, seed, row0, rows, batch, chunk, lag):
+    """the oracle's batch rule on the sub-model of the rows' features (parameters fetched BEFORE the device step)"""
+    d, m, ids = small_problem(capi, oracle, h, seed, row0, rows)
+    oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, batch, chunk, bias_lag=lag)
+    return d, m, ids
+
+
+def test_fused_minibatch_spot_check_at_full_size(capi, oracle):
+    """the bench mode (MINIBATCH rule, FMX_APPLY_FUSED, bias_lag 2) on the 25.6 GB model: 4 batches of 16 384 rows ==
+    the oracle's rule on the sub-model of the touched rows, colliding features included (about 0.5 % of the entries of
+    a batch share their feature with another example: those go through the segmented kernel)."""
+    rows, batch, chunk, lag = 65536, 16384, 256, 2
+    h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+    h.init_params(0.0, 0.05, 7)
+    h.synth_rows(0, 4321, 9_000_000, rows, NNZ)
+    d, m, ids = submodel_minibatch(capi, oracle, h, 4321, 9_000_000, rows, batch, chunk, lag)
+    st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, chunk, 0, lag)
+    assert 0 < st.deferred_features < 0.02 * rows * NNZ
+    w, v = h.get_param_rows(ids)
+    np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w, m.w, rtol=1e-4, atol=1e-6)
+    assert abs(h.get_w0() - m.w0) <= 1e-4 * abs(m.w0) + 1e-6
+    h.close()
+
+
+def test_fused_minibatch_is_deterministic_at_bench_batch(capi):
+    """two runs of the bench configuration (batch 262 144, bias_lag 2) give bit-identical predictions and bias"""
+    rows = 1 << 20
+    sums = []
+    for _ in range(2):
+        h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+        h.init_params(0.0, 0.05, 3)
+        h.synth_rows(0, 77, 0, rows, NNZ)
+        st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 262144, 0, 0, 2)
+        p = h.predict(0, rows)
+        sums.append((p.tobytes(), h.get_w0(), st.deferred_features))
+        h.close()
+    assert sums[0] == sums[1]
+    assert 0.02 * rows * NNZ < sums[0][2] < 0.06 * rows * NNZ   # ~4 % of the (batch, feature) pairs hold >= 2 occurrences
+
+
+def test_hogwild_at_bench_size_is_the_batch_rule_off_collisions(capi, oracle):
+    """HOGWILD where it is benchmarked (n = 1e8, one 65 536-row launch): every feature that occurs ONCE in the launch must
+    come out exactly as the batch rule leaves it (oracle, batch = launch, bias frozen for the launch); the features that
+    occur more than once race and are only counted and bounded."""
+    rows = 65536
+    h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+    h.init_params(0.0, 0.05, 7)
+    h.synth_rows(0, 999, 3_000_000, rows, NNZ)
+    d, m, ids = submodel_minibatch(capi, oracle, h, 999, 3_000_000, rows, rows, 256, 1)
+    for ap in (capi.APPLY_STORE,):
+        h.sgd_epoch(0, capi.SGD_HOGWILD, ap, rows, 256)
+    w, v = h.get_param_rows(ids)
+    counts = np.bincount(d.entries["id"], minlength=len(ids))
+    once = counts == 1
+    assert once.mean() > 0.95                                    # ~2 % of the touched features are shared
+    np.testing.assert_allclose(v[:, once], m.v[:, once], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w[once], m.w[once], rtol=1e-4, atol=1e-6)
+    # shared features: each racing writer applies a step of the right size from a value at most one update old
+    assert np.abs(v[:, ~once] - m.v[:, ~once]).max() < 5e-3
+    assert abs(h.get_w0() - m.w0) <= 1e-4 * abs(m.w0) + 1e-6     # the bias recurrence does not depend on the races
+    h.close()
+
+
 def test_pairwise_term_is_homogeneous_of_degree_two(capi):
     """with w = 0 and w0 = 0 the prediction is the pairwise term only; scaling V by 2 scales it by 4"""
     rows = 1 << 18

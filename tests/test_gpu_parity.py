@@ -189,6 +189,89 @@ def test_minibatch_bias_lag_matches_restated_rule(capi, oracle, name, batch, chu
     h.close()
 
 
+# ---------------------------------------------------------------------------------------------
+# FMX_APPLY_FUSED: the SAME batch rule in one pass (k_fused<FUSED_EXACT>) + the segmented kernel for the features that
+# occur more than once in a batch.  Held to the oracle's rule (bias_lag = d) on every fixture -- ML-shaped and Zipf ids
+# (most features collide), duplicate ids inside a row, ragged rows with empty ones, k = 1, k = 64, no linear term.
+# ---------------------------------------------------------------------------------------------
+FUSED_CASES = [("sgd_reg_ml", 1, 1, 1), ("sgd_reg_ml", 7, 1, 1), ("sgd_reg_ml", 64, 16, 2), ("sgd_reg_ml", 600, 64, 1),
+               ("sgd_reg_ml", 600, 64, 3), ("sgd_cls_ragged", 32, 8, 1), ("sgd_cls_ragged", 32, 8, 2),
+               ("sgd_cls_k64", 50, 64, 2), ("sgd_cls_k64", 300, 64, 1), ("sgd_reg_ragged_nolin", 16, 4, 2),
+               ("sgd_reg_k1", 25, 5, 4), ("sgd_cls_zipf_k32", 100, 10, 1), ("sgd_cls_zipf_k32", 100, 10, 2),
+               ("sgd_cls_dup", 10, 3, 1), ("sgd_cls_dup", 10, 3, 3)]
+
+
+@pytest.mark.parametrize("name,batch,chunk,lag", FUSED_CASES)
+def test_fused_minibatch_matches_restated_rule(capi, oracle, name, batch, chunk, lag):
+    g = Golden(name)
+    m = g.model(oracle, "init")
+    tr = g.data(oracle, "train")
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    upload(h, 0, tr)
+    deferred = 0
+    for _ in range(g.iters):
+        st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, chunk, 0, lag)
+        deferred += st.deferred_features
+        oracle.sgd_epoch_minibatch(m, tr, g.task, g.lr, g.min_target, g.max_target, batch, chunk, bias_lag=lag)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    if batch > 1 and name in ("sgd_reg_ml", "sgd_cls_zipf_k32", "sgd_cls_dup"):
+        assert deferred > 0                                    # these fixtures do exercise the collision path
+    h.close()
+
+
+@pytest.mark.parametrize("name,batch,chunk", [("sgd_reg_ml", 64, 16), ("sgd_cls_zipf_k32", 100, 10), ("sgd_cls_dup", 10, 3),
+                                              ("sgd_cls_ragged", 32, 8)])
+def test_fused_equals_segmented(capi, oracle, name, batch, chunk):
+    """the one-pass form and the two-pass segmented form of the rule (bias_lag = 1) agree to fp32 rounding"""
+    g = Golden(name)
+    m = g.model(oracle, "init")
+    tr = g.data(oracle, "train")
+    res = []
+    for ap, fl in ((capi.APPLY_FUSED, 0), (capi.APPLY_SEGMENTED, capi.FLAG_BIAS_LAG)):
+        h = make_handle(capi, g)
+        h.set_params(m.w0, m.w, m.v)
+        upload(h, 0, tr)
+        for _ in range(g.iters):
+            h.sgd_epoch(0, capi.SGD_MINIBATCH, ap, batch, chunk, fl, 1)
+        res.append(h.get_params())
+        h.close()
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0]) + 1e-6
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("task,batch,chunk,lag", [(1, 3000, 1024, 1), (0, 4096, 1024, 2), (1, 1500, 256, 3), (1, 9001, 256, 2),
+                                                  (0, 700, 512, 2), (1, 2048, 64, 4)])
+def test_fused_minibatch_many_batches_and_lags(capi, oracle, task, batch, chunk, lag):
+    """several batches per epoch with every bias-lag depth: the ring of bias slots / rest buffers, ragged last batch, the
+    four-wavefront recurrence kernel, collisions inside and across batches (4000 features, 54 000 entries)"""
+    n, nnz, rows, k = 4000, 6, 9001, 8
+    ent, row_ptr, y = datagen.onehot_fields(n - n % nnz, nnz, rows, seed=31 + batch, classification=(task == 1))
+    if task == 0:
+        y = (y * 0.5 + 0.1).astype(np.float32)
+    d = oracle.Data(ent, row_ptr, y)
+    m = oracle.Model(n, k, True, True, 0.002, 0.001, 0.003)
+    m.v[:] = oracle.init_values(3, n, k, 0.05)
+    m.w0 = 0.05
+    lo, hi = float(y.min()), float(y.max())
+    lr = min(0.01, 0.9 / (chunk * (1.0 if task == 0 else 0.25)))
+    h = capi.Handle(n, k, True, True, task, 0.002, 0.001, 0.003, lr, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, row_ptr, y)
+    for _ in range(2):
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, chunk, 0, lag)
+        oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, lag)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    h.close()
+
+
 def collision_free(n_rows, nnz, seed):
     """every feature occurs at most once in the whole data set."""
     rng = np.random.default_rng(seed)
@@ -202,8 +285,14 @@ def collision_free(n_rows, nnz, seed):
     return n, ent, row_ptr, y
 
 
+# (8,9) (8,17) (16,17) (32,33) (4,20) (2,40) ...: row lengths whose last entries are broadcast from lanes beyond the row
+# (EPI > 1): a cross-lane broadcast inside a lane-masked region reads 0 from masked-off source lanes, which dropped
+# those entries and wrote their rows to feature 0 (round-1 advisor finding); every broadcast now runs with all lanes on
 @pytest.mark.parametrize("k,nnz,apply", [(64, 32, "atomic"), (64, 32, "store"), (32, 16, "store"), (8, 5, "atomic"),
-                                        (128, 7, "store"), (256, 3, "atomic"), (64, 39, "store"), (16, 70, "store")])
+                                        (128, 7, "store"), (256, 3, "atomic"), (64, 39, "store"), (16, 70, "store"),
+                                        (8, 9, "store"), (8, 17, "atomic"), (8, 26, "store"), (8, 35, "store"), (16, 17, "store"),
+                                        (16, 21, "atomic"), (16, 34, "store"), (32, 33, "store"), (32, 35, "atomic"),
+                                        (4, 20, "store"), (2, 40, "store"), (2, 63, "atomic"), (1, 50, "store")])
 def test_hogwild_and_store_are_exact_without_collisions(capi, oracle, k, nnz, apply):
     """With no shared feature and no bias the update of a row is independent of every other row, so the
     asynchronous fused kernel, the minibatch kernels and the online reference loop must all agree."""
@@ -217,11 +306,15 @@ def test_hogwild_and_store_are_exact_without_collisions(capi, oracle, k, nnz, ap
     ap = capi.APPLY_ATOMIC if apply == "atomic" else capi.APPLY_STORE
     ref = m.copy()
     oracle.sgd_epoch_online(ref, d, 1, lr, -1.0, 1.0)
-    for mode, batch in ((capi.SGD_HOGWILD, 0), (capi.SGD_MINIBATCH, 64)):
+    for mode, batch in ((capi.SGD_HOGWILD, 0), (capi.SGD_MINIBATCH, 64), ("fused", 64)):
         h = capi.Handle(n, k, False, True, 1, 0.0, 0.01, 0.02, lr, -1.0, 1.0)
         h.set_params(m.w0, m.w, m.v)
         h.upload_rows(0, ent, row_ptr, y)
-        h.sgd_epoch(0, mode, ap, batch, 8)
+        if mode == "fused":
+            st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, 8, 0, 2)
+            assert st.deferred_features == (0 if nnz <= 64 else n_rows * nnz)    # rows beyond the register path are deferred whole
+        else:
+            h.sgd_epoch(0, mode, ap, batch, 8)
         w0, w, v = h.get_params()
         np.testing.assert_allclose(w, ref.w, rtol=RTOL, atol=1e-6)
         np.testing.assert_allclose(v, ref.v, rtol=RTOL, atol=1e-6)
@@ -281,6 +374,14 @@ def test_odd_k_and_long_rows(capi, oracle, k):
     h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 16, 4)
     oracle.sgd_epoch_minibatch(m, d, 0, 0.002, lo, hi, 16, 4)
     w0, w, v = h.get_params()
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    if k:
+        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+    # the one-pass form: rows of 120..150 entries exceed its register path and are deferred whole
+    h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 16, 4, 0, 2)
+    oracle.sgd_epoch_minibatch(m, d, 0, 0.002, lo, hi, 16, 4, bias_lag=2)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
     if k:
         np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)

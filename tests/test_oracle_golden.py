@@ -81,3 +81,64 @@ def test_synth_generator_definition(oracle):
     d2 = O.synth_rows(123, 50, 50, 8, 800)                        # row0 offset is consistent
     assert np.array_equal(d2.entries, d.entries[50 * 8:])
     assert O.lib().fmo_init_value(7, 3, 2, 0.5) == O.init_values(7, 8, 4, 0.5)[2, 3]
+
+
+def _numpy_minibatch_rule(m, d, task, lr, lo, hi, batch, chunk, lag):
+    """independent numpy restatement of the batch rule with a bias lag of `lag` batches (fm_oracle.h): used only to pin
+    the C oracle's bookkeeping of WHICH bias a batch's multipliers see."""
+    ids, x = d.entries["id"].astype(np.int64), d.entries["value"].astype(np.float64)
+    rp = d.row_ptr.astype(np.int64)
+
+    def mult_of(p, y):
+        if task == 0:
+            return -(y - np.clip(p, lo, hi))
+        return -y * (1.0 - 1.0 / (1.0 + np.exp(-y * p)))
+    w0_start = []
+    for r0 in range(0, d.n_rows, batch):
+        nb = min(batch, d.n_rows - r0)
+        w0_start.append(m.w0)
+        S, rest = np.zeros((nb, m.k)), np.zeros(nb)
+        for e in range(nb):
+            sl = slice(rp[r0 + e], rp[r0 + e + 1])
+            vx = m.v[:, ids[sl]] * x[sl]
+            S[e] = vx.sum(axis=1)
+            rest[e] = (m.w[ids[sl]] * x[sl]).sum() * m.k1 + 0.5 * (S[e] ** 2 - (vx ** 2).sum(axis=1)).sum()
+        y = d.target[r0:r0 + nb].astype(np.float64)
+        b = len(w0_start) - 1
+        w0_used = w0_start[max(b - lag + 1, 0)] if lag else None
+        mult = np.zeros(nb)
+        for c0 in range(0, nb, chunk):
+            sl = slice(c0, min(c0 + chunk, nb))
+            me = mult_of(m.w0 + rest[sl], y[sl])
+            mult[sl] = me if not lag else mult_of(w0_used + rest[sl], y[sl])
+            m.w0 -= lr * (me + m.reg0 * m.w0).sum()
+        dw, dv = np.zeros_like(m.w), np.zeros_like(m.v)
+        for e in range(nb):
+            for i in range(rp[r0 + e], rp[r0 + e + 1]):
+                j, xv = ids[i], x[i]
+                dw[j] += -lr * (mult[e] * xv + m.regw * m.w[j])
+                dv[:, j] += -lr * (mult[e] * (S[e] * xv - m.v[:, j] * xv * xv) + m.regv * m.v[:, j])
+        m.w += dw * m.k1
+        m.v += dv
+
+
+@pytest.mark.parametrize("lag", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", ["sgd_cls_zipf_k32", "sgd_reg_ml"])
+def test_bias_lag_depth_bookkeeping(oracle, name, lag):
+    O = oracle
+    g = Golden(name)
+    tr = g.data(O, "train")
+    rows = min(tr.n_rows, 400)
+    sub = O.Data(tr.entries[: int(tr.row_ptr[rows])], tr.row_ptr[: rows + 1], tr.target[:rows])
+    a, b = g.model(O, "init"), g.model(O, "init")
+    for _ in range(2):
+        O.sgd_epoch_minibatch(a, sub, g.task, g.lr, g.min_target, g.max_target, 50, 10, bias_lag=lag)
+        _numpy_minibatch_rule(b, sub, g.task, g.lr, g.min_target, g.max_target, 50, 10, lag)
+    np.testing.assert_allclose(a.w0, b.w0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a.w, b.w, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a.v, b.v, rtol=1e-9, atol=1e-12)
+    if lag >= 2:                                                  # and the depth does change the result
+        c = g.model(O, "init")
+        for _ in range(2):
+            O.sgd_epoch_minibatch(c, sub, g.task, g.lr, g.min_target, g.max_target, 50, 10, bias_lag=1)
+        assert np.abs(c.v - a.v).max() > 0
