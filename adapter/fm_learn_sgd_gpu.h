@@ -62,7 +62,7 @@ class fmx_sgd_binding : public Base {
     c.num_attribute = fm->num_attribute; c.num_factor = fm->num_factor; c.k0 = fm->k0; c.k1 = fm->k1;
     c.task = this->task; c.reg0 = fm->reg0; c.regw = fm->regw; c.regv = fm->regv; c.learn_rate = this->learn_rate;
     c.min_target = this->min_target; c.max_target = this->max_target; c.device = gpu_device;
-    c.shard_rank = 0; c.shard_world = 1; c.reserved = 0;
+    c.shard_rank = 0; c.shard_world = 1; c.shard_hash = 0;
     if (fmx_create(&c, &h) != FMX_OK) throw std::string(fmx_last_error(NULL));
     check(fmx_set_params(h, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
   }

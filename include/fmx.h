@@ -87,8 +87,12 @@ typedef struct fmx_config {
   double   max_target;
   int32_t  device;          /* HIP device ordinal; -1 = current device */
   int32_t  shard_rank;      /* feature sharding: this handle owns the features j with            */
-  int32_t  shard_world;     /*   j % shard_world == shard_rank  (1 = unsharded)                  */
-  int32_t  reserved;
+  int32_t  shard_world;     /*   owner(j) == shard_rank  (shard_world = 1: unsharded)            */
+  int32_t  shard_hash;      /* 0: owner(j) = j mod shard_world, local row j div shard_world.
+                               1: owner(j) = p(j) mod shard_world, local row p(j) div shard_world with p a fixed pseudo-random
+                                  PERMUTATION of [0, num_attribute) (4-round Feistel network, cycle-walked; north_star:
+                                  "row-sharded by feature-id hash"): balanced whatever the structure of the ids, still a dense
+                                  local table, and invertible, so the shard knows its features' global ids. */
 } fmx_config;
 
 typedef struct fmx_sgd_opts {
@@ -110,6 +114,9 @@ typedef struct fmx_sgd_opts {
 } fmx_sgd_opts;
 
 #define FMX_FLAG_TIME_MAIN_KERNEL 1u  /* bracket every launch of the dominant kernel with HIP events */
+#define FMX_FLAG_PIPELINE 4u          /* fmx_group_sgd_epoch: gather the sums of batch b+1 BEFORE the update of batch b lands, so that
+                                         their exchange runs under that update (one batch stale; oracle
+                                         fmo_sgd_epoch_minibatch_pipelined) */
 #define FMX_FLAG_BIAS_LAG 2u          /* MINIBATCH: the multipliers of a batch use the w0 of the batch START; w0 itself still
                                          advances through the micro-chunk recurrence, which then runs on a side stream
                                          overlapped with the next batch (oracle: fmo_sgd_epoch_minibatch_ex, bias_lag = 1) */
@@ -162,13 +169,14 @@ int fmx_get_params(fmx_handle h, double *w0, double *w, double *v);
 int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t seed);
 /* selected rows of the parameter block (spot checks at sizes where the full fm_model does not fit the host):
  * for i < count: w_out[i] = w[ids[i]], v_out[i*num_factor + f] = v[f][ids[i]].  Sharded handles accept only their
- * own features (id % shard_world == shard_rank). */
+ * own features. */
 int fmx_get_param_rows(fmx_handle h, const uint32_t *ids, uint32_t count, double *w_out, double *v_out);
 /* the scalar bias alone (cheap; used between minibatches by multi-process drivers) */
 int fmx_get_w0(fmx_handle h, double *w0);
 
 /* ---- attribute groups (`-meta`): DataMetaInfo::attr_group, src/libfm/src/Data.h:39-46, loaded by
- * loadGroupsFromFile (:85-97).  group_of_feature[n_local] (host, ids < num_groups) of this handle's features.
+ * loadGroupsFromFile (:85-97).  group_of_feature[num_attribute] (host, ids < num_groups), indexed by GLOBAL feature id
+ * (a feature shard keeps the entries of its own features).
  * Groups select the prior of a coordinate in ALS / MCMC (w_lambda(g), w_mu(g), v_lambda(g,f), v_mu(g,f);
  * fm_learn_mcmc.h:464-466, :583-585) and the learned regularisation in SGDA (reg_w(g), reg_v(g,f);
  * fm_learn_sgd_element_adapt_reg.h:155-166); plain SGD ignores them like the reference does.
@@ -205,7 +213,7 @@ int fmx_upload_block_rows(fmx_handle h, int slot, const void *entries, const uin
 int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz);
 int fmx_free_rows(fmx_handle h, int slot);
 /* copies a slot back to the host (tests / debugging): sizes via fmx_rows_info first.  Sharded handles return
- * their LOCAL rows (kept entries only, ids = global id / shard_world). Any pointer may be NULL. */
+ * their LOCAL rows (kept entries only, ids = local row of the feature on this shard). Any pointer may be NULL. */
 int fmx_rows_info(fmx_handle h, int slot, uint32_t *n_rows, uint64_t *nnz);
 int fmx_download_rows(fmx_handle h, int slot, void *entries, uint64_t *row_ptr, float *target);
 
@@ -248,6 +256,40 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
                    const fmx_sgd_opts *opts, void *stream);
 /* sharded predict: finish a partial buffer into y-hat (device float[n_rows]) */
 int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float *d_partial, float *d_yhat, void *stream);
+
+/* ---- several GPUs --------------------------------------------------------------------------------------------------
+ * libFM is ONE process that constructs the learner and calls learn() (libfm.cpp:271-293, :415).  To use P GPUs from that
+ * process, create P handles -- shard i of P (fmx_config::shard_rank / shard_world, normally shard_hash = 1) on device i --
+ * give every one of them the full parameter block and the full rows (each keeps its own features), and tie them together:
+ *   fmx_group_create     P handles on P DISTINCT devices: one RCCL communicator per handle (ncclCommInitRank inside one
+ *                        ncclGroupStart/End); P handles on ONE device: "loopback" -- the exchange is a local reduction kernel
+ *                        (tests and single-GPU boxes); a single unsharded handle: pass-through.
+ *   fmx_group_sgd_epoch  one epoch of the minibatch rule: per batch the partial sums of every shard (fmx_sgd_partial), ONE
+ *                        all-reduce of [batch][KP + 1] floats over xGMI, then multipliers / bias recurrence (redundantly,
+ *                        identically on every shard) and the update of the shard's own rows (fmx_sgd_finish).  The rule is
+ *                        the one a single handle runs with FMX_APPLY_SEGMENTED / FMX_APPLY_FUSED and the same bias_lag.
+ *   fmx_group_predict / fmx_group_evaluate   fm_learn::predict / evaluate over the shards.
+ * One process PER GPU instead (torchrun-style launchers): rank 0 calls fmx_comm_unique_id and hands the 128 bytes to the
+ * other ranks by whatever means the launcher has; every rank creates its shard handle, calls fmx_comm_init_rank and then
+ * plain fmx_sgd_epoch, which runs the same schedule with its one local shard.
+ * RCCL (librccl.so.1) is loaded on first use; without it only loopback groups and single handles work. */
+/* the ownership rule (fmx_config::shard_hash) as host arithmetic -- no device needed: owner[i] / local_row[i] of feature
+ * ids[i] (either output may be NULL), and the inverse: the global id of a shard's local row. */
+int fmx_shard_place(uint64_t num_attribute, int shard_world, int shard_hash, const uint32_t *ids, uint64_t count,
+                    int32_t *owner, uint32_t *local_row);
+int fmx_shard_global(uint64_t num_attribute, int shard_world, int shard_hash, int shard_rank, const uint32_t *local_rows,
+                     uint64_t count, uint32_t *ids);
+#define FMX_COMM_ID_BYTES 128
+typedef struct fmx_group_s *fmx_group;
+int fmx_comm_unique_id(void *id128);
+int fmx_comm_init_rank(fmx_handle h, const void *id128, int rank, int world);
+int fmx_comm_destroy(fmx_handle h);
+int fmx_group_create(fmx_handle *handles, int n, fmx_group *out);
+int fmx_group_destroy(fmx_group g);
+const char *fmx_group_last_error(fmx_group g);
+int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts *opts, fmx_epoch_stats *stats);
+int fmx_group_predict(fmx_group g, int slot, double *out);
+int fmx_group_evaluate(fmx_group g, int slot, fmx_eval *out);
 
 /* ---- fm_learn_mcmc (ALS = MCMC without sampling, libfm.cpp:135-139) ---------------------------------
  * The learner keeps e(c) = y-hat(c) - target(c) and q_f(c) per training row (e_q_term, fm_learn_mcmc.h:46-49)

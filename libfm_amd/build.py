@@ -2,7 +2,7 @@
 
     python -m libfm_amd.build [--force]
 
-Four translation units (csrc/fmx_core.hip, fmx_sgd.hip, fmx_als.hip, fmx_io.hip) are compiled in parallel and linked.
+Five translation units (csrc/fmx_core.hip, fmx_sgd.hip, fmx_als.hip, fmx_io.hip, fmx_comm.hip) are compiled in parallel and linked.
 """
 import os
 import subprocess
@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SRC = [os.path.join(CSRC, f) for f in ("fmx_core.hip", "fmx_sgd.hip", "fmx_als.hip", "fmx_io.hip")]
+SRC = [os.path.join(CSRC, f) for f in ("fmx_core.hip", "fmx_sgd.hip", "fmx_als.hip", "fmx_io.hip", "fmx_comm.hip")]
 DEPS = SRC + [os.path.join(CSRC, f) for f in ("fmx_internal.h", "fmx_kernels.h", "fmx_als_kernels.h")] + \
     [os.path.join(ROOT, "include", "fmx.h")]
 # experiments: FMX_DEFS="-DFMX_V_NT=1" FMX_OUT=libfmx_nt.so python -m libfm_amd.build --force ; run with FMX_LIB=<that file>
@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
     with ThreadPoolExecutor(len(SRC)) as ex:
         list(ex.map(cc, zip(SRC, objs)))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

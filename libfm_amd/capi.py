@@ -16,6 +16,8 @@ SGD_SEQUENTIAL, SGD_MINIBATCH, SGD_HOGWILD = 0, 1, 2
 APPLY_DEFAULT, APPLY_ATOMIC, APPLY_STORE, APPLY_SEGMENTED, APPLY_FUSED = 0, 1, 2, 3, 4
 FLAG_TIME_MAIN_KERNEL = 1
 FLAG_BIAS_LAG = 2
+FLAG_PIPELINE = 4
+COMM_ID_BYTES = 128
 MAX_SLOTS = 8
 
 ENTRY_DTYPE = np.dtype([("id", np.uint32), ("value", np.float32)])   # sparse_entry<float>, fmatrix.h:34-37
@@ -32,7 +34,7 @@ class Config(C.Structure):
     _fields_ = [("num_attribute", C.c_uint64), ("num_factor", C.c_int32), ("k0", C.c_int32), ("k1", C.c_int32),
                 ("task", C.c_int32), ("reg0", C.c_double), ("regw", C.c_double), ("regv", C.c_double),
                 ("learn_rate", C.c_double), ("min_target", C.c_double), ("max_target", C.c_double),
-                ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_hash", C.c_int32)]
 
 
 class SgdOpts(C.Structure):
@@ -109,6 +111,17 @@ SYMBOLS = [
     ("fmx_sgd_partial", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_sgd_finish", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(SgdOpts), C.c_void_p]),
     ("fmx_predict_finish", C.c_int, [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("fmx_shard_place", C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("fmx_shard_global", C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("fmx_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("fmx_comm_init_rank", C.c_int, [H, C.c_void_p, C.c_int, C.c_int]),
+    ("fmx_comm_destroy", C.c_int, [H]),
+    ("fmx_group_create", C.c_int, [C.POINTER(H), C.c_int, C.POINTER(H)]),
+    ("fmx_group_destroy", C.c_int, [H]),
+    ("fmx_group_last_error", C.c_char_p, [H]),
+    ("fmx_group_sgd_epoch", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(EpochStats)]),
+    ("fmx_group_predict", C.c_int, [H, C.c_int, C.c_void_p]),
+    ("fmx_group_evaluate", C.c_int, [H, C.c_int, C.POINTER(Eval)]),
     ("fmx_sgda_begin", C.c_int, [H]),
     ("fmx_sgda_epoch", C.c_int, [H, C.c_int, C.c_int, C.c_int, C.POINTER(EpochStats)]),
     ("fmx_sgda_get_reg", C.c_int, [H, C.c_void_p]),
@@ -152,11 +165,11 @@ class Handle:
     """Thin OO wrapper over an fmx_handle; every method is one C-ABI call."""
 
     def __init__(self, num_attribute, num_factor, k0=True, k1=True, task=TASK_REGRESSION, reg0=0.0, regw=0.0, regv=0.0,
-                 learn_rate=0.0, min_target=0.0, max_target=0.0, device=-1, shard_rank=0, shard_world=1):
+                 learn_rate=0.0, min_target=0.0, max_target=0.0, device=-1, shard_rank=0, shard_world=1, shard_hash=0):
         self.lib = load()
         self.cfg = Config(int(num_attribute), int(num_factor), int(bool(k0)), int(bool(k1)), int(task),
                           float(reg0), float(regw), float(regv), float(learn_rate), float(min_target),
-                          float(max_target), int(device), int(shard_rank), int(shard_world), 0)
+                          float(max_target), int(device), int(shard_rank), int(shard_world), int(shard_hash))
         self.h = H()
         rc = self.lib.fmx_create(C.byref(self.cfg), C.byref(self.h))
         if rc != FMX_OK:
@@ -222,8 +235,8 @@ class Handle:
             self.G = 1
             return
         group = np.ascontiguousarray(group, dtype=np.uint32)
-        if len(group) != self.n_local:
-            raise ValueError("set_groups: need one group id per local feature (%d), got %d" % (self.n_local, len(group)))
+        if len(group) != self.n:
+            raise ValueError("set_groups: need one group id per feature (%d), got %d" % (self.n, len(group)))
         G = int(group.max()) + 1 if len(group) else 1
         self._chk(self.lib.fmx_set_groups(self.h, _ptr(group), G))
         self.G = max(G, 1)
@@ -343,8 +356,13 @@ class Handle:
 
         def tab_v(x):
             x = np.asarray(x, dtype=np.float64)
-            if x.ndim == 1 and G > 1 and x.shape[0] == G and G != k:
-                x = x[:, None]                       # one value per group
+            if x.ndim == 1 and x.shape[0] != 1:
+                if G > 1 and G == k:                 # a [G] per-group vector and a [k] per-factor vector look the same
+                    raise ValueError("1-D v_lambda / v_mu is ambiguous with num_groups == num_factor: pass a [G][k] table")
+                if x.shape[0] == G and G > 1:
+                    x = x[:, None]                   # one value per group
+                elif x.shape[0] != k:
+                    raise ValueError("1-D v_lambda / v_mu must have num_groups (%d) or num_factor (%d) entries" % (G, k))
             return np.ascontiguousarray(np.broadcast_to(x, (G, k)))
         wl, wm, vl, vm = tab_w(w_lambda), tab_w(w_mu), tab_v(v_lambda), tab_v(v_mu)
         opts = AlsOpts(alpha, float(wm[0]), float(wl[0]), float(vm[0, 0]), float(vl[0, 0]), int(do_sample), 0, seed,
@@ -359,6 +377,12 @@ class Handle:
     def als_end(self):
         self._chk(self.lib.fmx_als_end(self.h))
 
+    # one process per GPU ---------------------------------------------------------------------
+    def comm_init_rank(self, unique_id, rank, world):
+        """unique_id: the COMM_ID_BYTES bytes rank 0 got from comm_unique_id() (handed over by the launcher)"""
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        self._chk(self.lib.fmx_comm_init_rank(self.h, buf, int(rank), int(world)))
+
     def info(self):
         inf = Info()
         self._chk(self.lib.fmx_get_info(self.h, C.byref(inf)))
@@ -366,3 +390,84 @@ class Handle:
 
     def synchronize(self):
         self._chk(self.lib.fmx_synchronize(self.h))
+
+
+def shard_place(n, world, shard_hash, ids):
+    """(owner, local_row) of every feature id under the library's ownership rule (host arithmetic, no device)"""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    owner, local = np.zeros(len(ids), dtype=np.int32), np.zeros(len(ids), dtype=np.uint32)
+    rc = load().fmx_shard_place(int(n), int(world), int(shard_hash), _ptr(ids), len(ids), _ptr(owner), _ptr(local))
+    if rc != FMX_OK:
+        raise FmxError(rc, "fmx_shard_place: bad argument")
+    return owner, local
+
+
+def shard_global(n, world, shard_hash, rank, local_rows):
+    local_rows = np.ascontiguousarray(local_rows, dtype=np.uint32)
+    ids = np.zeros(len(local_rows), dtype=np.uint32)
+    rc = load().fmx_shard_global(int(n), int(world), int(shard_hash), int(rank), _ptr(local_rows), len(local_rows), _ptr(ids))
+    if rc != FMX_OK:
+        raise FmxError(rc, "fmx_shard_global: bad argument")
+    return ids
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().fmx_comm_unique_id(buf)
+    if rc != FMX_OK:
+        raise FmxError(rc, load().fmx_last_error(None).decode())
+    return buf.raw
+
+
+class Group:
+    """fmx_group: the feature shards of one model, driven by this one process (RCCL between devices, a local reduction
+    when all shards share a device)."""
+
+    def __init__(self, handles):
+        self.lib = load()
+        self.handles = list(handles)
+        arr = (H * len(self.handles))(*[h.h for h in self.handles])
+        self.g = H()
+        rc = self.lib.fmx_group_create(arr, len(self.handles), C.byref(self.g))
+        if rc != FMX_OK:
+            raise FmxError(rc, (self.lib.fmx_last_error(self.handles[0].h) or self.lib.fmx_last_error(None)).decode())
+
+    def _chk(self, rc):
+        if rc != FMX_OK:
+            raise FmxError(rc, self.lib.fmx_group_last_error(self.g).decode())
+
+    def sgd_epoch(self, slot, mode=SGD_MINIBATCH, apply=APPLY_DEFAULT, batch=0, w0_chunk=0, flags=0, bias_lag=0):
+        opts = SgdOpts(mode, apply, batch, w0_chunk, flags, bias_lag)
+        st = EpochStats()
+        self._chk(self.lib.fmx_group_sgd_epoch(self.g, slot, C.byref(opts), C.byref(st)))
+        return st
+
+    def predict(self, slot, n_rows):
+        out = np.zeros(n_rows, dtype=np.float64)
+        self._chk(self.lib.fmx_group_predict(self.g, slot, _ptr(out)))
+        return out
+
+    def evaluate(self, slot):
+        ev = Eval()
+        self._chk(self.lib.fmx_group_evaluate(self.g, slot, C.byref(ev)))
+        return ev
+
+    def get_params(self):
+        """the full model: every shard writes its own features into the same host arrays"""
+        h0 = self.handles[0]
+        w, v = np.zeros(h0.n, dtype=np.float64), np.zeros((h0.k, h0.n), dtype=np.float64)
+        w0 = 0.0
+        for h in self.handles:
+            w0, w, v = h.get_params(w, v)
+        return w0, w, v
+
+    def close(self):
+        if self.g:
+            self.lib.fmx_group_destroy(self.g)
+            self.g = H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

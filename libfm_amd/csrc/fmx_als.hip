@@ -131,6 +131,8 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
   if (!h || !opts) return FMX_E_ARG;
   AlsState& a = h->als;
   if (a.slot < 0) return fail(h, FMX_E_STATE, "fmx_als_sweep before fmx_als_begin");
+  if (opts->num_groups != 0 && opts->num_groups != h->num_groups)     // validated BEFORE the first device write of the sweep
+    return fail(h, FMX_E_ARG, "fmx_als_sweep: opts->num_groups = %u but the handle has %u attribute groups", opts->num_groups, h->num_groups);
   HIPCHK(h, hipSetDevice(h->device));
   const Slot& s = h->slots[a.slot];
   const uint32_t N = s.n_rows;
@@ -163,8 +165,6 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
   // ---- priors per coordinate family and attribute group: [1 + k][2][NG] = lambda[NG] then mu[NG]
   const uint32_t NG = h->num_groups;
   const int kf = h->cfg.num_factor;
-  if (opts->num_groups != 0 && opts->num_groups != NG)
-    return fail(h, FMX_E_ARG, "fmx_als_sweep: opts->num_groups = %u but the handle has %u attribute groups", opts->num_groups, NG);
   const bool tabs = opts->num_groups != 0;
   a.prior_host.resize((size_t)(1 + kf) * 2 * NG);
   for (uint32_t g = 0; g < NG; g++) {

@@ -1,0 +1,453 @@
+// fmx_comm.hip -- C-ABI (include/fmx.h): several GPUs.  Feature shards (one handle per shard) trained by ONE host
+// process (the shape libFM has: a single process constructs and calls the learner, libfm.cpp:271-293,415) or by one
+// process per GPU; the per-minibatch exchange of the [B][KP + 1] partial sums is an RCCL all-reduce over xGMI, or -- for
+// shards that share a device (tests, single-GPU boxes) -- a local reduction kernel ("loopback").
+// RCCL is bound at run time (dlopen of librccl.so.1): libfmx.so has no link-time dependency on it, a process that never
+// creates a group with more than one device never loads it.
+#include "fmx_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+
+Rccl g_rccl;
+bool g_rccl_tried = false;
+Rccl* rccl() {                                   // bound once per process; nullptr (text in g_rccl.err) when unavailable
+  Rccl& r = g_rccl;
+  if (g_rccl_tried) return r.lib ? &r : nullptr;
+  g_rccl_tried = true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {                  // an already loaded copy (e.g. the one PyTorch ships) wins
+    r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    if (r.lib) break;
+  }
+  for (size_t i = 0; !r.lib && i < sizeof(names) / sizeof(names[0]); i++) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  if (!r.lib) { const char* e = dlerror(); r.err = std::string("cannot load librccl.so.1: ") + (e ? e : "?"); return nullptr; }
+#define BIND(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym)); \
+  if (!r.field) { r.err = std::string("librccl lacks ") + sym; r.lib = nullptr; return nullptr; }
+  BIND(GetUniqueId, "ncclGetUniqueId") BIND(CommInitRank, "ncclCommInitRank") BIND(CommDestroy, "ncclCommDestroy")
+  BIND(AllReduce, "ncclAllReduce") BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
+  BIND(GetErrorString, "ncclGetErrorString")
+#undef BIND
+  return &r;
+}
+const char* rccl_why() { return g_rccl.err.c_str(); }
+
+#define NCCLCHK(h, expr)                                                                                        \
+  do { ncclResult_t _r = (expr); if (_r != ncclSuccess)                                                         \
+      return fail((h), FMX_E_HIP, "%s failed: %s", #expr, rccl()->GetErrorString(_r)); } while (0)
+
+// loopback exchange: out[i] = sum over the shards' buffers (fixed order -> deterministic); out may alias bufs.p[0]
+struct BufList { const float* p[16]; int n; };
+__global__ void __launch_bounds__(256) k_sum_shards(BufList bufs, float* __restrict__ out, size_t n4, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(bufs.p[0])[i];
+    for (int r = 1; r < bufs.n; r++) {
+      const float4 b = reinterpret_cast<const float4*>(bufs.p[r])[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {               // tail (< 4 floats)
+    const size_t i = (n & ~(size_t)3) + threadIdx.x;
+    float a = bufs.p[0][i];
+    for (int r = 1; r < bufs.n; r++) a += bufs.p[r][i];
+    out[i] = a;
+  }
+}
+
+}  // namespace
+
+enum { GROUP_SINGLE = 0, GROUP_LOOPBACK = 1, GROUP_RCCL = 2 };
+
+struct fmx_group_s {
+  std::vector<fmx_handle> hs;
+  int kind = GROUP_SINGLE;
+  std::vector<ncclComm_t> comms;          // GROUP_RCCL: one per handle
+  bool owns_comms = false;                // created by fmx_group_create (not borrowed from fmx_comm_init_rank)
+  std::vector<hipEvent_t> ev_part;        // loopback: partial sums of shard i are ready
+  hipEvent_t ev_sum = nullptr;            // loopback: the sum is ready
+  std::string err;
+};
+
+static int gfail(fmx_group g, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  if (g) { g->err = buf; if (!g->hs.empty()) g->hs[0]->err = buf; }
+  return code;
+}
+#define GCHK(g, call) do { int _rc = (call); if (_rc != FMX_OK) { (g)->err = fmx_last_error(cur); return _rc; } } while (0)
+
+static int ensure_xbuf(fmx_handle h, size_t floats) {
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->stream_comm) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream_comm, hipStreamNonBlocking));
+    for (auto& e : h->ev_x) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (floats <= h->xcap) return FMX_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream_comm));
+  for (auto& b : h->xbuf) { if (b) hipFree(b); b = nullptr; }
+  h->xcap = 0;
+  for (auto& b : h->xbuf) HIPCHK(h, hipMalloc(&b, floats * sizeof(float)));
+  h->xcap = floats;
+  return FMX_OK;
+}
+
+// the exchange of one partial buffer: sum over the shards.  exchange_begin is called right after the partial sums were
+// enqueued on every shard's stream; exchange_end makes every shard's stream wait for the result (sum_of()).
+//   RCCL: in-place all-reduce on the shard's own COMM stream (ordered behind the gather by an event), so that it can run
+//         under whatever the compute stream does next (FMX_FLAG_PIPELINE: the update of the previous batch);
+//   loopback (all shards on one device): a reduction kernel on shard 0's stream into shard 0's buffer, read by all.
+static int exchange_begin(fmx_group g, int which, size_t count) {
+  const size_t n = g->hs.size();
+  if (g->kind == GROUP_RCCL) {
+    Rccl* R = rccl();
+    for (size_t i = 0; i < n; i++) {
+      fmx_handle h = g->hs[i];
+      HIPCHK(h, hipSetDevice(h->device));
+      HIPCHK(h, hipEventRecord(h->ev_x[which], h->stream));
+      HIPCHK(h, hipStreamWaitEvent(h->stream_comm, h->ev_x[which], 0));
+    }
+    if (n > 1) NCCLCHK(g->hs[0], R->GroupStart());
+    for (size_t i = 0; i < n; i++) {
+      fmx_handle h = g->hs[i];
+      HIPCHK(h, hipSetDevice(h->device));
+      NCCLCHK(h, R->AllReduce(h->xbuf[which], h->xbuf[which], count, ncclFloat32, ncclSum, g->comms[i], h->stream_comm));
+    }
+    if (n > 1) NCCLCHK(g->hs[0], R->GroupEnd());
+    for (size_t i = 0; i < n; i++) {
+      fmx_handle h = g->hs[i];
+      HIPCHK(h, hipSetDevice(h->device));
+      HIPCHK(h, hipEventRecord(h->ev_x[2 + which], h->stream_comm));
+    }
+  } else if (g->kind == GROUP_LOOPBACK) {
+    fmx_handle h0 = g->hs[0];
+    HIPCHK(h0, hipSetDevice(h0->device));
+    BufList bl; bl.n = (int)n;
+    for (size_t i = 0; i < n; i++) {
+      bl.p[i] = g->hs[i]->xbuf[which];
+      if (i) { HIPCHK(h0, hipEventRecord(g->ev_part[i], g->hs[i]->stream)); HIPCHK(h0, hipStreamWaitEvent(h0->stream, g->ev_part[i], 0)); }
+    }
+    hipLaunchKernelGGL(k_sum_shards, dim3((unsigned)std::min<size_t>((count / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, h0->stream,
+                       bl, h0->xbuf[which], count / 4, count);
+    HIPCHK(h0, hipGetLastError());
+    HIPCHK(h0, hipEventRecord(g->ev_sum, h0->stream));
+    for (size_t i = 1; i < n; i++) HIPCHK(h0, hipStreamWaitEvent(g->hs[i]->stream, g->ev_sum, 0));
+  }
+  return FMX_OK;
+}
+static int exchange_end(fmx_group g, int which) {
+  if (g->kind == GROUP_RCCL)
+    for (fmx_handle h : g->hs) { HIPCHK(h, hipSetDevice(h->device)); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_x[2 + which], 0)); }
+  return FMX_OK;
+}
+static const float* sum_of(fmx_group g, size_t i, int which) {
+  return (g->kind == GROUP_LOOPBACK) ? g->hs[0]->xbuf[which] : g->hs[i]->xbuf[which];
+}
+
+// a handle leaves: its group is told (a multi-handle group becomes unusable), its communicator and buffers are released
+void comm_free(fmx_handle h) {
+  hipSetDevice(h->device);
+  if (h->group) {
+    fmx_group g = h->group;
+    if (h->owns_group) { h->group = nullptr; h->owns_group = false; fmx_group_destroy(g); }
+    else { for (auto& x : g->hs) if (x == h) x = nullptr; h->group = nullptr; }
+  }
+  fmx_comm_destroy(h);
+  for (auto& b : h->xbuf) { if (b) hipFree(b); b = nullptr; }
+  h->xcap = 0;
+  if (h->stream_comm) { hipStreamDestroy(h->stream_comm); h->stream_comm = nullptr; }
+  for (auto& e : h->ev_x) { if (e) hipEventDestroy(e); e = nullptr; }
+}
+
+// fmx_sgd_epoch on a feature shard: the shard of a one-process-per-GPU job (fmx_comm_init_rank) runs the group schedule
+// with its one local member; a member of a multi-handle group must be driven through fmx_group_sgd_epoch
+int comm_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats) {
+  if (h->group && !h->owns_group)
+    return fail(h, FMX_E_STATE, "this shard belongs to a group: call fmx_group_sgd_epoch");
+  if (!h->comm)
+    return fail(h, FMX_E_STATE, "fmx_sgd_epoch on a feature shard needs a communicator (fmx_comm_init_rank) or a group (fmx_group_create); "
+                                "or drive fmx_sgd_partial + all-reduce + fmx_sgd_finish yourself");
+  if (!h->group) {
+    fmx_group g = new fmx_group_s();
+    g->hs.push_back(h); g->kind = GROUP_RCCL; g->comms.push_back((ncclComm_t)h->comm);
+    h->group = g; h->owns_group = true;
+  }
+  return fmx_group_sgd_epoch(h->group, slot, opts, stats);
+}
+
+extern "C" {
+
+// the ownership rule as host arithmetic (no device): what sharding.py, the CPU tests and host-side bucketing use
+int fmx_shard_place(uint64_t num_attribute, int shard_world, int shard_hash, const uint32_t* ids, uint64_t count,
+                    int32_t* owner, uint32_t* local_row) {
+  if (!ids && count) return FMX_E_ARG;
+  if (num_attribute == 0 || num_attribute > 0xFFFFFFFFull || shard_world < 1) return FMX_E_ARG;
+  fmx_config c; memset(&c, 0, sizeof(c));
+  c.num_attribute = num_attribute; c.shard_world = shard_world; c.shard_hash = shard_hash; c.shard_rank = 0;
+  const Shard sh = make_shard(c);
+  for (uint64_t i = 0; i < count; i++) {
+    if ((uint64_t)ids[i] >= num_attribute) return FMX_E_ARG;
+    const uint32_t p = sh.placed(ids[i]);
+    if (owner) owner[i] = (int32_t)(p % (uint32_t)shard_world);
+    if (local_row) local_row[i] = p / (uint32_t)shard_world;
+  }
+  return FMX_OK;
+}
+int fmx_shard_global(uint64_t num_attribute, int shard_world, int shard_hash, int shard_rank, const uint32_t* local_rows,
+                     uint64_t count, uint32_t* ids) {
+  if ((!local_rows || !ids) && count) return FMX_E_ARG;
+  if (num_attribute == 0 || num_attribute > 0xFFFFFFFFull || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return FMX_E_ARG;
+  fmx_config c; memset(&c, 0, sizeof(c));
+  c.num_attribute = num_attribute; c.shard_world = shard_world; c.shard_hash = shard_hash; c.shard_rank = shard_rank;
+  const Shard sh = make_shard(c);
+  for (uint64_t i = 0; i < count; i++) {
+    if ((uint64_t)local_rows[i] * (uint64_t)shard_world + (uint64_t)shard_rank >= num_attribute) return FMX_E_ARG;
+    ids[i] = sh.global(local_rows[i]);
+  }
+  return FMX_OK;
+}
+
+int fmx_comm_unique_id(void* id128) {
+  if (!id128) return FMX_E_ARG;
+  Rccl* R = rccl();
+  if (!R) return fail(nullptr, FMX_E_UNSUPPORTED, "fmx_comm_unique_id: %s", rccl_why());
+  static_assert(sizeof(ncclUniqueId) == FMX_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  if (R->GetUniqueId(&id) != ncclSuccess) return fail(nullptr, FMX_E_HIP, "ncclGetUniqueId failed");
+  memcpy(id128, &id, sizeof(id));
+  return FMX_OK;
+}
+
+int fmx_comm_init_rank(fmx_handle h, const void* id128, int rank, int world) {
+  if (!h || !id128) return FMX_E_ARG;
+  if (h->cfg.shard_rank != rank || h->cfg.shard_world != world)
+    return fail(h, FMX_E_ARG, "fmx_comm_init_rank: rank %d of %d but the handle is shard %d of %d", rank, world, h->cfg.shard_rank, h->cfg.shard_world);
+  if (h->comm) return fail(h, FMX_E_STATE, "fmx_comm_init_rank: the handle already has a communicator");
+  Rccl* R = rccl();
+  if (!R) return fail(h, FMX_E_UNSUPPORTED, "fmx_comm_init_rank: %s", rccl_why());
+  HIPCHK(h, hipSetDevice(h->device));
+  ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+  ncclComm_t c = nullptr;
+  NCCLCHK(h, R->CommInitRank(&c, world, id, rank));
+  h->comm = c;
+  return FMX_OK;
+}
+
+int fmx_comm_destroy(fmx_handle h) {
+  if (!h) return FMX_E_ARG;
+  if (h->comm) {
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (Rccl* R = rccl()) R->CommDestroy((ncclComm_t)h->comm);
+    h->comm = nullptr;
+  }
+  return FMX_OK;
+}
+
+int fmx_group_create(fmx_handle* handles, int n, fmx_group* out) {
+  if (!handles || !out || n < 1 || n > 16) return fail(nullptr, FMX_E_ARG, "fmx_group_create: 1..16 handles");
+  *out = nullptr;
+  for (int i = 0; i < n; i++) {
+    fmx_handle h = handles[i];
+    if (!h) return fail(nullptr, FMX_E_ARG, "fmx_group_create: handle %d is NULL", i);
+    if (h->cfg.shard_world != n || h->cfg.shard_rank != i)
+      return fail(h, FMX_E_ARG, "fmx_group_create: handle %d must be shard %d of %d (is %d of %d)", i, i, n, h->cfg.shard_rank, h->cfg.shard_world);
+    if (h->KP != handles[0]->KP || h->cfg.num_attribute != handles[0]->cfg.num_attribute || h->cfg.shard_hash != handles[0]->cfg.shard_hash)
+      return fail(h, FMX_E_ARG, "fmx_group_create: the shards describe different models");
+    if (h->group) return fail(h, FMX_E_STATE, "fmx_group_create: handle %d already belongs to a group", i);
+  }
+  fmx_group g = new fmx_group_s();
+  g->hs.assign(handles, handles + n);
+  bool same_dev = true, distinct = true;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) { if (handles[i]->device != handles[j]->device) same_dev = false; else distinct = false; }
+  if (n == 1) {
+    g->kind = handles[0]->comm ? GROUP_RCCL : GROUP_SINGLE;           // one local shard of a multi-process job, or no sharding at all
+    if (handles[0]->comm) g->comms.push_back((ncclComm_t)handles[0]->comm);
+  } else if (same_dev) {
+    g->kind = GROUP_LOOPBACK;
+    fmx_handle h0 = handles[0];
+    hipSetDevice(h0->device);
+    g->ev_part.resize(n, nullptr);
+    bool ok = hipEventCreateWithFlags(&g->ev_sum, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < n; i++) ok = hipEventCreateWithFlags(&g->ev_part[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { fmx_group_destroy(g); return fail(h0, FMX_E_HIP, "fmx_group_create: event creation failed"); }
+  } else if (distinct) {
+    Rccl* R = rccl();
+    if (!R) { delete g; return fail(handles[0], FMX_E_UNSUPPORTED, "fmx_group_create: %s", rccl_why()); }
+    g->kind = GROUP_RCCL;
+    g->comms.assign(n, nullptr);
+    g->owns_comms = true;
+    ncclUniqueId id;
+    ncclResult_t r = R->GetUniqueId(&id);
+    if (r == ncclSuccess) r = R->GroupStart();                         // one thread, several devices: ranks initialised as a group
+    for (int i = 0; r == ncclSuccess && i < n; i++) {
+      hipSetDevice(handles[i]->device);
+      r = R->CommInitRank(&g->comms[i], n, id, i);
+    }
+    if (r == ncclSuccess) r = R->GroupEnd();
+    if (r != ncclSuccess) { int rc = fail(handles[0], FMX_E_HIP, "fmx_group_create: RCCL initialisation failed: %s", R->GetErrorString(r)); fmx_group_destroy(g); return rc; }
+  } else {
+    delete g;
+    return fail(handles[0], FMX_E_UNSUPPORTED, "fmx_group_create: the shards must sit on pairwise distinct devices (RCCL) or all on one (loopback)");
+  }
+  for (int i = 0; i < n; i++) handles[i]->group = g;
+  *out = g;
+  return FMX_OK;
+}
+
+int fmx_group_destroy(fmx_group g) {
+  if (!g) return FMX_OK;
+  for (auto h : g->hs) if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (h->group == g) { h->group = nullptr; h->owns_group = false; } }
+  if (g->owns_comms) if (Rccl* R = rccl()) for (auto c : g->comms) if (c) R->CommDestroy(c);
+  for (auto e : g->ev_part) if (e) hipEventDestroy(e);
+  if (g->ev_sum) hipEventDestroy(g->ev_sum);
+  delete g;
+  return FMX_OK;
+}
+
+const char* fmx_group_last_error(fmx_group g) { return g ? g->err.c_str() : fmx_last_error(nullptr); }
+
+// one epoch of the minibatch rule over feature shards:  per batch  partial sums on every shard -> ONE exchange ->
+// multipliers / bias recurrence (redundantly on every shard) + update of the local rows.
+//   exact (default): the batch rule of oracle fmo_sgd_epoch_minibatch_ex -- identical, shard count aside, to what a single
+//                    unsharded handle computes with FMX_APPLY_SEGMENTED / FMX_APPLY_FUSED and the same bias_lag;
+//   FMX_FLAG_PIPELINE: the sums of batch b+1 are gathered BEFORE the update of batch b lands, so that their exchange runs
+//                    under that update ("one batch stale", oracle fmo_sgd_epoch_minibatch_pipelined).
+int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_epoch_stats* stats) {
+  if (!g || !opts_in) return FMX_E_ARG;
+  for (auto h : g->hs) if (!h) return gfail(g, FMX_E_STATE, "a member of the group was destroyed");
+  const size_t n = g->hs.size();
+  fmx_handle cur = g->hs[0];
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (g->kind == GROUP_SINGLE) { GCHK(g, fmx_sgd_epoch(cur, slot, opts_in, stats)); return FMX_OK; }
+  if (opts_in->mode != FMX_SGD_MINIBATCH) return gfail(g, FMX_E_UNSUPPORTED, "feature shards train with FMX_SGD_MINIBATCH (the split step)");
+  for (size_t i = 0; i < n; i++) {
+    cur = g->hs[i];
+    GCHK(g, check_slot(cur, slot, true));
+    if (cur->slots[slot].n_rows != g->hs[0]->slots[slot].n_rows) return gfail(g, FMX_E_STATE, "the shards hold different numbers of rows in slot %d", slot);
+  }
+  fmx_sgd_opts opts = *opts_in;
+  if (opts.apply == FMX_APPLY_FUSED || opts.apply == FMX_APPLY_DEFAULT) { opts.apply = FMX_APPLY_SEGMENTED; }
+  if (opts_in->apply == FMX_APPLY_FUSED) opts.flags |= FMX_FLAG_BIAS_LAG;       // FUSED implies the lag on one device: same rule here
+  const bool pipeline = (opts.flags & FMX_FLAG_PIPELINE) != 0;
+  const uint32_t n_rows = g->hs[0]->slots[slot].n_rows;
+  const uint32_t B = opts.batch ? opts.batch : 262144u;
+  opts.batch = B;
+  const size_t kp1 = (size_t)g->hs[0]->KP + 1;
+  const size_t cap = (size_t)std::min<uint32_t>(B, std::max<uint32_t>(n_rows, 1)) * kp1;
+  for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, ensure_xbuf(cur, cap)); GCHK(g, ensure_segments(cur, cur->slots[slot], B)); }
+  fmx_handle h0 = g->hs[0];
+  HIPCHK(h0, hipSetDevice(h0->device));
+  HIPCHK(h0, hipEventRecord(h0->ev0, h0->stream));
+  const uint64_t n_batch = ((uint64_t)n_rows + B - 1) / B;
+  auto rows_of = [&](uint64_t b) { return (uint32_t)std::min<uint64_t>(B, n_rows - b * B); };
+  auto gather = [&](uint64_t b) -> int {
+    for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_partial(cur, slot, b * B, rows_of(b), cur->xbuf[b & 1], cur->stream)); }
+    return exchange_begin(g, (int)(b & 1), (size_t)rows_of(b) * kp1);
+  };
+  auto update = [&](uint64_t b) -> int {
+    int erc = exchange_end(g, (int)(b & 1));
+    if (erc) return erc;
+    for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_finish(cur, slot, b * B, rows_of(b), sum_of(g, i, (int)(b & 1)), &opts, cur->stream)); }
+    return FMX_OK;
+  };
+  int rc = FMX_OK;
+  if (n_batch && pipeline) rc = gather(0);
+  for (uint64_t b = 0; b < n_batch && rc == FMX_OK; b++) {
+    if (pipeline) { if (b + 1 < n_batch) rc = gather(b + 1); }      // reads the parameters before update(b): one batch stale
+    else rc = gather(b);
+    if (rc == FMX_OK) rc = update(b);
+  }
+  if (rc) { g->err = g->hs[0]->err; return rc; }
+  for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_synchronize(cur)); }       // drains the side streams, bias back in h->w0
+  HIPCHK(h0, hipSetDevice(h0->device));
+  HIPCHK(h0, hipEventRecord(h0->ev1, h0->stream));
+  HIPCHK(h0, hipEventSynchronize(h0->ev1));
+  if (stats) {
+    float ms = 0;
+    HIPCHK(h0, hipEventElapsedTime(&ms, h0->ev0, h0->ev1));
+    stats->rows = n_rows; stats->batches = n_batch; stats->device_seconds = ms * 1e-3;
+    stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = n_batch;
+    stats->max_feature_count = h0->slots[slot].max_seg_count;
+  }
+  return FMX_OK;
+}
+
+// y-hat of every row of a slot over the shards (raw, like fmx_predict): partial sums -> exchange -> finish on shard 0
+int fmx_group_predict(fmx_group g, int slot, double* out) {
+  if (!g || !out) return FMX_E_ARG;
+  fmx_handle cur = g->hs[0];
+  if (g->kind == GROUP_SINGLE) { GCHK(g, fmx_predict(cur, slot, out)); return FMX_OK; }
+  const size_t n = g->hs.size();
+  for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, check_slot(cur, slot, false)); GCHK(g, lag_flush(cur)); }
+  fmx_handle h0 = g->hs[0];
+  const uint32_t n_rows = h0->slots[slot].n_rows;
+  const size_t kp1 = (size_t)h0->KP + 1;
+  const uint32_t chunk = 1u << 18;
+  std::vector<float> tmp(std::min<uint32_t>(chunk, std::max<uint32_t>(n_rows, 1)));
+  for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, ensure_xbuf(cur, (size_t)tmp.size() * kp1)); }
+  float* d_y = nullptr;
+  HIPCHK(h0, hipSetDevice(h0->device));
+  HIPCHK(h0, hipMalloc(&d_y, tmp.size() * sizeof(float)));
+  int rc = FMX_OK;
+  for (uint64_t r0 = 0; r0 < n_rows && rc == FMX_OK; r0 += chunk) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(chunk, n_rows - r0);
+    for (size_t i = 0; i < n && rc == FMX_OK; i++) { cur = g->hs[i]; rc = fmx_sgd_partial(cur, slot, r0, nb, cur->xbuf[0], cur->stream); }
+    if (rc == FMX_OK) rc = exchange_begin(g, 0, (size_t)nb * kp1);
+    if (rc == FMX_OK) rc = exchange_end(g, 0);
+    if (rc == FMX_OK) rc = fmx_predict_finish(h0, nb, sum_of(g, 0, 0), d_y, h0->stream);
+    if (rc == FMX_OK && hipMemcpyAsync(tmp.data(), d_y, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, h0->stream) != hipSuccess) rc = FMX_E_HIP;
+    for (size_t i = 0; i < n && rc == FMX_OK; i++) { hipSetDevice(g->hs[i]->device); if (hipStreamSynchronize(g->hs[i]->stream) != hipSuccess) rc = FMX_E_HIP; }
+    if (rc == FMX_OK) for (uint32_t r = 0; r < nb; r++) out[r0 + r] = (double)tmp[r];
+  }
+  hipSetDevice(h0->device);
+  hipFree(d_y);
+  if (rc) { g->err = fmx_last_error(cur); return rc; }
+  return FMX_OK;
+}
+
+// fm_learn::evaluate (fm_learn.h:93-153) over the shards: predictions as above, metric on the host like the reference
+int fmx_group_evaluate(fmx_group g, int slot, fmx_eval* out) {
+  if (!g || !out) return FMX_E_ARG;
+  fmx_handle h0 = g->hs[0];
+  if (g->kind == GROUP_SINGLE) { fmx_handle cur = h0; GCHK(g, fmx_evaluate(cur, slot, out)); return FMX_OK; }
+  { fmx_handle cur = h0; GCHK(g, check_slot(cur, slot, true)); }
+  const Slot& s = h0->slots[slot];
+  memset(out, 0, sizeof(*out));
+  out->rows = s.n_rows;
+  if (s.n_rows == 0) return FMX_OK;
+  std::vector<double> p(s.n_rows);
+  std::vector<float> y(s.n_rows);
+  int rc = fmx_group_predict(g, slot, p.data());
+  if (rc) return rc;
+  HIPCHK(h0, hipSetDevice(h0->device));
+  HIPCHK(h0, hipMemcpy(y.data(), s.target, (size_t)s.n_rows * sizeof(float), hipMemcpyDeviceToHost));
+  double se = 0, ae = 0, nc = 0;
+  for (uint32_t r = 0; r < s.n_rows; r++) {
+    if (h0->cfg.task == FMX_TASK_REGRESSION) {
+      const double pc = std::max(h0->cfg.min_target, std::min(h0->cfg.max_target, p[r]));       // fm_learn.h:138-139
+      const double e = pc - (double)y[r];
+      se += e * e; ae += std::fabs(e);
+    } else if ((p[r] >= 0 && y[r] >= 0) || (p[r] < 0 && y[r] < 0)) nc += 1;                   // fm_learn.h:118
+  }
+  out->rmse = std::sqrt(se / s.n_rows); out->mae = ae / s.n_rows; out->accuracy = nc / s.n_rows;
+  return FMX_OK;
+}
+
+}  // extern "C"

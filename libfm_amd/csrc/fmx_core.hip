@@ -29,10 +29,19 @@ Hyper make_hyper(const fmx_config& c) {
   return h;
 }
 
+Shard make_shard(const fmx_config& c) {
+  Shard sh;
+  sh.n = c.num_attribute; sh.rank = (uint32_t)c.shard_rank; sh.world = (uint32_t)c.shard_world;
+  sh.hashed = (c.shard_hash != 0 && c.shard_world > 1) ? 1u : 0u;
+  uint32_t bits = 1; while (bits < 32 && (1ull << bits) < c.num_attribute) bits++;
+  sh.half_bits = std::max<uint32_t>(1u, (bits + 1) / 2);         // 2 * half_bits >= bits: the Feistel domain covers [0, n)
+  return sh;
+}
+
 // persistent sizing: never launch more workgroups than can be resident (a second, partially filled round of
 // equally long grid-stride workgroups is pure tail), never more than the work needs.
 uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted) {
-  static std::unordered_map<const void*, int> cache;
+  auto& cache = h->occ_cache;                 // per handle (= per device, one calling thread): no process-wide state
   auto it = cache.find(kernel);
   int occ;
   if (it == cache.end()) {
@@ -76,6 +85,14 @@ int check_slot(fmx_handle h, int slot, bool need_target) {
   if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
   if (!h->slots[slot].used) return fail(h, FMX_E_STATE, "slot %d holds no rows (call fmx_upload_rows first)", slot);
   if (need_target && !h->slots[slot].target) return fail(h, FMX_E_STATE, "slot %d was uploaded without targets", slot);
+  return FMX_OK;
+}
+
+// an open ALS / MCMC session keeps device structures derived from its train slot (X^T segments, level lists, e/q of
+// that size): the slot must not be replaced, freed or re-bucketed until fmx_als_end
+int slot_in_session(fmx_handle h, int slot, const char* what) {
+  if (h->als.slot >= 0 && h->als.slot == slot)
+    return fail(h, FMX_E_STATE, "%s: slot %d is the train slot of an open ALS / MCMC session (call fmx_als_end first)", what, slot);
   return FMX_OK;
 }
 
@@ -129,6 +146,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     return fail(nullptr, FMX_E_ARG, "unknown task");                       // fm_learn.h:81 "unknown task"
   if (cfg->shard_world < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_world)
     return fail(nullptr, FMX_E_ARG, "bad shard_rank/shard_world");
+  if (cfg->shard_hash != 0 && cfg->shard_hash != 1) return fail(nullptr, FMX_E_ARG, "shard_hash must be 0 or 1");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
@@ -184,7 +202,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     }
   }
   CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
-  CREATE_CHK(hipMalloc(&h->w0_pp, 4 * sizeof(double)));
+  CREATE_CHK(hipMalloc(&h->w0_pp, 8 * sizeof(double)));
   {  // the side stream runs the one-workgroup bias recurrence next to chip-filling gathers: give it priority so
      // that its workgroup is placed as soon as any CU has room
     int lo = 0, hi = 0;
@@ -207,6 +225,7 @@ int fmx_destroy(fmx_handle h) {
   if (!h) return FMX_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  comm_free(h);
   als_free(h);
   sgda_free(h);
   for (auto& s : h->slots) free_slot(s);
@@ -224,8 +243,7 @@ int fmx_destroy(fmx_handle h) {
   for (auto ev : h->ev_pool) hipEventDestroy(ev);
   for (auto ev : h->ev_sync) hipEventDestroy(ev);
   if (h->lag.ev_rest) hipEventDestroy(h->lag.ev_rest);
-  if (h->lag.ev_scan[0]) hipEventDestroy(h->lag.ev_scan[0]);
-  if (h->lag.ev_scan[1]) hipEventDestroy(h->lag.ev_scan[1]);
+  for (auto e : h->lag.ev_scan) if (e) hipEventDestroy(e);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -260,7 +278,8 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
   HIPCHK(h, hipSetDevice(h->device));
   const uint64_t n = h->cfg.num_attribute;
   const int k = h->cfg.num_factor, KP = h->KP;
-  const int R = h->cfg.shard_rank, W = h->cfg.shard_world;
+  const int W = h->cfg.shard_world;
+  const Shard sh = make_shard(h->cfg);
   if (to_device) {
     HIPCHK(h, hipMemcpyAsync(h->w0, w0, sizeof(double), hipMemcpyHostToDevice, h->stream));
   } else {
@@ -277,10 +296,10 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
     if (w) {
       if (to_device) {
         STAGE_CHK(hipMemcpyAsync(stage, w + j0, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_w_in, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->tb);
+        hipLaunchKernelGGL(k_w_in, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, sh, h->tb);
       } else {
         if (W > 1) STAGE_CHK(hipMemcpyAsync(stage, w + j0, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_w_out, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, R, W, h->tb);
+        hipLaunchKernelGGL(k_w_out, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, stage, j0, cnt, sh, h->tb);
         STAGE_CHK(hipMemcpyAsync(w + j0, stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       }
       STAGE_CHK(hipStreamSynchronize(h->stream));
@@ -292,7 +311,7 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
                                    hipMemcpyHostToDevice, h->stream));
         const uint64_t total = (uint64_t)cnt * KP;
         hipLaunchKernelGGL(k_stage_in, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream,
-                           stage, j0, cnt, k, KP, R, W, h->tb);
+                           stage, j0, cnt, k, KP, sh, h->tb);
       } else {
         if (W > 1)
           for (int f = 0; f < k; f++)
@@ -300,7 +319,7 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
                                      hipMemcpyHostToDevice, h->stream));
         const uint64_t total = (uint64_t)cnt * k;
         hipLaunchKernelGGL(k_stage_out, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream,
-                           stage, j0, cnt, k, KP, R, W, h->tb);
+                           stage, j0, cnt, k, KP, sh, h->tb);
         for (int f = 0; f < k; f++)
           STAGE_CHK(hipMemcpyAsync(v + (size_t)f * n + j0, stage + (size_t)f * cnt, cnt * sizeof(double),
                                    hipMemcpyDeviceToHost, h->stream));
@@ -334,11 +353,12 @@ int fmx_get_param_rows(fmx_handle h, const uint32_t* ids, uint32_t count, double
   if (!h || !ids || !w_out) return FMX_E_ARG;
   { int _rc = lag_flush(h); if (_rc) return _rc; }
   const int k = h->cfg.num_factor;
+  const Shard sh = make_shard(h->cfg);
   if (k > 0 && !v_out) return fail(h, FMX_E_ARG, "fmx_get_param_rows: v_out is NULL");
   if (count == 0) return FMX_OK;
   for (uint32_t i = 0; i < count; i++) {
     if (ids[i] >= h->cfg.num_attribute) return fail(h, FMX_E_ARG, "feature id %u >= num_attribute", ids[i]);
-    if ((int)(ids[i] % (uint32_t)h->cfg.shard_world) != h->cfg.shard_rank) return fail(h, FMX_E_ARG, "feature id %u is not on this shard", ids[i]);
+    if (!sh.owns(ids[i])) return fail(h, FMX_E_ARG, "feature id %u is not on this shard", ids[i]);
   }
   HIPCHK(h, hipSetDevice(h->device));
   uint32_t* d_ids = nullptr; double* d_out = nullptr;
@@ -348,7 +368,7 @@ int fmx_get_param_rows(fmx_handle h, const uint32_t* ids, uint32_t count, double
   hipError_t er = hipMemcpyAsync(d_ids, ids, (size_t)count * 4, hipMemcpyHostToDevice, h->stream);
   if (er == hipSuccess) {
     hipLaunchKernelGGL(k_fetch_rows, dim3((uint32_t)((nout + 255) / 256)), dim3(256), 0, h->stream, d_ids, count, k,
-                       h->cfg.shard_world, h->tb, d_out, d_out + count);
+                       sh, h->tb, d_out, d_out + count);
     er = hipGetLastError();
   }
   if (er == hipSuccess) er = hipMemcpyAsync(w_out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -376,12 +396,17 @@ int fmx_set_groups(fmx_handle h, const uint32_t* group_of_feature, uint32_t num_
   if (h->grp) { hipFree(h->grp); h->grp = nullptr; }
   h->num_groups = 1;
   if (!group_of_feature || num_groups <= 1) return FMX_OK;
-  for (uint64_t j = 0; j < h->n_local; j++)
-    if (group_of_feature[j] >= num_groups)
-      return fail(h, FMX_E_ARG, "fmx_set_groups: feature %llu has group %u >= num_groups %u", (unsigned long long)j,
-                  group_of_feature[j], num_groups);
+  // the array is indexed by GLOBAL feature id ([num_attribute]); a shard keeps the entries of its own features
+  const Shard sh = make_shard(h->cfg);
+  std::vector<uint32_t> local(h->n_local);
+  for (uint64_t jl = 0; jl < h->n_local; jl++) {
+    const uint32_t j = sh.global(jl);
+    local[jl] = ((uint64_t)j < h->cfg.num_attribute) ? group_of_feature[j] : 0u;
+    if (local[jl] >= num_groups)
+      return fail(h, FMX_E_ARG, "fmx_set_groups: feature %u has group %u >= num_groups %u", j, local[jl], num_groups);
+  }
   HIPCHK(h, hipMalloc(&h->grp, h->n_local * sizeof(uint32_t)));
-  HIPCHK(h, hipMemcpy(h->grp, group_of_feature, h->n_local * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->grp, local.data(), h->n_local * sizeof(uint32_t), hipMemcpyHostToDevice));
   h->num_groups = num_groups;
   return FMX_OK;
 }
@@ -391,7 +416,7 @@ int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t 
   { int _rc = lag_flush(h); if (_rc) return _rc; }
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(k_init_params, dim3(256 * 8), dim3(256), 0, h->stream, h->tb, h->n_local,
-                     h->cfg.num_factor, h->KP, h->cfg.shard_rank, h->cfg.shard_world, (float)init_mean, init_stdev, seed);
+                     h->cfg.num_factor, h->KP, make_shard(h->cfg), (float)init_mean, init_stdev, seed);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -403,6 +428,7 @@ int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t 
 // ---------------------------------------------------------------------------------------------
 int fmx_free_rows(fmx_handle h, int slot) {
   if (!h || slot < 0 || slot >= FMX_MAX_SLOTS) return FMX_E_ARG;
+  { int _rc = slot_in_session(h, slot, "fmx_free_rows"); if (_rc) return _rc; }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_slot(h->slots[slot]);
@@ -413,6 +439,7 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
                     uint32_t n_rows, uint64_t nnz) {
   if (!h) return FMX_E_ARG;
   if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  { int _rc = slot_in_session(h, slot, "fmx_upload_rows"); if (_rc) return _rc; }
   if (!row_ptr || (nnz > 0 && !entries)) return fail(h, FMX_E_ARG, "fmx_upload_rows: null entries/row_ptr");
   if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return fail(h, FMX_E_ARG, "row_ptr[0] must be 0 and row_ptr[n_rows] == nnz");
   HIPCHK(h, hipSetDevice(h->device));
@@ -420,7 +447,8 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
   free_slot(h->slots[slot]);
   const Entry* src = static_cast<const Entry*>(entries);
   const uint64_t n = h->cfg.num_attribute;
-  const uint32_t W = (uint32_t)h->cfg.shard_world, R = (uint32_t)h->cfg.shard_rank;
+  const uint32_t W = (uint32_t)h->cfg.shard_world;
+  const Shard sh = make_shard(h->cfg);
   std::vector<Entry> local_ent;
   std::vector<uint64_t> local_ptr;
   const Entry* up_ent = src;
@@ -431,13 +459,13 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
   for (uint64_t i = 0; i < nnz; i++)
     if (src[i].id >= n) return fail(h, FMX_E_ARG, "feature id %u >= num_attribute %llu (row entry %llu)", src[i].id,
                                     (unsigned long long)n, (unsigned long long)i);
-  if (W > 1) {   // keep this shard's features, ids become local rows (j / world)
+  if (W > 1) {   // keep this shard's features, ids become local rows (Shard::place)
     local_ptr.resize((size_t)n_rows + 1);
     local_ent.reserve((size_t)(nnz / W + n_rows));
     for (uint32_t r = 0; r < n_rows; r++) {
       local_ptr[r] = local_ent.size();
       for (uint64_t i = row_ptr[r]; i < row_ptr[r + 1]; i++)
-        if (src[i].id % W == R) { Entry e; e.id = src[i].id / W; e.value = src[i].value; local_ent.push_back(e); }
+        { Entry e; if (sh.place(src[i].id, &e.id)) { e.value = src[i].value; local_ent.push_back(e); } }
     }
     local_ptr[n_rows] = local_ent.size();
     up_ent = local_ent.data(); up_ptr = local_ptr.data(); up_nnz = local_ent.size();
@@ -462,6 +490,7 @@ int fmx_upload_block_rows(fmx_handle h, int slot, const void* entries, const uin
   if (!h) return FMX_E_ARG;
   if (n_relations == 0) return fmx_upload_rows(h, slot, entries, row_ptr, target, n_rows, nnz);
   if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  { int _rc = slot_in_session(h, slot, "fmx_upload_block_rows"); if (_rc) return _rc; }
   if (!relations || n_relations > FMX_MAX_RELATIONS) return fail(h, FMX_E_ARG, "fmx_upload_block_rows: 1..%d relations", FMX_MAX_RELATIONS);
   if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "block-structured rows on a feature shard are not implemented");
   if (!row_ptr || (nnz > 0 && !entries)) return fail(h, FMX_E_ARG, "fmx_upload_block_rows: null entries/row_ptr");
@@ -571,6 +600,7 @@ int fmx_download_rows(fmx_handle h, int slot, void* entries, uint64_t* row_ptr, 
 int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz) {
   if (!h) return FMX_E_ARG;
   if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
+  { int _rc = slot_in_session(h, slot, "fmx_synth_rows"); if (_rc) return _rc; }
   if (nnz == 0 || n_rows == 0) return fail(h, FMX_E_ARG, "fmx_synth_rows: empty workload");
   const uint64_t n = h->cfg.num_attribute;
   const uint32_t fs = (uint32_t)(n / nnz);
@@ -578,7 +608,7 @@ int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_slot(h->slots[slot]);
-  const int R = h->cfg.shard_rank, W = h->cfg.shard_world;
+  const Shard sh = make_shard(h->cfg);
   Slot s;
   uint32_t* cnt = nullptr;
   HIPCHK(h, hipMalloc(&cnt, ((size_t)n_rows + 1) * sizeof(uint32_t)));
@@ -586,7 +616,7 @@ int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_
   HIPCHK(h, hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
   HIPCHK(h, hipMalloc(&s.target, (size_t)n_rows * sizeof(float)));
   const dim3 grid((n_rows + 255) / 256), block(256);
-  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, R, W, cnt,
+  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, sh, cnt,
                      (const uint64_t*)nullptr, (Entry*)nullptr, s.target);
   HIPCHK(h, hipGetLastError());
   {  // exclusive prefix sum u32 -> u64 over n_rows+1 items (last = total)
@@ -601,7 +631,7 @@ int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_
   uint64_t total = 0;
   HIPCHK(h, hipMemcpy(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost));
   HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
-  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, R, W, (uint32_t*)nullptr,
+  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, sh, (uint32_t*)nullptr,
                      (const uint64_t*)s.row_ptr, s.ent, (float*)nullptr);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));

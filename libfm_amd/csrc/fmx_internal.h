@@ -17,6 +17,7 @@
 #include <random>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 using namespace fmx;
@@ -59,9 +60,11 @@ struct AlsState {
 };
 
 struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping (split step): w0 lives in w0_pp[step & 1] while active
+  static constexpr uint32_t RING = 8;                 // >= depth + 2
   bool       active = false;
   uint64_t   step = 0;
-  hipEvent_t ev_rest = nullptr, ev_scan[2] = {nullptr, nullptr};
+  uint32_t   depth = 1;           // batches the multipliers' bias lags behind (fmx_sgd_opts::bias_lag)
+  hipEvent_t ev_rest = nullptr, ev_scan[RING] = {};
 };
 
 struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; };
@@ -80,7 +83,7 @@ struct fmx_context_s {
   Tab        tb = {nullptr, nullptr, 0, 0};   // V rows (+ co-located w), see fmx_kernels.h
   float*     w_sep = nullptr;    // separate w[] array (only when FMX_WPAD=0)
   double*    w0 = nullptr;       // device scalar
-  double*    w0_pp = nullptr;    // 2 doubles: ping-pong copies of w0 for the overlapped hogwild bias scan
+  double*    w0_pp = nullptr;    // 8 doubles: ring of bias copies for the overlapped recurrence (hogwild, fused, bias lag)
   hipStream_t stream2 = nullptr; // side stream of the hogwild bias scan
   hipStream_t stream3 = nullptr; // second launch stream of the hogwild macro-batches (odd launches)
   int        num_cu = 256;
@@ -95,14 +98,26 @@ struct fmx_context_s {
   std::vector<hipEvent_t> ev_sync;   // untimed events ordering the two hogwild streams
   std::string err;
   hipDeviceProp_t prop;
+  // several GPUs (fmx_comm.hip)
+  void*       comm = nullptr;         // ncclComm_t of a one-process-per-GPU job (fmx_comm_init_rank)
+  struct fmx_group_s* group = nullptr;
+  bool        owns_group = false;     // the 1-handle group fmx_sgd_epoch builds around `comm`
+  float*      xbuf[2] = {nullptr, nullptr};   // exchange buffers [batch][KP + 1]
+  size_t      xcap = 0;
+  hipStream_t stream_comm = nullptr;  // the all-reduce runs here, ordered by ev_x: [which] partial ready, [2 + which] sum ready
+  hipEvent_t  ev_x[4] = {};
+  std::unordered_map<const void*, int> occ_cache;   // resident_grid: occupancy per kernel on THIS handle's device
+  std::unordered_set<const void*> lds_raised;       // kernels whose dynamic-LDS limit was raised on THIS handle's device
 };
 
 // ---- helpers shared between the translation units -------------------------------------------------------------
 int fail(fmx_handle h, int code, const char* fmt, ...);                 // fmx_core.hip
 Hyper make_hyper(const fmx_config& c);
+Shard make_shard(const fmx_config& c);
 uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted);
 int ensure_scratch(fmx_handle h, size_t batch_cap, size_t rest_cap);
 int check_slot(fmx_handle h, int slot, bool need_target);
+int slot_in_session(fmx_handle h, int slot, const char* what);
 void free_segments(Slot& s);
 void free_slot(Slot& s);
 int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st);
@@ -110,6 +125,8 @@ int ensure_segments(fmx_handle h, Slot& s, uint32_t B);                 // fmx_s
 int lag_flush(fmx_handle h);                                             // fmx_sgd.hip
 void sgda_free(fmx_handle h);                                            // fmx_sgd.hip
 void als_free(fmx_handle h);                                             // fmx_als.hip
+void comm_free(fmx_handle h);                                            // fmx_comm.hip: communicator, group membership, exchange buffers
+int comm_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats);   // fmx_comm.hip
 
 #define HIPCHK(h, expr)                                                                         \
   do {                                                                                          \

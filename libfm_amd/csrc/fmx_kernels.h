@@ -43,6 +43,65 @@ struct Hyper {            // per-launch scalars (fm_model.h:56-57, fm_learn_sgd.
   double lr_d, reg0_d, regw_d, regv_d, min_d, max_d;   // unrounded copies for the fp64 sequential kernel
 };
 
+// counter-hash helper: identical definition in oracle/fm_oracle.c (fmo_mix64)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+  x ^= x >> 31;
+  return x;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Which shard owns feature j, and where it lives there (fmx_config::shard_rank / shard_world / shard_hash).
+//   plain : owner = j mod W, local row = j div W
+//   hashed: the same on p(j), p a pseudo-random PERMUTATION of [0, n): a 4-round Feistel network on 2*half_bits bits
+//           (round function = mix64 of the half and the round number), cycle-walked into [0, n) -- still a bijection, so
+//           the local table stays dense (n_local = ceil((n - rank) / W)) and a local row knows its global id (inverse).
+//           Balanced for any id structure (ids that are all multiples of W, one field per residue class, ...).
+// ----------------------------------------------------------------------------------------------
+struct Shard {
+  uint64_t n;
+  uint32_t rank, world, hashed, half_bits;
+  __host__ __device__ __forceinline__ uint32_t round_fn(uint32_t half, uint32_t round) const {
+    return (uint32_t)mix64(((uint64_t)half << 3 | round) + 0x5851F42D4C957F2DULL) & ((1u << half_bits) - 1u);
+  }
+  __host__ __device__ __forceinline__ uint32_t perm(uint32_t j) const {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t x = j;
+    do {
+      uint32_t l = x >> half_bits, r = x & mask;
+      for (uint32_t i = 0; i < 4; i++) { const uint32_t t = l ^ round_fn(r, i); l = r; r = t; }
+      x = (l << half_bits) | r;
+    } while ((uint64_t)x >= n);
+    return x;
+  }
+  __host__ __device__ __forceinline__ uint32_t perm_inv(uint32_t p) const {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t x = p;
+    do {
+      uint32_t l = x >> half_bits, r = x & mask;
+      for (uint32_t i = 4; i-- > 0;) { const uint32_t t = r ^ round_fn(l, i); r = l; l = t; }
+      x = (l << half_bits) | r;
+    } while ((uint64_t)x >= n);
+    return x;
+  }
+  __host__ __device__ __forceinline__ uint32_t placed(uint32_t j) const { return hashed ? perm(j) : j; }
+  __host__ __device__ __forceinline__ bool owns(uint32_t j) const { return world == 1 || placed(j) % world == rank; }
+  __host__ __device__ __forceinline__ uint32_t local(uint32_t j) const { return world == 1 ? j : placed(j) / world; }
+  // (owner test and local row in one evaluation of the permutation)
+  __host__ __device__ __forceinline__ bool place(uint32_t j, uint32_t* local_row) const {
+    if (world == 1) { *local_row = j; return true; }
+    const uint32_t p = placed(j);
+    *local_row = p / world;
+    return p % world == rank;
+  }
+  __host__ __device__ __forceinline__ uint32_t global(uint64_t local_row) const {
+    if (world == 1) return (uint32_t)local_row;
+    const uint32_t p = (uint32_t)(local_row * world + rank);
+    return hashed ? perm_inv(p) : p;
+  }
+};
+
 // ----------------------------------------------------------------------------------------------
 // small device helpers
 // ----------------------------------------------------------------------------------------------
@@ -1402,71 +1461,63 @@ k_yhat(const float* __restrict__ rest, uint32_t n_rows, int k0, const double* __
 }
 
 // ----------------------------------------------------------------------------------------------
-// parameter staging: reference layout (fp64, factor-major v[f][j]) <-> device (fp32, V[jl*KP+f]).
+// parameter staging: reference layout (fp64, factor-major v[f][j]) <-> device (fp32, V[local*KP+f]).
 // stage holds `cnt` consecutive GLOBAL features j0.. of factor rows: stage[f*cnt + (j-j0)].
-// feature j belongs to this shard iff j % world == rank; its local row is j / world.
+// Ownership and local row of a feature: Shard (above).
 // ----------------------------------------------------------------------------------------------
-static __global__ void k_stage_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
-                           int rank, int world, Tab tb) {
+static __global__ void k_stage_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP, Shard sh, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = (uint64_t)cnt * KP;
   if (t >= total) return;
   const uint32_t jj = (uint32_t)(t / KP); const int f = (int)(t % KP);
-  const uint64_t j = j0 + jj;
-  if ((int)(j % world) != rank) return;
-  tb.V[(j / world) * tb.rs + f] = (f < k) ? (float)stage[(size_t)f * cnt + jj] : 0.f;
+  uint32_t jl;
+  if (!sh.place((uint32_t)(j0 + jj), &jl)) return;
+  tb.V[(size_t)jl * tb.rs + f] = (f < k) ? (float)stage[(size_t)f * cnt + jj] : 0.f;
 }
-static __global__ void k_stage_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP,
-                            int rank, int world, Tab tb) {
+static __global__ void k_stage_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP, Shard sh, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = (uint64_t)cnt * k;
   if (t >= total) return;
   const int f = (int)(t / cnt); const uint32_t jj = (uint32_t)(t % cnt);
-  const uint64_t j = j0 + jj;
-  if ((int)(j % world) != rank) return;
-  stage[(size_t)f * cnt + jj] = (double)tb.V[(j / world) * tb.rs + f];
+  uint32_t jl;
+  if (!sh.place((uint32_t)(j0 + jj), &jl)) return;
+  stage[(size_t)f * cnt + jj] = (double)tb.V[(size_t)jl * tb.rs + f];
 }
-static __global__ void k_w_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, Tab tb) {
+static __global__ void k_w_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, Shard sh, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cnt) return;
-  const uint64_t j = j0 + t;
-  if ((int)(j % world) == rank) tb.w[(j / world) * tb.ws] = (float)stage[t];
+  uint32_t jl;
+  if (sh.place((uint32_t)(j0 + t), &jl)) tb.w[(size_t)jl * tb.ws] = (float)stage[t];
 }
-static __global__ void k_w_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, int rank, int world, Tab tb) {
+static __global__ void k_w_out(double* __restrict__ stage, uint64_t j0, uint32_t cnt, Shard sh, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cnt) return;
-  const uint64_t j = j0 + t;
-  if ((int)(j % world) == rank) stage[t] = (double)tb.w[(j / world) * tb.ws];
+  uint32_t jl;
+  if (sh.place((uint32_t)(j0 + t), &jl)) stage[t] = (double)tb.w[(size_t)jl * tb.ws];
 }
 
-static __global__ void k_fetch_rows(const uint32_t* __restrict__ ids, uint32_t count, int k, int world, Tab tb,
+static __global__ void k_fetch_rows(const uint32_t* __restrict__ ids, uint32_t count, int k, Shard sh, Tab tb,
                              double* __restrict__ w_out, double* __restrict__ v_out) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (uint64_t)count * (uint64_t)(k + 1)) return;
   const uint32_t i = (uint32_t)(t / (k + 1)); const int f = (int)(t % (k + 1));
-  const size_t jl = ids[i] / (uint32_t)world;
+  const size_t jl = sh.local(ids[i]);
   if (f == k) w_out[i] = (double)tb.w[jl * tb.ws];
   else v_out[(size_t)i * k + f] = (double)tb.V[jl * tb.rs + f];
 }
 
-// counter-hash helpers: identical definitions in oracle/fm_oracle.c (fmo_mix64, fmo_synth_id, ...)
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
-  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
-  x ^= x >> 27; x *= 0x94D049BB133111EBULL;
-  x ^= x >> 31;
-  return x;
-}
+// counter-hash helpers: identical definitions in oracle/fm_oracle.c (fmo_synth_id, ...)
 __host__ __device__ __forceinline__ uint64_t synth_key(uint64_t seed, uint64_t row, uint32_t field) {
   return mix64(seed + 0x9E3779B97F4A7C15ULL * (row + 1) + 0xC2B2AE3D27D4EB4FULL * ((uint64_t)field + 1));
 }
 
 static __global__ void k_init_params(Tab tb, uint64_t n_local, int k, int KP,
-                              int rank, int world, float mean, double stdev, uint64_t seed) {
+                              Shard sh, float mean, double stdev, uint64_t seed) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = t; i < n_local * (uint64_t)tb.rs; i += stride) {    // whole row incl. padding (and w if co-located)
     const uint64_t jl = i / tb.rs; const int f = (int)(i % tb.rs);
-    const uint64_t j = jl * world + rank;
+    const uint64_t j = sh.global(jl);
     float val = 0.f;
     if (f < k) {
       const uint64_t hsh = mix64(seed ^ (j * 0x9E3779B97F4A7C15ULL + (uint64_t)f * 0xD6E8FEB86659FD93ULL + 0x1234567ULL));
@@ -1478,9 +1529,9 @@ static __global__ void k_init_params(Tab tb, uint64_t n_local, int k, int KP,
   if (tb.ws == 1) for (uint64_t i = t; i < n_local; i += stride) tb.w[i] = 0.f;
 }
 
-// synthetic rows: field t owns ids [t*fs,(t+1)*fs); this shard keeps id % world == rank
+// synthetic rows: field t owns ids [t*fs,(t+1)*fs); this shard keeps the ids it owns (Shard)
 // pass 1 (count==true): row_cnt[r] = #kept entries; pass 2: fill at row_ptr[r]
-static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t fs, int rank, int world,
+static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t fs, Shard sh,
                         uint32_t* __restrict__ row_cnt, const uint64_t* __restrict__ row_ptr,
                         Entry* __restrict__ ent, float* __restrict__ target) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1490,8 +1541,9 @@ static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, ui
   for (uint32_t t = 0; t < nnz; t++) {
     const uint64_t hsh = synth_key(seed, row0 + r, t);
     const uint32_t id = t * fs + (uint32_t)(((hsh >> 32) * (uint64_t)fs) >> 32);
-    if ((int)(id % (uint32_t)world) == rank) {
-      if (ent) { ent[pos].id = id / (uint32_t)world; ent[pos].value = 1.0f; pos++; }
+    uint32_t jl;
+    if (sh.place(id, &jl)) {
+      if (ent) { ent[pos].id = jl; ent[pos].value = 1.0f; pos++; }
       c++;
     }
   }

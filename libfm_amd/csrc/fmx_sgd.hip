@@ -84,6 +84,7 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
 // builds the (batch, feature) segments of a slot for batch size B (device radix sort; once per data set)
 extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   if (s.seg_B == B && s.t_ent) return FMX_OK;
+  { int _rc = slot_in_session(h, (int)(&s - h->slots), "re-bucketing the rows for another batch size"); if (_rc) return _rc; }
   free_segments(s);
   const uint64_t nnz = s.nnz;
   const uint32_t n_batches = (s.n_rows + B - 1) / B;
@@ -202,8 +203,9 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     // micro-chunks that are multiples of 256 examples: four wavefronts share a chunk (k_scan4, pieces of 1024 or 256
     // examples), else one wavefront
     const int part = (getenv("FMX_SCAN_ONE_WAVE") || (chunk % 256u) != 0) ? 0 : ((chunk % 1024u) == 0 ? 1024 : 256);
-#define FMX_SCAN4(WM, TK, PT) do { auto kf = k_scan4<WM, TK, PT>; static bool raised = false;                                   \
-      if (!raised) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCAN4_LDS_BYTES)); raised = true; } \
+    // (function attributes are per-device state: the 128 KiB dynamic-LDS limit is raised once per handle, not per process)
+#define FMX_SCAN4(WM, TK, PT) do { auto kf = k_scan4<WM, TK, PT>;                                                                \
+      if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCAN4_LDS_BYTES)); h->lds_raised.insert((const void*)kf); } \
       hipLaunchKernelGGL(kf, dim3(1), dim3(256), SCAN4_LDS_BYTES, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
 #define FMX_SCAN(WM, TK) do { \
       if (part == 1024)     FMX_SCAN4(WM, TK, 1024); \
@@ -221,49 +223,54 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
   return FMX_OK;
 }
 
-// ---- FMX_FLAG_BIAS_LAG: the w0 recurrence of batch b runs on stream2 while the main stream goes on ------------
+// ---- FMX_FLAG_BIAS_LAG (split step): the w0 recurrence of batch b runs on stream2 while the main stream goes on ----
+// Depth d = opts->bias_lag (>= 1): the multipliers of batch b use the bias as it was after the recurrence of batch b - d.
+// Ring of R = d + 1 bias slots: slot (b + 1) % R holds the bias after batch b (all slots start as the current bias);
+// the recurrence of batch b reads slot b % R and writes slot (b + 1) % R; the multipliers of batch b read slot
+// (b - d + 1) % R, which is rewritten next by the recurrence of batch b + 1 -- enqueued after them.  d + 1 rest buffers.
 extern "C++" int lag_flush(fmx_handle h) {                      // make h->w0 the current bias again
   LagState& L = h->lag;
   if (!L.active) return FMX_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream2));
-  HIPCHK(h, hipMemcpy(h->w0, h->w0_pp + (L.step & 1), sizeof(double), hipMemcpyDeviceToDevice));
+  HIPCHK(h, hipMemcpy(h->w0, h->w0_pp + (L.step % (L.depth + 1)), sizeof(double), hipMemcpyDeviceToDevice));
   L.active = false; L.step = 0;
   return FMX_OK;
 }
-// call BEFORE producing the rest buffer of this step on `st`; returns which of the two rest buffers to use
-static int lag_prepare(fmx_handle h, hipStream_t st, int* slot) {
+// call BEFORE producing the rest buffer of this step on `st`; returns which of the d + 1 rest buffers to use
+static int lag_prepare(fmx_handle h, hipStream_t st, uint32_t depth, int* slot) {
   LagState& L = h->lag;
   if (!L.ev_rest) {
     HIPCHK(h, hipEventCreateWithFlags(&L.ev_rest, hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&L.ev_scan[0], hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&L.ev_scan[1], hipEventDisableTiming));
+    for (auto& e : L.ev_scan) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  if (L.active && L.depth != depth) { int rc = lag_flush(h); if (rc) return rc; }
   if (!L.active) {
-    HIPCHK(h, hipMemcpyAsync(h->w0_pp, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->w0_pp + 1, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+    L.depth = depth;
+    for (uint32_t r = 0; r <= depth; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
     L.active = true; L.step = 0;
-  } else {
-    HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[L.step & 1], 0));      // scan(step-2) is done with this buffer
+  } else if (L.step > depth) {
+    HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[(L.step - depth - 1) % LagState::RING], 0));   // recurrence (step - d - 1) is done with this rest buffer
   }
-  *slot = (int)(L.step & 1);
+  *slot = (int)(L.step % (depth + 1));
   return FMX_OK;
 }
 // call AFTER `rest` is complete on `st`: starts the recurrence on the side stream and leaves the multipliers of
-// this batch (batch-start bias) in h->mult on `st`
+// this batch (lagged bias) in h->mult on `st`
 static int lag_step(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
                     const Hyper& hy, hipStream_t st) {
   LagState& L = h->lag;
   const uint64_t b = L.step;
+  const uint32_t d = L.depth, R = d + 1;
   if (hy.k0) {
     HIPCHK(h, hipEventRecord(L.ev_rest, st));
     HIPCHK(h, hipStreamWaitEvent(h->stream2, L.ev_rest, 0));
-    int rc = launch_scan(h, rest, target, n_rows, chunk, hy, nullptr, h->stream2, h->w0_pp + (b & 1), h->w0_pp + ((b + 1) & 1));
+    int rc = launch_scan(h, rest, target, n_rows, chunk, hy, nullptr, h->stream2, h->w0_pp + (b % R), h->w0_pp + ((b + 1) % R));
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(L.ev_scan[b & 1], h->stream2));
-    if (b >= 1) HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[(b + 1) & 1], 0));   // scan(b-1) wrote w0_pp[b & 1]
+    HIPCHK(h, hipEventRecord(L.ev_scan[b % LagState::RING], h->stream2));
+    if (b >= d) HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[(b - d) % LagState::RING], 0));   // recurrence of batch b - d
   }
   hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
-                     (const double*)(h->w0_pp + (b & 1)), h->mult);
+                     (const double*)(h->w0_pp + ((b + R - d + 1) % R)), h->mult);
   HIPCHK(h, hipGetLastError());
   L.step++;
   return FMX_OK;
@@ -321,10 +328,12 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   const bool lag = opts && (opts->flags & FMX_FLAG_BIAS_LAG);
   const uint32_t Bcap = (opts && opts->batch) ? std::max(opts->batch, n_rows) : n_rows;
-  rc = ensure_scratch(h, n_rows, (size_t)Bcap * 2);
+  const uint32_t lag_depth = (opts && opts->bias_lag) ? opts->bias_lag : 1u;
+  if (lag_depth > 4) return fail(h, FMX_E_ARG, "bias_lag %u: at most 4 batches", lag_depth);
+  rc = ensure_scratch(h, n_rows, (size_t)Bcap * (lag_depth + 1));
   if (rc) return rc;
   int rslot = 0;
-  if (lag) { rc = lag_prepare(h, st, &rslot); if (rc) return rc; } else { rc = lag_flush(h); if (rc) return rc; }
+  if (lag) { rc = lag_prepare(h, st, lag_depth, &rslot); if (rc) return rc; } else { rc = lag_flush(h); if (rc) return rc; }
   float* rest_buf = h->rest + (size_t)rslot * Bcap;
   const float* S = d_partial;
   const float* c = d_partial + (size_t)n_rows * h->KP;
@@ -336,7 +345,7 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_SEGMENTED || apply == FMX_APPLY_FUSED) {
     // the driver walks the slot in batches of opts->batch rows (the last one may be short)
     const uint32_t B = (opts && opts->batch) ? opts->batch : n_rows;
-    if (row0 % B != 0 || (n_rows != B && row0 + n_rows != s.n_rows))
+    if (row0 % B != 0 || n_rows > B || n_rows != std::min<uint64_t>(B, s.n_rows - row0))
       return fail(h, FMX_E_ARG, "fmx_sgd_finish: rows [%llu,+%u) are not batch %u of the slot", (unsigned long long)row0, n_rows, B);
     rc = ensure_segments(h, h->slots[slot], B);
     if (rc) return rc;
@@ -429,9 +438,8 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   if (stats) memset(stats, 0, sizeof(*stats));
   if (s.n_rows == 0) return FMX_OK;
   if (h->cfg.shard_world > 1 && opts->mode != FMX_SGD_MINIBATCH)
-    return fail(h, FMX_E_UNSUPPORTED, "feature-sharded handles train through fmx_sgd_partial / fmx_sgd_finish");
-  if (h->cfg.shard_world > 1)
-    return fail(h, FMX_E_UNSUPPORTED, "fmx_sgd_epoch on a feature shard: drive fmx_sgd_partial + all-reduce + fmx_sgd_finish");
+    return fail(h, FMX_E_UNSUPPORTED, "feature shards train with FMX_SGD_MINIBATCH (the split step)");
+  if (h->cfg.shard_world > 1) return comm_sgd_epoch(h, slot, opts, stats);
   const Hyper hy = make_hyper(h->cfg);
   const bool timed = (opts->flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
   uint64_t batches = 0, main_launches = 0, deferred = 0;
@@ -500,8 +508,10 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
     const uint32_t B = opts->batch ? opts->batch : 16384u;
     const bool lag = (opts->flags & FMX_FLAG_BIAS_LAG) != 0;
+    const uint32_t lag_depth = opts->bias_lag ? opts->bias_lag : 1u;
+    if (lag_depth > 4) return fail(h, FMX_E_ARG, "bias_lag %u: at most 4 batches", lag_depth);
     const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
-    rc = ensure_scratch(h, (size_t)Bc * (lag ? 2 : 1), 0);
+    rc = ensure_scratch(h, (size_t)Bc * (lag ? lag_depth + 1 : 1), 0);
     if (rc) return rc;
     const bool segmented = (opts->apply == FMX_APPLY_DEFAULT || opts->apply == FMX_APPLY_SEGMENTED);
     if (segmented) {
@@ -512,7 +522,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     for (uint64_t row0 = 0; row0 < s.n_rows; row0 += B) {
       const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
       int pslot = 0;
-      if (lag) { rc = lag_prepare(h, h->stream, &pslot); if (rc) return rc; }
+      if (lag) { rc = lag_prepare(h, h->stream, lag_depth, &pslot); if (rc) return rc; }
       float* S = h->partial + (size_t)pslot * Bc * (size_t)(h->KP + 1);
       float* rest = S + (size_t)nb * h->KP;
       KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, h->stream,
@@ -527,7 +537,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     return fail(h, FMX_E_ARG, "unknown SGD mode %d", opts->mode);
   }
   if (h->lag.active) {     // the last recurrence must finish inside the timed region; then w0 returns to h->w0
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->lag.ev_scan[(h->lag.step + 1) & 1], 0));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->lag.ev_scan[(h->lag.step - 1) % LagState::RING], 0));
   }
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

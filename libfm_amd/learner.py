@@ -255,10 +255,13 @@ class FMLearnALS:
         self._h.set_groups(self.groups)
 
     def _v_table(self, x):
-        """v_lambda-like value -> [G][k] (scalar, one value per group, or the full table)."""
+        """v_lambda-like value -> [G][k].  Scalar, the full [G][k] table, or a 1-D vector that ALWAYS means one value per
+        attribute group (what `-regular 'r0,w_1..w_G,v_1..v_G'` supplies, libfm.cpp:353-363) -- never per factor."""
         G, k = self._h.G, max(self.fm.num_factor, 1)
         x = np.asarray(x, dtype=np.float64)
-        if x.ndim == 1 and x.shape[0] == G:
+        if x.ndim == 1 and x.shape[0] != 1:
+            if x.shape[0] != G:
+                raise ValueError("a 1-D v_lambda holds one value per attribute group (%d), got %d" % (G, x.shape[0]))
             x = x[:, None]
         return np.ascontiguousarray(np.broadcast_to(x, (G, k)))
 

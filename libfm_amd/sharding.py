@@ -3,8 +3,9 @@ look, and the layout of the per-minibatch exchange buffer.  libfmx.so implements
 fmx_synth_rows (filtering) and fmx_sgd_partial / fmx_sgd_finish (buffer); bench.py and the tests use these helpers
 so that the N>1 path is correct by construction and checkable on CPU (tests/test_sharded_gloo.py).
 
-Decomposition (BASELINE.json north_star): V and w are row-sharded by feature id,
-owner(j) = j mod world, local row = j div world; every rank sees EVERY example restricted to its own features;
+Decomposition (BASELINE.json north_star): V and w are row-sharded by feature id -- owner and local
+row of a feature come from the library's ownership rule (fmx_shard_place: plain mod / div, or the hashed permutation);
+every rank sees EVERY example restricted to its own features;
 w0 is replicated.  Per minibatch one all-reduce (sum) of
 
     buffer[0 : B*KP]        S[e][f]  = sum over the rank's features of v[f][j] * x_ej       (fm_model.h:116-125)
@@ -15,26 +16,35 @@ w0 recurrence (identical on all ranks) and updates only its own rows.
 """
 import numpy as np
 
-
-def owner(j, world):
-    return j % world
+from . import capi
 
 
-def local_row(j, world):
-    return j // world
+def place(ids, n, world, shard_hash=0):
+    """(owner, local_row) of feature ids: the library's own rule (fmx_shard_place, host arithmetic: plain = id mod /
+    div world; hashed = the same on a fixed pseudo-random permutation of [0, n), include/fmx.h fmx_config::shard_hash)"""
+    return capi.shard_place(n, world, shard_hash, ids)
+
+
+def owned_ids(n, rank, world, shard_hash=0):
+    """global ids of the rank's local rows 0 .. n_local-1 (fmx_shard_global)"""
+    return capi.shard_global(n, world, shard_hash, rank, np.arange(n_local(n, rank, world), dtype=np.uint32))
 
 
 def n_local(n, rank, world):
     return (n - rank + world - 1) // world if n > rank else 0
 
 
-def filter_rows(entries, row_ptr, rank, world):
-    """entries/row_ptr of the rows restricted to the rank's features, ids renumbered to local rows."""
+def filter_rows(entries, row_ptr, rank, world, n=None, shard_hash=0):
+    """entries/row_ptr of the rows restricted to the rank's features, ids renumbered to local rows (what
+    fmx_upload_rows does on a sharded handle)."""
     ids = entries["id"]
-    keep = (ids % world) == rank
+    if n is None:
+        n = int(ids.max()) + 1 if len(ids) else 1
+    own, loc = place(ids, n, world, shard_hash)
+    keep = own == rank
     row_of = np.repeat(np.arange(len(row_ptr) - 1), np.diff(row_ptr.astype(np.int64)))
     out = entries[keep].copy()
-    out["id"] = out["id"] // world
+    out["id"] = loc[keep]
     counts = np.bincount(row_of[keep], minlength=len(row_ptr) - 1)
     new_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
     return out, new_ptr

@@ -382,5 +382,49 @@ def main():
         print("%-22s n=%d k=%d rows=%d/%d  eval[-1]=%s" % (name, init.n, init.k, tr.n_rows, te.n_rows, ev[-1]))
 
 
+def make_mcmc_seed_band(seeds=range(101, 113)):
+    """the REFERENCE's own seed-to-seed distribution on the MCMC fixtures: -seed changes its libc rand() stream (initial
+    model AND every draw).  Per fixture: the test metric (RMSE / accuracy) of the posterior-mean prediction for each seed
+    and the seed-averaged prediction.  tests/test_gpu_mcmc.py holds the mean and spread of OUR chains to this band."""
+    out = {}
+    for name, case in MCMC_CASES.items():
+        z = np.load(os.path.join(HERE, name + ".npz"))
+        cfg = case["cfg"]
+        tr = O.Data(z["train_entries"], z["train_row_ptr"], z["train_target"])
+        te = O.Data(z["test_entries"], z["test_row_ptr"], z["test_target"])
+        y = z["test_target"].astype(np.float64)
+        metrics, preds = [], []
+        with tempfile.TemporaryDirectory() as td:
+            trf, tef = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm")
+            tr.write_libsvm(trf)
+            te.write_libsvm(tef)
+            env = {}
+            if "groups" in case:
+                write_meta(os.path.join(td, "meta"), case, case["n_nominal"])
+                env = {"FMX_META": os.path.join(td, "meta")}
+            for seed in seeds:
+                pre = os.path.join(td, "o%d" % seed)
+                O.run_ref_harness(["mcmc", trf, tef, cfg["task"], cfg["k0"], cfg["k1"], cfg["k"], cfg["iters"],
+                                   repr(cfg["init_stdev"]), seed, pre], env=env)
+                p = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+                preds.append(p)
+                metrics.append(np.sqrt(np.mean((p - y) ** 2)) if cfg["task"] == "r" else np.mean((p >= 0.5) == (y > 0)))
+        out[name + "_metric"] = np.array(metrics)
+        out[name + "_pred_mean"] = np.mean(preds, axis=0)
+        # every chain against the mean of the OTHER chains (leave-one-out): the reference's own chain-to-posterior band
+        tot = np.sum(preds, axis=0)
+        out[name + "_loo_corr"] = np.array([np.corrcoef(p, (tot - p) / (len(preds) - 1))[0, 1] for p in preds])
+        out[name + "_loo_rms"] = np.array([np.sqrt(np.mean((p - (tot - p) / (len(preds) - 1)) ** 2)) for p in preds])
+        pm = out[name + "_pred_mean"]
+        print("%-22s reference over %d seeds: metric mean %.4f sd %.4f (min %.4f max %.4f); one chain vs the seed mean: corr %.4f..%.4f"
+              % (name, len(metrics), np.mean(metrics), np.std(metrics, ddof=1), np.min(metrics), np.max(metrics),
+                 min(np.corrcoef(p, pm)[0, 1] for p in preds), max(np.corrcoef(p, pm)[0, 1] for p in preds)))
+    out["seeds"] = np.array(list(seeds))
+    np.savez_compressed(os.path.join(HERE, "mcmc_ref_seed_band.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--mcmc-seed-band" in sys.argv:
+        make_mcmc_seed_band()        # does not touch the other fixtures
+    else:
+        main()

@@ -1,0 +1,148 @@
+"""GPU: several feature shards driven through the C-ABI alone (fmx_group_*; no torch, no Python in the step).
+On a one-GPU box the shards share the device and the exchange is the library's loopback reduction kernel; with two or
+more visible devices the same calls run over RCCL.  Bar: the sharded run trains the SAME model as one unsharded handle
+under the same rule (batch, micro-chunk, bias lag) -- 1e-4 -- and both sit on the oracle's rule."""
+import numpy as np
+import pytest
+
+import datagen
+from common import Golden
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from libfm_amd import build, capi
+    build.build()
+    if capi.load().fmx_device_count() == 0:
+        pytest.fail("gpu-marked test without a HIP device")
+    return capi
+
+
+def make_group(capi, world, devices, n, k, task, reg, lr, lo, hi, shard_hash, k0=True, k1=True):
+    hs = [capi.Handle(n, k, k0, k1, task, reg[0], reg[1], reg[2], lr, lo, hi, device=devices[r], shard_rank=r,
+                      shard_world=world, shard_hash=shard_hash) for r in range(world)]
+    return hs, capi.Group(hs)
+
+
+@pytest.mark.parametrize("world,shard_hash,lag,pipeline", [(2, 0, 1, False), (2, 1, 1, False), (3, 1, 2, False), (4, 1, 1, True),
+                                                           (2, 1, 3, False), (8, 1, 2, False)])
+@pytest.mark.parametrize("name", ["sgd_cls_zipf_k32", "sgd_reg_ml"])
+def test_group_trains_the_unsharded_model(capi, oracle, name, world, shard_hash, lag, pipeline):
+    g = Golden(name)
+    m = g.model(oracle, "init")
+    tr, te = g.data(oracle, "train"), g.data(oracle, "test")
+    batch, chunk = 100, 10
+    hs, grp = make_group(capi, world, [0] * world, g.n, g.k, g.task, g.reg, g.lr, g.min_target, g.max_target, shard_hash, g.k0, g.k1)
+    for h in hs:
+        h.set_params(m.w0, m.w, m.v)
+        h.upload_rows(0, tr.entries, tr.row_ptr, tr.target)
+        h.upload_rows(1, te.entries, te.row_ptr, te.target)
+    flags = capi.FLAG_BIAS_LAG | (capi.FLAG_PIPELINE if pipeline else 0)
+    for _ in range(g.iters):
+        grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, chunk, flags, lag)
+        oracle.sgd_epoch_minibatch(m, tr, g.task, g.lr, g.min_target, g.max_target, batch, chunk, bias_lag=lag, pipelined=pipeline)
+    w0, w, v = grp.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    # predictions and the evaluation over the shards
+    np.testing.assert_allclose(grp.predict(1, te.n_rows), oracle.predict_raw(m, te), rtol=RTOL, atol=5e-5)
+    ev = grp.evaluate(0)
+    ref, mae = oracle.evaluate(m, tr, g.task, g.min_target, g.max_target)
+    if g.task == 0:
+        assert abs(ev.rmse - ref) <= 1e-4 * ref + 1e-6 and abs(ev.mae - mae) <= 1e-4 * mae + 1e-6
+    else:
+        assert abs(ev.accuracy - ref) * tr.n_rows <= 3
+    grp.close()
+    for h in hs:
+        h.close()
+
+
+def test_hashed_ownership_balances_structured_ids(capi):
+    """ids that are all multiples of 8 (or all inside one residue class of any small modulus) land on ONE shard under
+    `j mod P`; the permutation spreads them"""
+    n, world = 1 << 20, 8
+    ids = (np.arange(20000, dtype=np.uint32) * 8) % n
+    ent = np.zeros(len(ids), dtype=capi.ENTRY_DTYPE)
+    ent["id"], ent["value"] = ids, 1.0
+    rp = np.arange(0, len(ids) + 1, 4, dtype=np.uint64)
+    y = np.zeros(len(rp) - 1, dtype=np.float32)
+    counts = {0: [], 1: []}
+    for hashed in (0, 1):
+        for r in range(world):
+            h = capi.Handle(n, 2, True, True, 0, shard_rank=r, shard_world=world, shard_hash=hashed)
+            h.upload_rows(0, ent, rp, y)
+            counts[hashed].append(len(h.download_rows(0)[0]))
+            h.close()
+    assert counts[0][0] == len(ids) and sum(counts[0][1:]) == 0          # mod: everything on shard 0
+    assert sum(counts[1]) == len(ids)
+    assert max(counts[1]) < 1.15 * len(ids) / world and min(counts[1]) > 0.85 * len(ids) / world
+
+
+@pytest.mark.parametrize("shard_hash", [0, 1])
+def test_sharded_params_round_trip_and_rows(capi, oracle, shard_hash):
+    """set_params / get_params / get_param_rows / init_params agree between a sharded and an unsharded handle"""
+    n, k, world = 5003, 8, 3
+    rng = np.random.default_rng(5)
+    w, v = rng.normal(0, 1, n), rng.normal(0, 1, (k, n))
+    hs = [capi.Handle(n, k, shard_rank=r, shard_world=world, shard_hash=shard_hash) for r in range(world)]
+    for h in hs:
+        h.set_params(0.5, w, v)
+    wo, vo = np.zeros(n), np.zeros((k, n))
+    seen = np.zeros(n, dtype=int)
+    for h in hs:
+        w1, v1 = np.full(n, np.nan), np.full((k, n), np.nan)
+        _, w1, v1 = h.get_params(w1, v1)
+        own = ~np.isnan(w1)
+        seen += own
+        assert own.sum() == h.n_local
+        wo[own], vo[:, own] = w1[own], v1[:, own]
+        ids = np.flatnonzero(own)[:50].astype(np.uint32)
+        wr, vr = h.get_param_rows(ids)
+        assert np.array_equal(wr, w1[ids]) and np.array_equal(vr, v1[:, ids])
+    assert (seen == 1).all()                                              # every feature has exactly one owner
+    assert np.array_equal(wo, w.astype(np.float32).astype(np.float64))
+    assert np.array_equal(vo, v.astype(np.float32).astype(np.float64))
+    # device-side fill: the value of a feature does not depend on how the table is sharded
+    full = capi.Handle(n, k)
+    full.init_params(0.0, 0.1, 9)
+    _, wf, vf = full.get_params()
+    for h in hs:
+        h.init_params(0.0, 0.1, 9)
+    for h in hs:
+        w1, v1 = np.full(n, np.nan), np.full((k, n), np.nan)
+        _, w1, v1 = h.get_params(w1, v1)
+        own = ~np.isnan(w1)
+        assert np.array_equal(v1[:, own], vf[:, own])
+    full.close()
+    for h in hs:
+        h.close()
+
+
+def test_group_at_bench_shape_matches_single_handle(capi):
+    """n = 1e7, k = 64, 32 nnz: 4 loopback shards == one handle running the one-pass form of the same rule"""
+    n, k, nnz, rows, batch = 10_000_000, 64, 32, 1 << 17, 32768
+    h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+    h.init_params(0.0, 0.05, 3)
+    h.synth_rows(0, 11, 0, rows, nnz)
+    h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, 0, 0, 2)
+    p_one = h.predict(0, rows)
+    w0_one = h.get_w0()
+    h.close()
+    world = 4
+    hs = [capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0, shard_rank=r,
+                      shard_world=world, shard_hash=1) for r in range(world)]
+    for x in hs:
+        x.init_params(0.0, 0.05, 3)
+        x.synth_rows(0, 11, 0, rows, nnz)
+    grp = capi.Group(hs)
+    grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, 0, 0, 2)
+    p_grp = grp.predict(0, rows)
+    assert abs(hs[0].get_w0() - w0_one) <= 1e-5 * abs(w0_one) + 1e-7
+    np.testing.assert_allclose(p_grp, p_one, rtol=1e-4, atol=2e-5)
+    grp.close()
+    for x in hs:
+        x.close()

@@ -1,23 +1,50 @@
 """GPU: the Gibbs sampler (fm_learn_mcmc, do_sample = 1, do_multilevel = 1) -- STATISTICAL parity.
 
 The reference draws from one sequential libc rand() stream with rejection loops (random.h); no parallel sampler
-can reproduce it bit-for-bit, so the bar is: same model, same hyper-priors, same data -> the posterior-mean test
-predictions of our chain agree with those of the reference's chain (fixtures produced by oracle/_ref/ref_harness
-mcmc, 40 iterations): test RMSE / accuracy within 3 % and a prediction correlation inside the band the REFERENCE
-shows against itself when only its -seed changes (measured with three other seeds: regression 0.986-0.990, rms
-difference 0.09-0.11; classification 0.967-0.972, rms difference 0.075-0.082)."""
+can reproduce it bit-for-bit, so the bar is the reference's OWN seed-to-seed distribution:
+tests/golden/mcmc_ref_seed_band.npz (tests/golden/make_golden.py --mcmc-seed-band) holds, per fixture, the test metric
+(RMSE / accuracy) of the reference's posterior-mean prediction for 12 seeds, the seed-averaged prediction, and every
+reference chain's correlation / rms distance to the mean of the OTHER chains.  Our sampler runs N_SEEDS chains and must
+  * have the same mean metric:  |mean_gpu - mean_ref| < 3 * sd_ref * sqrt(1/N_SEEDS + 1/12)   (3 standard errors),
+  * not be wider than twice the reference's spread (nor collapsed to a point),
+  * produce single chains that sit as close to the reference's seed-averaged posterior mean as the reference's own chains
+    do (small margin), and a seed-averaged prediction that is closer still.
+A biased or over-/under-dispersed sampler fails these; a single-seed band several sigma wide (round 1) did not see it."""
 import io
 
 import numpy as np
 import pytest
 
 from common import Golden
+from conftest import GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
-# test RMSE of the REFERENCE's posterior mean over 10 other seeds (stock harness, 40 iterations): mean (sd 0.0053 / 0.0061);
-# the committed fixture is ONE such run (0.5806 / 0.5739), so the bar is the reference's distribution, not that sample.
-# Our sampler over 12 seeds (tests/dev_mcmc_band.py): 0.588 (0.5777-0.6011) / 0.5677 (0.5537-0.5738).
-REF_RMSE_MEAN = {"mcmc_reg_ml": 0.5871, "mcmc_reg_ml_groups": 0.5677}
+N_SEEDS = 8
+BAND = np.load(GOLDEN_DIR + "/mcmc_ref_seed_band.npz")
+
+
+def check_against_band(name, preds, y, task):
+    """preds: N_SEEDS posterior-mean test predictions of our chains"""
+    ref_m, ref_pm = BAND[name + "_metric"], BAND[name + "_pred_mean"]
+    ref_corr, ref_rms = BAND[name + "_loo_corr"], BAND[name + "_loo_rms"]
+    if task == 0:
+        metric = np.array([np.sqrt(np.mean((p - y) ** 2)) for p in preds])
+    else:
+        metric = np.array([np.mean((p >= 0.5) == (y > 0)) for p in preds])
+    sd_ref = ref_m.std(ddof=1)
+    se = sd_ref * np.sqrt(1.0 / len(preds) + 1.0 / len(ref_m))
+    info = (name, metric.mean(), ref_m.mean(), metric.std(ddof=1), sd_ref)
+    assert abs(metric.mean() - ref_m.mean()) < 3.0 * se, info                   # same mean (3 standard errors)
+    assert 0.25 * sd_ref < metric.std(ddof=1) < 2.0 * sd_ref, info              # same spread (within 2x; 4x on the low side)
+    corr = np.array([np.corrcoef(p, ref_pm)[0, 1] for p in preds])
+    rms = np.array([np.sqrt(np.mean((p - ref_pm) ** 2)) for p in preds])
+    # single chains against the reference's seed-averaged prediction: inside the reference's own chain-to-mean band
+    assert corr.min() > ref_corr.min() - 0.004, (name, corr.min(), ref_corr.min())
+    assert rms.max() < 1.15 * ref_rms.max(), (name, rms.max(), ref_rms.max())
+    # our seed average against theirs: the sampling noise averages out, what is left would be bias
+    pm = np.mean(preds, axis=0)
+    assert np.corrcoef(pm, ref_pm)[0, 1] > ref_corr.max(), (name, np.corrcoef(pm, ref_pm)[0, 1], ref_corr.max())
+    assert np.sqrt(np.mean((pm - ref_pm) ** 2)) < 0.6 * ref_rms.min(), (name, np.sqrt(np.mean((pm - ref_pm) ** 2)), ref_rms.min())
 
 
 def run_chain(g, oracle, seed):
@@ -44,49 +71,25 @@ def run_chain(g, oracle, seed):
 
 def test_mcmc_regression_posterior_mean(oracle):
     g = Golden("mcmc_reg_ml")
-    ref = g.z["pred_out"]
-    y = g.test_target.astype(np.float64)
-    p, l = run_chain(g, oracle, seed=3)
-    rmse_ref = np.sqrt(np.mean((ref - y) ** 2))
-    rmse = np.sqrt(np.mean((p - y) ** 2))
-    assert abs(rmse - REF_RMSE_MEAN[g.name]) < 0.035, (rmse, rmse_ref)   # reference over 10 seeds: sd 0.005-0.006; ours: sd 0.008
-    assert np.corrcoef(p, ref)[0, 1] > 0.975                 # reference vs reference (other seeds): 0.986-0.990
-    assert np.sqrt(np.mean((p - ref) ** 2)) < 0.14           # reference vs reference: 0.093-0.112
-    assert all(np.isfinite(x["alpha"]) and x["alpha"] > 0 for x in l.log)
+    runs = [run_chain(g, oracle, seed=100 + i) for i in range(N_SEEDS)]
+    check_against_band(g.name, [p for p, _ in runs], g.test_target.astype(np.float64), 0)
+    assert all(np.isfinite(x["alpha"]) and x["alpha"] > 0 for _, l in runs for x in l.log)
+    assert not np.array_equal(runs[0][0], runs[1][0])          # seeds give different chains
 
 
 def test_mcmc_classification_posterior_mean(oracle):
     g = Golden("mcmc_cls_fields")
-    ref = g.z["pred_out"]
-    y = g.test_target
-    p, l = run_chain(g, oracle, seed=5)
-    acc_ref = np.mean((ref >= 0.5) == (y > 0))
-    acc = np.mean((p >= 0.5) == (y > 0))
-    assert abs(acc - acc_ref) < 0.03, (acc, acc_ref)
-    assert np.corrcoef(p, ref)[0, 1] > 0.955                 # reference vs reference (other seeds): 0.967-0.972
-    assert np.sqrt(np.mean((p - ref) ** 2)) < 0.10           # reference vs reference: 0.075-0.082
-    assert (p >= 0).all() and (p <= 1).all()
-
-
-def test_mcmc_two_seeds_differ_but_agree(oracle):
-    g = Golden("mcmc_reg_ml")
-    p1, _ = run_chain(g, oracle, seed=1)
-    p2, _ = run_chain(g, oracle, seed=2)
-    assert not np.array_equal(p1, p2)
-    assert np.corrcoef(p1, p2)[0, 1] > 0.97
+    preds = [run_chain(g, oracle, seed=200 + i)[0] for i in range(N_SEEDS)]
+    check_against_band(g.name, preds, g.test_target, 1)
+    assert all((p >= 0).all() and (p <= 1).all() for p in preds)
 
 
 def test_mcmc_attribute_groups_posterior_mean(oracle):
     """two attribute groups (users / items): lambda and mu are drawn per group (fm_learn_mcmc.h:941-1097)"""
     g = Golden("mcmc_reg_ml_groups")
-    ref = g.z["pred_out"]
-    y = g.test_target.astype(np.float64)
-    p, l = run_chain(g, oracle, seed=3)
-    rmse_ref = np.sqrt(np.mean((ref - y) ** 2))
-    rmse = np.sqrt(np.mean((p - y) ** 2))
-    assert abs(rmse - REF_RMSE_MEAN[g.name]) < 0.035, (rmse, rmse_ref)   # reference over 10 seeds: sd 0.005-0.006; ours: sd 0.008
-    assert np.corrcoef(p, ref)[0, 1] > 0.970                 # reference vs reference on this fixture: 0.980-0.983
-    assert np.sqrt(np.mean((p - ref) ** 2)) < 0.155          # reference vs reference: 0.120-0.130 (ours 0.115-0.133)
+    runs = [run_chain(g, oracle, seed=300 + i) for i in range(N_SEEDS)]
+    check_against_band(g.name, [p for p, _ in runs], g.test_target.astype(np.float64), 0)
+    l = runs[0][1]
     assert l.w_lambda_last.shape == (2,) and l.v_lambda_last.shape == (2, g.k)
     assert abs(l.w_lambda_last[0] - l.w_lambda_last[1]) > 1e-6 * abs(l.w_lambda_last[0])      # the groups got their own draws
 

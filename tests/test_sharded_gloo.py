@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, B, chunk, out_dir):
+def _worker(rank, world, port, B, chunk, shard_hash, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -31,11 +31,11 @@ def _worker(rank, world, port, B, chunk, out_dir):
     tr = g.data(O, "train")
     k, n, KP = g.k, g.n, g.k                                  # k = 32 is already a power of two
     # this rank's shard: its rows of V / w and its view of the rows
-    mine = np.arange(rank, n, world)
+    mine = sh.owned_ids(n, rank, world, shard_hash).astype(np.int64)   # global id of every local row (product code)
     V = m.v[:, mine].T.copy()                                 # [n_local][k]
     w = m.w[mine].copy()
     w0 = m.w0
-    ent, rp = sh.filter_rows(tr.entries, tr.row_ptr, rank, world)
+    ent, rp = sh.filter_rows(tr.entries, tr.row_ptr, rank, world, n, shard_hash)
     rp = rp.astype(np.int64)
     y = tr.target.astype(np.float64)
     lr, (reg0, regw, regv) = g.lr, g.reg
@@ -75,12 +75,12 @@ def _worker(rank, world, port, B, chunk, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B,chunk", [(100, 10), (64, 64)])
-def test_two_feature_shards_equal_the_unsharded_rule(oracle, tmp_path, B, chunk):
+@pytest.mark.parametrize("B,chunk,shard_hash", [(100, 10, 1), (64, 64, 0)])
+def test_two_feature_shards_equal_the_unsharded_rule(oracle, tmp_path, B, chunk, shard_hash):
     import torch.multiprocessing as mp
     from common import Golden
     world, port = 2, 29600 + (os.getpid() % 200)
-    mp.spawn(_worker, args=(world, port, B, chunk, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, B, chunk, shard_hash, str(tmp_path)), nprocs=world, join=True)
     g = Golden("sgd_cls_zipf_k32")
     m = g.model(oracle, "init")
     tr = g.data(oracle, "train")
@@ -93,15 +93,39 @@ def test_two_feature_shards_equal_the_unsharded_rule(oracle, tmp_path, B, chunk)
         np.testing.assert_allclose(float(z["w0"]), m.w0, rtol=1e-9, atol=1e-12)
 
 
-def test_filter_rows_matches_ownership_rule():
+@pytest.mark.parametrize("shard_hash", [0, 1])
+def test_filter_rows_matches_ownership_rule(shard_hash):
     sys.path.insert(0, ROOT)
     from libfm_amd import sharding as sh
     import datagen
     ent, rp, _ = datagen.ragged_real(97, 50, 9, seed=3, empty_every=7)
     total = 0
     for r in range(3):
-        e, p = sh.filter_rows(ent, rp, r, 3)
+        e, p = sh.filter_rows(ent, rp, r, 3, 97, shard_hash)
         assert len(p) == len(rp) and p[-1] == len(e)
         total += len(e)
         assert (e["id"] < sh.n_local(97, r, 3)).all()
     assert total == len(ent)
+
+
+@pytest.mark.parametrize("n,world", [(97, 3), (1000, 8), (65536, 8), (65537, 5), (1, 1), (7, 8), (3_000_001, 8)])
+def test_hashed_ownership_is_a_balanced_bijection(n, world):
+    """the library's hashed rule (fmx_shard_place / fmx_shard_global, include/fmx.h): every feature has one (owner, local
+    row), local rows are dense, the inverse recovers the id, and structured id sets spread over the shards"""
+    sys.path.insert(0, ROOT)
+    from libfm_amd import sharding as sh
+    ids = np.arange(n, dtype=np.uint32)
+    own, loc = sh.place(ids, n, world, 1)
+    assert own.min() >= 0 and own.max() < world
+    key = loc.astype(np.int64) * world + own
+    assert np.array_equal(np.sort(key), np.arange(n))                  # a permutation of [0, n): dense local tables
+    for r in range(world):
+        back = sh.owned_ids(n, r, world, 1)
+        assert len(back) == sh.n_local(n, r, world) == int((own == r).sum())
+        assert np.array_equal(own[back], np.full(len(back), r)) and np.array_equal(loc[back], np.arange(len(back)))
+    if n >= 65536:
+        for stride in (world, 2 * world, 1024):                        # ids of one residue class: all on one shard under mod
+            cnt = np.bincount(own[::stride], minlength=world)
+            assert cnt.max() < 1.25 * cnt.mean() + 8, (stride, cnt)
+    own0, loc0 = sh.place(ids, n, world, 0)                            # the plain rule
+    assert np.array_equal(own0, ids % world) and np.array_equal(loc0, ids // world)
