@@ -23,8 +23,15 @@ template <class Base>
 class fmx_sgd_binding : public Base {
  public:
   int gpu_device;
-  fmx_sgd_binding() : gpu_device(-1), h(NULL) {}
-  virtual ~fmx_sgd_binding() { if (h) fmx_destroy(h); }
+  // several GPUs from this ONE process: the devices of the feature shards (empty = one unsharded handle on gpu_device).
+  // Distinct ordinals -> RCCL over xGMI; the same ordinal repeated -> shards on one device with the library's loopback
+  // exchange (tests, single-GPU boxes).  The model is split by the hashed ownership rule (fmx_config::shard_hash = 1).
+  std::vector<int> gpu_devices;
+  fmx_sgd_binding() : gpu_device(-1), h(NULL), grp(NULL) {}
+  virtual ~fmx_sgd_binding() {
+    if (grp) fmx_group_destroy(grp);
+    for (size_t i = 0; i < hs.size(); i++) fmx_destroy(hs[i]);
+  }
 
   virtual double evaluate(Data& data) {                   // fm_learn::evaluate (fm_learn.h:93-153)
     open();
@@ -34,7 +41,7 @@ class fmx_sgd_binding : public Base {
   virtual void predict(Data& data, DVector<double>& out) {   // fm_learn_sgd::predict (fm_learn_sgd.h:76-90)
     assert(data.data->getNumRows() == out.dim);
     open();
-    check(fmx_predict(h, slot_of(data), out.value));
+    gcheck(fmx_group_predict(grp, slot_of(data), out.value));
     for (uint i = 0; i < out.dim; i++) {
       double p = out(i);
       if (this->task == Base::TASK_REGRESSION) {
@@ -50,26 +57,39 @@ class fmx_sgd_binding : public Base {
   }
 
  protected:
-  fmx_handle h;
+  fmx_handle h;                                            // shard 0 (the only handle without gpu_devices)
+  std::vector<fmx_handle> hs;                              // every shard
+  fmx_group grp;
   std::vector<Data*> slots;
 
   void check(int rc) { if (rc != FMX_OK) throw std::string(fmx_last_error(h)); }
+  void gcheck(int rc) { if (rc != FMX_OK) throw std::string(fmx_group_last_error(grp)); }
 
-  void open() {                                            // once: device context + parameters (fm_model.h:46-48)
+  void open() {                                            // once: device context(s) + parameters (fm_model.h:46-48)
     if (h) return;
     fm_model* fm = this->fm;
-    fmx_config c;
-    c.num_attribute = fm->num_attribute; c.num_factor = fm->num_factor; c.k0 = fm->k0; c.k1 = fm->k1;
-    c.task = this->task; c.reg0 = fm->reg0; c.regw = fm->regw; c.regv = fm->regv; c.learn_rate = this->learn_rate;
-    c.min_target = this->min_target; c.max_target = this->max_target; c.device = gpu_device;
-    c.shard_rank = 0; c.shard_world = 1; c.shard_hash = 0;
-    if (fmx_create(&c, &h) != FMX_OK) throw std::string(fmx_last_error(NULL));
-    check(fmx_set_params(h, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
+    const int world = gpu_devices.empty() ? 1 : (int)gpu_devices.size();
+    for (int r = 0; r < world; r++) {
+      fmx_config c;
+      c.num_attribute = fm->num_attribute; c.num_factor = fm->num_factor; c.k0 = fm->k0; c.k1 = fm->k1;
+      c.task = this->task; c.reg0 = fm->reg0; c.regw = fm->regw; c.regv = fm->regv; c.learn_rate = this->learn_rate;
+      c.min_target = this->min_target; c.max_target = this->max_target;
+      c.device = gpu_devices.empty() ? gpu_device : gpu_devices[r];
+      c.shard_rank = r; c.shard_world = world; c.shard_hash = world > 1 ? 1 : 0;
+      fmx_handle x = NULL;
+      if (fmx_create(&c, &x) != FMX_OK) throw std::string(fmx_last_error(NULL));
+      hs.push_back(x);
+      if (r == 0) h = x;
+      // every shard is handed the FULL block and keeps its own features
+      if (fmx_set_params(x, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL) != FMX_OK) throw std::string(fmx_last_error(x));
+    }
+    if (fmx_group_create(&hs[0], world, &grp) != FMX_OK) throw std::string(fmx_last_error(hs[0]));
   }
 
   void fetch_params() {                                    // main() reads fm afterwards (libfm.cpp:418-434)
     fm_model* fm = this->fm;
-    check(fmx_get_params(h, &fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
+    for (size_t r = 0; r < hs.size(); r++)                 // every shard writes its own features into the host block
+      if (fmx_get_params(hs[r], &fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL) != FMX_OK) throw std::string(fmx_last_error(hs[r]));
   }
 
   int slot_of(Data& d) {                                   // uploads a Data set once (Data.h:49-73)
@@ -86,15 +106,16 @@ class fmx_sgd_binding : public Base {
       ent.insert(ent.end(), r.data, r.data + r.size);
       row_ptr.push_back(ent.size());
     }
-    check(fmx_upload_rows(h, (int)slots.size(), ent.empty() ? NULL : &ent[0], (const uint64_t*)&row_ptr[0],
-                          d.target.value, d.data->getNumRows(), ent.size()));
+    for (size_t r = 0; r < hs.size(); r++)                 // a shard keeps the entries of its own features
+      if (fmx_upload_rows(hs[r], (int)slots.size(), ent.empty() ? NULL : &ent[0], (const uint64_t*)&row_ptr[0],
+                          d.target.value, d.data->getNumRows(), ent.size()) != FMX_OK) throw std::string(fmx_last_error(hs[r]));
     slots.push_back(&d);
     return (int)slots.size() - 1;
   }
 
   double evaluate_slot(int s) {
     fmx_eval ev;
-    check(fmx_evaluate(h, s, &ev));
+    gcheck(fmx_group_evaluate(grp, s, &ev));
     if (this->log != NULL) {                                // same rlog fields as fm_learn.h:124-127,146-150
       if (this->task == Base::TASK_REGRESSION) { this->log->log("rmse", ev.rmse); this->log->log("mae", ev.mae); }
       else { this->log->log("accuracy", ev.accuracy); }
@@ -128,7 +149,7 @@ class fm_learn_sgd_gpu : public fmx_sgd_binding<fm_learn_sgd> {
     opts.w0_chunk = gpu_w0_chunk; opts.flags = gpu_flags; opts.bias_lag = gpu_bias_lag;
     for (int i = 0; i < num_iter; i++) {
       fmx_epoch_stats st;
-      check(fmx_sgd_epoch(h, s_train, &opts, &st));
+      gcheck(fmx_group_sgd_epoch(grp, s_train, &opts, &st));
       double rmse_train = evaluate_slot(s_train);
       double rmse_test = evaluate_slot(s_test);
       std::cout << "#Iter=" << std::setw(3) << i << "\tTrain=" << rmse_train << "\tTest=" << rmse_test << std::endl;

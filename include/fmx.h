@@ -230,8 +230,17 @@ typedef struct fmx_host_rows {
   uint32_t  num_feature;    /* largest id + 1 (Data.h:226-228) */
   uint64_t  nnz;
   float     min_target, max_target;   /* Data.h:205-206 */
+  uint32_t  flags;          /* FMX_HOST_PINNED: the buffers are page-locked (hipHostMalloc) */
+  uint32_t  reserved;
 } fmx_host_rows;
+#define FMX_HOST_PINNED 1u
 int  fmx_read_libsvm(const char *path, fmx_host_rows *out, char *err, size_t err_len);
+/* Data::load, binary branch (src/libfm/src/Data.h:119-178): <prefix>.x + <prefix>.y as written by tools/convert.cpp:137-200
+ * (LargeSparseMatrix::saveToBinaryFile, src/util/fmatrix.h:44-50,121-140; DVector::saveToBinaryFile, matrix.h:344-358), or --
+ * when only the transpose is on disk, which is what als / mcmc runs keep (libfm.cpp:143-147, tools/transpose.cpp) --
+ * <prefix>.xt + <prefix>.y, from which the rows are rebuilt; the older .data / .datat / .target names work too.
+ * With a HIP device present the buffers are page-locked, so fmx_upload_rows moves them by DMA while it checks the ids. */
+int  fmx_read_binary(const char *prefix, fmx_host_rows *out, char *err, size_t err_len);
 void fmx_free_host_rows(fmx_host_rows *rows);
 
 /* ---- fm_model::predict over a data set (fm_model.h:105-127 via fm_learn.h:63-65) -------------- */

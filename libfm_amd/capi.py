@@ -60,7 +60,8 @@ class Relation(C.Structure):
 
 class HostRows(C.Structure):
     _fields_ = [("entries", C.c_void_p), ("row_ptr", C.c_void_p), ("target", C.c_void_p), ("n_rows", C.c_uint32),
-                ("num_feature", C.c_uint32), ("nnz", C.c_uint64), ("min_target", C.c_float), ("max_target", C.c_float)]
+                ("num_feature", C.c_uint32), ("nnz", C.c_uint64), ("min_target", C.c_float), ("max_target", C.c_float),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class AlsOpts(C.Structure):
@@ -99,6 +100,7 @@ SYMBOLS = [
     ("fmx_upload_block_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                         C.POINTER(Relation), C.c_uint32]),
     ("fmx_read_libsvm", C.c_int, [C.c_char_p, C.POINTER(HostRows), C.c_char_p, C.c_size_t]),
+    ("fmx_read_binary", C.c_int, [C.c_char_p, C.POINTER(HostRows), C.c_char_p, C.c_size_t]),
     ("fmx_free_host_rows", None, [C.POINTER(HostRows)]),
     ("fmx_synth_rows", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     ("fmx_free_rows", C.c_int, [H, C.c_int]),

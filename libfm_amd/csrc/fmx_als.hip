@@ -13,6 +13,7 @@ extern "C++" void als_free(fmx_handle h) {
   if (a.seen) hipFree(a.seen);
   if (a.level_list) hipFree(a.level_list);
   if (a.prior) hipFree(a.prior);
+  if (a.vt) hipFree(a.vt);
   a = AlsState();
 }
 
@@ -78,6 +79,10 @@ int fmx_als_begin(fmx_handle h, int train_slot) {
   HIPCHK(h, hipMemcpy(a.seen, seen.data(), seen.size(), hipMemcpyHostToDevice));
   HIPCHK(h, hipMalloc(&a.e, (size_t)N * sizeof(EQ)));
   HIPCHK(h, hipMalloc(&a.q, (size_t)N * (size_t)h->KP * sizeof(double)));
+  if (h->cfg.num_factor > 0 && nseg > 0 && !getenv("FMX_ALS_NO_SHADOW")) {      // (the env switch is the A/B knob of the profile)
+    a.vt_stride = ((size_t)nseg + 63) & ~(size_t)63;
+    HIPCHK(h, hipMalloc(&a.vt, (size_t)h->cfg.num_factor * a.vt_stride * sizeof(float)));
+  }
   // ---- first prediction and e -= target (fm_learn_mcmc_simultaneous.h:69-86)
   rc = als_eterms(h, s, a.e, a.q);
   if (rc) return rc;
@@ -195,11 +200,17 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
       const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
       if (!cnt) continue;
       FMX_ALS_DRAW(false, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                   h->tb.w, h->tb.ws, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
+                   h->tb.w, h->tb.ws, 0, 0u, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
                    opts->seed, (uint64_t)(a.iter * 1024 + 1000));
     }
     hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.w, h->tb.ws, a.prior, a.prior + NG, h->grp,
                        opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 1001));
+  }
+  // the factors of the features with a training column, factor-major for the duration of the sweep (k_als_shadow)
+  const bool shadow = a.vt != nullptr && nseg > 0 && h->cfg.num_factor > 0;
+  if (shadow) {
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_als_shadow<KP, true>), dim3(std::min<uint32_t>((nseg + 63) / 64, 4096)), dim3(256), 0, st,
+                                          a.level_list, s.seg_feat, nseg, h->tb, a.vt, a.vt_stride));
   }
   for (int f = 0; f < h->cfg.num_factor; f++) {            // per factor: q_f is ready (k_als_eterms), draw_v per level :528-595
     double* qf = a.q + (size_t)f * N;
@@ -209,10 +220,19 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
     for (uint32_t l = 0; l < n_levels; l++) {
       const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
       if (!cnt) continue;
-      FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                   h->tb.V + f, h->tb.rs, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
-                   opts->seed, (uint64_t)(a.iter * 1024 + f));
+      if (shadow)
+        FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                     a.vt + (size_t)f * a.vt_stride, 1u, 1, a.level_ptr[l], a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
+                     opts->seed, (uint64_t)(a.iter * 1024 + f));
+      else
+        FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                     h->tb.V + f, h->tb.rs, 0, 0u, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
+                     opts->seed, (uint64_t)(a.iter * 1024 + f));
     }
+  }
+  if (shadow) {
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_als_shadow<KP, false>), dim3(std::min<uint32_t>((nseg + 63) / 64, 4096)), dim3(256), 0, st,
+                                          a.level_list, s.seg_feat, nseg, h->tb, a.vt, a.vt_stride));
   }
   if (h->cfg.num_factor > 0) {                             // empty-row draws of every factor (:586-595) in one pass
     KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_unseen_v<KP>), (h->n_local + Map<KP>::EPI - 1) / Map<KP>::EPI, st, a.seen, h->n_local,

@@ -295,11 +295,52 @@ __device__ __forceinline__ void als_param_store(float* p, float v) {
 #endif
 }
 
+// ---- factor-major shadow of the factors of the features that have a training column ------------------------------
+// A draw touches ONE float of its feature's 4*KP-byte row: 4 useful bytes per 128-byte line, read and written, once per
+// (factor, feature) -- k * 2 line touches per feature and sweep.  Vt[f][pos] (pos = position of the feature's segment in
+// the level-ordered list) holds the same numbers factor-major: the draws of one (factor, level) launch then read and
+// write CONSECUTIVE floats.  k_als_pack / k_als_unpack move a sweep's factors between the two layouts in one coalesced
+// pass each (whole rows in, 64 consecutive positions per factor out, through an LDS tile).
+template <int KP, bool PACK>
+__global__ void __launch_bounds__(256)
+k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict__ seg_feat, uint32_t nseg, const Tab tb,
+             float* __restrict__ vt, size_t vt_stride) {
+  __shared__ float tile[64][KP + 1];                            // [position in block][factor], padded against bank conflicts
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t p0 = blockIdx.x * 64u; p0 < nseg; p0 += gridDim.x * 64u) {
+    const uint32_t np = min(64u, nseg - p0);
+    if (PACK) {
+      for (uint32_t i = tid; i < np * KP; i += 256) {             // rows: KP consecutive floats each (coalesced)
+        const uint32_t r = i / KP, f = i % KP;
+        tile[r][f] = tb.V[(size_t)seg_feat[level_list[p0 + r]] * tb.rs + f];
+      }
+      __syncthreads();
+      for (uint32_t i = tid; i < (uint32_t)KP * 64u; i += 256) {  // per factor 64 consecutive positions
+        const uint32_t f = i / 64u, r = i % 64u;
+        if (r < np) vt[(size_t)f * vt_stride + p0 + r] = tile[r][f];
+      }
+    } else {
+      for (uint32_t i = tid; i < (uint32_t)KP * 64u; i += 256) {
+        const uint32_t f = i / 64u, r = i % 64u;
+        if (r < np) tile[r][f] = vt[(size_t)f * vt_stride + p0 + r];
+      }
+      __syncthreads();
+      for (uint32_t i = tid; i < np * KP; i += 256) {
+        const uint32_t r = i / KP, f = i % KP;
+        tb.V[(size_t)seg_feat[level_list[p0 + r]] * tb.rs + f] = tile[r][f];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// param_by_pos: the coordinate of list entry li lives at param[(pos0 + li) * pstride] (the factor-major shadow) instead of
+// param[feature * pstride] (the table itself)
 template <bool IS_V, int G>
 __global__ void __launch_bounds__(256)
 k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
            uint32_t nseg_total, uint32_t nnz, const uint32_t* __restrict__ seg_list, uint32_t n_list,
-           float* __restrict__ param, uint32_t pstride, EQ* __restrict__ eq,
+           float* __restrict__ param, uint32_t pstride, int param_by_pos, uint32_t pos0, EQ* __restrict__ eq,
            double alpha, const double* __restrict__ lambda_g, const double* __restrict__ mu_g, const uint32_t* __restrict__ attr_group,
            int do_sample, uint64_t seed, uint64_t stream) {
   constexpr uint32_t GPW = 64 / G;                      // feature groups per wavefront
@@ -316,8 +357,8 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
     const double lambda = lambda_g[g], mu = mu_g[g];
     const uint32_t a = seg_rel[s];
     const uint32_t b = have ? ((s + 1 < nseg_total) ? seg_rel[s + 1] : nnz) : a;
-    float* pt = param + (size_t)j * pstride;
-    const double th = (double)als_param_load(pt);
+    float* pt = param + (size_t)(param_by_pos ? pos0 + (have ? li : n_list - 1) : j) * pstride;
+    const double th = (double)(param_by_pos ? *pt : als_param_load(pt));
     double t_he = 0.0, t_hh = 0.0;
     for (uint32_t i = a + lane; i < b; i += G) {
       const TEntry te = als_stream8(t_ent + i);
@@ -340,7 +381,7 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
     if (isnan(nt) || isinf(nt)) continue;                          // keep the old value, caches untouched
     const float ntf = (float)nt;
     const double d = th - (double)ntf;                             // theta_old - theta (of the STORED value)
-    if (lane == 0) als_param_store(pt, ntf);
+    if (lane == 0) { if (param_by_pos) *pt = ntf; else als_param_store(pt, ntf); }
     if (d != 0.0) {
       // update e (and q): one lane per (row, run of occurrences).  A row holding this feature more than once has its
       // occurrences adjacent (the sort is stable in row order); the first one walks the run sequentially exactly

@@ -55,6 +55,8 @@ struct AlsState {
   uint32_t* level_list = nullptr; // segments ordered by level
   std::vector<uint32_t> level_ptr;
   uint64_t  iter = 0;
+  float*    vt = nullptr;         // [num_factor][vt_stride] factor-major shadow of the seen features' factors, level order
+  size_t    vt_stride = 0;
   double*   prior = nullptr;      // [1 + k][2][G]: per coordinate family (row 0 = w, 1+f = v_f) lambda[G] then mu[G]
   std::vector<double> prior_host;
 };

@@ -6,6 +6,8 @@
 #include "../../include/fmx.h"
 #pragma GCC visibility pop
 
+#include <hip/hip_runtime_api.h>          // hipHostMalloc for the binary reader's pinned staging buffers (no kernels here)
+
 #include <algorithm>
 #include <cctype>
 #include <cerrno>
@@ -54,8 +56,129 @@ extern "C" {
 
 void fmx_free_host_rows(fmx_host_rows* r) {
   if (!r) return;
-  free(r->entries); free(r->row_ptr); free(r->target);
+  if (r->flags & FMX_HOST_PINNED) { if (r->entries) hipHostFree(r->entries); if (r->row_ptr) hipHostFree(r->row_ptr); if (r->target) hipHostFree(r->target); }
+  else { free(r->entries); free(r->row_ptr); free(r->target); }
   memset(r, 0, sizeof(*r));
+}
+
+}  // extern "C"
+
+// ---- Data::load, binary branch (src/libfm/src/Data.h:119-178) ---------------------------------------------------------
+// <prefix>.x   LargeSparseMatrix::saveToBinaryFile (src/util/fmatrix.h:44-50 header, :121-140 body): file_header
+//              {uint id = 2; uint float_size = 4; uint64 num_values; uint num_rows; uint num_cols} then per row
+//              {uint size; sparse_entry<float>[size]}  -- written by tools/convert.cpp:137-200
+// <prefix>.xt  the transposed matrix in the same format (tools/transpose.cpp; what als / mcmc read, libfm.cpp:143-147)
+// <prefix>.y   DVector<float>::saveToBinaryFile (src/util/matrix.h:344-358): {uint 1; uint 4; uint dim} + floats
+// (and the older names .data / .datat / .target, Data.h:120-121).  The rows land in page-locked host memory when a HIP
+// device is present, so fmx_upload_rows moves them by DMA at PCIe speed while it validates the ids.
+namespace {
+struct XHeader { uint32_t id, float_size; uint64_t num_values; uint32_t num_rows, num_cols; };
+static_assert(sizeof(XHeader) == 24, "file_header layout (fmatrix.h:44-50)");
+
+struct HostBuf {                       // page-locked when possible
+  bool pinned = false;
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    if (pinned && hipHostMalloc(&p, std::max<size_t>(bytes, 8), hipHostMallocDefault) == hipSuccess) return p;
+    if (pinned) { (void)hipGetLastError(); return nullptr; }
+    return malloc(std::max<size_t>(bytes, 8));
+  }
+};
+
+bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
+
+// reads one matrix file into (entries, row_ptr); returns "" or the error text
+std::string read_matrix(const std::string& path, HostBuf& hb, Entry** ent_out, uint64_t** ptr_out, XHeader* hdr_out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return "could not open " + path;                                            // fmatrix.h:197
+  XHeader h;
+  if (fread(&h, sizeof(h), 1, f) != 1) { fclose(f); return path + ": truncated header"; }
+  if (h.id != 2 || h.float_size != 4) { fclose(f); return path + ": not a libFM binary matrix (file id / float size; fmatrix.h:188-189)"; }
+  Entry* ent = (Entry*)hb.alloc(h.num_values * sizeof(Entry));
+  uint64_t* ptr = (uint64_t*)hb.alloc(((size_t)h.num_rows + 1) * sizeof(uint64_t));
+  if (!ent || !ptr) { fclose(f); return path + ": out of (page-locked) memory"; }
+  *ent_out = ent; *ptr_out = ptr;                                                    // owned by the caller from here on
+  uint64_t pos = 0;
+  ptr[0] = 0;
+  for (uint32_t r = 0; r < h.num_rows; r++) {
+    uint32_t size;
+    if (fread(&size, 4, 1, f) != 1) { fclose(f); return path + ": truncated (row sizes)"; }
+    if (pos + size > h.num_values) { fclose(f); return path + ": more entries than its header announces"; }
+    if (size && fread(ent + pos, sizeof(Entry), size, f) != size) { fclose(f); return path + ": truncated (row entries)"; }
+    pos += size;
+    ptr[r + 1] = pos;
+  }
+  fclose(f);
+  if (pos != h.num_values) return path + ": fewer entries than its header announces";
+  *hdr_out = h;
+  return "";
+}
+}  // namespace
+
+extern "C" {
+
+int fmx_read_binary(const char* prefix, fmx_host_rows* out, char* err, size_t err_len) {
+  if (!prefix || !out) return io_fail(err, err_len, FMX_E_ARG, "fmx_read_binary: null argument");
+  memset(out, 0, sizeof(*out));
+  const std::string p(prefix);
+  std::string fx, fxt, fy;
+  if (file_exists(p + ".target") && (file_exists(p + ".data") || file_exists(p + ".datat"))) {       // Data.h:120-121
+    fy = p + ".target"; if (file_exists(p + ".data")) fx = p + ".data"; else fxt = p + ".datat";
+  } else if (file_exists(p + ".y") && (file_exists(p + ".x") || file_exists(p + ".xt"))) {          // Data.h:122-123
+    fy = p + ".y"; if (file_exists(p + ".x")) fx = p + ".x"; else fxt = p + ".xt";
+  } else {
+    return io_fail(err, err_len, FMX_E_ARG, "fmx_read_binary: neither " + p + ".x/.xt + .y nor " + p + ".data/.datat + .target exist");
+  }
+  HostBuf hb;
+  int ndev = 0;
+  hb.pinned = (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0);
+  if (!hb.pinned) (void)hipGetLastError();
+  out->flags = hb.pinned ? FMX_HOST_PINNED : 0u;
+  // ---- targets
+  FILE* f = fopen(fy.c_str(), "rb");
+  if (!f) return io_fail(err, err_len, FMX_E_ARG, "could not open " + fy);
+  uint32_t yh[3];
+  if (fread(yh, 4, 3, f) != 3 || yh[0] != 1 || yh[1] != 4) { fclose(f); return io_fail(err, err_len, FMX_E_ARG, fy + ": not a libFM binary float vector (matrix.h:360-380)"); }
+  const uint32_t n_rows = yh[2];
+  out->target = (float*)hb.alloc((size_t)n_rows * sizeof(float));
+  if (!out->target || (n_rows && fread(out->target, 4, n_rows, f) != n_rows)) { fclose(f); fmx_free_host_rows(out); return io_fail(err, err_len, FMX_E_ARG, fy + ": truncated or out of memory"); }
+  fclose(f);
+  // ---- design matrix
+  XHeader h;
+  Entry* ent = nullptr; uint64_t* ptr = nullptr;
+  const std::string msg = read_matrix(fx.empty() ? fxt : fx, hb, &ent, &ptr, &h);
+  out->entries = ent; out->row_ptr = ptr;
+  if (!msg.empty()) { fmx_free_host_rows(out); return io_fail(err, err_len, FMX_E_ARG, msg); }
+  if (!fx.empty()) {
+    if (h.num_rows != n_rows) { fmx_free_host_rows(out); return io_fail(err, err_len, FMX_E_ARG, fx + ": row count differs from " + fy + " (Data.h:144)"); }
+    out->num_feature = h.num_cols;                                                    // Data.h:145
+  } else {
+    // only X^T on disk (the als / mcmc input, libfm.cpp:143-147): rebuild the rows.  Column c of X^T lists {row, value} in
+    // ascending row order, so one counting pass + one scatter gives every row with ascending feature ids.
+    if (h.num_cols != n_rows) { fmx_free_host_rows(out); return io_fail(err, err_len, FMX_E_ARG, fxt + ": column count differs from " + fy); }
+    Entry* x = (Entry*)hb.alloc(h.num_values * sizeof(Entry));
+    uint64_t* xp = (uint64_t*)hb.alloc(((size_t)n_rows + 1) * sizeof(uint64_t));
+    bool ok = x && xp;
+    if (ok) {
+      memset(xp, 0, ((size_t)n_rows + 1) * sizeof(uint64_t));
+      for (uint64_t i = 0; i < h.num_values && ok; i++) { if (ent[i].id >= n_rows) ok = false; else xp[ent[i].id + 1]++; }
+    }
+    if (ok) {
+      for (uint32_t r = 0; r < n_rows; r++) xp[r + 1] += xp[r];
+      std::vector<uint64_t> fill(xp, xp + n_rows);
+      for (uint32_t j = 0; j < h.num_rows; j++)
+        for (uint64_t i = ptr[j]; i < ptr[j + 1]; i++) { Entry e; e.id = j; e.value = ent[i].value; x[fill[ent[i].id]++] = e; }
+    }
+    if (hb.pinned) { hipHostFree(ent); hipHostFree(ptr); } else { free(ent); free(ptr); }
+    out->entries = x; out->row_ptr = xp;
+    if (!ok) { fmx_free_host_rows(out); return io_fail(err, err_len, FMX_E_ARG, fxt + ": a row id exceeds the number of cases, or out of memory"); }
+    out->num_feature = h.num_rows;                                                    // Data.h:157
+  }
+  out->n_rows = n_rows; out->nnz = h.num_values;
+  float min_t = std::numeric_limits<float>::max(), max_t = -std::numeric_limits<float>::max();     // Data.h:166-171
+  for (uint32_t r = 0; r < n_rows; r++) { min_t = std::min(min_t, out->target[r]); max_t = std::max(max_t, out->target[r]); }
+  out->min_target = n_rows ? min_t : 0.f; out->max_target = n_rows ? max_t : 0.f;
+  return FMX_OK;
 }
 
 int fmx_read_libsvm(const char* path, fmx_host_rows* out, char* err, size_t err_len) {

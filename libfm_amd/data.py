@@ -41,6 +41,30 @@ def read_libsvm(path):
     return ent, row_ptr, y
 
 
+def _host_rows_to_numpy(lib, rows):
+    import ctypes as C
+    try:
+        ent = np.ctypeslib.as_array(C.cast(rows.entries, C.POINTER(C.c_uint64)), (max(rows.nnz, 1),))[:rows.nnz].view(ENTRY_DTYPE).copy()
+        row_ptr = np.ctypeslib.as_array(C.cast(rows.row_ptr, C.POINTER(C.c_uint64)), (rows.n_rows + 1,)).copy()
+        y = np.ctypeslib.as_array(C.cast(rows.target, C.POINTER(C.c_float)), (max(rows.n_rows, 1),))[:rows.n_rows].copy()
+        return ent, row_ptr, y, int(rows.num_feature)
+    finally:
+        lib.fmx_free_host_rows(C.byref(rows))
+
+
+def read_binary(prefix):
+    """Data::load's binary branch through the C-ABI (fmx_read_binary): <prefix>.x + .y, or <prefix>.xt + .y (the rows are
+    rebuilt from the transpose), or the older .data / .datat / .target.  Returns (entries, row_ptr, target, num_feature)."""
+    import ctypes as C
+    from . import capi
+    lib = capi.load()
+    rows, err = capi.HostRows(), C.create_string_buffer(512)
+    rc = lib.fmx_read_binary(os.fsencode(prefix), C.byref(rows), err, len(err))
+    if rc != capi.FMX_OK:
+        raise ValueError(err.value.decode(errors="replace"))
+    return _host_rows_to_numpy(lib, rows)
+
+
 def read_libsvm_py(path):
     """the same format in pure Python (slow; kept as an independent cross-check of the native reader in the tests)"""
     ids, vals, sizes, ys = [], [], [], []
@@ -184,7 +208,7 @@ def write_binary(prefix, entries, row_ptr, target, num_cols=None):
 
 def load(name):
     """Data::load auto-detection (Data.h:113-125): binary <name>.x/.y if present, else libsvm text <name>."""
-    if os.path.exists(name + ".x") and os.path.exists(name + ".y"):
-        ent, row_ptr, _ = read_binary_x(name + ".x")
-        return ent, row_ptr, read_binary_y(name + ".y")
+    if os.path.exists(name + ".y") and (os.path.exists(name + ".x") or os.path.exists(name + ".xt")):
+        ent, row_ptr, y, _ = read_binary(name)                       # native reader of the C-ABI
+        return ent, row_ptr, y
     return read_libsvm(name)

@@ -11,7 +11,9 @@
 // usage:
 //   ref_harness sgd  <train> <test> <task r|c> <k0> <k1> <k> <iters> <lr> <reg0> <regw> <regv> <init_stdev> <seed> <out_prefix>
 //   ref_harness sgd_gpu <same arguments as sgd> [mode 0|1|2] [batch] [w0_chunk]
-//                    (same driver, but the learner is adapter/fm_learn_sgd_gpu.h -> libfmx.so; needs a GPU)
+//                    (same driver, but the learner is adapter/fm_learn_sgd_gpu.h -> libfmx.so; needs a GPU;
+//                     env FMX_GPU_DEVICES="0,0" | "0,1,..": one feature shard per listed device, FMX_GPU_APPLY / FMX_GPU_FLAGS /
+//                     FMX_GPU_BIAS_LAG: fmx_sgd_opts fields)
 //   ref_harness sgda <same arguments as sgd> <validation>   (fm_learn_sgd_element_adapt_reg; also dumps .reg.txt: reg_w, reg_v[f])
 //   ref_harness sgda_gpu <same arguments as sgda>           (the learner is fm_learn_sgda_gpu of adapter/fm_learn_sgd_gpu.h; needs a GPU)
 //   ref_harness mcmc_gpu <same arguments as mcmc>           (Gibbs sampling through adapter/fm_learn_mcmc_gpu.h; needs a GPU)
@@ -204,6 +206,12 @@ int main(int argc, char** argv) {
       if (argc > a) fml->gpu_mode = atoi(argv[a++]);
       if (argc > a) fml->gpu_batch = atoi(argv[a++]);
       if (argc > a) fml->gpu_w0_chunk = atoi(argv[a++]);
+      if (const char* dv = getenv("FMX_GPU_DEVICES")) {      // e.g. "0,1,2,3" (RCCL) or "0,0" (two shards on one device)
+        for (const char* p = dv; *p;) { fml->gpu_devices.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p) p++; }
+      }
+      if (const char* e = getenv("FMX_GPU_APPLY")) fml->gpu_apply = atoi(e);
+      if (const char* e = getenv("FMX_GPU_FLAGS")) fml->gpu_flags = (uint)atoi(e);
+      if (const char* e = getenv("FMX_GPU_BIAS_LAG")) fml->gpu_bias_lag = (uint)atoi(e);
       fml->num_iter = iters;
       fml->fm = &fm; fml->max_target = train.max_target; fml->min_target = train.min_target; fml->meta = &meta;
       set_task(fml, task, train, test);

@@ -79,6 +79,72 @@ def test_reads_what_the_reference_convert_tool_writes(tmp_path, oracle):
     assert open(pre + ".y", "rb").read() == open(str(tmp_path / "w") + ".y", "rb").read()
 
 
+def test_binary_reader_of_the_c_abi(tmp_path, oracle):
+    """fmx_read_binary (C-ABI, host side): .x + .y; only .xt + .y (rows rebuilt from the transpose); the legacy names;
+    ragged rows with empty ones; and the files it must refuse."""
+    from libfm_amd import data as D
+    ent, rp, y = datagen.ragged_real(120, 300, 9, seed=4, empty_every=7)
+    pre = str(tmp_path / "r")
+    D.write_binary(pre, ent, rp, y, num_cols=120)
+    e2, r2, y2, nf = D.read_binary(pre)
+    assert np.array_equal(e2, ent) and np.array_equal(r2, rp) and np.array_equal(y2, y) and nf == 120
+    assert np.array_equal(D.read_binary_x(pre + ".x")[0], e2)                       # the numpy reader agrees
+    # transpose only: what an als / mcmc run keeps on disk (libfm.cpp:143-147)
+    t_ent, t_ptr = D.transpose(ent, rp, 120)
+    pt = str(tmp_path / "t")
+    D.write_binary_matrix(pt + ".xt", t_ent, t_ptr, num_cols=len(rp) - 1)
+    os.link(pre + ".y", pt + ".y")
+    e3, r3, y3, nf3 = D.read_binary(pt)
+    assert np.array_equal(r3, rp) and np.array_equal(y3, y) and nf3 == 120
+    for r in range(len(rp) - 1):                                                    # same rows, entries in ascending id order
+        a, b = int(rp[r]), int(rp[r + 1])
+        order = np.argsort(ent["id"][a:b], kind="stable")
+        assert np.array_equal(e3[a:b], ent[a:b][order])
+    # legacy names (Data.h:120-121)
+    pl = str(tmp_path / "legacy")
+    os.link(pre + ".x", pl + ".data"); os.link(pre + ".y", pl + ".target")
+    assert np.array_equal(D.read_binary(pl)[0], ent)
+    # refusals
+    with pytest.raises(ValueError, match="neither"):
+        D.read_binary(str(tmp_path / "missing"))
+    bad = str(tmp_path / "bad")
+    raw = bytearray(open(pre + ".x", "rb").read())
+    raw[0] = 9                                                                       # wrong file id (fmatrix.h:188)
+    open(bad + ".x", "wb").write(raw); os.link(pre + ".y", bad + ".y")
+    with pytest.raises(ValueError, match="not a libFM binary matrix"):
+        D.read_binary(bad)
+    trunc = str(tmp_path / "trunc")
+    open(trunc + ".x", "wb").write(open(pre + ".x", "rb").read()[:-5]); os.link(pre + ".y", trunc + ".y")
+    with pytest.raises(ValueError, match="truncated"):
+        D.read_binary(trunc)
+    short = str(tmp_path / "short")
+    os.link(pre + ".x", short + ".x")
+    open(short + ".y", "wb").write(np.array([1, 4, 5], dtype="<u4").tobytes() + np.zeros(5, dtype="<f4").tobytes())
+    with pytest.raises(ValueError, match="row count differs"):
+        D.read_binary(short)
+
+
+TRANSPOSE = os.path.join(ROOT, "oracle", "_ref", "transpose")
+
+
+@pytest.mark.skipif(not (os.path.exists(CONVERT) and os.path.exists(TRANSPOSE)), reason="oracle/_ref/convert / transpose not built (needs /root/reference)")
+def test_binary_reader_on_the_reference_tools_output(tmp_path, oracle):
+    """convert + transpose of the REFERENCE write the files; fmx_read_binary reads .x and, alone, .xt"""
+    from libfm_amd import data as D
+    ent, rp, y = datagen.movielens_shaped(60, 45, 400, seed=6)
+    txt = str(tmp_path / "d.libfm")
+    oracle.Data(ent, rp, y).write_libsvm(txt)
+    pre = str(tmp_path / "d")
+    subprocess.run([CONVERT, "--ifile", txt, "--ofilex", pre + ".x", "--ofiley", pre + ".y"], check=True, capture_output=True)
+    subprocess.run([TRANSPOSE, "--ifile", pre + ".x", "--ofile", pre + ".xt"], check=True, capture_output=True)
+    e2, r2, y2, nf = D.read_binary(pre)
+    assert np.array_equal(e2, ent) and np.array_equal(r2, rp) and np.array_equal(y2, y) and nf == int(ent["id"].max()) + 1
+    only_t = str(tmp_path / "t")
+    os.link(pre + ".xt", only_t + ".xt"); os.link(pre + ".y", only_t + ".y")
+    e3, r3, y3, nf3 = D.read_binary(only_t)
+    assert np.array_equal(e3, ent) and np.array_equal(r3, rp) and nf3 == nf       # these rows already have ascending ids
+
+
 LIBFM = os.path.join(ROOT, "oracle", "_ref", "libFM")
 
 
