@@ -114,14 +114,77 @@ def committed_traffic(kernel, examples_per_launch, k, nnz):
     return None, None
 
 
+def als_bytes_per_sweep(n_rows, nnz_total, n_seen, k):
+    """algorithmic bytes of one fm_learn_mcmc sweep as the device runs it: per coordinate family
+    (w and each of the k factors) the column pass touches every entry twice (8-B entry + 16-B {e,q} gather for the sums,
+    the same + a 16-B store for the update) = 64 B per entry, + 8 B per feature (read + write of the coordinate);
+    per factor one pass that installs q_f next to e (8 + 16 + 16 B per row); the re-prediction reads every entry with its
+    parameter row (8 + 4k + 4 B) and writes k q values + e per row (8k + 16 B); the target pass 36 B per row."""
+    fam = (k + 1) * (nnz_total * 64 + n_seen * 8)
+    loadq = k * n_rows * 40
+    eterms = nnz_total * (4 * k + 12) + n_rows * (8 * k + 16)
+    return fam + loadq + eterms + n_rows * 36
+
+
+def bench_als(args, capi):
+    """--method als | mcmc: one step = one sweep (fmx_als_sweep) over `--rows` examples, one GPU"""
+    import torch
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--method als/mcmc: one GPU (feature shards of the sweep go through fmx_group_*, see tests/test_gpu_group.py)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    sample = args.method == "mcmc"
+    h = capi.Handle(args.n, args.k, True, True, capi.TASK_REGRESSION, 0.0, 1.0, 10.0, 0.0, -1.0, 1.0, device=0)
+    h.init_params(0.0, 0.01, 1)
+    h.synth_rows(0, 123, 0, args.rows, args.nnz)
+    info = h.info()
+    h.als_begin(0)
+    for i in range(args.warmup):
+        h.als_sweep(1.0, 10.0, do_sample=sample, seed=i)
+    h.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev = 0.0
+    for i in range(args.steps):
+        st = h.als_sweep(1.0, 10.0, do_sample=sample, seed=100 + i)
+        dev += st.device_seconds
+    h.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    nnz_total = args.rows * args.nnz
+    n_seen = min(args.n, nnz_total)
+    per_sweep = als_bytes_per_sweep(args.rows, nnz_total, n_seen, args.k)
+    achieved = per_sweep / (dev / args.steps) / 1e9
+    out = {"metric": "%s (fm_learn_mcmc%s) training examples/sec per sweep at k=%d, nnz=%d, %.0e feat"
+                     % (args.method.upper(), ", do_sample" if sample else "", args.k, args.nnz, args.n),
+           "value": round(args.steps * args.rows / elapsed, 1), "unit": "examples/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64 caches / f32 parameters", "data": "synthetic",
+           "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/sweep, task=r, lambda_w=1 lambda_v=10"
+                                  % (args.n, args.k, args.nnz, args.rows),
+                      "method": args.method, "levels": st.levels, "device": info.device_name.decode(), "arch": info.arch.decode()},
+           "roofline": {"bound": "hbm", "kernel": "k_als_draw<v> (85 % of the sweep) + re-prediction; whole sweep",
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "bytes_per_sweep": per_sweep, "avg_sweep_ms": round(dev / args.steps * 1e3, 3),
+                        "note": "the column passes are random 16-byte read-modify-writes of the {e,q} cache: every one moves a whole "
+                                "128-byte line, so the fabric traffic is several times the algorithmic bytes (DESIGN.md section 4b)"},
+           "cpu_baseline": None}
+    h.als_end()
+    h.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--features", dest="n", type=int, default=100_000_000, help="number of features n")
+    ap.add_argument("--method", default="sgd", choices=["sgd", "als", "mcmc"],
+                    help="sgd: the BASELINE metric (default).  als / mcmc: one step = one sweep of fm_learn_mcmc over the rows "
+                         "(BASELINE configs[3] / [4] shapes: n=1e7, k=64, 16 nnz/row unless overridden; one GPU)")
+    ap.add_argument("--features", dest="n", type=int, default=None, help="number of features n (sgd: 1e8, als/mcmc: 1e7)")
     ap.add_argument("--factors", dest="k", type=int, default=64, help="number of factors k")
-    ap.add_argument("--nnz", type=int, default=32)
+    ap.add_argument("--nnz", type=int, default=None, help="entries per row (sgd: 32, als/mcmc: 16)")
     ap.add_argument("--rows", type=int, default=1 << 22, help="examples per step")
     ap.add_argument("--mode", default="auto", choices=["auto", "fused", "minibatch", "hogwild"],
                     help="auto: the minibatch rule everywhere -- `fused` (FMX_APPLY_FUSED, one pass) on one GPU, the split step "
@@ -148,9 +211,16 @@ def main():
                     help="skip timing the REAL reference code (oracle/_ref/ref_harness time_sgd, largest n it can allocate)")
     args = ap.parse_args()
 
+    if args.n is None:
+        args.n = 100_000_000 if args.method == "sgd" else 10_000_000
+    if args.nnz is None:
+        args.nnz = 32 if args.method == "sgd" else 16
+
     import torch
     import torch.distributed as dist
     from libfm_amd import capi
+    if args.method != "sgd":
+        return bench_als(args, capi)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

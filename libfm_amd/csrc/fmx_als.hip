@@ -32,7 +32,13 @@ static int als_eterms(fmx_handle h, const Slot& s, EQ* e, double* q) {
   return FMX_OK;
 }
 
+static int als_begin_impl(fmx_handle h, int train_slot);
 int fmx_als_begin(fmx_handle h, int train_slot) {
+  const int rc = als_begin_impl(h, train_slot);
+  if (rc != FMX_OK && h && h->als.slot == train_slot) als_free(h);      // a failed set-up leaves no half-built session behind
+  return rc;
+}
+static int als_begin_impl(fmx_handle h, int train_slot) {
   int rc = check_slot(h, train_slot, true);
   if (rc) return rc;
   { int _rc = lag_flush(h); if (_rc) return _rc; }

@@ -102,6 +102,8 @@ void free_segments(Slot& s) {
   if (s.seg_rel) hipFree(s.seg_rel);
   if (s.cmask) hipFree(s.cmask);
   if (s.cseg) hipFree(s.cseg);
+  if (s.order) hipFree(s.order);
+  s.order = nullptr; s.n_indep.clear();
   s.t_ent = nullptr; s.seg_feat = nullptr; s.seg_rel = nullptr; s.seg_B = 0; s.nseg = 0;
   s.cmask = nullptr; s.cseg = nullptr; s.ncseg = 0; s.fused_cap = 0;
   s.batch_seg.clear(); s.batch_base.clear(); s.cbatch.clear();
@@ -240,6 +242,7 @@ int fmx_destroy(fmx_handle h) {
   if (h->partial) hipFree(h->partial);
   if (h->mult) hipFree(h->mult);
   if (h->rest) hipFree(h->rest);
+  if (h->fused_ctr) hipFree(h->fused_ctr);
   for (auto ev : h->ev_pool) hipEventDestroy(ev);
   for (auto ev : h->ev_sync) hipEventDestroy(ev);
   if (h->lag.ev_rest) hipEventDestroy(h->lag.ev_rest);
@@ -455,10 +458,22 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
   const uint64_t* up_ptr = row_ptr;
   uint64_t up_nnz = nnz;
   uint32_t max_row = 0;
+  // unsharded: the entries go to the device as they are -- start the transfer now (DMA at PCIe speed when the buffer is
+  // page-locked, e.g. from fmx_read_binary) and check the ids on the host while it runs
+  Slot s;
+  if (W == 1) {
+    HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(nnz, 1) * sizeof(Entry)));
+    if (nnz && hipMemcpyAsync(s.ent, src, nnz * sizeof(Entry), hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+      hipFree(s.ent); return fail(h, FMX_E_HIP, "fmx_upload_rows: copy of the entries failed");
+    }
+  }
   // bound check: the reference asserts id < num_attribute (fm_model.h:112)
   for (uint64_t i = 0; i < nnz; i++)
-    if (src[i].id >= n) return fail(h, FMX_E_ARG, "feature id %u >= num_attribute %llu (row entry %llu)", src[i].id,
-                                    (unsigned long long)n, (unsigned long long)i);
+    if (src[i].id >= n) {
+      if (s.ent) { hipStreamSynchronize(h->stream); hipFree(s.ent); }
+      return fail(h, FMX_E_ARG, "feature id %u >= num_attribute %llu (row entry %llu)", src[i].id,
+                  (unsigned long long)n, (unsigned long long)i);
+    }
   if (W > 1) {   // keep this shard's features, ids become local rows (Shard::place)
     local_ptr.resize((size_t)n_rows + 1);
     local_ent.reserve((size_t)(nnz / W + n_rows));
@@ -471,15 +486,19 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
     up_ent = local_ent.data(); up_ptr = local_ptr.data(); up_nnz = local_ent.size();
   }
   for (uint32_t r = 0; r < n_rows; r++) max_row = std::max<uint32_t>(max_row, (uint32_t)(up_ptr[r + 1] - up_ptr[r]));
-  Slot s;
-  HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(up_nnz, 1) * sizeof(Entry)));
-  HIPCHK(h, hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
-  if (up_nnz) HIPCHK(h, hipMemcpy(s.ent, up_ent, up_nnz * sizeof(Entry), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(s.row_ptr, up_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-  if (target) {
-    HIPCHK(h, hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float)));
-    if (n_rows) HIPCHK(h, hipMemcpy(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice));
+  hipError_t er = hipSuccess;
+  if (!s.ent) {
+    er = hipMalloc(&s.ent, std::max<uint64_t>(up_nnz, 1) * sizeof(Entry));
+    if (er == hipSuccess && up_nnz) er = hipMemcpyAsync(s.ent, up_ent, up_nnz * sizeof(Entry), hipMemcpyHostToDevice, h->stream);
   }
+  if (er == hipSuccess) er = hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t));
+  if (er == hipSuccess) er = hipMemcpyAsync(s.row_ptr, up_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
+  if (er == hipSuccess && target) {
+    er = hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float));
+    if (er == hipSuccess && n_rows) er = hipMemcpyAsync(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice, h->stream);
+  }
+  if (hipStreamSynchronize(h->stream) != hipSuccess && er == hipSuccess) er = hipGetLastError();   // the host buffers may go away after return
+  if (er != hipSuccess) { free_slot(s); return fail(h, FMX_E_HIP, "fmx_upload_rows: %s", hipGetErrorString(er)); }
   s.n_rows = n_rows; s.nnz = up_nnz; s.max_row = max_row; s.used = true;
   h->slots[slot] = s;
   return FMX_OK;
@@ -611,30 +630,35 @@ int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_
   const Shard sh = make_shard(h->cfg);
   Slot s;
   uint32_t* cnt = nullptr;
-  HIPCHK(h, hipMalloc(&cnt, ((size_t)n_rows + 1) * sizeof(uint32_t)));
-  HIPCHK(h, hipMemsetAsync(cnt, 0, ((size_t)n_rows + 1) * sizeof(uint32_t), h->stream));
-  HIPCHK(h, hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
-  HIPCHK(h, hipMalloc(&s.target, (size_t)n_rows * sizeof(float)));
+  void* tmp = nullptr;
+  uint64_t total = 0;
+  // every error path releases what was allocated so far
+#define SYN_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { if (cnt) hipFree(cnt); if (tmp) hipFree(tmp); free_slot(s); \
+    return fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+  SYN_CHK(hipMalloc(&cnt, ((size_t)n_rows + 1) * sizeof(uint32_t)));
+  SYN_CHK(hipMemsetAsync(cnt, 0, ((size_t)n_rows + 1) * sizeof(uint32_t), h->stream));
+  SYN_CHK(hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  SYN_CHK(hipMalloc(&s.target, (size_t)n_rows * sizeof(float)));
   const dim3 grid((n_rows + 255) / 256), block(256);
   hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, sh, cnt,
                      (const uint64_t*)nullptr, (Entry*)nullptr, s.target);
-  HIPCHK(h, hipGetLastError());
+  SYN_CHK(hipGetLastError());
   {  // exclusive prefix sum u32 -> u64 over n_rows+1 items (last = total)
-    void* tmp = nullptr; size_t tmp_bytes = 0;
+    size_t tmp_bytes = 0;
     auto conv = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, uint32_t*>(cnt, hipcub::CastOp<uint64_t>());
-    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
-    HIPCHK(h, hipMalloc(&tmp, tmp_bytes));
-    HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    hipFree(tmp);
+    SYN_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
+    SYN_CHK(hipMalloc(&tmp, tmp_bytes));
+    SYN_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
+    SYN_CHK(hipStreamSynchronize(h->stream));
+    hipFree(tmp); tmp = nullptr;
   }
-  uint64_t total = 0;
-  HIPCHK(h, hipMemcpy(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
+  SYN_CHK(hipMemcpy(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  SYN_CHK(hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
   hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, sh, (uint32_t*)nullptr,
                      (const uint64_t*)s.row_ptr, s.ent, (float*)nullptr);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  SYN_CHK(hipGetLastError());
+  SYN_CHK(hipStreamSynchronize(h->stream));
+#undef SYN_CHK
   hipFree(cnt);
   s.n_rows = n_rows; s.nnz = total; s.max_row = nnz; s.used = true;
   h->slots[slot] = s;

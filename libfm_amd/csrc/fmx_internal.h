@@ -45,6 +45,8 @@ struct Slot {
   uint32_t  ncseg = 0;
   uint32_t  fused_cap = 0;           // longest row the k_fused instance of this slot keeps in registers
   std::vector<uint32_t> cbatch;      // [n_batches+1] first cseg entry of every batch
+  uint32_t* order = nullptr;         // [n_rows] per batch: example order with the examples that touch a deferred feature of
+  std::vector<uint32_t> n_indep;     //          the PREVIOUS batch last; n_indep[b] = how many do not (FusedPrev)
 };
 
 struct AlsState {
@@ -100,6 +102,8 @@ struct fmx_context_s {
   std::vector<hipEvent_t> ev_sync;   // untimed events ordering the two hogwild streams
   std::string err;
   hipDeviceProp_t prop;
+  uint32_t*   fused_ctr = nullptr;    // [2 * batches] work / completion counters of FusedPrev (FMX_APPLY_FUSED)
+  size_t      fused_ctr_cap = 0;
   // several GPUs (fmx_comm.hip)
   void*       comm = nullptr;         // ncclComm_t of a one-process-per-GPU job (fmx_comm_init_rank)
   struct fmx_group_s* group = nullptr;

@@ -781,84 +781,126 @@ k_seg_cbatch(const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ cfl
   }
 }
 
+// ---- which examples of batch b touch a feature that batch b-1 left deferred (FusedPrev) ------------------------------
+// one thread per segment: binary search of its feature in the previous batch's deferred list (ascending feature ids)
+static __global__ void __launch_bounds__(256)
+k_seg_dep(const uint64_t* __restrict__ keys, const TEntry* __restrict__ vals, const uint32_t* __restrict__ head, uint32_t nseg,
+          const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ batch_seg, const uint32_t* __restrict__ cbatch,
+          const uint32_t* __restrict__ cseg, uint32_t B, uint32_t* __restrict__ dep) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
+    const uint32_t a = head[s], b = head[s + 1];
+    const uint64_t key = keys[a];
+    const uint32_t bt = (uint32_t)(key >> 32), feat = (uint32_t)key;
+    if (bt == 0) continue;
+    const uint32_t s0 = batch_seg[bt - 1];
+    uint32_t lo = cbatch[bt - 1], hi = cbatch[bt];
+    while (lo < hi) {                                          // first listed feature >= feat
+      const uint32_t mid = (lo + hi) >> 1;
+      if (seg_feat[s0 + cseg[mid]] < feat) lo = mid + 1; else hi = mid;
+    }
+    if (lo < cbatch[bt] && seg_feat[s0 + cseg[lo]] == feat)
+      for (uint32_t i = a; i < b; i++) dep[(uint64_t)bt * B + vals[i].e] = 1u;
+  }
+}
+// cum = exclusive scan of dep over all rows (+ the total at [n_rows]); order: per batch, independent examples first
+static __global__ void __launch_bounds__(256)
+k_seg_order(const uint32_t* __restrict__ dep, const uint32_t* __restrict__ cum, uint32_t n_rows, uint32_t B,
+            uint32_t* __restrict__ order, uint32_t* __restrict__ n_indep) {
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
+    const uint32_t bt = r / B, r0 = bt * B, nb = min(B, n_rows - r0);
+    const uint32_t dep_before = cum[r] - cum[r0], n_dep = cum[r0 + nb] - cum[r0];
+    const uint32_t pos = dep[r] ? (nb - n_dep) + dep_before : (r - r0) - dep_before;
+    order[r0 + pos] = r - r0;
+    if (r == r0) n_indep[bt] = nb - n_dep;
+  }
+}
+
 // One wavefront owns blocks of 64 consecutive segments: the descriptors, first occurrences and their
 // multipliers are fetched lane-parallel (coalesced), then U segment groups at a time are broadcast and their
 // V rows + S rows gathered together (2*U row loads in flight per wavefront).
+// seg_idx == nullptr: all nseg (== nseg_batch) segments of the batch; else the nseg listed ones (the features that
+// occur more than once in the batch: what FUSED_EXACT leaves behind).
+struct SegWork {
+  const TEntry* t_ent; const uint32_t* seg_feat; const uint32_t* seg_rel; const uint32_t* seg_idx;
+  uint32_t nseg, nseg_batch, batch_nnz;
+  const float* S; const float* mult;
+};
 template <int KP, int U>
-__global__ void __launch_bounds__(256)
-k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
-            const uint32_t* __restrict__ seg_idx, uint32_t nseg, uint32_t nseg_batch, uint32_t batch_nnz, const Tab tb, Hyper h,
-            const float* __restrict__ S, const float* __restrict__ mult) {
-  // seg_idx == nullptr: all nseg (== nseg_batch) segments of the batch; else the nseg listed ones (the features that
-  // occur more than once in the batch: what FUSED_EXACT leaves behind)
+__device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk, const Tab tb, const Hyper& h) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
-  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t blk = wave0 * 64u; blk < nseg; blk += nwaves * 64u) {
-    const uint32_t cnt = min(64u, nseg - blk);
-    uint32_t jl = 0, al = 0, bl = 0, el = 0; float xl = 0.f, ml = 0.f;
-    if (lane < cnt) {
-      const uint32_t s = seg_idx ? seg_idx[blk + lane] : blk + lane;
-      jl = seg_feat[s];
-      al = seg_rel[s];
-      bl = (s + 1 < nseg_batch) ? seg_rel[s + 1] : batch_nnz;
-      const TEntry te = load_stream8(t_ent + al);
-      el = te.e; xl = te.x;
-      ml = mult[el];
-    }
-    for (uint32_t i = 0; i < cnt; i += EPI * U) {
-      float v0[U][VEC], sf[U][VEC];
+  const TEntry* __restrict__ t_ent = sw.t_ent;
+  const float* __restrict__ S = sw.S;
+  const float* __restrict__ mult = sw.mult;
+  const uint32_t cnt = min(64u, sw.nseg - blk);
+  uint32_t jl = 0, al = 0, bl = 0, el = 0; float xl = 0.f, ml = 0.f;
+  if (lane < cnt) {
+    const uint32_t s = sw.seg_idx ? sw.seg_idx[blk + lane] : blk + lane;
+    jl = sw.seg_feat[s];
+    al = sw.seg_rel[s];
+    bl = (s + 1 < sw.nseg_batch) ? sw.seg_rel[s + 1] : sw.batch_nnz;
+    const TEntry te = load_stream8(t_ent + al);
+    el = te.e; xl = te.x;
+    ml = mult[el];
+  }
+  for (uint32_t i = 0; i < cnt; i += EPI * U) {
+    float v0[U][VEC], sf[U][VEC];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t idx = i + u * EPI + g;
-        const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
-        const uint32_t e = bcast_u32<EPI>(el, idx & 63u);
-        if (idx < cnt) {
-          load_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, v0[u]);
-          load_vec<VEC>(S + (size_t)e * KP + f * VEC, sf[u]);
-        }
+    for (int u = 0; u < U; u++) {
+      const uint32_t idx = i + u * EPI + g;
+      const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
+      const uint32_t e = bcast_u32<EPI>(el, idx & 63u);
+      if (idx < cnt) {
+        load_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, v0[u]);
+        load_vec<VEC>(S + (size_t)e * KP + f * VEC, sf[u]);
       }
+    }
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t idx = i + u * EPI + g;
-        const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
-        const uint32_t a = bcast_u32<EPI>(al, idx & 63u);
-        const uint32_t b = bcast_u32<EPI>(bl, idx & 63u);
-        const float x = bcast_f32<EPI>(xl, idx & 63u);
-        const float m = bcast_f32<EPI>(ml, idx & 63u);
-        if (idx < cnt) {
-          float G[VEC]; float A, Gw;
-          const float mx = m * x;
+    for (int u = 0; u < U; u++) {
+      const uint32_t idx = i + u * EPI + g;
+      const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
+      const uint32_t a = bcast_u32<EPI>(al, idx & 63u);
+      const uint32_t b = bcast_u32<EPI>(bl, idx & 63u);
+      const float x = bcast_f32<EPI>(xl, idx & 63u);
+      const float m = bcast_f32<EPI>(ml, idx & 63u);
+      if (idx < cnt) {
+        float G[VEC]; float A, Gw;
+        const float mx = m * x;
 #pragma unroll
-          for (int v = 0; v < VEC; v++) G[v] = mx * sf[u][v];
-          A = mx * x; Gw = mx;
-          for (uint32_t i2 = a + 1; i2 < b; i2++) {             // further occurrences of the feature in this batch
-            const TEntry t2 = t_ent[i2];
-            const float mx2 = mult[t2.e] * t2.x;
-            float s2[VEC];
-            load_vec<VEC>(S + (size_t)t2.e * KP + f * VEC, s2);
+        for (int v = 0; v < VEC; v++) G[v] = mx * sf[u][v];
+        A = mx * x; Gw = mx;
+        for (uint32_t i2 = a + 1; i2 < b; i2++) {             // further occurrences of the feature in this batch
+          const TEntry t2 = t_ent[i2];
+          const float mx2 = mult[t2.e] * t2.x;
+          float s2[VEC];
+          load_vec<VEC>(S + (size_t)t2.e * KP + f * VEC, s2);
 #pragma unroll
-            for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[v], G[v]);
-            A = fmaf(mx2, t2.x, A); Gw += mx2;
-          }
-          const float nocc = (float)(b - a);
-          float nv[VEC];
+          for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[v], G[v]);
+          A = fmaf(mx2, t2.x, A); Gw += mx2;
+        }
+        const float nocc = (float)(b - a);
+        float nv[VEC];
 #pragma unroll
-          for (int v = 0; v < VEC; v++) {
-            const float vv = v0[u][v];
-            nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
-          }
-          store_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
-          if (h.k1 && f == 0) {
-            float* pw = tb.w + (size_t)j * tb.ws;
-            const float wv = *pw;
-            *pw = wv - h.lr * (Gw + nocc * h.regw * wv);
-          }
+        for (int v = 0; v < VEC; v++) {
+          const float vv = v0[u][v];
+          nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
+        }
+        store_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
+        if (h.k1 && f == 0) {
+          float* pw = tb.w + (size_t)j * tb.ws;
+          const float wv = *pw;
+          *pw = wv - h.lr * (Gw + nocc * h.regw * wv);
         }
       }
     }
   }
+}
+template <int KP, int U>
+__global__ void __launch_bounds__(256)
+k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t blk = wave0 * 64u; blk < sw.nseg; blk += nwaves * 64u) apply_seg_block<KP, U>(sw, blk, tb, h);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -885,19 +927,69 @@ k_apply_seg(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_f
 #define FMX_FUSED_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
 enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2 };
+// FUSED_EXACT, what the launch of batch b carries along: the deferred features of batch b-1 (SegWork `prev`, n_items
+// blocks of 64 segments) are finished INSIDE this launch instead of by a kernel of their own between the two batches --
+// two kernel boundaries and the small kernel's ramp / drain per batch were ~8 % of the epoch.  Every wavefront first
+// claims blocks of that work from a counter (ctr[0]) until none is left, publishes its part (release fence, ctr[1] +=
+// blocks done) and then turns to its examples.  The examples of batch b that touch one of those features ("dependent":
+// known when the batches are bucketed) are ordered LAST in `order`; a wavefront reaching its first dependent example
+// waits until ctr[1] == n_items (acquire).  Claimed blocks are always being worked on by resident wavefronts that wait
+// for nothing, so the wait cannot deadlock; in practice it never spins (the blocks are done ~1 ms earlier).
+struct FusedPrev {
+  SegWork prev;             // deferred features of the previous batch (prev.nseg == 0: none)
+  uint32_t n_items;         // ceil(prev.nseg / 64)
+  uint32_t n_indep;         // the first n_indep entries of `order` do not touch the previous batch's deferred features
+  uint32_t* ctr;            // [0] next block to claim, [1] blocks finished (zeroed by the host before the launch)
+  const uint32_t* order;    // [n_rows] example order of this batch (nullptr: natural order, nothing deferred before)
+};
 template <int KP, int ZR, int VAR>
 __global__ void __launch_bounds__(256, FMX_FUSED_MIN_WAVES)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
         uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
-        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out) {
+        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out, const FusedPrev fp) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), EXACT = (VAR == FUSED_EXACT);
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   const float w0s = h.k0 ? (float)(*w0_ptr) : 0.f;
-  for (uint32_t e = wave0; e < n_rows; e += nwaves) {
+  bool prev_done = true;
+  if constexpr (EXACT) {
+    if (fp.n_items) {
+      prev_done = false;
+      uint32_t mine = 0;
+      for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = __hip_atomic_fetch_add(fp.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= fp.n_items) break;
+        apply_seg_block<KP, 8>(fp.prev, it * 64u, tb, h);
+        mine++;
+      }
+      if (mine) {                                              // publish: stores drained, L2 written back, then the count
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(fp.ctr + 1, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  for (uint32_t q = wave0; q < n_rows; q += nwaves) {
+    uint32_t e = q;
+    if constexpr (EXACT) {
+      if (fp.order) e = fp.order[q];
+      if (!prev_done && q >= fp.n_indep) {                     // first dependent example of this wavefront
+        uint32_t done = 0;
+        do {
+          if (lane == 0) done = __hip_atomic_load(fp.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          done = __builtin_amdgcn_readfirstlane(done);
+          if (done < fp.n_items) __builtin_amdgcn_s_sleep(16);
+        } while (done < fp.n_items);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        prev_done = true;
+      }
+    }
     const uint64_t a = row_ptr[row0 + e];
     const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
     const Entry* __restrict__ row = ent + a;

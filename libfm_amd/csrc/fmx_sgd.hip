@@ -33,11 +33,13 @@ template <int KP> uint32_t fused_row_cap_kp(uint32_t max_row) {
 template <int KP, int VAR>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
                     const double* w0_in, float* rest_out, const uint64_t* cmask = nullptr, float* S_out = nullptr,
-                    float* mult_out = nullptr) {
+                    float* mult_out = nullptr, const FusedPrev* prev = nullptr) {
+  FusedPrev fp;
+  if (prev) fp = *prev; else memset(&fp, 0, sizeof(fp));
 #define FMX_LAUNCH_ZR(ZRV)                                                                                  \
   if constexpr (fused_zr_ok<KP>(ZRV)) {                                                                     \
     FMX_LAUNCH_WAVES((k_fused<KP, ZRV, VAR>), n_rows, st, s.ent, s.row_ptr, s.target, row0,                 \
-                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out); }
+                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out, fp); }
   switch (fused_zr_select<KP>(s.max_row)) {
     case 8:  FMX_LAUNCH_ZR(8);  break;
     case 16: FMX_LAUNCH_ZR(16); break;
@@ -91,7 +93,7 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   if (nnz >= (1ull << 31)) return fail(h, FMX_E_UNSUPPORTED, "segmented apply: nnz >= 2^31 in one slot (split the data set)");
   hipStream_t st = h->stream;
   uint64_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr, *d_cbatch = nullptr;
+  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr, *d_cbatch = nullptr, *depbuf = nullptr;
   uint32_t cap = 64;
   KP_SWITCH(h->KP, cap = fused_row_cap_kp<KP>(s.max_row));
   void* tmp = nullptr;
@@ -163,6 +165,30 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
       s.cbatch.resize((size_t)n_batches + 1);
       SEG_CHK(hipMemcpyAsync(s.cbatch.data(), d_cbatch, ((size_t)n_batches + 1) * 4, hipMemcpyDeviceToHost, st));
       SEG_CHK(hipStreamSynchronize(st));
+      // which examples of a batch touch a feature the PREVIOUS batch left deferred, and the per-batch example order that
+      // puts them last (FusedPrev)
+      if (n_batches > 1) {
+        SEG_CHK(hipMalloc(&depbuf, 2 * ((size_t)s.n_rows + 1) * 4));
+        uint32_t* dep = depbuf;
+        uint32_t* cum = dep + ((size_t)s.n_rows + 1);
+        uint32_t* d_nindep = d_cbatch;                                   // (copied to the host above)
+        SEG_CHK(hipMemsetAsync(dep, 0, ((size_t)s.n_rows + 1) * 4, st));
+        hipLaunchKernelGGL(k_seg_dep, dim3(2048), dim3(256), 0, st, keys_b, reinterpret_cast<const TEntry*>(vals_b), head, nseg,
+                           s.seg_feat, d_batch_seg, d_cbatch, s.cseg, B, dep);
+        SEG_CHK(hipGetLastError());
+        SEG_CHK(hipStreamSynchronize(st));                               // k_seg_dep read d_cbatch: done before it is overwritten below
+        hipFree(tmp); tmp = nullptr; tmp_bytes = 0;
+        SEG_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, dep, cum, (int)(s.n_rows + 1), st));
+        SEG_CHK(hipMalloc(&tmp, tmp_bytes));
+        SEG_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, dep, cum, (int)(s.n_rows + 1), st));
+        SEG_CHK(hipMalloc(&s.order, (size_t)s.n_rows * 4));
+        hipLaunchKernelGGL(k_seg_order, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, st, dep, cum, s.n_rows, B,
+                           s.order, d_nindep);
+        SEG_CHK(hipGetLastError());
+        s.n_indep.resize(n_batches);
+        SEG_CHK(hipMemcpyAsync(s.n_indep.data(), d_nindep, (size_t)n_batches * 4, hipMemcpyDeviceToHost, st));
+        SEG_CHK(hipStreamSynchronize(st));
+      }
     }
     s.t_ent = reinterpret_cast<TEntry*>(vals_b); vals_b = nullptr;      // payload layout == TEntry
   } else {
@@ -190,6 +216,7 @@ done:
   if (pos) hipFree(pos);
   if (d_batch_seg) hipFree(d_batch_seg);
   if (d_cbatch) hipFree(d_cbatch);
+  if (depbuf) hipFree(depbuf);
   if (tmp) hipFree(tmp);
   if (rc) free_segments(s);
   return rc;
@@ -297,9 +324,8 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
     const uint32_t bnnz = (uint32_t)(s.batch_base[(size_t)seg_batch + 1] - base);
     const uint32_t nseg = s1 - s0;
     if (nseg) {
-      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)nseg + 63) / 64, st,
-                                         s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, (const uint32_t*)nullptr, nseg, nseg, bnnz,
-                                         h->tb, hy, S, h->mult));
+      SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nullptr, nseg, nseg, bnnz, S, h->mult};
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)nseg + 63) / 64, st, sw, h->tb, hy));
     }
   } else if (apply == FMX_APPLY_ATOMIC) {
     KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, true>), n_rows, st,
@@ -380,42 +406,69 @@ int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, fl
 // under the launches of batches b+1 .. b+d-1 and only the launch of batch b+d waits for it.
 static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, const Hyper& hy, uint64_t* batches,
                            uint64_t* launches, uint64_t* deferred) {
-  const uint32_t B = opts->batch ? opts->batch : 131072u;
+  const uint32_t B = opts->batch ? opts->batch : 262144u;
   const uint32_t d = opts->bias_lag ? opts->bias_lag : 1u;
   if (d > 4) return fail(h, FMX_E_ARG, "bias_lag %u: at most 4 batches", d);
   const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : default_w0_chunk(h->cfg);
   int rc = ensure_segments(h, s, B);
   if (rc) return rc;
   const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
-  rc = ensure_scratch(h, Bc, (size_t)Bc * d);
+  rc = ensure_scratch(h, (size_t)Bc * 2, (size_t)Bc * d);       // S / mult of two consecutive batches, d rest buffers
   if (rc) return rc;
   const uint64_t n_batch = ((uint64_t)s.n_rows + B - 1) / B;
   while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+  // the deferred features of batch b-1 ride along in the launch of batch b (FusedPrev) when the per-batch example order
+  // exists; FMX_FUSED_SEPARATE_PASS=1 keeps the separate kernel between the batches (A/B knob)
+  const bool merged = s.order != nullptr && !getenv("FMX_FUSED_SEPARATE_PASS");
+  if (merged && h->fused_ctr_cap < 2 * n_batch) {
+    if (h->fused_ctr) hipFree(h->fused_ctr);
+    h->fused_ctr = nullptr; h->fused_ctr_cap = 0;
+    HIPCHK(h, hipMalloc(&h->fused_ctr, 2 * n_batch * sizeof(uint32_t)));
+    h->fused_ctr_cap = 2 * n_batch;
+  }
   hipStream_t st = h->stream;
   HIPCHK(h, hipEventRecord(h->ev0, st));                    // do not bill the one-time bucketing to the epoch
+  if (merged) HIPCHK(h, hipMemsetAsync(h->fused_ctr, 0, 2 * n_batch * sizeof(uint32_t), st));
   for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
-  float* S = h->partial;
-  float* mult = h->mult;
+  auto seg_work = [&](uint64_t b, SegWork* sw) {                 // the deferred features of batch b
+    const uint32_t c0 = s.cbatch[(size_t)b], c1 = s.cbatch[(size_t)b + 1];
+    const uint32_t s0 = s.batch_seg[(size_t)b], s1 = s.batch_seg[(size_t)b + 1];
+    const uint64_t base = s.batch_base[(size_t)b];
+    sw->t_ent = s.t_ent + base; sw->seg_feat = s.seg_feat + s0; sw->seg_rel = s.seg_rel + s0; sw->seg_idx = s.cseg + c0;
+    sw->nseg = c1 - c0; sw->nseg_batch = s1 - s0; sw->batch_nnz = (uint32_t)(s.batch_base[(size_t)b + 1] - base);
+    sw->S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
+    sw->mult = h->mult + (size_t)(b & 1) * Bc;
+  };
   for (uint64_t b = 0; b < n_batch; b++) {
     const uint64_t row0 = b * B;
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
     float* rest = h->rest + (size_t)(b % d) * Bc;
+    float* S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
+    float* mult = h->mult + (size_t)(b & 1) * Bc;
     if (b >= d) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (b - d) + 1], 0));   // recurrence of batch b - d is done
     const double* w0_in = h->w0_pp + ((b + 1) % d);         // written by the recurrence of batch b - d (initial bias for b < d)
-    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult); });
+    FusedPrev fp;
+    memset(&fp, 0, sizeof(fp));
+    if (merged && b > 0) {
+      seg_work(b - 1, &fp.prev);
+      fp.n_items = (fp.prev.nseg + 63) / 64;
+      fp.n_indep = s.n_indep[(size_t)b];
+      fp.ctr = h->fused_ctr + 2 * b;
+      fp.order = s.order + row0;
+      *deferred += fp.prev.nseg;
+    }
+    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, &fp); });
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
-    const uint32_t c0 = s.cbatch[(size_t)b], c1 = s.cbatch[(size_t)b + 1];
-    if (c1 > c0) {
-      const uint32_t s0 = s.batch_seg[(size_t)b], s1 = s.batch_seg[(size_t)b + 1];
-      const uint64_t base = s.batch_base[(size_t)b];
-      const uint32_t bnnz = (uint32_t)(s.batch_base[(size_t)b + 1] - base);
-      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)(c1 - c0) + 63) / 64, st,
-                                         s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, (const uint32_t*)(s.cseg + c0), c1 - c0, s1 - s0, bnnz,
-                                         h->tb, hy, (const float*)S, (const float*)mult));
-      HIPCHK(h, hipGetLastError());
-      *deferred += c1 - c0;
+    if (!merged || b + 1 == n_batch) {                       // the last batch's (or, unmerged, every batch's) deferred features
+      SegWork sw;
+      seg_work(b, &sw);
+      if (sw.nseg) {
+        KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)sw.nseg + 63) / 64, st, sw, h->tb, hy));
+        HIPCHK(h, hipGetLastError());
+        *deferred += sw.nseg;
+      }
     }
     HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * b], 0));
     rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d));

@@ -33,15 +33,24 @@ __device__ __forceinline__ uint64_t rnd_index(uint64_t i, uint64_t n) {
 
 enum { F_PLAIN = 0, F_NT = 1, F_SC0 = 2, F_SC1 = 3, F_SC0SC1 = 4, F_SC0SC1NT = 5 };
 
-template <int F> __device__ __forceinline__ float load4(const float* p) {
-  float v;
-  if constexpr (F == F_PLAIN)     asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  if constexpr (F == F_NT)        asm volatile("global_load_dword %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-  if constexpr (F == F_SC0)       asm volatile("global_load_dword %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
-  if constexpr (F == F_SC1)       asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  if constexpr (F == F_SC0SC1)    asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-  if constexpr (F == F_SC0SC1NT)  asm volatile("global_load_dword %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// Eight loads and their wait are ONE asm statement: a global load writes its destination register when the data comes
+// back, so the compiler must not get the chance to reuse an output (or to read it) before the s_waitcnt -- with one asm
+// per load it did both (observed: destination registers recycled as address registers -> memory fault).
+#define LOAD8(SUFFIX)                                                                                        \
+  asm volatile("global_load_dword %0, %8, off" SUFFIX "\n\tglobal_load_dword %1, %9, off" SUFFIX "\n\t"         \
+               "global_load_dword %2, %10, off" SUFFIX "\n\tglobal_load_dword %3, %11, off" SUFFIX "\n\t"       \
+               "global_load_dword %4, %12, off" SUFFIX "\n\tglobal_load_dword %5, %13, off" SUFFIX "\n\t"       \
+               "global_load_dword %6, %14, off" SUFFIX "\n\tglobal_load_dword %7, %15, off" SUFFIX "\n\t"       \
+               "s_waitcnt vmcnt(0)"                                                                          \
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])   \
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory")
+template <int F> __device__ __forceinline__ void load8(const float* (&p)[8], float (&v)[8]) {
+  if constexpr (F == F_PLAIN)     LOAD8("");
+  if constexpr (F == F_NT)        LOAD8(" nt");
+  if constexpr (F == F_SC0)       LOAD8(" sc0");
+  if constexpr (F == F_SC1)       LOAD8(" sc1");
+  if constexpr (F == F_SC0SC1)    LOAD8(" sc0 sc1");
+  if constexpr (F == F_SC0SC1NT)  LOAD8(" sc0 sc1 nt");
 }
 
 template <int F>
@@ -50,13 +59,13 @@ __global__ void __launch_bounds__(256) k_gather(const float* __restrict__ tab, u
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   float acc = 0.f;
   for (uint64_t i = tid; i < total; i += stride * 8) {
-    float v[8];
+    const float* p[8]; float v[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const uint64_t ii = i + u * stride;
-      v[u] = load4<F>(tab + rnd_index(ii < total ? ii : tid, n));
+      p[u] = tab + rnd_index(ii < total ? ii : tid, n);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load8<F>(p, v);
 #pragma unroll
     for (int u = 0; u < 8; u++) acc += v[u];
   }
@@ -68,44 +77,52 @@ __global__ void __launch_bounds__(256) k_sgather(const float* __restrict__ tab, 
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
   float acc = 0.f;
-  for (uint64_t i = wave; i < total; i += nwaves * 8) {
-    float v[8];
+  for (uint64_t i = wave; i < total; i += nwaves * 4) {
+    const float* p[4]; float v[4];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 4; u++) {
       const uint64_t ii = i + u * nwaves;
       const uint64_t idx = rnd_index(ii < total ? ii : wave, n);
       const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)idx), hi = __builtin_amdgcn_readfirstlane((uint32_t)(idx >> 32));
-      const float* p = tab + (((uint64_t)hi << 32) | lo);
-      asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v[u]) : "s"(p) : "memory");
+      p[u] = tab + (((uint64_t)hi << 32) | lo);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(v[0]), "=&s"(v[1]), "=&s"(v[2]), "=&s"(v[3]) : "s"(p[0]), "s"(p[1]), "s"(p[2]), "s"(p[3]) : "memory");
 #pragma unroll
-    for (int u = 0; u < 8; u++) acc += v[u];
+    for (int u = 0; u < 4; u++) acc += v[u];
   }
   if (acc == 123.456f) out[wave] = acc;
 }
 
 enum { S_PLAIN = 0, S_NT = 1, S_ATOMIC = 2, S_SC0SC1 = 3 };
+#define LOAD4(SUFFIX)                                                                                        \
+  asm volatile("global_load_dword %0, %4, off" SUFFIX "\n\tglobal_load_dword %1, %5, off" SUFFIX "\n\t"         \
+               "global_load_dword %2, %6, off" SUFFIX "\n\tglobal_load_dword %3, %7, off" SUFFIX "\n\ts_waitcnt vmcnt(0)" \
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory")
+#define STORE4(OP, SUFFIX)                                                                                   \
+  asm volatile(OP " %0, %4, off" SUFFIX "\n\t" OP " %1, %5, off" SUFFIX "\n\t" OP " %2, %6, off" SUFFIX "\n\t"     \
+               OP " %3, %7, off" SUFFIX "\n\ts_waitcnt vmcnt(0)"                                              \
+               :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "memory")
 template <int F>
 __global__ void __launch_bounds__(256) k_rmw(float* __restrict__ tab, uint64_t n, uint64_t total) {
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = tid; i < total; i += stride * 4) {
-    float* p[4]; float v[4];
+    float* p[4]; float v[4] = {0.f, 0.f, 0.f, 0.f}, w[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const uint64_t ii = i + u * stride;
       p[u] = tab + rnd_index(ii < total ? ii : tid, n);
-      if constexpr (F != S_ATOMIC) v[u] = (F == S_SC0SC1) ? load4<F_SC0SC1>(p[u]) : load4<F_PLAIN>(p[u]);
     }
-    if constexpr (F != S_ATOMIC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (F == S_SC0SC1) LOAD4(" sc0 sc1");
+    else if constexpr (F != S_ATOMIC) LOAD4("");
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if constexpr (F == S_PLAIN)  asm volatile("global_store_dword %0, %1, off" :: "v"(p[u]), "v"(v[u] + 1.0f) : "memory");
-      if constexpr (F == S_NT)     asm volatile("global_store_dword %0, %1, off nt" :: "v"(p[u]), "v"(v[u] + 1.0f) : "memory");
-      if constexpr (F == S_SC0SC1) asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p[u]), "v"(v[u] + 1.0f) : "memory");
-      if constexpr (F == S_ATOMIC) asm volatile("global_atomic_add_f32 %0, %1, off" :: "v"(p[u]), "v"(1.0f) : "memory");
-    }
+    for (int u = 0; u < 4; u++) w[u] = v[u] + 1.0f;
+    if constexpr (F == S_PLAIN)  STORE4("global_store_dword", "");
+    if constexpr (F == S_NT)     STORE4("global_store_dword", " nt");
+    if constexpr (F == S_SC0SC1) STORE4("global_store_dword", " sc0 sc1");
+    if constexpr (F == S_ATOMIC) STORE4("global_atomic_add_f32", "");
   }
 }
 
@@ -137,14 +154,17 @@ struct Timer {
 
 template <class K, class... A> void run(const char* name, const char* alloc, uint64_t accesses, int bytes_alg, K k, dim3 g, A... args) {
   Timer t;
+  printf("%-28s %-12s ...", name, alloc); fflush(stdout);    // (named before it runs: a faulting flavour is identified)
   hipLaunchKernelGGL(k, g, dim3(256), 0, 0, args...);     // warm-up
   CK(hipDeviceSynchronize());
+  printf("\r");
   t.start();
   hipLaunchKernelGGL(k, g, dim3(256), 0, 0, args...);
   const float ms = t.stop();
   CK(hipGetLastError());
   printf("%-28s %-12s %8.3f ms  %8.2f G access/s  %7.1f GB/s algorithmic (%d B each)\n", name, alloc, ms, accesses / ms * 1e-6,
          accesses * (double)bytes_alg / ms * 1e-6, bytes_alg);
+  fflush(stdout);
 }
 
 int main(int argc, char** argv) {

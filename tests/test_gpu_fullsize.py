@@ -105,26 +105,56 @@ def test_fused_minibatch_is_deterministic_at_bench_batch(capi):
     assert 0.02 * rows * NNZ < sums[0][2] < 0.06 * rows * NNZ   # ~4 % of the (batch, feature) pairs hold >= 2 occurrences
 
 
+def test_fused_merged_pass_equals_separate_pass(capi, monkeypatch):
+    """the deferred features of batch b-1 are finished INSIDE the launch of batch b (FusedPrev: claimed blocks, release /
+    acquire hand-off to the examples that depend on them) -- or, with FMX_FUSED_SEPARATE_PASS=1, by a kernel of their own
+    between the launches.  Same arithmetic, so the two schedules must agree BIT FOR BIT; a dependent example that read a
+    row (or a linear weight sharing a 128-byte line with another feature's) before the hand-off would show up here.
+    Bench configuration: n = 1e8, batch 262 144 -- ~10 % of a batch's examples depend on the previous batch."""
+    rows = 1 << 20
+    res = []
+    for separate in ("1", None):
+        if separate:
+            monkeypatch.setenv("FMX_FUSED_SEPARATE_PASS", separate)
+        else:
+            monkeypatch.delenv("FMX_FUSED_SEPARATE_PASS", raising=False)
+        h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+        h.init_params(0.0, 0.05, 3)
+        h.synth_rows(0, 78, 0, rows, NNZ)
+        for _ in range(2):
+            st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 262144, 0, 0, 2)
+        res.append((h.predict(0, rows).tobytes(), h.get_w0(), st.deferred_features))
+        h.close()
+    assert res[0][2] == res[1][2] > 0
+    assert res[0][1] == res[1][1]
+    assert res[0][0] == res[1][0]
+
+
 def test_hogwild_at_bench_size_is_the_batch_rule_off_collisions(capi, oracle):
-    """HOGWILD where it is benchmarked (n = 1e8, one 65 536-row launch): every feature that occurs ONCE in the launch must
-    come out exactly as the batch rule leaves it (oracle, batch = launch, bias frozen for the launch); the features that
-    occur more than once race and are only counted and bounded."""
+    """HOGWILD where it is benchmarked (n = 1e8, one 65 536-row launch, bias frozen for the launch).  An example none of
+    whose features occurs anywhere else in the launch is independent of every other example, so its parameter rows must
+    come out exactly as the batch rule leaves them (oracle, batch = launch).  Examples that share a feature with another
+    one race: a racing reader may see its partner's update, which perturbs that example's sums and with them ALL of its
+    rows -- those are counted and bounded, not held to 1e-4."""
     rows = 65536
     h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
     h.init_params(0.0, 0.05, 7)
     h.synth_rows(0, 999, 3_000_000, rows, NNZ)
     d, m, ids = submodel_minibatch(capi, oracle, h, 999, 3_000_000, rows, rows, 256, 1)
-    for ap in (capi.APPLY_STORE,):
-        h.sgd_epoch(0, capi.SGD_HOGWILD, ap, rows, 256)
+    h.sgd_epoch(0, capi.SGD_HOGWILD, capi.APPLY_STORE, rows, 256)
     w, v = h.get_param_rows(ids)
+    fid = d.entries["id"].reshape(rows, NNZ)                     # sub-model ids, one row of 32 per example
     counts = np.bincount(d.entries["id"], minlength=len(ids))
-    once = counts == 1
-    assert once.mean() > 0.95                                    # ~2 % of the touched features are shared
-    np.testing.assert_allclose(v[:, once], m.v[:, once], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(w[once], m.w[once], rtol=1e-4, atol=1e-6)
-    # shared features: each racing writer applies a step of the right size from a value at most one update old
-    assert np.abs(v[:, ~once] - m.v[:, ~once]).max() < 5e-3
-    assert abs(h.get_w0() - m.w0) <= 1e-4 * abs(m.w0) + 1e-6     # the bias recurrence does not depend on the races
+    free_example = (counts[fid] == 1).all(axis=1)                # every feature of the example occurs once in the launch
+    assert 0.40 < free_example.mean() < 0.65                     # (1 - 0.0207)^32 = 0.51
+    free = np.unique(fid[free_example])
+    racing = np.setdiff1d(np.arange(len(ids)), free)
+    np.testing.assert_allclose(v[:, free], m.v[:, free], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w[free], m.w[free], rtol=1e-4, atol=1e-6)
+    # the rest: every racing writer applies a step of the right size from a value at most one update old
+    assert np.abs(v[:, racing] - m.v[:, racing]).max() < 2e-2
+    assert np.abs(v[:, racing] - m.v[:, racing]).mean() < 2e-5
+    assert abs(h.get_w0() - m.w0) <= 1e-3 * abs(m.w0) + 1e-6     # the bias recurrence sees the racing examples' sums
     h.close()
 
 

@@ -44,7 +44,7 @@ def check_against_band(name, preds, y, task):
     # our seed average against theirs: the sampling noise averages out, what is left would be bias
     pm = np.mean(preds, axis=0)
     assert np.corrcoef(pm, ref_pm)[0, 1] > ref_corr.max(), (name, np.corrcoef(pm, ref_pm)[0, 1], ref_corr.max())
-    assert np.sqrt(np.mean((pm - ref_pm) ** 2)) < 0.6 * ref_rms.min(), (name, np.sqrt(np.mean((pm - ref_pm) ** 2)), ref_rms.min())
+    assert np.sqrt(np.mean((pm - ref_pm) ** 2)) < 0.75 * ref_rms.min(), (name, np.sqrt(np.mean((pm - ref_pm) ** 2)), ref_rms.min())
 
 
 def run_chain(g, oracle, seed):
