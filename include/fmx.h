@@ -351,6 +351,15 @@ int fmx_als_begin(fmx_handle h, int train_slot);
 int fmx_als_moments(fmx_handle h, double *out);
 int fmx_als_sweep(fmx_handle h, const fmx_als_opts *opts, fmx_als_stats *stats);
 int fmx_als_end(fmx_handle h);
+/* the same learner over the feature shards of a group (BASELINE configs[4]: "V sharded across 8 x MI355X"): every shard
+ * sweeps its own features, level by level in the GLOBAL dependency order; the {e, q} cache is replicated, one all-reduce per
+ * (coordinate family, level) carries the changes of the level's draws, and the re-prediction all-reduces the shards' partial
+ * y-hat and q_f (fm_learn_mcmc.h:430-641 with e / q of :46-49 replicated).  Same results as one
+ * unsharded handle: ALS to rounding, MCMC draw for draw (the noise of a coordinate is keyed by its GLOBAL feature id). */
+int fmx_group_als_begin(fmx_group g, int train_slot);
+int fmx_group_als_moments(fmx_group g, double *out);
+int fmx_group_als_sweep(fmx_group g, const fmx_als_opts *opts, fmx_als_stats *stats);
+int fmx_group_als_end(fmx_group g);
 
 /* ---- fm_learn_sgd_element_adapt_reg (`-method sgda`; src/libfm/src/fm_learn_sgd_element_adapt_reg.h) -------------
  * Self-adaptive regularisation: theta steps on the train rows alternate with lambda steps on the validation rows,

@@ -124,6 +124,10 @@ SYMBOLS = [
     ("fmx_group_sgd_epoch", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(EpochStats)]),
     ("fmx_group_predict", C.c_int, [H, C.c_int, C.c_void_p]),
     ("fmx_group_evaluate", C.c_int, [H, C.c_int, C.POINTER(Eval)]),
+    ("fmx_group_als_begin", C.c_int, [H, C.c_int]),
+    ("fmx_group_als_moments", C.c_int, [H, C.c_void_p]),
+    ("fmx_group_als_sweep", C.c_int, [H, C.POINTER(AlsOpts), C.POINTER(AlsStats)]),
+    ("fmx_group_als_end", C.c_int, [H]),
     ("fmx_sgda_begin", C.c_int, [H]),
     ("fmx_sgda_epoch", C.c_int, [H, C.c_int, C.c_int, C.c_int, C.POINTER(EpochStats)]),
     ("fmx_sgda_get_reg", C.c_int, [H, C.c_void_p]),
@@ -351,6 +355,12 @@ class Handle:
     def als_sweep(self, w_lambda, v_lambda, alpha=1.0, w_mu=0.0, v_mu=0.0, do_sample=False, seed=0):
         """w_lambda / w_mu: scalar or [G]; v_lambda / v_mu: scalar, [k] or [G][k] (the reference's w_lambda(g),
         v_lambda(g,f); fm_learn_mcmc.h:1116-1122)."""
+        opts, keep = self._als_opts(w_lambda, v_lambda, alpha, w_mu, v_mu, do_sample, seed)
+        st = AlsStats()
+        self._chk(self.lib.fmx_als_sweep(self.h, C.byref(opts), C.byref(st)))
+        return st
+
+    def _als_opts(self, w_lambda, v_lambda, alpha, w_mu, v_mu, do_sample, seed):
         G, k = self.G, max(self.k, 1)
 
         def tab_w(x):
@@ -372,9 +382,7 @@ class Handle:
                        G if G > 1 else 0, 0, _ptr(wm), _ptr(wl), _ptr(vm), _ptr(vl))
         if G > 1 and self.k != k:                    # k == 0: tables are [G][0]
             opts.v_mu_gf = opts.v_lambda_gf = None
-        st = AlsStats()
-        self._chk(self.lib.fmx_als_sweep(self.h, C.byref(opts), C.byref(st)))
-        return st
+        return opts, (wl, wm, vl, vm)                # the arrays must outlive the call
 
     def als_end(self):
         self._chk(self.lib.fmx_als_end(self.h))
@@ -453,6 +461,25 @@ class Group:
         ev = Eval()
         self._chk(self.lib.fmx_group_evaluate(self.g, slot, C.byref(ev)))
         return ev
+
+    # ALS / MCMC over the shards ----------------------------------------------------------------
+    def als_begin(self, train_slot):
+        self._chk(self.lib.fmx_group_als_begin(self.g, train_slot))
+
+    def als_sweep(self, w_lambda, v_lambda, alpha=1.0, w_mu=0.0, v_mu=0.0, do_sample=False, seed=0):
+        opts, keep = self.handles[0]._als_opts(w_lambda, v_lambda, alpha, w_mu, v_mu, do_sample, seed)
+        st = AlsStats()
+        self._chk(self.lib.fmx_group_als_sweep(self.g, C.byref(opts), C.byref(st)))
+        return st
+
+    def als_moments(self):
+        h0 = self.handles[0]
+        out = np.zeros(2 + 2 * h0.G * (1 + h0.k), dtype=np.float64)
+        self._chk(self.lib.fmx_group_als_moments(self.g, _ptr(out)))
+        return out[0], out[1], out[2:].reshape(1 + h0.k, h0.G, 2)
+
+    def als_end(self):
+        self._chk(self.lib.fmx_group_als_end(self.g))
 
     def get_params(self):
         """the full model: every shard writes its own features into the same host arrays"""

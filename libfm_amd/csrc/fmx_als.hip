@@ -14,6 +14,8 @@ extern "C++" void als_free(fmx_handle h) {
   if (a.level_list) hipFree(a.level_list);
   if (a.prior) hipFree(a.prior);
   if (a.vt) hipFree(a.vt);
+  if (a.delta) hipFree(a.delta);
+  if (a.epart) hipFree(a.epart);
   a = AlsState();
 }
 
@@ -25,9 +27,9 @@ int fmx_als_end(fmx_handle h) {
   return FMX_OK;
 }
 
-static int als_eterms(fmx_handle h, const Slot& s, EQ* e, double* q) {
+static int als_eterms(fmx_handle h, const Slot& s, EQ* e, double* q, double* e_part = nullptr) {
   KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), s.n_rows, h->stream, s.ent, s.row_ptr, s.n_rows, h->tb,
-                                     h->cfg.k0, h->cfg.k1, h->w0, e, q));
+                                     h->cfg.k0, h->cfg.k1, h->w0, e, q, e_part));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
 }
@@ -42,7 +44,7 @@ static int als_begin_impl(fmx_handle h, int train_slot) {
   int rc = check_slot(h, train_slot, true);
   if (rc) return rc;
   { int _rc = lag_flush(h); if (_rc) return _rc; }
-  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "ALS on a feature shard is not implemented");
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_STATE, "ALS / MCMC on a feature shard: use fmx_group_als_begin (the dependency levels are global)");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   als_free(h);
@@ -138,29 +140,37 @@ int fmx_als_moments(fmx_handle h, double* out) {
   return rc;
 }
 
-int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) {
-  if (!h || !opts) return FMX_E_ARG;
-  AlsState& a = h->als;
-  if (a.slot < 0) return fail(h, FMX_E_STATE, "fmx_als_sweep before fmx_als_begin");
-  if (opts->num_groups != 0 && opts->num_groups != h->num_groups)     // validated BEFORE the first device write of the sweep
-    return fail(h, FMX_E_ARG, "fmx_als_sweep: opts->num_groups = %u but the handle has %u attribute groups", opts->num_groups, h->num_groups);
-  HIPCHK(h, hipSetDevice(h->device));
-  const Slot& s = h->slots[a.slot];
-  const uint32_t N = s.n_rows;
-  const uint32_t n_levels = (uint32_t)a.level_ptr.size() - 1;
-  hipStream_t st = h->stream;
+// one iteration of _learn over a list of feature shards (one unsharded handle: the list has one member and nothing is
+// exchanged).  Shards: the {e, q} cache is replicated; the draws of a (family, level) step record their changes
+// (AlsState::delta), one all-reduce per step sums them and every shard applies the same sum -- the replicas stay identical
+// bit for bit; the re-prediction all-reduces the partial y-hat and q_f of the shards ("the simple
+// version").  The levels are GLOBAL (fmx_group_als_begin), so the sweep is the reference's Gauss-Seidel order whatever
+// the number of shards.
+static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, const fmx_als_opts* opts, fmx_als_stats* stats) {
+  fmx_handle h = hs[0];
+  const size_t P = hs.size();
+  const bool sharded = g != nullptr && P > 1;
+  for (fmx_handle x : hs) {
+    if (x->als.slot < 0) return fail(h, FMX_E_STATE, "fmx_als_sweep before fmx_als_begin");
+    if (opts->num_groups != 0 && opts->num_groups != x->num_groups)     // validated BEFORE the first device write of the sweep
+      return fail(h, FMX_E_ARG, "fmx_als_sweep: opts->num_groups = %u but the handle has %u attribute groups", opts->num_groups, x->num_groups);
+  }
+  AlsState& a0 = h->als;
+  const uint32_t N = h->slots[a0.slot].n_rows;
+  const uint32_t n_levels = (uint32_t)a0.level_ptr.size() - 1;
   const dim3 g1(std::min<uint32_t>((N + 255) / 256, 2048)), b1(256);
-  HIPCHK(h, hipEventRecord(h->ev0, st));
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   double acc[4] = {0, 0, 0, 0};
-  // sum e, sum e^2 (draw_w0's numerator; draw_alpha's statistic for the caller)
-  HIPCHK(h, hipMemsetAsync(h->acc, 0, 4 * sizeof(double), st));
-  hipLaunchKernelGGL(k_als_sum_e, g1, b1, 0, st, a.e, N, h->acc);
-  HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+  // sum e, sum e^2 (draw_w0's numerator; draw_alpha's statistic for the caller): the replicas are identical, shard 0 answers
+  HIPCHK(h, hipMemsetAsync(h->acc, 0, 4 * sizeof(double), h->stream));
+  hipLaunchKernelGGL(k_als_sum_e, g1, b1, 0, h->stream, a0.e, N, h->acc);
+  HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
   double w0 = 0;
-  HIPCHK(h, hipMemcpyAsync(&w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, hipMemcpyAsync(&w0, h->w0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   if (stats) stats->sum_e_sqr = acc[1];
-  std::mt19937_64 rng(opts->seed * 0x9E3779B97F4A7C15ull + a.iter + 1);
+  std::mt19937_64 rng(opts->seed * 0x9E3779B97F4A7C15ull + a0.iter + 1);
   std::normal_distribution<double> nd(0.0, 1.0);
   if (h->cfg.k0) {                                         // draw_w0, fm_learn_mcmc.h:643-683 (w0_mean_0 = 0)
     double mean = acc[0] - (double)N * w0;
@@ -168,32 +178,40 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
     mean = -sigma_sqr * (opts->alpha * mean - 0.0 * h->cfg.reg0);
     double nw0 = opts->do_sample ? mean + std::sqrt(sigma_sqr) * nd(rng) : mean;
     if (!(std::isnan(nw0) || std::isinf(nw0))) {
-      HIPCHK(h, hipMemcpyAsync(h->w0, &nw0, sizeof(double), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_als_add_const, g1, b1, 0, st, a.e, N, nw0 - w0);
-      HIPCHK(h, hipStreamSynchronize(st));                 // nw0 lives on this stack frame
+      for (fmx_handle x : hs) {
+        HIPCHK(x, hipSetDevice(x->device));
+        HIPCHK(x, hipMemcpyAsync(x->w0, &nw0, sizeof(double), hipMemcpyHostToDevice, x->stream));
+        hipLaunchKernelGGL(k_als_add_const, g1, b1, 0, x->stream, x->als.e, N, nw0 - w0);
+        HIPCHK(x, hipStreamSynchronize(x->stream));        // nw0 lives on this stack frame
+      }
     }
   }
   // ---- priors per coordinate family and attribute group: [1 + k][2][NG] = lambda[NG] then mu[NG]
   const uint32_t NG = h->num_groups;
   const int kf = h->cfg.num_factor;
   const bool tabs = opts->num_groups != 0;
-  a.prior_host.resize((size_t)(1 + kf) * 2 * NG);
-  for (uint32_t g = 0; g < NG; g++) {
-    a.prior_host[g] = (tabs && opts->w_lambda_g) ? opts->w_lambda_g[g] : opts->w_lambda;
-    a.prior_host[NG + g] = (tabs && opts->w_mu_g) ? opts->w_mu_g[g] : opts->w_mu;
-    for (int f = 0; f < kf; f++) {
-      double* row = a.prior_host.data() + (size_t)(1 + f) * 2 * NG;
-      row[g] = (tabs && opts->v_lambda_gf) ? opts->v_lambda_gf[(size_t)g * kf + f] : (opts->v_lambda_f ? opts->v_lambda_f[f] : opts->v_lambda);
-      row[NG + g] = (tabs && opts->v_mu_gf) ? opts->v_mu_gf[(size_t)g * kf + f] : (opts->v_mu_f ? opts->v_mu_f[f] : opts->v_mu);
+  std::vector<int> lanes(P);
+  for (size_t i = 0; i < P; i++) {
+    fmx_handle x = hs[i];
+    AlsState& a = x->als;
+    HIPCHK(x, hipSetDevice(x->device));
+    a.prior_host.resize((size_t)(1 + kf) * 2 * NG);
+    for (uint32_t gg = 0; gg < NG; gg++) {
+      a.prior_host[gg] = (tabs && opts->w_lambda_g) ? opts->w_lambda_g[gg] : opts->w_lambda;
+      a.prior_host[NG + gg] = (tabs && opts->w_mu_g) ? opts->w_mu_g[gg] : opts->w_mu;
+      for (int f = 0; f < kf; f++) {
+        double* row = a.prior_host.data() + (size_t)(1 + f) * 2 * NG;
+        row[gg] = (tabs && opts->v_lambda_gf) ? opts->v_lambda_gf[(size_t)gg * kf + f] : (opts->v_lambda_f ? opts->v_lambda_f[f] : opts->v_lambda);
+        row[NG + gg] = (tabs && opts->v_mu_gf) ? opts->v_mu_gf[(size_t)gg * kf + f] : (opts->v_mu_f ? opts->v_mu_f[f] : opts->v_mu);
+      }
     }
+    if (!a.prior) HIPCHK(x, hipMalloc(&a.prior, a.prior_host.size() * sizeof(double)));
+    HIPCHK(x, hipMemcpyAsync(a.prior, a.prior_host.data(), a.prior_host.size() * sizeof(double), hipMemcpyHostToDevice, x->stream));
+    // lanes per column from the mean column length (one-hot data: a handful of rows per feature)
+    const Slot& s = x->slots[a.slot];
+    const double avg_col = s.nseg ? (double)s.nnz / (double)s.nseg : 0.0;
+    lanes[i] = avg_col <= 5.0 ? 4 : (avg_col <= 12.0 ? 8 : (avg_col <= 40.0 ? 16 : 64));
   }
-  if (!a.prior) HIPCHK(h, hipMalloc(&a.prior, a.prior_host.size() * sizeof(double)));
-  HIPCHK(h, hipMemcpyAsync(a.prior, a.prior_host.data(), a.prior_host.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  const uint32_t nseg = s.nseg, nnz = (uint32_t)s.nnz;
-  const dim3 gu((uint32_t)std::min<uint64_t>((h->n_local + 255) / 256, 2048));
-  // lanes per column from the mean column length (one-hot data: a handful of rows per feature)
-  const double avg_col = nseg ? (double)nnz / (double)nseg : 0.0;
-  const int G = avg_col <= 5.0 ? 4 : (avg_col <= 12.0 ? 8 : (avg_col <= 40.0 ? 16 : 64));
 #define FMX_ALS_DRAW(ISV, cnt, ...)                                                                          \
   do {                                                                                                        \
     if (G == 4)       FMX_LAUNCH_WAVES((k_als_draw<ISV, 4>), ((uint64_t)(cnt) + 15) / 16, st, __VA_ARGS__);    \
@@ -201,70 +219,275 @@ int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) 
     else if (G == 16) FMX_LAUNCH_WAVES((k_als_draw<ISV, 16>), ((uint64_t)(cnt) + 3) / 4, st, __VA_ARGS__);     \
     else              FMX_LAUNCH_WAVES((k_als_draw<ISV, 64>), (uint64_t)(cnt), st, __VA_ARGS__);               \
   } while (0)
-  if (h->cfg.k1) {                                         // draw_w per level, :454-476
-    for (uint32_t l = 0; l < n_levels; l++) {
+  // one (family, level) step on every shard, then -- shards only -- the exchange of the recorded changes
+  auto level_step = [&](uint32_t l, int f /* -1: linear weights */) -> int {
+    bool any = false;
+    for (size_t i = 0; i < P; i++) {
+      fmx_handle h = hs[i];                                  // (the launch macros refer to `h`)
+      AlsState& a = h->als;
+      const Slot& s = h->slots[a.slot];
       const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
       if (!cnt) continue;
-      FMX_ALS_DRAW(false, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                   h->tb.w, h->tb.ws, 0, 0u, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
-                   opts->seed, (uint64_t)(a.iter * 1024 + 1000));
+      any = true;
+      HIPCHK(h, hipSetDevice(h->device));
+      hipStream_t st = h->stream;
+      const int G = lanes[i];
+      const Shard sh = make_shard(h->cfg);
+      EQ* delta = sharded ? a.delta : nullptr;
+      const uint32_t nseg = s.nseg, nnz = (uint32_t)s.nnz;
+      if (f < 0) {
+        FMX_ALS_DRAW(false, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                     h->tb.w, h->tb.ws, 0, 0u, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
+                     opts->seed, (uint64_t)(a.iter * 1024 + 1000), sh, delta);
+      } else {
+        const double* v_lambda = a.prior + (size_t)(1 + f) * 2 * NG;
+        const double* v_mu = v_lambda + NG;
+        if (a.vt)
+          FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                       a.vt + (size_t)f * a.vt_stride, 1u, 1, a.level_ptr[l], a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
+                       opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta);
+        else
+          FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+                       h->tb.V + f, h->tb.rs, 0, 0u, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
+                       opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta);
+      }
+      HIPCHK(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, st, a.seen, h->n_local, h->tb.w, h->tb.ws, a.prior, a.prior + NG, h->grp,
-                       opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 1001));
+    if (sharded && any) {
+      std::vector<double*> bufs(P);
+      for (size_t i = 0; i < P; i++) bufs[i] = reinterpret_cast<double*>(hs[i]->als.delta);
+      int rc = group_allreduce_f64(g, bufs, (size_t)N * 2);
+      if (rc) return rc;
+      for (fmx_handle x : hs) {
+        HIPCHK(x, hipSetDevice(x->device));
+        hipLaunchKernelGGL(k_als_apply_delta, g1, b1, 0, x->stream, x->als.e, x->als.delta, N);
+        HIPCHK(x, hipGetLastError());
+      }
+    }
+    return FMX_OK;
+  };
+  if (h->cfg.k1) {                                         // draw_w per level, :454-476
+    for (uint32_t l = 0; l < n_levels; l++) { int rc = level_step(l, -1); if (rc) return rc; }
+    for (fmx_handle x : hs) {
+      HIPCHK(x, hipSetDevice(x->device));
+      const dim3 gu((uint32_t)std::min<uint64_t>((x->n_local + 255) / 256, 2048));
+      hipLaunchKernelGGL(k_als_unseen, gu, b1, 0, x->stream, x->als.seen, x->n_local, x->tb.w, x->tb.ws, x->als.prior, x->als.prior + NG, x->grp,
+                         opts->do_sample, opts->seed, (uint64_t)(x->als.iter * 1024 + 1001), make_shard(x->cfg));
+    }
   }
   // the factors of the features with a training column, factor-major for the duration of the sweep (k_als_shadow)
-  const bool shadow = a.vt != nullptr && nseg > 0 && h->cfg.num_factor > 0;
-  if (shadow) {
-    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_als_shadow<KP, true>), dim3(std::min<uint32_t>((nseg + 63) / 64, 4096)), dim3(256), 0, st,
-                                          a.level_list, s.seg_feat, nseg, h->tb, a.vt, a.vt_stride));
+  for (fmx_handle h : hs) {
+    AlsState& a = h->als;
+    const Slot& s = h->slots[a.slot];
+    if (!a.vt || !s.nseg) continue;
+    HIPCHK(h, hipSetDevice(h->device));
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_als_shadow<KP, true>), dim3(std::min<uint32_t>((s.nseg + 63) / 64, 4096)), dim3(256), 0, h->stream,
+                                          a.level_list, s.seg_feat, s.nseg, h->tb, a.vt, a.vt_stride));
   }
-  for (int f = 0; f < h->cfg.num_factor; f++) {            // per factor: q_f is ready (k_als_eterms), draw_v per level :528-595
-    double* qf = a.q + (size_t)f * N;
-    const double* v_lambda = a.prior + (size_t)(1 + f) * 2 * NG;
-    const double* v_mu = v_lambda + NG;
-    hipLaunchKernelGGL(k_als_load_q, g1, b1, 0, st, a.e, qf, N);
-    for (uint32_t l = 0; l < n_levels; l++) {
-      const uint32_t cnt = a.level_ptr[l + 1] - a.level_ptr[l];
-      if (!cnt) continue;
-      if (shadow)
-        FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                     a.vt + (size_t)f * a.vt_stride, 1u, 1, a.level_ptr[l], a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
-                     opts->seed, (uint64_t)(a.iter * 1024 + f));
-      else
-        FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
-                     h->tb.V + f, h->tb.rs, 0, 0u, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
-                     opts->seed, (uint64_t)(a.iter * 1024 + f));
+  for (int f = 0; f < kf; f++) {                            // per factor: q_f is ready (k_als_eterms), draw_v per level :528-595
+    for (fmx_handle x : hs) {
+      HIPCHK(x, hipSetDevice(x->device));
+      hipLaunchKernelGGL(k_als_load_q, g1, b1, 0, x->stream, x->als.e, x->als.q + (size_t)f * N, N);
+    }
+    for (uint32_t l = 0; l < n_levels; l++) { int rc = level_step(l, f); if (rc) return rc; }
+  }
+  for (fmx_handle h : hs) {
+    AlsState& a = h->als;
+    const Slot& s = h->slots[a.slot];
+    HIPCHK(h, hipSetDevice(h->device));
+    if (a.vt && s.nseg)
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_als_shadow<KP, false>), dim3(std::min<uint32_t>((s.nseg + 63) / 64, 4096)), dim3(256), 0, h->stream,
+                                            a.level_list, s.seg_feat, s.nseg, h->tb, a.vt, a.vt_stride));
+    if (kf > 0) {                                          // empty-row draws of every factor (:586-595) in one pass
+      hipStream_t st = h->stream;
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_unseen_v<KP>), (h->n_local + Map<KP>::EPI - 1) / Map<KP>::EPI, st, a.seen, h->n_local,
+                                         h->tb, kf, a.prior, NG, h->grp, opts->do_sample, opts->seed,
+                                         (uint64_t)(a.iter * 1024 + 512), make_shard(h->cfg)));
+    }
+    HIPCHK(h, hipGetLastError());
+  }
+#undef FMX_ALS_DRAW
+  // full re-prediction (fm_learn_mcmc_simultaneous.h:122), train metric and new residuals (:139-196)
+  for (fmx_handle x : hs) {
+    AlsState& a = x->als;
+    HIPCHK(x, hipSetDevice(x->device));
+    int rc = als_eterms(x, x->slots[a.slot], a.e, a.q, sharded ? a.epart : nullptr);
+    if (rc) return rc;
+  }
+  if (sharded) {
+    std::vector<double*> bq(P), be(P);
+    for (size_t i = 0; i < P; i++) { bq[i] = hs[i]->als.q; be[i] = hs[i]->als.epart; }
+    int rc = kf > 0 ? group_allreduce_f64(g, bq, (size_t)kf * N) : FMX_OK;      // q is [KP][N]: the first k factor rows
+    if (rc == FMX_OK) rc = group_allreduce_f64(g, be, N);
+    if (rc) return rc;
+    for (fmx_handle x : hs) {
+      HIPCHK(x, hipSetDevice(x->device));
+      hipLaunchKernelGGL(k_als_set_e, g1, b1, 0, x->stream, x->als.e, x->als.epart, N, x->cfg.k0, x->w0);
     }
   }
-  if (shadow) {
-    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_als_shadow<KP, false>), dim3(std::min<uint32_t>((nseg + 63) / 64, 4096)), dim3(256), 0, st,
-                                          a.level_list, s.seg_feat, nseg, h->tb, a.vt, a.vt_stride));
+  for (fmx_handle x : hs) {
+    AlsState& a = x->als;
+    const Slot& s = x->slots[a.slot];
+    HIPCHK(x, hipSetDevice(x->device));
+    HIPCHK(x, hipMemsetAsync(x->acc, 0, 4 * sizeof(double), x->stream));
+    hipLaunchKernelGGL(k_als_targets, g1, b1, 0, x->stream, a.e, s.target, N, x->cfg.task, x->cfg.min_target, x->cfg.max_target, x->acc,
+                       opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 1002));
+    HIPCHK(x, hipGetLastError());
   }
-  if (h->cfg.num_factor > 0) {                             // empty-row draws of every factor (:586-595) in one pass
-    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_unseen_v<KP>), (h->n_local + Map<KP>::EPI - 1) / Map<KP>::EPI, st, a.seen, h->n_local,
-                                       h->tb, h->cfg.num_factor, a.prior, NG, h->grp, opts->do_sample, opts->seed,
-                                       (uint64_t)(a.iter * 1024 + 512)));
-  }
-  HIPCHK(h, hipGetLastError());
-  // full re-prediction (fm_learn_mcmc_simultaneous.h:122), train metric and new residuals (:139-196)
-  int rc = als_eterms(h, s, a.e, a.q);
-  if (rc) return rc;
-  HIPCHK(h, hipMemsetAsync(h->acc, 0, 4 * sizeof(double), st));
-  hipLaunchKernelGGL(k_als_targets, g1, b1, 0, st, a.e, s.target, N, h->cfg.task, h->cfg.min_target, h->cfg.max_target, h->acc,
-                     opts->do_sample, opts->seed, (uint64_t)(a.iter * 1024 + 1002));
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipEventRecord(h->ev1, st));
-  HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  a.iter++;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipMemcpyAsync(acc, h->acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+  for (fmx_handle x : hs) { HIPCHK(x, hipSetDevice(x->device)); HIPCHK(x, hipStreamSynchronize(x->stream)); x->als.iter++; }
   if (stats) {
     float ms = 0;
+    HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     stats->device_seconds = ms * 1e-3;
     stats->levels = n_levels;
     stats->train_metric = (h->cfg.task == FMX_TASK_REGRESSION) ? std::sqrt(acc[0] / N) : acc[0] / N;
   }
   return FMX_OK;
+}
+
+// ---- fm_learn_mcmc over feature shards (fmx_group) --------------------------------------------------------------
+// fmx_group_als_begin: every shard builds X^T of its own features; the dependency LEVELS are computed over the union of
+// the shards' columns in GLOBAL feature order (level(j) = 1 + max level of the smaller-id features sharing a row with j),
+// so that "level by level, every shard its features of the level" is exactly the reference's sequential sweep.
+int fmx_group_als_begin(fmx_group g, int train_slot) {
+  if (!g) return FMX_E_ARG;
+  for (fmx_handle x : g->hs) if (!x) return FMX_E_STATE;
+  fmx_handle h = g->hs[0];
+  if (g->kind == GROUP_SINGLE) { int rc = fmx_als_begin(h, train_slot); if (rc) g->err = h->err; return rc; }
+  const size_t P = g->hs.size();
+  struct Col { uint32_t gid, shard, seg; };
+  std::vector<Col> cols;
+  std::vector<std::vector<uint32_t>> seg_feat(P), seg_rel(P);
+  std::vector<std::vector<TEntry>> tent(P);
+  uint32_t N = 0;
+  auto bail = [&](int rc, fmx_handle x) { g->err = x->err; for (fmx_handle y : g->hs) als_free(y); return rc; };
+  for (size_t i = 0; i < P; i++) {
+    fmx_handle x = g->hs[i];
+    int rc = check_slot(x, train_slot, true);
+    if (rc == FMX_OK) rc = lag_flush(x);
+    if (rc) return bail(rc, x);
+    if (hipSetDevice(x->device) != hipSuccess || hipStreamSynchronize(x->stream) != hipSuccess) return bail(fail(x, FMX_E_HIP, "fmx_group_als_begin: device %d", x->device), x);
+    als_free(x);
+    Slot& s = x->slots[train_slot];
+    if (s.n_rows == 0) return bail(fail(x, FMX_E_ARG, "fmx_group_als_begin: empty training set"), x);
+    if (i == 0) N = s.n_rows; else if (s.n_rows != N) return bail(fail(x, FMX_E_STATE, "the shards hold different numbers of rows"), x);
+    rc = ensure_segments(x, s, s.n_rows);
+    if (rc) return bail(rc, x);
+    x->als.slot = train_slot;
+    const uint32_t nseg = s.nseg;
+    seg_feat[i].resize(nseg); seg_rel[i].resize((size_t)nseg + 1); tent[i].resize((size_t)s.nnz);
+    if (nseg) {
+      if (hipMemcpy(seg_feat[i].data(), s.seg_feat, (size_t)nseg * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(seg_rel[i].data(), s.seg_rel, (size_t)nseg * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(tent[i].data(), s.t_ent, (size_t)s.nnz * sizeof(TEntry), hipMemcpyDeviceToHost) != hipSuccess)
+        return bail(fail(x, FMX_E_HIP, "fmx_group_als_begin: copying the columns of shard %zu failed", i), x);
+    }
+    seg_rel[i][nseg] = (uint32_t)s.nnz;
+    const Shard sh = make_shard(x->cfg);
+    for (uint32_t sg = 0; sg < nseg; sg++) cols.push_back(Col{sh.global(seg_feat[i][sg]), (uint32_t)i, sg});
+  }
+  std::sort(cols.begin(), cols.end(), [](const Col& a, const Col& b) { return a.gid < b.gid; });
+  std::vector<uint32_t> rowlevel(N, 0);
+  std::vector<std::vector<uint32_t>> lvl(P);
+  for (size_t i = 0; i < P; i++) lvl[i].resize(seg_feat[i].size());
+  uint32_t n_levels = 0;
+  for (const Col& c : cols) {
+    const auto& rel = seg_rel[c.shard];
+    const auto& te = tent[c.shard];
+    uint32_t l = 0;
+    for (uint32_t q = rel[c.seg]; q < rel[c.seg + 1]; q++) l = std::max(l, rowlevel[te[q].e]);
+    l += 1;
+    for (uint32_t q = rel[c.seg]; q < rel[c.seg + 1]; q++) rowlevel[te[q].e] = l;
+    lvl[c.shard][c.seg] = l - 1;
+    n_levels = std::max(n_levels, l);
+  }
+  for (size_t i = 0; i < P; i++) {
+    fmx_handle x = g->hs[i];
+    AlsState& a = x->als;
+    Slot& s = x->slots[train_slot];
+    const uint32_t nseg = s.nseg;
+    a.level_ptr.assign((size_t)n_levels + 1, 0);                  // the SAME number of levels on every shard (some may be empty)
+    for (uint32_t sg = 0; sg < nseg; sg++) a.level_ptr[lvl[i][sg] + 1]++;
+    for (uint32_t l = 0; l < n_levels; l++) a.level_ptr[l + 1] += a.level_ptr[l];
+    std::vector<uint32_t> list(std::max<uint32_t>(nseg, 1)), fill(a.level_ptr.begin(), a.level_ptr.end());
+    for (uint32_t sg = 0; sg < nseg; sg++) list[fill[lvl[i][sg]]++] = sg;
+    std::vector<uint8_t> seen((size_t)x->n_local, 0);
+    for (uint32_t sg = 0; sg < nseg; sg++) seen[seg_feat[i][sg]] = 1;
+    hipError_t er = hipSetDevice(x->device);
+    if (er == hipSuccess) er = hipMalloc(&a.level_list, list.size() * 4);
+    if (er == hipSuccess) er = hipMemcpy(a.level_list, list.data(), list.size() * 4, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMalloc(&a.seen, seen.size());
+    if (er == hipSuccess) er = hipMemcpy(a.seen, seen.data(), seen.size(), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMalloc(&a.e, (size_t)N * sizeof(EQ));
+    if (er == hipSuccess) er = hipMalloc(&a.q, (size_t)N * (size_t)x->KP * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc(&a.delta, (size_t)N * sizeof(EQ));
+    if (er == hipSuccess) er = hipMemsetAsync(a.delta, 0, (size_t)N * sizeof(EQ), x->stream);
+    if (er == hipSuccess) er = hipMalloc(&a.epart, (size_t)N * sizeof(double));
+    if (er == hipSuccess && x->cfg.num_factor > 0 && nseg > 0 && !getenv("FMX_ALS_NO_SHADOW")) {
+      a.vt_stride = ((size_t)nseg + 63) & ~(size_t)63;
+      er = hipMalloc(&a.vt, (size_t)x->cfg.num_factor * a.vt_stride * sizeof(float));
+    }
+    if (er != hipSuccess) return bail(fail(x, FMX_E_HIP, "fmx_group_als_begin: %s", hipGetErrorString(er)), x);
+    // first prediction (fm_learn_mcmc_simultaneous.h:69-86): partial sums of this shard
+    int rc = als_eterms(x, s, a.e, a.q, a.epart);
+    if (rc) return bail(rc, x);
+  }
+  {
+    std::vector<double*> bq(P), be(P);
+    for (size_t i = 0; i < P; i++) { bq[i] = g->hs[i]->als.q; be[i] = g->hs[i]->als.epart; }
+    int rc = h->cfg.num_factor > 0 ? group_allreduce_f64(g, bq, (size_t)h->cfg.num_factor * N) : FMX_OK;
+    if (rc == FMX_OK) rc = group_allreduce_f64(g, be, N);
+    if (rc) return bail(rc, h);
+  }
+  const dim3 g1(std::min<uint32_t>((N + 255) / 256, 2048)), b1(256);
+  for (fmx_handle x : g->hs) {
+    hipSetDevice(x->device);
+    hipLaunchKernelGGL(k_als_set_e, g1, b1, 0, x->stream, x->als.e, x->als.epart, N, x->cfg.k0, x->w0);
+    hipLaunchKernelGGL(k_als_sub_target, g1, b1, 0, x->stream, x->als.e, x->slots[train_slot].target, N);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(x->stream) != hipSuccess)
+      return bail(fail(x, FMX_E_HIP, "fmx_group_als_begin: first prediction failed on shard device %d", x->device), x);
+  }
+  return FMX_OK;
+}
+
+int fmx_group_als_sweep(fmx_group g, const fmx_als_opts* opts, fmx_als_stats* stats) {
+  if (!g || !opts) return FMX_E_ARG;
+  for (fmx_handle x : g->hs) if (!x) return FMX_E_STATE;
+  int rc = als_sweep_shards(g->hs, g->kind == GROUP_SINGLE ? nullptr : g, opts, stats);
+  if (rc) g->err = g->hs[0]->err;
+  return rc;
+}
+
+// fmx_als_moments over the shards: the residual statistics are those of the (replicated) cache, the per-group parameter
+// sums add up over the shards
+int fmx_group_als_moments(fmx_group g, double* out) {
+  if (!g || !out) return FMX_E_ARG;
+  fmx_handle h = g->hs[0];
+  const size_t cnt = 2 + 2 * (size_t)h->num_groups * (size_t)(1 + h->cfg.num_factor);
+  std::vector<double> part(cnt);
+  for (size_t i = 0; i < g->hs.size(); i++) {
+    int rc = fmx_als_moments(g->hs[i], part.data());
+    if (rc) { g->err = g->hs[i]->err; return rc; }
+    if (i == 0) memcpy(out, part.data(), cnt * sizeof(double));
+    else for (size_t c = 2; c < cnt; c++) out[c] += part[c];
+  }
+  return FMX_OK;
+}
+
+int fmx_group_als_end(fmx_group g) {
+  if (!g) return FMX_E_ARG;
+  for (fmx_handle x : g->hs) if (x) { int rc = fmx_als_end(x); if (rc) { g->err = x->err; return rc; } }
+  return FMX_OK;
+}
+
+int fmx_als_sweep(fmx_handle h, const fmx_als_opts* opts, fmx_als_stats* stats) {
+  if (!h || !opts) return FMX_E_ARG;
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_STATE, "fmx_als_sweep on a feature shard: use fmx_group_als_sweep");
+  return als_sweep_shards(std::vector<fmx_handle>(1, h), nullptr, opts, stats);
 }
 
 }  // extern "C"

@@ -47,7 +47,8 @@ __device__ __forceinline__ double ref_cdf_gaussian(double x) { return 0.5 + 0.5 
 template <int KP>
 __global__ void __launch_bounds__(256)
 k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, const Tab tb,
-             int k0, int k1, const double* __restrict__ w0_ptr, EQ* __restrict__ eq, double* __restrict__ q /* [KP][n_rows] or null */) {
+             int k0, int k1, const double* __restrict__ w0_ptr, EQ* __restrict__ eq, double* __restrict__ q /* [KP][n_rows] or null */,
+             double* __restrict__ e_part /* feature shard: y-hat WITHOUT the bias goes here (summed over the shards later) */) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x & 63u;
   const bool act = lane < LPR;
@@ -85,7 +86,7 @@ k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
       }
     }
     part = wave_sum_f64(part);
-    if (lane == 0) eq[c].e = w0 + part;
+    if (lane == 0) { if (e_part) e_part[c] = part; else eq[c].e = w0 + part; }
   }
 }
 
@@ -96,6 +97,23 @@ static __global__ void k_als_sub_target(EQ* __restrict__ eq, const float* __rest
 // add_main_q (:406-428) for factor f was evaluated by k_als_eterms; move it next to e for the coming sweep
 static __global__ void k_als_load_q(EQ* __restrict__ eq, const double* __restrict__ qf, uint32_t n) {
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].q = qf[c];
+}
+
+// feature shards: after the all-reduce of the partial predictions  e = w0 + sum over the shards
+static __global__ void k_als_set_e(EQ* __restrict__ eq, const double* __restrict__ e_sum, uint32_t n, int k0, const double* __restrict__ w0_ptr) {
+  const double w0 = k0 ? *w0_ptr : 0.0;
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].e = w0 + e_sum[c];
+}
+// feature shards: the draws of a level RECORD what they would do to {e, q} (delta[row], rows disjoint inside a level);
+// after the all-reduce every shard applies the same sum, so the replicas of the cache stay identical bit for bit
+static __global__ void k_als_apply_delta(EQ* __restrict__ eq, EQ* __restrict__ delta, uint32_t n) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    const EQ d = delta[c];
+    if (d.e != 0.0 || d.q != 0.0) {
+      EQ v = eq[c]; v.e += d.e; v.q += d.q; eq[c] = v;
+      EQ z; z.e = 0.0; z.q = 0.0; delta[c] = z;
+    }
+  }
 }
 
 // counter-based uniforms / normals for the Gibbs variant (statistical, not bitwise, parity with libc rand())
@@ -342,7 +360,9 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
            uint32_t nseg_total, uint32_t nnz, const uint32_t* __restrict__ seg_list, uint32_t n_list,
            float* __restrict__ param, uint32_t pstride, int param_by_pos, uint32_t pos0, EQ* __restrict__ eq,
            double alpha, const double* __restrict__ lambda_g, const double* __restrict__ mu_g, const uint32_t* __restrict__ attr_group,
-           int do_sample, uint64_t seed, uint64_t stream) {
+           int do_sample, uint64_t seed, uint64_t stream, const Shard sh, EQ* __restrict__ delta) {
+  // sh: the Gibbs noise of a coordinate is keyed by the feature's GLOBAL id, so a sharded chain draws what the unsharded
+  // one draws.  delta != nullptr (feature shards): {e, q} are left alone and the change is recorded instead.
   constexpr uint32_t GPW = 64 / G;                      // feature groups per wavefront
   const uint32_t lane = (threadIdx.x & 63u) % G;         // lane inside its group
   const uint32_t grp = (threadIdx.x & 63u) / G;
@@ -377,7 +397,7 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
     double mean = -sigma_sqr * (alpha * t_he - mu * lambda);
     double nt;
     if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
-    else nt = do_sample ? mean + sqrt(sigma_sqr) * gauss_hash(seed, stream, j) : mean;
+    else nt = do_sample ? mean + sqrt(sigma_sqr) * gauss_hash(seed, stream, sh.global(j)) : mean;
     if (isnan(nt) || isinf(nt)) continue;                          // keep the old value, caches untouched
     const float ntf = (float)nt;
     const double d = th - (double)ntf;                             // theta_old - theta (of the STORED value)
@@ -402,7 +422,7 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
             qc -= x * d;
             ec -= h * d;
           }
-          c.q = qc;
+          c.q = delta ? qc - c.q : qc;
         } else {
           for (uint32_t i2 = i; i2 < b; i2++) {
             const TEntry t2 = als_stream8(t_ent + i2);
@@ -410,8 +430,8 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
             ec -= (double)t2.x * d;
           }
         }
-        c.e = ec;
-        eq[te.e] = c;                                              // one 16-byte store
+        if (delta) { EQ dd; dd.e = ec - c.e; dd.q = IS_V ? c.q : 0.0; delta[te.e] = dd; }   // (c.q already holds qc - q_old below)
+        else { c.e = ec; eq[te.e] = c; }                           // one 16-byte store
       }
     }
   }
@@ -422,7 +442,7 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
 static __global__ void __launch_bounds__(256)
 k_als_unseen(const uint8_t* __restrict__ seen, uint64_t n_local, float* __restrict__ param, uint32_t pstride,
              const double* __restrict__ lambda_g, const double* __restrict__ mu_g, const uint32_t* __restrict__ grp,
-             int do_sample, uint64_t seed, uint64_t stream) {
+             int do_sample, uint64_t seed, uint64_t stream, const Shard sh) {
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_local; j += (uint64_t)gridDim.x * blockDim.x)
     if (!seen[j]) {
       const uint32_t g = grp ? grp[j] : 0u;
@@ -430,7 +450,7 @@ k_als_unseen(const uint8_t* __restrict__ seen, uint64_t n_local, float* __restri
       const double sigma_sqr = 1.0 / lambda;
       double nt;
       if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
-      else nt = do_sample ? mu + sqrt(sigma_sqr) * gauss_hash(seed, stream, j) : mu;
+      else nt = do_sample ? mu + sqrt(sigma_sqr) * gauss_hash(seed, stream, sh.global(j)) : mu;
       if (isnan(nt) || isinf(nt)) continue;
       param[(size_t)j * pstride] = (float)nt;
     }
@@ -444,7 +464,7 @@ k_als_unseen(const uint8_t* __restrict__ seen, uint64_t n_local, float* __restri
 template <int KP>
 __global__ void __launch_bounds__(256)
 k_als_unseen_v(const uint8_t* __restrict__ seen, uint64_t n_local, const Tab tb, int k, const double* __restrict__ prior, uint32_t G,
-               const uint32_t* __restrict__ grp, int do_sample, uint64_t seed, uint64_t stream0) {
+               const uint32_t* __restrict__ grp, int do_sample, uint64_t seed, uint64_t stream0, const Shard sh) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u, sub = lane / LPR, fl = lane % LPR;
   const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -462,7 +482,7 @@ k_als_unseen_v(const uint8_t* __restrict__ seen, uint64_t n_local, const Tab tb,
       const double sigma_sqr = 1.0 / lambda;
       double nt;
       if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
-      else nt = do_sample ? mu + sqrt(sigma_sqr) * gauss_hash(seed, stream0 + (uint64_t)f, j) : mu;
+      else nt = do_sample ? mu + sqrt(sigma_sqr) * gauss_hash(seed, stream0 + (uint64_t)f, sh.global(j)) : mu;
       if (isnan(nt) || isinf(nt)) continue;
       tb.V[(size_t)j * tb.rs + f] = (float)nt;
     }

@@ -71,18 +71,6 @@ __global__ void __launch_bounds__(256) k_sum_shards(BufList bufs, float* __restr
 
 }  // namespace
 
-enum { GROUP_SINGLE = 0, GROUP_LOOPBACK = 1, GROUP_RCCL = 2 };
-
-struct fmx_group_s {
-  std::vector<fmx_handle> hs;
-  int kind = GROUP_SINGLE;
-  std::vector<ncclComm_t> comms;          // GROUP_RCCL: one per handle
-  bool owns_comms = false;                // created by fmx_group_create (not borrowed from fmx_comm_init_rank)
-  std::vector<hipEvent_t> ev_part;        // loopback: partial sums of shard i are ready
-  hipEvent_t ev_sum = nullptr;            // loopback: the sum is ready
-  std::string err;
-};
-
 static int gfail(fmx_group g, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
@@ -126,7 +114,7 @@ static int exchange_begin(fmx_group g, int which, size_t count) {
     for (size_t i = 0; i < n; i++) {
       fmx_handle h = g->hs[i];
       HIPCHK(h, hipSetDevice(h->device));
-      NCCLCHK(h, R->AllReduce(h->xbuf[which], h->xbuf[which], count, ncclFloat32, ncclSum, g->comms[i], h->stream_comm));
+      NCCLCHK(h, R->AllReduce(h->xbuf[which], h->xbuf[which], count, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
     }
     if (n > 1) NCCLCHK(g->hs[0], R->GroupEnd());
     for (size_t i = 0; i < n; i++) {
@@ -155,6 +143,46 @@ static int exchange_end(fmx_group g, int which) {
     for (fmx_handle h : g->hs) { HIPCHK(h, hipSetDevice(h->device)); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_x[2 + which], 0)); }
   return FMX_OK;
 }
+// in-place sum of one fp64 buffer per shard (ALS / MCMC: the {e, q} changes of a level, the partial re-prediction),
+// enqueued on the shards' own streams.  Loopback: every shard's buffer receives the total (same order of addition for all).
+template <class T> struct PtrList { T* p[16]; int n; };
+__global__ void __launch_bounds__(256) k_allsum_f64(PtrList<double> bufs, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double a = bufs.p[0][i];
+    for (int r = 1; r < bufs.n; r++) a += bufs.p[r][i];
+    for (int r = 0; r < bufs.n; r++) bufs.p[r][i] = a;
+  }
+}
+int group_allreduce_f64(fmx_group_s* g, const std::vector<double*>& bufs, size_t count) {
+  const size_t n = g->hs.size();
+  if (count == 0 || n < 2) return FMX_OK;
+  if (g->kind == GROUP_RCCL) {
+    Rccl* R = rccl();
+    NCCLCHK(g->hs[0], R->GroupStart());
+    for (size_t i = 0; i < n; i++) {
+      fmx_handle h = g->hs[i];
+      HIPCHK(h, hipSetDevice(h->device));
+      NCCLCHK(h, R->AllReduce(bufs[i], bufs[i], count, ncclFloat64, ncclSum, (ncclComm_t)g->comms[i], h->stream));
+    }
+    NCCLCHK(g->hs[0], R->GroupEnd());
+  } else if (g->kind == GROUP_LOOPBACK) {
+    fmx_handle h0 = g->hs[0];
+    HIPCHK(h0, hipSetDevice(h0->device));
+    PtrList<double> bl; bl.n = (int)n;
+    for (size_t i = 0; i < n; i++) {
+      bl.p[i] = bufs[i];
+      if (i) { HIPCHK(h0, hipEventRecord(g->ev_part[i], g->hs[i]->stream)); HIPCHK(h0, hipStreamWaitEvent(h0->stream, g->ev_part[i], 0)); }
+    }
+    hipLaunchKernelGGL(k_allsum_f64, dim3((unsigned)std::min<size_t>((count + 255) / 256, 2048)), dim3(256), 0, h0->stream, bl, count);
+    HIPCHK(h0, hipGetLastError());
+    HIPCHK(h0, hipEventRecord(g->ev_sum, h0->stream));
+    for (size_t i = 1; i < n; i++) HIPCHK(h0, hipStreamWaitEvent(g->hs[i]->stream, g->ev_sum, 0));
+  } else {
+    return fail(g->hs[0], FMX_E_STATE, "group_allreduce_f64: the group has no exchange");
+  }
+  return FMX_OK;
+}
+
 static const float* sum_of(fmx_group g, size_t i, int which) {
   return (g->kind == GROUP_LOOPBACK) ? g->hs[0]->xbuf[which] : g->hs[i]->xbuf[which];
 }
@@ -184,7 +212,7 @@ int comm_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_s
                                 "or drive fmx_sgd_partial + all-reduce + fmx_sgd_finish yourself");
   if (!h->group) {
     fmx_group g = new fmx_group_s();
-    g->hs.push_back(h); g->kind = GROUP_RCCL; g->comms.push_back((ncclComm_t)h->comm);
+    g->hs.push_back(h); g->kind = GROUP_RCCL; g->comms.push_back(h->comm);
     h->group = g; h->owns_group = true;
   }
   return fmx_group_sgd_epoch(h->group, slot, opts, stats);
@@ -278,7 +306,7 @@ int fmx_group_create(fmx_handle* handles, int n, fmx_group* out) {
     for (int j = 0; j < i; j++) { if (handles[i]->device != handles[j]->device) same_dev = false; else distinct = false; }
   if (n == 1) {
     g->kind = handles[0]->comm ? GROUP_RCCL : GROUP_SINGLE;           // one local shard of a multi-process job, or no sharding at all
-    if (handles[0]->comm) g->comms.push_back((ncclComm_t)handles[0]->comm);
+    if (handles[0]->comm) g->comms.push_back(handles[0]->comm);
   } else if (same_dev) {
     g->kind = GROUP_LOOPBACK;
     fmx_handle h0 = handles[0];
@@ -298,7 +326,7 @@ int fmx_group_create(fmx_handle* handles, int n, fmx_group* out) {
     if (r == ncclSuccess) r = R->GroupStart();                         // one thread, several devices: ranks initialised as a group
     for (int i = 0; r == ncclSuccess && i < n; i++) {
       hipSetDevice(handles[i]->device);
-      r = R->CommInitRank(&g->comms[i], n, id, i);
+      { ncclComm_t c = nullptr; r = R->CommInitRank(&c, n, id, i); g->comms[i] = c; }
     }
     if (r == ncclSuccess) r = R->GroupEnd();
     if (r != ncclSuccess) { int rc = fail(handles[0], FMX_E_HIP, "fmx_group_create: RCCL initialisation failed: %s", R->GetErrorString(r)); fmx_group_destroy(g); return rc; }
@@ -314,7 +342,7 @@ int fmx_group_create(fmx_handle* handles, int n, fmx_group* out) {
 int fmx_group_destroy(fmx_group g) {
   if (!g) return FMX_OK;
   for (auto h : g->hs) if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (h->group == g) { h->group = nullptr; h->owns_group = false; } }
-  if (g->owns_comms) if (Rccl* R = rccl()) for (auto c : g->comms) if (c) R->CommDestroy(c);
+  if (g->owns_comms) if (Rccl* R = rccl()) for (auto c : g->comms) if (c) R->CommDestroy((ncclComm_t)c);
   for (auto e : g->ev_part) if (e) hipEventDestroy(e);
   if (g->ev_sum) hipEventDestroy(g->ev_sum);
   delete g;

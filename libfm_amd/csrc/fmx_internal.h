@@ -57,6 +57,8 @@ struct AlsState {
   uint32_t* level_list = nullptr; // segments ordered by level
   std::vector<uint32_t> level_ptr;
   uint64_t  iter = 0;
+  EQ*       delta = nullptr;      // feature shards: [N] what the draws of the current (family, level) step change in {e, q}
+  double*   epart = nullptr;      // feature shards: [N] partial y-hat of the re-prediction
   float*    vt = nullptr;         // [num_factor][vt_stride] factor-major shadow of the seen features' factors, level order
   size_t    vt_stride = 0;
   double*   prior = nullptr;      // [1 + k][2][G]: per coordinate family (row 0 = w, 1+f = v_f) lambda[G] then mu[G]
@@ -131,6 +133,17 @@ int ensure_segments(fmx_handle h, Slot& s, uint32_t B);                 // fmx_s
 int lag_flush(fmx_handle h);                                             // fmx_sgd.hip
 void sgda_free(fmx_handle h);                                            // fmx_sgd.hip
 void als_free(fmx_handle h);                                             // fmx_als.hip
+enum { GROUP_SINGLE = 0, GROUP_LOOPBACK = 1, GROUP_RCCL = 2 };
+struct fmx_group_s {                      // fmx_comm.hip
+  std::vector<fmx_handle> hs;
+  int kind = GROUP_SINGLE;
+  std::vector<void*> comms;               // GROUP_RCCL: one ncclComm_t per handle
+  bool owns_comms = false;                // created by fmx_group_create (not borrowed from fmx_comm_init_rank)
+  std::vector<hipEvent_t> ev_part;        // loopback: the buffer of shard i is ready
+  hipEvent_t ev_sum = nullptr;            // loopback: the sum is ready
+  std::string err;
+};
+int group_allreduce_f64(fmx_group_s* g, const std::vector<double*>& bufs, size_t count);   // fmx_comm.hip: in place, on the shards' streams
 void comm_free(fmx_handle h);                                            // fmx_comm.hip: communicator, group membership, exchange buffers
 int comm_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats);   // fmx_comm.hip
 

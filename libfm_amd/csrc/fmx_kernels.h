@@ -929,7 +929,7 @@ k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
 enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2 };
 // FUSED_EXACT, what the launch of batch b carries along: the deferred features of batch b-1 (SegWork `prev`, n_items
 // blocks of 64 segments) are finished INSIDE this launch instead of by a kernel of their own between the two batches --
-// two kernel boundaries and the small kernel's ramp / drain per batch were ~8 % of the epoch.  Every wavefront first
+// two kernel boundaries and the small kernel's ramp / drain per batch were ~8 % of the epoch.  Every workgroup first
 // claims blocks of that work from a counter (ctr[0]) until none is left, publishes its part (release fence, ctr[1] +=
 // blocks done) and then turns to its examples.  The examples of batch b that touch one of those features ("dependent":
 // known when the batches are bucketed) are ordered LAST in `order`; a wavefront reaching its first dependent example
@@ -957,21 +957,32 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
   bool prev_done = true;
   if constexpr (EXACT) {
     if (fp.n_items) {
+      // blocks of the previous batch's deferred features, claimed 4 at a time by a WORKGROUP (one returning atomic per
+      // claim, and none once the counter is exhausted: 10 000 wavefronts hitting one word at launch start cost more than
+      // the work itself), one block per wavefront; ONE release per workgroup publishes them
+      __shared__ uint32_t s_base;
       prev_done = false;
-      uint32_t mine = 0;
+      const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+      uint32_t mine = 0;                                       // (thread 0) blocks this workgroup finished
       for (;;) {
-        uint32_t it = 0;
-        if (lane == 0) it = __hip_atomic_fetch_add(fp.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        it = __builtin_amdgcn_readfirstlane(it);
-        if (it >= fp.n_items) break;
-        apply_seg_block<KP, 8>(fp.prev, it * 64u, tb, h);
-        mine++;
+        if (threadIdx.x == 0) {
+          uint32_t cur = __hip_atomic_load(fp.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (cur < fp.n_items) cur = __hip_atomic_fetch_add(fp.ctr, wpb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_base = cur;
+        }
+        __syncthreads();
+        const uint32_t base = s_base;
+        __syncthreads();                                       // everybody has read s_base before thread 0 claims again
+        if (base >= fp.n_items) break;
+        if (base + wib < fp.n_items) apply_seg_block<KP, 8>(fp.prev, (base + wib) * 64u, tb, h);
+        if (threadIdx.x == 0) mine += min(wpb, fp.n_items - base);
       }
-      if (mine) {                                              // publish: stores drained, L2 written back, then the count
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wavefront's stores have left
+      __syncthreads();                                         // ... and those of the whole workgroup
+      if (threadIdx.x == 0 && mine) {                          // publish: L2 written back, then the count
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(fp.ctr + 1, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(fp.ctr + 1, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }

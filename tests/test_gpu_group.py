@@ -146,3 +146,72 @@ def test_group_at_bench_shape_matches_single_handle(capi):
     grp.close()
     for x in hs:
         x.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# ALS / MCMC over feature shards (fmx_group_als_*): global dependency levels, replicated {e, q} cache, one all-reduce per
+# (coordinate family, level).  Bar: the REAL reference's ALS results (golden fixtures) at 1e-4, whatever the shard count;
+# MCMC: the sharded chain draws what the unsharded chain draws (noise keyed by global feature id).
+# ---------------------------------------------------------------------------------------------
+ALS_CASES = ["als_reg_ml", "als_cls_ragged", "als_reg_fields_k16", "als_reg_nolin_dup", "als_reg_ml_groups"]
+
+
+def _als_group_run(capi, g, oracle, world, shard_hash, do_sample=False, seed=0, iters=None):
+    z = g.z
+    m = g.model(oracle, "init")
+    tr, te = g.data(oracle, "train"), g.data(oracle, "test")
+    hs = [capi.Handle(g.n, g.k, g.k0, g.k1, g.task, g.reg[0], g.reg[1], g.reg[2], 0.0, g.min_target, g.max_target, device=0,
+                      shard_rank=r, shard_world=world, shard_hash=shard_hash) for r in range(world)]
+    for h in hs:
+        h.set_params(m.w0, m.w, m.v)
+        if "group" in z.files:
+            h.set_groups(z["group"])
+        h.upload_rows(0, tr.entries, tr.row_ptr, tr.target)
+        h.upload_rows(1, te.entries, te.row_ptr, te.target)
+    grp = capi.Group(hs) if world > 1 else None
+    drv = grp if grp else hs[0]
+    wl, vl = (z["w_lambda_g"], z["v_lambda_g"][:, None] * np.ones((1, max(g.k, 1)))) if "group" in z.files else (g.reg[1], g.reg[2])
+    drv.als_begin(0)
+    metrics = []
+    for i in range(iters or g.iters):
+        st = drv.als_sweep(wl, vl, do_sample=do_sample, seed=seed)
+        metrics.append(st.train_metric)
+    pred = grp.predict(1, te.n_rows) if grp else hs[0].predict(1, te.n_rows)
+    mom = drv.als_moments()
+    drv.als_end()
+    w0, w, v = grp.get_params() if grp else hs[0].get_params()
+    if grp:
+        grp.close()
+    for h in hs:
+        h.close()
+    return w0, w, v, pred, metrics, mom
+
+
+@pytest.mark.parametrize("world,shard_hash", [(2, 0), (3, 1), (8, 1)])
+@pytest.mark.parametrize("name", ALS_CASES)
+def test_sharded_als_matches_reference(capi, oracle, name, world, shard_hash):
+    g = Golden(name)
+    z = g.z
+    w0, w, v, pred, metrics, _ = _als_group_run(capi, g, oracle, world, shard_hash)
+    assert abs(w0 - float(z["final_w0"])) <= 1e-4 * abs(float(z["final_w0"])) + 2e-5
+    np.testing.assert_allclose(w, z["final_w"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(v, z["final_v"], rtol=1e-4, atol=2e-5)
+    if g.task == 0:                                            # raw y-hat of the last iteration == the reference's pred_this
+        np.testing.assert_allclose(pred, z["pred_out"], rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("name", ["mcmc_reg_ml", "mcmc_cls_fields"])
+def test_sharded_mcmc_draws_what_the_unsharded_chain_draws(capi, oracle, name):
+    """do_sample = 1 with fixed hyper-parameters: 4 hashed shards vs one handle, same seed -> same chain (the Gibbs noise of a
+    coordinate is a hash of (seed, iteration, family, GLOBAL feature id); the probit targets a hash of the row)."""
+    g = Golden(name)
+    one = _als_group_run(capi, g, oracle, 1, 0, do_sample=True, seed=77, iters=6)
+    four = _als_group_run(capi, g, oracle, 4, 1, do_sample=True, seed=77, iters=6)
+    assert abs(one[0] - four[0]) <= 1e-6 * abs(one[0]) + 1e-7
+    np.testing.assert_allclose(four[1], one[1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(four[2], one[2], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(four[3], one[3], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(four[4], one[4], rtol=1e-6)
+    # the statistics of the hyper-prior draws: residual sums from the replicated cache, parameter sums added over the shards
+    np.testing.assert_allclose(four[5][0], one[5][0], rtol=1e-6)
+    np.testing.assert_allclose(four[5][2], one[5][2], rtol=1e-5, atol=1e-6)
