@@ -25,24 +25,34 @@
 class fm_learn_als_gpu : public fm_learn_mcmc {
  public:
   int gpu_device;
+  // several GPUs from this ONE process (BASELINE configs[4]): the devices of the feature shards; empty = one unsharded
+  // handle on gpu_device.  Distinct ordinals: RCCL; the same ordinal repeated: shards on one device (loopback exchange).
+  std::vector<int> gpu_devices;
   unsigned long long gpu_seed;                             // seed of the device-side coordinate draws (do_sample); 0 = derive
-  fm_learn_als_gpu() : gpu_device(-1), gpu_seed(0), h(NULL) {}   // it from libc rand(), i.e. from main's -seed (libfm.cpp:115-116)
-  virtual ~fm_learn_als_gpu() { if (h) fmx_destroy(h); }
+  fm_learn_als_gpu() : gpu_device(-1), gpu_seed(0), h(NULL), grp(NULL) {}   // it from libc rand(), i.e. from main's -seed (libfm.cpp:115-116)
+  virtual ~fm_learn_als_gpu() { if (grp) fmx_group_destroy(grp); for (size_t i = 0; i < hs.size(); i++) fmx_destroy(hs[i]); }
 
   virtual void learn(Data& train, Data& test) {            // fm_learn_mcmc::learn (:1160-1201) + _learn
     pred_sum_all.setSize(test.num_cases); pred_sum_all_but5.setSize(test.num_cases); pred_this.setSize(test.num_cases);
     pred_sum_all.init(0.0); pred_sum_all_but5.init(0.0); pred_this.init(0.0);
-    fmx_config c;
-    c.num_attribute = fm->num_attribute; c.num_factor = fm->num_factor; c.k0 = fm->k0; c.k1 = fm->k1;
-    c.task = task; c.reg0 = fm->reg0; c.regw = fm->regw; c.regv = fm->regv; c.learn_rate = 0;
-    c.min_target = min_target; c.max_target = max_target; c.device = gpu_device;
-    c.shard_rank = 0; c.shard_world = 1; c.shard_hash = 0;
-    if (fmx_create(&c, &h) != FMX_OK) throw std::string(fmx_last_error(NULL));
-    check(fmx_set_params(h, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
-    upload(0, train); upload(1, test);
+    const int world = gpu_devices.empty() ? 1 : (int)gpu_devices.size();
     const uint G = meta->num_attr_groups;
-    if (G > 1) check(fmx_set_groups(h, (const uint32_t*)meta->attr_group.value, G));   // DVector<uint>, Data.h:41
-    check(fmx_als_begin(h, 0));
+    for (int r = 0; r < world; r++) {
+      fmx_config c;
+      c.num_attribute = fm->num_attribute; c.num_factor = fm->num_factor; c.k0 = fm->k0; c.k1 = fm->k1;
+      c.task = task; c.reg0 = fm->reg0; c.regw = fm->regw; c.regv = fm->regv; c.learn_rate = 0;
+      c.min_target = min_target; c.max_target = max_target; c.device = gpu_devices.empty() ? gpu_device : gpu_devices[r];
+      c.shard_rank = r; c.shard_world = world; c.shard_hash = world > 1 ? 1 : 0;
+      fmx_handle x = NULL;
+      if (fmx_create(&c, &x) != FMX_OK) throw std::string(fmx_last_error(NULL));
+      hs.push_back(x);
+      if (r == 0) h = x;
+      if (fmx_set_params(x, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL) != FMX_OK) throw std::string(fmx_last_error(x));
+      if (G > 1 && fmx_set_groups(x, (const uint32_t*)meta->attr_group.value, G) != FMX_OK) throw std::string(fmx_last_error(x));   // DVector<uint>, Data.h:41
+    }
+    if (fmx_group_create(&hs[0], world, &grp) != FMX_OK) throw std::string(fmx_last_error(hs[0]));
+    upload(0, train); upload(1, test);
+    gcheck(fmx_group_als_begin(grp, 0));
     fmx_als_opts o;
     memset(&o, 0, sizeof(o));
     const int k = fm->num_factor;
@@ -51,7 +61,7 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
     std::vector<double> p(test.num_cases);
     for (uint i = 0; i < num_iter; i++) {
       if (do_multilevel) {                                                   // the prior draws of draw_all (:433-452, :519-527)
-        check(fmx_als_moments(h, &mom[0]));
+        gcheck(fmx_group_als_moments(grp, &mom[0]));
         draw_priors_from_moments(mom, train.num_cases);
       } else {
         alpha = alpha_0; w_mu.init(mu_0); if (k > 0) v_mu.init(mu_0);        // draw_alpha / draw_*_mu without multilevel
@@ -66,8 +76,8 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
         o.v_lambda_f = k > 0 ? v_lambda.value[0] : NULL; o.v_mu_f = k > 0 ? v_mu.value[0] : NULL;
       }
       fmx_als_stats st;
-      check(fmx_als_sweep(h, &o, &st));
-      check(fmx_predict(h, 1, p.empty() ? NULL : &p[0]));
+      gcheck(fmx_group_als_sweep(grp, &o, &st));
+      gcheck(fmx_group_predict(grp, 1, p.empty() ? NULL : &p[0]));
       double rmse_or_acc = 0;
       for (uint c2 = 0; c2 < test.num_cases; c2++) {                       // _learn :127-138 / :151-161
         double v = p[c2];
@@ -87,13 +97,17 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
       rmse_or_acc = (task == TASK_REGRESSION) ? std::sqrt(rmse_or_acc / test.num_cases) : rmse_or_acc / test.num_cases;
       std::cout << "#Iter=" << std::setw(3) << i << "\tTrain=" << st.train_metric << "\tTest=" << rmse_or_acc << std::endl;
     }
-    check(fmx_als_end(h));
-    check(fmx_get_params(h, &fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
+    gcheck(fmx_group_als_end(grp));
+    for (size_t r = 0; r < hs.size(); r++)                   // every shard writes its own features into the host block
+      if (fmx_get_params(hs[r], &fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL) != FMX_OK) throw std::string(fmx_last_error(hs[r]));
   }
 
  protected:
-  fmx_handle h;
+  fmx_handle h;                                            // shard 0 (the only handle without gpu_devices)
+  std::vector<fmx_handle> hs;
+  fmx_group grp;
   void check(int rc) { if (rc != FMX_OK) throw std::string(fmx_last_error(h)); }
+  void gcheck(int rc) { if (rc != FMX_OK) throw std::string(fmx_group_last_error(grp)); }
 
   // mom = fmx_als_moments: {sum e^2, sum e} then [1 + k][G][2] = per coordinate family and group {sum theta, sum theta^2}
   void draw_priors_from_moments(const std::vector<double>& mom, uint num_train_total) {
@@ -160,8 +174,10 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
       rel[r].data_row_to_relation_row = (const uint32_t*)d.relation(r).data_row_to_relation_row.value;
       rel[r].attr_offset = rd->attr_offset;
     }
-    check(fmx_upload_block_rows(h, slot, main.ent.empty() ? NULL : &main.ent[0], (const uint64_t*)&main.row_ptr[0], d.target.value,
-                                d.num_cases, main.ent.size(), rel.empty() ? NULL : &rel[0], (uint32_t)rel.size()));
+    for (size_t r = 0; r < hs.size(); r++)                   // (block-structured rows are refused on shards by the library)
+      if (fmx_upload_block_rows(hs[r], slot, main.ent.empty() ? NULL : &main.ent[0], (const uint64_t*)&main.row_ptr[0], d.target.value,
+                                d.num_cases, main.ent.size(), rel.empty() ? NULL : &rel[0], (uint32_t)rel.size()) != FMX_OK)
+        throw std::string(fmx_last_error(hs[r]));
   }
 };
 

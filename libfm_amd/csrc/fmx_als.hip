@@ -322,7 +322,7 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
     if (rc) return rc;
     for (fmx_handle x : hs) {
       HIPCHK(x, hipSetDevice(x->device));
-      hipLaunchKernelGGL(k_als_set_e, g1, b1, 0, x->stream, x->als.e, x->als.epart, N, x->cfg.k0, x->w0);
+      hipLaunchKernelGGL(k_als_set_e, g1, b1, 0, x->stream, x->als.e, x->als.epart, x->als.q, x->cfg.num_factor, N, x->cfg.k0, x->w0);
     }
   }
   for (fmx_handle x : hs) {
@@ -446,7 +446,7 @@ int fmx_group_als_begin(fmx_group g, int train_slot) {
   const dim3 g1(std::min<uint32_t>((N + 255) / 256, 2048)), b1(256);
   for (fmx_handle x : g->hs) {
     hipSetDevice(x->device);
-    hipLaunchKernelGGL(k_als_set_e, g1, b1, 0, x->stream, x->als.e, x->als.epart, N, x->cfg.k0, x->w0);
+    hipLaunchKernelGGL(k_als_set_e, g1, b1, 0, x->stream, x->als.e, x->als.epart, x->als.q, x->cfg.num_factor, N, x->cfg.k0, x->w0);
     hipLaunchKernelGGL(k_als_sub_target, g1, b1, 0, x->stream, x->als.e, x->slots[train_slot].target, N);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(x->stream) != hipSuccess)
       return bail(fail(x, FMX_E_HIP, "fmx_group_als_begin: first prediction failed on shard device %d", x->device), x);

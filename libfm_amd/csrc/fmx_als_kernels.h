@@ -48,7 +48,7 @@ template <int KP>
 __global__ void __launch_bounds__(256)
 k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, const Tab tb,
              int k0, int k1, const double* __restrict__ w0_ptr, EQ* __restrict__ eq, double* __restrict__ q /* [KP][n_rows] or null */,
-             double* __restrict__ e_part /* feature shard: y-hat WITHOUT the bias goes here (summed over the shards later) */) {
+             double* __restrict__ e_part /* feature shard: lin - 0.5 * sum of squares goes here (k_als_set_e finishes y-hat) */) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x & 63u;
   const bool act = lane < LPR;
@@ -78,8 +78,10 @@ k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
     }
     double part = lin - 0.5 * sq;
     if (act) {
+      if (!e_part) {                                           // (a shard's factor sums are partial: their squares wait for the all-reduce)
 #pragma unroll
-      for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+        for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+      }
       if (q) {
 #pragma unroll
         for (int v = 0; v < VEC; v++) q[(size_t)(lane * VEC + v) * n_rows + c] = sum[v];
@@ -99,10 +101,16 @@ static __global__ void k_als_load_q(EQ* __restrict__ eq, const double* __restric
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].q = qf[c];
 }
 
-// feature shards: after the all-reduce of the partial predictions  e = w0 + sum over the shards
-static __global__ void k_als_set_e(EQ* __restrict__ eq, const double* __restrict__ e_sum, uint32_t n, int k0, const double* __restrict__ w0_ptr) {
+// feature shards: a shard's re-prediction leaves c_part = lin - 0.5 * sum_f sum_i (v x)^2 and its partial q_f; after the
+// all-reduce of both   e = w0 + c + 0.5 * sum_f q_f^2   (fm_model.h:116-125: the square is of the COMPLETE factor sum)
+static __global__ void k_als_set_e(EQ* __restrict__ eq, const double* __restrict__ c_sum, const double* __restrict__ q, int k, uint32_t n,
+                                   int k0, const double* __restrict__ w0_ptr) {
   const double w0 = k0 ? *w0_ptr : 0.0;
-  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) eq[c].e = w0 + e_sum[c];
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    double p = w0 + c_sum[c];
+    for (int f = 0; f < k; f++) { const double s = q[(size_t)f * n + c]; p += 0.5 * s * s; }
+    eq[c].e = p;
+  }
 }
 // feature shards: the draws of a level RECORD what they would do to {e, q} (delta[row], rows disjoint inside a level);
 // after the all-reduce every shard applies the same sum, so the replicas of the cache stay identical bit for bit

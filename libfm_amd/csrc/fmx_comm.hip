@@ -50,22 +50,24 @@ const char* rccl_why() { return g_rccl.err.c_str(); }
   do { ncclResult_t _r = (expr); if (_r != ncclSuccess)                                                         \
       return fail((h), FMX_E_HIP, "%s failed: %s", #expr, rccl()->GetErrorString(_r)); } while (0)
 
-// loopback exchange: out[i] = sum over the shards' buffers (fixed order -> deterministic); out may alias bufs.p[0]
-struct BufList { const float* p[16]; int n; };
-__global__ void __launch_bounds__(256) k_sum_shards(BufList bufs, float* __restrict__ out, size_t n4, size_t n) {
+// loopback exchange: EVERY shard's buffer receives the sum over the shards' buffers (fixed order -> deterministic), the
+// in-place semantics of an all-reduce: a shard then reads only its own buffer, so no shard's next gather can overwrite
+// what another shard's update is still reading
+struct BufList { float* p[16]; int n; };
+__global__ void __launch_bounds__(256) k_sum_shards(BufList bufs, size_t n4, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 a = reinterpret_cast<const float4*>(bufs.p[0])[i];
     for (int r = 1; r < bufs.n; r++) {
       const float4 b = reinterpret_cast<const float4*>(bufs.p[r])[i];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    reinterpret_cast<float4*>(out)[i] = a;
+    for (int r = 0; r < bufs.n; r++) reinterpret_cast<float4*>(bufs.p[r])[i] = a;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {               // tail (< 4 floats)
     const size_t i = (n & ~(size_t)3) + threadIdx.x;
     float a = bufs.p[0][i];
     for (int r = 1; r < bufs.n; r++) a += bufs.p[r][i];
-    out[i] = a;
+    for (int r = 0; r < bufs.n; r++) bufs.p[r][i] = a;
   }
 }
 
@@ -99,7 +101,7 @@ static int ensure_xbuf(fmx_handle h, size_t floats) {
 // enqueued on every shard's stream; exchange_end makes every shard's stream wait for the result (sum_of()).
 //   RCCL: in-place all-reduce on the shard's own COMM stream (ordered behind the gather by an event), so that it can run
 //         under whatever the compute stream does next (FMX_FLAG_PIPELINE: the update of the previous batch);
-//   loopback (all shards on one device): a reduction kernel on shard 0's stream into shard 0's buffer, read by all.
+//   loopback (all shards on one device): a reduction kernel on shard 0's stream that leaves the sum in every shard's buffer.
 static int exchange_begin(fmx_group g, int which, size_t count) {
   const size_t n = g->hs.size();
   if (g->kind == GROUP_RCCL) {
@@ -131,7 +133,7 @@ static int exchange_begin(fmx_group g, int which, size_t count) {
       if (i) { HIPCHK(h0, hipEventRecord(g->ev_part[i], g->hs[i]->stream)); HIPCHK(h0, hipStreamWaitEvent(h0->stream, g->ev_part[i], 0)); }
     }
     hipLaunchKernelGGL(k_sum_shards, dim3((unsigned)std::min<size_t>((count / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, h0->stream,
-                       bl, h0->xbuf[which], count / 4, count);
+                       bl, count / 4, count);
     HIPCHK(h0, hipGetLastError());
     HIPCHK(h0, hipEventRecord(g->ev_sum, h0->stream));
     for (size_t i = 1; i < n; i++) HIPCHK(h0, hipStreamWaitEvent(g->hs[i]->stream, g->ev_sum, 0));
@@ -183,9 +185,7 @@ int group_allreduce_f64(fmx_group_s* g, const std::vector<double*>& bufs, size_t
   return FMX_OK;
 }
 
-static const float* sum_of(fmx_group g, size_t i, int which) {
-  return (g->kind == GROUP_LOOPBACK) ? g->hs[0]->xbuf[which] : g->hs[i]->xbuf[which];
-}
+static const float* sum_of(fmx_group g, size_t i, int which) { return g->hs[i]->xbuf[which]; }
 
 // a handle leaves: its group is told (a multi-handle group becomes unusable), its communicator and buffers are released
 void comm_free(fmx_handle h) {

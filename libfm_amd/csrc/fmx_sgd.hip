@@ -417,9 +417,10 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   if (rc) return rc;
   const uint64_t n_batch = ((uint64_t)s.n_rows + B - 1) / B;
   while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
-  // the deferred features of batch b-1 ride along in the launch of batch b (FusedPrev) when the per-batch example order
-  // exists; FMX_FUSED_SEPARATE_PASS=1 keeps the separate kernel between the batches (A/B knob)
-  const bool merged = s.order != nullptr && !getenv("FMX_FUSED_SEPARATE_PASS");
+  // FMX_FUSED_MERGE=1: the deferred features of batch b-1 ride along in the launch of batch b (FusedPrev) instead of a
+  // kernel of their own between the launches.  Bit-identical results (tests/test_gpu_fullsize.py), but MEASURED SLOWER
+  // (198 vs 207 M examples/s at batch 262 144, 187 vs 213 at 524 288, same box): kept as an A/B knob, off by default.
+  const bool merged = s.order != nullptr && getenv("FMX_FUSED_MERGE") && atoi(getenv("FMX_FUSED_MERGE")) > 0;
   if (merged && h->fused_ctr_cap < 2 * n_batch) {
     if (h->fused_ctr) hipFree(h->fused_ctr);
     h->fused_ctr = nullptr; h->fused_ctr_cap = 0;

@@ -287,7 +287,12 @@ int main(int argc, char** argv) {
       fm.w.init_normal(fm.init_mean, fm.init_stdev);          // libfm.cpp:283
       fm_learn_mcmc* fml;
 #ifdef FMX_WITH_GPU_ADAPTER
-      if (als_gpu) fml = new fm_learn_als_gpu(); else
+      if (als_gpu) {
+        fm_learn_als_gpu* gl = new fm_learn_als_gpu();
+        if (const char* dv = getenv("FMX_GPU_DEVICES"))        // one feature shard per listed device ("0,0": two on one GPU)
+          for (const char* p = dv; *p;) { gl->gpu_devices.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p) p++; }
+        fml = gl;
+      } else
 #endif
       fml = new fm_learn_mcmc_simultaneous();
       fml->validation = NULL;

@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/r02c
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-( timeout 1200 python -m pytest tests -q -m gpu --maxfail=12 --deselect tests/test_gpu_fullsize.py 2>&1 | tail -60 ) > $OUT/pytest_gpu.log 2>&1
+( timeout 1200 python -m pytest tests -q -m gpu --maxfail=12 --ignore=tests/test_gpu_fullsize.py 2>&1 | tail -60 ) > $OUT/pytest_gpu.log 2>&1
 tail -5 $OUT/pytest_gpu.log
 ( timeout 600 python -m pytest tests/test_gpu_fullsize.py -q -m gpu --maxfail=5 2>&1 | tail -40 ) > $OUT/pytest_full.log 2>&1
 tail -3 $OUT/pytest_full.log

@@ -52,8 +52,10 @@ def test_reference_driver_with_gpu_learner(oracle, name):
         assert np.abs(ev[-1] - z["eval"][-1]).max() <= 2.0 / 100
 
 
-@pytest.mark.parametrize("name", ["als_reg_ml", "als_cls_ragged", "als_reg_fields_k16", "als_reg_ml_groups", "als_cls_fields_groups"])
-def test_reference_driver_with_gpu_als_learner(oracle, name):
+@pytest.mark.parametrize("name,devices", [("als_reg_ml", None), ("als_cls_ragged", None), ("als_reg_fields_k16", None),
+                                          ("als_reg_ml_groups", None), ("als_cls_fields_groups", None),
+                                          ("als_reg_ml", "0,0"), ("als_cls_fields_groups", "0,0,0"), ("als_reg_fields_k16", "0,0,0,0")])
+def test_reference_driver_with_gpu_als_learner(oracle, name, devices):
     """adapter/fm_learn_mcmc_gpu.h: the reference's loader (X^T only for als, libfm.cpp:143-147), RNG and output code
     with the GPU ALS learner must land on the stock learner's results (golden fixture)."""
     if not os.path.exists(HARNESS):
@@ -68,6 +70,8 @@ def test_reference_driver_with_gpu_als_learner(oracle, name):
         cfg = ["als_gpu", trf, tef, str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]),
                repr(g.reg[0]), repr(g.reg[1]), repr(g.reg[2]), repr(float(z["init_stdev"])), int(z["seed"]), pre]
         env = dict(os.environ)
+        if devices:                       # gpu_devices: feature shards (here on one device) through fmx_group_als_*
+            env["FMX_GPU_DEVICES"] = devices
         if "group" in z.files:            # -meta + per-group lambdas: the adapter reads the reference's own meta / w_lambda / v_lambda
             with open(os.path.join(td, "meta"), "w") as f:
                 f.write("".join("%d\n" % x for x in z["group"]))

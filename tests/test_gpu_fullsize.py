@@ -106,18 +106,18 @@ def test_fused_minibatch_is_deterministic_at_bench_batch(capi):
 
 
 def test_fused_merged_pass_equals_separate_pass(capi, monkeypatch):
-    """the deferred features of batch b-1 are finished INSIDE the launch of batch b (FusedPrev: claimed blocks, release /
-    acquire hand-off to the examples that depend on them) -- or, with FMX_FUSED_SEPARATE_PASS=1, by a kernel of their own
-    between the launches.  Same arithmetic, so the two schedules must agree BIT FOR BIT; a dependent example that read a
-    row (or a linear weight sharing a 128-byte line with another feature's) before the hand-off would show up here.
-    Bench configuration: n = 1e8, batch 262 144 -- ~10 % of a batch's examples depend on the previous batch."""
+    """the deferred features of batch b-1 are finished by a kernel of their own between the launches (default) -- or, with
+    FMX_FUSED_MERGE=1, INSIDE the launch of batch b (FusedPrev: claimed blocks, release / acquire hand-off to the examples
+    that depend on them; measured slower, kept as a knob).  Same arithmetic, so the two schedules must agree BIT FOR BIT; a
+    dependent example that read a row (or a linear weight sharing a line with another feature's) before the hand-off would
+    show up here.  Bench configuration: n = 1e8, batch 262 144 -- ~10 % of a batch's examples depend on the previous batch."""
     rows = 1 << 20
     res = []
-    for separate in ("1", None):
-        if separate:
-            monkeypatch.setenv("FMX_FUSED_SEPARATE_PASS", separate)
+    for merge in (None, "1"):
+        if merge:
+            monkeypatch.setenv("FMX_FUSED_MERGE", merge)
         else:
-            monkeypatch.delenv("FMX_FUSED_SEPARATE_PASS", raising=False)
+            monkeypatch.delenv("FMX_FUSED_MERGE", raising=False)
         h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
         h.init_params(0.0, 0.05, 3)
         h.synth_rows(0, 78, 0, rows, NNZ)
