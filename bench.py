@@ -194,14 +194,17 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the all-reduce through the host (testing the N>1 path without RCCL)")
     ap.add_argument("--same-device", action="store_true", help="testing: all ranks use cuda:0")
+    ap.add_argument("--driver", default="lib", choices=["lib", "torch"],
+                    help="several GPUs: lib = the library's own schedule and RCCL binding (fmx_comm_init_rank + fmx_sgd_epoch; torch only "
+                         "hands the communicator id to the ranks); torch = libfm_amd/distributed.py (partial -> dist.all_reduce -> finish)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="testing: drive the multi-GPU code path (ShardedSGD + all-reduce) even with one rank")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 262144 sharded); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default = 256 at lr 0.01, classification)")
-    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
-                    help="sharded: do not overlap the all-reduce of batch b+1 with the update of batch b (exact batch rule instead of "
-                         "the one-batch-stale pipelined rule; libfm_amd/distributed.py)")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true",
+                    help="sharded: overlap the all-reduce of batch b+1 with the update of batch b (the one-batch-stale pipelined rule, "
+                         "oracle fmo_sgd_epoch_minibatch_pipelined).  Default OFF: every N runs the SAME rule as N = 1")
     ap.add_argument("--no-bias-lag", action="store_true", help="minibatch: keep the w0 recurrence on the critical path (exact chunk coupling)")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -281,6 +284,26 @@ def main():
                 deferred += st.deferred_features
         rows_per_launch = min(batch, args.rows)
         kind = "fused" if args.mode in ("hogwild", "fused") else "apply"
+    elif args.driver == "lib" and args.backend == "nccl":
+        # the library's own multi-GPU schedule: rank 0 creates the RCCL id, torch.distributed only carries it to the others
+        batch = args.batch or 262144
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init_rank(uid[0], rank, world)
+        lib_flags = lagf | (capi.FLAG_PIPELINE if args.pipeline else 0)
+        lib_lag = args.bias_lag if lagf else 0
+
+        class _Drv:
+            def synchronize(self):
+                h.synchronize()
+        drv = _Drv()
+
+        def step(timed):
+            h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, args.w0_chunk, lib_flags, lib_lag)
+        bias_lag = lib_lag
+        rows_per_launch = min(batch, args.rows)
+        kind = "apply"
+        main_time, main_launches = 0.0, 0
     else:
         from libfm_amd.distributed import ShardedSGD
         batch = args.batch or 262144                 # per-rank compute side: 691 (131 072) -> 765 M examples/s (262 144) at P = 8
@@ -381,7 +404,8 @@ def main():
             "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
-                       "w0_chunk": args.w0_chunk or 256, "bias_lag": bias_lag, "pipeline": bool(args.pipeline) if sharded else False, "sharding": "features mod %d" % world if world > 1 else "none",
+                       "w0_chunk": args.w0_chunk or 256, "bias_lag": bias_lag, "pipeline": bool(args.pipeline) if sharded else False, "sharding": "feature-id hash (permutation) over %d shards" % world if world > 1 else "none",
+                       "driver": (args.driver if sharded else "single handle"),
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,
             "cpu_baseline": cpu_ref if (cpu_ref and "value" in cpu_ref) else cpu,

@@ -171,6 +171,15 @@ int fmx_init_params(fmx_handle h, double init_mean, double init_stdev, uint64_t 
  * for i < count: w_out[i] = w[ids[i]], v_out[i*num_factor + f] = v[f][ids[i]].  Sharded handles accept only their
  * own features. */
 int fmx_get_param_rows(fmx_handle h, const uint32_t *ids, uint32_t count, double *w_out, double *v_out);
+/* fm_model::saveModel / loadModel (fm_model.h:132-190; `-save_model`, `-load_model`, libfm.cpp:258-269, 431-434): the
+ * reference's text file ("#global bias W0", "#unary interactions Wj", "#pairwise interactions Vj,f": one line per feature,
+ * its factors separated by blanks; doubles as an ostream prints them).  The device table is feature-major -- the file's own
+ * order -- so it is streamed in row chunks without ever building the fp64 factor-major block on the host.
+ * fmx_load_model fails with FMX_E_ARG "malformed model file" where loadModel returns 0 (wrong number of factors per line,
+ * truncated file); a k = 1 file, which the reference's splitString cannot read back (fm_model.h:195-205), is accepted.
+ * Shards: every shard may load the same file (it keeps its own features); saving a sharded model goes through fmx_get_params. */
+int fmx_save_model(fmx_handle h, const char *path);
+int fmx_load_model(fmx_handle h, const char *path);
 /* the scalar bias alone (cheap; used between minibatches by multi-process drivers) */
 int fmx_get_w0(fmx_handle h, double *w0);
 

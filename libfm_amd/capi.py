@@ -95,6 +95,8 @@ SYMBOLS = [
     ("fmx_init_params", C.c_int, [H, C.c_double, C.c_double, C.c_uint64]),
     ("fmx_get_param_rows", C.c_int, [H, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_get_w0", C.c_int, [H, C.POINTER(C.c_double)]),
+    ("fmx_save_model", C.c_int, [H, C.c_char_p]),
+    ("fmx_load_model", C.c_int, [H, C.c_char_p]),
     ("fmx_set_groups", C.c_int, [H, C.c_void_p, C.c_uint32]),
     ("fmx_upload_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     ("fmx_upload_block_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
@@ -228,6 +230,14 @@ class Handle:
         v = np.zeros((len(ids), max(self.k, 1)), dtype=np.float64)
         self._chk(self.lib.fmx_get_param_rows(self.h, _ptr(ids), len(ids), _ptr(w), _ptr(v) if self.k > 0 else None))
         return w, v[:, :self.k].T.copy()
+
+    def save_model(self, path):
+        """fm_model::saveModel (fm_model.h:132-154) straight from the device table"""
+        self._chk(self.lib.fmx_save_model(self.h, os.fsencode(path)))
+
+    def load_model(self, path):
+        """fm_model::loadModel (fm_model.h:160-190); raises FmxError "malformed model file" where the reference returns 0"""
+        self._chk(self.lib.fmx_load_model(self.h, os.fsencode(path)))
 
     def get_w0(self):
         w0 = C.c_double(0)

@@ -382,6 +382,151 @@ int fmx_get_param_rows(fmx_handle h, const uint32_t* ids, uint32_t count, double
   return FMX_OK;
 }
 
+// ---- fm_model::saveModel / loadModel (fm_model.h:132-190) straight from / into the device table ----------------------
+// The device keeps the factors FEATURE-major, which is the order of the file's "#pairwise interactions Vj,f" section (one
+// line per feature, its k factors in order): the table is streamed in chunks of rows, never converted to the reference's
+// fp64 factor-major block (51 GB at the north-star size).  Numbers are written as the reference's ostream writes doubles
+// (6 significant digits, printf "%g").
+int fmx_save_model(fmx_handle h, const char* path) {
+  if (!h || !path) return FMX_E_ARG;
+  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "fmx_save_model on a feature shard: collect the parameters with fmx_get_params");
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  FILE* f = fopen(path, "w");
+  if (!f) return fail(h, FMX_E_ARG, "fmx_save_model: cannot open %s", path);
+  const uint64_t n = h->cfg.num_attribute;
+  const int k = h->cfg.num_factor;
+  const size_t chunk = 1u << 16;
+  std::vector<float> buf(chunk * (size_t)std::max<uint32_t>(h->tb.rs, 1));
+  int rc = FMX_OK;
+  if (h->cfg.k0) {
+    double w0 = 0;
+    if (hipMemcpy(&w0, h->w0, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = FMX_E_HIP;
+    fprintf(f, "#global bias W0\n%g\n", w0);
+  }
+  if (rc == FMX_OK && h->cfg.k1) {
+    fprintf(f, "#unary interactions Wj\n");
+    for (uint64_t j0 = 0; j0 < n && rc == FMX_OK; j0 += chunk) {
+      const size_t cnt = (size_t)std::min<uint64_t>(chunk, n - j0);
+      if (h->tb.ws == 1) { if (hipMemcpy(buf.data(), h->tb.w + j0, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = FMX_E_HIP; }
+      else if (hipMemcpy2D(buf.data(), sizeof(float), h->tb.w + j0 * h->tb.ws, (size_t)h->tb.ws * sizeof(float), sizeof(float), cnt, hipMemcpyDeviceToHost) != hipSuccess) rc = FMX_E_HIP;
+      for (size_t i = 0; i < cnt && rc == FMX_OK; i++) fprintf(f, "%g\n", (double)buf[i]);
+    }
+  }
+  if (rc == FMX_OK) {
+    fprintf(f, "#pairwise interactions Vj,f\n");
+    for (uint64_t j0 = 0; j0 < n && rc == FMX_OK; j0 += chunk) {
+      const size_t cnt = (size_t)std::min<uint64_t>(chunk, n - j0);
+      if (k > 0 && hipMemcpy(buf.data(), h->tb.V + j0 * h->tb.rs, cnt * (size_t)h->tb.rs * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = FMX_E_HIP;
+      for (size_t i = 0; i < cnt && rc == FMX_OK; i++) {
+        const float* row = buf.data() + i * h->tb.rs;
+        for (int ff = 0; ff < k; ff++) { fprintf(f, "%g", (double)row[ff]); if (ff != k - 1) fputc(' ', f); }
+        fputc('\n', f);
+      }
+    }
+  }
+  const bool werr = ferror(f) != 0;
+  if (fclose(f) != 0 || werr) return fail(h, FMX_E_ARG, "fmx_save_model: write error on %s", path);
+  if (rc != FMX_OK) return fail(h, rc, "fmx_save_model: device copy failed");
+  return FMX_OK;
+}
+
+// returns FMX_E_ARG ("malformed model file") where fm_model::loadModel returns 0 (libfm.cpp:264-267).  Every shard of a
+// sharded model may load the same file: it keeps its own features.
+int fmx_load_model(fmx_handle h, const char* path) {
+  if (!h || !path) return FMX_E_ARG;
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  FILE* f = fopen(path, "r");
+  if (!f) return fail(h, FMX_E_ARG, "malformed model file (cannot open %s)", path);
+  const uint64_t n = h->cfg.num_attribute;
+  const int k = h->cfg.num_factor;
+  const Shard sh = make_shard(h->cfg);
+  char* line = nullptr; size_t cap = 0;
+  auto next = [&]() -> bool { return getline(&line, &cap, f) >= 0; };
+  int rc = FMX_OK;
+  const char* what = "";
+  std::vector<float> stage;
+  std::vector<uint32_t> rows;
+  auto flush_w = [&]() {                                    // scatter the staged linear weights to their local rows
+    for (size_t i = 0; i < rows.size() && rc == FMX_OK; i++)
+      if (hipMemcpyAsync(h->tb.w + (size_t)rows[i] * h->tb.ws, &stage[i], sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = FMX_E_HIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = FMX_E_HIP;
+    rows.clear(); stage.clear();
+  };
+  if (h->cfg.k0) {
+    double w0 = 0;
+    if (!next() || !next()) { rc = FMX_E_ARG; what = "bias section"; }
+    else { w0 = atof(line); if (hipMemcpy(h->w0, &w0, sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = FMX_E_HIP; }
+  }
+  if (rc == FMX_OK && h->cfg.k1) {
+    if (!next()) { rc = FMX_E_ARG; what = "linear section"; }
+    const size_t chunk = 1u << 16;
+    std::vector<float> wbuf;
+    uint64_t j0 = 0;
+    for (uint64_t j = 0; j < n && rc == FMX_OK; j++) {
+      if (!next()) { rc = FMX_E_ARG; what = "linear weights"; break; }
+      const float val = (float)atof(line);
+      if (sh.world == 1) {
+        wbuf.push_back(val);
+        if (wbuf.size() == chunk || j + 1 == n) {
+          if (h->tb.ws == 1) { if (hipMemcpy(h->tb.w + j0, wbuf.data(), wbuf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = FMX_E_HIP; }
+          else if (hipMemcpy2D(h->tb.w + j0 * h->tb.ws, (size_t)h->tb.ws * sizeof(float), wbuf.data(), sizeof(float), sizeof(float), wbuf.size(), hipMemcpyHostToDevice) != hipSuccess) rc = FMX_E_HIP;
+          j0 = j + 1; wbuf.clear();
+        }
+      } else {
+        uint32_t jl;
+        if (sh.place((uint32_t)j, &jl)) { rows.push_back(jl); stage.push_back(val); if (rows.size() == chunk) flush_w(); }
+      }
+    }
+    if (rc == FMX_OK && !rows.empty()) flush_w();
+  }
+  if (rc == FMX_OK && !next()) { rc = FMX_E_ARG; what = "factor section"; }
+  if (rc == FMX_OK) {
+    const size_t chunk = 1u << 14;
+    std::vector<float> vbuf(chunk * (size_t)h->tb.rs, 0.f);
+    size_t filled = 0; uint64_t j0 = 0;
+    for (uint64_t j = 0; j < n && rc == FMX_OK; j++) {
+      if (!next()) { rc = FMX_E_ARG; what = "factor rows"; break; }
+      uint32_t jl = (uint32_t)j;
+      const bool mine = sh.place((uint32_t)j, &jl);
+      float* row = vbuf.data() + filled * h->tb.rs;
+      // the reference splits at single blanks and wants exactly num_factor tokens (fm_model.h:176-179)
+      int cnt = 0;
+      char* p = line;
+      size_t len = strlen(p);
+      while (len && (p[len - 1] == '\n' || p[len - 1] == '\r')) p[--len] = 0;
+      if (k > 0) {
+        for (char* tok = p;; ) {
+          char* sp = strchr(tok, ' ');
+          if (sp) *sp = 0;
+          if (cnt < k) row[cnt] = (float)atof(tok);
+          cnt++;
+          if (!sp) break;
+          tok = sp + 1;
+        }
+        if (cnt != k) { rc = FMX_E_ARG; what = "factor count of a row"; break; }
+      }
+      if (sh.world == 1) {
+        filled++;
+        if (filled == chunk || j + 1 == n) {
+          if (k > 0 && hipMemcpy(h->tb.V + j0 * h->tb.rs, vbuf.data(), filled * (size_t)h->tb.rs * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = FMX_E_HIP;
+          j0 = j + 1; filled = 0;
+        }
+      } else if (mine && k > 0) {
+        if (hipMemcpy(h->tb.V + (size_t)jl * h->tb.rs, row, (size_t)k * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = FMX_E_HIP;
+      }
+    }
+  }
+  free(line);
+  fclose(f);
+  if (rc == FMX_E_ARG) return fail(h, FMX_E_ARG, "malformed model file (%s)", what);
+  if (rc != FMX_OK) return fail(h, rc, "fmx_load_model: device copy failed");
+  return FMX_OK;
+}
+
 int fmx_get_w0(fmx_handle h, double* w0) {
   if (!h || !w0) return FMX_E_ARG;
   { int _rc = lag_flush(h); if (_rc) return _rc; }

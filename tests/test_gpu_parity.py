@@ -521,3 +521,57 @@ def test_max_feature_count_is_reported(capi):
     assert st.max_feature_count == expect >= 50
     assert h.sgd_epoch(0, capi.SGD_HOGWILD, capi.APPLY_DEFAULT, 0, 16).max_feature_count == 0
     h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# fm_model::saveModel / loadModel (fm_model.h:132-190) straight from / into the device table (fmx_save_model / fmx_load_model)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["sgd_reg_ml", "sgd_cls_k64", "sgd_reg_ragged_nolin", "sgd_reg_k1"])
+def test_model_file_from_the_device_table(capi, oracle, name, tmp_path):
+    from libfm_amd import learner as L
+    g = Golden(name)
+    m = g.model(oracle, "final")
+    # what the device holds: the fp32 rounding of the reference's parameters
+    w32, v32 = m.w.astype(np.float32).astype(np.float64), m.v.astype(np.float32).astype(np.float64)
+    h = make_handle(capi, g)
+    h.set_params(m.w0, m.w, m.v)
+    dev_file, py_file = str(tmp_path / "dev.model"), str(tmp_path / "py.model")
+    h.save_model(dev_file)
+    fm = L.FMModel()                                           # the Python writer is byte-identical to the stock binary's (tests/test_data_formats.py)
+    fm.num_attribute, fm.num_factor, fm.k0, fm.k1 = g.n, g.k, bool(g.k0), bool(g.k1)
+    fm.w0, fm.w, fm.v = m.w0, w32, v32
+    fm.save_model(py_file)
+    assert open(dev_file).read() == open(py_file).read()
+    # and back: a fresh handle (and two shards of one) load the file
+    fm2 = L.FMModel()
+    fm2.num_attribute, fm2.num_factor, fm2.k0, fm2.k1 = g.n, g.k, bool(g.k0), bool(g.k1)
+    assert fm2.load_model(py_file)
+    want_w = fm2.w.astype(np.float32).astype(np.float64) if g.k1 else np.zeros(g.n)
+    want_v = fm2.v.astype(np.float32).astype(np.float64)
+    h2 = make_handle(capi, g)
+    h2.load_model(dev_file)
+    w0, w, v = h2.get_params()
+    assert (w0 == fm2.w0 or not g.k0) and np.array_equal(w, want_w) and np.array_equal(v, want_v)
+    h2.close()
+    w, v = np.zeros(g.n), np.zeros((g.k, g.n))
+    for r in range(2):
+        hs = make_handle(capi, g, shard_rank=r, shard_world=2, shard_hash=1)
+        hs.load_model(dev_file)
+        _, w, v = hs.get_params(w, v)
+        hs.close()
+    assert np.array_equal(w, want_w) and np.array_equal(v, want_v)
+    # malformed files: fm_model::loadModel returns 0 (libfm.cpp:264-267 "malformed model file")
+    if g.k > 1:
+        bad = str(tmp_path / "bad.model")
+        lines = open(dev_file).read().splitlines()
+        lines[-1] = " ".join(lines[-1].split(" ")[:-1])         # one factor short
+        open(bad, "w").write("\n".join(lines) + "\n")
+        with pytest.raises(capi.FmxError, match="malformed model file"):
+            h.load_model(bad)
+    trunc = str(tmp_path / "trunc.model")
+    open(trunc, "w").write("\n".join(open(dev_file).read().splitlines()[:-3]) + "\n")
+    with pytest.raises(capi.FmxError, match="malformed model file"):
+        h.load_model(trunc)
+    with pytest.raises(capi.FmxError, match="malformed model file"):
+        h.load_model(str(tmp_path / "missing.model"))
+    h.close()
