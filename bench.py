@@ -348,6 +348,16 @@ def main():
                 h.sgd_epoch(0, *a)
             h.synchronize()
             return round(n * args.rows / (time.perf_counter() - t1), 1)
+        # the V-gather on its own: fm_model::predict over the same rows (k_rowsums + fused evaluation), the kernel north_star's
+        # ">= 60 % of the HBM-read roofline on the V-gather" is about; v_read_frac = rows/s x nnz*k*4 B / 8 TB/s
+        ev_s = 0.0
+        h.evaluate(0)
+        for _ in range(5):
+            ev_s += h.evaluate(0).device_seconds
+        rps = 5 * args.rows / ev_s
+        extras["predict"] = {"mode": "fm_model::predict + evaluate over the step's rows (k_rowsums), the full model incl. linear weights",
+                             "value": round(rps, 1), "unit": "rows/s", "v_read_frac": v_read_fraction(rps, args.k, args.nnz),
+                             "frac": round(rps * (args.nnz * (4 * args.k + 12) + 4) / 1e9 / HBM_PEAK_GBS, 4)}
         if args.mode != "hogwild":
             extras["hogwild"] = {"mode": "hogwild (asynchronous one-pass step; parity only metric-level -- NOT the headline)",
                                  "batch": 262144, "value": timed_epochs(5, capi.SGD_HOGWILD, capi.APPLY_DEFAULT, 262144, args.w0_chunk, 0),
