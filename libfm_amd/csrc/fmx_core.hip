@@ -26,6 +26,7 @@ Hyper make_hyper(const fmx_config& c) {
   h.task = c.task; h.k0 = c.k0; h.k1 = c.k1;
   h.lr_d = c.learn_rate; h.reg0_d = c.reg0; h.regw_d = c.regw; h.regv_d = c.regv;
   h.min_d = c.min_target; h.max_d = c.max_target;
+  h.sgda = 0;
   return h;
 }
 

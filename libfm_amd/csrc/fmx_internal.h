@@ -73,7 +73,7 @@ struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping (split step):
   hipEvent_t ev_rest = nullptr, ev_scan[RING] = {};
 };
 
-struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; };
+struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; double* dreg = nullptr; };
 
 struct fmx_context_s {
   fmx_config cfg;

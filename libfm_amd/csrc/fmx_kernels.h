@@ -41,6 +41,7 @@ struct Hyper {            // per-launch scalars (fm_model.h:56-57, fm_learn_sgd.
   float min_target, max_target;
   int   task, k0, k1;
   double lr_d, reg0_d, regw_d, regv_d, min_d, max_d;   // unrounded copies for the fp64 sequential kernel
+  int   sgda;              // 1: the multiplier of fm_learn_sgd_element_adapt_reg (2 (p - y) for regression, :142)
 };
 
 // counter-hash helper: identical definition in oracle/fm_oracle.c (fmo_mix64)
@@ -242,7 +243,7 @@ __device__ __forceinline__ float multiplier(const Hyper& h, float p, float y) {
   if (h.task == 0) {
     p = fminf(h.max_target, p);
     p = fmaxf(h.min_target, p);
-    return -(y - p);
+    return h.sgda ? 2.0f * (p - y) : -(y - p);
   }
   return -y * (1.0f - 1.0f / (1.0f + __expf(-y * p)));
 }
@@ -255,7 +256,7 @@ template <int TASK> __device__ __forceinline__ float multiplier_task(const Hyper
   if constexpr (TASK == 0) {
     p = fminf(h.max_target, p);
     p = fmaxf(h.min_target, p);
-    return -(y - p);
+    return h.sgda ? 2.0f * (p - y) : -(y - p);
   } else {
     return -y * (1.0f - __builtin_amdgcn_rcpf(1.0f + __expf(-y * p)));
   }
@@ -1325,6 +1326,166 @@ k_sgda(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, cons
   if (act) {
 #pragma unroll
     for (int v = 0; v < VEC; v++) reg[1 + lane * VEC + v] = reg_v[v];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// SGDA in batch form (oracle fmo_sgda_epoch_minibatch; C-ABI fmx_sgda_epoch_minibatch).  The theta step of a batch is the
+// minibatch rule (k_rowsums -> k_scan -> k_sgda_apply_seg) with the learner's multiplier (Hyper::sgda), reg_0 = 0 and the
+// LEARNED regularisation 2 reg(g[,f]) theta per occurrence; the shadow gradient of a touched parameter becomes the sum of
+// its occurrences' gradients.  The lambda step of the batch: one wavefront per validation row (k_sgda_lambda) evaluates
+// sgd_lambda_step (:201-248 through predict_scaled :171-199) with the regularisation frozen at its batch-start values and
+// adds its changes to dreg with fp64 atomics; k_sgda_reg_update applies the sums, clamped at 0.
+// reg / dreg: [G][1 + KP] doubles, reg[g*(1+KP)] = reg_w(g), reg[g*(1+KP)+1+f] = reg_v(g,f).
+// ----------------------------------------------------------------------------------------------
+template <int KP, int U>
+__global__ void __launch_bounds__(256)
+k_sgda_apply_seg(const SegWork sw, const Tab tb, Hyper h, const double* __restrict__ reg, const uint32_t* __restrict__ grp,
+                 float* __restrict__ gw, float* __restrict__ gv) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  const TEntry* __restrict__ t_ent = sw.t_ent;
+  const float* __restrict__ S = sw.S;
+  const float* __restrict__ mult = sw.mult;
+  for (uint32_t blk = wave0 * 64u; blk < sw.nseg; blk += nwaves * 64u) {
+    const uint32_t cnt = min(64u, sw.nseg - blk);
+    uint32_t jl = 0, al = 0, bl = 0;
+    if (lane < cnt) {
+      const uint32_t s = blk + lane;
+      jl = sw.seg_feat[s];
+      al = sw.seg_rel[s];
+      bl = (s + 1 < sw.nseg_batch) ? sw.seg_rel[s + 1] : sw.batch_nnz;
+    }
+    for (uint32_t i = 0; i < cnt; i += EPI * U) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t idx = i + u * EPI + g;
+        const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
+        const uint32_t a = bcast_u32<EPI>(al, idx & 63u);
+        const uint32_t b = bcast_u32<EPI>(bl, idx & 63u);
+        if (idx < cnt) {
+          float v0[VEC], G[VEC]; float A = 0.f, Gw = 0.f;
+          load_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, v0);
+#pragma unroll
+          for (int v = 0; v < VEC; v++) G[v] = 0.f;
+          for (uint32_t i2 = a; i2 < b; i2++) {                 // every occurrence of the feature in this batch
+            const TEntry t2 = t_ent[i2];
+            const float mx = mult[t2.e] * t2.x;
+            float s2[VEC];
+            load_vec<VEC>(S + (size_t)t2.e * KP + f * VEC, s2);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) G[v] = fmaf(mx, s2[v], G[v]);
+            A = fmaf(mx, t2.x, A); Gw += mx;
+          }
+          const uint32_t gg = grp ? grp[j] : 0u;
+          const double* rg = reg + (size_t)gg * (1 + KP);
+          const float nocc = (float)(b - a);
+          float nv[VEC], sh[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const float vv = v0[v];
+            sh[v] = G[v] - vv * A;                               // sum over the occurrences of mult x (S_f - v x)  (:161)
+            nv[v] = vv - h.lr * (sh[v] + nocc * 2.0f * (float)rg[1 + f * VEC + v] * vv);
+          }
+          store_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
+          store_vec<VEC>(gv + (size_t)j * tb.rs + f * VEC, sh);
+          if (h.k1 && f == 0) {
+            float* pw = tb.w + (size_t)j * tb.ws;
+            const float wv = *pw;
+            gw[j] = Gw;                                          // :153
+            *pw = wv - h.lr * (Gw + nocc * 2.0f * (float)rg[0] * wv);
+          }
+        }
+      }
+    }
+  }
+}
+
+// one wavefront (= one workgroup, LDS tables per group) per validation row; rows vpos0 .. vpos0 + n_rows - 1, cyclic
+template <int KP>
+__global__ void __launch_bounds__(64)
+k_sgda_lambda(const Entry* __restrict__ vent, const uint64_t* __restrict__ vrow_ptr, const float* __restrict__ vtarget, uint32_t v_rows,
+              uint32_t vpos0, uint32_t n_rows, const Tab tb, const float* __restrict__ gw, const float* __restrict__ gv, Hyper h,
+              const double* __restrict__ w0_ptr, const double* __restrict__ reg, double* __restrict__ dreg,
+              const uint32_t* __restrict__ grp, uint32_t G) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  extern __shared__ double lam_lds[];
+  double* lwg = lam_lds;                       // [G]
+  double* sfg = lwg + G;                       // [G][KP]
+  double* sdfg = sfg + (size_t)G * KP;         // [G][KP]
+  const uint32_t lane = threadIdx.x;
+  const bool act = lane < LPR;
+  const double w0 = h.k0 ? *w0_ptr : 0.0;
+  for (uint32_t t = blockIdx.x; t < n_rows; t += gridDim.x) {
+    const uint32_t r = (uint32_t)(((uint64_t)vpos0 + t) % v_rows);
+    const uint64_t va = vrow_ptr[r];
+    const uint32_t vsize = (uint32_t)(vrow_ptr[r + 1] - va);
+    const double vy = (double)vtarget[r];
+    for (uint32_t c = lane; c < G; c += 64) lwg[c] = 0.0;
+    for (uint32_t c = lane; c < G * KP; c += 64) { sfg[c] = 0.0; sdfg[c] = 0.0; }
+    __syncthreads();
+    double plin = 0.0, q_dash = 0.0;
+    double s_dash[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) s_dash[v] = 0.0;
+    for (uint32_t i = 0; i < vsize; i++) {
+      const Entry e = vent[va + i];
+      const uint32_t g = grp ? grp[e.id] : 0u;
+      const double x = (double)e.value;
+      const double* rg = reg + (size_t)g * (1 + KP);
+      if (h.k1 && lane == 0) {
+        const double wv = (double)tb.w[(size_t)e.id * tb.ws];
+        plin += (wv - h.lr_d * ((double)gw[e.id] + 2 * rg[0] * wv)) * x;             // predict_scaled :178-184
+        lwg[g] += x * wv;                                                            // :215-218
+      }
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const size_t c = (size_t)g * KP + lane * VEC + v;
+          const double vv = (double)tb.V[(size_t)e.id * tb.rs + lane * VEC + v];
+          const double v_dash = vv - h.lr_d * ((double)gv[(size_t)e.id * tb.rs + lane * VEC + v] + 2 * rg[1 + lane * VEC + v] * vv);
+          const double d = v_dash * x;
+          s_dash[v] += d; q_dash += d * d;                                           // :186-196
+          sfg[c] += vv * x;                                                          // :233-238
+          sdfg[c] += d * vv * x;
+        }
+      }
+    }
+    double vpart = plin - 0.5 * q_dash;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) vpart += 0.5 * s_dash[v] * s_dash[v];
+    }
+    double vp = w0 + wave_sum_d(vpart);
+    double grad_loss;
+    if (h.task == 0) { vp = fmin(h.max_d, vp); vp = fmax(h.min_d, vp); grad_loss = 2 * (vp - vy); }
+    else grad_loss = vy * ((1.0 / (1.0 + exp(-vy * vp))) - 1.0);
+    __syncthreads();
+    for (uint32_t g = 0; g < G; g++) {
+      if (h.k1 && lane == 0) {
+        const double lw = lwg[g];
+        if (lw != 0.0) unsafeAtomicAdd(dreg + (size_t)g * (1 + KP), -h.lr_d * grad_loss * (-2 * h.lr_d * lw));   // :219-221
+      }
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const size_t c = (size_t)g * KP + lane * VEC + v;
+          const double a = sfg[c], b = sdfg[c];
+          if (a != 0.0 || b != 0.0)
+            unsafeAtomicAdd(dreg + (size_t)g * (1 + KP) + 1 + lane * VEC + v, -h.lr_d * grad_loss * (-2 * h.lr_d * (s_dash[v] * a - b)));   // :240-243
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+static __global__ void k_sgda_reg_update(double* __restrict__ reg, double* __restrict__ dreg, uint32_t cells, int KP, int k1) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += gridDim.x * blockDim.x) {
+    const bool is_w = (c % (uint32_t)(1 + KP)) == 0;
+    if (!is_w || k1) reg[c] = fmax(0.0, reg[c] + dreg[c]);          // :222, :245
+    dreg[c] = 0.0;
   }
 }
 

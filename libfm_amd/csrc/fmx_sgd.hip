@@ -635,6 +635,7 @@ extern "C++" void sgda_free(fmx_handle h) {
   if (h->sgda.gw) hipFree(h->sgda.gw);
   if (h->sgda.gv) hipFree(h->sgda.gv);
   if (h->sgda.reg) hipFree(h->sgda.reg);
+  if (h->sgda.dreg) hipFree(h->sgda.dreg);
   h->sgda = SgdaState();
 }
 
@@ -657,6 +658,8 @@ int fmx_sgda_begin(fmx_handle h) {
   HIPCHK(h, hipMalloc(&h->sgda.gw, h->n_local * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->sgda.gv, nv * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->sgda.reg, nreg * sizeof(double)));
+  HIPCHK(h, hipMalloc(&h->sgda.dreg, nreg * sizeof(double)));
+  HIPCHK(h, hipMemsetAsync(h->sgda.dreg, 0, nreg * sizeof(double), h->stream));
   HIPCHK(h, hipMemsetAsync(h->sgda.gw, 0, h->n_local * sizeof(float), h->stream));
   HIPCHK(h, hipMemsetAsync(h->sgda.gv, 0, nv * sizeof(float), h->stream));
   HIPCHK(h, hipMemsetAsync(h->sgda.reg, 0, nreg * sizeof(double), h->stream));
@@ -714,6 +717,76 @@ int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lam
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     stats->rows = s.n_rows; stats->batches = s.n_rows; stats->device_seconds = ms * 1e-3;
     stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = 1;
+  }
+  return FMX_OK;
+}
+
+// the batch form of the learner (oracle fmo_sgda_epoch_minibatch): per batch of `batch` train rows the theta step as a
+// minibatch rule, then -- do_lambda_steps -- the lambda steps of the next `batch` validation rows, summed and applied once
+int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, uint32_t batch,
+                             uint32_t w0_chunk, fmx_epoch_stats* stats) {
+  int rc = check_slot(h, train_slot, true);
+  if (rc) return rc;
+  rc = check_slot(h, validation_slot, true);
+  if (rc) return rc;
+  if (!h->sgda.reg) return fail(h, FMX_E_STATE, "fmx_sgda_epoch_minibatch before fmx_sgda_begin");
+  { int _rc = lag_flush(h); if (_rc) return _rc; }
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[train_slot];
+  const Slot& v = h->slots[validation_slot];
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (s.n_rows == 0) return FMX_OK;
+  Hyper hy = make_hyper(h->cfg);
+  hy.sgda = 1; hy.reg0 = 0.f; hy.reg0_d = 0.0;                  // reg_0 = 0 (:100, :149)
+  const uint32_t B = batch ? batch : 16384u;
+  // micro-chunk of the bias: this learner's regression multiplier is 2 (p - y), i.e. twice the curvature of plain SGD
+  uint32_t chunk = w0_chunk ? w0_chunk : std::max<uint32_t>(1u, default_w0_chunk(h->cfg) / (h->cfg.task == FMX_TASK_REGRESSION ? 2u : 1u));
+  rc = ensure_segments(h, s, B);
+  if (rc) return rc;
+  const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
+  rc = ensure_scratch(h, Bc, 0);
+  if (rc) return rc;
+  const size_t G = h->num_groups, cells = G * (1 + (size_t)h->KP);
+  const size_t lds = (G + 2 * G * (size_t)h->KP) * sizeof(double);
+  if (do_lambda_steps && lds > 64 * 1024)
+    return fail(h, FMX_E_UNSUPPORTED, "SGDA batch form: %zu attribute groups x %d factors need %zu bytes of LDS per validation row (limit 65536)", G, h->KP, lds);
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipEventRecord(h->ev0, st));
+  uint64_t vpos = 0, batches = 0;                                // validation->data->begin() at the start of the epoch (:266)
+  for (uint64_t row0 = 0; row0 < s.n_rows; row0 += B) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
+    float* S = h->partial;
+    float* rest = S + (size_t)nb * h->KP;
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, st, s.ent, s.row_ptr, row0, nb, h->tb, h->cfg.k1, S, rest));
+    rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, h->mult, st);
+    if (rc) return rc;
+    const size_t bi = (size_t)(row0 / B);
+    const uint32_t s0 = s.batch_seg[bi], s1 = s.batch_seg[bi + 1];
+    const uint64_t base = s.batch_base[bi];
+    if (s1 > s0) {
+      SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nullptr, s1 - s0, s1 - s0, (uint32_t)(s.batch_base[bi + 1] - base), S, h->mult};
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_sgda_apply_seg<KP, 4>), ((uint64_t)(s1 - s0) + 63) / 64, st, sw, h->tb, hy,
+                                         (const double*)h->sgda.reg, (const uint32_t*)h->grp, h->sgda.gw, h->sgda.gv));
+    }
+    if (do_lambda_steps && v.n_rows) {
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda_lambda<KP>), dim3(std::min<uint32_t>(nb, 8192)), dim3(64), lds, st, v.ent, v.row_ptr, v.target,
+                                            v.n_rows, (uint32_t)vpos, nb, h->tb, (const float*)h->sgda.gw, (const float*)h->sgda.gv, hy,
+                                            (const double*)h->w0, (const double*)h->sgda.reg, h->sgda.dreg, (const uint32_t*)h->grp, (uint32_t)G));
+      hipLaunchKernelGGL(k_sgda_reg_update, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, h->sgda.reg, h->sgda.dreg, (uint32_t)cells,
+                         h->KP, h->cfg.k1);
+      vpos = (vpos + nb) % v.n_rows;
+    }
+    HIPCHK(h, hipGetLastError());
+    batches++;
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (stats) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    stats->rows = s.n_rows; stats->batches = batches; stats->device_seconds = ms * 1e-3;
+    stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = batches;
+    stats->max_feature_count = s.max_seg_count;
   }
   return FMX_OK;
 }

@@ -387,6 +387,159 @@ static void sgda_lambda_step(fmo_model *m, fmo_sgda_state *st, const fmo_entry *
   free(acc);
 }
 
+/* The minibatch restatement of SGDA used by the GPU batch form (fmx_sgda_epoch_minibatch), in the spirit of
+ * fmo_sgd_epoch_minibatch: per batch of B train rows
+ *   theta: steps 1-3 of the batch rule with this learner's multiplier (2 (p - y) for regression, :142), reg_0 = 0 and the
+ *          LEARNED regularisation 2 reg(g[,f]) theta per occurrence (:149-166); the shadow gradient of a touched parameter
+ *          becomes the SUM of its occurrences' gradients in the batch (one occurrence: the reference's value);
+ *   lambda (do_lambda_steps): the next B validation rows (cyclic, :271-274), every one evaluated like sgd_lambda_step
+ *          (:201-248 through predict_scaled :171-199) with the parameters and shadows the theta step just left and the
+ *          regularisation values of the batch START; their reg changes are summed and applied -- clamped at 0 -- once.
+ * batch == 1 and w0_chunk == 1: the reference loop (rows without a repeated id), see the tests. */
+void fmo_sgda_epoch_minibatch(fmo_model *m, fmo_sgda_state *st, const fmo_data *train, const fmo_data *val, int task,
+                              double learn_rate, double min_target, double max_target, int do_lambda_steps,
+                              uint32_t batch, uint32_t w0_chunk) {
+  const int k = m->k;
+  const size_t n = (size_t)m->n, kk = (size_t)(k > 0 ? k : 1);
+  const uint32_t G = st->num_groups;
+  const double lr = learn_rate;
+  if (batch == 0 || batch > train->n_rows) batch = train->n_rows;
+  if (w0_chunk == 0 || w0_chunk > batch) w0_chunk = batch;
+  double *S = (double *)malloc(sizeof(double) * (size_t)batch * kk);
+  double *rest = (double *)malloc(sizeof(double) * batch);
+  double *mult = (double *)malloc(sizeof(double) * batch);
+  double *dw = (double *)calloc(n, sizeof(double)), *dv = (double *)calloc(n * kk, sizeof(double));
+  double *gw = (double *)calloc(n, sizeof(double)), *gv = (double *)calloc(n * kk, sizeof(double));   /* this batch's shadow sums */
+  unsigned char *touched = (unsigned char *)calloc(n ? n : 1, 1);
+  double *dreg_w = (double *)malloc(sizeof(double) * G), *dreg_v = (double *)malloc(sizeof(double) * G * kk);
+  double *reg_w0 = (double *)malloc(sizeof(double) * G), *reg_v0 = (double *)malloc(sizeof(double) * G * kk);
+  double *acc = (double *)malloc(sizeof(double) * 2 * G);
+  st->val_pos = 0;
+  for (uint32_t r0 = 0; r0 < train->n_rows; r0 += batch) {
+    const uint32_t nb = (train->n_rows - r0 < batch) ? (train->n_rows - r0) : batch;
+    /* ---- theta, step 1 */
+    for (uint32_t e = 0; e < nb; e++) {
+      const fmo_entry *row = train->entries + train->row_ptr[r0 + e];
+      const uint32_t size = (uint32_t)(train->row_ptr[r0 + e + 1] - train->row_ptr[r0 + e]);
+      double res = 0;
+      if (m->k1) for (uint32_t i = 0; i < size; i++) res += m->w[row[i].id] * row[i].value;
+      for (int f = 0; f < k; f++) {
+        double s = 0, q = 0;
+        for (uint32_t i = 0; i < size; i++) { double d = V(m, f, row[i].id) * row[i].value; s += d; q += d * d; }
+        S[(size_t)e * kk + f] = s;
+        res += 0.5 * (s * s - q);
+      }
+      rest[e] = res;
+    }
+    /* ---- theta, step 2: bias micro-chunks, reg_0 = 0 */
+    for (uint32_t c0 = 0; c0 < nb; c0 += w0_chunk) {
+      const uint32_t nc = (nb - c0 < w0_chunk) ? (nb - c0) : w0_chunk;
+      const double w0s = m->k0 ? m->w0 : 0.0;
+      double a = 0;
+      for (uint32_t e = c0; e < c0 + nc; e++) {
+        double p = w0s + rest[e];
+        const double y = (double)train->target[r0 + e];
+        double me;
+        if (task == 0) { p = (max_target < p) ? max_target : p; p = (min_target > p) ? min_target : p; me = 2 * (p - y); }
+        else me = y * ((1.0 / (1.0 + exp(-y * p))) - 1.0);
+        mult[e] = me;
+        a += me;
+      }
+      if (m->k0) m->w0 -= lr * a;
+    }
+    /* ---- theta, step 3 */
+    for (uint32_t e = 0; e < nb; e++) {
+      const fmo_entry *row = train->entries + train->row_ptr[r0 + e];
+      const uint32_t size = (uint32_t)(train->row_ptr[r0 + e + 1] - train->row_ptr[r0 + e]);
+      for (uint32_t i = 0; i < size; i++) {
+        const size_t j = row[i].id;
+        const uint32_t g = GRP(st, j);
+        const double x = row[i].value;
+        touched[j] = 1;
+        if (m->k1) { const double gr = mult[e] * x; gw[j] += gr; dw[j] += -(lr * (gr + 2 * st->reg_w[g] * m->w[j])); }
+        for (int f = 0; f < k; f++) {
+          const double v = V(m, f, j);
+          const double gr = mult[e] * (x * (S[(size_t)e * kk + f] - v * x));
+          gv[(size_t)f * n + j] += gr;
+          dv[(size_t)f * n + j] += -(lr * (gr + 2 * st->reg_v[(size_t)g * k + f] * v));
+        }
+      }
+    }
+    for (uint32_t e = 0; e < nb; e++) {                           /* apply, move the shadows, clear */
+      const fmo_entry *row = train->entries + train->row_ptr[r0 + e];
+      const uint32_t size = (uint32_t)(train->row_ptr[r0 + e + 1] - train->row_ptr[r0 + e]);
+      for (uint32_t i = 0; i < size; i++) {
+        const size_t j = row[i].id;
+        if (!touched[j]) continue;
+        touched[j] = 0;
+        if (m->k1) { m->w[j] += dw[j]; st->grad_w[j] = gw[j]; dw[j] = 0; gw[j] = 0; }
+        for (int f = 0; f < k; f++) {
+          const size_t c = (size_t)f * n + j;
+          V(m, f, j) += dv[c]; st->grad_v[c] = gv[c]; dv[c] = 0; gv[c] = 0;
+        }
+      }
+    }
+    if (!do_lambda_steps || val->n_rows == 0) continue;
+    /* ---- lambda over the next nb validation rows, regularisation frozen at its batch-start values */
+    memcpy(reg_w0, st->reg_w, sizeof(double) * G);
+    memcpy(reg_v0, st->reg_v, sizeof(double) * G * (size_t)k);
+    for (uint32_t g = 0; g < G; g++) dreg_w[g] = 0;
+    for (size_t c = 0; c < (size_t)G * kk; c++) dreg_v[c] = 0;
+    for (uint32_t t = 0; t < nb; t++) {
+      if (st->val_pos >= val->n_rows) st->val_pos = 0;
+      const fmo_entry *row = val->entries + val->row_ptr[st->val_pos];
+      const uint32_t size = (uint32_t)(val->row_ptr[st->val_pos + 1] - val->row_ptr[st->val_pos]);
+      const double target = (double)val->target[st->val_pos];
+      st->val_pos++;
+      double p = 0.0;
+      if (m->k0) p += m->w0;
+      if (m->k1)
+        for (uint32_t i = 0; i < size; i++) {
+          const uint32_t g = GRP(st, row[i].id);
+          const double w = m->w[row[i].id];
+          p += (w - lr * (st->grad_w[row[i].id] + 2 * reg_w0[g] * w)) * row[i].value;
+        }
+      for (int f = 0; f < k; f++) {
+        double s = 0.0, q = 0.0;
+        for (uint32_t i = 0; i < size; i++) {
+          const uint32_t g = GRP(st, row[i].id);
+          const double v = V(m, f, row[i].id);
+          const double d = (v - lr * (st->grad_v[(size_t)f * n + row[i].id] + 2 * reg_v0[(size_t)g * k + f] * v)) * row[i].value;
+          s += d; q += d * d;
+        }
+        p += 0.5 * (s * s - q);
+      }
+      double grad_loss;
+      if (task == 0) { p = (max_target < p) ? max_target : p; p = (min_target > p) ? min_target : p; grad_loss = 2 * (p - target); }
+      else grad_loss = target * ((1.0 / (1.0 + exp(-target * p))) - 1.0);
+      if (m->k1) {
+        for (uint32_t g = 0; g < G; g++) acc[g] = 0;
+        for (uint32_t i = 0; i < size; i++) acc[GRP(st, row[i].id)] += row[i].value * m->w[row[i].id];
+        for (uint32_t g = 0; g < G; g++) dreg_w[g] -= lr * grad_loss * (-2 * lr * acc[g]);
+      }
+      for (int f = 0; f < k; f++) {
+        double sum_f_dash = 0.0;
+        double *sum_f = acc, *sum_f_dash_f = acc + G;
+        for (uint32_t g = 0; g < 2 * G; g++) acc[g] = 0.0;
+        for (uint32_t i = 0; i < size; i++) {
+          const uint32_t g = GRP(st, row[i].id);
+          const double v = V(m, f, row[i].id);
+          const double v_dash = v - lr * (st->grad_v[(size_t)f * n + row[i].id] + 2 * reg_v0[(size_t)g * k + f] * v);
+          sum_f_dash += v_dash * row[i].value;
+          sum_f[g] += v * row[i].value;
+          sum_f_dash_f[g] += v_dash * row[i].value * v * row[i].value;
+        }
+        for (uint32_t g = 0; g < G; g++)
+          dreg_v[(size_t)g * k + f] -= lr * grad_loss * (-2 * lr * (sum_f_dash * sum_f[g] - sum_f_dash_f[g]));
+      }
+    }
+    for (uint32_t g = 0; g < G; g++) { const double x = reg_w0[g] + dreg_w[g]; st->reg_w[g] = m->k1 ? ((0.0 > x) ? 0.0 : x) : reg_w0[g]; }
+    for (size_t c = 0; c < (size_t)G * (size_t)k; c++) { const double x = reg_v0[c] + dreg_v[c]; st->reg_v[c] = (0.0 > x) ? 0.0 : x; }
+  }
+  free(S); free(rest); free(mult); free(dw); free(dv); free(gw); free(gv); free(touched);
+  free(dreg_w); free(dreg_v); free(reg_w0); free(reg_v0); free(acc);
+}
+
 /* one iteration of fm_learn_sgd_element_adapt_reg::learn (:262-279) */
 void fmo_sgda_epoch(fmo_model *m, fmo_sgda_state *st, const fmo_data *train, const fmo_data *val, int task,
                     double learn_rate, double min_target, double max_target, int do_lambda_steps) {

@@ -132,6 +132,12 @@ typedef struct {
 } fmo_sgda_state;
 void fmo_sgda_epoch(fmo_model *m, fmo_sgda_state *st, const fmo_data *train, const fmo_data *val, int task,
                     double learn_rate, double min_target, double max_target, int do_lambda_steps);
+/* the batch restatement (GPU: fmx_sgda_epoch_minibatch): theta steps as a minibatch rule with the learned regularisation
+ * and summed shadow gradients, then the batch's lambda steps with the regularisation frozen at its batch-start values,
+ * summed and clamped once.  batch = w0_chunk = 1 is the reference loop (see fm_oracle.c). */
+void fmo_sgda_epoch_minibatch(fmo_model *m, fmo_sgda_state *st, const fmo_data *train, const fmo_data *val, int task,
+                              double learn_rate, double min_target, double max_target, int do_lambda_steps,
+                              uint32_t batch, uint32_t w0_chunk);
 
 /* ---------------- ALS (coordinate descent; "MCMC without sampling", libfm.cpp:135-139) ---------------- */
 

@@ -82,6 +82,8 @@ def lib():
                                            C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.fmo_sgda_epoch.argtypes = [C.POINTER(_Model), C.POINTER(_SgdaState), C.POINTER(_Data), C.POINTER(_Data), C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_int]
+        L.fmo_sgda_epoch_minibatch.argtypes = [C.POINTER(_Model), C.POINTER(_SgdaState), C.POINTER(_Data), C.POINTER(_Data), C.c_int,
+                                               C.c_double, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_uint32]
         L.fmo_fill_params.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_double, C.c_int]
         L.fmo_time_sgd_synth.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_double]
         L.fmo_time_sgd_synth.restype = C.c_double
@@ -305,8 +307,9 @@ class SgdaState:
         self.grad_v = np.zeros((max(k, 1), n), dtype=np.float64)
 
 
-def sgda_learn(m, train, val, task, lr, min_target, max_target, num_iter, group=None):
-    """fm_learn_sgd_element_adapt_reg::learn (:250-279): w := 0, regs := 0, then num_iter epochs (lambda steps from the 2nd)."""
+def sgda_learn(m, train, val, task, lr, min_target, max_target, num_iter, group=None, batch=None, w0_chunk=1):
+    """fm_learn_sgd_element_adapt_reg::learn (:250-279): w := 0, regs := 0, then num_iter epochs (lambda steps from the 2nd).
+    batch: None = the reference's online loop; an int = the batch restatement (fmo_sgda_epoch_minibatch)."""
     st = SgdaState(m.n, m.k, group)
     if m.k == 0:
         st.reg_v = np.zeros((st.num_groups, 0), dtype=np.float64)
@@ -315,6 +318,10 @@ def sgda_learn(m, train, val, task, lr, min_target, max_target, num_iter, group=
         cm, ctr, cv = m._c(), train._c(), val._c()
         cs = _SgdaState(st.reg_w.ctypes.data, st.reg_v.ctypes.data, st.grad_w.ctypes.data, st.grad_v.ctypes.data, 0,
                         st.num_groups, None if st.group is None else st.group.ctypes.data)
-        lib().fmo_sgda_epoch(C.byref(cm), C.byref(cs), C.byref(ctr), C.byref(cv), task, lr, min_target, max_target, int(i > 0))
+        if batch is None:
+            lib().fmo_sgda_epoch(C.byref(cm), C.byref(cs), C.byref(ctr), C.byref(cv), task, lr, min_target, max_target, int(i > 0))
+        else:
+            lib().fmo_sgda_epoch_minibatch(C.byref(cm), C.byref(cs), C.byref(ctr), C.byref(cv), task, lr, min_target, max_target,
+                                           int(i > 0), int(batch), int(w0_chunk))
         m.w0 = cm.w0
     return st
