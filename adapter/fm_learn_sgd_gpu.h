@@ -173,6 +173,10 @@ class fm_learn_sgd_gpu : public fmx_sgd_binding<fm_learn_sgd> {
 #ifdef FM_LEARN_SGD_ELEMENT_ADAPT_REG_H_
 class fm_learn_sgda_gpu : public fmx_sgd_binding<fm_learn_sgd_element_adapt_reg> {
  public:
+  // 0 (default): the reference's strictly online order on one wavefront (a parity instrument, slower than the CPU);
+  // > 0: the batch form (fmx_sgda_epoch_minibatch) with batches of gpu_batch rows and bias micro-chunks of gpu_w0_chunk
+  uint gpu_batch, gpu_w0_chunk;
+  fm_learn_sgda_gpu() : gpu_batch(0), gpu_w0_chunk(0) {}
   virtual void learn(Data& train, Data& test) {
     fm_learn_sgd::learn(train, test);                     // prints learnrate/#iterations, rejects relations
     if (validation == NULL) throw "sgda needs a validation set";
@@ -190,7 +194,8 @@ class fm_learn_sgda_gpu : public fmx_sgd_binding<fm_learn_sgd_element_adapt_reg>
     std::vector<double> reg((size_t)G * (1 + fm->num_factor));
     for (int i = 0; i < num_iter; i++) {
       fmx_epoch_stats st;
-      check(fmx_sgda_epoch(h, s_train, s_val, i > 0, &st));             // no lambda steps in the first iteration (:269)
+      if (gpu_batch > 0) check(fmx_sgda_epoch_minibatch(h, s_train, s_val, i > 0, gpu_batch, gpu_w0_chunk, &st));
+      else check(fmx_sgda_epoch(h, s_train, s_val, i > 0, &st));        // no lambda steps in the first iteration (:269)
       double rmse_val = evaluate_slot(s_val);
       double rmse_train = evaluate_slot(s_train);
       double rmse_test = evaluate_slot(s_test);

@@ -372,7 +372,7 @@ int fmx_group_als_end(fmx_group g);
 
 /* ---- fm_learn_sgd_element_adapt_reg (`-method sgda`; src/libfm/src/fm_learn_sgd_element_adapt_reg.h) -------------
  * Self-adaptive regularisation: theta steps on the train rows alternate with lambda steps on the validation rows,
- * strictly online, so this learner exists in the reference-order (one wavefront) form only.  Regularisation is
+ * strictly online: fmx_sgda_epoch is that order on one wavefront (a parity instrument), fmx_sgda_epoch_minibatch the batch form.  Regularisation is
  * learned per attribute group (fmx_set_groups): reg_w(g), reg_v(g,f).
  *   fmx_sgda_begin : the learner's start of learn() (:256-262): w := 0, reg_w := 0, reg_v := 0, shadow gradients := 0
  *   fmx_sgda_epoch : one iteration of the epoch loop (:262-279); do_lambda_steps = 0 in the first iteration (:269)
@@ -381,6 +381,14 @@ int fmx_group_als_end(fmx_group g);
  */
 int fmx_sgda_begin(fmx_handle h);
 int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, fmx_epoch_stats *stats);
+/* the learner in BATCH form (oracle fmo_sgda_epoch_minibatch; the online order above is one wavefront and slower than the
+ * reference's CPU): per batch of `batch` train rows (0 = 16384) the theta steps as a minibatch rule -- this learner's
+ * multiplier, reg_0 = 0, the learned regularisation 2 reg(g[,f]) theta per occurrence, the shadow gradient of a touched
+ * parameter = the sum of its occurrences' gradients -- then, do_lambda_steps, the lambda steps of the next `batch` validation
+ * rows (cyclic, :271-274), each as sgd_lambda_step (:201-248) with the regularisation of the batch start, their changes
+ * summed and applied, clamped at 0, once.  batch = w0_chunk = 1 is the reference's loop.  w0_chunk 0 = library default. */
+int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, uint32_t batch,
+                             uint32_t w0_chunk, fmx_epoch_stats *stats);
 int fmx_sgda_get_reg(fmx_handle h, double *reg /* [G][1 + num_factor] */);
 int fmx_sgda_end(fmx_handle h);
 

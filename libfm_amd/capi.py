@@ -132,6 +132,7 @@ SYMBOLS = [
     ("fmx_group_als_end", C.c_int, [H]),
     ("fmx_sgda_begin", C.c_int, [H]),
     ("fmx_sgda_epoch", C.c_int, [H, C.c_int, C.c_int, C.c_int, C.POINTER(EpochStats)]),
+    ("fmx_sgda_epoch_minibatch", C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(EpochStats)]),
     ("fmx_sgda_get_reg", C.c_int, [H, C.c_void_p]),
     ("fmx_sgda_end", C.c_int, [H]),
     ("fmx_als_begin", C.c_int, [H, C.c_int]),
@@ -341,6 +342,11 @@ class Handle:
     def sgda_epoch(self, train_slot, val_slot, do_lambda):
         st = EpochStats()
         self._chk(self.lib.fmx_sgda_epoch(self.h, train_slot, val_slot, int(do_lambda), C.byref(st)))
+        return st
+
+    def sgda_epoch_minibatch(self, train_slot, val_slot, do_lambda, batch=0, w0_chunk=0):
+        st = EpochStats()
+        self._chk(self.lib.fmx_sgda_epoch_minibatch(self.h, train_slot, val_slot, int(do_lambda), int(batch), int(w0_chunk), C.byref(st)))
         return st
 
     def sgda_get_reg(self):

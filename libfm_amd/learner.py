@@ -379,10 +379,12 @@ def _keep_finite(new, old):
 
 class FMLearnSGDA(FMLearnSGD):
     """fm_learn_sgd_element_adapt_reg (`-method sgda`, fm_learn_sgd_element_adapt_reg.h:44-93) on the GPU: theta steps
-    on the train rows alternate with lambda steps on `validation` (libfm.cpp:276-279).  Reference-order only."""
+    on the train rows alternate with lambda steps on `validation` (libfm.cpp:276-279).  gpu_batch = 0: the reference's
+    strictly online order (one wavefront, parity); > 0: the batch form (fmx_sgda_epoch_minibatch)."""
 
     def __init__(self):
         super().__init__()
+        self.gpu_batch, self.gpu_w0_chunk = 0, 0
         self.validation = None
         self.groups = None               # DataMetaInfo::attr_group (None = one group)
         self.reg_w = 0.0                 # one group: scalar / [k]; with groups: [G] / [G][k]  (:84-85)
@@ -398,7 +400,8 @@ class FMLearnSGDA(FMLearnSGD):
         h.set_groups(self.groups)
         h.sgda_begin()
         for i in range(self.num_iter):
-            stats = h.sgda_epoch(st, sv, i > 0)
+            stats = (h.sgda_epoch_minibatch(st, sv, i > 0, self.gpu_batch, self.gpu_w0_chunk) if self.gpu_batch > 0
+                     else h.sgda_epoch(st, sv, i > 0))
             rmse_val = self.evaluate(self.validation)
             rmse_train = self.evaluate(train)
             rmse_test = self.evaluate(test)

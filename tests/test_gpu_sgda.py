@@ -50,3 +50,81 @@ def test_sgda_matches_reference(oracle, name):
         np.testing.assert_allclose(l.reg_v, z["regs"][1:], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(l.predict(test), z["pred_out"], rtol=1e-4, atol=5e-5)
     l.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the batch form (fmx_sgda_epoch_minibatch) against its oracle restatement (fmo_sgda_epoch_minibatch, itself pinned to the
+# reference at batch 1 by tests/test_oracle_sgda_golden.py): parameters 1e-4, learned regularisation 1e-3
+# ---------------------------------------------------------------------------------------------
+def _val(g):
+    vt = g.z["val_target"].copy()
+    return np.where(vt <= 0, -1.0, 1.0).astype(np.float32) if g.task == 1 else vt
+
+
+@pytest.mark.parametrize("name,batch,chunk", [("sgda_reg_ml", 1, 1), ("sgda_reg_ml", 16, 4), ("sgda_reg_ml", 100, 8),
+                                              ("sgda_cls_fields", 32, 8), ("sgda_cls_fields", 7, 1),
+                                              ("sgda_reg_ml_groups", 16, 4), ("sgda_cls_fields_groups", 50, 10)])
+def test_sgda_batch_form_matches_its_rule(oracle, name, batch, chunk):
+    from libfm_amd import capi
+    O = oracle
+    g = Golden(name)
+    z = g.z
+    group = z["group"] if "group" in z.files else None
+    m = g.model(O, "init")
+    m.reg0 = m.regw = m.regv = 0.0
+    tr = g.data(O, "train")
+    va = O.Data(z["val_entries"], z["val_row_ptr"], _val(g))
+    h = capi.Handle(g.n, g.k, g.k0, g.k1, g.task, 0.0, 0.0, 0.0, g.lr, g.min_target, g.max_target)
+    h.set_params(m.w0, m.w, m.v)
+    if group is not None:
+        h.set_groups(group)
+    h.upload_rows(0, tr.entries, tr.row_ptr, tr.target)
+    h.upload_rows(1, va.entries, va.row_ptr, va.target)
+    h.sgda_begin()
+    for i in range(g.iters):
+        h.sgda_epoch_minibatch(0, 1, i > 0, batch, chunk)
+    reg = h.sgda_get_reg()
+    w0, w, v = h.get_params()
+    h.sgda_end()
+    h.close()
+    st = O.sgda_learn(m, tr, va, g.task, g.lr, g.min_target, g.max_target, g.iters, group, batch=batch, w0_chunk=chunk)
+    assert abs(w0 - m.w0) <= 1e-4 * abs(m.w0) + 2e-5
+    np.testing.assert_allclose(w, m.w, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(reg[:, 0], st.reg_w, rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(reg[:, 1:], st.reg_v[:, :g.k], rtol=1e-3, atol=1e-7)
+    if batch == 1 and not g.has_duplicate_ids():               # ... and at batch 1 that rule is the reference itself
+        np.testing.assert_allclose(v, z["final_v"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(w, z["final_w"], rtol=1e-4, atol=2e-5)
+
+
+def test_sgda_batch_form_mid_size(oracle):
+    """20 000 train / 5 000 validation rows over 6 400 one-hot features, k = 16, batch 1 024: thousands of features collide in
+    every batch, the validation pointer wraps around four times per epoch"""
+    from libfm_amd import capi
+    import datagen
+    O = oracle
+    n, nnz, k, lr = 6400, 8, 16, 0.002
+    ent, rp, y = datagen.onehot_fields(n, nnz, 20000, seed=3, classification=False)
+    ev, rv, yv = datagen.onehot_fields(n, nnz, 5000, seed=4, classification=False)
+    lo, hi = float(y.min()), float(y.max())
+    m = O.Model(n, k, True, True, 0.0, 0.0, 0.0)
+    m.v[:] = O.init_values(9, n, k, 0.05)
+    tr, va = O.Data(ent, rp, y), O.Data(ev, rv, yv)
+    h = capi.Handle(n, k, True, True, 0, 0.0, 0.0, 0.0, lr, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, rp, y)
+    h.upload_rows(1, ev, rv, yv)
+    h.sgda_begin()
+    for i in range(3):
+        h.sgda_epoch_minibatch(0, 1, i > 0, 1024, 64)
+    reg = h.sgda_get_reg()
+    w0, w, v = h.get_params()
+    h.sgda_end()
+    h.close()
+    st = O.sgda_learn(m, tr, va, 0, lr, lo, hi, 3, None, batch=1024, w0_chunk=64)
+    assert abs(w0 - m.w0) <= 1e-4 * abs(m.w0) + 2e-5
+    np.testing.assert_allclose(w, m.w, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(reg[0, 0], st.reg_w[0], rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(reg[0, 1:], st.reg_v[0, :k], rtol=2e-3, atol=1e-7)
