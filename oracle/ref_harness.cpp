@@ -235,7 +235,12 @@ int main(int argc, char** argv) {
       validation.relation.setSize(0);
       fm_learn_sgd_element_adapt_reg* fml;
 #ifdef FMX_WITH_GPU_ADAPTER
-      if (sgda_gpu) fml = new fm_learn_sgda_gpu(); else
+      if (sgda_gpu) {
+        fm_learn_sgda_gpu* gl = new fm_learn_sgda_gpu();
+        if (const char* e = getenv("FMX_GPU_BATCH")) gl->gpu_batch = (uint)atoi(e);            // > 0: the batch form of the learner
+        if (const char* e = getenv("FMX_GPU_W0_CHUNK")) gl->gpu_w0_chunk = (uint)atoi(e);
+        fml = gl;
+      } else
 #endif
       fml = new fm_learn_sgd_element_adapt_reg();
       fml->num_iter = iters;

@@ -126,10 +126,11 @@ def test_reference_driver_with_gpu_als_learner_on_relations(oracle, tmp_path):
     np.testing.assert_allclose(pred_out, z["pred_out"], rtol=1e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("name", ["sgda_reg_ml", "sgda_cls_fields_groups"])
-def test_reference_driver_with_gpu_sgda_learner(oracle, name, tmp_path):
+@pytest.mark.parametrize("name,batch", [("sgda_reg_ml", 0), ("sgda_cls_fields_groups", 0), ("sgda_reg_ml", 16), ("sgda_cls_fields_groups", 32)])
+def test_reference_driver_with_gpu_sgda_learner(oracle, name, batch, tmp_path):
     """adapter fm_learn_sgda_gpu (`-method sgda`): the reference's loaders / init / output code with the device learner
-    must land on the stock fm_learn_sgd_element_adapt_reg results, incl. the learned reg_w(g), reg_v(g,f)."""
+    must land on the stock fm_learn_sgd_element_adapt_reg results, incl. the learned reg_w(g), reg_v(g,f) (batch 0: the
+    reference's online order) -- or, gpu_batch > 0, on the oracle's batch restatement of the learner."""
     if not os.path.exists(HARNESS):
         pytest.skip("oracle/_ref/ref_harness_gpu not built (needs /root/reference at build time)")
     O = oracle
@@ -148,10 +149,25 @@ def test_reference_driver_with_gpu_sgda_learner(oracle, name, tmp_path):
     pre = os.path.join(td, "out")
     cfg = ["sgda_gpu", f[0], f[1], str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]), repr(g.lr),
            "0", "0", "0", repr(float(z["init_stdev"])), int(z["seed"]), pre, f[2]]
+    if batch:
+        env["FMX_GPU_BATCH"], env["FMX_GPU_W0_CHUNK"] = str(batch), "4"
     r = subprocess.run([HARNESS] + [str(c) for c in cfg], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Training using self-adaptive-regularization SGD." in r.stdout and "#Iter=" in r.stdout
     final = O.Model.from_dump(pre + ".final.bin")
+    if batch:                                                  # the oracle's batch rule from the same (reference-seeded) start
+        m = O.Model.from_dump(pre + ".init.bin")
+        m.reg0 = m.regw = m.regv = 0.0
+        vt = z["val_target"].copy()
+        if g.task == 1:
+            vt = np.where(vt <= 0, -1.0, 1.0).astype(np.float32)
+        st = O.sgda_learn(m, g.data(O, "train"), O.Data(z["val_entries"], z["val_row_ptr"], vt), g.task, g.lr, g.min_target,
+                          g.max_target, g.iters, z["group"] if "group" in z.files else None, batch=batch, w0_chunk=4)
+        np.testing.assert_allclose(final.v, m.v, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(final.w, m.w, rtol=1e-4, atol=2e-5)
+        want = np.concatenate([np.concatenate([[st.reg_w[gg]], st.reg_v[gg, :g.k]]) for gg in range(st.num_groups)])
+        np.testing.assert_allclose(np.loadtxt(pre + ".reg.txt").ravel(), want, rtol=1e-3, atol=1e-7)
+        return
     np.testing.assert_allclose(final.v, z["final_v"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(final.w, z["final_w"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(np.loadtxt(pre + ".reg.txt"), z["regs"], rtol=1e-3, atol=1e-7)
