@@ -217,6 +217,19 @@ typedef struct fmx_relation {
 } fmx_relation;
 int fmx_upload_block_rows(fmx_handle h, int slot, const void *entries, const uint64_t *row_ptr, const float *target,
                           uint32_t n_rows, uint64_t nnz, const fmx_relation *relations, uint32_t n_relations);
+/* the same with a choice of representation:
+ *   FMX_BLOCKS_EXPAND  the joined rows are materialised on the device (what fmx_upload_block_rows does): any learner runs on
+ *                      them, at the data volume of the joined table;
+ *   FMX_BLOCKS_KEEP    main rows and blocks stay apart, as in the reference: fmx_predict / fmx_evaluate add the block rows'
+ *                      sums through the mapping, and fmx_als_* sweeps a block's attributes through per-block-row caches
+ *                      (fm_learn_mcmc.h:478-527 cache set-up, :734-790 draw_w_rel, :849-909 draw_v_rel, restated): a block
+ *                      attribute costs its column in the BLOCK plus two passes over the main rows per block and coordinate
+ *                      family, not a column of the joined table.  ALS / MCMC and predict only (the reference's SGD learners
+ *                      reject relations too, fm_learn_sgd.h:61-63). */
+#define FMX_BLOCKS_EXPAND 0u
+#define FMX_BLOCKS_KEEP 1u
+int fmx_upload_block_rows_ex(fmx_handle h, int slot, const void *entries, const uint64_t *row_ptr, const float *target,
+                             uint32_t n_rows, uint64_t nnz, const fmx_relation *relations, uint32_t n_relations, uint32_t flags);
 /* synthetic one-hot field rows generated on the device (bench workload; same
  * definition as oracle/fm_oracle.c fmo_synth_rows): rows row0 .. row0+n_rows-1 */
 int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz);

@@ -17,6 +17,7 @@ APPLY_DEFAULT, APPLY_ATOMIC, APPLY_STORE, APPLY_SEGMENTED, APPLY_FUSED = 0, 1, 2
 FLAG_TIME_MAIN_KERNEL = 1
 FLAG_BIAS_LAG = 2
 FLAG_PIPELINE = 4
+BLOCKS_EXPAND, BLOCKS_KEEP = 0, 1
 COMM_ID_BYTES = 128
 MAX_SLOTS = 8
 
@@ -101,6 +102,8 @@ SYMBOLS = [
     ("fmx_upload_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     ("fmx_upload_block_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                         C.POINTER(Relation), C.c_uint32]),
+    ("fmx_upload_block_rows_ex", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                           C.POINTER(Relation), C.c_uint32, C.c_uint32]),
     ("fmx_read_libsvm", C.c_int, [C.c_char_p, C.POINTER(HostRows), C.c_char_p, C.c_size_t]),
     ("fmx_read_binary", C.c_int, [C.c_char_p, C.POINTER(HostRows), C.c_char_p, C.c_size_t]),
     ("fmx_free_host_rows", None, [C.POINTER(HostRows)]),
@@ -284,9 +287,10 @@ class Handle:
         self._chk(self.lib.fmx_free_rows(self.h, slot))
 
     # compute ---------------------------------------------------------------------------------
-    def upload_block_rows(self, slot, entries, row_ptr, target, relations):
+    def upload_block_rows(self, slot, entries, row_ptr, target, relations, keep=False):
         """relations: list of (entries, row_ptr, data_row_to_relation_row, attr_offset) -- `-relation` blocks
-        (relation.h:32-60); the rows are expanded on the device."""
+        (relation.h:32-60).  keep=False: the joined rows are expanded on the device; keep=True (FMX_BLOCKS_KEEP): main rows and
+        blocks stay apart, ALS / MCMC sweep the blocks through per-block-row caches like the reference."""
         entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
         row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
         target = None if target is None else np.ascontiguousarray(target, dtype=np.float32)
@@ -300,8 +304,8 @@ class Handle:
                 raise ValueError("relation %d: the row mapping has %d entries for %d data rows" % (i, len(mp), n_rows))
             keep += [re, rp, mp]
             arr[i] = Relation(_ptr(re) if len(re) else None, _ptr(rp), len(rp) - 1, 0, len(re), _ptr(mp), int(off))
-        self._chk(self.lib.fmx_upload_block_rows(self.h, slot, _ptr(entries) if len(entries) else None, _ptr(row_ptr),
-                                                 _ptr(target), n_rows, len(entries), arr, len(relations)))
+        self._chk(self.lib.fmx_upload_block_rows_ex(self.h, slot, _ptr(entries) if len(entries) else None, _ptr(row_ptr),
+                                                    _ptr(target), n_rows, len(entries), arr, len(relations), 1 if keep else 0))
         return n_rows
 
     def predict(self, slot, n_rows):

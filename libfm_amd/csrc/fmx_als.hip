@@ -16,6 +16,12 @@ extern "C++" void als_free(fmx_handle h) {
   if (a.vt) hipFree(a.vt);
   if (a.delta) hipFree(a.delta);
   if (a.epart) hipFree(a.epart);
+  for (AlsBlock& b : a.blk) {
+    if (b.level_list) hipFree(b.level_list);
+    if (b.cache) hipFree(b.cache);
+    if (b.qb_all) hipFree(b.qb_all);
+    if (b.cpart) hipFree(b.cpart);
+  }
   a = AlsState();
 }
 
@@ -30,6 +36,64 @@ int fmx_als_end(fmx_handle h) {
 static int als_eterms(fmx_handle h, const Slot& s, EQ* e, double* q, double* e_part = nullptr) {
   KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), s.n_rows, h->stream, s.ent, s.row_ptr, s.n_rows, h->tb,
                                      h->cfg.k0, h->cfg.k1, h->w0, e, q, e_part));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
+// the dependency levels of the columns of a (transposed) data set: level(j) = 1 + max level of the earlier columns sharing a
+// row with j (host, O(nnz)); fills level_ptr and uploads the level-ordered column list; marks seen[id_offset + feature]
+static int build_levels(fmx_handle h, const Slot& s, std::vector<uint32_t>& level_ptr, uint32_t** d_level_list, std::vector<uint8_t>* seen,
+                        uint32_t id_offset) {
+  const uint32_t N = s.n_rows, nseg = s.nseg;
+  std::vector<uint32_t> seg_feat(nseg), seg_rel((size_t)nseg + 1), lvl(nseg), rowlevel(std::max<uint32_t>(N, 1), 0);
+  std::vector<TEntry> tent((size_t)s.nnz);
+  if (nseg) {
+    HIPCHK(h, hipMemcpy(seg_feat.data(), s.seg_feat, (size_t)nseg * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(seg_rel.data(), s.seg_rel, (size_t)nseg * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(tent.data(), s.t_ent, (size_t)s.nnz * sizeof(TEntry), hipMemcpyDeviceToHost));
+  }
+  seg_rel[nseg] = (uint32_t)s.nnz;
+  uint32_t n_levels = 0;
+  for (uint32_t sg = 0; sg < nseg; sg++) {
+    uint32_t l = 0;
+    for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) l = std::max(l, rowlevel[tent[i].e]);
+    l += 1;
+    if (getenv("FMX_ALS_SEQUENTIAL")) l = sg + 1;      // debugging aid: one feature per level (the reference's order, serial)
+    for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) rowlevel[tent[i].e] = l;
+    lvl[sg] = l - 1;
+    n_levels = std::max(n_levels, l);
+  }
+  level_ptr.assign((size_t)n_levels + 1, 0);
+  for (uint32_t sg = 0; sg < nseg; sg++) level_ptr[lvl[sg] + 1]++;
+  for (uint32_t l = 0; l < n_levels; l++) level_ptr[l + 1] += level_ptr[l];
+  std::vector<uint32_t> list(std::max<uint32_t>(nseg, 1)), fill(level_ptr.begin(), level_ptr.end());
+  for (uint32_t sg = 0; sg < nseg; sg++) list[fill[lvl[sg]]++] = sg;
+  if (seen) for (uint32_t sg = 0; sg < nseg; sg++) (*seen)[(size_t)id_offset + seg_feat[sg]] = 1;
+  HIPCHK(h, hipMalloc(d_level_list, list.size() * 4));
+  HIPCHK(h, hipMemcpy(*d_level_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+  return FMX_OK;
+}
+
+// y-hat (and q_f for the coming sweep) of the session's rows.  With kept blocks the main rows and every block's rows are
+// evaluated separately -- a block row once, however many main rows map to it -- and combined through the mappings;
+// the squares are of the COMPLETE factor sums (k_als_set_e).
+static int als_repredict(fmx_handle h, const Slot& s, AlsState& a) {
+  if (s.blocks.empty()) return als_eterms(h, s, a.e, a.q);
+  const uint32_t N = s.n_rows;
+  const dim3 g1(std::min<uint32_t>((N + 255) / 256, 2048)), b1(256);
+  int rc = als_eterms(h, s, a.e, a.q, a.epart);
+  if (rc) return rc;
+  for (size_t r = 0; r < s.blocks.size(); r++) {
+    const BlockRows& br = *s.blocks[r];
+    AlsBlock& ab = a.blk[r];
+    const uint32_t B = br.rows.n_rows;
+    Tab tb = h->tb;                                          // the block's attribute 0 is global attribute attr_offset
+    tb.V += (size_t)br.attr_offset * tb.rs; tb.w += (size_t)br.attr_offset * tb.ws;
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), B, h->stream, br.rows.ent, br.rows.row_ptr, B, tb,
+                                       0, h->cfg.k1, (const double*)h->w0, (EQ*)nullptr, ab.qb_all, ab.cpart));
+    hipLaunchKernelGGL(k_rel_combine, g1, b1, 0, h->stream, br.map, N, B, ab.cpart, ab.qb_all, h->cfg.num_factor, a.epart, a.q);
+  }
+  hipLaunchKernelGGL(k_als_set_e, g1, b1, 0, h->stream, a.e, a.epart, a.q, h->cfg.num_factor, N, h->cfg.k0, h->w0);
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
 }
@@ -54,37 +118,32 @@ static int als_begin_impl(fmx_handle h, int train_slot) {
   if (rc) return rc;
   AlsState& a = h->als;
   a.slot = train_slot;
-  const uint32_t N = s.n_rows, nseg = s.nseg;
-  // ---- dependency levels (host, O(nnz)): level(j) = 1 + max level of earlier features sharing a row with j
-  std::vector<uint32_t> seg_feat(nseg), seg_rel(nseg + 1), lvl(nseg), rowlevel(N, 0);
-  std::vector<TEntry> tent((size_t)s.nnz);
-  if (nseg) {
-    HIPCHK(h, hipMemcpy(seg_feat.data(), s.seg_feat, (size_t)nseg * 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(seg_rel.data(), s.seg_rel, (size_t)nseg * 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(tent.data(), s.t_ent, (size_t)s.nnz * sizeof(TEntry), hipMemcpyDeviceToHost));
-  }
-  seg_rel[nseg] = (uint32_t)s.nnz;
-  uint32_t n_levels = 0;
-  for (uint32_t sg = 0; sg < nseg; sg++) {
-    uint32_t l = 0;
-    for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) l = std::max(l, rowlevel[tent[i].e]);
-    l += 1;
-    if (getenv("FMX_ALS_SEQUENTIAL")) l = sg + 1;      // debugging aid: one feature per level (the reference's order, serial)
-    for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) rowlevel[tent[i].e] = l;
-    lvl[sg] = l - 1;
-    n_levels = std::max(n_levels, l);
-  }
-  a.level_ptr.assign((size_t)n_levels + 1, 0);
-  for (uint32_t sg = 0; sg < nseg; sg++) a.level_ptr[lvl[sg] + 1]++;
-  for (uint32_t l = 0; l < n_levels; l++) a.level_ptr[l + 1] += a.level_ptr[l];
-  std::vector<uint32_t> list(std::max<uint32_t>(nseg, 1)), fill(a.level_ptr.begin(), a.level_ptr.end());
-  for (uint32_t sg = 0; sg < nseg; sg++) list[fill[lvl[sg]]++] = sg;
+  const uint32_t N = s.n_rows;
+  // ---- dependency levels of the main features, then -- kept `-relation` blocks -- of every block's attributes over
+  //      the block's own rows (two block attributes conflict iff they share a block row)
   std::vector<uint8_t> seen((size_t)h->n_local, 0);
-  for (uint32_t sg = 0; sg < nseg; sg++) seen[seg_feat[sg]] = 1;
-  HIPCHK(h, hipMalloc(&a.level_list, list.size() * 4));
-  HIPCHK(h, hipMemcpy(a.level_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+  rc = build_levels(h, s, a.level_ptr, &a.level_list, &seen, 0);
+  if (rc) return rc;
+  a.blk.resize(s.blocks.size());
+  for (size_t r = 0; r < s.blocks.size(); r++) {
+    BlockRows& br = *s.blocks[r];
+    AlsBlock& ab = a.blk[r];
+    const uint32_t B = br.rows.n_rows;
+    rc = ensure_segments(h, br.rows, std::max<uint32_t>(B, 1));            // X^T of the block (device radix sort)
+    if (rc) return rc;
+    rc = build_levels(h, br.rows, ab.level_ptr, &ab.level_list, &seen, br.attr_offset);
+    if (rc) return rc;
+    HIPCHK(h, hipMalloc(&ab.cache, (size_t)7 * std::max<uint32_t>(B, 1) * sizeof(double)));
+    HIPCHK(h, hipMemsetAsync(ab.cache, 0, (size_t)7 * std::max<uint32_t>(B, 1) * sizeof(double), h->stream));
+    HIPCHK(h, hipMalloc(&ab.qb_all, (size_t)h->KP * std::max<uint32_t>(B, 1) * sizeof(double)));
+    HIPCHK(h, hipMalloc(&ab.cpart, (size_t)std::max<uint32_t>(B, 1) * sizeof(double)));
+    const double avg_col = br.rows.nseg ? (double)br.rows.nnz / (double)br.rows.nseg : 0.0;
+    ab.lanes = avg_col <= 5.0 ? 4 : (avg_col <= 12.0 ? 8 : (avg_col <= 40.0 ? 16 : 64));
+  }
+  const uint32_t nseg = s.nseg;
   HIPCHK(h, hipMalloc(&a.seen, seen.size()));
   HIPCHK(h, hipMemcpy(a.seen, seen.data(), seen.size(), hipMemcpyHostToDevice));
+  if (!s.blocks.empty()) HIPCHK(h, hipMalloc(&a.epart, (size_t)N * sizeof(double)));
   HIPCHK(h, hipMalloc(&a.e, (size_t)N * sizeof(EQ)));
   HIPCHK(h, hipMalloc(&a.q, (size_t)N * (size_t)h->KP * sizeof(double)));
   if (h->cfg.num_factor > 0 && nseg > 0 && !getenv("FMX_ALS_NO_SHADOW")) {      // (the env switch is the A/B knob of the profile)
@@ -92,7 +151,7 @@ static int als_begin_impl(fmx_handle h, int train_slot) {
     HIPCHK(h, hipMalloc(&a.vt, (size_t)h->cfg.num_factor * a.vt_stride * sizeof(float)));
   }
   // ---- first prediction and e -= target (fm_learn_mcmc_simultaneous.h:69-86)
-  rc = als_eterms(h, s, a.e, a.q);
+  rc = als_repredict(h, s, a);
   if (rc) return rc;
   hipLaunchKernelGGL(k_als_sub_target, dim3(std::min<uint32_t>((N + 255) / 256, 2048)), dim3(256), 0, h->stream, a.e, s.target, N);
   HIPCHK(h, hipGetLastError());
@@ -266,8 +325,52 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
     }
     return FMX_OK;
   };
+  // kept `-relation` blocks (one unsharded handle): after the main features of a family, every block in turn -- caches from
+  // the main rows, the block's attributes level by level on the caches, the accumulated changes back (fm_learn_mcmc.h:478-509
+  // for w, :603-633 for v_f)
+  auto block_steps = [&](int f /* -1: linear weights */) -> int {
+    fmx_handle h = hs[0];
+    AlsState& a = h->als;
+    const Slot& s = h->slots[a.slot];
+    hipStream_t st = h->stream;
+    for (size_t r = 0; r < s.blocks.size(); r++) {
+      const BlockRows& br = *s.blocks[r];
+      AlsBlock& ab = a.blk[r];
+      const uint32_t B = br.rows.n_rows;
+      if (!B) continue;
+      const dim3 gb(std::min<uint32_t>((B + 31) / 32, 2048));
+      if (f >= 0) {
+        hipLaunchKernelGGL(k_rel_load_qb, dim3(std::min<uint32_t>((B + 255) / 256, 2048)), b1, 0, st, ab.cache, (const double*)(ab.qb_all + (size_t)f * B), B);
+        hipLaunchKernelGGL((k_rel_aggregate<true, 8>), gb, b1, 0, st, br.brow_ptr, br.brow_list, B, (const EQ*)a.e, ab.cache);
+      } else {
+        hipLaunchKernelGGL((k_rel_aggregate<false, 8>), gb, b1, 0, st, br.brow_ptr, br.brow_list, B, (const EQ*)a.e, ab.cache);
+      }
+      const double* lam = (f < 0) ? a.prior : a.prior + (size_t)(1 + f) * 2 * NG;
+      const double* mu = lam + NG;
+      float* param = (f < 0) ? h->tb.w : h->tb.V + f;
+      const uint32_t pstride = (f < 0) ? h->tb.ws : h->tb.rs;
+      const uint64_t stream_id = (uint64_t)(a.iter * 1024 + (f < 0 ? 1000 : f));
+      const uint32_t nl = (uint32_t)ab.level_ptr.size() - 1;
+      for (uint32_t l = 0; l < nl; l++) {
+        const uint32_t cnt = ab.level_ptr[l + 1] - ab.level_ptr[l];
+        if (!cnt) continue;
+#define FMX_REL_DRAW(ISV, GG) FMX_LAUNCH_WAVES((k_rel_draw<ISV, GG>), ((uint64_t)cnt * GG + 63) / 64, st, br.rows.t_ent, br.rows.seg_feat,        \
+          br.rows.seg_rel, br.rows.nseg, (uint32_t)br.rows.nnz, ab.level_list + ab.level_ptr[l], cnt, param, pstride, br.attr_offset,             \
+          br.brow_ptr, B, ab.cache, opts->alpha, lam, mu, h->grp, opts->do_sample, opts->seed, stream_id)
+        if (f < 0) { if (ab.lanes <= 4) FMX_REL_DRAW(false, 4); else if (ab.lanes == 8) FMX_REL_DRAW(false, 8); else if (ab.lanes == 16) FMX_REL_DRAW(false, 16); else FMX_REL_DRAW(false, 64); }
+        else       { if (ab.lanes <= 4) FMX_REL_DRAW(true, 4);  else if (ab.lanes == 8) FMX_REL_DRAW(true, 8);  else if (ab.lanes == 16) FMX_REL_DRAW(true, 16);  else FMX_REL_DRAW(true, 64); }
+#undef FMX_REL_DRAW
+      }
+      if (f >= 0) hipLaunchKernelGGL((k_rel_sync<true>), g1, b1, 0, st, br.map, N, B, (const double*)ab.cache, a.e);
+      else        hipLaunchKernelGGL((k_rel_sync<false>), g1, b1, 0, st, br.map, N, B, (const double*)ab.cache, a.e);
+      HIPCHK(h, hipGetLastError());
+    }
+    return FMX_OK;
+  };
+  const bool has_blocks = !sharded && !h->slots[a0.slot].blocks.empty();
   if (h->cfg.k1) {                                         // draw_w per level, :454-476
     for (uint32_t l = 0; l < n_levels; l++) { int rc = level_step(l, -1); if (rc) return rc; }
+    if (has_blocks) { int rc = block_steps(-1); if (rc) return rc; }
     for (fmx_handle x : hs) {
       HIPCHK(x, hipSetDevice(x->device));
       const dim3 gu((uint32_t)std::min<uint64_t>((x->n_local + 255) / 256, 2048));
@@ -290,6 +393,7 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
       hipLaunchKernelGGL(k_als_load_q, g1, b1, 0, x->stream, x->als.e, x->als.q + (size_t)f * N, N);
     }
     for (uint32_t l = 0; l < n_levels; l++) { int rc = level_step(l, f); if (rc) return rc; }
+    if (has_blocks) { int rc = block_steps(f); if (rc) return rc; }
   }
   for (fmx_handle h : hs) {
     AlsState& a = h->als;
@@ -311,7 +415,7 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
   for (fmx_handle x : hs) {
     AlsState& a = x->als;
     HIPCHK(x, hipSetDevice(x->device));
-    int rc = als_eterms(x, x->slots[a.slot], a.e, a.q, sharded ? a.epart : nullptr);
+    int rc = sharded ? als_eterms(x, x->slots[a.slot], a.e, a.q, a.epart) : als_repredict(x, x->slots[a.slot], a);
     if (rc) return rc;
   }
   if (sharded) {
@@ -374,6 +478,7 @@ int fmx_group_als_begin(fmx_group g, int train_slot) {
     als_free(x);
     Slot& s = x->slots[train_slot];
     if (s.n_rows == 0) return bail(fail(x, FMX_E_ARG, "fmx_group_als_begin: empty training set"), x);
+    if (!s.blocks.empty()) return bail(fail(x, FMX_E_UNSUPPORTED, "fmx_group_als_begin: block-structured rows on feature shards are not implemented"), x);
     if (i == 0) N = s.n_rows; else if (s.n_rows != N) return bail(fail(x, FMX_E_STATE, "the shards hold different numbers of rows"), x);
     rc = ensure_segments(x, s, s.n_rows);
     if (rc) return bail(rc, x);

@@ -445,6 +445,184 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// `-relation` blocks kept apart from the main rows (FMX_BLOCKS_KEEP): the reference's per-block-row caches
+// (relation_cache, fm_learn_mcmc.h:50-58; set-up :478-527 / :603-615, draw_w_rel :734-790, draw_v_rel :849-909), restated.
+// A block attribute j has value x_bj in block row b, i.e. in EVERY main row c that maps to b.  With
+//   wnum[b] = #{c -> b},  we[b] = sum_{c->b} e_c,  and for a factor:  qb[b] = the block row's own factor sum,
+//   qrest(c) = q_c - qb[b(c)],  weq[b] = sum e_c qrest(c),  wc[b] = sum qrest(c),  wc2[b] = sum qrest(c)^2
+// the sums over the main rows a draw needs collapse to sums over the block's column:
+//   w:  sum h e = sum_b x we[b],                         sum h^2 = sum_b x^2 wnum[b]
+//   v:  h_b = x (qb[b] - x v);  sum h e = sum_b (h_b we[b] + x weq[b]);  sum h^2 = sum_b (h_b^2 wnum + 2 wc x h_b + x^2 wc2)
+// and a new value changes the caches of its column only; the main rows are touched twice per (block, family): once to build
+// the caches (k_rel_aggregate), once to push the accumulated changes back (k_rel_sync):
+//   e_c += dy[b] + qrest(c) (qb[b] - qb0[b]),   q_c = qrest(c) + qb[b]
+// cache: struct of arrays [7][B]: 0 we, 1 weq, 2 wc, 3 wc2, 4 qb, 5 dy, 6 qb0.
+// ----------------------------------------------------------------------------------------------
+template <bool IS_V, int G>
+__global__ void __launch_bounds__(256)
+k_rel_aggregate(const uint32_t* __restrict__ brow_ptr, const uint32_t* __restrict__ brow_list, uint32_t B, const EQ* __restrict__ eq,
+                double* __restrict__ cache) {
+  const uint32_t lane = (threadIdx.x & 63u) % G, grp = (threadIdx.x & 63u) / G;
+  constexpr uint32_t GPW = 64 / G;
+  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t b0 = wave0 * GPW; b0 < B; b0 += nwaves * GPW) {
+    const uint32_t b = b0 + grp;
+    const bool have = b < B;
+    const uint32_t a0 = have ? brow_ptr[b] : 0u, a1 = have ? brow_ptr[b + 1] : 0u;
+    const double qb = (IS_V && have) ? cache[(size_t)4 * B + b] : 0.0;
+    double we = 0.0, weq = 0.0, wc = 0.0, wc2 = 0.0;
+    for (uint32_t i = a0 + lane; i < a1; i += G) {
+      const EQ c = eq[brow_list[i]];
+      we += c.e;
+      if (IS_V) { const double qr = c.q - qb; weq += c.e * qr; wc += qr; wc2 += qr * qr; }
+    }
+    we = group_sum_f64<G>(we);
+    if (IS_V) { weq = group_sum_f64<G>(weq); wc = group_sum_f64<G>(wc); wc2 = group_sum_f64<G>(wc2); }
+    if (have && lane == 0) {
+      cache[b] = we;
+      if (IS_V) { cache[(size_t)B + b] = weq; cache[(size_t)2 * B + b] = wc; cache[(size_t)3 * B + b] = wc2; cache[(size_t)6 * B + b] = qb; }
+      cache[(size_t)5 * B + b] = 0.0;
+    }
+  }
+}
+
+// one group of G lanes per block attribute of the current level (columns of the block's X^T: {block row, value})
+template <bool IS_V, int G>
+__global__ void __launch_bounds__(256)
+k_rel_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
+           uint32_t nseg_total, uint32_t nnz, const uint32_t* __restrict__ seg_list, uint32_t n_list,
+           float* __restrict__ param, uint32_t pstride, uint32_t attr_offset, const uint32_t* __restrict__ brow_ptr, uint32_t B,
+           double* __restrict__ cache, double alpha, const double* __restrict__ lambda_g, const double* __restrict__ mu_g,
+           const uint32_t* __restrict__ attr_group, int do_sample, uint64_t seed, uint64_t stream) {
+  constexpr uint32_t GPW = 64 / G;
+  const uint32_t lane = (threadIdx.x & 63u) % G, grp = (threadIdx.x & 63u) / G;
+  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  double* we = cache; double* weq = cache + B; double* wc = cache + (size_t)2 * B; double* wc2 = cache + (size_t)3 * B;
+  double* qb = cache + (size_t)4 * B; double* dy = cache + (size_t)5 * B;
+  for (uint32_t lw = wave0 * GPW; lw < n_list; lw += nwaves * GPW) {
+    const uint32_t li = lw + grp;
+    const bool have = li < n_list;
+    const uint32_t s = seg_list[have ? li : n_list - 1];
+    const uint32_t j = seg_feat[s] + attr_offset;                  // global attribute id (libfm.cpp:213-216)
+    const uint32_t g = attr_group ? attr_group[j] : 0u;
+    const double lambda = lambda_g[g], mu = mu_g[g];
+    const uint32_t a = seg_rel[s];
+    const uint32_t b = have ? ((s + 1 < nseg_total) ? seg_rel[s + 1] : nnz) : a;
+    float* pt = param + (size_t)j * pstride;
+    const double th = (double)*pt;
+    double t_he = 0.0, t_hh = 0.0;
+    for (uint32_t i = a + lane; i < b; i += G) {
+      const TEntry te = t_ent[i];
+      const double x = (double)te.x;
+      const double wnum = (double)(brow_ptr[te.e + 1] - brow_ptr[te.e]);
+      if (IS_V) {
+        const double h = x * (qb[te.e] - x * th);
+        t_he += h * we[te.e] + x * weq[te.e];                        // :858
+        t_hh += h * h * wnum + 2 * wc[te.e] * x * h + x * x * wc2[te.e];   // :859
+      } else {
+        t_he += x * we[te.e];                                        // :744
+        t_hh += x * x * wnum;                                        // :745
+      }
+    }
+    t_he = group_sum_f64<G>(t_he);
+    t_hh = group_sum_f64<G>(t_hh);
+    if (!have) continue;
+    t_he -= th * t_hh;                                               // :749, :863
+    const double sigma_sqr = 1.0 / (lambda + alpha * t_hh);
+    const double mean = -sigma_sqr * (alpha * t_he - mu * lambda);
+    double nt;
+    if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
+    else nt = do_sample ? mean + sqrt(sigma_sqr) * gauss_hash(seed, stream, j) : mean;
+    if (isnan(nt) || isinf(nt)) continue;
+    const float ntf = (float)nt;
+    const double d = th - (double)ntf;                               // theta_old - theta (of the STORED value)
+    if (lane == 0) *pt = ntf;
+    if (d != 0.0) {
+      // the caches of the column's block rows: one lane per (block row, run of occurrences); a block row holding the
+      // attribute more than once has its occurrences adjacent and is walked sequentially by the first (as in k_als_draw)
+      for (uint32_t i = a + lane; i < b; i += G) {
+        const TEntry te = t_ent[i];
+        if (i > a && t_ent[i - 1].e == te.e) continue;
+        const uint32_t r = te.e;
+        const double wnum = (double)(brow_ptr[r + 1] - brow_ptr[r]);
+        double c_we = we[r], c_dy = dy[r];
+        if (IS_V) {
+          double c_weq = weq[r], c_q = qb[r];
+          const double c_wc = wc[r], c_wc2 = wc2[r];
+          for (uint32_t i2 = i; i2 < b; i2++) {
+            const TEntry t2 = t_ent[i2];
+            if (t2.e != r) break;
+            const double x = (double)t2.x;
+            const double h = x * (c_q - x * th);                     // :898
+            c_we -= d * (h * wnum + x * c_wc);                       // :899
+            c_q -= d * x;                                            // :900
+            c_weq -= d * (h * c_wc + x * c_wc2);                     // :901
+            c_dy -= d * h;                                           // :902  y += (v - v_old) h
+          }
+          weq[r] = c_weq; qb[r] = c_q;
+        } else {
+          for (uint32_t i2 = i; i2 < b; i2++) {
+            const TEntry t2 = t_ent[i2];
+            if (t2.e != r) break;
+            const double x = (double)t2.x;
+            c_we -= x * d * wnum;                                    // :786
+            c_dy -= d * x;                                           // :787  y += (w - w_old) h
+          }
+        }
+        we[r] = c_we; dy[r] = c_dy;
+      }
+    }
+  }
+}
+
+// push the block's accumulated changes back into the main rows' {e, q}
+template <bool IS_V>
+__global__ void __launch_bounds__(256)
+k_rel_sync(const uint32_t* __restrict__ map, uint32_t n, uint32_t B, const double* __restrict__ cache, EQ* __restrict__ eq) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    const uint32_t b = map[c];
+    EQ v = eq[c];
+    if (IS_V) {
+      const double qb = cache[(size_t)4 * B + b], qb0 = cache[(size_t)6 * B + b];
+      const double qr = v.q - qb0;
+      v.e += cache[(size_t)5 * B + b] + qr * (qb - qb0);            // :631
+      v.q = qr + qb;                                                 // :632
+    } else {
+      v.e += cache[(size_t)5 * B + b];                               // :506
+    }
+    eq[c] = v;
+  }
+}
+// the block rows' factor sums of factor f become the block's qb for the coming sweep of v_f
+static __global__ void k_rel_load_qb(double* __restrict__ cache, const double* __restrict__ qb_f, uint32_t B) {
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) cache[(size_t)4 * B + b] = qb_f[b];
+}
+// re-prediction of a slot with kept blocks: add the block rows' partial sums (c = lin - 0.5 sum of squares, q_f) to the main rows'
+static __global__ void __launch_bounds__(256)
+k_rel_combine(const uint32_t* __restrict__ map, uint32_t n, uint32_t B, const double* __restrict__ cpart_b, const double* __restrict__ qb_all,
+              int k, double* __restrict__ cpart, double* __restrict__ q) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    const uint32_t b = map[c];
+    cpart[c] += cpart_b[b];
+    for (int f = 0; f < k; f++) q[(size_t)f * n + c] += qb_all[(size_t)f * B + b];
+  }
+}
+// the fp32 form for fmx_predict / fmx_evaluate: partial buffers [rows][KP] + [rows] (k_rowsums<KP, true, false>)
+template <int KP>
+__global__ void __launch_bounds__(256)
+k_rel_add_partial(const uint32_t* __restrict__ map, uint32_t n, uint32_t B, const float* __restrict__ pb, float* __restrict__ pm) {
+  const uint64_t total = (uint64_t)n * (KP + 1);
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = (uint32_t)(t / (KP + 1)); const uint32_t f = (uint32_t)(t % (KP + 1));
+    const uint32_t b = map[c];
+    if (f < KP) pm[(size_t)c * KP + f] += pb[(size_t)b * KP + f];
+    else pm[(size_t)n * KP + c] += pb[(size_t)B * KP + b];
+  }
+}
+
 // features without a training column: the empty-row draw (:467-476, :586-595): theta = prior mean mu = 0
 // (sigma^2 = 1/lambda; lambda = 0 -> sigma^2 = inf -> theta = 0); MCMC: mu + N(0,1)/sqrt(lambda)
 static __global__ void __launch_bounds__(256)

@@ -110,7 +110,19 @@ void free_segments(Slot& s) {
   s.batch_seg.clear(); s.batch_base.clear(); s.cbatch.clear();
 }
 
+void free_block(BlockRows* b) {
+  if (!b) return;
+  free_slot(b->rows);
+  if (b->map) hipFree(b->map);
+  if (b->brow_ptr) hipFree(b->brow_ptr);
+  if (b->brow_list) hipFree(b->brow_list);
+  if (b->pbuf) hipFree(b->pbuf);
+  delete b;
+}
+
 void free_slot(Slot& s) {
+  for (BlockRows* b : s.blocks) free_block(b);
+  s.blocks.clear();
   free_segments(s);
   if (s.ent) hipFree(s.ent);
   if (s.row_ptr) hipFree(s.row_ptr);
@@ -120,6 +132,31 @@ void free_slot(Slot& s) {
 
 // rest[e] (= y-hat - w0) for rows [row0,row0+n) of a slot, single device
 int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st) {
+  if (!s.blocks.empty()) {
+    // kept `-relation` blocks: the partial sums of the main rows, plus -- through the mappings -- those of the block rows
+    // (every block row is evaluated once, however many main rows use it), then rest = c + 0.5 * sum_f S_f^2
+    if (row0 != 0 || n != s.n_rows) return fail(h, FMX_E_ARG, "rows with kept blocks are predicted as a whole");
+    int rc = ensure_scratch(h, n, 0);
+    if (rc) return rc;
+    float* S = h->partial;
+    float* c = S + (size_t)n * h->KP;
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n, st, s.ent, s.row_ptr, (uint64_t)0, n, h->tb, h->cfg.k1, S, c));
+    for (BlockRows* br : s.blocks) {
+      const uint32_t B = br->rows.n_rows;
+      if (!B) continue;
+      Tab tb = h->tb;                                        // the block's attribute 0 is global attribute attr_offset
+      tb.V += (size_t)br->attr_offset * tb.rs; tb.w += (size_t)br->attr_offset * tb.ws;
+      float* Sb = br->pbuf;
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), B, st, br->rows.ent, br->rows.row_ptr, (uint64_t)0, B, tb, h->cfg.k1,
+                                         Sb, Sb + (size_t)B * h->KP));
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rel_add_partial<KP>), dim3(std::min<uint32_t>((uint32_t)(((uint64_t)n * (h->KP + 1) + 255) / 256), 4096)),
+                                            dim3(256), 0, st, br->map, n, B, (const float*)Sb, S));
+    }
+    KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n + Map<KP>::EPI - 1) / Map<KP>::EPI)), dim3(256), 0, st,
+                                          (const float*)S, (const float*)c, n, rest));
+    HIPCHK(h, hipGetLastError());
+    return FMX_OK;
+  }
   KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, false, true>), n, st,
                                      s.ent, s.row_ptr, row0, n, h->tb, h->cfg.k1, (float*)nullptr, rest));
   HIPCHK(h, hipGetLastError());
@@ -650,8 +687,49 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
   return FMX_OK;
 }
 
+// FMX_BLOCKS_KEEP: the main rows and every block stay apart on the device -- nothing of the size of the joined table is
+// built.  fm_model::predict and the ALS / MCMC sweeps then work block-wise (fmx_als.hip, k_rel_*).
+static int upload_blocks_kept(fmx_handle h, int slot, const void* entries, const uint64_t* row_ptr, const float* target,
+                              uint32_t n_rows, uint64_t nnz, const fmx_relation* relations, uint32_t n_relations) {
+  int rc = fmx_upload_rows(h, slot, entries, row_ptr, target, n_rows, nnz);          // the main rows as any other data set
+  if (rc) return rc;
+  Slot& s = h->slots[slot];
+  for (uint32_t r = 0; r < n_relations; r++) {
+    const fmx_relation& q = relations[r];
+    BlockRows* b = new BlockRows();
+    s.blocks.push_back(b);
+    b->attr_offset = (uint32_t)q.attr_offset;
+    std::vector<uint32_t> cnt((size_t)q.n_rows + 1, 0), list(std::max<uint32_t>(n_rows, 1));
+    for (uint32_t c = 0; c < n_rows; c++) cnt[q.data_row_to_relation_row[c] + 1]++;
+    for (uint32_t i = 0; i < q.n_rows; i++) cnt[i + 1] += cnt[i];
+    { std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+      for (uint32_t c = 0; c < n_rows; c++) list[fill[q.data_row_to_relation_row[c]]++] = c; }   // ascending main row inside a block row
+    uint32_t max_row = 0;
+    for (uint32_t i = 0; i < q.n_rows; i++) max_row = std::max<uint32_t>(max_row, (uint32_t)(q.row_ptr[i + 1] - q.row_ptr[i]));
+    hipError_t er = hipMalloc(&b->rows.ent, std::max<uint64_t>(q.nnz, 1) * sizeof(Entry));
+    if (er == hipSuccess && q.nnz) er = hipMemcpy(b->rows.ent, q.entries, q.nnz * sizeof(Entry), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMalloc(&b->rows.row_ptr, ((size_t)q.n_rows + 1) * sizeof(uint64_t));
+    if (er == hipSuccess) er = hipMemcpy(b->rows.row_ptr, q.row_ptr, ((size_t)q.n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMalloc(&b->map, std::max<uint32_t>(n_rows, 1) * sizeof(uint32_t));
+    if (er == hipSuccess && n_rows) er = hipMemcpy(b->map, q.data_row_to_relation_row, (size_t)n_rows * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMalloc(&b->brow_ptr, cnt.size() * sizeof(uint32_t));
+    if (er == hipSuccess) er = hipMemcpy(b->brow_ptr, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMalloc(&b->brow_list, list.size() * sizeof(uint32_t));
+    if (er == hipSuccess) er = hipMemcpy(b->brow_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMalloc(&b->pbuf, std::max<size_t>((size_t)q.n_rows, 1) * (size_t)(h->KP + 1) * sizeof(float));
+    if (er != hipSuccess) { free_slot(s); return fail(h, FMX_E_HIP, "fmx_upload_block_rows_ex: %s", hipGetErrorString(er)); }
+    b->rows.n_rows = q.n_rows; b->rows.nnz = q.nnz; b->rows.max_row = max_row; b->rows.used = true;
+  }
+  return FMX_OK;
+}
+
 int fmx_upload_block_rows(fmx_handle h, int slot, const void* entries, const uint64_t* row_ptr, const float* target,
                           uint32_t n_rows, uint64_t nnz, const fmx_relation* relations, uint32_t n_relations) {
+  return fmx_upload_block_rows_ex(h, slot, entries, row_ptr, target, n_rows, nnz, relations, n_relations, FMX_BLOCKS_EXPAND);
+}
+
+int fmx_upload_block_rows_ex(fmx_handle h, int slot, const void* entries, const uint64_t* row_ptr, const float* target,
+                             uint32_t n_rows, uint64_t nnz, const fmx_relation* relations, uint32_t n_relations, uint32_t flags) {
   if (!h) return FMX_E_ARG;
   if (n_relations == 0) return fmx_upload_rows(h, slot, entries, row_ptr, target, n_rows, nnz);
   if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
@@ -677,6 +755,7 @@ int fmx_upload_block_rows(fmx_handle h, int slot, const void* entries, const uin
       if (q.data_row_to_relation_row[c] >= q.n_rows)
         return fail(h, FMX_E_ARG, "relation %u: main row %u maps to block row %u >= %u", r, c, q.data_row_to_relation_row[c], q.n_rows);
   }
+  if (flags & FMX_BLOCKS_KEEP) return upload_blocks_kept(h, slot, entries, row_ptr, target, n_rows, nnz, relations, n_relations);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_slot(h->slots[slot]);

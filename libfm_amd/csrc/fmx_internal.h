@@ -47,6 +47,28 @@ struct Slot {
   std::vector<uint32_t> cbatch;      // [n_batches+1] first cseg entry of every batch
   uint32_t* order = nullptr;         // [n_rows] per batch: example order with the examples that touch a deferred feature of
   std::vector<uint32_t> n_indep;     //          the PREVIOUS batch last; n_indep[b] = how many do not (FusedPrev)
+  std::vector<struct BlockRows*> blocks;   // `-relation` blocks kept apart from these (main) rows; empty: plain / expanded rows
+};
+
+// one `-relation` block kept apart from the main rows (fmx_upload_block_rows_ex, FMX_BLOCKS_KEEP): RelationData +
+// RelationJoin, src/libfm/src/relation.h:32-60
+struct BlockRows {
+  Slot      rows;                  // the block's own rows (ids local to the block); owns the block's X^T segments too
+  uint32_t* map = nullptr;         // [main rows] -> block row (RelationJoin::data_row_to_relation_row)
+  uint32_t  attr_offset = 0;       // RelationData::attr_offset: global id of the block's attribute 0
+  uint32_t* brow_ptr = nullptr;    // [block rows + 1] / brow_list [main rows]: the main rows that map to a block row
+  uint32_t* brow_list = nullptr;
+  float*    pbuf = nullptr;        // [block rows][KP + 1] partial sums of the block rows (predict)
+};
+void free_block(BlockRows* b);
+
+struct AlsBlock {                  // ALS / MCMC state of one kept block (fm_learn_mcmc.h:50-58 relation_cache, restated)
+  uint32_t* level_list = nullptr;
+  std::vector<uint32_t> level_ptr;
+  double*   cache = nullptr;       // [7][block rows]: we, weq, wc, wc2, qb, dy, qb0   (struct of arrays)
+  double*   qb_all = nullptr;      // [KP][block rows]: the block rows' factor sums of the latest re-prediction
+  double*   cpart = nullptr;       // [block rows]: lin - 0.5 * sum of squares of the block rows
+  int       lanes = 8;
 };
 
 struct AlsState {
@@ -57,6 +79,7 @@ struct AlsState {
   uint32_t* level_list = nullptr; // segments ordered by level
   std::vector<uint32_t> level_ptr;
   uint64_t  iter = 0;
+  std::vector<AlsBlock> blk;      // kept blocks of the train slot
   EQ*       delta = nullptr;      // feature shards: [N] what the draws of the current (family, level) step change in {e, q}
   double*   epart = nullptr;      // feature shards: [N] partial y-hat of the re-prediction
   float*    vt = nullptr;         // [num_factor][vt_stride] factor-major shadow of the seen features' factors, level order

@@ -86,7 +86,9 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
 // builds the (batch, feature) segments of a slot for batch size B (device radix sort; once per data set)
 extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   if (s.seg_B == B && s.t_ent) return FMX_OK;
-  { int _rc = slot_in_session(h, (int)(&s - h->slots), "re-bucketing the rows for another batch size"); if (_rc) return _rc; }
+  if (&s >= h->slots && &s < h->slots + FMX_MAX_SLOTS) {          // (the rows of a kept `-relation` block are bucketed by their own session)
+    int _rc = slot_in_session(h, (int)(&s - h->slots), "re-bucketing the rows for another batch size"); if (_rc) return _rc;
+  }
   free_segments(s);
   const uint64_t nnz = s.nnz;
   const uint32_t n_batches = (s.n_rows + B - 1) / B;
@@ -496,6 +498,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   Slot& s = h->slots[slot];
   if (stats) memset(stats, 0, sizeof(*stats));
   if (s.n_rows == 0) return FMX_OK;
+  if (!s.blocks.empty()) return fail(h, FMX_E_UNSUPPORTED, "relations are not supported with SGD");   // fm_learn_sgd.h:61-63
   if (h->cfg.shard_world > 1 && opts->mode != FMX_SGD_MINIBATCH)
     return fail(h, FMX_E_UNSUPPORTED, "feature shards train with FMX_SGD_MINIBATCH (the split step)");
   if (h->cfg.shard_world > 1 || h->comm) return comm_sgd_epoch(h, slot, opts, stats);   // (a communicator of one rank drives the same schedule)

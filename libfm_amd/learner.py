@@ -33,6 +33,8 @@ class Data:
         self.min_target = float(self.target.min()) if self.num_cases else 0.0   # Data.h:62-63
         self.max_target = float(self.target.max()) if self.num_cases else 0.0
         self.relation = []                                       # Data.h:68: DVector<RelationJoin>
+        self.keep_blocks = True        # relations: keep main rows and blocks apart on the device (per-block caches, like the
+        #                                reference) instead of materialising the joined rows (FMX_BLOCKS_KEEP / _EXPAND)
 
     def add_relation(self, rel, data_row_to_relation_row, attr_offset):
         """RelationJoin (relation.h:53-60): `rel` = a data.Relation (the block's own rows), the main-row -> block-row
@@ -45,7 +47,7 @@ class Data:
 
     def upload(self, h, slot):
         if self.relation:
-            h.upload_block_rows(slot, self.entries, self.row_ptr, self.target, self.relation)
+            h.upload_block_rows(slot, self.entries, self.row_ptr, self.target, self.relation, keep=self.keep_blocks)
         else:
             h.upload_rows(slot, self.entries, self.row_ptr, self.target)
 

@@ -1,6 +1,7 @@
-"""GPU: block-structured data (`-relation`): fmx_upload_block_rows expands the joined rows on the device; ALS on them
-must land on the REAL reference's block-structured run (fixtures rel_als_*; the reference sweeps per-block caches,
-fm_learn_mcmc.h:478-527, 734-790, 849-909).  Tolerance 1e-4 as for every ALS test."""
+"""GPU: block-structured data (`-relation`).  FMX_BLOCKS_KEEP keeps main rows and blocks apart and sweeps the blocks through
+per-block-row caches (the reference's algorithm, fm_learn_mcmc.h:478-527, 734-790, 849-909, restated); FMX_BLOCKS_EXPAND joins
+the rows on the device.  Either way ALS must land on the REAL reference's block-structured run (fixtures rel_als_*).
+Tolerance 1e-4 as for every ALS test."""
 import contextlib
 import io
 import os
@@ -38,8 +39,35 @@ def test_device_expansion_is_the_flat_design_matrix():
     h.close()
 
 
+def test_kept_blocks_predict_like_the_expanded_rows(oracle):
+    """FMX_BLOCKS_KEEP: fm_model::predict / evaluate add the block rows' sums through the mappings -- same numbers as on the
+    materialised join; the SGD learners refuse such rows like the reference (fm_learn_sgd.h:61-63)."""
+    from libfm_amd import capi
+    (ent, rp, y), blocks, maps = datagen.block_structured(40, 25, 300, seed=5)
+    n_main = 7
+    flat_ent, flat_rp, offs = datagen.expand_blocks(ent, rp, blocks, maps, n_main)
+    n, k = offs[-1] + blocks[-1][2], 8
+    m = oracle.Model(n, k, True, True, 0.0, 0.0, 0.0)
+    m.v[:] = oracle.init_values(3, n, k, 0.3)
+    m.w[:] = oracle.init_values(4, n, 1, 0.3)[0]
+    m.w0 = 0.25
+    h = capi.Handle(n, k, True, True, 0, 0, 0, 0, 0.01, float(y.min()), float(y.max()))
+    h.set_params(m.w0, m.w, m.v)
+    rel = [(be, bp, mp, off) for (be, bp, _), mp, off in zip(blocks, maps, offs)]
+    h.upload_block_rows(0, ent, rp, y, rel, keep=True)
+    h.upload_block_rows(1, ent, rp, y, rel, keep=False)
+    want = oracle.predict_raw(m, oracle.Data(flat_ent, flat_rp, y))
+    np.testing.assert_allclose(h.predict(0, 300), want, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(h.predict(1, 300), want, rtol=1e-4, atol=5e-5)
+    assert abs(h.evaluate(0).rmse - h.evaluate(1).rmse) < 1e-5
+    with pytest.raises(capi.FmxError, match="relations are not supported with SGD"):
+        h.sgd_epoch(0, capi.SGD_MINIBATCH)
+    h.close()
+
+
+@pytest.mark.parametrize("keep", [True, False])
 @pytest.mark.parametrize("name", CASES)
-def test_als_on_relations_matches_reference(oracle, name):
+def test_als_on_relations_matches_reference(oracle, name, keep):
     from libfm_amd import data as D
     from libfm_amd import learner as L
     g = Golden(name)
@@ -63,6 +91,7 @@ def test_als_on_relations_matches_reference(oracle, name):
         train.add_relation(rel, z["rel%d_train" % i], off)
         test.add_relation(rel, z["rel%d_test" % i], off)
         off += nf
+    train.keep_blocks = test.keep_blocks = keep                # per-block caches (like the reference) / materialised join
     l.init()
     l.learn(train, test)
     assert abs(l.fm.w0 - float(z["final_w0"])) <= 1e-4 * abs(float(z["final_w0"])) + 2e-5
