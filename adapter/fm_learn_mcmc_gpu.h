@@ -8,7 +8,9 @@
 // -regular) and replaces the iteration loop of fm_learn_mcmc_simultaneous::_learn (fm_learn_mcmc_simultaneous.h:
 // 56-270) by fmx_als_begin / fmx_als_sweep.  Attribute groups (`-meta`) are passed through: meta->attr_group ->
 // fmx_set_groups, w_lambda(g) / v_lambda(g,f) / w_mu(g) / v_mu(g,f) -> the opts tables.  Relations (`-relation`,
-// Data::relation) go to fmx_upload_block_rows, which joins the blocks on the device.
+// Data::relation) go to fmx_upload_block_rows_ex: on one handle main rows and blocks stay apart (FMX_BLOCKS_KEEP) and the
+// sweeps run over per-block-row caches like fm_learn_mcmc.h:478-527 / 734-790 / 849-909; on feature shards (or with
+// gpu_blocks_expand) the library joins the blocks on the device instead.
 // With do_multilevel the hyper-prior draws (draw_alpha :911-939, draw_w_lambda / draw_w_mu :941-1017, draw_v_lambda /
 // draw_v_mu :1019-1097) stay on the host, in the reference's order and with the reference's own ran_gamma /
 // ran_gaussian (src/util/random.h), fed by the per-group statistics fmx_als_moments reduces on the device; with
@@ -28,8 +30,9 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
   // several GPUs from this ONE process (BASELINE configs[4]): the devices of the feature shards; empty = one unsharded
   // handle on gpu_device.  Distinct ordinals: RCCL; the same ordinal repeated: shards on one device (loopback exchange).
   std::vector<int> gpu_devices;
+  bool gpu_blocks_expand;           // relations: materialise the joined rows on the device instead of keeping the blocks
   unsigned long long gpu_seed;                             // seed of the device-side coordinate draws (do_sample); 0 = derive
-  fm_learn_als_gpu() : gpu_device(-1), gpu_seed(0), h(NULL), grp(NULL) {}   // it from libc rand(), i.e. from main's -seed (libfm.cpp:115-116)
+  fm_learn_als_gpu() : gpu_device(-1), gpu_blocks_expand(false), gpu_seed(0), h(NULL), grp(NULL) {}   // it from libc rand(), i.e. from main's -seed (libfm.cpp:115-116)
   virtual ~fm_learn_als_gpu() { if (grp) fmx_group_destroy(grp); for (size_t i = 0; i < hs.size(); i++) fmx_destroy(hs[i]); }
 
   virtual void learn(Data& train, Data& test) {            // fm_learn_mcmc::learn (:1160-1201) + _learn
@@ -174,9 +177,10 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
       rel[r].data_row_to_relation_row = (const uint32_t*)d.relation(r).data_row_to_relation_row.value;
       rel[r].attr_offset = rd->attr_offset;
     }
-    for (size_t r = 0; r < hs.size(); r++)                   // (block-structured rows are refused on shards by the library)
-      if (fmx_upload_block_rows(hs[r], slot, main.ent.empty() ? NULL : &main.ent[0], (const uint64_t*)&main.row_ptr[0], d.target.value,
-                                d.num_cases, main.ent.size(), rel.empty() ? NULL : &rel[0], (uint32_t)rel.size()) != FMX_OK)
+    uint32_t how = (hs.size() > 1 || gpu_blocks_expand || rel.empty()) ? FMX_BLOCKS_EXPAND : FMX_BLOCKS_KEEP;   // shards sweep joined rows
+    for (size_t r = 0; r < hs.size(); r++)
+      if (fmx_upload_block_rows_ex(hs[r], slot, main.ent.empty() ? NULL : &main.ent[0], (const uint64_t*)&main.row_ptr[0], d.target.value,
+                                   d.num_cases, main.ent.size(), rel.empty() ? NULL : &rel[0], (uint32_t)rel.size(), how) != FMX_OK)
         throw std::string(fmx_last_error(hs[r]));
   }
 };

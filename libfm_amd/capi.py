@@ -295,14 +295,14 @@ class Handle:
         row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
         target = None if target is None else np.ascontiguousarray(target, dtype=np.float32)
         n_rows = len(row_ptr) - 1
-        keep, arr = [], (Relation * max(len(relations), 1))()
+        alive, arr = [], (Relation * max(len(relations), 1))()
         for i, (re, rp, mp, off) in enumerate(relations):
             re = np.ascontiguousarray(re, dtype=ENTRY_DTYPE)
             rp = np.ascontiguousarray(rp, dtype=np.uint64)
             mp = np.ascontiguousarray(mp, dtype=np.uint32)
             if len(mp) != n_rows:
                 raise ValueError("relation %d: the row mapping has %d entries for %d data rows" % (i, len(mp), n_rows))
-            keep += [re, rp, mp]
+            alive += [re, rp, mp]
             arr[i] = Relation(_ptr(re) if len(re) else None, _ptr(rp), len(rp) - 1, 0, len(re), _ptr(mp), int(off))
         self._chk(self.lib.fmx_upload_block_rows_ex(self.h, slot, _ptr(entries) if len(entries) else None, _ptr(row_ptr),
                                                     _ptr(target), n_rows, len(entries), arr, len(relations), 1 if keep else 0))

@@ -296,6 +296,7 @@ int main(int argc, char** argv) {
         fm_learn_als_gpu* gl = new fm_learn_als_gpu();
         if (const char* dv = getenv("FMX_GPU_DEVICES"))        // one feature shard per listed device ("0,0": two on one GPU)
           for (const char* p = dv; *p;) { gl->gpu_devices.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p) p++; }
+        if (const char* e = getenv("FMX_GPU_BLOCKS")) gl->gpu_blocks_expand = !strcmp(e, "expand");   // default: blocks kept apart
         fml = gl;
       } else
 #endif

@@ -89,9 +89,11 @@ def test_reference_driver_with_gpu_als_learner(oracle, name, devices):
     np.testing.assert_allclose(pred_out, z["pred_out"], rtol=1e-4, atol=5e-5)
 
 
-def test_reference_driver_with_gpu_als_learner_on_relations(oracle, tmp_path):
+@pytest.mark.parametrize("blocks", ["keep", "expand"])
+def test_reference_driver_with_gpu_als_learner_on_relations(oracle, tmp_path, blocks):
     """block-structured data through the reference's own RelationData / RelationJoin loaders (FMX_RELATIONS = `-relation`)
-    into adapter/fm_learn_mcmc_gpu.h -> fmx_upload_block_rows; result = the stock block-structured learner's (fixture)."""
+    into adapter/fm_learn_mcmc_gpu.h -> fmx_upload_block_rows_ex (blocks kept apart with per-block caches, or joined on the
+    device); result = the stock block-structured learner's (fixture)."""
     if not os.path.exists(HARNESS):
         pytest.skip("oracle/_ref/ref_harness_gpu not built (needs /root/reference at build time)")
     from libfm_amd import data as D
@@ -114,6 +116,7 @@ def test_reference_driver_with_gpu_als_learner_on_relations(oracle, tmp_path):
         names.append(px)
     env = dict(os.environ)
     env["FMX_RELATIONS"] = ",".join(names)
+    env["FMX_GPU_BLOCKS"] = blocks
     env["FMX_GROUP_REG"] = ",".join(repr(float(x)) for x in list(z["w_lambda_g"]) + list(z["v_lambda_g"]))
     cfg = ["als_gpu", trf, tef, str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), int(z["iters"]),
            repr(g.reg[0]), repr(g.reg[1]), repr(g.reg[2]), repr(float(z["init_stdev"])), int(z["seed"]), pre]

@@ -101,6 +101,45 @@ def test_als_on_relations_matches_reference(oracle, name, keep):
     l.close()
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_sampled_chain_on_kept_blocks_is_the_chain_on_joined_rows(oracle, name):
+    """do_sample = 1 (Gibbs draws, fixed hyper-parameters): the noise of a coordinate is keyed by (seed, iteration, family,
+    GLOBAL attribute id), the probit targets by the data row -- so the block-wise sweep must draw the chain of the joined rows."""
+    from libfm_amd import data as D
+    from libfm_amd import learner as L
+    g = Golden(name)
+    z = g.z
+    res = []
+    for keep in (True, False):
+        fm = L.FMModel()
+        fm.num_attribute, fm.num_factor, fm.k0, fm.k1 = g.n, g.k, bool(g.k0), bool(g.k1)
+        m = g.model(oracle, "init")
+        fm.w0, fm.w, fm.v = m.w0, m.w.copy(), m.v.copy()
+        l = L.FMLearnALS()
+        l.fm, l.task, l.num_iter, l.min_target, l.max_target = fm, g.task, 6, g.min_target, g.max_target
+        l.w_lambda, l.v_lambda, l.do_sample, l.seed = 2.0, 3.0, True, 1234
+        l.out = io.StringIO()
+        train = L.Data(z["train_entries"], z["train_row_ptr"], g.train_target)
+        test = L.Data(z["test_entries"], z["test_row_ptr"], g.test_target)
+        off = int(z["n_main"])
+        for i, (be, bp, nf) in enumerate(blocks_of(z)):
+            rel = D.Relation(be, bp, nf)
+            train.add_relation(rel, z["rel%d_train" % i], off)
+            test.add_relation(rel, z["rel%d_test" % i], off)
+            off += nf
+        train.keep_blocks = test.keep_blocks = keep
+        l.init()
+        l.learn(train, test)
+        res.append((l.fm.w0, l.fm.w.copy(), l.fm.v.copy(), l.predict(test).copy()))
+        l.close()
+    (w0a, wa, va, pa), (w0b, wb, vb, pb) = res
+    assert np.abs(va).max() > 0.05 and np.abs(va - g.model(oracle, "init").v).max() > 0.05      # the chain moved
+    assert abs(w0a - w0b) <= 1e-4 * abs(w0b) + 2e-5
+    np.testing.assert_allclose(wa, wb, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(va, vb, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-4)
+
+
 def test_cli_relation_flag(tmp_path, oracle):
     """`-method als -relation a,b` with the reference's file set (<a>.xt, <a>.train, <a>.test, <a>.groups) and the same
     seed as the reference run behind the fixture -> the same -out predictions."""
