@@ -163,11 +163,12 @@ def bench_als(args, capi):
            "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/sweep, task=r, lambda_w=1 lambda_v=10"
                                   % (args.n, args.k, args.nnz, args.rows),
                       "method": args.method, "levels": st.levels, "device": info.device_name.decode(), "arch": info.arch.decode()},
-           "roofline": {"bound": "hbm", "kernel": "k_als_draw<v> (85 % of the sweep) + re-prediction; whole sweep",
+           "roofline": {"bound": "hbm", "kernel": "k_als_draw<v> + k_als_rows<v> (80 % of the sweep) + re-prediction; whole sweep",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": None, "bytes_per_sweep": per_sweep, "avg_sweep_ms": round(dev / args.steps * 1e3, 3),
-                        "note": "the column passes are random 16-byte read-modify-writes of the {e,q} cache: every one moves a whole "
-                                "128-byte line, so the fabric traffic is several times the algorithmic bytes (DESIGN.md section 4b)"},
+                        "note": "bound by the fabric's random-request rate, not by bytes: the column sums gather one 16-byte {e,q} "
+                                "per entry at 48 G requests/s (55 G/s is what a random 4..16-byte read gets on this part, "
+                                "scripts/ubench/w_gather); the update runs as a row-ordered stream (DESIGN.md section 4b)"},
            "cpu_baseline": None}
     h.als_end()
     h.close()

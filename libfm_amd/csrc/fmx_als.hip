@@ -16,6 +16,10 @@ extern "C++" void als_free(fmx_handle h) {
   if (a.vt) hipFree(a.vt);
   if (a.delta) hipFree(a.delta);
   if (a.epart) hipFree(a.epart);
+  if (a.r_row) hipFree(a.r_row);
+  if (a.r_pos) hipFree(a.r_pos);
+  if (a.r_x) hipFree(a.r_x);
+  if (a.dth) hipFree(a.dth);
   for (AlsBlock& b : a.blk) {
     if (b.level_list) hipFree(b.level_list);
     if (b.cache) hipFree(b.cache);
@@ -43,7 +47,8 @@ static int als_eterms(fmx_handle h, const Slot& s, EQ* e, double* q, double* e_p
 // the dependency levels of the columns of a (transposed) data set: level(j) = 1 + max level of the earlier columns sharing a
 // row with j (host, O(nnz)); fills level_ptr and uploads the level-ordered column list; marks seen[id_offset + feature]
 static int build_levels(fmx_handle h, const Slot& s, std::vector<uint32_t>& level_ptr, uint32_t** d_level_list, std::vector<uint8_t>* seen,
-                        uint32_t id_offset) {
+                        uint32_t id_offset, std::vector<uint32_t>* seg_level = nullptr, std::vector<uint32_t>* seg_pos = nullptr,
+                        std::vector<uint32_t>* lev_ent = nullptr) {
   const uint32_t N = s.n_rows, nseg = s.nseg;
   std::vector<uint32_t> seg_feat(nseg), seg_rel((size_t)nseg + 1), lvl(nseg), rowlevel(std::max<uint32_t>(N, 1), 0);
   std::vector<TEntry> tent((size_t)s.nnz);
@@ -67,7 +72,15 @@ static int build_levels(fmx_handle h, const Slot& s, std::vector<uint32_t>& leve
   for (uint32_t sg = 0; sg < nseg; sg++) level_ptr[lvl[sg] + 1]++;
   for (uint32_t l = 0; l < n_levels; l++) level_ptr[l + 1] += level_ptr[l];
   std::vector<uint32_t> list(std::max<uint32_t>(nseg, 1)), fill(level_ptr.begin(), level_ptr.end());
-  for (uint32_t sg = 0; sg < nseg; sg++) list[fill[lvl[sg]]++] = sg;
+  if (seg_pos) seg_pos->assign(std::max<uint32_t>(nseg, 1), 0);
+  if (lev_ent) lev_ent->assign((size_t)n_levels + 1, 0);
+  for (uint32_t sg = 0; sg < nseg; sg++) {
+    if (seg_pos) (*seg_pos)[sg] = fill[lvl[sg]] - level_ptr[lvl[sg]];      // position inside its level's list
+    if (lev_ent) (*lev_ent)[lvl[sg] + 1] += seg_rel[sg + 1] - seg_rel[sg];
+    list[fill[lvl[sg]]++] = sg;
+  }
+  if (lev_ent) for (uint32_t l = 0; l < n_levels; l++) (*lev_ent)[l + 1] += (*lev_ent)[l];
+  if (seg_level) seg_level->swap(lvl);
   if (seen) for (uint32_t sg = 0; sg < nseg; sg++) (*seen)[(size_t)id_offset + seg_feat[sg]] = 1;
   HIPCHK(h, hipMalloc(d_level_list, list.size() * 4));
   HIPCHK(h, hipMemcpy(*d_level_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
@@ -98,6 +111,41 @@ static int als_repredict(fmx_handle h, const Slot& s, AlsState& a) {
   return FMX_OK;
 }
 
+// the split step's row-ordered copy of X^T (AlsState::r_*): device radix sort of the entries by (level of the feature, row)
+static int als_build_rows(fmx_handle h, const Slot& s, AlsState& a, const std::vector<uint32_t>& seg_level, const std::vector<uint32_t>& seg_pos) {
+  const uint32_t nnz = (uint32_t)s.nnz, nseg = s.nseg;
+  hipStream_t st = h->stream;
+  uint64_t *ka = nullptr, *kb = nullptr; uint32_t *va = nullptr, *vb = nullptr, *d_lvl = nullptr, *d_pos = nullptr; void* tmp = nullptr;
+  int rc = FMX_OK;
+#define ROW_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    rc = fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); goto done; } } while (0)
+  {
+    uint32_t big = 1;
+    for (size_t l = 0; l + 1 < a.level_ptr.size(); l++) big = std::max(big, a.level_ptr[l + 1] - a.level_ptr[l]);
+    int bits_level = 1; while ((1ull << bits_level) < a.level_ptr.size()) bits_level++;
+    size_t tmp_bytes = 0;
+    const dim3 gr(std::min<uint32_t>((nnz + 255) / 256, 8192)), bl(256);
+    ROW_CHK(hipMalloc(&ka, (size_t)nnz * 8)); ROW_CHK(hipMalloc(&kb, (size_t)nnz * 8));
+    ROW_CHK(hipMalloc(&va, (size_t)nnz * 4)); ROW_CHK(hipMalloc(&vb, (size_t)nnz * 4));
+    ROW_CHK(hipMalloc(&d_lvl, (size_t)nseg * 4)); ROW_CHK(hipMalloc(&d_pos, (size_t)nseg * 4));
+    ROW_CHK(hipMalloc(&a.r_row, (size_t)nnz * 4)); ROW_CHK(hipMalloc(&a.r_pos, (size_t)nnz * 4)); ROW_CHK(hipMalloc(&a.r_x, (size_t)nnz * 4));
+    ROW_CHK(hipMalloc(&a.dth, (size_t)big * sizeof(float2)));
+    ROW_CHK(hipMemcpyAsync(d_lvl, seg_level.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+    ROW_CHK(hipMemcpyAsync(d_pos, seg_pos.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_als_rowkeys, gr, bl, 0, st, s.t_ent, s.seg_rel, nseg, nnz, d_lvl, ka, va);
+    ROW_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ka, kb, va, vb, (int)nnz, 0, 32 + bits_level, st));
+    ROW_CHK(hipMalloc(&tmp, tmp_bytes));
+    ROW_CHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, ka, kb, va, vb, (int)nnz, 0, 32 + bits_level, st));
+    hipLaunchKernelGGL(k_als_rowfill, gr, bl, 0, st, s.t_ent, s.seg_rel, nseg, nnz, d_pos, vb, a.r_row, a.r_pos, a.r_x);
+    ROW_CHK(hipGetLastError());
+    ROW_CHK(hipStreamSynchronize(st));
+  }
+done:
+#undef ROW_CHK
+  for (void* p : {(void*)ka, (void*)kb, (void*)va, (void*)vb, (void*)d_lvl, (void*)d_pos, tmp}) if (p) hipFree(p);
+  return rc;
+}
+
 static int als_begin_impl(fmx_handle h, int train_slot);
 int fmx_als_begin(fmx_handle h, int train_slot) {
   const int rc = als_begin_impl(h, train_slot);
@@ -122,8 +170,20 @@ static int als_begin_impl(fmx_handle h, int train_slot) {
   // ---- dependency levels of the main features, then -- kept `-relation` blocks -- of every block's attributes over
   //      the block's own rows (two block attributes conflict iff they share a block row)
   std::vector<uint8_t> seen((size_t)h->n_local, 0);
-  rc = build_levels(h, s, a.level_ptr, &a.level_list, &seen, 0);
-  if (rc) return rc;
+  {
+    // levels with many entries take the split step (column sums + draw, then the {e, q} update as a row-ordered stream):
+    // a fused draw pays two random touches of the {e, q} cache per entry, the split one.  FMX_ALS_SPLIT_MIN: threshold in
+    // entries per level (0 = never split); small levels are launch-bound and stay fused.
+    const char* env = getenv("FMX_ALS_SPLIT_MIN");
+    a.split_min = env ? (uint32_t)strtoul(env, nullptr, 10) : 65536u;
+    std::vector<uint32_t> seg_level, seg_pos;
+    rc = build_levels(h, s, a.level_ptr, &a.level_list, &seen, 0, &seg_level, &seg_pos, &a.lev_ent);
+    if (rc) return rc;
+    bool any = false;
+    for (size_t l = 0; a.split_min && l + 1 < a.lev_ent.size(); l++) any = any || (a.lev_ent[l + 1] - a.lev_ent[l] >= a.split_min);
+    if (any && s.nnz > 0 && s.nnz < (1ull << 32)) { rc = als_build_rows(h, s, a, seg_level, seg_pos); if (rc) return rc; }
+    else a.split_min = 0;
+  }
   a.blk.resize(s.blocks.size());
   for (size_t r = 0; r < s.blocks.size(); r++) {
     BlockRows& br = *s.blocks[r];
@@ -294,21 +354,27 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
       const Shard sh = make_shard(h->cfg);
       EQ* delta = sharded ? a.delta : nullptr;
       const uint32_t nseg = s.nseg, nnz = (uint32_t)s.nnz;
+      const uint32_t n_ent = (!sharded && a.split_min && a.r_row) ? a.lev_ent[l + 1] - a.lev_ent[l] : 0u;
+      float2* dth = (n_ent && n_ent >= a.split_min) ? a.dth : nullptr;     // split step for this level?
       if (f < 0) {
         FMX_ALS_DRAW(false, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
                      h->tb.w, h->tb.ws, 0, 0u, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
-                     opts->seed, (uint64_t)(a.iter * 1024 + 1000), sh, delta);
+                     opts->seed, (uint64_t)(a.iter * 1024 + 1000), sh, delta, dth);
+        if (dth) hipLaunchKernelGGL((k_als_rows<false>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
+                                    a.r_row + a.lev_ent[l], a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
       } else {
         const double* v_lambda = a.prior + (size_t)(1 + f) * 2 * NG;
         const double* v_mu = v_lambda + NG;
         if (a.vt)
           FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
                        a.vt + (size_t)f * a.vt_stride, 1u, 1, a.level_ptr[l], a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
-                       opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta);
+                       opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta, dth);
         else
           FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
                        h->tb.V + f, h->tb.rs, 0, 0u, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
-                       opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta);
+                       opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta, dth);
+        if (dth) hipLaunchKernelGGL((k_als_rows<true>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
+                                    a.r_row + a.lev_ent[l], a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
       }
       HIPCHK(h, hipGetLastError());
     }

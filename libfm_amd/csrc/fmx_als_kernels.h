@@ -368,9 +368,11 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
            uint32_t nseg_total, uint32_t nnz, const uint32_t* __restrict__ seg_list, uint32_t n_list,
            float* __restrict__ param, uint32_t pstride, int param_by_pos, uint32_t pos0, EQ* __restrict__ eq,
            double alpha, const double* __restrict__ lambda_g, const double* __restrict__ mu_g, const uint32_t* __restrict__ attr_group,
-           int do_sample, uint64_t seed, uint64_t stream, const Shard sh, EQ* __restrict__ delta) {
+           int do_sample, uint64_t seed, uint64_t stream, const Shard sh, EQ* __restrict__ delta, float2* __restrict__ dth) {
   // sh: the Gibbs noise of a coordinate is keyed by the feature's GLOBAL id, so a sharded chain draws what the unsharded
   // one draws.  delta != nullptr (feature shards): {e, q} are left alone and the change is recorded instead.
+  // dth != nullptr (split step): only the column sums and the draw happen here; {old, new} value of list entry li goes to
+  // dth[li] and k_als_rows applies the change to {e, q} in ROW order (streams instead of a second random pass).
   constexpr uint32_t GPW = 64 / G;                      // feature groups per wavefront
   const uint32_t lane = (threadIdx.x & 63u) % G;         // lane inside its group
   const uint32_t grp = (threadIdx.x & 63u) / G;
@@ -406,10 +408,14 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
     double nt;
     if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
     else nt = do_sample ? mean + sqrt(sigma_sqr) * gauss_hash(seed, stream, sh.global(j)) : mean;
-    if (isnan(nt) || isinf(nt)) continue;                          // keep the old value, caches untouched
+    if (isnan(nt) || isinf(nt)) {                                  // keep the old value, caches untouched
+      if (dth && lane == 0) dth[li] = make_float2((float)th, (float)th);
+      continue;
+    }
     const float ntf = (float)nt;
     const double d = th - (double)ntf;                             // theta_old - theta (of the STORED value)
     if (lane == 0) { if (param_by_pos) *pt = ntf; else als_param_store(pt, ntf); }
+    if (dth) { if (lane == 0) dth[li] = make_float2((float)th, ntf); continue; }
     if (d != 0.0) {
       // update e (and q): one lane per (row, run of occurrences).  A row holding this feature more than once has its
       // occurrences adjacent (the sort is stable in row order); the first one walks the run sequentially exactly
@@ -442,6 +448,55 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
         else { c.e = ec; eq[te.e] = c; }                           // one 16-byte store
       }
     }
+  }
+}
+
+// ---- split step, second half: the level's entries in ROW order ------------------------------------------------------
+// Features of one level never share a row, so a row holds at most one run of entries of the level (the occurrences of ONE
+// feature).  r_row / r_pos / r_x: row, position of the entry's feature in the level's list (index into dth), value -- sorted
+// by row, so {e, q} are read and written as a stream and the only gather is the 8-byte {old, new} pair of a table the size
+// of the level (cache-resident), instead of a second random pass over the 16-byte {e, q} cache of ALL rows.
+template <bool IS_V>
+__global__ void __launch_bounds__(256)
+k_als_rows(const uint32_t* __restrict__ r_row, const uint32_t* __restrict__ r_pos, const float* __restrict__ r_x, uint32_t n_ent,
+           const float2* __restrict__ dth, EQ* __restrict__ eq) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_ent; t += gridDim.x * blockDim.x) {
+    const uint32_t row = __builtin_nontemporal_load(r_row + t);
+    if (t > 0 && r_row[t - 1] == row) continue;                     // a later occurrence: walked by the first of its run
+    const float2 tt = dth[__builtin_nontemporal_load(r_pos + t)];
+    const double th = (double)tt.x, d = (double)tt.x - (double)tt.y;   // theta_old - theta
+    if (d == 0.0) continue;
+    EQ c = eq[row];
+    for (uint32_t i2 = t; i2 < n_ent; i2++) {                       // :839-846: q is updated between the occurrences
+      if (i2 > t && r_row[i2] != row) break;
+      const double x = (double)__builtin_nontemporal_load(r_x + i2);
+      if (IS_V) { const double h = x * (c.q - x * th); c.q -= x * d; c.e -= h * d; }
+      else c.e -= x * d;
+    }
+    eq[row] = c;
+  }
+}
+// set-up of the row-ordered lists: key = (level of the entry's feature, row), value = entry index in X^T
+static __global__ void __launch_bounds__(256)
+k_als_rowkeys(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_rel, uint32_t nseg, uint32_t nnz,
+              const uint32_t* __restrict__ seg_level, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
+    uint32_t lo = 0, hi = nseg;                                     // the segment of entry i: last sg with seg_rel[sg] <= i
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_rel[mid] <= i) lo = mid; else hi = mid; }
+    keys[i] = ((uint64_t)seg_level[lo] << 32) | (uint64_t)t_ent[i].e;
+    vals[i] = i;
+  }
+}
+static __global__ void __launch_bounds__(256)
+k_als_rowfill(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_rel, uint32_t nseg, uint32_t nnz,
+              const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ vals, uint32_t* __restrict__ r_row,
+              uint32_t* __restrict__ r_pos, float* __restrict__ r_x) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += gridDim.x * blockDim.x) {
+    const uint32_t i = vals[t];
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_rel[mid] <= i) lo = mid; else hi = mid; }
+    const TEntry te = t_ent[i];
+    r_row[t] = te.e; r_x[t] = te.x; r_pos[t] = seg_pos[lo];
   }
 }
 

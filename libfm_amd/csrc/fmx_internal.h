@@ -84,6 +84,11 @@ struct AlsState {
   double*   epart = nullptr;      // feature shards: [N] partial y-hat of the re-prediction
   float*    vt = nullptr;         // [num_factor][vt_stride] factor-major shadow of the seen features' factors, level order
   size_t    vt_stride = 0;
+  // split step (large levels of an unsharded session): the entries of every level in ROW order + the draws' {old, new} pairs
+  uint32_t* r_row = nullptr; uint32_t* r_pos = nullptr; float* r_x = nullptr;   // [nnz], level after level
+  float2*   dth = nullptr;        // [largest level]
+  std::vector<uint32_t> lev_ent;  // [n_levels + 1] entry range of each level in r_*
+  uint32_t  split_min = 0;        // levels with at least this many entries take the split step (0: none)
   double*   prior = nullptr;      // [1 + k][2][G]: per coordinate family (row 0 = w, 1+f = v_f) lambda[G] then mu[G]
   std::vector<double> prior_host;
 };

@@ -31,8 +31,17 @@ def make_learner(g, oracle):
     return L, l
 
 
+@pytest.fixture(params=["fused", "split"])
+def draw_form(request, monkeypatch):
+    """fused: column sums, draw and {e, q} update in one launch per (family, level); split: the update as a row-ordered
+    stream (k_als_rows) -- the library's choice for levels of >= FMX_ALS_SPLIT_MIN entries (read at fmx_als_begin), forced
+    here for every level so that the small fixtures run it too (duplicate ids in a row, ragged rows, groups, probit)."""
+    monkeypatch.setenv("FMX_ALS_SPLIT_MIN", "1" if request.param == "split" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", CASES)
-def test_als_matches_reference(oracle, name):
+def test_als_matches_reference(oracle, name, draw_form):
     g = Golden(name)
     L, l = make_learner(g, oracle)
     z = g.z
@@ -48,7 +57,7 @@ def test_als_matches_reference(oracle, name):
     l.close()
 
 
-def test_als_field_data_bigger_than_fixture(oracle):
+def test_als_field_data_bigger_than_fixture(oracle, draw_form):
     """one-hot field rows (level = field): 16 fields, k = 32, compared with the pinned oracle."""
     from libfm_amd import learner as L
     n, nnz = 3200, 16
@@ -76,7 +85,7 @@ def test_als_field_data_bigger_than_fixture(oracle):
     l.close()
 
 
-def test_als_mid_size_against_oracle(oracle):
+def test_als_mid_size_against_oracle(oracle, draw_form):
     """50 000 rows x 16 one-hot fields over 200 000 features, k = 16, classification (probit targets): thousands of
     columns per level and G = 4 lanes per column -- a different launch regime from the small fixtures."""
     from libfm_amd import learner as L
@@ -100,3 +109,34 @@ def test_als_mid_size_against_oracle(oracle):
     np.testing.assert_allclose(l.pred_this, pred, rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose([x["train"] for x in l.log], metric, rtol=1e-4)
     l.close()
+
+
+@pytest.mark.parametrize("task,do_sample", [(0, False), (1, True)])
+def test_split_step_is_the_fused_step(oracle, monkeypatch, task, do_sample):
+    """the row-ordered update performs the same fp64 operations per row as the fused kernel's second pass (the {old, new} pair
+    travels as two fp32 numbers, both exact), so the two forms agree to fp64 rounding (the compiler contracts the
+    multiply-adds of the two kernels differently) -- fp32-identical parameters, also for a sampled chain."""
+    from libfm_amd import learner as L
+    n, nnz, k = 60000, 12, 8
+    ent, rp, y = datagen.onehot_fields(n, nnz, 30000, seed=31, classification=bool(task))
+    ent2, rp2, y2 = datagen.onehot_fields(n, nnz, 2000, seed=32, classification=bool(task))
+    res = []
+    for split_min in ("0", "1", "20000"):                      # never / always / the big levels only (30 000 entries each)
+        monkeypatch.setenv("FMX_ALS_SPLIT_MIN", split_min)
+        fm = L.FMModel()
+        fm.num_attribute, fm.num_factor = n, k
+        fm.w0, fm.w, fm.v = 0.1, oracle.init_values(5, n, 1, 0.1)[0].copy(), oracle.init_values(4, n, k, 0.1).copy()
+        l = L.FMLearnALS()
+        l.fm, l.task, l.num_iter, l.min_target, l.max_target = fm, task, 3, float(y.min()), float(y.max())
+        l.w_lambda, l.v_lambda, l.do_sample, l.seed = 1.0, 4.0, do_sample, 99
+        l.out = io.StringIO()
+        l.init()
+        l.learn(L.Data(ent, rp, y), L.Data(ent2, rp2, y2))
+        res.append((l.fm.w0, l.fm.w.copy(), l.fm.v.copy(), l.predict(L.Data(ent2, rp2, y2)).copy()))
+        l.close()
+    assert np.abs(res[0][2] - oracle.init_values(4, n, k, 0.1)).max() > 1e-3
+    for other in res[1:]:
+        assert abs(other[0] - res[0][0]) < 1e-10
+        np.testing.assert_allclose(other[1], res[0][1], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(other[2], res[0][2], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(other[3], res[0][3], rtol=1e-9, atol=1e-9)
