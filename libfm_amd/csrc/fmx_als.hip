@@ -38,7 +38,7 @@ int fmx_als_end(fmx_handle h) {
 }
 
 static int als_eterms(fmx_handle h, const Slot& s, EQ* e, double* q, double* e_part = nullptr) {
-  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), s.n_rows, h->stream, s.ent, s.row_ptr, s.n_rows, h->tb,
+  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), ((uint64_t)s.n_rows + EtermsRows<KP>::R - 1) / EtermsRows<KP>::R, h->stream, s.ent, s.row_ptr, s.n_rows, h->tb,
                                      h->cfg.k0, h->cfg.k1, h->w0, e, q, e_part));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
@@ -102,7 +102,7 @@ static int als_repredict(fmx_handle h, const Slot& s, AlsState& a) {
     const uint32_t B = br.rows.n_rows;
     Tab tb = h->tb;                                          // the block's attribute 0 is global attribute attr_offset
     tb.V += (size_t)br.attr_offset * tb.rs; tb.w += (size_t)br.attr_offset * tb.ws;
-    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), B, h->stream, br.rows.ent, br.rows.row_ptr, B, tb,
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_eterms<KP>), ((uint64_t)B + EtermsRows<KP>::R - 1) / EtermsRows<KP>::R, h->stream, br.rows.ent, br.rows.row_ptr, B, tb,
                                        0, h->cfg.k1, (const double*)h->w0, (EQ*)nullptr, ab.qb_all, ab.cpart));
     hipLaunchKernelGGL(k_rel_combine, g1, b1, 0, h->stream, br.map, N, B, ab.cpart, ab.qb_all, h->cfg.num_factor, a.epart, a.q);
   }
@@ -330,6 +330,7 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
     const Slot& s = x->slots[a.slot];
     const double avg_col = s.nseg ? (double)s.nnz / (double)s.nseg : 0.0;
     lanes[i] = avg_col <= 5.0 ? 4 : (avg_col <= 12.0 ? 8 : (avg_col <= 40.0 ? 16 : 64));
+    if (const char* e = getenv("FMX_ALS_LANES")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 64) lanes[i] = v; }   // tuning knob
   }
 #define FMX_ALS_DRAW(ISV, cnt, ...)                                                                          \
   do {                                                                                                        \

@@ -44,51 +44,89 @@ __device__ __forceinline__ double ref_cdf_gaussian(double x) { return 0.5 + 0.5 
 // coming sweep (add_main_q :406-428 evaluated for every factor at once: v_f does not change before its own
 // sweep, so the value is the one the reference would compute later).
 // ----------------------------------------------------------------------------------------------
+// Rows per wavefront pass: the q_f of R consecutive rows leave through an LDS tile, so a store covers 8 R contiguous bytes
+// of every factor's row of q[KP][n_rows] instead of 8 (one lane per factor, one row at a time).
+template <int KP> struct EtermsRows { static constexpr int R = (KP > 128) ? 4 : 8; };
 template <int KP>
 __global__ void __launch_bounds__(256)
 k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, const Tab tb,
              int k0, int k1, const double* __restrict__ w0_ptr, EQ* __restrict__ eq, double* __restrict__ q /* [KP][n_rows] or null */,
              double* __restrict__ e_part /* feature shard: lin - 0.5 * sum of squares goes here (k_als_set_e finishes y-hat) */) {
-  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
-  const uint32_t lane = threadIdx.x & 63u;
-  const bool act = lane < LPR;
-  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI, R = EtermsRows<KP>::R, U = 8;
+  __shared__ double tile[4][R][KP + 1];                            // [wavefront][row][factor], padded against bank conflicts
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t g = lane / LPR, f = lane % LPR;                  // EPI entries per load instruction, sub-group g takes one
   const double w0 = k0 ? *w0_ptr : 0.0;
-  for (uint32_t c = wave0; c < n_rows; c += nwaves) {
-    const uint64_t a = row_ptr[c];
-    const uint32_t size = (uint32_t)(row_ptr[c + 1] - a);
-    double sum[VEC]; double sq = 0.0, lin = 0.0;
+  // every wavefront of a workgroup makes the same number of trips (the tile hand-over uses the workgroup barrier)
+  for (uint64_t cb = (uint64_t)blockIdx.x * 4 * R; cb < n_rows; cb += (uint64_t)gridDim.x * 4 * R) {
+    const uint64_t c0 = cb + (uint64_t)wv * R;
+    double e_keep = 0.0;                                           // lane r keeps the scalar of row c0 + r
+    for (int r = 0; r < R; r++) {
+      const uint64_t c = c0 + r;
+      if (c >= n_rows) break;                                      // (wave-uniform)
+      const uint64_t a = row_ptr[c];
+      const uint32_t size = (uint32_t)(row_ptr[c + 1] - a);
+      double sum[VEC]; double part = 0.0;                          // part: this lane's share of lin - 0.5 * sum of squares
 #pragma unroll
-    for (int v = 0; v < VEC; v++) sum[v] = 0.0;
-    for (uint32_t i = 0; i < size; i++) {
-      const Entry en = ent[a + i];
-      const double x = (double)en.value;
-      if (k1 && lane == 0) lin += (double)tb.w[(size_t)en.id * tb.ws] * x;
-      if (act) {
-        float vv[VEC];
-        load_vec<VEC>(tb.V + (size_t)en.id * tb.rs + lane * VEC, vv);
+      for (int v = 0; v < VEC; v++) sum[v] = 0.0;
+      for (uint32_t base = 0; base < size; base += 64) {
+        const uint32_t cnt = min(64u, size - base);
+        Entry en; en.id = 0; en.value = 0.f;
+        if (lane < cnt) {
+          en = load_stream8(ent + a + base + lane);                // one entry per lane, broadcast below
+          if (k1) part += (double)load_w(tb.w + (size_t)en.id * tb.ws) * (double)en.value;
+        }
+        for (uint32_t i = 0; i < cnt; i += EPI * U) {
+          float vr[U][VEC]; float xs[U];
 #pragma unroll
-        for (int v = 0; v < VEC; v++) {
-          const double d = (double)vv[v] * x;
-          sum[v] += d;
-          sq += d * d;
+          for (int u = 0; u < U; u++) {                            // U rows of V in flight per lane
+            const uint32_t idx = i + u * EPI + g;
+            const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
+            xs[u] = bcast_f32<EPI>(en.value, idx & 63u);
+            if (idx < cnt) load_row<VEC, 4>(tb.V + (size_t)id * tb.rs + f * VEC, vr[u]);
+            else {
+              xs[u] = 0.f;
+#pragma unroll
+              for (int v = 0; v < VEC; v++) vr[u][v] = 0.f;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+              const double d = (double)vr[u][v] * (double)xs[u];
+              sum[v] += d;
+              part -= 0.5 * d * d;
+            }
         }
       }
-    }
-    double part = lin - 0.5 * sq;
-    if (act) {
-      if (!e_part) {                                           // (a shard's factor sums are partial: their squares wait for the all-reduce)
+      if constexpr (EPI > 1) {                                     // the sub-groups' partial factor sums -> complete, in every lane
 #pragma unroll
-        for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
-      }
-      if (q) {
+        for (int v = 0; v < VEC; v++)
 #pragma unroll
-        for (int v = 0; v < VEC; v++) q[(size_t)(lane * VEC + v) * n_rows + c] = sum[v];
+          for (int o = LPR; o < 64; o <<= 1) sum[v] += __shfl_xor(sum[v], o);
+      }
+      if (g == 0) {
+        if (!e_part) {                                             // (a shard's factor sums are partial: their squares wait for the all-reduce)
+#pragma unroll
+          for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; v++) tile[wv][r][f * VEC + v] = sum[v];
+      }
+      part = wave_sum_f64(part);
+      if (lane == (uint32_t)r) e_keep = part;
+    }
+    if (lane < R && c0 + lane < n_rows) { if (e_part) e_part[c0 + lane] = e_keep; else eq[c0 + lane].e = w0 + e_keep; }
+    __syncthreads();
+    if (q && c0 < n_rows) {
+      const uint32_t nr = (uint32_t)min((uint64_t)R, (uint64_t)n_rows - c0);
+      for (uint32_t i = lane; i < (uint32_t)R * KP; i += 64) {     // R consecutive rows of one factor per 8 R bytes
+        const uint32_t r = i % R, ff = i / R;
+        if (r < nr) q[(size_t)ff * n_rows + c0 + r] = tile[wv][r][ff];
       }
     }
-    part = wave_sum_f64(part);
-    if (lane == 0) { if (e_part) e_part[c] = part; else eq[c].e = w0 + part; }
+    __syncthreads();
   }
 }
 
@@ -456,24 +494,29 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
 // feature).  r_row / r_pos / r_x: row, position of the entry's feature in the level's list (index into dth), value -- sorted
 // by row, so {e, q} are read and written as a stream and the only gather is the 8-byte {old, new} pair of a table the size
 // of the level (cache-resident), instead of a second random pass over the 16-byte {e, q} cache of ALL rows.
+#ifndef FMX_ALS_ROWS_NT
+#define FMX_ALS_ROWS_NT 1
+#endif
 template <bool IS_V>
 __global__ void __launch_bounds__(256)
 k_als_rows(const uint32_t* __restrict__ r_row, const uint32_t* __restrict__ r_pos, const float* __restrict__ r_x, uint32_t n_ent,
            const float2* __restrict__ dth, EQ* __restrict__ eq) {
+  constexpr bool NT_EQ = FMX_ALS_ROWS_NT;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_ent; t += gridDim.x * blockDim.x) {
     const uint32_t row = __builtin_nontemporal_load(r_row + t);
     if (t > 0 && r_row[t - 1] == row) continue;                     // a later occurrence: walked by the first of its run
     const float2 tt = dth[__builtin_nontemporal_load(r_pos + t)];
     const double th = (double)tt.x, d = (double)tt.x - (double)tt.y;   // theta_old - theta
     if (d == 0.0) continue;
-    EQ c = eq[row];
+    EQ c;                                                           // {e, q} is a stream here: keep it out of the way of dth in L2
+    if (NT_EQ) { c.e = __builtin_nontemporal_load(&eq[row].e); c.q = __builtin_nontemporal_load(&eq[row].q); } else c = eq[row];
     for (uint32_t i2 = t; i2 < n_ent; i2++) {                       // :839-846: q is updated between the occurrences
       if (i2 > t && r_row[i2] != row) break;
       const double x = (double)__builtin_nontemporal_load(r_x + i2);
       if (IS_V) { const double h = x * (c.q - x * th); c.q -= x * d; c.e -= h * d; }
       else c.e -= x * d;
     }
-    eq[row] = c;
+    if (NT_EQ) { __builtin_nontemporal_store(c.e, &eq[row].e); __builtin_nontemporal_store(c.q, &eq[row].q); } else eq[row] = c;
   }
 }
 // set-up of the row-ordered lists: key = (level of the entry's feature, row), value = entry index in X^T
