@@ -829,7 +829,10 @@ struct SegWork {
 // SPW = segments per wavefront-block (<= 64).  64 for the dense form (millions of segments: plenty of wavefronts); 16 for
 // the short list of deferred features (a few 100 000): with 64 the pass ran on ~5 000 wavefronts, each a serial chain of
 // eight dependent gather rounds -- 166 us for 350 MB (2 TB/s, latency-bound) -- four times as many shorter chains fill the chip.
-template <int KP, int U, int SPW = 64>
+// PRE2 (the deferred list, where every feature has >= 2 occurrences): the SECOND occurrence's descriptor, multiplier and S row
+// are fetched in the same pipelined rounds as the first instead of in the serial tail loop (entry -> multiplier -> S row, three
+// dependent gathers per segment) -- same operations in the same order, the loop only starts at the third occurrence.
+template <int KP, int U, int SPW = 64, bool PRE2 = (SPW < 64)>
 __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk, const Tab tb, const Hyper& h) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
@@ -837,7 +840,7 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
   const float* __restrict__ S = sw.S;
   const float* __restrict__ mult = sw.mult;
   const uint32_t cnt = min((uint32_t)SPW, sw.nseg - blk);
-  uint32_t jl = 0, al = 0, bl = 0, el = 0; float xl = 0.f, ml = 0.f;
+  uint32_t jl = 0, al = 0, bl = 0, el = 0, e2l = 0; float xl = 0.f, ml = 0.f, x2l = 0.f, m2l = 0.f;
   if (lane < cnt) {
     const uint32_t s = sw.seg_idx ? sw.seg_idx[blk + lane] : blk + lane;
     jl = sw.seg_feat[s];
@@ -845,18 +848,28 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
     bl = (s + 1 < sw.nseg_batch) ? sw.seg_rel[s + 1] : sw.batch_nnz;
     const TEntry te = load_stream8(t_ent + al);
     el = te.e; xl = te.x;
+    if (PRE2 && bl - al >= 2) { const TEntry t2 = load_stream8(t_ent + al + 1); e2l = t2.e; x2l = t2.x; m2l = mult[e2l]; }
     ml = mult[el];
   }
   for (uint32_t i = 0; i < cnt; i += EPI * U) {
-    float v0[U][VEC], sf[U][VEC];
+    float v0[U][VEC], sf[U][VEC], sf2[PRE2 ? U : 1][VEC];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t idx = i + u * EPI + g;
       const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
       const uint32_t e = bcast_u32<EPI>(el, idx & 63u);
+      uint32_t e2 = 0, n2 = 0;
+      if (PRE2) { e2 = bcast_u32<EPI>(e2l, idx & 63u); n2 = bcast_u32<EPI>(bl - al, idx & 63u); }
       if (idx < cnt) {
         load_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, v0[u]);
         load_vec<VEC>(S + (size_t)e * KP + f * VEC, sf[u]);
+        if (PRE2) {
+          if (n2 >= 2) load_vec<VEC>(S + (size_t)e2 * KP + f * VEC, sf2[u]);
+          else {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) sf2[u][v] = 0.f;
+          }
+        }
       }
     }
 #pragma unroll
@@ -867,13 +880,22 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
       const uint32_t b = bcast_u32<EPI>(bl, idx & 63u);
       const float x = bcast_f32<EPI>(xl, idx & 63u);
       const float m = bcast_f32<EPI>(ml, idx & 63u);
+      float x2 = 0.f, m2 = 0.f;                               // (cross-lane reads run with every lane enabled: outside the guard)
+      if (PRE2) { x2 = bcast_f32<EPI>(x2l, idx & 63u); m2 = bcast_f32<EPI>(m2l, idx & 63u); }
       if (idx < cnt) {
         float G[VEC]; float A, Gw;
         const float mx = m * x;
 #pragma unroll
         for (int v = 0; v < VEC; v++) G[v] = mx * sf[u][v];
         A = mx * x; Gw = mx;
-        for (uint32_t i2 = a + 1; i2 < b; i2++) {             // further occurrences of the feature in this batch
+        uint32_t i2 = PRE2 ? a + 2 : a + 1;
+        if (PRE2 && b - a >= 2) {
+          const float mx2 = m2 * x2;
+#pragma unroll
+          for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, sf2[u][v], G[v]);
+          A = fmaf(mx2, x2, A); Gw += mx2;
+        }
+        for (; i2 < b; i2++) {                                // further occurrences of the feature in this batch
           const TEntry t2 = t_ent[i2];
           const float mx2 = mult[t2.e] * t2.x;
           float s2[VEC];
