@@ -140,6 +140,35 @@ static int exchange_begin(fmx_group g, int which, size_t count) {
   }
   return FMX_OK;
 }
+// RCCL, chunked: the all-reduce of ONE run of rows of the batch buffer (its [rows][KP] factor sums and its [rows] scalars),
+// enqueued behind the sums of that run; the next run is summed on the compute stream meanwhile.  `last`: the event the
+// update waits for (exchange_end) is recorded behind this chunk.
+static int exchange_rows(fmx_group g, int which, size_t off_s, size_t cnt_s, size_t off_c, size_t cnt_c, bool last) {
+  const size_t n = g->hs.size();
+  Rccl* R = rccl();
+  for (size_t i = 0; i < n; i++) {
+    fmx_handle h = g->hs[i];
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->ev_x[which], h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream_comm, h->ev_x[which], 0));
+  }
+  NCCLCHK(g->hs[0], R->GroupStart());
+  for (size_t i = 0; i < n; i++) {
+    fmx_handle h = g->hs[i];
+    HIPCHK(h, hipSetDevice(h->device));
+    float* b = h->xbuf[which];
+    NCCLCHK(h, R->AllReduce(b + off_s, b + off_s, cnt_s, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
+    NCCLCHK(h, R->AllReduce(b + off_c, b + off_c, cnt_c, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
+  }
+  NCCLCHK(g->hs[0], R->GroupEnd());
+  if (last)
+    for (size_t i = 0; i < n; i++) {
+      fmx_handle h = g->hs[i];
+      HIPCHK(h, hipSetDevice(h->device));
+      HIPCHK(h, hipEventRecord(h->ev_x[2 + which], h->stream_comm));
+    }
+  return FMX_OK;
+}
 static int exchange_end(fmx_group g, int which) {
   if (g->kind == GROUP_RCCL)
     for (fmx_handle h : g->hs) { HIPCHK(h, hipSetDevice(h->device)); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_x[2 + which], 0)); }
@@ -385,9 +414,30 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
   HIPCHK(h0, hipEventRecord(h0->ev0, h0->stream));
   const uint64_t n_batch = ((uint64_t)n_rows + B - 1) / B;
   auto rows_of = [&](uint64_t b) { return (uint32_t)std::min<uint64_t>(B, n_rows - b * B); };
+  // RCCL: the batch is summed and exchanged in runs of rows, so that the wire works while the next run is being summed (the sums of
+  // a row do not depend on the other rows of the batch: nothing changes in the rule).  FMX_XCHG_CHUNKS: runs per batch (1 = one
+  // exchange per batch, as the loopback exchange always does).
+  static const uint32_t xchunks = getenv("FMX_XCHG_CHUNKS") ? (uint32_t)std::max(1, atoi(getenv("FMX_XCHG_CHUNKS"))) : 4u;
   auto gather = [&](uint64_t b) -> int {
-    for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_partial(cur, slot, b * B, rows_of(b), cur->xbuf[b & 1], cur->stream)); }
-    return exchange_begin(g, (int)(b & 1), (size_t)rows_of(b) * kp1);
+    const uint32_t nb = rows_of(b);
+    const int which = (int)(b & 1);
+    if (g->kind == GROUP_RCCL && xchunks > 1 && nb >= 64 * xchunks) {
+      const uint32_t step = ((nb + xchunks - 1) / xchunks + 63u) & ~63u;
+      for (uint32_t r0 = 0; r0 < nb; r0 += step) {
+        const uint32_t nr = std::min(step, nb - r0);
+        const size_t off_s = (size_t)r0 * (kp1 - 1), off_c = (size_t)nb * (kp1 - 1) + r0;
+        for (size_t i = 0; i < n; i++) {
+          cur = g->hs[i];
+          HIPCHK(cur, hipSetDevice(cur->device));
+          GCHK(g, sgd_partial_rows(cur, cur->slots[slot], b * B + r0, nr, cur->xbuf[which] + off_s, cur->xbuf[which] + off_c, cur->stream));
+        }
+        int erc = exchange_rows(g, which, off_s, (size_t)nr * (kp1 - 1), off_c, nr, r0 + nr >= nb);
+        if (erc) return erc;
+      }
+      return FMX_OK;
+    }
+    for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_partial(cur, slot, b * B, nb, cur->xbuf[which], cur->stream)); }
+    return exchange_begin(g, which, (size_t)nb * kp1);
   };
   auto update = [&](uint64_t b) -> int {
     int erc = exchange_end(g, (int)(b & 1));

@@ -158,6 +158,7 @@ void free_segments(Slot& s);
 void free_slot(Slot& s);
 int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st);
 int ensure_segments(fmx_handle h, Slot& s, uint32_t B);                 // fmx_sgd.hip
+int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st);   // fmx_sgd.hip
 int lag_flush(fmx_handle h);                                             // fmx_sgd.hip
 void sgda_free(fmx_handle h);                                            // fmx_sgd.hip
 void als_free(fmx_handle h);                                             // fmx_als.hip

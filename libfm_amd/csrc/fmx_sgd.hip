@@ -83,6 +83,15 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
   return FMX_OK;
 }
 
+// a run of rows of a batch into the batch's partial buffer (S: [batch rows][KP], c: [batch rows]) -- the chunked exchange of
+// fmx_group_sgd_epoch enqueues the all-reduce of one run while the next one is being summed
+extern "C++" int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st) {
+  if (n_rows == 0) return FMX_OK;
+  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st, s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c));
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
 // builds the (batch, feature) segments of a slot for batch size B (device radix sort; once per data set)
 extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   if (s.seg_B == B && s.t_ent) return FMX_OK;

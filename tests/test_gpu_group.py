@@ -122,6 +122,50 @@ def test_sharded_params_round_trip_and_rows(capi, oracle, shard_hash):
         h.close()
 
 
+@pytest.mark.parametrize("world,lag,pipeline", [(1, 2, False), (1, 1, True), (2, 2, False), (4, 1, False)])
+def test_library_rccl_schedule_matches_the_oracle_rule(capi, oracle, world, lag, pipeline):
+    """the schedule a libFM process runs on several GPUs (fmx_comm_init_rank / a group of handles on distinct devices ->
+    fmx_sgd_epoch): partial sums and their all-reduce in RUNS of rows (the wire works while the next run is summed), then the
+    update.  world = 1: one rank through the RCCL binding (the all-reduce is the identity, every offset of the chunked
+    exchange is still exercised: batches of 1000 rows = runs of 256 / 256 / 256 / 232, ragged last batch); world > 1: one
+    handle per GPU from this one process, where that many GPUs are visible."""
+    import torch
+    if world > torch.cuda.device_count():
+        pytest.skip("needs %d GPUs" % world)
+    n, k, nnz, rows, batch, chunk = 5000, 16, 12, 3300, 1000, 50
+    ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed=77, zipf=1.1)
+    m = oracle.Model(n, k, True, True, 0.0, 0.002, 0.01)
+    m.v[:] = oracle.init_values(8, n, k, 0.1)
+    m.w[:] = oracle.init_values(9, n, 1, 0.1)[0]
+    m.w0 = 0.05
+    d = oracle.Data(ent, rp, y)
+    hs = [capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.002, 0.01, 0.004, -1.0, 1.0, device=r, shard_rank=r,
+                      shard_world=world, shard_hash=1) for r in range(world)]
+    for h in hs:
+        h.set_params(m.w0, m.w, m.v)
+        h.upload_rows(0, ent, rp, y)
+    flags = capi.FLAG_BIAS_LAG | (capi.FLAG_PIPELINE if pipeline else 0)
+    if world == 1:
+        hs[0].comm_init_rank(capi.comm_unique_id(), 0, 1)
+        run = lambda: hs[0].sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, chunk, flags, lag)
+        grp = None
+    else:
+        grp = capi.Group(hs)
+        run = lambda: grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, chunk, flags, lag)
+    for _ in range(3):
+        run()
+        oracle.sgd_epoch_minibatch(m, d, 1, 0.004, -1.0, 1.0, batch, chunk, bias_lag=lag, pipelined=pipeline)
+    w0, w, v = grp.get_params() if grp else hs[0].get_params()
+    assert np.abs(m.v).max() < 10.0 and np.abs(m.v - oracle.init_values(8, n, k, 0.1)).max() > 1e-3      # trained, not diverged
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    if grp:
+        grp.close()
+    for h in hs:
+        h.close()
+
+
 def test_group_at_bench_shape_matches_single_handle(capi):
     """n = 1e7, k = 64, 32 nnz: 4 loopback shards == one handle running the one-pass form of the same rule"""
     n, k, nnz, rows, batch = 10_000_000, 64, 32, 1 << 17, 32768
