@@ -101,7 +101,8 @@ struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping (split step):
   hipEvent_t ev_rest = nullptr, ev_scan[RING] = {};
 };
 
-struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; double* dreg = nullptr; };
+struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; double* dreg = nullptr;   // dreg: [workgroups][G][1 + KP] partial lambda changes
+                   size_t dreg_cap = 0; };
 
 struct fmx_context_s {
   fmx_config cfg;

@@ -1357,7 +1357,7 @@ k_sgda(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, cons
 // LEARNED regularisation 2 reg(g[,f]) theta per occurrence; the shadow gradient of a touched parameter becomes the sum of
 // its occurrences' gradients.  The lambda step of the batch: one wavefront per validation row (k_sgda_lambda) evaluates
 // sgd_lambda_step (:201-248 through predict_scaled :171-199) with the regularisation frozen at its batch-start values and
-// adds its changes to dreg with fp64 atomics; k_sgda_reg_update applies the sums, clamped at 0.
+// leaves its workgroup's summed changes in dpart; k_sgda_reg_update adds the partials in a fixed order, clamped at 0.
 // reg / dreg: [G][1 + KP] doubles, reg[g*(1+KP)] = reg_w(g), reg[g*(1+KP)+1+f] = reg_v(g,f).
 // ----------------------------------------------------------------------------------------------
 template <int KP, int U>
@@ -1425,57 +1425,106 @@ k_sgda_apply_seg(const SegWork sw, const Tab tb, Hyper h, const double* __restri
   }
 }
 
-// one wavefront (= one workgroup, LDS tables per group) per validation row; rows vpos0 .. vpos0 + n_rows - 1, cyclic
-template <int KP>
+// one wavefront (= one workgroup) per validation row at a time; rows vpos0 .. vpos0 + n_rows - 1, cyclic.  The workgroup SUMS the
+// changes of all its rows (registers when there is one attribute group, LDS tables per group otherwise) and leaves ONE partial
+// [G][1 + KP] in dpart[blockIdx.x]; k_sgda_reg_update adds the partials in a fixed order (deterministic; the first version added
+// every row's 1 + k changes to dreg with fp64 atomics -- 65 536 rows on 65 addresses: 0.85 ms of a 1.2 ms batch).
+// Entries are loaded one per lane and broadcast; U parameter rows and their gradient rows are in flight per lane.
+template <int KP, bool GROUPED>
 __global__ void __launch_bounds__(64)
 k_sgda_lambda(const Entry* __restrict__ vent, const uint64_t* __restrict__ vrow_ptr, const float* __restrict__ vtarget, uint32_t v_rows,
               uint32_t vpos0, uint32_t n_rows, const Tab tb, const float* __restrict__ gw, const float* __restrict__ gv, Hyper h,
-              const double* __restrict__ w0_ptr, const double* __restrict__ reg, double* __restrict__ dreg,
+              const double* __restrict__ w0_ptr, const double* __restrict__ reg, double* __restrict__ dpart,
               const uint32_t* __restrict__ grp, uint32_t G) {
-  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, U = 4;
   extern __shared__ double lam_lds[];
-  double* lwg = lam_lds;                       // [G]
-  double* sfg = lwg + G;                       // [G][KP]
-  double* sdfg = sfg + (size_t)G * KP;         // [G][KP]
+  double* lwg = lam_lds;                       // GROUPED: [G]         sum x w of the row, per group
+  double* sfg = lwg + G;                       //          [G][KP]     sum v x
+  double* sdfg = sfg + (size_t)G * KP;         //          [G][KP]     sum v' x v x
+  double* acc = sdfg + (size_t)G * KP;         //          [G][1 + KP] this workgroup's changes
   const uint32_t lane = threadIdx.x;
   const bool act = lane < LPR;
   const double w0 = h.k0 ? *w0_ptr : 0.0;
+  const uint32_t cells = G * (1 + KP);
+  double acc_w = 0.0, acc_v[VEC];              // !GROUPED: the same in registers (lane 0 / factor lanes)
+  double rg0 = 0.0, rgv[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; v++) { acc_v[v] = 0.0; rgv[v] = 0.0; }
+  if (!GROUPED) {
+    rg0 = reg[0];
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) rgv[v] = reg[1 + lane * VEC + v];
+    }
+  } else {
+    for (uint32_t c = lane; c < cells; c += 64) acc[c] = 0.0;
+  }
   for (uint32_t t = blockIdx.x; t < n_rows; t += gridDim.x) {
     const uint32_t r = (uint32_t)(((uint64_t)vpos0 + t) % v_rows);
     const uint64_t va = vrow_ptr[r];
     const uint32_t vsize = (uint32_t)(vrow_ptr[r + 1] - va);
     const double vy = (double)vtarget[r];
-    for (uint32_t c = lane; c < G; c += 64) lwg[c] = 0.0;
-    for (uint32_t c = lane; c < G * KP; c += 64) { sfg[c] = 0.0; sdfg[c] = 0.0; }
-    __syncthreads();
-    double plin = 0.0, q_dash = 0.0;
-    double s_dash[VEC];
+    if (GROUPED) {
+      for (uint32_t c = lane; c < G; c += 64) lwg[c] = 0.0;
+      for (uint32_t c = lane; c < G * KP; c += 64) { sfg[c] = 0.0; sdfg[c] = 0.0; }
+      __syncthreads();
+    }
+    double vpart = 0.0, lw = 0.0;              // per lane: share of (linear part - 0.5 sum (v' x)^2); sum x w (one group)
+    double s_dash[VEC], sf[VEC], sdf[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; v++) s_dash[v] = 0.0;
-    for (uint32_t i = 0; i < vsize; i++) {
-      const Entry e = vent[va + i];
-      const uint32_t g = grp ? grp[e.id] : 0u;
-      const double x = (double)e.value;
-      const double* rg = reg + (size_t)g * (1 + KP);
-      if (h.k1 && lane == 0) {
-        const double wv = (double)tb.w[(size_t)e.id * tb.ws];
-        plin += (wv - h.lr_d * ((double)gw[e.id] + 2 * rg[0] * wv)) * x;             // predict_scaled :178-184
-        lwg[g] += x * wv;                                                            // :215-218
+    for (int v = 0; v < VEC; v++) { s_dash[v] = 0.0; sf[v] = 0.0; sdf[v] = 0.0; }
+    for (uint32_t base = 0; base < vsize; base += 64) {
+      const uint32_t cnt = min(64u, vsize - base);
+      Entry en; en.id = 0; en.value = 0.f;
+      uint32_t gl = 0;
+      if (lane < cnt) {
+        en = load_stream8(vent + va + base + lane);
+        if (GROUPED) gl = grp ? grp[en.id] : 0u;
+        if (h.k1) {
+          const double x = (double)en.value;
+          const double wv = (double)tb.w[(size_t)en.id * tb.ws];
+          const double r0 = GROUPED ? reg[(size_t)gl * (1 + KP)] : rg0;
+          vpart += (wv - h.lr_d * ((double)gw[en.id] + 2 * r0 * wv)) * x;           // predict_scaled :178-184
+          if (GROUPED) unsafeAtomicAdd(lwg + gl, x * wv); else lw += x * wv;           // :215-218
+        }
       }
-      if (act) {
+      for (uint32_t i = 0; i < cnt; i += U) {
+        float vr[U][VEC], gr[U][VEC]; float xs[U]; uint32_t gs[U];
 #pragma unroll
-        for (int v = 0; v < VEC; v++) {
-          const size_t c = (size_t)g * KP + lane * VEC + v;
-          const double vv = (double)tb.V[(size_t)e.id * tb.rs + lane * VEC + v];
-          const double v_dash = vv - h.lr_d * ((double)gv[(size_t)e.id * tb.rs + lane * VEC + v] + 2 * rg[1 + lane * VEC + v] * vv);
-          const double d = v_dash * x;
-          s_dash[v] += d; q_dash += d * d;                                           // :186-196
-          sfg[c] += vv * x;                                                          // :233-238
-          sdfg[c] += d * vv * x;
+        for (int u = 0; u < U; u++) {
+          const uint32_t idx = i + u;
+          const uint32_t id = bcast_u32<1>(en.id, idx & 63u);
+          xs[u] = bcast_f32<1>(en.value, idx & 63u);
+          gs[u] = GROUPED ? bcast_u32<1>(gl, idx & 63u) : 0u;
+          if (idx < cnt && act) {
+            load_vec<VEC>(tb.V + (size_t)id * tb.rs + lane * VEC, vr[u]);
+            load_vec<VEC>(gv + (size_t)id * tb.rs + lane * VEC, gr[u]);
+          } else {
+            xs[u] = 0.f;
+#pragma unroll
+            for (int v = 0; v < VEC; v++) { vr[u][v] = 0.f; gr[u][v] = 0.f; }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (i + u >= cnt || !act) continue;
+          const double x = (double)xs[u];
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const double vv = (double)vr[u][v];
+            const double rv = GROUPED ? reg[(size_t)gs[u] * (1 + KP) + 1 + lane * VEC + v] : rgv[v];
+            const double v_dash = vv - h.lr_d * ((double)gr[u][v] + 2 * rv * vv);
+            const double d = v_dash * x;
+            s_dash[v] += d; vpart -= 0.5 * d * d;                                      // :186-196
+            if (GROUPED) {
+              const size_t c = (size_t)gs[u] * KP + lane * VEC + v;
+              sfg[c] += vv * x;                                                        // :233-238 (one lane per cell: no race)
+              sdfg[c] += d * vv * x;
+            } else { sf[v] += vv * x; sdf[v] += d * vv * x; }
+          }
         }
       }
     }
-    double vpart = plin - 0.5 * q_dash;
     if (act) {
 #pragma unroll
       for (int v = 0; v < VEC; v++) vpart += 0.5 * s_dash[v] * s_dash[v];
@@ -1484,30 +1533,56 @@ k_sgda_lambda(const Entry* __restrict__ vent, const uint64_t* __restrict__ vrow_
     double grad_loss;
     if (h.task == 0) { vp = fmin(h.max_d, vp); vp = fmax(h.min_d, vp); grad_loss = 2 * (vp - vy); }
     else grad_loss = vy * ((1.0 / (1.0 + exp(-vy * vp))) - 1.0);
-    __syncthreads();
-    for (uint32_t g = 0; g < G; g++) {
-      if (h.k1 && lane == 0) {
-        const double lw = lwg[g];
-        if (lw != 0.0) unsafeAtomicAdd(dreg + (size_t)g * (1 + KP), -h.lr_d * grad_loss * (-2 * h.lr_d * lw));   // :219-221
-      }
+    const double scale = -h.lr_d * grad_loss * (-2 * h.lr_d);
+    if (!GROUPED) {
+      lw = wave_sum_d(lw);
+      if (h.k1 && lane == 0) acc_w += scale * lw;                                    // :219-221
       if (act) {
 #pragma unroll
-        for (int v = 0; v < VEC; v++) {
-          const size_t c = (size_t)g * KP + lane * VEC + v;
-          const double a = sfg[c], b = sdfg[c];
-          if (a != 0.0 || b != 0.0)
-            unsafeAtomicAdd(dreg + (size_t)g * (1 + KP) + 1 + lane * VEC + v, -h.lr_d * grad_loss * (-2 * h.lr_d * (s_dash[v] * a - b)));   // :240-243
+        for (int v = 0; v < VEC; v++) acc_v[v] += scale * (s_dash[v] * sf[v] - sdf[v]);   // :240-243
+      }
+    } else {
+      __syncthreads();
+      for (uint32_t g = 0; g < G; g++) {
+        if (h.k1 && lane == 0) acc[(size_t)g * (1 + KP)] += scale * lwg[g];
+        if (act) {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const size_t c = (size_t)g * KP + lane * VEC + v;
+            acc[(size_t)g * (1 + KP) + 1 + lane * VEC + v] += scale * (s_dash[v] * sfg[c] - sdfg[c]);
+          }
         }
       }
+      __syncthreads();
     }
+  }
+  double* out = dpart + (size_t)blockIdx.x * cells;
+  if (!GROUPED) {
+    if (lane == 0) out[0] = acc_w;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) out[1 + lane * VEC + v] = acc_v[v];
+    }
+  } else {
     __syncthreads();
+    for (uint32_t c = lane; c < cells; c += 64) out[c] = acc[c];
   }
 }
-static __global__ void k_sgda_reg_update(double* __restrict__ reg, double* __restrict__ dreg, uint32_t cells, int KP, int k1) {
-  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += gridDim.x * blockDim.x) {
-    const bool is_w = (c % (uint32_t)(1 + KP)) == 0;
-    if (!is_w || k1) reg[c] = fmax(0.0, reg[c] + dreg[c]);          // :222, :245
-    dreg[c] = 0.0;
+// reg += sum over the workgroups' partials (fixed order), clamped at 0 (:222, :245)
+static __global__ void __launch_bounds__(256)
+k_sgda_reg_update(double* __restrict__ reg, const double* __restrict__ dpart, uint32_t n_part, uint32_t cells, int KP, int k1) {
+  __shared__ double red[256];
+  for (uint32_t c = blockIdx.x; c < cells; c += gridDim.x) {
+    double a = 0.0;
+    for (uint32_t p = threadIdx.x; p < n_part; p += 256) a += dpart[(size_t)p * cells + c];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+      const bool is_w = (c % (uint32_t)(1 + KP)) == 0;
+      if (!is_w || k1) reg[c] = fmax(0.0, reg[c] + red[0]);
+    }
+    __syncthreads();
   }
 }
 

@@ -670,8 +670,6 @@ int fmx_sgda_begin(fmx_handle h) {
   HIPCHK(h, hipMalloc(&h->sgda.gw, h->n_local * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->sgda.gv, nv * sizeof(float)));
   HIPCHK(h, hipMalloc(&h->sgda.reg, nreg * sizeof(double)));
-  HIPCHK(h, hipMalloc(&h->sgda.dreg, nreg * sizeof(double)));
-  HIPCHK(h, hipMemsetAsync(h->sgda.dreg, 0, nreg * sizeof(double), h->stream));
   HIPCHK(h, hipMemsetAsync(h->sgda.gw, 0, h->n_local * sizeof(float), h->stream));
   HIPCHK(h, hipMemsetAsync(h->sgda.gv, 0, nv * sizeof(float), h->stream));
   HIPCHK(h, hipMemsetAsync(h->sgda.reg, 0, nreg * sizeof(double), h->stream));
@@ -759,9 +757,18 @@ int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, 
   rc = ensure_scratch(h, Bc, 0);
   if (rc) return rc;
   const size_t G = h->num_groups, cells = G * (1 + (size_t)h->KP);
-  const size_t lds = (G + 2 * G * (size_t)h->KP) * sizeof(double);
+  const bool grouped = G > 1;                                    // one group: the row's tables and the workgroup's sums live in registers
+  const size_t lds = grouped ? (G + 2 * G * (size_t)h->KP + cells) * sizeof(double) : 0;
   if (do_lambda_steps && lds > 64 * 1024)
     return fail(h, FMX_E_UNSUPPORTED, "SGDA batch form: %zu attribute groups x %d factors need %zu bytes of LDS per validation row (limit 65536)", G, h->KP, lds);
+  // workgroups of the lambda step (one partial [G][1 + KP] each, summed in a fixed order by k_sgda_reg_update)
+  const uint32_t n_wg = (uint32_t)std::max<size_t>(64, std::min<size_t>(4096, ((size_t)8 << 20) / cells));
+  if (do_lambda_steps && h->sgda.dreg_cap < (size_t)n_wg * cells) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->sgda.dreg) { hipFree(h->sgda.dreg); h->sgda.dreg = nullptr; h->sgda.dreg_cap = 0; }
+    HIPCHK(h, hipMalloc(&h->sgda.dreg, (size_t)n_wg * cells * sizeof(double)));
+    h->sgda.dreg_cap = (size_t)n_wg * cells;
+  }
   hipStream_t st = h->stream;
   HIPCHK(h, hipEventRecord(h->ev0, st));
   uint64_t vpos = 0, batches = 0;                                // validation->data->begin() at the start of the epoch (:266)
@@ -781,11 +788,15 @@ int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, 
                                          (const double*)h->sgda.reg, (const uint32_t*)h->grp, h->sgda.gw, h->sgda.gv));
     }
     if (do_lambda_steps && v.n_rows) {
-      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda_lambda<KP>), dim3(std::min<uint32_t>(nb, 8192)), dim3(64), lds, st, v.ent, v.row_ptr, v.target,
+      const uint32_t wg = std::min<uint32_t>(nb, n_wg);
+      if (grouped) { KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda_lambda<KP, true>), dim3(wg), dim3(64), lds, st, v.ent, v.row_ptr, v.target,
                                             v.n_rows, (uint32_t)vpos, nb, h->tb, (const float*)h->sgda.gw, (const float*)h->sgda.gv, hy,
-                                            (const double*)h->w0, (const double*)h->sgda.reg, h->sgda.dreg, (const uint32_t*)h->grp, (uint32_t)G));
-      hipLaunchKernelGGL(k_sgda_reg_update, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, h->sgda.reg, h->sgda.dreg, (uint32_t)cells,
-                         h->KP, h->cfg.k1);
+                                            (const double*)h->w0, (const double*)h->sgda.reg, h->sgda.dreg, (const uint32_t*)h->grp, (uint32_t)G)); }
+      else         { KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sgda_lambda<KP, false>), dim3(wg), dim3(64), 0, st, v.ent, v.row_ptr, v.target,
+                                            v.n_rows, (uint32_t)vpos, nb, h->tb, (const float*)h->sgda.gw, (const float*)h->sgda.gv, hy,
+                                            (const double*)h->w0, (const double*)h->sgda.reg, h->sgda.dreg, (const uint32_t*)h->grp, (uint32_t)G)); }
+      hipLaunchKernelGGL(k_sgda_reg_update, dim3((unsigned)std::min<size_t>(cells, 1024)), dim3(256), 0, st, h->sgda.reg, (const double*)h->sgda.dreg,
+                         wg, (uint32_t)cells, h->KP, h->cfg.k1);
       vpos = (vpos + nb) % v.n_rows;
     }
     HIPCHK(h, hipGetLastError());
