@@ -832,8 +832,11 @@ struct SegWork {
 // PRE2 (the deferred list, where every feature has >= 2 occurrences): the SECOND occurrence's descriptor, multiplier and S row
 // are fetched in the same pipelined rounds as the first instead of in the serial tail loop (entry -> multiplier -> S row, three
 // dependent gathers per segment) -- same operations in the same order, the loop only starts at the third occurrence.
-template <int KP, int U, int SPW = 64, bool PRE2 = (SPW < 64)>
-__device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk, const Tab tb, const Hyper& h) {
+// SGDA (fm_learn_sgd_element_adapt_reg, batch form): the regularisation is the learned per-group table (2 reg(g) theta, :155-163)
+// and the gradient sums of the step are kept for the lambda step (gw, gv: :153, :161).
+struct SgdaExtra { const double* reg; const uint32_t* grp; float* gw; float* gv; };
+template <int KP, int U, int SPW = 64, bool PRE2 = (SPW < 64), bool SGDA = false>
+__device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk, const Tab tb, const Hyper& h, const SgdaExtra sx = SgdaExtra{}) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const TEntry* __restrict__ t_ent = sw.t_ent;
@@ -906,16 +909,35 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
         }
         const float nocc = (float)(b - a);
         float nv[VEC];
+        if constexpr (SGDA) {
+          const double* rg = sx.reg + (size_t)(sx.grp ? sx.grp[j] : 0u) * (1 + KP);
+          float sh[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; v++) {
-          const float vv = v0[u][v];
-          nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
-        }
-        store_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
-        if (h.k1 && f == 0) {
-          float* pw = tb.w + (size_t)j * tb.ws;
-          const float wv = *pw;
-          *pw = wv - h.lr * (Gw + nocc * h.regw * wv);
+          for (int v = 0; v < VEC; v++) {
+            const float vv = v0[u][v];
+            sh[v] = G[v] - vv * A;                               // sum over the occurrences of mult x (S_f - v x)  (:161)
+            nv[v] = vv - h.lr * (sh[v] + nocc * 2.0f * (float)rg[1 + f * VEC + v] * vv);
+          }
+          store_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
+          store_vec<VEC>(sx.gv + (size_t)j * tb.rs + f * VEC, sh);
+          if (h.k1 && f == 0) {
+            float* pw = tb.w + (size_t)j * tb.ws;
+            const float wv = *pw;
+            sx.gw[j] = Gw;                                       // :153
+            *pw = wv - h.lr * (Gw + nocc * 2.0f * (float)rg[0] * wv);
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const float vv = v0[u][v];
+            nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
+          }
+          store_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
+          if (h.k1 && f == 0) {
+            float* pw = tb.w + (size_t)j * tb.ws;
+            const float wv = *pw;
+            *pw = wv - h.lr * (Gw + nocc * h.regw * wv);
+          }
         }
       }
     }
@@ -1364,65 +1386,10 @@ template <int KP, int U>
 __global__ void __launch_bounds__(256)
 k_sgda_apply_seg(const SegWork sw, const Tab tb, Hyper h, const double* __restrict__ reg, const uint32_t* __restrict__ grp,
                  float* __restrict__ gw, float* __restrict__ gv) {
-  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
-  const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  const TEntry* __restrict__ t_ent = sw.t_ent;
-  const float* __restrict__ S = sw.S;
-  const float* __restrict__ mult = sw.mult;
-  for (uint32_t blk = wave0 * 64u; blk < sw.nseg; blk += nwaves * 64u) {
-    const uint32_t cnt = min(64u, sw.nseg - blk);
-    uint32_t jl = 0, al = 0, bl = 0;
-    if (lane < cnt) {
-      const uint32_t s = blk + lane;
-      jl = sw.seg_feat[s];
-      al = sw.seg_rel[s];
-      bl = (s + 1 < sw.nseg_batch) ? sw.seg_rel[s + 1] : sw.batch_nnz;
-    }
-    for (uint32_t i = 0; i < cnt; i += EPI * U) {
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t idx = i + u * EPI + g;
-        const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
-        const uint32_t a = bcast_u32<EPI>(al, idx & 63u);
-        const uint32_t b = bcast_u32<EPI>(bl, idx & 63u);
-        if (idx < cnt) {
-          float v0[VEC], G[VEC]; float A = 0.f, Gw = 0.f;
-          load_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, v0);
-#pragma unroll
-          for (int v = 0; v < VEC; v++) G[v] = 0.f;
-          for (uint32_t i2 = a; i2 < b; i2++) {                 // every occurrence of the feature in this batch
-            const TEntry t2 = t_ent[i2];
-            const float mx = mult[t2.e] * t2.x;
-            float s2[VEC];
-            load_vec<VEC>(S + (size_t)t2.e * KP + f * VEC, s2);
-#pragma unroll
-            for (int v = 0; v < VEC; v++) G[v] = fmaf(mx, s2[v], G[v]);
-            A = fmaf(mx, t2.x, A); Gw += mx;
-          }
-          const uint32_t gg = grp ? grp[j] : 0u;
-          const double* rg = reg + (size_t)gg * (1 + KP);
-          const float nocc = (float)(b - a);
-          float nv[VEC], sh[VEC];
-#pragma unroll
-          for (int v = 0; v < VEC; v++) {
-            const float vv = v0[v];
-            sh[v] = G[v] - vv * A;                               // sum over the occurrences of mult x (S_f - v x)  (:161)
-            nv[v] = vv - h.lr * (sh[v] + nocc * 2.0f * (float)rg[1 + f * VEC + v] * vv);
-          }
-          store_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
-          store_vec<VEC>(gv + (size_t)j * tb.rs + f * VEC, sh);
-          if (h.k1 && f == 0) {
-            float* pw = tb.w + (size_t)j * tb.ws;
-            const float wv = *pw;
-            gw[j] = Gw;                                          // :153
-            *pw = wv - h.lr * (Gw + nocc * 2.0f * (float)rg[0] * wv);
-          }
-        }
-      }
-    }
-  }
+  const SgdaExtra sx{reg, grp, gw, gv};
+  for (uint32_t blk = wave0 * 64u; blk < sw.nseg; blk += nwaves * 64u) apply_seg_block<KP, U, 64, false, true>(sw, blk, tb, h, sx);
 }
 
 // one wavefront (= one workgroup) per validation row at a time; rows vpos0 .. vpos0 + n_rows - 1, cyclic.  The workgroup SUMS the

@@ -784,7 +784,7 @@ int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, 
     const uint64_t base = s.batch_base[bi];
     if (s1 > s0) {
       SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, nullptr, s1 - s0, s1 - s0, (uint32_t)(s.batch_base[bi + 1] - base), S, h->mult};
-      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_sgda_apply_seg<KP, 4>), ((uint64_t)(s1 - s0) + 63) / 64, st, sw, h->tb, hy,
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_sgda_apply_seg<KP, 8>), ((uint64_t)(s1 - s0) + 63) / 64, st, sw, h->tb, hy,
                                          (const double*)h->sgda.reg, (const uint32_t*)h->grp, h->sgda.gw, h->sgda.gv));
     }
     if (do_lambda_steps && v.n_rows) {
