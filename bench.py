@@ -300,7 +300,7 @@ def main():
         drv = _Drv()
 
         def step(timed):
-            h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, args.w0_chunk, lib_flags, lib_lag)
+            h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, args.w0_chunk, lib_flags, lib_lag)
         bias_lag = lib_lag
         rows_per_launch = min(batch, args.rows)
         kind = "apply"

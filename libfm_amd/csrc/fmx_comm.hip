@@ -400,7 +400,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     if (cur->slots[slot].n_rows != g->hs[0]->slots[slot].n_rows) return gfail(g, FMX_E_STATE, "the shards hold different numbers of rows in slot %d", slot);
   }
   fmx_sgd_opts opts = *opts_in;
-  if (opts.apply == FMX_APPLY_FUSED || opts.apply == FMX_APPLY_DEFAULT) { opts.apply = FMX_APPLY_SEGMENTED; }
+  if (opts.apply == FMX_APPLY_FUSED) opts.apply = FMX_APPLY_DEFAULT;             // the split step's own choice (sgd_finish_impl)
   if (opts_in->apply == FMX_APPLY_FUSED) opts.flags |= FMX_FLAG_BIAS_LAG;       // FUSED implies the lag on one device: same rule here
   const bool pipeline = (opts.flags & FMX_FLAG_PIPELINE) != 0;
   const uint32_t n_rows = g->hs[0]->slots[slot].n_rows;

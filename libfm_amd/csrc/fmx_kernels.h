@@ -970,11 +970,14 @@ k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
 //       not fit the register path): those entries are NOT written here (their rows keep the batch-start value for
 //       every reader); the example leaves its factor sums S_e and multiplier behind and k_apply_seg finishes exactly
 //       those features afterwards (one owner per feature, all occurrences summed).  Bit-for-bit the batch rule.
+//   FUSED_APPLY : the second half of that for the SPLIT step (a feature shard after the exchange, the two-pass form): the
+//       complete sums S_e and the multiplier are GIVEN (S_out / mult_out are read), nothing is predicted; the rows of the
+//       batch-unique features are gathered, updated and written back, the others are left to k_apply_seg as above.
 // ----------------------------------------------------------------------------------------------
 #ifndef FMX_FUSED_MIN_WAVES
 #define FMX_FUSED_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
-enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2 };
+enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2, FUSED_APPLY = 3 };
 constexpr int FUSED_PREV_SPW = 16;     // segments per claimed block of the deferred-feature work
 // FUSED_EXACT, what the launch of batch b carries along: the deferred features of batch b-1 (SegWork `prev`, n_items
 // blocks of 64 segments) are finished INSIDE this launch instead of by a kernel of their own between the two batches --
@@ -998,7 +1001,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
         const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out, const FusedPrev fp) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
-  constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), EXACT = (VAR == FUSED_EXACT);
+  constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), EXACT = (VAR == FUSED_EXACT), APPLY = (VAR == FUSED_APPLY), MASKED = EXACT || APPLY;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
@@ -1053,9 +1056,9 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
     const uint64_t a = row_ptr[row0 + e];
     const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
     const Entry* __restrict__ row = ent + a;
-    const float y = target[row0 + e];
+    const float y = APPLY ? 0.f : target[row0 + e];
     uint64_t cm = 0;
-    if constexpr (EXACT) cm = cmask[row0 + e];
+    if constexpr (MASKED) cm = cmask[row0 + e];
     if (size <= (uint32_t)(ZR * EPI) && size <= 64u) {
       Entry en; en.id = 0; en.value = 0.f;
       float wv = 0.f;
@@ -1073,7 +1076,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       for (int t = 0; t < ZR; t++) {
         const uint32_t idx = t * EPI + g;
         const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
-        if (idx < size) {
+        if (idx < size) {                                      // (APPLY: deferred rows are gathered too -- 4 % of them; a test per row slot costs more)
           load_row<VEC, 1>(tb.V + (size_t)id * tb.rs + f * VEC, vr[t]);
         } else {
 #pragma unroll
@@ -1082,6 +1085,11 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       }
       // phase B: sums (fm_model.h:116-125); lanes >= size hold value 0, so no guard is needed on x
       float sum[VEC]; float sq = 0.f;
+      float mult;
+      if constexpr (APPLY) {                                   // complete sums and multiplier of the example: given
+        load_vec<VEC>(S_out + (size_t)e * KP + f * VEC, sum);
+        mult = mult_out[e];
+      } else {
 #pragma unroll
       for (int v = 0; v < VEC; v++) sum[v] = 0.f;
 #pragma unroll
@@ -1105,14 +1113,15 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       }
       const float rest = wave_sum_dpp(part);
       if (lane == 0) rest_out[e] = rest;
-      const float mult = multiplier(h, w0s + rest, y);
+      mult = multiplier(h, w0s + rest, y);
+      }
       if constexpr (EXACT) {
         if (cm != 0) {                                         // some feature of this example is finished by k_apply_seg
           if (lane < LPR) store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
           if (lane == 0) mult_out[e] = mult;
         }
       }
-      if (h.k1 && lane < size && !(EXACT && ((cm >> lane) & 1ull))) {             // fm_sgd.h:38-43
+      if (h.k1 && lane < size && !(MASKED && ((cm >> lane) & 1ull))) {            // fm_sgd.h:38-43
         const float dw = -h.lr * (mult * en.value + h.regw * wv);
         if (ATOMIC) unsafeAtomicAdd(tb.w + (size_t)en.id * tb.ws, dw); else tb.w[(size_t)en.id * tb.ws] = wv + dw;
       }
@@ -1122,7 +1131,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         const uint32_t idx = t * EPI + g;
         const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
         const float x = bcast_f32<EPI>(en.value, idx & 63u);
-        if (idx < size && !(EXACT && ((cm >> (idx & 63u)) & 1ull))) {
+        if (idx < size && !(MASKED && ((cm >> (idx & 63u)) & 1ull))) {
           float* pv = tb.V + (size_t)id * tb.rs + f * VEC;
           float nv[VEC];
 #pragma unroll
@@ -1135,7 +1144,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
           if (!ATOMIC) store_row<VEC, 2>(pv, nv);
         }
       }
-    } else {
+    } else if constexpr (!APPLY) {                             // (APPLY: such a row is deferred as a whole, cm == ~0)
       float sum[VEC], sq, lin;
       row_sums<KP, 8>(row, size, tb, h.k1, sum, sq, lin);
 #pragma unroll

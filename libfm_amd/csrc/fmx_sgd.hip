@@ -326,10 +326,28 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
                : launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
   if (rc) return rc;
   int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
+  // split step, library's choice (DEFAULT / FUSED): the features that occur once in the batch are written back example-major
+  // (k_fused<FUSED_APPLY>: the wavefront holds S_e, no gather per occurrence), the others by their owner (k_apply_seg over the
+  // batch's cseg list) -- the second half of what k_fused<EXACT> + k_apply_seg do in one pass on an unsharded handle.
+  // FMX_APPLY_SEGMENTED keeps the dense owner-per-feature pass.  FMX_SPLIT_DENSE=1: A/B knob (dense pass for DEFAULT too).
+  static const bool split_dense = getenv("FMX_SPLIT_DENSE") && atoi(getenv("FMX_SPLIT_DENSE"));
+  const bool masked = (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) && s.cmask && !s.cbatch.empty() && !split_dense;
   if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) apply = FMX_APPLY_SEGMENTED;   // split step: same rule, two passes
   if (apply == FMX_APPLY_SEGMENTED && seg_batch < 0) return fail(h, FMX_E_STATE, "segmented apply needs batch-aligned rows");
   if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
-  if (apply == FMX_APPLY_SEGMENTED) {
+  if (apply == FMX_APPLY_SEGMENTED && masked) {
+    const size_t b = (size_t)seg_batch;
+    KP_SWITCH(h->KP, rc = (launch_fused_zr<KP, FUSED_APPLY>(h, s, hy, row0, n_rows, st, (const double*)h->w0, nullptr,
+                                                               (const uint64_t*)s.cmask, const_cast<float*>(S), h->mult)));
+    if (rc) return rc;
+    const uint32_t c0 = s.cbatch[b], c1 = s.cbatch[b + 1];
+    if (c1 > c0) {
+      const uint32_t s0 = s.batch_seg[b], s1 = s.batch_seg[b + 1];
+      const uint64_t base = s.batch_base[b];
+      SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, s.cseg + c0, c1 - c0, s1 - s0, (uint32_t)(s.batch_base[b + 1] - base), S, h->mult};
+      KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 16>), ((uint64_t)sw.nseg + 15) / 16, st, sw, h->tb, hy));
+    }
+  } else if (apply == FMX_APPLY_SEGMENTED) {
     const uint32_t s0 = s.batch_seg[(size_t)seg_batch], s1 = s.batch_seg[(size_t)seg_batch + 1];
     const uint64_t base = s.batch_base[(size_t)seg_batch];
     const uint32_t bnnz = (uint32_t)(s.batch_base[(size_t)seg_batch + 1] - base);
