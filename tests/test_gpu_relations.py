@@ -65,9 +65,10 @@ def test_kept_blocks_predict_like_the_expanded_rows(oracle):
     h.close()
 
 
-@pytest.mark.parametrize("keep", [True, False])
+@pytest.mark.parametrize("keep,split", [(True, False), (False, False), (True, True), (False, True)])
 @pytest.mark.parametrize("name", CASES)
-def test_als_on_relations_matches_reference(oracle, name, keep):
+def test_als_on_relations_matches_reference(oracle, name, keep, split, monkeypatch):
+    monkeypatch.setenv("FMX_ALS_SPLIT_MIN", "1" if split else "0")   # main features: split / fused form of the draws
     from libfm_amd import data as D
     from libfm_amd import learner as L
     g = Golden(name)
