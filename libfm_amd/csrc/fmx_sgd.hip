@@ -331,7 +331,10 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
   // batch's cseg list) -- the second half of what k_fused<EXACT> + k_apply_seg do in one pass on an unsharded handle.
   // FMX_APPLY_SEGMENTED keeps the dense owner-per-feature pass.  FMX_SPLIT_DENSE=1: A/B knob (dense pass for DEFAULT too).
   static const bool split_dense = getenv("FMX_SPLIT_DENSE") && atoi(getenv("FMX_SPLIT_DENSE"));
-  const bool masked = (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) && s.cmask && !s.cbatch.empty() && !split_dense;
+  // ... where rows are long enough to fill a wavefront's gather: measured per rank of a P-way sharded step (scripts/gpu_shard_probe.py,
+  // dense vs example-major second pass): 32 entries per row +5 %, 16 entries -4 %, 8 entries -18 %, 4 entries -17 %.
+  const bool masked = (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) && s.cmask && !s.cbatch.empty() && !split_dense &&
+                      s.nnz >= (uint64_t)24 * s.n_rows;
   if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) apply = FMX_APPLY_SEGMENTED;   // split step: same rule, two passes
   if (apply == FMX_APPLY_SEGMENTED && seg_batch < 0) return fail(h, FMX_E_STATE, "segmented apply needs batch-aligned rows");
   if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
