@@ -388,6 +388,32 @@ def test_odd_k_and_long_rows(capi, oracle, k):
     h.close()
 
 
+@pytest.mark.parametrize("k,nnz", [(3, 12), (20, 12), (100, 12), (200, 12), (256, 9), (64, 40), (32, 33)])
+def test_batch_rule_register_paths_at_every_row_width(capi, oracle, k, nnz):
+    """short rows (they fit the register path) at every padded factor count (KP = 4 .. 256: 1, 2 or 4 floats per lane, several
+    entries per load instruction below KP = 64): the one-pass form (k_fused<EXACT> + deferred list), the split step's second
+    pass (k_fused<APPLY>, rows of >= 24 entries) and the dense owner pass, all against the oracle's rule."""
+    n, rows, batch, chunk, lag = 3000, 700, 100, 10, 2
+    ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed=400 + k, zipf=1.05)
+    d = oracle.Data(ent, rp, y)
+    for apply_, flags in ((capi.APPLY_FUSED, 0), (capi.APPLY_DEFAULT, capi.FLAG_BIAS_LAG), (capi.APPLY_SEGMENTED, capi.FLAG_BIAS_LAG)):
+        m = oracle.Model(n, k, True, True, 0.0, 0.001, 0.002)
+        m.v[:] = oracle.init_values(11, n, k, 0.05)
+        m.w[:] = oracle.init_values(12, n, 1, 0.05)[0]
+        m.w0 = -0.05
+        h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.001, 0.002, 0.01, -1.0, 1.0)
+        h.set_params(m.w0, m.w, m.v)
+        h.upload_rows(0, ent, rp, y)
+        for _ in range(2):
+            h.sgd_epoch(0, capi.SGD_MINIBATCH, apply_, batch, chunk, flags, lag)
+            oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, batch, chunk, bias_lag=lag)
+        w0, w, v = h.get_params()
+        assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+        np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+        h.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # synthetic workload + device init: integer work is bit-exact against the oracle's definition
 # ---------------------------------------------------------------------------------------------
