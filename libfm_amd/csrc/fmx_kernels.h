@@ -977,7 +977,7 @@ k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
 #ifndef FMX_FUSED_MIN_WAVES
 #define FMX_FUSED_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
-enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2, FUSED_APPLY = 3 };
+enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2, FUSED_APPLY = 3, FUSED_EXACT_MERGED = 4 };   // 4: EXACT + FusedPrev (FMX_FUSED_MERGE)
 constexpr int FUSED_PREV_SPW = 16;     // segments per claimed block of the deferred-feature work
 // FUSED_EXACT, what the launch of batch b carries along: the deferred features of batch b-1 (SegWork `prev`, n_items
 // blocks of 64 segments) are finished INSIDE this launch instead of by a kernel of their own between the two batches --
@@ -1001,13 +1001,14 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
         const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out, const FusedPrev fp) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
-  constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), EXACT = (VAR == FUSED_EXACT), APPLY = (VAR == FUSED_APPLY), MASKED = EXACT || APPLY;
+  constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), PREV = (VAR == FUSED_EXACT_MERGED), EXACT = (VAR == FUSED_EXACT) || PREV,
+                 APPLY = (VAR == FUSED_APPLY), MASKED = EXACT || APPLY;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   const float w0s = h.k0 ? (float)(*w0_ptr) : 0.f;
   bool prev_done = true;
-  if constexpr (EXACT) {
+  if constexpr (PREV) {
     if (fp.n_items) {
       // blocks of the previous batch's deferred features, claimed 4 at a time by a WORKGROUP (one returning atomic per
       // claim, and none once the counter is exhausted: 10 000 wavefronts hitting one word at launch start cost more than
@@ -1040,7 +1041,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
   }
   for (uint32_t q = wave0; q < n_rows; q += nwaves) {
     uint32_t e = q;
-    if constexpr (EXACT) {
+    if constexpr (PREV) {
       if (fp.order) e = fp.order[q];
       if (!prev_done && q >= fp.n_indep) {                     // first dependent example of this wavefront
         uint32_t done = 0;

@@ -490,7 +490,8 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       fp.order = s.order + row0;
       *deferred += fp.prev.nseg;
     }
-    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, &fp); });
+    if (merged) { KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT_MERGED>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, &fp); }); }
+    else        { KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, nullptr); }); }
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
