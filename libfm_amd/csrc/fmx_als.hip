@@ -452,7 +452,7 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
     if (!a.vt || !s.nseg) continue;
     HIPCHK(h, hipSetDevice(h->device));
     KP_SWITCH(h->KP, hipLaunchKernelGGL((k_als_shadow<KP, true>), dim3(std::min<uint32_t>((s.nseg + 63) / 64, 4096)), dim3(256), 0, h->stream,
-                                          a.level_list, s.seg_feat, s.nseg, h->tb, a.vt, a.vt_stride));
+                                          a.level_list, s.seg_feat, s.nseg, h->tb, a.vt, a.vt_stride, (uint32_t)h->cfg.num_factor));
   }
   for (int f = 0; f < kf; f++) {                            // per factor: q_f is ready (k_als_eterms), draw_v per level :528-595
     for (fmx_handle x : hs) {
@@ -468,7 +468,7 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
     HIPCHK(h, hipSetDevice(h->device));
     if (a.vt && s.nseg)
       KP_SWITCH(h->KP, hipLaunchKernelGGL((k_als_shadow<KP, false>), dim3(std::min<uint32_t>((s.nseg + 63) / 64, 4096)), dim3(256), 0, h->stream,
-                                            a.level_list, s.seg_feat, s.nseg, h->tb, a.vt, a.vt_stride));
+                                            a.level_list, s.seg_feat, s.nseg, h->tb, a.vt, a.vt_stride, (uint32_t)h->cfg.num_factor));
     if (kf > 0) {                                          // empty-row draws of every factor (:586-595) in one pass
       hipStream_t st = h->stream;
       KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_als_unseen_v<KP>), (h->n_local + Map<KP>::EPI - 1) / Map<KP>::EPI, st, a.seen, h->n_local,

@@ -368,7 +368,7 @@ __device__ __forceinline__ void als_param_store(float* p, float v) {
 template <int KP, bool PACK>
 __global__ void __launch_bounds__(256)
 k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict__ seg_feat, uint32_t nseg, const Tab tb,
-             float* __restrict__ vt, size_t vt_stride) {
+             float* __restrict__ vt, size_t vt_stride, uint32_t k /* rows of vt: num_factor (<= KP) */) {
   __shared__ float tile[64][KP + 1];                            // [position in block][factor], padded against bank conflicts
   const uint32_t tid = threadIdx.x;
   for (uint32_t p0 = blockIdx.x * 64u; p0 < nseg; p0 += gridDim.x * 64u) {
@@ -379,19 +379,19 @@ k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict
         tile[r][f] = tb.V[(size_t)seg_feat[level_list[p0 + r]] * tb.rs + f];
       }
       __syncthreads();
-      for (uint32_t i = tid; i < (uint32_t)KP * 64u; i += 256) {  // per factor 64 consecutive positions
+      for (uint32_t i = tid; i < k * 64u; i += 256) {             // per factor 64 consecutive positions
         const uint32_t f = i / 64u, r = i % 64u;
         if (r < np) vt[(size_t)f * vt_stride + p0 + r] = tile[r][f];
       }
     } else {
-      for (uint32_t i = tid; i < (uint32_t)KP * 64u; i += 256) {
+      for (uint32_t i = tid; i < k * 64u; i += 256) {
         const uint32_t f = i / 64u, r = i % 64u;
         if (r < np) tile[r][f] = vt[(size_t)f * vt_stride + p0 + r];
       }
       __syncthreads();
       for (uint32_t i = tid; i < np * KP; i += 256) {
         const uint32_t r = i / KP, f = i % KP;
-        tb.V[(size_t)seg_feat[level_list[p0 + r]] * tb.rs + f] = tile[r][f];
+        if (f < k) tb.V[(size_t)seg_feat[level_list[p0 + r]] * tb.rs + f] = tile[r][f];   // (the padding columns stay zero)
       }
     }
     __syncthreads();
