@@ -151,3 +151,85 @@ def test_random_shape_feature_shards(capi, oracle, seed):
     grp.close()
     for h in hs:
         h.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shape_sgda_both_forms(capi, oracle, seed):
+    """fm_learn_sgd_element_adapt_reg on random shapes (odd factor counts, 1 .. 4 attribute groups): the device learner in
+    reference order against the restated online loop, the batch form against its restated rule."""
+    n, k, task, (ent, rp, y), batch, chunk, _, _, _ = _case(400 + seed)
+    k = min(k, 65)
+    rng = np.random.default_rng(500 + seed)
+    G = int(rng.integers(1, 5))
+    group = None if G == 1 else rng.integers(0, G, n).astype(np.uint32)
+    if group is not None:
+        group[:G] = np.arange(G)                               # every group is used
+    lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
+    lr = 0.002
+    rows = len(y)
+    n_val = max(20, rows // 3)
+    va_rp = rp[:n_val + 1].copy()
+    tr, va = oracle.Data(ent, rp, y), oracle.Data(ent[:int(va_rp[-1])].copy(), va_rp, y[:n_val].copy())
+    for b in (None, batch):                                    # None: the reference's online order
+        m = oracle.Model(n, k, True, True, 0.0, 0.0, 0.0)
+        m.v[:] = oracle.init_values(51 + seed, n, k, 0.05)
+        h = capi.Handle(n, k, True, True, task, 0.0, 0.0, 0.0, lr, lo, hi)
+        h.set_params(m.w0, m.w, m.v)
+        if group is not None:
+            h.set_groups(group)
+        h.upload_rows(0, tr.entries, tr.row_ptr, tr.target)
+        h.upload_rows(1, va.entries, va.row_ptr, va.target)
+        h.sgda_begin()
+        for i in range(3):
+            if b is None:
+                h.sgda_epoch(0, 1, i > 0)
+            else:
+                h.sgda_epoch_minibatch(0, 1, i > 0, b, chunk)
+        reg = h.sgda_get_reg()
+        w0, w, v = h.get_params()
+        h.sgda_end()
+        h.close()
+        st = oracle.sgda_learn(m, tr, va, task, lr, lo, hi, 3, group, batch=b, w0_chunk=chunk)
+        what = "seed %d batch %s: n=%d k=%d task=%d G=%d chunk=%d" % (seed, b, n, k, task, G, chunk)
+        assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 2e-5, what
+        np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5, err_msg=what)
+        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5, err_msg=what)
+        np.testing.assert_allclose(reg[:, 0], st.reg_w, rtol=1e-3, atol=1e-7, err_msg=what)
+        np.testing.assert_allclose(reg[:, 1:1 + k], st.reg_v[:, :k], rtol=1e-3, atol=1e-7, err_msg=what)
+
+
+@pytest.mark.parametrize("k,seed", [(1, 0), (5, 1), (33, 2), (70, 3)])
+def test_kept_blocks_equal_joined_rows_at_odd_factor_counts(capi, oracle, k, seed, monkeypatch):
+    """`-relation` blocks kept apart (per-block-row caches) against the device join, ALS and a sampled chain, factor counts that
+    are not their own padding; main features in the split and in the fused form of the draws."""
+    from libfm_amd import data as D
+    from libfm_amd import learner as L
+    import io
+    (ent, rp, y), blocks, maps = datagen.block_structured(30, 20, 250, seed=60 + seed)
+    n_main = 7
+    _, _, offs = datagen.expand_blocks(ent, rp, blocks, maps, n_main)
+    n = offs[-1] + blocks[-1][2]
+    res = []
+    for keep, split, sample in ((True, "0", False), (False, "0", False), (True, "1", False), (True, "0", True), (False, "1", True)):
+        monkeypatch.setenv("FMX_ALS_SPLIT_MIN", split)
+        fm = L.FMModel()
+        fm.num_attribute, fm.num_factor = n, k
+        fm.w0, fm.w, fm.v = 0.0, oracle.init_values(71, n, 1, 0.1)[0].copy(), oracle.init_values(72, n, k, 0.1).copy()
+        l = L.FMLearnALS()
+        l.fm, l.task, l.num_iter, l.min_target, l.max_target = fm, 0, 3, float(y.min()), float(y.max())
+        l.w_lambda, l.v_lambda, l.do_sample, l.seed = 1.5, 4.0, sample, 9
+        l.out = io.StringIO()
+        train = L.Data(ent, rp, y)
+        for (be, bp, nf), mp, off in zip(blocks, maps, offs):
+            train.add_relation(D.Relation(be, bp, nf), mp, off)
+        train.keep_blocks = keep
+        l.init()
+        l.learn(train, train)
+        res.append((sample, l.fm.w0, l.fm.w.copy(), l.fm.v.copy()))
+        l.close()
+    for sample in (False, True):
+        same = [r for r in res if r[0] == sample]
+        for other in same[1:]:
+            assert abs(other[1] - same[0][1]) <= RTOL * abs(same[0][1]) + 2e-5
+            np.testing.assert_allclose(other[2], same[0][2], rtol=RTOL, atol=5e-5)
+            np.testing.assert_allclose(other[3], same[0][3], rtol=RTOL, atol=5e-5)
