@@ -233,3 +233,52 @@ def test_kept_blocks_equal_joined_rows_at_odd_factor_counts(capi, oracle, k, see
             assert abs(other[1] - same[0][1]) <= RTOL * abs(same[0][1]) + 2e-5
             np.testing.assert_allclose(other[2], same[0][2], rtol=RTOL, atol=5e-5)
             np.testing.assert_allclose(other[3], same[0][3], rtol=RTOL, atol=5e-5)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shape_sharded_als(capi, oracle, seed):
+    """fm_learn_mcmc over 2 .. 4 feature shards (global dependency levels, one all-reduce per (family, level)) on random shapes:
+    ALS against the oracle, and a sampled chain against the chain one handle draws with the same seed."""
+    n, k, task, (ent, rp, y), _, _, _, k0, k1 = _case(600 + seed, als=True)
+    k = min(k, 33)
+    rng = np.random.default_rng(700 + seed)
+    world, shard_hash = int(rng.integers(2, 5)), int(rng.integers(0, 2))
+    lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
+    wl, vl = float(rng.uniform(0.5, 3.0)), float(rng.uniform(1.0, 10.0))
+    d = oracle.Data(ent, rp, y)
+    init_v, init_w = oracle.init_values(81 + seed, n, k, 0.1), oracle.init_values(82 + seed, n, 1, 0.1)[0]
+
+    def run(world, do_sample):
+        hs = [capi.Handle(n, k, k0, k1, task, 0.0, wl, vl, 0.0, lo, hi, device=0, shard_rank=r, shard_world=world,
+                          shard_hash=shard_hash) for r in range(world)]
+        for h in hs:
+            h.set_params(0.0, init_w if k1 else np.zeros(n), init_v)
+            h.upload_rows(0, ent, rp, y)
+        grp = capi.Group(hs) if world > 1 else None
+        drv = grp if grp else hs[0]
+        drv.als_begin(0)
+        for _ in range(3):
+            drv.als_sweep(wl, vl, do_sample=do_sample, seed=5)
+        drv.als_end()
+        out = grp.get_params() if grp else hs[0].get_params()
+        if grp:
+            grp.close()
+        for h in hs:
+            h.close()
+        return out
+
+    m = oracle.Model(n, k, k0, k1, 0.0, wl, vl)
+    m.v[:] = init_v
+    if k1:
+        m.w[:] = init_w
+    te = oracle.Data(ent[:int(rp[20])].copy(), rp[:21].copy(), y[:20].copy())
+    oracle.als_learn(m, d, te, task, 3, wl, vl, lo, hi)
+    what = "seed %d: world=%d hash=%d n=%d k=%d task=%d k0=%d k1=%d" % (seed, world, shard_hash, n, k, task, k0, k1)
+    w0, w, v = run(world, False)
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 2e-5, what
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5, err_msg=what)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5, err_msg=what)
+    one, many = run(1, True), run(world, True)
+    assert abs(one[0] - many[0]) <= RTOL * abs(one[0]) + 2e-5, what
+    np.testing.assert_allclose(many[1], one[1], rtol=RTOL, atol=5e-5, err_msg=what)
+    np.testing.assert_allclose(many[2], one[2], rtol=RTOL, atol=5e-5, err_msg=what)
