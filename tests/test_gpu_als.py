@@ -140,3 +140,29 @@ def test_split_step_is_the_fused_step(oracle, monkeypatch, task, do_sample):
         np.testing.assert_allclose(other[1], res[0][1], rtol=1e-6, atol=1e-8)
         np.testing.assert_allclose(other[2], res[0][2], rtol=1e-6, atol=1e-8)
         np.testing.assert_allclose(other[3], res[0][3], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("k", [100, 200])
+def test_als_wide_rows_against_oracle(oracle, k, draw_form):
+    """KP = 128 / 256 (two / four floats per lane; the re-prediction hands 8 / 4 rows of q_f per wavefront through LDS)"""
+    from libfm_amd import learner as L
+    n, nnz = 1200, 6
+    ent, rp, y = datagen.onehot_fields(n, nnz, 700, seed=41 + k, classification=False)
+    ent2, rp2, y2 = datagen.onehot_fields(n, nnz, 100, seed=42 + k, classification=False)
+    m = oracle.Model(n, k, True, True, 0.0, 1.0, 6.0)
+    m.v[:] = oracle.init_values(14, n, k, 0.05)
+    m.w[:] = oracle.init_values(15, n, 1, 0.05)[0]
+    lo, hi = float(y.min()), float(y.max())
+    fm = L.FMModel()
+    fm.num_attribute, fm.num_factor = n, k
+    fm.w0, fm.w, fm.v = m.w0, m.w.copy(), m.v.copy()
+    l = L.FMLearnALS()
+    l.fm, l.task, l.num_iter, l.min_target, l.max_target, l.w_lambda, l.v_lambda = fm, 0, 2, lo, hi, 1.0, 6.0
+    l.out = io.StringIO()
+    l.init()
+    l.learn(L.Data(ent, rp, y), L.Data(ent2, rp2, y2))
+    pred, metric = oracle.als_learn(m, oracle.Data(ent, rp, y), oracle.Data(ent2, rp2, y2), 0, 2, 1.0, 6.0, lo, hi)
+    np.testing.assert_allclose(l.fm.v, m.v, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(l.fm.w, m.w, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(l.pred_this, pred, rtol=1e-4, atol=5e-5)
+    l.close()
