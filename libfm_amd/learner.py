@@ -104,11 +104,11 @@ class FMModel:
                 self.w = np.array([float(x) for x in lines[pos:pos + self.num_attribute]], dtype=np.float64)
                 pos += self.num_attribute
             pos += 1
-            rows = [[float(x) for x in ln.split(" ")] for ln in lines[pos:pos + self.num_attribute]]
+            rows = [[float(x) for x in ln.split(" ") if x != ""] for ln in lines[pos:pos + self.num_attribute]]
             if len(rows) != self.num_attribute or any(len(r) != self.num_factor for r in rows):
                 return False
-            self.v = np.ascontiguousarray(np.array(rows, dtype=np.float64).T)
-            return True
+            self.v = np.ascontiguousarray(np.array(rows, dtype=np.float64).reshape(self.num_attribute, self.num_factor).T)
+            return True                                          # (-dim 1,1,0: n empty lines, as fm_model.h:160-190 reads them)
         except (OSError, ValueError, IndexError):
             return False
 

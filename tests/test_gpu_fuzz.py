@@ -282,3 +282,36 @@ def test_random_shape_sharded_als(capi, oracle, seed):
     assert abs(one[0] - many[0]) <= RTOL * abs(one[0]) + 2e-5, what
     np.testing.assert_allclose(many[1], one[1], rtol=RTOL, atol=5e-5, err_msg=what)
     np.testing.assert_allclose(many[2], one[2], rtol=RTOL, atol=5e-5, err_msg=what)
+
+
+@pytest.mark.parametrize("k,k0,k1", [(5, True, True), (33, False, True), (70, True, False), (0, True, True)])
+def test_model_file_at_odd_factor_counts(capi, oracle, k, k0, k1, tmp_path):
+    """fm_model::saveModel / loadModel through the device table when the row is padded (k < KP): the file is the Python writer's
+    byte for byte (that one is the stock binary's, tests/test_data_formats.py), and loads back exactly -- one handle and 3 shards."""
+    from libfm_amd import learner as L
+    n = 137
+    w = oracle.init_values(91 + k, n, 1, 0.3)[0] if k1 else np.zeros(n)
+    v = oracle.init_values(92 + k, n, max(k, 1), 0.3)[:k]
+    w32, v32 = w.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64)
+    h = capi.Handle(n, k, k0, k1, 0, 0, 0, 0, 0.01, -1.0, 1.0)
+    h.set_params(0.375 if k0 else 0.0, w, v if k else None)
+    dev_file, py_file = str(tmp_path / "dev.model"), str(tmp_path / "py.model")
+    h.save_model(dev_file)
+    fm = L.FMModel()
+    fm.num_attribute, fm.num_factor, fm.k0, fm.k1 = n, k, k0, k1
+    fm.w0, fm.w, fm.v = (0.375 if k0 else 0.0), w32, v32
+    fm.save_model(py_file)
+    assert open(dev_file).read() == open(py_file).read()
+    h.close()
+    got_w, got_v = np.zeros(n), np.zeros((k, n))
+    for r in range(3):
+        hs = capi.Handle(n, k, k0, k1, 0, 0, 0, 0, 0.01, -1.0, 1.0, shard_rank=r, shard_world=3, shard_hash=1)
+        hs.load_model(py_file)
+        w0, got_w, got_v = hs.get_params(got_w, got_v)
+        assert w0 == (0.375 if k0 else 0.0)
+        hs.close()
+    fm2 = L.FMModel()                                          # (the text file holds 6 significant digits: compare with its reader)
+    fm2.num_attribute, fm2.num_factor, fm2.k0, fm2.k1 = n, k, k0, k1
+    assert fm2.load_model(py_file)
+    want_w = fm2.w.astype(np.float32).astype(np.float64) if k1 else np.zeros(n)
+    assert np.array_equal(got_w, want_w) and np.array_equal(got_v, fm2.v.astype(np.float32).astype(np.float64)[:k])
