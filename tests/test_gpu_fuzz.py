@@ -315,3 +315,77 @@ def test_model_file_at_odd_factor_counts(capi, oracle, k, k0, k1, tmp_path):
     assert fm2.load_model(py_file)
     want_w = fm2.w.astype(np.float32).astype(np.float64) if k1 else np.zeros(n)
     assert np.array_equal(got_w, want_w) and np.array_equal(got_v, fm2.v.astype(np.float32).astype(np.float64)[:k])
+
+
+def test_no_factors_at_all(capi, oracle, monkeypatch):
+    """`-dim 1,1,0` (a linear model: legal in libFM) through ALS in both draw forms, both SGDA forms, sharded SGD and sharded ALS"""
+    n, nnz, rows = 300, 6, 400
+    ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed=5, zipf=1.05, classification=False)
+    d = oracle.Data(ent, rp, y)
+    lo, hi = float(y.min()), float(y.max())
+    te = oracle.Data(ent[:int(rp[20])].copy(), rp[:21].copy(), y[:20].copy())
+    w_init = oracle.init_values(3, n, 1, 0.1)[0]
+
+    def fresh():
+        m = oracle.Model(n, 0, True, True, 0.0, 1.0, 1.0)
+        m.w[:] = w_init
+        return m
+    # ALS, one handle (fused / split draws) and 3 shards
+    ref = fresh()
+    oracle.als_learn(ref, d, te, 0, 3, 1.0, 1.0, lo, hi)
+    for world, split in ((1, "0"), (1, "1"), (3, "0")):
+        monkeypatch.setenv("FMX_ALS_SPLIT_MIN", split)
+        hs = [capi.Handle(n, 0, True, True, 0, 0.0, 1.0, 1.0, 0.0, lo, hi, device=0, shard_rank=r, shard_world=world, shard_hash=1)
+              for r in range(world)]
+        for h in hs:
+            h.set_params(0.0, w_init, None)
+            h.upload_rows(0, ent, rp, y)
+        grp = capi.Group(hs) if world > 1 else None
+        drv = grp if grp else hs[0]
+        drv.als_begin(0)
+        for _ in range(3):
+            drv.als_sweep(1.0, 1.0)
+        drv.als_end()
+        w0, w, _ = grp.get_params() if grp else hs[0].get_params()
+        assert abs(w0 - ref.w0) <= RTOL * abs(ref.w0) + 2e-5
+        np.testing.assert_allclose(w, ref.w, rtol=RTOL, atol=2e-5)
+        if grp:
+            grp.close()
+        for h in hs:
+            h.close()
+    # SGD over 2 shards, SGDA in both forms
+    lr = 0.01
+    m = fresh()
+    hs = [capi.Handle(n, 0, True, True, 0, 0.0, 0.001, 0.0, lr, lo, hi, device=0, shard_rank=r, shard_world=2) for r in range(2)]
+    for h in hs:
+        h.set_params(0.0, w_init, None)
+        h.upload_rows(0, ent, rp, y)
+    grp = capi.Group(hs)
+    m.regw = 0.001
+    for _ in range(2):
+        grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, 64, 8, capi.FLAG_BIAS_LAG, 2)
+        oracle.sgd_epoch_minibatch(m, d, 0, lr, lo, hi, 64, 8, bias_lag=2)
+    w0, w, _ = grp.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    grp.close()
+    for h in hs:
+        h.close()
+    for b in (None, 50):
+        m = fresh()
+        m.regw = 0.0
+        h = capi.Handle(n, 0, True, True, 0, 0.0, 0.0, 0.0, 0.002, lo, hi)
+        h.set_params(0.0, w_init, None)
+        h.upload_rows(0, ent, rp, y)
+        h.upload_rows(1, te.entries, te.row_ptr, te.target)
+        h.sgda_begin()
+        for i in range(3):
+            h.sgda_epoch(0, 1, i > 0) if b is None else h.sgda_epoch_minibatch(0, 1, i > 0, b, 4)
+        reg = h.sgda_get_reg()
+        w0, w, _ = h.get_params()
+        h.sgda_end()
+        h.close()
+        st = oracle.sgda_learn(m, d, te, 0, 0.002, lo, hi, 3, None, batch=b, w0_chunk=4)
+        assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 2e-5
+        np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+        np.testing.assert_allclose(reg[:, 0], st.reg_w, rtol=1e-3, atol=1e-7)
