@@ -389,3 +389,44 @@ def test_no_factors_at_all(capi, oracle, monkeypatch):
         assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 2e-5
         np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
         np.testing.assert_allclose(reg[:, 0], st.reg_w, rtol=1e-3, atol=1e-7)
+
+
+def test_empty_and_single_row_data_sets(capi, oracle):
+    """0 rows and 1 row through upload / predict / evaluate / every SGD form / SGDA / ALS: no crash, the one-row results are the rule's"""
+    n, k = 50, 8
+    empty = (np.zeros(0, dtype=datagen.ENTRY_DTYPE), np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.float32))
+    h = capi.Handle(n, k, True, True, 0, 0.0, 0.001, 0.001, 0.01, -2.0, 2.0)
+    h.init_params(0.1, 0.1, 7)
+    w0_before = h.get_w0()
+    h.upload_rows(0, *empty)
+    assert len(h.predict(0, 0)) == 0
+    assert h.evaluate(0).rows == 0
+    for mode, apply_, flags, lag in ((capi.SGD_SEQUENTIAL, capi.APPLY_DEFAULT, 0, 0), (capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, 0, 0),
+                                     (capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 2), (capi.SGD_HOGWILD, capi.APPLY_STORE, 0, 0)):
+        st = h.sgd_epoch(0, mode, apply_, 16, 4, flags, lag)
+        assert st.rows == 0
+    assert h.get_w0() == w0_before
+    with pytest.raises(capi.FmxError):
+        h.als_begin(0)                                         # "empty training set"
+    # one row
+    ent = np.zeros(3, dtype=datagen.ENTRY_DTYPE)
+    ent["id"], ent["value"] = [4, 9, 30], [1.0, -0.5, 2.0]
+    rp, y = np.array([0, 3], dtype=np.uint64), np.array([1.5], dtype=np.float32)
+    d = oracle.Data(ent, rp, y)
+    w0, w, v = h.get_params()
+    for apply_, flags, lag in ((capi.APPLY_FUSED, 0, 1), (capi.APPLY_DEFAULT, 0, 0), (capi.APPLY_SEGMENTED, capi.FLAG_BIAS_LAG, 2)):
+        m = oracle.Model(n, k, True, True, 0.0, 0.001, 0.001)
+        m.w0, m.w[:], m.v[:] = w0, w, v
+        h.set_params(w0, w, v)
+        h.upload_rows(1, ent, rp, y)
+        h.sgd_epoch(1, capi.SGD_MINIBATCH, apply_, 16, 4, flags, lag)
+        oracle.sgd_epoch_minibatch(m, d, 0, 0.01, -2.0, 2.0, 16, 4, bias_lag=lag)
+        g0, gw, gv = h.get_params()
+        assert abs(g0 - m.w0) <= RTOL * abs(m.w0) + 1e-6
+        np.testing.assert_allclose(gw, m.w, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(gv, m.v, rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(h.predict(1, 1), oracle.predict_raw(m, d), rtol=RTOL, atol=1e-5)
+    h.als_begin(1)
+    h.als_sweep(1.0, 2.0)
+    h.als_end()
+    h.close()
