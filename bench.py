@@ -259,7 +259,7 @@ def main():
 
     lr, regv = 0.01, 0.001
     h = capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
-                    device=local_rank, shard_rank=rank, shard_world=world)
+                    device=local_rank, shard_rank=rank, shard_world=world, shard_hash=1 if world > 1 else 0)
     h.init_params(0.0, 0.01, 1)
     h.synth_rows(0, 123, 0, args.rows, args.nnz)
     info = h.info()
