@@ -1,4 +1,5 @@
 // fmx_als.hip -- C-ABI (include/fmx.h): the ALS / MCMC learner (level-scheduled coordinate sweeps, fmx_als_kernels.h).
+#define FMX_GRID_OVER_DEFAULT 2                    // = FMX_GRID_OVER_ALS (fmx_internal.h): the column kernels keep grid-stride workgroups
 #include "fmx_internal.h"
 
 extern "C" {

@@ -39,9 +39,12 @@ Shard make_shard(const fmx_config& c) {
   return sh;
 }
 
-// persistent sizing: never launch more workgroups than can be resident (a second, partially filled round of
-// equally long grid-stride workgroups is pure tail), never more than the work needs.
-uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted) {
+// grid sizing: never more workgroups than the work needs, and at most `over` x what can be resident (the kernels stride
+// over their work).  Which `over` is a measured per-family choice (scripts/gpu_ab_inprocess.py FMX_GRID_OVER a b <what>,
+// alternating inside one process): the row-gather kernels of the SGD family want NO cap -- one workgroup per four examples and
+// the dispatcher balancing them beats grid-stride workgroups (one-pass step: x1 -7 %, x2 0, x8 +1.7 %, uncapped +3.0 %; two-pass
+// +5.9 %, hogwild +4.7 %, predict +3.2 %) -- while the column kernels of the ALS sweep lose 8 % uncapped and keep x2.
+uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted, int over_default) {
   auto& cache = h->occ_cache;                 // per handle (= per device, one calling thread): no process-wide state
   auto it = cache.find(kernel);
   int occ;
@@ -54,10 +57,8 @@ uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted
     occ = it->second;
   }
   uint64_t blocks = (n_waves_wanted + 3) / 4;
-  // over-subscribe: more (shorter) workgroups than can be resident let the dispatcher balance the tail;
-  // measured better than an exactly-resident persistent grid for these gather kernels
-  int over = 2;
-  if (const char* e = getenv("FMX_GRID_OVER")) over = atoi(e) > 0 ? atoi(e) : 1;
+  int over = over_default;
+  if (const char* e = getenv(over_default == FMX_GRID_OVER_ALS ? "FMX_GRID_OVER_ALS" : "FMX_GRID_OVER")) over = atoi(e) > 0 ? atoi(e) : 1;
   const uint64_t cap = (uint64_t)occ * (uint64_t)h->num_cu * (uint64_t)over;
   if (blocks < 1) blocks = 1;
   if (blocks > cap) blocks = cap;

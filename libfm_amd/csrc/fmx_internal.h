@@ -151,7 +151,12 @@ struct fmx_context_s {
 int fail(fmx_handle h, int code, const char* fmt, ...);                 // fmx_core.hip
 Hyper make_hyper(const fmx_config& c);
 Shard make_shard(const fmx_config& c);
-uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted);
+constexpr int FMX_GRID_OVER_SGD = 1 << 16;   // effectively uncapped
+constexpr int FMX_GRID_OVER_ALS = 2;
+#ifndef FMX_GRID_OVER_DEFAULT
+#define FMX_GRID_OVER_DEFAULT FMX_GRID_OVER_SGD      // fmx_als.hip defines it as FMX_GRID_OVER_ALS before including this header
+#endif
+uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted, int over_default = FMX_GRID_OVER_DEFAULT);
 int ensure_scratch(fmx_handle h, size_t batch_cap, size_t rest_cap);
 int check_slot(fmx_handle h, int slot, bool need_target);
 int slot_in_session(fmx_handle h, int slot, const char* what);
