@@ -1169,6 +1169,30 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
 }
 
 // ----------------------------------------------------------------------------------------------
+// k_place_probe: what a training step does to the factor table, on a table that holds nothing yet -- every wavefront reads 32
+// random rows of `row_floats` floats and writes them back scaled (non-temporal both ways; the table is all zeros at that point).  fmx_create times it on candidate
+// allocations of the table: on this part the rate of exactly this access pattern depends on WHERE in HBM an allocation landed
+// (scripts/ubench/placement.hip: 5.9 vs 5.3 TB/s for same-sized tables of one process), so the table goes where it runs fastest.
+// ----------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256)
+k_place_probe(float* __restrict__ tab, uint64_t n_rows, uint32_t row_floats, uint32_t n_waves, uint64_t salt) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= n_waves) return;
+  const uint32_t lanes_per_row = min(64u, row_floats), rows_per_load = 64u / lanes_per_row;
+  const uint32_t sub = lane / lanes_per_row, col = lane % lanes_per_row;
+  float v[32]; uint64_t at[32];
+#pragma unroll
+  for (int t = 0; t < 32; t++) {
+    const uint64_t r = (uint64_t)(((unsigned __int128)mix64(((uint64_t)wave * 32 + t) * rows_per_load + sub + salt) * n_rows) >> 64);
+    at[t] = r * row_floats + col;
+    v[t] = __builtin_nontemporal_load(tab + at[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < 32; t++) __builtin_nontemporal_store(v[t] * 0.999f, tab + at[t]);   // (a plain write-back of the loaded value is a no-op the
+}                                                                                           //  compiler removes together with the load; the table is zero)
+
+// ----------------------------------------------------------------------------------------------
 // k_sequential: the reference trajectory (batch = 1, storage order) on ONE wavefront, for parity.
 // Loads bypass the per-CU L1 (agent-scope relaxed atomics -> sc1) and every row ends with a drain of
 // the store queue, so row r+1 sees row r's update exactly like fm_learn_sgd_element.h:56-67.
