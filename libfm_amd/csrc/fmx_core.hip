@@ -228,53 +228,62 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     if (const char* e = getenv("FMX_WPAD")) wpad = atoi(e);
     if (wpad < 0 || (wpad % 4) != 0) wpad = 0;
     h->tb.rs = (uint32_t)(h->KP + wpad);
-    // Placement of the factor table.  The rate of the step's random row gather + write-back depends on where in HBM the table's
-    // allocation landed (same size, same process, same kernel: two classes ~11 % apart, stable for the life of the allocation;
-    // scripts/ubench/placement.hip) -- the one quantity that decided whether a process ran the bench at 16.4 or
-    // at 18-20 ms per step.  So a table of >= 1 GB is allocated up to three times (the earlier candidates are held meanwhile, so that
-    // the later ones are other memory), each candidate is timed under k_place_probe, the fastest is kept.  FMX_V_PLACE=0: first fit.
-    {
-      const size_t vbytes = h->n_local * (size_t)h->tb.rs * sizeof(float);
+    // Placement of the parameter tables.  The rate of the step's random row gather + write-back depends on where in HBM the table's
+    // allocation landed (same size, same process, same kernel: two classes 11-20 % apart, stable for the life of the allocation;
+    // scripts/ubench/placement.hip, placement_w.hip) -- the one quantity that decided whether a process ran the
+    // bench at 16.4 or at 18-20 ms per step.  So a table of >= 256 MB is allocated up to `max_tries` times (the earlier candidates
+    // are held meanwhile, so that the later ones are other memory), each candidate is zeroed and timed under a probe with the step's
+    // traffic shape, the fastest is kept.  FMX_V_PLACE=0: first fit.
+    auto alloc_placed = [&](float** out, size_t bytes, int max_tries, bool rows, const char* what) -> hipError_t {
       int tries = 1;
-      if (vbytes >= ((size_t)1 << 30) && !(getenv("FMX_V_PLACE") && atoi(getenv("FMX_V_PLACE")) == 0)) {
+      if (bytes >= ((size_t)256 << 20) && !(getenv("FMX_V_PLACE") && atoi(getenv("FMX_V_PLACE")) == 0)) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-          tries = (int)std::min<size_t>(3, std::max<size_t>(1, free_b / (vbytes + ((size_t)4 << 30))));   // candidates must fit side by side
+          tries = (int)std::min<size_t>((size_t)max_tries, std::max<size_t>(1, free_b / (bytes + ((size_t)4 << 30))));   // candidates sit side by side
       }
-      float* cand[3] = {nullptr, nullptr, nullptr};
-      float ms_of[3] = {0.f, 0.f, 0.f};
+      float* cand[4] = {nullptr, nullptr, nullptr, nullptr};
+      float ms_of[4] = {0.f, 0.f, 0.f, 0.f};
       int n_cand = 0, best = 0;
-      for (int c = 0; c < tries; c++) {
-        if (hipMalloc(&cand[c], vbytes) != hipSuccess) { (void)hipGetLastError(); cand[c] = nullptr; break; }
+      hipError_t er = hipSuccess;
+      for (int c = 0; c < tries && er == hipSuccess; c++) {
+        if (hipMalloc(&cand[c], bytes) != hipSuccess) { (void)hipGetLastError(); cand[c] = nullptr; break; }
         n_cand = c + 1;
-        if (tries == 1) break;
-        CREATE_CHK(hipMemsetAsync(cand[c], 0, vbytes, h->stream));   // (a never-written allocation answers the probe in 30 us: not the placement's rate)
-        const uint32_t waves = 1u << 19;                      // 2^19 wavefronts x 32 rows: 8 GB of traffic at k = 64, ~1.5 ms
-        for (int rep = 0; rep < 2; rep++) {                   // (first launch: page-table warm-up)
-          CREATE_CHK(hipEventRecord(h->ev0, h->stream));
-          hipLaunchKernelGGL(k_place_probe, dim3(waves / 4), dim3(256), 0, h->stream, cand[c], (uint64_t)h->n_local, h->tb.rs, waves, (uint64_t)rep * 7919 + 1);
-          CREATE_CHK(hipGetLastError());
-          CREATE_CHK(hipEventRecord(h->ev1, h->stream));
-          CREATE_CHK(hipEventSynchronize(h->ev1));
-          CREATE_CHK(hipEventElapsedTime(&ms_of[c], h->ev0, h->ev1));
+        er = hipMemsetAsync(cand[c], 0, bytes, h->stream);   // (also: a never-written allocation answers the probe in 30 us)
+        if (tries == 1 || er != hipSuccess) break;
+        for (int rep = 0; rep < 2 && er == hipSuccess; rep++) {           // (first launch: page-table warm-up)
+          er = hipEventRecord(h->ev0, h->stream);
+          if (rows) {                                         // 2^19 wavefronts x 32 rows: 8 GB of traffic at k = 64, ~1.5 ms
+            const uint32_t waves = 1u << 19;
+            hipLaunchKernelGGL(k_place_probe, dim3(waves / 4), dim3(256), 0, h->stream, cand[c], (uint64_t)h->n_local, h->tb.rs, waves, (uint64_t)rep * 7919 + 1);
+          } else {                                            // 2^24 random 4-byte read-modify-writes, ~0.5 ms
+            const uint64_t total = 1ull << 24;
+            hipLaunchKernelGGL(k_place_probe_w, dim3((unsigned)(total / 256)), dim3(256), 0, h->stream, cand[c], (uint64_t)(bytes / sizeof(float)), total, (uint64_t)rep * 7919 + 1);
+          }
+          if (er == hipSuccess) er = hipGetLastError();
+          if (er == hipSuccess) er = hipEventRecord(h->ev1, h->stream);
+          if (er == hipSuccess) er = hipEventSynchronize(h->ev1);
+          if (er == hipSuccess) er = hipEventElapsedTime(&ms_of[c], h->ev0, h->ev1);
         }
         if (ms_of[c] < ms_of[best]) best = c;
-        if (c >= 1 && ms_of[best] < 0.95f * std::max(ms_of[0], ms_of[1])) break;   // two classes seen: the fast one is in hand
+        float worst = 0.f;
+        for (int i = 0; i <= c; i++) worst = std::max(worst, ms_of[i]);
+        if (c >= 1 && ms_of[best] < 0.95f * worst) break;     // two classes seen: the fast one is in hand
       }
-      if (!cand[0]) CREATE_CHK(hipMalloc(&cand[0], vbytes));  // (reports the allocation failure)
-      if (getenv("FMX_DEBUG")) fprintf(stderr, "fmx: factor table %zu bytes, %d candidate placements, probe %.3f / %.3f / %.3f ms, kept #%d\n",
-                                       vbytes, n_cand, ms_of[0], ms_of[1], ms_of[2], best);
-      for (int c = 0; c < n_cand; c++) if (c != best && cand[c]) hipFree(cand[c]);
-      h->tb.V = cand[best];
-      if (tries == 1) CREATE_CHK(hipMemsetAsync(h->tb.V, 0, vbytes, h->stream));   // (probed candidates are zero: the probe writes back what it read)
-    }
+      if (er == hipSuccess && !cand[0]) er = hipMalloc(&cand[0], bytes);      // (reports the allocation failure)
+      if (getenv("FMX_DEBUG")) fprintf(stderr, "fmx: %s %zu bytes, %d candidate placement(s), probe %.3f / %.3f / %.3f / %.3f ms, kept #%d\n",
+                                       what, bytes, n_cand, ms_of[0], ms_of[1], ms_of[2], ms_of[3], best);
+      for (int c = 0; c < 4; c++) if ((c != best || er != hipSuccess) && cand[c]) { hipFree(cand[c]); cand[c] = nullptr; }
+      *out = cand[best];
+      return er;
+    };
+    CREATE_CHK(alloc_placed(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float), 3, true, "factor table"));
     if (wpad == 0) {
       // FMX_W_ALLOC (experiment, scripts/ubench/w_gather.hip): 1 = uncached, 2 = fine-grained allocation of the w array
       const int walloc = getenv("FMX_W_ALLOC") ? atoi(getenv("FMX_W_ALLOC")) : 0;
       if (walloc == 1)      CREATE_CHK(hipExtMallocWithFlags((void**)&h->w_sep, h->n_local * sizeof(float), hipDeviceMallocUncached));
       else if (walloc == 2) CREATE_CHK(hipExtMallocWithFlags((void**)&h->w_sep, h->n_local * sizeof(float), hipDeviceMallocFinegrained));
-      else                  CREATE_CHK(hipMalloc(&h->w_sep, h->n_local * sizeof(float)));
-      CREATE_CHK(hipMemsetAsync(h->w_sep, 0, h->n_local * sizeof(float), h->stream));
+      else                  CREATE_CHK(alloc_placed(&h->w_sep, h->n_local * sizeof(float), 4, false, "linear weights"));
+      if (walloc) CREATE_CHK(hipMemsetAsync(h->w_sep, 0, h->n_local * sizeof(float), h->stream));
       h->tb.w = h->w_sep; h->tb.ws = 1;
     } else {
       h->tb.w = h->tb.V + h->KP; h->tb.ws = h->tb.rs;

@@ -1192,6 +1192,15 @@ k_place_probe(float* __restrict__ tab, uint64_t n_rows, uint32_t row_floats, uin
   for (int t = 0; t < 32; t++) __builtin_nontemporal_store(v[t] * 0.999f, tab + at[t]);   // (a plain write-back of the loaded value is a no-op the
 }                                                                                           //  compiler removes together with the load; the table is zero)
 
+// the same for the linear weights: random 4-byte read-modify-writes of a zeroed table (32 w_j per example in the step)
+static __global__ void __launch_bounds__(256)
+k_place_probe_w(float* __restrict__ tab, uint64_t n, uint64_t total, uint64_t salt) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= total) return;
+  const uint64_t j = (uint64_t)(((unsigned __int128)mix64(tid + salt) * n) >> 64);
+  tab[j] = tab[j] * 0.999f;
+}
+
 // ----------------------------------------------------------------------------------------------
 // k_sequential: the reference trajectory (batch = 1, storage order) on ONE wavefront, for parity.
 // Loads bypass the per-CU L1 (agent-scope relaxed atomics -> sc1) and every row ends with a drain of
