@@ -231,18 +231,19 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     // Placement of the parameter tables.  The rate of the step's random row gather + write-back depends on where in HBM the table's
     // allocation landed (same size, same process, same kernel: two classes 11-20 % apart, stable for the life of the allocation;
     // scripts/ubench/placement.hip, placement_w.hip) -- the one quantity that decided whether a process ran the
-    // bench at 16.4 or at 18-20 ms per step.  So a table of >= 256 MB is allocated up to `max_tries` times (the earlier candidates
+    // bench at 16.4 or at 18-20 ms per step.  So a table of >= 256 MB is allocated up to `max_tries` (<= 6) times (the earlier candidates
     // are held meanwhile, so that the later ones are other memory), each candidate is zeroed and timed under a probe with the step's
     // traffic shape, the fastest is kept.  FMX_V_PLACE=0: first fit.
     auto alloc_placed = [&](float** out, size_t bytes, int max_tries, bool rows, const char* what) -> hipError_t {
+      constexpr int MAXC = 6;
       int tries = 1;
       if (bytes >= ((size_t)256 << 20) && !(getenv("FMX_V_PLACE") && atoi(getenv("FMX_V_PLACE")) == 0)) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-          tries = (int)std::min<size_t>((size_t)max_tries, std::max<size_t>(1, free_b / (bytes + ((size_t)4 << 30))));   // candidates sit side by side
+          tries = (int)std::min<size_t>((size_t)std::min(max_tries, MAXC), std::max<size_t>(1, free_b / (bytes + ((size_t)4 << 30))));   // candidates sit side by side
       }
-      float* cand[4] = {nullptr, nullptr, nullptr, nullptr};
-      float ms_of[4] = {0.f, 0.f, 0.f, 0.f};
+      float* cand[MAXC] = {};
+      float ms_of[MAXC] = {};
       int n_cand = 0, best = 0;
       hipError_t er = hipSuccess;
       for (int c = 0; c < tries && er == hipSuccess; c++) {
@@ -270,13 +271,13 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
         if (c >= 1 && ms_of[best] < 0.95f * worst) break;     // two classes seen: the fast one is in hand
       }
       if (er == hipSuccess && !cand[0]) er = hipMalloc(&cand[0], bytes);      // (reports the allocation failure)
-      if (getenv("FMX_DEBUG")) fprintf(stderr, "fmx: %s %zu bytes, %d candidate placement(s), probe %.3f / %.3f / %.3f / %.3f ms, kept #%d\n",
-                                       what, bytes, n_cand, ms_of[0], ms_of[1], ms_of[2], ms_of[3], best);
-      for (int c = 0; c < 4; c++) if ((c != best || er != hipSuccess) && cand[c]) { hipFree(cand[c]); cand[c] = nullptr; }
+      if (getenv("FMX_DEBUG")) fprintf(stderr, "fmx: %s %zu bytes, %d candidate placement(s), probe %.3f / %.3f / %.3f / %.3f / %.3f / %.3f ms, kept #%d\n",
+                                       what, bytes, n_cand, ms_of[0], ms_of[1], ms_of[2], ms_of[3], ms_of[4], ms_of[5], best);
+      for (int c = 0; c < MAXC; c++) if ((c != best || er != hipSuccess) && cand[c]) { hipFree(cand[c]); cand[c] = nullptr; }
       *out = cand[best];
       return er;
     };
-    CREATE_CHK(alloc_placed(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float), 3, true, "factor table"));
+    CREATE_CHK(alloc_placed(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float), 6, true, "factor table"));
     if (wpad == 0) {
       // FMX_W_ALLOC (experiment, scripts/ubench/w_gather.hip): 1 = uncached, 2 = fine-grained allocation of the w array
       const int walloc = getenv("FMX_W_ALLOC") ? atoi(getenv("FMX_W_ALLOC")) : 0;
