@@ -147,7 +147,11 @@ typedef struct fmx_eval {
 } fmx_eval;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
-/* replaces: fm_model fm; fm.init() allocation (fm_model.h:91-99) + new fm_learn_* (libfm.cpp:271-293) */
+/* replaces: fm_model fm; fm.init() allocation (fm_model.h:91-99) + new fm_learn_* (libfm.cpp:271-293)
+ * Parameter tables of >= 256 MB are PLACED: up to six (factor table) / four (linear weights) candidate allocations are held
+ * side by side for a few milliseconds, each timed under the training step's access pattern, the fastest kept -- where in HBM a
+ * table lands moves the step by 10-20 % on MI355X.  The number of candidates adapts to the free device
+ * memory; environment FMX_V_PLACE=0 switches the probing off (first fit). */
 int fmx_create(const fmx_config *cfg, fmx_handle *out);
 int fmx_destroy(fmx_handle h);
 /* text of the last error on this handle (h may be NULL: last creation error). Never NULL. */
