@@ -133,7 +133,9 @@ class fm_learn_sgd_gpu : public fmx_sgd_binding<fm_learn_sgd> {
   int gpu_apply;         // FMX_APPLY_*
   uint gpu_batch, gpu_w0_chunk, gpu_flags, gpu_bias_lag;   // fmx_sgd_opts::flags / ::bias_lag
 
-  fm_learn_sgd_gpu() : gpu_mode(FMX_SGD_MINIBATCH), gpu_apply(FMX_APPLY_DEFAULT), gpu_batch(0), gpu_w0_chunk(0), gpu_flags(0), gpu_bias_lag(0) {}
+  // defaults: the batch rule in one pass (FMX_APPLY_FUSED, bias lag 2), batch chosen by the library from the rows' collision
+  // mass (fmx_sgd_opts::batch = 0), an explicit batch the rule diverges at is refused (FMX_E_ARG -> thrown like any error)
+  fm_learn_sgd_gpu() : gpu_mode(FMX_SGD_MINIBATCH), gpu_apply(FMX_APPLY_FUSED), gpu_batch(0), gpu_w0_chunk(0), gpu_flags(FMX_FLAG_REJECT_UNSTABLE), gpu_bias_lag(2) {}
 
   virtual void init() {                                   // fm_learn_sgd_element::init (:40-46)
     fm_learn_sgd::init();
@@ -150,6 +152,8 @@ class fm_learn_sgd_gpu : public fmx_sgd_binding<fm_learn_sgd> {
     for (int i = 0; i < num_iter; i++) {
       fmx_epoch_stats st;
       gcheck(fmx_group_sgd_epoch(grp, s_train, &opts, &st));
+      if (i == 0 && (st.status & FMX_STAT_BATCH_CUT))
+        std::cerr << "libfmx: batch " << st.batch_used << " (collision mass of the rows " << st.collision_mass << ", gain " << st.batch_gain << ")" << std::endl;
       double rmse_train = evaluate_slot(s_train);
       double rmse_test = evaluate_slot(s_test);
       std::cout << "#Iter=" << std::setw(3) << i << "\tTrain=" << rmse_train << "\tTest=" << rmse_test << std::endl;

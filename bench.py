@@ -183,6 +183,10 @@ def main():
     ap.add_argument("--method", default="sgd", choices=["sgd", "als", "mcmc"],
                     help="sgd: the BASELINE metric (default).  als / mcmc: one step = one sweep of fm_learn_mcmc over the rows "
                          "(BASELINE configs[3] / [4] shapes: n=1e7, k=64, 16 nnz/row unless overridden; one GPU)")
+    ap.add_argument("--workload", default="uniform", choices=["uniform", "criteo"],
+                    help="uniform: the BASELINE metric's rows (uniform ids within 32 fields of 1e8 features).  criteo: BASELINE configs[2] "
+                         "on one GPU -- n = 3.3e7, 39 fields (13 of <= 100 ids, 26 Zipf 1.05), fmx_synth_rows_ex(FMX_SYNTH_CRITEO); the library "
+                         "cuts the batch to the rows' stability bound (fmx_sgd_opts::batch = 0)")
     ap.add_argument("--features", dest="n", type=int, default=None, help="number of features n (sgd: 1e8, als/mcmc: 1e7)")
     ap.add_argument("--factors", dest="k", type=int, default=64, help="number of factors k")
     ap.add_argument("--nnz", type=int, default=None, help="entries per row (sgd: 32, als/mcmc: 16)")
@@ -215,10 +219,11 @@ def main():
                     help="skip timing the REAL reference code (oracle/_ref/ref_harness time_sgd, largest n it can allocate)")
     args = ap.parse_args()
 
+    criteo = args.workload == "criteo"
     if args.n is None:
-        args.n = 100_000_000 if args.method == "sgd" else 10_000_000
+        args.n = (33_000_000 if criteo else 100_000_000) if args.method == "sgd" else 10_000_000
     if args.nnz is None:
-        args.nnz = 32 if args.method == "sgd" else 16
+        args.nnz = (39 if criteo else 32) if args.method == "sgd" else 16
 
     import torch
     import torch.distributed as dist
@@ -252,7 +257,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cpu, cpu_ref = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not criteo:   # (the CPU legs time the uniform workload)
         cpu = cpu_baseline(args.n, args.k, args.nnz, args.cpu_rows)
         if args.cpu_reference:
             cpu_ref = cpu_reference(args.n, args.k, args.nnz, args.cpu_rows)
@@ -261,7 +266,7 @@ def main():
     h = capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
                     device=local_rank, shard_rank=rank, shard_world=world, shard_hash=1 if world > 1 else 0)
     h.init_params(0.0, 0.01, 1)
-    h.synth_rows(0, 123, 0, args.rows, args.nnz)
+    h.synth_rows(0, 123, 0, args.rows, args.nnz, capi.SYNTH_CRITEO if criteo else capi.SYNTH_UNIFORM)
     info = h.info()
     mode = capi.SGD_HOGWILD if args.mode == "hogwild" else capi.SGD_MINIBATCH
     apply_ = {"default": capi.APPLY_DEFAULT, "segmented": capi.APPLY_SEGMENTED, "atomic": capi.APPLY_ATOMIC,
@@ -272,17 +277,20 @@ def main():
     lagf = 0 if (args.no_bias_lag or args.mode == "hogwild") else capi.FLAG_BIAS_LAG
     bias_lag = args.bias_lag if args.mode == "fused" else (1 if lagf else 0)
     deferred = 0
+    batch_stats = None
     if not sharded:
-        batch = args.batch or (16384 if args.mode == "minibatch" else 262144)
+        # --batch 0: the library's choice (fmx_sgd_opts::batch = 0 -> 262144 cut to the rows' stability bound; hogwild: rows per launch)
+        batch = h.sgd_batch_info(0, args.batch).batch if args.mode != "hogwild" else (args.batch or 262144)
         main_time, main_launches = 0.0, 0
 
         def step(timed):
-            nonlocal main_time, main_launches, deferred
-            st = h.sgd_epoch(0, mode, apply_, batch, args.w0_chunk, (capi.FLAG_TIME_MAIN_KERNEL if timed else 0) | lagf, bias_lag)
+            nonlocal main_time, main_launches, deferred, batch_stats
+            st = h.sgd_epoch(0, mode, apply_, args.batch, args.w0_chunk, (capi.FLAG_TIME_MAIN_KERNEL if timed else 0) | lagf, bias_lag)
             if timed:
                 main_time += st.main_kernel_seconds
                 main_launches += st.main_kernel_launches
                 deferred += st.deferred_features
+                batch_stats = st
         rows_per_launch = min(batch, args.rows)
         kind = "fused" if args.mode in ("hogwild", "fused") else "apply"
     elif args.driver == "lib" and args.backend == "nccl":
@@ -339,7 +347,7 @@ def main():
         elapsed = float(t.item())
 
     extras = {}
-    if rank == 0 and not sharded and not args.no_extras and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_extras and not args.no_cpu_baseline and not criteo:
         # secondary figures, never `value`: the asynchronous mode (metric-level parity only) and the two-pass form of the rule
         def timed_epochs(n, *a):
             h.sgd_epoch(0, *a)
@@ -412,7 +420,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
+            "config": {"workload": ("Criteo-shaped (13 fields of <= 100 ids + %d Zipf(1.05) fields) n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
+                                    % (args.nnz - 13, args.n, args.k, args.nnz, args.rows, lr, regv)) if criteo else
+                                   "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
                        "w0_chunk": args.w0_chunk or 256, "bias_lag": bias_lag, "pipeline": bool(args.pipeline) if sharded else False, "sharding": "feature-id hash (permutation) over %d shards" % world if world > 1 else "none",
@@ -421,6 +431,10 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu_ref if (cpu_ref and "value" in cpu_ref) else cpu,
         }
+        if batch_stats is not None and args.mode != "hogwild":
+            out["config"]["batch_rule"] = {"batch": batch_stats.batch_used, "collision_mass": round(batch_stats.collision_mass, 6),
+                                           "gain": round(batch_stats.batch_gain, 4),
+                                           "cut": bool(batch_stats.status & capi.STAT_BATCH_CUT), "unstable": bool(batch_stats.status & capi.STAT_UNSTABLE)}
         if cpu_ref and "value" in cpu_ref and cpu is not None:
             out["cpu_port"] = cpu
         if exchange is not None:

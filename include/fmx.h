@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 3
+#define FMX_ABI_VERSION 4
 
 enum {
   FMX_OK = 0,
@@ -98,8 +98,16 @@ typedef struct fmx_config {
 typedef struct fmx_sgd_opts {
   int32_t  mode;            /* FMX_SGD_* */
   int32_t  apply;           /* FMX_APPLY_* (MINIBATCH and HOGWILD) */
-  uint32_t batch;           /* MINIBATCH: rows per minibatch, 0 = 16384.  HOGWILD: rows per launch during which
-                               w0 is frozen (macro-batch), 0 = 262144 */
+  uint32_t batch;           /* MINIBATCH: rows per minibatch.  0 = library default: 262144, CUT to the largest power of two that
+                               keeps the batch rule stable on THIS data set: learn_rate * curvature * batch * C <= 1, C = the
+                               collision mass of the slot's rows (fmx_sgd_batch_info).  The rule freezes every parameter for one
+                               batch; two examples of a batch that share features push those in the same direction from the
+                               same stale state, so the step along "what the rows have in common" is learn_rate * batch * C where
+                               the reference (batch 1, fm_sgd.h:33-51) takes `batch` small steps.  Uniform ids over 1e8 features:
+                               C = 1e-5, no cut; Criteo-shaped rows (100-id fields, Zipf heads): C = 1, batch 256 at
+                               learn_rate 0.01.  An explicit batch is honoured (fmx_epoch_stats::status reports FMX_STAT_UNSTABLE;
+                               with FMX_FLAG_REJECT_UNSTABLE the call fails with FMX_E_ARG instead of training).
+                               HOGWILD: rows per launch during which w0 is frozen (macro-batch), 0 = 262144 */
   uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default: the largest power of two <= 256
                              * with learn_rate * chunk * curvature <= 1 (curvature 1 for regression, 1/4 for classification).
                              * The reference moves w0 after every example (fm_sgd.h:34-37); a chunk is one batch step of
@@ -117,6 +125,8 @@ typedef struct fmx_sgd_opts {
 #define FMX_FLAG_PIPELINE 4u          /* fmx_group_sgd_epoch: gather the sums of batch b+1 BEFORE the update of batch b lands, so that
                                          their exchange runs under that update (one batch stale; oracle
                                          fmo_sgd_epoch_minibatch_pipelined) */
+#define FMX_FLAG_REJECT_UNSTABLE 8u    /* MINIBATCH with an explicit batch: fail with FMX_E_ARG when learn_rate * curvature * batch * C > 2
+                                         (the batch rule diverges there; tests/test_oracle_stability.py) instead of training */
 #define FMX_FLAG_BIAS_LAG 2u          /* MINIBATCH: the multipliers of a batch use the w0 of the batch START; w0 itself still
                                          advances through the micro-chunk recurrence, which then runs on a side stream
                                          overlapped with the next batch (oracle: fmo_sgd_epoch_minibatch_ex, bias_lag = 1) */
@@ -128,14 +138,29 @@ typedef struct fmx_epoch_stats {
   double   main_kernel_seconds; /* HIP-event time summed over launches of the dominant kernel only */
   uint64_t main_kernel_launches;
   uint32_t max_feature_count; /* MINIBATCH with the segmented update: occurrences of the most frequent feature inside one
-                               * batch.  The batch rule applies them at once (a step of learn_rate * count on that feature,
-                               * where the reference takes `count` small steps), so keep learn_rate * count * curvature
-                               * well below 1 (curvature: x^2 for regression, x^2 / 4 for classification) -- pick the batch
-                               * size accordingly, or use SEQUENTIAL / HOGWILD for data with very frequent features. */
-  uint32_t reserved;
+                               * batch (the longest segment k_apply_seg sums) */
+  uint32_t batch_used;      /* MINIBATCH: rows per batch this epoch ran with (the resolved fmx_sgd_opts::batch) */
   uint64_t deferred_features; /* FMX_APPLY_FUSED: (batch, feature) pairs finished by the segmented kernel, summed over the
                                * epoch's batches (features occurring more than once in their batch; the rest was one pass) */
+  double   collision_mass;  /* C of the slot's rows: sum over features j of (sum over rows of |x_j| / n_rows)^2 = the expected
+                               number of features two random rows share (value-weighted) */
+  double   batch_gain;      /* learn_rate * curvature * batch_used * C (curvature 1 regression, 1/4 classification): the batch
+                               rule follows the reference's online loop for <= 1, degrades above and diverges beyond ~2 */
+  uint32_t status;          /* FMX_STAT_* */
+  uint32_t reserved;
 } fmx_epoch_stats;
+
+#define FMX_STAT_BATCH_CUT 1u   /* batch = 0 resolved below the 262144 default because of the rows' collision mass */
+#define FMX_STAT_UNSTABLE  2u   /* batch_gain > 2: an explicit batch the rule is not stable at on this data */
+
+/* what fmx_sgd_epoch would use for `batch` on this slot (no training): the rows' collision mass (computed once per slot on the
+ * device: one histogram pass over the entries), the resolved batch and its gain.  opts may be NULL (= batch 0). */
+typedef struct fmx_batch_info {
+  double   collision_mass;
+  double   batch_gain;
+  uint32_t batch;
+  uint32_t status;          /* FMX_STAT_* */
+} fmx_batch_info;
 
 /* what fm_learn::evaluate_regression / evaluate_classification compute (fm_learn.h:113-153) */
 typedef struct fmx_eval {
@@ -209,7 +234,7 @@ int fmx_upload_rows(fmx_handle h, int slot, const void *entries, const uint64_t 
  * attribute ids start at attr_offset (libfm.cpp:213-216).  The rows are expanded ON THE DEVICE into one CSR
  * (main entries, then the blocks in order) so that the slot behaves like any other; the learners then compute what
  * the reference's per-block caches compute (fm_learn_mcmc.h:478-527, 734-790, 849-909) on the same design matrix.
- * At most 8 relations; not available on sharded handles. */
+ * At most 8 relations.  A feature shard (shard_world > 1) joins the rows on the host and keeps its own features. */
 typedef struct fmx_relation {
   const void     *entries;                    /* the block's own rows: sparse_entry<float>[nnz], ids local to the block */
   const uint64_t *row_ptr;                    /* [n_rows + 1] */
@@ -237,6 +262,15 @@ int fmx_upload_block_rows_ex(fmx_handle h, int slot, const void *entries, const 
 /* synthetic one-hot field rows generated on the device (bench workload; same
  * definition as oracle/fm_oracle.c fmo_synth_rows): rows row0 .. row0+n_rows-1 */
 int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz);
+/* the same with a choice of id distribution:
+ *   FMX_SYNTH_UNIFORM  uniform ids within each of the nnz fields (fmx_synth_rows)
+ *   FMX_SYNTH_CRITEO   BASELINE configs[2] / SURVEY section 8d "Criteo-shaped": the first 13 fields ("numeric", binned) hold at
+ *                      most 100 ids each with a geometric frequency profile, the other nnz - 13 fields share the remaining ids
+ *                      equally and draw them Zipf(s = 1.05) (inverse-CDF of the continuous power law); labels +-1 with a 1:3
+ *                      imbalance.  Needs nnz > 13 and num_attribute >= 1300 + (nnz - 13). */
+#define FMX_SYNTH_UNIFORM 0u
+#define FMX_SYNTH_CRITEO 1u
+int fmx_synth_rows_ex(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t shape);
 int fmx_free_rows(fmx_handle h, int slot);
 /* copies a slot back to the host (tests / debugging): sizes via fmx_rows_info first.  Sharded handles return
  * their LOCAL rows (kept entries only, ids = local row of the feature on this shard). Any pointer may be NULL. */
@@ -278,6 +312,7 @@ int fmx_evaluate(fmx_handle h, int slot, fmx_eval *out);
 
 /* ---- fm_learn_sgd_element::learn, one epoch (fm_learn_sgd_element.h:56-67) -------------------- */
 int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_epoch_stats *stats);
+int fmx_sgd_batch_info(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_batch_info *out);
 
 /* ---- minibatch step split at the exchange point, for one-process-per-GPU drivers --------------
  * partial: floats per batch = fmx_partial_floats(h, batch): [batch][KP] partial factor sums followed by

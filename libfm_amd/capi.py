@@ -17,6 +17,9 @@ APPLY_DEFAULT, APPLY_ATOMIC, APPLY_STORE, APPLY_SEGMENTED, APPLY_FUSED = 0, 1, 2
 FLAG_TIME_MAIN_KERNEL = 1
 FLAG_BIAS_LAG = 2
 FLAG_PIPELINE = 4
+FLAG_REJECT_UNSTABLE = 8
+STAT_BATCH_CUT, STAT_UNSTABLE = 1, 2
+SYNTH_UNIFORM, SYNTH_CRITEO = 0, 1
 BLOCKS_EXPAND, BLOCKS_KEEP = 0, 1
 COMM_ID_BYTES = 128
 MAX_SLOTS = 8
@@ -46,7 +49,12 @@ class SgdOpts(C.Structure):
 class EpochStats(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("batches", C.c_uint64), ("device_seconds", C.c_double),
                 ("main_kernel_seconds", C.c_double), ("main_kernel_launches", C.c_uint64),
-                ("max_feature_count", C.c_uint32), ("reserved", C.c_uint32), ("deferred_features", C.c_uint64)]
+                ("max_feature_count", C.c_uint32), ("batch_used", C.c_uint32), ("deferred_features", C.c_uint64),
+                ("collision_mass", C.c_double), ("batch_gain", C.c_double), ("status", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [("collision_mass", C.c_double), ("batch_gain", C.c_double), ("batch", C.c_uint32), ("status", C.c_uint32)]
 
 
 class Eval(C.Structure):
@@ -108,12 +116,14 @@ SYMBOLS = [
     ("fmx_read_binary", C.c_int, [C.c_char_p, C.POINTER(HostRows), C.c_char_p, C.c_size_t]),
     ("fmx_free_host_rows", None, [C.POINTER(HostRows)]),
     ("fmx_synth_rows", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+    ("fmx_synth_rows_ex", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     ("fmx_free_rows", C.c_int, [H, C.c_int]),
     ("fmx_rows_info", C.c_int, [H, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     ("fmx_download_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("fmx_predict", C.c_int, [H, C.c_int, C.c_void_p]),
     ("fmx_evaluate", C.c_int, [H, C.c_int, C.POINTER(Eval)]),
     ("fmx_sgd_epoch", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(EpochStats)]),
+    ("fmx_sgd_batch_info", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(BatchInfo)]),
     ("fmx_partial_floats", C.c_int, [H, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("fmx_sgd_partial", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_sgd_finish", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(SgdOpts), C.c_void_p]),
@@ -271,8 +281,8 @@ class Handle:
                                            _ptr(target), n_rows, len(entries)))
         return n_rows
 
-    def synth_rows(self, slot, seed, row0, n_rows, nnz):
-        self._chk(self.lib.fmx_synth_rows(self.h, slot, int(seed), int(row0), int(n_rows), int(nnz)))
+    def synth_rows(self, slot, seed, row0, n_rows, nnz, shape=SYNTH_UNIFORM):
+        self._chk(self.lib.fmx_synth_rows_ex(self.h, slot, int(seed), int(row0), int(n_rows), int(nnz), int(shape)))
 
     def download_rows(self, slot):
         n_rows, nnz = C.c_uint32(0), C.c_uint64(0)
@@ -323,6 +333,13 @@ class Handle:
         st = EpochStats()
         self._chk(self.lib.fmx_sgd_epoch(self.h, slot, C.byref(opts), C.byref(st)))
         return st
+
+    def sgd_batch_info(self, slot, batch=0, mode=SGD_MINIBATCH, apply=APPLY_DEFAULT):
+        """the batch fmx_sgd_epoch would run with on this slot, the rows' collision mass and the gain (fmx_batch_info)"""
+        opts = SgdOpts(mode, apply, batch, 0, 0, 0)
+        bi = BatchInfo()
+        self._chk(self.lib.fmx_sgd_batch_info(self.h, slot, C.byref(opts), C.byref(bi)))
+        return bi
 
     def partial_floats(self, batch):
         n = C.c_uint64(0)

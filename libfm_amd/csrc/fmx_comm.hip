@@ -214,6 +214,19 @@ int group_allreduce_f64(fmx_group_s* g, const std::vector<double*>& bufs, size_t
   return FMX_OK;
 }
 
+// one double summed over the ranks of a one-process-per-GPU job (the shards' shares of the rows' collision mass)
+int comm_sum_double(fmx_handle h, double* v) {
+  if (!h->comm) return FMX_OK;
+  Rccl* R = rccl();
+  if (!R) return fail(h, FMX_E_UNSUPPORTED, "comm_sum_double: %s", rccl_why());
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->acc, v, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  NCCLCHK(h, R->AllReduce(h->acc, h->acc, 1, ncclFloat64, ncclSum, (ncclComm_t)h->comm, h->stream));
+  HIPCHK(h, hipMemcpyAsync(v, h->acc, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return FMX_OK;
+}
+
 static const float* sum_of(fmx_group g, size_t i, int which) { return g->hs[i]->xbuf[which]; }
 
 // a handle leaves: its group is told (a multi-handle group becomes unusable), its communicator and buffers are released
@@ -404,7 +417,13 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
   if (opts_in->apply == FMX_APPLY_FUSED) opts.flags |= FMX_FLAG_BIAS_LAG;       // FUSED implies the lag on one device: same rule here
   const bool pipeline = (opts.flags & FMX_FLAG_PIPELINE) != 0;
   const uint32_t n_rows = g->hs[0]->slots[slot].n_rows;
-  const uint32_t B = opts.batch ? opts.batch : 262144u;
+  fmx_batch_info bi;                                              // the same batch as one unsharded handle would choose
+  cur = g->hs[0];
+  GCHK(g, sgd_resolve_batch(cur, cur->slots[slot], opts_in, &bi));
+  if ((opts_in->flags & FMX_FLAG_REJECT_UNSTABLE) && (bi.status & FMX_STAT_UNSTABLE))
+    return gfail(g, FMX_E_ARG, "batch %u on these rows: learn_rate * curvature * batch * collision mass = %.3g > 2 -- the batch rule diverges",
+                 bi.batch, bi.batch_gain);
+  const uint32_t B = bi.batch;
   opts.batch = B;
   const size_t kp1 = (size_t)g->hs[0]->KP + 1;
   const size_t cap = (size_t)std::min<uint32_t>(B, std::max<uint32_t>(n_rows, 1)) * kp1;
@@ -463,6 +482,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     stats->rows = n_rows; stats->batches = n_batch; stats->device_seconds = ms * 1e-3;
     stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = n_batch;
     stats->max_feature_count = h0->slots[slot].max_seg_count;
+    stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
   }
   return FMX_OK;
 }

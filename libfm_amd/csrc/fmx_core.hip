@@ -164,6 +164,50 @@ int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* r
   return FMX_OK;
 }
 
+// collision mass of a slot's rows (cached in the slot): one histogram pass over the entries + one reduction.  On a feature
+// shard this is the shard's share (its features only); the shares add up to the rows' C (fmx_comm.hip sums them).
+int ensure_coll_mass(fmx_handle h, Slot& s) {
+  if (s.coll_mass >= 0.0) return FMX_OK;
+  if (s.nnz == 0 || s.n_rows == 0) { s.coll_mass = 0.0; return FMX_OK; }
+  HIPCHK(h, hipSetDevice(h->device));
+  const uint32_t M = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n_local, 1), 1ull << 27);
+  float* hist = nullptr;
+  HIPCHK(h, hipMalloc(&hist, (size_t)M * sizeof(float)));
+  hipError_t er = hipMemsetAsync(hist, 0, (size_t)M * sizeof(float), h->stream);
+  if (er == hipSuccess) er = hipMemsetAsync(h->acc, 0, sizeof(double), h->stream);
+  if (er == hipSuccess) {
+    hipLaunchKernelGGL(k_coll_hist, dim3((unsigned)std::min<uint64_t>((s.nnz + 255) / 256, 8192)), dim3(256), 0, h->stream, s.ent, s.nnz, M, hist);
+    hipLaunchKernelGGL(k_coll_sumsq, dim3((unsigned)std::min<uint64_t>(((uint64_t)M + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                       (const float*)hist, M, 1.0 / (double)s.n_rows, h->acc);
+    er = hipGetLastError();
+  }
+  double c = 0.0;
+  if (er == hipSuccess) er = hipMemcpyAsync(&c, h->acc, sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+  hipFree(hist);
+  if (er != hipSuccess) return fail(h, FMX_E_HIP, "collision mass of the rows: %s", hipGetErrorString(er));
+  s.coll_mass = c;
+  return FMX_OK;
+}
+
+// the batch an epoch runs with (fmx_sgd_opts::batch): explicit, or the default cut to learn_rate * curvature * batch * C <= 1
+void resolve_batch(const fmx_config& cfg, double coll_mass, uint32_t requested, uint32_t dflt, double curv_scale, fmx_batch_info* out) {
+  const double curv = ((cfg.task == FMX_TASK_REGRESSION) ? 1.0 : 0.25) * curv_scale;
+  const double per_row = cfg.learn_rate * curv * coll_mass;         // gain of one row of batch
+  uint32_t B = requested ? requested : dflt;
+  uint32_t status = 0;
+  if (!requested && per_row > 0.0 && (double)B * per_row > 1.0) {
+    uint32_t cut = 1;
+    while ((double)(cut * 2) * per_row <= 1.0 && cut * 2 <= dflt) cut *= 2;
+    B = cut; status |= FMX_STAT_BATCH_CUT;
+  }
+  out->collision_mass = coll_mass;
+  out->batch = B;
+  out->batch_gain = (double)B * per_row;
+  if (out->batch_gain > 2.0) status |= FMX_STAT_UNSTABLE;
+  out->status = status;
+}
+
 extern "C" {
 
 int fmx_abi_version(void) { return FMX_ABI_VERSION; }
@@ -784,7 +828,8 @@ int fmx_upload_block_rows_ex(fmx_handle h, int slot, const void* entries, const 
   if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
   { int _rc = slot_in_session(h, slot, "fmx_upload_block_rows"); if (_rc) return _rc; }
   if (!relations || n_relations > FMX_MAX_RELATIONS) return fail(h, FMX_E_ARG, "fmx_upload_block_rows: 1..%d relations", FMX_MAX_RELATIONS);
-  if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "block-structured rows on a feature shard are not implemented");
+  if (h->cfg.shard_world > 1 && (flags & FMX_BLOCKS_KEEP))
+    return fail(h, FMX_E_UNSUPPORTED, "kept relation blocks on a feature shard are not implemented: upload them with FMX_BLOCKS_EXPAND");
   if (!row_ptr || (nnz > 0 && !entries)) return fail(h, FMX_E_ARG, "fmx_upload_block_rows: null entries/row_ptr");
   if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return fail(h, FMX_E_ARG, "row_ptr[0] must be 0 and row_ptr[n_rows] == nnz");
   const uint64_t n = h->cfg.num_attribute;
@@ -805,6 +850,28 @@ int fmx_upload_block_rows_ex(fmx_handle h, int slot, const void* entries, const 
         return fail(h, FMX_E_ARG, "relation %u: main row %u maps to block row %u >= %u", r, c, q.data_row_to_relation_row[c], q.n_rows);
   }
   if (flags & FMX_BLOCKS_KEEP) return upload_blocks_kept(h, slot, entries, row_ptr, target, n_rows, nnz, relations, n_relations);
+  if (h->cfg.shard_world > 1) {
+    // a feature shard: the joined rows (main entries, then every block's mapped row with its ids shifted, libfm.cpp:213-216) are
+    // built on the host and go through fmx_upload_rows, which keeps the shard's own features like for any rows
+    std::vector<uint64_t> jp((size_t)n_rows + 1, 0);
+    for (uint32_t c = 0; c < n_rows; c++) {
+      uint64_t sz = row_ptr[c + 1] - row_ptr[c];
+      for (uint32_t r = 0; r < n_relations; r++) { const uint32_t b = relations[r].data_row_to_relation_row[c]; sz += relations[r].row_ptr[b + 1] - relations[r].row_ptr[b]; }
+      jp[c + 1] = jp[c] + sz;
+    }
+    std::vector<Entry> je((size_t)jp[n_rows]);
+    for (uint32_t c = 0; c < n_rows; c++) {
+      uint64_t o = jp[c];
+      for (uint64_t i = row_ptr[c]; i < row_ptr[c + 1]; i++) je[o++] = src[i];
+      for (uint32_t r = 0; r < n_relations; r++) {
+        const fmx_relation& q = relations[r];
+        const Entry* qe = static_cast<const Entry*>(q.entries);
+        const uint32_t b = q.data_row_to_relation_row[c];
+        for (uint64_t i = q.row_ptr[b]; i < q.row_ptr[b + 1]; i++) { Entry e = qe[i]; e.id += (uint32_t)q.attr_offset; je[o++] = e; }
+      }
+    }
+    return fmx_upload_rows(h, slot, je.data(), jp.data(), target, n_rows, jp[n_rows]);
+  }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_slot(h->slots[slot]);
@@ -891,12 +958,23 @@ int fmx_download_rows(fmx_handle h, int slot, void* entries, uint64_t* row_ptr, 
 }
 
 int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz) {
+  return fmx_synth_rows_ex(h, slot, seed, row0, n_rows, nnz, FMX_SYNTH_UNIFORM);
+}
+
+int fmx_synth_rows_ex(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t shape) {
   if (!h) return FMX_E_ARG;
   if (slot < 0 || slot >= FMX_MAX_SLOTS) return fail(h, FMX_E_ARG, "slot %d out of range", slot);
   { int _rc = slot_in_session(h, slot, "fmx_synth_rows"); if (_rc) return _rc; }
   if (nnz == 0 || n_rows == 0) return fail(h, FMX_E_ARG, "fmx_synth_rows: empty workload");
+  if (shape != FMX_SYNTH_UNIFORM && shape != FMX_SYNTH_CRITEO) return fail(h, FMX_E_ARG, "fmx_synth_rows_ex: unknown shape %u", shape);
   const uint64_t n = h->cfg.num_attribute;
-  const uint32_t fs = (uint32_t)(n / nnz);
+  uint32_t fs = (uint32_t)(n / nnz);
+  if (shape == FMX_SYNTH_CRITEO) {
+    const uint64_t dense = (uint64_t)SYNTH_DENSE_FIELDS * SYNTH_DENSE_IDS;
+    if (nnz <= SYNTH_DENSE_FIELDS || n < dense + (nnz - SYNTH_DENSE_FIELDS))
+      return fail(h, FMX_E_ARG, "fmx_synth_rows_ex: the Criteo shape needs nnz > 13 and num_attribute >= 1300 + (nnz - 13)");
+    fs = (uint32_t)((n - dense) / (nnz - SYNTH_DENSE_FIELDS));
+  }
   if (fs == 0) return fail(h, FMX_E_ARG, "fmx_synth_rows: num_attribute < nnz");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -914,7 +992,7 @@ int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_
   SYN_CHK(hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
   SYN_CHK(hipMalloc(&s.target, (size_t)n_rows * sizeof(float)));
   const dim3 grid((n_rows + 255) / 256), block(256);
-  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, sh, cnt,
+  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, shape, sh, cnt,
                      (const uint64_t*)nullptr, (Entry*)nullptr, s.target);
   SYN_CHK(hipGetLastError());
   {  // exclusive prefix sum u32 -> u64 over n_rows+1 items (last = total)
@@ -928,7 +1006,7 @@ int fmx_synth_rows(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint32_
   }
   SYN_CHK(hipMemcpy(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost));
   SYN_CHK(hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
-  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, sh, (uint32_t*)nullptr,
+  hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, shape, sh, (uint32_t*)nullptr,
                      (const uint64_t*)s.row_ptr, s.ent, (float*)nullptr);
   SYN_CHK(hipGetLastError());
   SYN_CHK(hipStreamSynchronize(h->stream));

@@ -30,6 +30,7 @@ struct Slot {
   uint64_t  nnz = 0;
   uint32_t  max_row = 0;
   bool      used = false;
+  double    coll_mass = -1.0;        // collision mass of the rows (ensure_coll_mass); < 0: not computed yet
   // per-batch transposed rows for FMX_APPLY_SEGMENTED (built lazily for one batch size)
   uint32_t  seg_B = 0;
   TEntry*   t_ent = nullptr;
@@ -164,6 +165,10 @@ void free_segments(Slot& s);
 void free_slot(Slot& s);
 int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st);
 int ensure_segments(fmx_handle h, Slot& s, uint32_t B);                 // fmx_sgd.hip
+int ensure_coll_mass(fmx_handle h, Slot& s);                             // fmx_core.hip
+void resolve_batch(const fmx_config& cfg, double coll_mass, uint32_t requested, uint32_t dflt, double curv_scale, fmx_batch_info* out);
+constexpr uint32_t FMX_DEFAULT_BATCH = 262144u;                          // fmx_sgd_opts::batch = 0, before the stability cut
+int sgd_resolve_batch(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, fmx_batch_info* bi);   // fmx_sgd.hip: + the shards' shares
 int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st);   // fmx_sgd.hip
 int lag_flush(fmx_handle h);                                             // fmx_sgd.hip
 void sgda_free(fmx_handle h);                                            // fmx_sgd.hip
@@ -181,6 +186,7 @@ struct fmx_group_s {                      // fmx_comm.hip
 int group_allreduce_f64(fmx_group_s* g, const std::vector<double*>& bufs, size_t count);   // fmx_comm.hip: in place, on the shards' streams
 void comm_free(fmx_handle h);                                            // fmx_comm.hip: communicator, group membership, exchange buffers
 int comm_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats);   // fmx_comm.hip
+int comm_sum_double(fmx_handle h, double* v);                            // fmx_comm.hip
 
 #define HIPCHK(h, expr)                                                                         \
   do {                                                                                          \

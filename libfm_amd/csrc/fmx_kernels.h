@@ -898,14 +898,32 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
           for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, sf2[u][v], G[v]);
           A = fmaf(mx2, x2, A); Gw += mx2;
         }
-        for (; i2 < b; i2++) {                                // further occurrences of the feature in this batch
-          const TEntry t2 = t_ent[i2];
-          const float mx2 = mult[t2.e] * t2.x;
-          float s2[VEC];
-          load_vec<VEC>(S + (size_t)t2.e * KP + f * VEC, s2);
+        // further occurrences of the feature in this batch, TL at a time: the descriptors, then the multipliers and S rows of all
+        // TL are issued before the first is used (a frequent feature of Criteo-shaped rows has dozens to thousands per batch; one
+        // at a time this was a chain of three dependent gathers per occurrence).  Added in occurrence order, as before.
+        constexpr int TL = (VEC <= 2) ? 8 : 4;
+        for (; i2 < b; i2 += TL) {
+          TEntry tt[TL]; float mm[TL]; float s2[TL][VEC];
 #pragma unroll
-          for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[v], G[v]);
-          A = fmaf(mx2, t2.x, A); Gw += mx2;
+          for (int q = 0; q < TL; q++) { tt[q].e = 0; tt[q].x = 0.f; if (i2 + q < b) tt[q] = t_ent[i2 + q]; }
+#pragma unroll
+          for (int q = 0; q < TL; q++) {
+            mm[q] = 0.f;
+            if (i2 + q < b) { mm[q] = mult[tt[q].e]; load_vec<VEC>(S + (size_t)tt[q].e * KP + f * VEC, s2[q]); }
+            else {
+#pragma unroll
+              for (int v = 0; v < VEC; v++) s2[q][v] = 0.f;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < TL; q++) {
+            if (i2 + q < b) {
+              const float mx2 = mm[q] * tt[q].x;
+#pragma unroll
+              for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[q][v], G[v]);
+              A = fmaf(mx2, tt[q].x, A); Gw += mx2;
+            }
+          }
         }
         const float nocc = (float)(b - a);
         float nv[VEC];
@@ -1906,7 +1924,24 @@ static __global__ void k_init_params(Tab tb, uint64_t n_local, int k, int KP,
 
 // synthetic rows: field t owns ids [t*fs,(t+1)*fs); this shard keeps the ids it owns (Shard)
 // pass 1 (count==true): row_cnt[r] = #kept entries; pass 2: fill at row_ptr[r]
-static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t fs, Shard sh,
+// shape 0: uniform within field.  shape 1 ("Criteo-shaped", BASELINE configs[2]): fields 0..12 hold 100 ids each, drawn with a
+// geometric profile (a binned numeric column: bin = floor(12 * Exp(1)), capped at 99: the first bin has 8 % of the rows); the
+// other fields share the remaining ids equally (fs2 each) and draw Zipf(1.05) through the inverse CDF of the continuous
+// power law on [1, fs2 + 1): id 0 of such a field is met by 9 % of the rows at fs2 = 1.27e6.
+constexpr uint32_t SYNTH_DENSE_FIELDS = 13, SYNTH_DENSE_IDS = 100;
+__device__ __forceinline__ uint32_t synth_id(uint64_t hsh, uint32_t t, uint32_t fs, uint32_t shape) {
+  if (shape == 0) return t * fs + (uint32_t)(((hsh >> 32) * (uint64_t)fs) >> 32);
+  const double u = (double)(hsh >> 11) * (1.0 / 9007199254740992.0);          // [0, 1)
+  if (t < SYNTH_DENSE_FIELDS) {
+    const uint32_t bin = (uint32_t)fmin(99.0, floor(-12.0 * log(1.0 - u)));
+    return t * SYNTH_DENSE_IDS + bin;
+  }
+  const double e = 1.0 - 1.05;                                                  // x = (1 + u ((fs + 1)^e - 1))^(1 / e)
+  const double x = pow(1.0 + u * (pow((double)fs + 1.0, e) - 1.0), 1.0 / e);
+  const uint32_t off = (uint32_t)fmin((double)(fs - 1), fmax(0.0, floor(x) - 1.0));
+  return SYNTH_DENSE_FIELDS * SYNTH_DENSE_IDS + (t - SYNTH_DENSE_FIELDS) * fs + off;
+}
+static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, uint32_t nnz, uint32_t fs, uint32_t shape, Shard sh,
                         uint32_t* __restrict__ row_cnt, const uint64_t* __restrict__ row_ptr,
                         Entry* __restrict__ ent, float* __restrict__ target) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1914,8 +1949,7 @@ static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, ui
   uint64_t pos = row_ptr ? row_ptr[r] : 0;
   uint32_t c = 0;
   for (uint32_t t = 0; t < nnz; t++) {
-    const uint64_t hsh = synth_key(seed, row0 + r, t);
-    const uint32_t id = t * fs + (uint32_t)(((hsh >> 32) * (uint64_t)fs) >> 32);
+    const uint32_t id = synth_id(synth_key(seed, row0 + r, t), t, fs, shape);
     uint32_t jl;
     if (sh.place(id, &jl)) {
       if (ent) { ent[pos].id = jl; ent[pos].value = 1.0f; pos++; }
@@ -1923,7 +1957,30 @@ static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, ui
     }
   }
   if (row_cnt) row_cnt[r] = c;
-  if (target) target[r] = (synth_key(seed, row0 + r, 0xFFFFFFFFu) & 1) ? 1.0f : -1.0f;
+  if (target) {
+    const uint64_t hb = synth_key(seed, row0 + r, 0xFFFFFFFFu);
+    target[r] = (shape == 0 ? (hb & 1) : ((hb & 3) == 0)) ? 1.0f : -1.0f;      // Criteo-shaped: one positive in four
+  }
+}
+
+// ---- collision mass of a row set: C = sum_j (sum_rows |x_j| / n_rows)^2 (fmx_sgd_opts::batch, fmx_sgd_batch_info) ------------
+// hist[id mod M] += |x| per entry (M = table size, or 2^27 buckets for larger tables: folding can only raise C, i.e. cut the batch more)
+static __global__ void __launch_bounds__(256)
+k_coll_hist(const Entry* __restrict__ ent, uint64_t nnz, uint32_t M, float* __restrict__ hist) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x) {
+    const Entry e = ent[i];
+    unsafeAtomicAdd(hist + (e.id % M), fabsf(e.value));
+  }
+}
+static __global__ void __launch_bounds__(256)
+k_coll_sumsq(const float* __restrict__ hist, uint32_t M, double inv_rows, double* __restrict__ out) {
+  double a = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (uint64_t)gridDim.x * blockDim.x) {
+    const double f = (double)hist[i] * inv_rows;
+    a += f * f;
+  }
+  a = wave_sum_d(a);
+  if ((threadIdx.x & 63u) == 0 && a != 0.0) unsafeAtomicAdd(out, a);
 }
 
 }  // namespace fmx

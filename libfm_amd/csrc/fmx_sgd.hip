@@ -71,6 +71,7 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
   const Slot& s = h->slots[slot];
   if (row0 + n_rows > s.n_rows) return fail(h, FMX_E_ARG, "fmx_sgd_partial: rows [%llu,+%u) outside slot (%u rows)",
                                             (unsigned long long)row0, n_rows, s.n_rows);
+  if (!s.blocks.empty()) return fail(h, FMX_E_UNSUPPORTED, "relations are not supported with SGD");   // fm_learn_sgd.h:61-63
   if (!d_partial) return fail(h, FMX_E_ARG, "fmx_sgd_partial: d_partial is NULL");
   if (n_rows == 0) return FMX_OK;
   HIPCHK(h, hipSetDevice(h->device));
@@ -90,6 +91,36 @@ extern "C++" int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, ui
   KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st, s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
+}
+
+// the batch an epoch of the MINIBATCH rule runs with on this slot (fmx_sgd_opts::batch): the rows' collision mass -- summed over
+// the feature shards when the handle is one -- and the stability cut of the default
+extern "C++" int sgd_resolve_batch(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, fmx_batch_info* bi) {
+  const int slot = (int)(&s - h->slots);
+  double C = 0.0;
+  if (h->group && !h->owns_group && h->group->hs.size() > 1) {          // one process, several shards: their shares add up
+    for (fmx_handle m : h->group->hs) {
+      if (!m) return fail(h, FMX_E_STATE, "a member of the group was destroyed");
+      int rc = ensure_coll_mass(m, m->slots[slot]);
+      if (rc) { h->err = m->err; return rc; }
+      C += m->slots[slot].coll_mass;
+    }
+  } else {
+    int rc = ensure_coll_mass(h, s);
+    if (rc) return rc;
+    C = s.coll_mass;
+    if (h->comm && h->cfg.shard_world > 1) { rc = comm_sum_double(h, &C); if (rc) return rc; }   // one process per GPU
+  }
+  resolve_batch(h->cfg, C, opts ? opts->batch : 0u, FMX_DEFAULT_BATCH, 1.0, bi);
+  return FMX_OK;
+}
+
+int fmx_sgd_batch_info(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_batch_info* out) {
+  int rc = check_slot(h, slot, false);
+  if (rc) return rc;
+  if (!out) return fail(h, FMX_E_ARG, "fmx_sgd_batch_info: out is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  return sgd_resolve_batch(h, h->slots[slot], opts, out);
 }
 
 // builds the (batch, feature) segments of a slot for batch size B (device radix sort; once per data set)
@@ -240,7 +271,8 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     double* wo = w0_out ? w0_out : h->w0;
     // micro-chunks that are multiples of 256 examples: four wavefronts share a chunk (k_scan4, pieces of 1024 or 256
     // examples), else one wavefront
-    const int part = (getenv("FMX_SCAN_ONE_WAVE") || (chunk % 256u) != 0) ? 0 : ((chunk % 1024u) == 0 ? 1024 : 256);
+    // (batches of a few thousand rows: the 128 KiB-LDS workgroup costs more to place than the recurrence takes)
+    const int part = (n_rows <= 8192u || (chunk % 256u) != 0) ? 0 : ((chunk % 1024u) == 0 ? 1024 : 256);
     // (function attributes are per-device state: the 128 KiB dynamic-LDS limit is raised once per handle, not per process)
 #define FMX_SCAN4(WM, TK, PT) do { auto kf = k_scan4<WM, TK, PT>;                                                                \
       if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCAN4_LDS_BYTES)); h->lds_raised.insert((const void*)kf); } \
@@ -379,6 +411,7 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   if (rc) return rc;
   Slot& s = h->slots[slot];
   if (row0 + n_rows > s.n_rows) return fail(h, FMX_E_ARG, "fmx_sgd_finish: rows outside slot");
+  if (!s.blocks.empty()) return fail(h, FMX_E_UNSUPPORTED, "relations are not supported with SGD");   // fm_learn_sgd.h:61-63
   if (!d_partial) return fail(h, FMX_E_ARG, "fmx_sgd_finish: d_partial is NULL");
   if (((uintptr_t)d_partial & 15u) != 0) return fail(h, FMX_E_ARG, "fmx_sgd_finish: d_partial must be 16-byte aligned");
   if (n_rows == 0) return FMX_OK;
@@ -438,7 +471,7 @@ int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, fl
 // under the launches of batches b+1 .. b+d-1 and only the launch of batch b+d waits for it.
 static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, const Hyper& hy, uint64_t* batches,
                            uint64_t* launches, uint64_t* deferred) {
-  const uint32_t B = opts->batch ? opts->batch : 262144u;
+  const uint32_t B = opts->batch;                           // resolved by the caller (sgd_resolve_batch)
   const uint32_t d = opts->bias_lag ? opts->bias_lag : 1u;
   if (d > 4) return fail(h, FMX_E_ARG, "bias_lag %u: at most 4 batches", d);
   const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : default_w0_chunk(h->cfg);
@@ -448,7 +481,11 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   rc = ensure_scratch(h, (size_t)Bc * 2, (size_t)Bc * d);       // S / mult of two consecutive batches, d rest buffers
   if (rc) return rc;
   const uint64_t n_batch = ((uint64_t)s.n_rows + B - 1) / B;
-  while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+  // small batches (what the stability cut leaves of data with frequent features): a batch is a few microseconds of work, so
+  // the recurrence goes on the launch stream itself -- no side stream, no events, three launches per batch.  Same rule, same
+  // ring of bias slots: what a batch reads does not depend on which stream wrote it.
+  const bool side = B >= 32768u;
+  if (side) while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
   // FMX_FUSED_MERGE=1: the deferred features of batch b-1 ride along in the launch of batch b (FusedPrev) instead of a
   // kernel of their own between the launches.  Bit-identical results (tests/test_gpu_fullsize.py), but MEASURED SLOWER
   // (198 vs 207 M examples/s at batch 262 144, 187 vs 213 at 524 288, same box): kept as an A/B knob, off by default.
@@ -478,7 +515,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     float* rest = h->rest + (size_t)(b % d) * Bc;
     float* S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
     float* mult = h->mult + (size_t)(b & 1) * Bc;
-    if (b >= d) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (b - d) + 1], 0));   // recurrence of batch b - d is done
+    if (side && b >= d) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (b - d) + 1], 0));   // recurrence of batch b - d is done
     const double* w0_in = h->w0_pp + ((b + 1) % d);         // written by the recurrence of batch b - d (initial bias for b < d)
     FusedPrev fp;
     memset(&fp, 0, sizeof(fp));
@@ -494,28 +531,28 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     else        { KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, nullptr); }); }
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
+    if (side) HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
     if (!merged || b + 1 == n_batch) {                       // the last batch's (or, unmerged, every batch's) deferred features
       SegWork sw;
       seg_work(b, &sw);
       if (sw.nseg) {
-        // segments per wavefront of the deferred-feature pass (FMX_P2_SPW = 8 | 16 | 32 | 64: A/B knob; default 16)
-        static const int spw = getenv("FMX_P2_SPW") ? atoi(getenv("FMX_P2_SPW")) : 16;
-        if (spw == 8)       { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 8>), ((uint64_t)sw.nseg + 7) / 8, st, sw, h->tb, hy)); }
-        else if (spw == 32) { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 32>), ((uint64_t)sw.nseg + 31) / 32, st, sw, h->tb, hy)); }
-        else if (spw == 64) { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 64>), ((uint64_t)sw.nseg + 63) / 64, st, sw, h->tb, hy)); }
-        else                { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 16>), ((uint64_t)sw.nseg + 15) / 16, st, sw, h->tb, hy)); }
+        // segments per wavefront of the deferred-feature pass: 16 (measured best at the bench shape: 8 / 16 / 32 / 64 -> 244.5 / 245.0 /
+        // 243.0 / 241.0 M examples/s), fewer when the list is short (the small batches of rows with frequent features: a few
+        // hundred to a few thousand segments, many of them long) so that the pass still spreads over the chip
+        if (sw.nseg >= 16u * 2048u)     { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 16>), ((uint64_t)sw.nseg + 15) / 16, st, sw, h->tb, hy)); }
+        else if (sw.nseg >= 4u * 2048u) { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 4>), ((uint64_t)sw.nseg + 3) / 4, st, sw, h->tb, hy)); }
+        else                            { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 1>), (uint64_t)sw.nseg, st, sw, h->tb, hy)); }
         HIPCHK(h, hipGetLastError());
         *deferred += sw.nseg;
       }
     }
-    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * b], 0));
-    rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d));
+    if (side) HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * b], 0));
+    rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, side ? h->stream2 : st, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d));
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_sync[2 * b + 1], h->stream2));
+    if (side) HIPCHK(h, hipEventRecord(h->ev_sync[2 * b + 1], h->stream2));
     (*batches)++; (*launches)++;
   }
-  HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (n_batch - 1) + 1], 0));
+  if (side) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (n_batch - 1) + 1], 0));
   if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_batch % d), sizeof(double), hipMemcpyDeviceToDevice, st));
   return FMX_OK;
 }
@@ -534,6 +571,17 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     return fail(h, FMX_E_UNSUPPORTED, "feature shards train with FMX_SGD_MINIBATCH (the split step)");
   if (h->cfg.shard_world > 1 || h->comm) return comm_sgd_epoch(h, slot, opts, stats);   // (a communicator of one rank drives the same schedule)
   const Hyper hy = make_hyper(h->cfg);
+  fmx_sgd_opts ropts = *opts;                               // MINIBATCH: `batch` resolved against the rows' collision mass
+  fmx_batch_info bi; memset(&bi, 0, sizeof(bi));
+  if (opts->mode == FMX_SGD_MINIBATCH) {
+    rc = sgd_resolve_batch(h, s, opts, &bi);
+    if (rc) return rc;
+    if ((opts->flags & FMX_FLAG_REJECT_UNSTABLE) && (bi.status & FMX_STAT_UNSTABLE))
+      return fail(h, FMX_E_ARG, "batch %u on these rows: learn_rate * curvature * batch * collision mass = %.3g > 2 -- the batch rule "
+                                "diverges (collision mass %.4g; batch 0 lets the library choose)", bi.batch, bi.batch_gain, bi.collision_mass);
+    ropts.batch = bi.batch;
+    opts = &ropts;
+  }
   const bool timed = (opts->flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
   uint64_t batches = 0, main_launches = 0, deferred = 0;
   size_t ev_used = 0;
@@ -599,7 +647,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     rc = sgd_epoch_fused(h, s, opts, hy, &batches, &main_launches, &deferred);
     if (rc) return rc;
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
-    const uint32_t B = opts->batch ? opts->batch : 16384u;
+    const uint32_t B = opts->batch;
     const bool lag = (opts->flags & FMX_FLAG_BIAS_LAG) != 0;
     const uint32_t lag_depth = opts->bias_lag ? opts->bias_lag : 1u;
     if (lag_depth > 4) return fail(h, FMX_E_ARG, "bias_lag %u: at most 4 batches", lag_depth);
@@ -645,6 +693,9 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     stats->device_seconds = ms * 1e-3;
     if (opts->mode == FMX_SGD_MINIBATCH && s.seg_B) stats->max_feature_count = s.max_seg_count;
     stats->deferred_features = deferred;
+    if (opts->mode == FMX_SGD_MINIBATCH) {
+      stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
+    }
     if (opts->mode == FMX_SGD_MINIBATCH && timed && opts->apply != FMX_APPLY_FUSED) {
       double tot = 0;
       for (size_t i = 0; i + 1 < ev_used; i += 2) {
@@ -724,6 +775,7 @@ int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lam
   HIPCHK(h, hipSetDevice(h->device));
   const Slot& s = h->slots[train_slot];
   const Slot& v = h->slots[validation_slot];
+  if (!s.blocks.empty() || !v.blocks.empty()) return fail(h, FMX_E_UNSUPPORTED, "relations are not supported with SGD");   // fm_learn_sgd.h:61-63
   const Hyper hy = make_hyper(h->cfg);
   if (stats) memset(stats, 0, sizeof(*stats));
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
@@ -768,9 +820,15 @@ int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, 
   const Slot& v = h->slots[validation_slot];
   if (stats) memset(stats, 0, sizeof(*stats));
   if (s.n_rows == 0) return FMX_OK;
+  if (!s.blocks.empty() || !v.blocks.empty()) return fail(h, FMX_E_UNSUPPORTED, "relations are not supported with SGD");   // fm_learn_sgd.h:61-63
   Hyper hy = make_hyper(h->cfg);
   hy.sgda = 1; hy.reg0 = 0.f; hy.reg0_d = 0.0;                  // reg_0 = 0 (:100, :149)
-  const uint32_t B = batch ? batch : 16384u;
+  // batch 0: the default cut to the rows' stability bound; this learner's regression multiplier is 2 (p - y): twice the curvature
+  fmx_batch_info bi;
+  rc = ensure_coll_mass(h, s);
+  if (rc) return rc;
+  resolve_batch(h->cfg, s.coll_mass, batch, FMX_DEFAULT_BATCH, h->cfg.task == FMX_TASK_REGRESSION ? 2.0 : 1.0, &bi);
+  const uint32_t B = bi.batch;
   // micro-chunk of the bias: this learner's regression multiplier is 2 (p - y), i.e. twice the curvature of plain SGD
   uint32_t chunk = w0_chunk ? w0_chunk : std::max<uint32_t>(1u, default_w0_chunk(h->cfg) / (h->cfg.task == FMX_TASK_REGRESSION ? 2u : 1u));
   rc = ensure_segments(h, s, B);
@@ -832,6 +890,7 @@ int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, 
     stats->rows = s.n_rows; stats->batches = batches; stats->device_seconds = ms * 1e-3;
     stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = batches;
     stats->max_feature_count = s.max_seg_count;
+    stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
   }
   return FMX_OK;
 }

@@ -122,7 +122,7 @@ class FMLearnSGD:
 
     MODES = {"sequential": capi.SGD_SEQUENTIAL, "minibatch": capi.SGD_MINIBATCH, "hogwild": capi.SGD_HOGWILD}
     APPLY = {"default": capi.APPLY_DEFAULT, "atomic": capi.APPLY_ATOMIC, "store": capi.APPLY_STORE,
-             "segmented": capi.APPLY_SEGMENTED}
+             "segmented": capi.APPLY_SEGMENTED, "fused": capi.APPLY_FUSED}
 
     def __init__(self):
         self.fm = None
@@ -132,9 +132,11 @@ class FMLearnSGD:
         self.num_iter = 100                                     # libfm.cpp:274 default
         self.learn_rate = None                                  # no default in the reference (libfm.cpp:391-392)
         self.mode = "minibatch"
-        self.batch = 0
+        self.batch = 0                                          # 0: the library's choice (262144 cut to the rows' stability bound)
         self.w0_chunk = 0
-        self.apply = "default"
+        self.apply = "fused"                                    # the batch rule in one pass (hogwild: "default")
+        self.bias_lag = 2
+        self.reject_unstable = True                             # an explicit batch the rule diverges at raises instead of training
         self.device = -1
         self.log = []                                           # one dict per iteration (rlog fields)
         self.out = sys.stdout
@@ -169,12 +171,15 @@ class FMLearnSGD:
         print("SGD: DON'T FORGET TO SHUFFLE THE ROWS IN TRAINING DATA TO GET THE BEST RESULTS.", file=self.out)
         st = self._slot(train)
         for i in range(self.num_iter):
-            stats = self._h.sgd_epoch(st, self.MODES[self.mode], self.APPLY[self.apply], self.batch, self.w0_chunk)
-            if i == 0 and stats.max_feature_count * self.learn_rate > 1.0:
-                # the batch rule applies all occurrences of a feature inside one batch at once (include/fmx.h)
-                print("WARNING: a feature occurs %d times per batch: learn_rate * count = %g; use a smaller -batch, or "
-                      "-gpu_mode sequential / hogwild" % (stats.max_feature_count, stats.max_feature_count * self.learn_rate),
-                      file=self.out)
+            apply_ = self.APPLY[self.apply]
+            if self.mode != "minibatch" and apply_ == capi.APPLY_FUSED:
+                apply_ = capi.APPLY_DEFAULT
+            flags = capi.FLAG_REJECT_UNSTABLE if (self.reject_unstable and self.mode == "minibatch") else 0
+            stats = self._h.sgd_epoch(st, self.MODES[self.mode], apply_, self.batch, self.w0_chunk, flags,
+                                      self.bias_lag if apply_ == capi.APPLY_FUSED else 0)
+            if i == 0 and self.mode == "minibatch" and (stats.status & capi.STAT_BATCH_CUT):
+                print("libfmx: batch %d (collision mass of the rows %.4g, gain %.3g)" % (stats.batch_used, stats.collision_mass,
+                                                                                        stats.batch_gain), file=sys.stderr)
             rmse_train = self.evaluate(train)
             rmse_test = self.evaluate(test)
             print("#Iter=%3d\tTrain=%g\tTest=%g" % (i, rmse_train, rmse_test), file=self.out)   # :71

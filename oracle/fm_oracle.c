@@ -162,12 +162,25 @@ void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double l
 }
 
 static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double learn_rate, double min_target, double max_target,
-                           uint32_t batch, uint32_t w0_chunk, int bias_lag, int stale);
+                           uint32_t batch, uint32_t w0_chunk, int bias_lag, int stale, const uint8_t *hot);
 
 void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                                 double min_target, double max_target,
                                 uint32_t batch, uint32_t w0_chunk, int bias_lag) {
-  minibatch_impl(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, bias_lag, 0);
+  minibatch_impl(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, bias_lag, 0, NULL);
+}
+
+/* the same rule with a HOT set (hot[j] != 0): the linear weights of hot features advance WITH the bias in the micro-chunk
+ * recurrence of step 2 (same chunks, same multipliers me), and everybody else sees them with the bias's lag.  Why: the
+ * batch rule freezes a parameter for `batch` examples; that is harmless for a feature met once or twice per batch, but the
+ * linear weights of frequent features (a 100-id field, the head of a Zipf field) together span the same stiff direction as
+ * the bias -- a step of learn_rate * sum over the batch of [same id in some field] -- and diverge like the bias would
+ * (tests: the Criteo-shaped set of tests/datagen.py diverges at batch 1024 without a hot set, follows the online loop with
+ * one).  Still fm_sgd.h:38-43 per occurrence; batch = w0_chunk = 1 is the reference loop whatever the hot set. */
+void fmo_sgd_epoch_minibatch_hot(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                                 double min_target, double max_target,
+                                 uint32_t batch, uint32_t w0_chunk, int bias_lag, const uint8_t *hot) {
+  minibatch_impl(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, bias_lag, 0, hot);
 }
 
 /* the pipelined multi-GPU schedule (libfm_amd/distributed.py, pipeline=True): the sums of batch b+1 are gathered
@@ -178,13 +191,27 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
 void fmo_sgd_epoch_minibatch_pipelined(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                                        double min_target, double max_target,
                                        uint32_t batch, uint32_t w0_chunk, int bias_lag) {
-  minibatch_impl(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, bias_lag, 1);
+  minibatch_impl(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, bias_lag, 1, NULL);
 }
 
 static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double learn_rate, double min_target, double max_target,
-                           uint32_t batch, uint32_t w0_chunk, int bias_lag, int stale) {
+                           uint32_t batch, uint32_t w0_chunk, int bias_lag, int stale, const uint8_t *hot) {
   const int k = m->k;
   const size_t n = (size_t)m->n;
+  if (!m->k1) hot = NULL;                                      /* no linear term: nothing to advance */
+  /* hot set: slot of every hot feature, its weight at the start of the last 8 batches (what a lagged reader sees), and
+   * the chunk's gradient sums */
+  uint32_t nH = 0;
+  int64_t *hslot = NULL; uint32_t *hfeat = NULL; double *whist = NULL, *hacc = NULL; uint32_t *hcnt = NULL;
+  if (hot) {
+    hslot = (int64_t *)malloc(sizeof(int64_t) * (n ? n : 1));
+    for (size_t j = 0; j < n; j++) hslot[j] = hot[j] ? (int64_t)nH++ : -1;
+    hfeat = (uint32_t *)malloc(sizeof(uint32_t) * (nH ? nH : 1));
+    for (size_t j = 0; j < n; j++) if (hslot[j] >= 0) hfeat[hslot[j]] = (uint32_t)j;
+    whist = (double *)malloc(sizeof(double) * 8 * (nH ? nH : 1));
+    hacc = (double *)calloc(nH ? nH : 1, sizeof(double));
+    hcnt = (uint32_t *)calloc(nH ? nH : 1, sizeof(uint32_t));
+  }
   if (batch == 0 || batch > d->n_rows) batch = d->n_rows;
   if (w0_chunk == 0 || w0_chunk > batch) w0_chunk = batch;
   const size_t kk = (size_t)(k > 0 ? k : 1);
@@ -208,13 +235,18 @@ static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double lea
     uint32_t nb = (d->n_rows - r0 < batch) ? (d->n_rows - r0) : batch;
     const double *w_src = (stale && r0 > 0) ? w_prev : m->w;
     const double *v_src = (stale && r0 > 0) ? v_prev : m->v;
-    /* step 1: sums from batch-start parameters (fm_model.h:110-126 without the bias) */
+    /* which snapshot a lagged reader of batch bno sees (bias and hot linear weights alike) */
+    if (hot) for (uint32_t s = 0; s < nH; s++) whist[(size_t)(bno % 8) * nH + s] = m->w[hfeat[s]];
+    const uint32_t lag_snap = (bias_lag > 0 && bno + 1 >= (uint32_t)bias_lag) ? bno + 1 - (uint32_t)bias_lag : (bias_lag > 0 ? 0 : bno);
+    const double *w_lag = hot ? whist + (size_t)(lag_snap % 8) * nH : NULL;
+    /* step 1: sums from batch-start parameters (fm_model.h:110-126 without the bias); hot linear weights: lagged snapshot */
     for (uint32_t e = 0; e < nb; e++) {
       const fmo_entry *row = d->entries + d->row_ptr[r0 + e];
       uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
       double res = 0;
       if (m->k1)
-        for (uint32_t i = 0; i < size; i++) res += w_src[row[i].id] * row[i].value;
+        for (uint32_t i = 0; i < size; i++)
+          res += ((hot && hslot[row[i].id] >= 0) ? w_lag[hslot[row[i].id]] : w_src[row[i].id]) * row[i].value;
       for (int f = 0; f < k; f++) {
         double s = 0, q = 0;
         for (uint32_t i = 0; i < size; i++) {
@@ -242,12 +274,42 @@ static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double lea
       double acc = 0;
       for (uint32_t e = c0; e < c0 + nc; e++) {
         double p = w0s + rest[e];
+        if (hot) {                                             /* the hot weights as they are at the chunk start, not the snapshot */
+          const fmo_entry *row = d->entries + d->row_ptr[r0 + e];
+          uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
+          for (uint32_t i = 0; i < size; i++) {
+            const int64_t s = hslot[row[i].id];
+            if (s >= 0) p += (m->w[row[i].id] - w_lag[s]) * row[i].value;
+          }
+        }
         double me = fmo_multiplier(task, p, (double)d->target[r0 + e], min_target, max_target);
         mult[e] = bias_lag ? fmo_multiplier(task, w0_batch + rest[e], (double)d->target[r0 + e], min_target, max_target) : me;
         acc += me + m->reg0 * w0s;
+        if (hot) {
+          const fmo_entry *row = d->entries + d->row_ptr[r0 + e];
+          uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
+          for (uint32_t i = 0; i < size; i++) {
+            const int64_t s = hslot[row[i].id];
+            if (s >= 0) { hacc[s] += me * row[i].value; hcnt[s]++; }
+          }
+        }
         if (nc == 1 && m->k0) m->w0 -= learn_rate * (me + m->reg0 * m->w0);  /* literal form at chunk 1 */
       }
       if (m->k0 && nc != 1) m->w0 -= learn_rate * acc;
+      if (hot) {                                               /* fm_sgd.h:38-43 per occurrence, from the chunk-start weight */
+        for (uint32_t e = c0; e < c0 + nc; e++) {
+          const fmo_entry *row = d->entries + d->row_ptr[r0 + e];
+          uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
+          for (uint32_t i = 0; i < size; i++) {
+            const int64_t s = hslot[row[i].id];
+            if (s >= 0 && hcnt[s]) {
+              double *w = &m->w[row[i].id];
+              *w -= learn_rate * (hacc[s] + (double)hcnt[s] * m->regw * (*w));
+              hacc[s] = 0.0; hcnt[s] = 0;
+            }
+          }
+        }
+      }
     }
     if (stale) {                                               /* what batch b+1's early gather will see */
       memcpy(w_prev, m->w, sizeof(double) * n);
@@ -259,6 +321,7 @@ static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double lea
       uint32_t size = (uint32_t)(d->row_ptr[r0 + e + 1] - d->row_ptr[r0 + e]);
       if (m->k1)
         for (uint32_t i = 0; i < size; i++) {
+          if (hot && hslot[row[i].id] >= 0) continue;          /* advanced by the recurrence of step 2 */
           double w = m->w[row[i].id];
           dw[row[i].id] += -(learn_rate * (mult[e] * row[i].value + m->regw * w));
         }
@@ -285,6 +348,7 @@ static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double lea
     }
   }
   free(S); free(rest); free(mult); free(sum_sqr); free(dw); free(dv); free(w_prev); free(v_prev);
+  free(hslot); free(hfeat); free(whist); free(hacc); free(hcnt);
 }
 
 /* ------------------------------- SGDA ------------------------------- */

@@ -108,6 +108,14 @@ void fmo_sgd_epoch_minibatch(fmo_model *m, const fmo_data *d, int task, double l
 void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                                 double min_target, double max_target,
                                 uint32_t batch, uint32_t w0_chunk, int bias_lag);
+/* the same with a HOT set (hot[j] != 0, [n] bytes; NULL = none): the linear weights of the hot features advance with the bias
+ * in step 2 -- inside a micro-chunk every example sees w0 and the hot w_j of the chunk start, p_e = w0 + rest_e with the hot
+ * part of rest_e re-evaluated from them; after the chunk w_j -= lr * sum_{e in chunk, j in e}(mult_e * x + regw * w_j)
+ * (fm_sgd.h:38-43 per occurrence) -- and step 3 leaves them alone.  Readers that lag the bias (bias_lag) see the hot weights
+ * with the same lag.  Everything else (V of all features, w of the others) is the rule above.  GPU: fmx_sgd_opts::hot_count. */
+void fmo_sgd_epoch_minibatch_hot(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                                 double min_target, double max_target,
+                                 uint32_t batch, uint32_t w0_chunk, int bias_lag, const uint8_t *hot);
 /* the pipelined multi-GPU schedule: step 1 of batch b reads the parameters as they were BEFORE the update of batch
  * b-1 was applied (the gather of batch b overlaps the exchange / update of batch b-1); everything else as above. */
 void fmo_sgd_epoch_minibatch_pipelined(fmo_model *m, const fmo_data *d, int task, double learn_rate,

@@ -69,6 +69,7 @@ def lib():
         L.fmo_sgd_epoch_minibatch.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32]
         L.fmo_sgd_epoch_minibatch_ex.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_int]
         L.fmo_sgd_epoch_minibatch_pipelined.argtypes = L.fmo_sgd_epoch_minibatch_ex.argtypes
+        L.fmo_sgd_epoch_minibatch_hot.argtypes = L.fmo_sgd_epoch_minibatch_ex.argtypes + [C.c_void_p]
         L.fmo_multiplier.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.fmo_multiplier.restype = C.c_double
         L.fmo_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -213,12 +214,28 @@ def sgd_epoch_online(m, d, task, lr, min_target, max_target):
     m.w0 = cm.w0
 
 
-def sgd_epoch_minibatch(m, d, task, lr, min_target, max_target, batch, w0_chunk, bias_lag=False, pipelined=False):
-    """pipelined: the multi-GPU overlap schedule -- the sums of a batch are gathered one update early (fm_oracle.h)"""
+def sgd_epoch_minibatch(m, d, task, lr, min_target, max_target, batch, w0_chunk, bias_lag=False, pipelined=False, hot=None):
+    """pipelined: the multi-GPU overlap schedule -- the sums of a batch are gathered one update early (fm_oracle.h).
+    hot: bool / uint8 [n] flags of the features whose linear weight advances with the bias (fmo_sgd_epoch_minibatch_hot)."""
     cm, cd = m._c(), d._c()
-    fn = lib().fmo_sgd_epoch_minibatch_pipelined if pipelined else lib().fmo_sgd_epoch_minibatch_ex
-    fn(C.byref(cm), C.byref(cd), task, lr, min_target, max_target, batch, w0_chunk, int(bias_lag))
+    if hot is not None:
+        assert not pipelined
+        hot = np.ascontiguousarray(hot, dtype=np.uint8)
+        assert hot.shape == (m.n,)
+        lib().fmo_sgd_epoch_minibatch_hot(C.byref(cm), C.byref(cd), task, lr, min_target, max_target, batch, w0_chunk, int(bias_lag),
+                                          hot.ctypes.data)
+    else:
+        fn = lib().fmo_sgd_epoch_minibatch_pipelined if pipelined else lib().fmo_sgd_epoch_minibatch_ex
+        fn(C.byref(cm), C.byref(cd), task, lr, min_target, max_target, batch, w0_chunk, int(bias_lag))
     m.w0 = cm.w0
+
+
+def hot_features(d, n, batch, hot_count):
+    """the hot set of a data set as the library defines it (fmx_sgd_opts::hot_count): features that occur at least hot_count
+    times per batch on average, i.e. count_j * batch >= hot_count * n_rows (batch clipped to the data set)."""
+    cnt = np.bincount(d.entries["id"], minlength=n).astype(np.int64)
+    b = min(int(batch), d.n_rows) if batch else d.n_rows
+    return (cnt * b >= int(hot_count) * d.n_rows) & (cnt > 0)
 
 
 def synth_rows(seed, row0, n_rows, nnz, n):

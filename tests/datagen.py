@@ -118,3 +118,56 @@ def expand_blocks(main_entries, main_row_ptr, blocks, maps, num_main_attr):
         vals.append(rv)
     ent, rp, _ = _pack(ids, vals, np.zeros(len(ids)))
     return ent, rp, offs
+
+
+def criteo_shaped(n_rows, seed, n_dense=13, dense_ids=100, n_cat=26, cat_ids=5000, zipf=1.05, classification=True):
+    """BASELINE configs[2] / SURVEY section 8d in small: n_dense "numeric" fields binned into <= dense_ids ids with a geometric
+    profile (bin = floor(12 Exp(1)): the first bin holds 8 % of the rows) + n_cat categorical fields Zipf(zipf) over cat_ids ids
+    each (the head id of a field is met by ~12 % of the rows at cat_ids = 5000), values 1.0; labels from a planted FM with a
+    click-through-like 1:3.5 imbalance.  Returns (entries, row_ptr, target, n)."""
+    rng = np.random.default_rng(seed)
+    z = n_dense + n_cat
+    offs = np.concatenate([[0], np.cumsum([dense_ids] * n_dense + [cat_ids] * n_cat)])
+    n = int(offs[-1])
+    p = 1.0 / np.arange(1, cat_ids + 1) ** zipf
+    p /= p.sum()
+    cols = []
+    for t in range(z):
+        if t < n_dense:
+            c = np.minimum(rng.exponential(12.0, n_rows).astype(np.int64), dense_ids - 1)
+        else:
+            c = rng.choice(cat_ids, size=n_rows, p=p)
+        cols.append(c + offs[t])
+    idm = np.stack(cols, 1)
+    wtrue = rng.normal(0, 0.6, n)
+    vtrue = rng.normal(0, 0.25, (n, 4))
+    sv = vtrue[idm]
+    s = wtrue[idm].sum(1) / np.sqrt(z) + 0.5 * ((sv.sum(1) ** 2).sum(1) - (sv ** 2).sum((1, 2))) / z
+    s = s - np.median(s) - 0.8
+    if classification:
+        y = np.where(rng.random(n_rows) < 1.0 / (1.0 + np.exp(-2.0 * s)), 1.0, -1.0)
+    else:
+        y = np.round(s + rng.normal(0, 0.3, n_rows), 3)
+    ent = np.zeros(n_rows * z, dtype=ENTRY_DTYPE)
+    ent["id"] = idm.reshape(-1).astype(np.uint32)
+    ent["value"] = 1.0
+    row_ptr = np.arange(n_rows + 1, dtype=np.uint64) * np.uint64(z)
+    return ent, row_ptr, y.astype(np.float32), n
+
+
+def collision_mass(entries, n_rows, n):
+    """C of fmx_sgd_opts::batch: sum over features of (sum over rows of |x_j| / n_rows)^2"""
+    cnt = np.bincount(entries["id"], weights=np.abs(entries["value"].astype(np.float64)), minlength=n)
+    return float(((cnt / n_rows) ** 2).sum())
+
+
+def stable_batch(lr, task, C, default=262144, curv_scale=1.0):
+    """the library's choice for fmx_sgd_opts::batch = 0 (fmx_core.hip resolve_batch): the default, cut to the largest power of two
+    with lr * curvature * batch * C <= 1"""
+    per_row = lr * (1.0 if task == 0 else 0.25) * curv_scale * C
+    if per_row <= 0 or default * per_row <= 1.0:
+        return default
+    b = 1
+    while (b * 2) * per_row <= 1.0 and b * 2 <= default:
+        b *= 2
+    return b

@@ -1,0 +1,187 @@
+"""GPU: frequent features (BASELINE configs[2]).  The library chooses the batch of the minibatch rule from the
+rows' collision mass (fmx_sgd_opts::batch = 0); with it the product's default mode trains Criteo-shaped rows and lands on the
+REAL reference's metrics; an explicit batch beyond the stability bound is reported (FMX_STAT_UNSTABLE) or refused
+(FMX_FLAG_REJECT_UNSTABLE)."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import datagen as DG
+from common import Golden
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+HARNESS_GPU = os.path.join(ROOT, "oracle", "_ref", "ref_harness_gpu")
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from libfm_amd import capi as c
+    if c.load().fmx_device_count() == 0:
+        pytest.fail("no HIP device: the GPU tests must run on the MI355X box")
+    return c
+
+
+def criteo(rows, seed=5, cat_ids=2000):
+    return DG.criteo_shaped(rows, seed, cat_ids=cat_ids)
+
+
+def test_batch_info_is_the_collision_mass_rule(capi):
+    e, rp, y, n = criteo(20000)
+    C = DG.collision_mass(e, 20000, n)
+    for task, lr in ((capi.TASK_CLASSIFICATION, 0.01), (capi.TASK_REGRESSION, 0.002)):
+        h = capi.Handle(n, 8, True, True, task, 0.0, 0.0, 0.001, lr, -1.0, 1.0, device=0)
+        h.upload_rows(0, e, rp, y)
+        bi = h.sgd_batch_info(0)
+        assert abs(bi.collision_mass - C) <= 1e-5 * C
+        assert bi.batch == DG.stable_batch(lr, task, C) and bi.batch < 4096
+        assert bi.status & capi.STAT_BATCH_CUT and not (bi.status & capi.STAT_UNSTABLE)
+        assert abs(bi.batch_gain - lr * (1.0 if task == 0 else 0.25) * bi.batch * C) < 1e-9
+        big = h.sgd_batch_info(0, batch=16384)
+        assert big.batch == 16384 and big.status & capi.STAT_UNSTABLE
+        h.close()
+    # uniform ids over a wide table: nothing to cut
+    h = capi.Handle(10_000_000, 8, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0)
+    h.synth_rows(0, 3, 0, 50000, 16)
+    bi = h.sgd_batch_info(0)
+    assert bi.batch == 262144 and bi.status == 0 and bi.collision_mass < 1e-3
+    h.close()
+
+
+def test_shards_add_up_to_the_same_batch(capi):
+    e, rp, y, n = criteo(8000)
+    h = capi.Handle(n, 8, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0)
+    h.upload_rows(0, e, rp, y)
+    one = h.sgd_batch_info(0)
+    h.close()
+    hs = [capi.Handle(n, 8, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0,
+                      shard_rank=r, shard_world=3, shard_hash=1) for r in range(3)]
+    for s in hs:
+        s.upload_rows(0, e, rp, y)
+    g = capi.Group(hs)
+    bi = hs[1].sgd_batch_info(0)
+    assert bi.batch == one.batch and abs(bi.collision_mass - one.collision_mass) <= 1e-5 * one.collision_mass
+    g.close()
+    for s in hs:
+        s.close()
+
+
+@pytest.mark.parametrize("apply_,lag", [("fused", 2), ("fused", 1), ("segmented", 0)])
+def test_default_batch_on_criteo_shaped_rows_is_the_oracle_rule(capi, oracle, apply_, lag):
+    """batch = 0: dozens of small batches per epoch (the in-stream recurrence path), every feature of the dense fields in every
+    batch's deferred list -- against the oracle's rule at the batch the library chose, 1e-4"""
+    O = oracle
+    e, rp, y, n = criteo(6000)
+    d = O.Data(e, rp, y)
+    m = O.Model(n, 8, True, True, 0.0, 0.0005, 0.001)
+    m.v[:] = O.init_values(1, n, 8, 0.05)
+    h = capi.Handle(n, 8, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0005, 0.001, 0.01, -1.0, 1.0, device=0)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, e, rp, y)
+    B = h.sgd_batch_info(0).batch
+    assert B == DG.stable_batch(0.01, 1, DG.collision_mass(e, 6000, n)) and 6000 // B >= 10
+    for _ in range(2):
+        if apply_ == "fused":
+            st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)
+        else:
+            st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 0, 0, 0, 0)
+        assert st.batch_used == B and st.status == capi.STAT_BATCH_CUT and st.batch_gain <= 1.0
+        O.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, B, min(256, B), bias_lag=lag)
+    w0, w, v = h.get_params()
+    np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(w, m.w, rtol=1e-4, atol=2e-5)
+    assert abs(w0 - m.w0) <= 1e-4 * abs(m.w0) + 2e-5
+    h.close()
+
+
+def test_segments_of_a_thousand_occurrences_match_the_oracle(capi, oracle):
+    """an explicit batch far beyond the stability bound is still the batch rule, exactly: one batch in which the head ids occur
+    1 000+ times (the longest segments k_apply_seg sums) vs the oracle at 1e-4; the epoch is flagged FMX_STAT_UNSTABLE and,
+    on request, refused"""
+    O = oracle
+    e, rp, y, n = criteo(16384)
+    d = O.Data(e, rp, y)
+    m = O.Model(n, 16, True, True, 0.0, 0.0, 0.001)
+    m.v[:] = O.init_values(2, n, 16, 0.02)
+    h = capi.Handle(n, 16, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.002, -1.0, 1.0, device=0)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, e, rp, y)
+    st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 8192, 256, 0, 1)
+    assert st.max_feature_count >= 1000 and st.batch_used == 8192
+    assert st.status & capi.STAT_UNSTABLE and st.batch_gain > 2.0
+    O.sgd_epoch_minibatch(m, d, 1, 0.002, -1.0, 1.0, 8192, 256, bias_lag=1)
+    w0, w, v = h.get_params()
+    np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(w, m.w, rtol=1e-4, atol=2e-5)
+    with pytest.raises(capi.FmxError) as ei:
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 8192, 256, capi.FLAG_REJECT_UNSTABLE, 1)
+    assert ei.value.code == -1 and "diverges" in ei.value.text
+    h.close()
+
+
+def _run_harness(exe, mode, O, tr, te, task, k, iters, lr, reg, stdev, seed, td, tag):
+    trf, tef, pre = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm"), os.path.join(td, tag)
+    if not os.path.exists(trf):
+        tr.write_libsvm(trf)
+        te.write_libsvm(tef)
+    cfg = [mode, trf, tef, task, 1, 1, k, iters, repr(lr), repr(reg[0]), repr(reg[1]), repr(reg[2]), repr(stdev), seed, pre]
+    r = subprocess.run([exe] + [str(c) for c in cfg], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    ev = np.loadtxt(pre + ".eval.txt", ndmin=2)
+    pred = np.fromfile(pre + ".pred_out.bin", dtype=np.float64)
+    return ev[-1], pred, r
+
+
+def test_default_mode_lands_on_the_real_reference_criteo_shaped(oracle):
+    """BASELINE configs[2] in small (39 fields: 13 x <= 100 ids, 26 x Zipf 1.05): the REAL reference (fm_learn_sgd_element,
+    compiled from its own sources, CPU) against the product's default mode through the reference-side adapter (one-pass batch
+    rule, batch chosen from the collision mass).  Bands: accuracy +-0.005, log loss of the -out probabilities +-0.005."""
+    if not (os.path.exists(HARNESS_GPU) and os.path.exists(HARNESS)):
+        pytest.skip("oracle/_ref harnesses not built (need /root/reference at build time)")
+    O = oracle
+    e, rp, y, n = DG.criteo_shaped(50000, 11, cat_ids=5000)
+    z, ntr = 39, 40000
+    y01 = np.where(y > 0, 1.0, 0.0).astype(np.float32)               # the reference rewrites <= 0 to -1 itself (libfm.cpp:302-306)
+    tr = O.Data(e[:ntr * z], rp[:ntr + 1], y01[:ntr])
+    te = O.Data(e[ntr * z:], rp[ntr:] - rp[ntr], y01[ntr:])
+    with tempfile.TemporaryDirectory() as td:
+        a = _run_harness(HARNESS, "sgd", O, tr, te, "c", 8, 4, 0.01, (0.0, 0.0, 0.001), 0.01, 42, td, "ref")
+        b = _run_harness(HARNESS_GPU, "sgd_gpu", O, tr, te, "c", 8, 4, 0.01, (0.0, 0.0, 0.001), 0.01, 42, td, "gpu")
+    assert "libfmx: batch" in b[2].stderr                             # the adapter reports the cut
+    yt = np.where(y[ntr:] > 0, 1.0, -1.0)
+
+    def ll(p):
+        p = np.clip(p, 1e-12, 1 - 1e-12)
+        return float(-np.mean(np.where(yt > 0, np.log(p), np.log(1 - p))))
+    assert np.abs(a[0] - b[0]).max() <= 0.005, (a[0], b[0])            # accuracy train / test
+    assert abs(ll(a[1]) - ll(b[1])) <= 0.005, (ll(a[1]), ll(b[1]))
+    assert a[0][0] > 0.80                                              # the reference did learn (train accuracy; base rate 0.78)
+
+
+def test_default_mode_lands_on_the_real_reference_config0():
+    """BASELINE configs[0] (ML-100K-shaped, k = 8, 20 iterations): the golden fixture holds the STOCK binary's result (0.571616 /
+    0.627836); the product's default mode (one-pass batch rule, library-chosen batch) must end within |dRMSE| <= 0.003 of it,
+    train and test, and stay within 0.01 of it on the way (every iteration's line)."""
+    import io
+    from libfm_amd import learner as L
+    from conftest import GOLDEN_DIR
+    Z = np.load(os.path.join(GOLDEN_DIR, "c1_ml100k_shaped.npz"))
+    train = L.Data(Z["train_entries"], Z["train_row_ptr"].astype(np.uint64), Z["train_target"])
+    test = L.Data(Z["test_entries"], Z["test_row_ptr"].astype(np.uint64), Z["test_target"])
+    fm = L.FMModel()
+    fm.num_attribute, fm.num_factor, fm.regv = 943 + 1682, 8, 0.01
+    fm.w0, fm.w, fm.v = float(Z["init_w0"]), Z["init_w"].copy(), Z["init_v"].copy()
+    l = L.FMLearnSGD()
+    l.fm, l.task, l.num_iter, l.learn_rate = fm, 0, 20, 0.01
+    l.min_target, l.max_target = train.min_target, train.max_target
+    l.out = io.StringIO()
+    l.init()
+    l.learn(train, test)
+    lines = np.array([[float(x.split("=")[1]) for x in ln.split("\t")[1:3]] for ln in l.out.getvalue().splitlines() if ln.startswith("#Iter=")])
+    l.close()
+    assert np.abs(lines[-1] - Z["stdout_iters"][-1]).max() <= 0.003, (lines[-1], Z["stdout_iters"][-1])
+    assert np.abs(lines[2:] - Z["stdout_iters"][2:]).max() <= 0.01
