@@ -126,52 +126,167 @@ def als_bytes_per_sweep(n_rows, nnz_total, n_seen, k):
     return fam + loadq + eterms + n_rows * 36
 
 
-def bench_als(args, capi):
-    """--method als | mcmc: one step = one sweep (fmx_als_sweep) over `--rows` examples, one GPU"""
-    import torch
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
-        raise SystemExit("--method als/mcmc: one GPU (feature shards of the sweep go through fmx_group_*, see tests/test_gpu_group.py)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
-    sample = args.method == "mcmc"
-    h = capi.Handle(args.n, args.k, True, True, capi.TASK_REGRESSION, 0.0, 1.0, 10.0, 0.0, -1.0, 1.0, device=0)
+def cpu_reference_mcmc(method, k, nnz, rows=150000, n=1500000):
+    """cpu_baseline of the als / mcmc figures: the REAL reference's fm_learn_mcmc::learn (src/libfm/src/fm_learn_mcmc.h:430-641,
+    1160-1201 through fm_learn_mcmc_simultaneous.h:56-270; oracle/_ref/ref_harness als | mcmc), one thread, ONE iteration on a
+    bounded sample of the same synthetic rows (fewer rows and features than the GPU leg: the reference needs ~27 ns per entry and
+    factor)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(exe):
+        return None
+    from oracle import oracle as O
+    d = O.synth_rows(123, 0, rows, nnz, n)
+    with tempfile.TemporaryDirectory() as td:
+        trf, tef = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm")
+        d.write_libsvm(trf)
+        O.Data(d.entries[:nnz * 100], d.row_ptr[:101], d.target[:100]).write_libsvm(tef)
+        # the last id must appear so that the reference sizes the model like the GPU leg's sample (num_feature = max id + 1)
+        with open(trf, "a") as f:
+            f.write("1 %d:1\n" % (n - 1))
+        cfg = [exe, method, trf, tef, "r", "1", "1", str(k), "1"] + (["0", "1", "10"] if method == "als" else []) + ["0.01", "1", os.path.join(td, "o")]
+        r = subprocess.run(cfg, capture_output=True, text=True)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-200:]}
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{\"learn_seconds\"")]
+    if not line:
+        return {"error": "no timing line"}
+    t = json.loads(line[-1])
+    return {"value": round(t["rows"] * t["iters"] / t["learn_seconds"], 1), "unit": "examples/s", "cores": 1, "kind": "reference",
+            "sample": "1 iteration of the reference's fm_learn_mcmc (%s) over %d synthetic rows, n=%d k=%d nnz=%d (oracle/_ref/ref_harness %s); "
+                      "the GPU leg runs n=1e7 and 100x the rows" % ("do_sample" if method == "mcmc" else "ALS", t["rows"], n, k, nnz, method),
+            "seconds": round(t["learn_seconds"], 3), "host_cores": os.cpu_count() or 1}
+
+
+def run_als(capi, method, n, k, nnz, rows, steps, warmup, with_cpu):
+    """one step = one sweep (fmx_als_sweep) over `rows` examples, one GPU; returns the figure as a dict"""
+    sample = method == "mcmc"
+    h = capi.Handle(n, k, True, True, capi.TASK_REGRESSION, 0.0, 1.0, 10.0, 0.0, -1.0, 1.0, device=0)
     h.init_params(0.0, 0.01, 1)
-    h.synth_rows(0, 123, 0, args.rows, args.nnz)
+    h.synth_rows(0, 123, 0, rows, nnz)
     info = h.info()
     h.als_begin(0)
-    for i in range(args.warmup):
+    for i in range(warmup):
         h.als_sweep(1.0, 10.0, do_sample=sample, seed=i)
     h.synchronize()
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     dev = 0.0
-    for i in range(args.steps):
+    for i in range(steps):
         st = h.als_sweep(1.0, 10.0, do_sample=sample, seed=100 + i)
         dev += st.device_seconds
     h.synchronize()
-    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    nnz_total = args.rows * args.nnz
-    n_seen = min(args.n, nnz_total)
-    per_sweep = als_bytes_per_sweep(args.rows, nnz_total, n_seen, args.k)
-    achieved = per_sweep / (dev / args.steps) / 1e9
+    nnz_total = rows * nnz
+    n_seen = min(n, nnz_total)
+    per_sweep = als_bytes_per_sweep(rows, nnz_total, n_seen, k)
+    achieved = per_sweep / (dev / steps) / 1e9
     out = {"metric": "%s (fm_learn_mcmc%s) training examples/sec per sweep at k=%d, nnz=%d, %.0e feat"
-                     % (args.method.upper(), ", do_sample" if sample else "", args.k, args.nnz, args.n),
-           "value": round(args.steps * args.rows / elapsed, 1), "unit": "examples/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                     % (method.upper(), ", do_sample" if sample else "", k, nnz, n),
+           "value": round(steps * rows / elapsed, 1), "unit": "examples/s", "n_gpus": 1, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f64 caches / f32 parameters", "data": "synthetic",
            "config": {"workload": "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/sweep, task=r, lambda_w=1 lambda_v=10"
-                                  % (args.n, args.k, args.nnz, args.rows),
-                      "method": args.method, "levels": st.levels, "device": info.device_name.decode(), "arch": info.arch.decode()},
+                                  % (n, k, nnz, rows),
+                      "method": method, "levels": st.levels, "device": info.device_name.decode(), "arch": info.arch.decode()},
            "roofline": {"bound": "hbm", "kernel": "k_als_draw<v> + k_als_rows<v> (80 % of the sweep) + re-prediction; whole sweep",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "bytes_per_sweep": per_sweep, "avg_sweep_ms": round(dev / args.steps * 1e3, 3),
+                        "traffic": None, "bytes_per_sweep": per_sweep, "avg_sweep_ms": round(dev / steps * 1e3, 3),
                         "note": "bound by the fabric's random-request rate, not by bytes: the column sums gather one 16-byte {e,q} "
                                 "per entry at 48 G requests/s (55 G/s is what a random 4..16-byte read gets on this part, "
                                 "scripts/ubench/w_gather); the update runs as a row-ordered stream (DESIGN.md section 4b)"},
-           "cpu_baseline": None}
+           "cpu_baseline": cpu_reference_mcmc(method, k, nnz) if with_cpu else None}
     h.als_end()
     h.close()
+    return out
+
+
+def bench_als(args, capi):
+    """--method als | mcmc: one step = one sweep (fmx_als_sweep) over `--rows` examples, one GPU"""
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--method als/mcmc: one GPU (feature shards of the sweep go through fmx_group_*, see tests/test_gpu_group.py)")
+    if capi.load().fmx_device_count() == 0:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    out = run_als(capi, args.method, args.n, args.k, args.nnz, args.rows, args.steps, args.warmup, not args.no_cpu_baseline)
+    print(json.dumps(out), flush=True)
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def bench_group(args, capi, criteo):
+    """--gpus N from ONE process (the shape libFM has, libfm.cpp:271-293,415): N feature shards, one handle each, tied together by
+    fmx_group_create -- RCCL between distinct devices, the loopback reduction when they share one (--same-device: the N > 1 code
+    path on a one-GPU box) -- and driven by fmx_group_sgd_epoch.  The rule is the one N = 1 runs."""
+    N = args.gpus
+    ndev = capi.load().fmx_device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if not args.same_device and ndev < N:
+        raise SystemExit("--gpus %d but %d HIP device(s) visible (--same-device puts every shard on device 0)" % (N, ndev))
+    lr, regv = 0.01, 0.001
+    hs = [capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
+                      device=0 if args.same_device else r, shard_rank=r, shard_world=N, shard_hash=1) for r in range(N)]
+    for h in hs:
+        h.init_params(0.0, 0.01, 1)
+        h.synth_rows(0, 123, 0, args.rows, args.nnz, capi.SYNTH_CRITEO if criteo else capi.SYNTH_UNIFORM)
+    info = hs[0].info()
+    g = capi.Group(hs)
+    lagf = 0 if args.no_bias_lag else capi.FLAG_BIAS_LAG
+    flags = lagf | (capi.FLAG_PIPELINE if args.pipeline else 0)
+    lag = args.bias_lag if lagf else 0
+
+    def sync():
+        for h in hs:
+            h.synchronize()
+    for _ in range(args.warmup):
+        g.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, args.batch, args.w0_chunk, flags, lag)
+    sync()
+    phases, dev_s, st = [0.0, 0.0, 0.0], 0.0, None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = g.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, args.batch, args.w0_chunk, flags | capi.FLAG_TIME_MAIN_KERNEL, lag)
+        dev_s += st.device_seconds
+        for i in range(3):
+            phases[i] += st.phase_seconds[i]
+    sync()
+    elapsed = time.perf_counter() - t0
+    value = args.steps * args.rows / elapsed
+    n_batches = max(1, int(st.batches)) * args.steps
+    per_ex = algorithmic_bytes(args.k, args.nnz, "rowsums") + algorithmic_bytes(args.k, args.nnz, "apply")
+    achieved = value * per_ex / N / 1e9
+    wire = 4 * (info.k_padded + 1)
+    out = {
+        "metric": "SGD training examples/sec at k=%d, nnz=%d, %.0e feat" % (args.k, args.nnz, args.n),
+        "value": round(value, 1), "unit": "examples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
+                               % ("Criteo-shaped" if criteo else "synthetic one-hot fields", args.n, args.k, args.nnz, args.rows, lr, regv),
+                   "mode": "minibatch (split step)", "batch": int(st.batch_used), "w0_chunk": args.w0_chunk or 256, "bias_lag": lag,
+                   "pipeline": bool(args.pipeline), "sharding": "feature-id hash (permutation) over %d shards" % N,
+                   "driver": "one process, fmx_group (%s)" % ("loopback: all shards on device 0" if args.same_device else "RCCL, one communicator per device"),
+                   "batch_rule": {"batch": int(st.batch_used), "collision_mass": round(st.collision_mass, 6), "gain": round(st.batch_gain, 4)},
+                   "device": info.device_name.decode(), "arch": info.arch.decode()},
+        "roofline": {"bound": "hbm", "kernel": "k_rowsums + update (whole step, per GPU)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "v_read_frac": v_read_fraction(value, args.k, args.nnz, N),
+                     "traffic": None, "bytes_per_example": per_ex, "examples_per_launch": int(st.batch_used)},
+        "exchange": {"collective": "all_reduce(sum) fp32, one per batch" + (", in 4 runs of rows overlapped with the sums" if not args.same_device else " (local reduction kernel)"),
+                     "bytes_per_example": wire, "payload_MB_per_batch": round(wire * min(int(st.batch_used), args.rows) / 1e6, 2),
+                     "algbw_GBps": round(value * wire / 1e9, 2), "pipelined": bool(args.pipeline),
+                     "backend": "loopback" if args.same_device else "rccl"},
+        # where a batch's time goes on shard 0 (HIP events on its compute stream): partial sums / exposed exchange / update
+        "phases_ms_per_batch": {"sums": round(phases[0] / n_batches * 1e3, 4), "exchange_exposed": round(phases[1] / n_batches * 1e3, 4),
+                                "update": round(phases[2] / n_batches * 1e3, 4), "device_total": round(dev_s / n_batches * 1e3, 4)},
+        "cpu_baseline": None,
+    }
+    g.close()
+    for h in hs:
+        h.close()
     print(json.dumps(out), flush=True)
 
 
@@ -198,7 +313,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (hogwild, two-pass minibatch)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the all-reduce through the host (testing the N>1 path without RCCL)")
-    ap.add_argument("--same-device", action="store_true", help="testing: all ranks use cuda:0")
+    ap.add_argument("--same-device", action="store_true", help="testing: every shard / rank on device 0 (several GPUs from one process: the loopback exchange)")
+    ap.add_argument("--one-process", action="store_true",
+                    help="several GPUs: drive all shards from this process through fmx_group_* (one host thread) instead of one process per GPU")
     ap.add_argument("--driver", default="lib", choices=["lib", "torch"],
                     help="several GPUs: lib = the library's own schedule and RCCL binding (fmx_comm_init_rank + fmx_sgd_epoch; torch only "
                          "hands the communicator id to the ranks); torch = libfm_amd/distributed.py (partial -> dist.all_reduce -> finish)")
@@ -231,6 +348,15 @@ def main():
     if args.method != "sgd":
         return bench_als(args, capi)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: either all shards from this process (fmx_group_*), or -- the default on N distinct
+        # devices -- re-exec as one process per GPU, which is how the library's RCCL schedule keeps N host threads busy
+        if args.same_device or args.one_process:
+            return bench_group(args, capi, criteo)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -295,12 +421,13 @@ def main():
         kind = "fused" if args.mode in ("hogwild", "fused") else "apply"
     elif args.driver == "lib" and args.backend == "nccl":
         # the library's own multi-GPU schedule: rank 0 creates the RCCL id, torch.distributed only carries it to the others
-        batch = args.batch or 262144
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         h.comm_init_rank(uid[0], rank, world)
         lib_flags = lagf | (capi.FLAG_PIPELINE if args.pipeline else 0)
         lib_lag = args.bias_lag if lagf else 0
+        batch = h.sgd_batch_info(0, args.batch).batch           # (sums the shards' shares of the collision mass over RCCL)
+        phases = [0.0, 0.0, 0.0]
 
         class _Drv:
             def synchronize(self):
@@ -308,7 +435,13 @@ def main():
         drv = _Drv()
 
         def step(timed):
-            h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, args.w0_chunk, lib_flags, lib_lag)
+            nonlocal batch_stats
+            st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, args.w0_chunk,
+                             lib_flags | (capi.FLAG_TIME_MAIN_KERNEL if timed else 0), lib_lag)
+            if timed:
+                batch_stats = st
+                for i in range(3):
+                    phases[i] += st.phase_seconds[i]
         bias_lag = lib_lag
         rows_per_launch = min(batch, args.rows)
         kind = "apply"
@@ -439,10 +572,22 @@ def main():
             out["cpu_port"] = cpu
         if exchange is not None:
             out["exchange"] = exchange
+            if args.driver == "lib" and args.backend == "nccl" and batch_stats is not None:
+                nb = max(1, int(batch_stats.batches)) * args.steps
+                out["phases_ms_per_batch"] = {"sums": round(phases[0] / nb * 1e3, 4), "exchange_exposed": round(phases[1] / nb * 1e3, 4),
+                                              "update": round(phases[2] / nb * 1e3, 4), "rank": 0}
         out.update(extras)
     h.close()
     if sharded:
         dist.destroy_process_group()
+    if rank == 0 and not sharded and not args.no_extras and not criteo and args.mode == "fused":
+        # the other two learners north_star names (BASELINE configs[3] / [4] shapes on one GPU): one line each, never `value`
+        for method in ("als", "mcmc"):
+            try:
+                o = run_als(capi, method, 10_000_000, 64, 16, 1 << 22, 2, 1, not args.no_cpu_baseline)
+                out[method] = {kk: o[kk] for kk in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "cpu_baseline")}
+            except Exception as exc:                             # a secondary figure must not take the headline down
+                out[method] = {"error": str(exc)[:200]}
     if rank == 0:
         # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION): flush it first so that the JSON
         # line is the LAST line on stdout

@@ -148,6 +148,11 @@ typedef struct fmx_epoch_stats {
                                rule follows the reference's online loop for <= 1, degrades above and diverges beyond ~2 */
   uint32_t status;          /* FMX_STAT_* */
   uint32_t reserved;
+  double   phase_seconds[4]; /* fmx_group_sgd_epoch / feature shards with FMX_FLAG_TIME_MAIN_KERNEL, HIP events on the first local
+                               shard's compute stream, summed over the epoch's batches: [0] partial sums of the batch (fmx_sgd_partial),
+                               [1] exposed exchange (end of the sums -> the reduced sums are available: what the wire costs beyond
+                               what the sums hid), [2] update (multipliers, recurrence hand-off, write-back of the local rows),
+                               [3] unused.  Zero on a single unsharded handle. */
 } fmx_epoch_stats;
 
 #define FMX_STAT_BATCH_CUT 1u   /* batch = 0 resolved below the 262144 default because of the rows' collision mass */

@@ -50,7 +50,8 @@ class EpochStats(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("batches", C.c_uint64), ("device_seconds", C.c_double),
                 ("main_kernel_seconds", C.c_double), ("main_kernel_launches", C.c_uint64),
                 ("max_feature_count", C.c_uint32), ("batch_used", C.c_uint32), ("deferred_features", C.c_uint64),
-                ("collision_mass", C.c_double), ("batch_gain", C.c_double), ("status", C.c_uint32), ("reserved", C.c_uint32)]
+                ("collision_mass", C.c_double), ("batch_gain", C.c_double), ("status", C.c_uint32), ("reserved", C.c_uint32),
+                ("phase_seconds", C.c_double * 4)]
 
 
 class BatchInfo(C.Structure):

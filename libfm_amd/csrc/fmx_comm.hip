@@ -458,17 +458,36 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_partial(cur, slot, b * B, nb, cur->xbuf[which], cur->stream)); }
     return exchange_begin(g, which, (size_t)nb * kp1);
   };
+  // FMX_FLAG_TIME_MAIN_KERNEL: where a batch's time goes on the first local shard (fmx_epoch_stats::phase_seconds) -- four timing
+  // events per batch on its compute stream, read after the epoch (at most the first 1024 batches)
+  const bool timed = (opts.flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
+  const uint64_t n_timed = timed ? std::min<uint64_t>(n_batch, 1024) : 0;
+  while (h0->ev_pool.size() < 4 * n_timed) { hipEvent_t e; HIPCHK(h0, hipEventCreate(&e)); h0->ev_pool.push_back(e); }
+  auto mark = [&](uint64_t b, int which) -> int {
+    if (b >= n_timed) return FMX_OK;
+    HIPCHK(h0, hipSetDevice(h0->device));
+    HIPCHK(h0, hipEventRecord(h0->ev_pool[4 * b + which], h0->stream));
+    return FMX_OK;
+  };
+  auto gather_timed = [&](uint64_t b) -> int {
+    int erc = mark(b, 0);
+    if (erc == FMX_OK) erc = gather(b);
+    if (erc == FMX_OK) erc = mark(b, 1);
+    return erc;
+  };
   auto update = [&](uint64_t b) -> int {
     int erc = exchange_end(g, (int)(b & 1));
     if (erc) return erc;
+    erc = mark(b, 2);
+    if (erc) return erc;
     for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_finish(cur, slot, b * B, rows_of(b), sum_of(g, i, (int)(b & 1)), &opts, cur->stream)); }
-    return FMX_OK;
+    return mark(b, 3);
   };
   int rc = FMX_OK;
-  if (n_batch && pipeline) rc = gather(0);
+  if (n_batch && pipeline) rc = gather_timed(0);
   for (uint64_t b = 0; b < n_batch && rc == FMX_OK; b++) {
-    if (pipeline) { if (b + 1 < n_batch) rc = gather(b + 1); }      // reads the parameters before update(b): one batch stale
-    else rc = gather(b);
+    if (pipeline) { if (b + 1 < n_batch) rc = gather_timed(b + 1); }      // reads the parameters before update(b): one batch stale
+    else rc = gather_timed(b);
     if (rc == FMX_OK) rc = update(b);
   }
   if (rc) { g->err = g->hs[0]->err; return rc; }
@@ -483,6 +502,13 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = n_batch;
     stats->max_feature_count = h0->slots[slot].max_seg_count;
     stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
+    for (uint64_t b = 0; b < n_timed; b++) {
+      float a = 0, x = 0, u = 0;
+      HIPCHK(h0, hipEventElapsedTime(&a, h0->ev_pool[4 * b], h0->ev_pool[4 * b + 1]));
+      HIPCHK(h0, hipEventElapsedTime(&x, h0->ev_pool[4 * b + 1], h0->ev_pool[4 * b + 2]));
+      HIPCHK(h0, hipEventElapsedTime(&u, h0->ev_pool[4 * b + 2], h0->ev_pool[4 * b + 3]));
+      stats->phase_seconds[0] += a * 1e-3; stats->phase_seconds[1] += x * 1e-3; stats->phase_seconds[2] += u * 1e-3;
+    }
   }
   return FMX_OK;
 }

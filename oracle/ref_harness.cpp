@@ -321,7 +321,10 @@ int main(int argc, char** argv) {
         for (uint g = 0; g < meta.num_attr_groups; g++) { for (int f = 0; f < fm.num_factor; f++) fml->v_lambda(g, f) = reg[j]; j++; }
       }
       dump_params(prefix + ".init.bin", fm);
+      const double t_learn0 = wall();
       fml->learn(train, test);
+      // (bench.py's cpu_baseline of the als / mcmc extra keys: the reference's own fm_learn_mcmc::learn, one thread)
+      printf("{\"learn_seconds\": %.6f, \"iters\": %d, \"rows\": %u}\n", wall() - t_learn0, iters, (unsigned)train.num_cases);
       dump_params(prefix + ".final.bin", fm);
       DVector<double> pred; pred.setSize(test.num_cases);
       fml->predict(test, pred);                                // fm_learn_mcmc.h:380-404

@@ -1,0 +1,48 @@
+"""GPU: bench.py as the driver types it.  `python bench.py --gpus 2 --same-device` must run by itself on a one-GPU box (two
+feature shards on device 0 through fmx_group_*: the N > 1 code path with the loopback exchange) and print one JSON line that
+carries the contract's keys plus `exchange`, `config.sharding` and the per-phase times; the N = 1 line carries `roofline` and the
+library-chosen batch; the Criteo-shaped workload (BASELINE configs[2]) runs with the batch cut to its stability bound."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"]
+
+
+def run_bench(*args):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + [str(a) for a in args], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    for k in KEYS:
+        assert k in out, k
+    return out
+
+
+def test_two_shards_on_one_device_as_typed():
+    out = run_bench("--gpus", 2, "--same-device", "--features", 4_000_000, "--rows", 131072, "--batch", 32768, "--steps", 2, "--warmup", 1)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "2 shards" in out["config"]["sharding"] and out["config"]["batch"] == 32768
+    assert out["exchange"]["bytes_per_example"] == 4 * 65 and out["exchange"]["backend"] == "loopback"
+    ph = out["phases_ms_per_batch"]
+    assert ph["sums"] > 0 and ph["update"] > 0 and ph["exchange_exposed"] >= 0
+    assert ph["sums"] + ph["exchange_exposed"] + ph["update"] <= 1.2 * ph["device_total"] + 0.05
+
+
+def test_single_gpu_line_and_criteo_shape():
+    out = run_bench("--features", 4_000_000, "--rows", 262144, "--steps", 2, "--warmup", 1, "--no-cpu-baseline", "--no-extras")
+    assert out["n_gpus"] == 1 and out["config"]["batch_rule"]["cut"] is False and out["roofline"]["frac"] > 0
+    out = run_bench("--workload", "criteo", "--features", 2_000_000, "--rows", 65536, "--steps", 1, "--warmup", 1)
+    br = out["config"]["batch_rule"]
+    assert br["cut"] is True and br["unstable"] is False and br["gain"] <= 1.0 and br["batch"] <= 2048
+    assert "Criteo-shaped" in out["config"]["workload"]

@@ -89,6 +89,25 @@ def test_fused_minibatch_spot_check_at_full_size(capi, oracle):
     h.close()
 
 
+def test_fused_minibatch_at_the_bench_batch_against_oracle(capi, oracle):
+    """the configuration BENCH reports -- n = 1e8, batch 262 144, bias lag 2, library-default micro-chunk -- against the oracle's
+    rule: one full batch (1.27 deferred features per example, 8.3 M touched parameter rows: a 4.3 GB fp64 sub-model on the host)
+    plus a short second one, 1e-4."""
+    rows, batch, lag = 262144 + 16384, 262144, 2
+    h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+    h.init_params(0.0, 0.05, 11)
+    h.synth_rows(0, 2024, 40_000_000, rows, NNZ)
+    d, m, ids = submodel_minibatch(capi, oracle, h, 2024, 40_000_000, rows, batch, 256, lag)
+    st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)       # batch 0 / chunk 0: what bench.py passes
+    assert st.batch_used == batch and st.status == 0 and st.batches == 2
+    assert 1.0 * rows < st.deferred_features < 1.5 * rows
+    w, v = h.get_param_rows(ids)
+    np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w, m.w, rtol=1e-4, atol=1e-6)
+    assert abs(h.get_w0() - m.w0) <= 1e-4 * abs(m.w0) + 1e-6
+    h.close()
+
+
 def test_fused_minibatch_is_deterministic_at_bench_batch(capi):
     """two runs of the bench configuration (batch 262 144, bias_lag 2) give bit-identical predictions and bias"""
     rows = 1 << 20
