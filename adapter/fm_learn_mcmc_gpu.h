@@ -42,6 +42,7 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
     const uint G = meta->num_attr_groups;
     for (int r = 0; r < world; r++) {
       fmx_config c;
+      memset(&c, 0, sizeof(c));                              // (place_candidates, als_split_min, exchange_runs: library defaults)
       c.num_attribute = fm->num_attribute; c.num_factor = fm->num_factor; c.k0 = fm->k0; c.k1 = fm->k1;
       c.task = task; c.reg0 = fm->reg0; c.regw = fm->regw; c.regv = fm->regv; c.learn_rate = 0;
       c.min_target = min_target; c.max_target = max_target; c.device = gpu_devices.empty() ? gpu_device : gpu_devices[r];

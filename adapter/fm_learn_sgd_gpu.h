@@ -13,6 +13,7 @@
 #ifndef FM_LEARN_SGD_GPU_H_
 #define FM_LEARN_SGD_GPU_H_
 
+#include <cstring>
 #include <vector>
 #include <string>
 #include "fmx.h"
@@ -71,6 +72,7 @@ class fmx_sgd_binding : public Base {
     const int world = gpu_devices.empty() ? 1 : (int)gpu_devices.size();
     for (int r = 0; r < world; r++) {
       fmx_config c;
+      memset(&c, 0, sizeof(c));                              // (place_candidates, als_split_min, exchange_runs: library defaults)
       c.num_attribute = fm->num_attribute; c.num_factor = fm->num_factor; c.k0 = fm->k0; c.k1 = fm->k1;
       c.task = this->task; c.reg0 = fm->reg0; c.regw = fm->regw; c.regv = fm->regv; c.learn_rate = this->learn_rate;
       c.min_target = this->min_target; c.max_target = this->max_target;

@@ -93,6 +93,14 @@ typedef struct fmx_config {
                                   PERMUTATION of [0, num_attribute) (4-round Feistel network, cycle-walked; north_star:
                                   "row-sharded by feature-id hash"): balanced whatever the structure of the ids, still a dense
                                   local table, and invertible, so the shard knows its features' global ids. */
+  int32_t  place_candidates;/* parameter tables of >= 256 MB are PLACED by measurement (see fmx_create): how many candidate allocations
+                               may be held side by side and probed.  0 = default (2), 1 = first fit (no probe, no transient memory), <= 6 */
+  uint32_t als_split_min;   /* ALS / MCMC: dependency levels with at least this many entries update {e, q} as a row-ordered stream
+                               (the split step) instead of inside the fused draw.  0 = library default (65536),
+                               1 = every level, 0xFFFFFFFF = never */
+  uint32_t exchange_runs;   /* several GPUs over RCCL: a batch's partial sums are exchanged in this many runs of rows, the all-reduce of
+                               one run travelling while the next is summed.  0 = default (4), 1 = one all-reduce per batch */
+  uint32_t reserved;
 } fmx_config;
 
 typedef struct fmx_sgd_opts {
@@ -178,10 +186,9 @@ typedef struct fmx_eval {
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* replaces: fm_model fm; fm.init() allocation (fm_model.h:91-99) + new fm_learn_* (libfm.cpp:271-293)
- * Parameter tables of >= 256 MB are PLACED: up to six (factor table) / four (linear weights) candidate allocations are held
- * side by side for a few milliseconds, each timed under the training step's access pattern, the fastest kept -- where in HBM a
- * table lands moves the step by 10-20 % on MI355X.  The number of candidates adapts to the free device
- * memory; environment FMX_V_PLACE=0 switches the probing off (first fit). */
+ * Parameter tables of >= 256 MB are PLACED: up to fmx_config::place_candidates (default 2) candidate allocations are held side by
+ * side for a few milliseconds, each timed under the training step's access pattern, the fastest kept -- which physical memory a
+ * table lands in moves the step by 10-20 % on MI355X; the transient footprint is one extra table. */
 int fmx_create(const fmx_config *cfg, fmx_handle *out);
 int fmx_destroy(fmx_handle h);
 /* text of the last error on this handle (h may be NULL: last creation error). Never NULL. */

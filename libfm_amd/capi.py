@@ -38,7 +38,12 @@ class Config(C.Structure):
     _fields_ = [("num_attribute", C.c_uint64), ("num_factor", C.c_int32), ("k0", C.c_int32), ("k1", C.c_int32),
                 ("task", C.c_int32), ("reg0", C.c_double), ("regw", C.c_double), ("regv", C.c_double),
                 ("learn_rate", C.c_double), ("min_target", C.c_double), ("max_target", C.c_double),
-                ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_hash", C.c_int32)]
+                ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_hash", C.c_int32),
+                ("place_candidates", C.c_int32), ("als_split_min", C.c_uint32), ("exchange_runs", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+ALS_SPLIT_NEVER = 0xFFFFFFFF
+ALS_SPLIT_MIN = 0           # default of Handle(als_split_min=None): 0 = the library's choice (tests set 1 / ALS_SPLIT_NEVER to force a form)
 
 
 class SgdOpts(C.Structure):
@@ -188,11 +193,13 @@ class Handle:
     """Thin OO wrapper over an fmx_handle; every method is one C-ABI call."""
 
     def __init__(self, num_attribute, num_factor, k0=True, k1=True, task=TASK_REGRESSION, reg0=0.0, regw=0.0, regv=0.0,
-                 learn_rate=0.0, min_target=0.0, max_target=0.0, device=-1, shard_rank=0, shard_world=1, shard_hash=0):
+                 learn_rate=0.0, min_target=0.0, max_target=0.0, device=-1, shard_rank=0, shard_world=1, shard_hash=0,
+                 place_candidates=0, als_split_min=None, exchange_runs=0):
         self.lib = load()
         self.cfg = Config(int(num_attribute), int(num_factor), int(bool(k0)), int(bool(k1)), int(task),
                           float(reg0), float(regw), float(regv), float(learn_rate), float(min_target),
-                          float(max_target), int(device), int(shard_rank), int(shard_world), int(shard_hash))
+                          float(max_target), int(device), int(shard_rank), int(shard_world), int(shard_hash),
+                          int(place_candidates), int(ALS_SPLIT_MIN if als_split_min is None else als_split_min), int(exchange_runs), 0)
         self.h = H()
         rc = self.lib.fmx_create(C.byref(self.cfg), C.byref(self.h))
         if rc != FMX_OK:

@@ -64,7 +64,6 @@ static int build_levels(fmx_handle h, const Slot& s, std::vector<uint32_t>& leve
     uint32_t l = 0;
     for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) l = std::max(l, rowlevel[tent[i].e]);
     l += 1;
-    if (getenv("FMX_ALS_SEQUENTIAL")) l = sg + 1;      // debugging aid: one feature per level (the reference's order, serial)
     for (uint32_t i = seg_rel[sg]; i < seg_rel[sg + 1]; i++) rowlevel[tent[i].e] = l;
     lvl[sg] = l - 1;
     n_levels = std::max(n_levels, l);
@@ -173,10 +172,9 @@ static int als_begin_impl(fmx_handle h, int train_slot) {
   std::vector<uint8_t> seen((size_t)h->n_local, 0);
   {
     // levels with many entries take the split step (column sums + draw, then the {e, q} update as a row-ordered stream):
-    // a fused draw pays two random touches of the {e, q} cache per entry, the split one.  FMX_ALS_SPLIT_MIN: threshold in
-    // entries per level (0 = never split); small levels are launch-bound and stay fused.
-    const char* env = getenv("FMX_ALS_SPLIT_MIN");
-    a.split_min = env ? (uint32_t)strtoul(env, nullptr, 10) : 65536u;
+    // a fused draw pays two random touches of the {e, q} cache per entry, the split one.  fmx_config::als_split_min: threshold in
+    // entries per level; small levels are launch-bound and stay fused.
+    a.split_min = h->cfg.als_split_min == 0 ? 65536u : (h->cfg.als_split_min == 0xFFFFFFFFu ? 0u : h->cfg.als_split_min);
     std::vector<uint32_t> seg_level, seg_pos;
     rc = build_levels(h, s, a.level_ptr, &a.level_list, &seen, 0, &seg_level, &seg_pos, &a.lev_ent);
     if (rc) return rc;
@@ -207,7 +205,7 @@ static int als_begin_impl(fmx_handle h, int train_slot) {
   if (!s.blocks.empty()) HIPCHK(h, hipMalloc(&a.epart, (size_t)N * sizeof(double)));
   HIPCHK(h, hipMalloc(&a.e, (size_t)N * sizeof(EQ)));
   HIPCHK(h, hipMalloc(&a.q, (size_t)N * (size_t)h->KP * sizeof(double)));
-  if (h->cfg.num_factor > 0 && nseg > 0 && !getenv("FMX_ALS_NO_SHADOW")) {      // (the env switch is the A/B knob of the profile)
+  if (h->cfg.num_factor > 0 && nseg > 0) {      // (the env switch is the A/B knob of the profile)
     a.vt_stride = ((size_t)nseg + 63) & ~(size_t)63;
     HIPCHK(h, hipMalloc(&a.vt, (size_t)h->cfg.num_factor * a.vt_stride * sizeof(float)));
   }
@@ -332,7 +330,6 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
     const double avg_col = s.nseg ? (double)s.nnz / (double)s.nseg : 0.0;
     // (measured at 6.7 entries per column, inside one process: 4 lanes 161.4 ms per sweep, 8 lanes 164.4, 16 lanes 195)
     lanes[i] = avg_col <= 8.0 ? 4 : (avg_col <= 16.0 ? 8 : (avg_col <= 40.0 ? 16 : 64));
-    if (const char* e = getenv("FMX_ALS_LANES")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 64) lanes[i] = v; }   // tuning knob
   }
 #define FMX_ALS_DRAW(ISV, cnt, ...)                                                                          \
   do {                                                                                                        \
@@ -601,7 +598,7 @@ int fmx_group_als_begin(fmx_group g, int train_slot) {
     if (er == hipSuccess) er = hipMalloc(&a.delta, (size_t)N * sizeof(EQ));
     if (er == hipSuccess) er = hipMemsetAsync(a.delta, 0, (size_t)N * sizeof(EQ), x->stream);
     if (er == hipSuccess) er = hipMalloc(&a.epart, (size_t)N * sizeof(double));
-    if (er == hipSuccess && x->cfg.num_factor > 0 && nseg > 0 && !getenv("FMX_ALS_NO_SHADOW")) {
+    if (er == hipSuccess && x->cfg.num_factor > 0 && nseg > 0) {
       a.vt_stride = ((size_t)nseg + 63) & ~(size_t)63;
       er = hipMalloc(&a.vt, (size_t)x->cfg.num_factor * a.vt_stride * sizeof(float));
     }
@@ -640,6 +637,7 @@ int fmx_group_als_sweep(fmx_group g, const fmx_als_opts* opts, fmx_als_stats* st
 // sums add up over the shards
 int fmx_group_als_moments(fmx_group g, double* out) {
   if (!g || !out) return FMX_E_ARG;
+  for (auto m : g->hs) if (!m) { g->err = "a member of the group was destroyed"; return FMX_E_STATE; }
   fmx_handle h = g->hs[0];
   const size_t cnt = 2 + 2 * (size_t)h->num_groups * (size_t)(1 + h->cfg.num_factor);
   std::vector<double> part(cnt);

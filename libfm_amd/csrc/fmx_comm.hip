@@ -434,9 +434,9 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
   const uint64_t n_batch = ((uint64_t)n_rows + B - 1) / B;
   auto rows_of = [&](uint64_t b) { return (uint32_t)std::min<uint64_t>(B, n_rows - b * B); };
   // RCCL: the batch is summed and exchanged in runs of rows, so that the wire works while the next run is being summed (the sums of
-  // a row do not depend on the other rows of the batch: nothing changes in the rule).  FMX_XCHG_CHUNKS: runs per batch (1 = one
-  // exchange per batch, as the loopback exchange always does).
-  static const uint32_t xchunks = getenv("FMX_XCHG_CHUNKS") ? (uint32_t)std::max(1, atoi(getenv("FMX_XCHG_CHUNKS"))) : 4u;
+  // a row do not depend on the other rows of the batch: nothing changes in the rule).  fmx_config::exchange_runs: runs per batch
+  // (1 = one exchange per batch, as the loopback exchange always does).
+  const uint32_t xchunks = g->hs[0]->cfg.exchange_runs ? g->hs[0]->cfg.exchange_runs : 4u;
   auto gather = [&](uint64_t b) -> int {
     const uint32_t nb = rows_of(b);
     const int which = (int)(b & 1);
@@ -516,6 +516,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
 // y-hat of every row of a slot over the shards (raw, like fmx_predict): partial sums -> exchange -> finish on shard 0
 int fmx_group_predict(fmx_group g, int slot, double* out) {
   if (!g || !out) return FMX_E_ARG;
+  for (auto m : g->hs) if (!m) return gfail(g, FMX_E_STATE, "a member of the group was destroyed");
   fmx_handle cur = g->hs[0];
   if (g->kind == GROUP_SINGLE) { GCHK(g, fmx_predict(cur, slot, out)); return FMX_OK; }
   const size_t n = g->hs.size();
@@ -549,6 +550,7 @@ int fmx_group_predict(fmx_group g, int slot, double* out) {
 // fm_learn::evaluate (fm_learn.h:93-153) over the shards: predictions as above, metric on the host like the reference
 int fmx_group_evaluate(fmx_group g, int slot, fmx_eval* out) {
   if (!g || !out) return FMX_E_ARG;
+  for (auto m : g->hs) if (!m) return gfail(g, FMX_E_STATE, "a member of the group was destroyed");
   fmx_handle h0 = g->hs[0];
   if (g->kind == GROUP_SINGLE) { fmx_handle cur = h0; GCHK(g, fmx_evaluate(cur, slot, out)); return FMX_OK; }
   { fmx_handle cur = h0; GCHK(g, check_slot(cur, slot, true)); }

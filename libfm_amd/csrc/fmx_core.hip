@@ -57,8 +57,7 @@ uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted
     occ = it->second;
   }
   uint64_t blocks = (n_waves_wanted + 3) / 4;
-  int over = over_default;
-  if (const char* e = getenv(over_default == FMX_GRID_OVER_ALS ? "FMX_GRID_OVER_ALS" : "FMX_GRID_OVER")) over = atoi(e) > 0 ? atoi(e) : 1;
+  const int over = over_default;
   const uint64_t cap = (uint64_t)occ * (uint64_t)h->num_cu * (uint64_t)over;
   if (blocks < 1) blocks = 1;
   if (blocks > cap) blocks = cap;
@@ -104,8 +103,6 @@ void free_segments(Slot& s) {
   if (s.seg_rel) hipFree(s.seg_rel);
   if (s.cmask) hipFree(s.cmask);
   if (s.cseg) hipFree(s.cseg);
-  if (s.order) hipFree(s.order);
-  s.order = nullptr; s.n_indep.clear();
   s.t_ent = nullptr; s.seg_feat = nullptr; s.seg_rel = nullptr; s.seg_B = 0; s.nseg = 0;
   s.cmask = nullptr; s.cseg = nullptr; s.ncseg = 0; s.fused_cap = 0;
   s.batch_seg.clear(); s.batch_base.clear(); s.cbatch.clear();
@@ -232,6 +229,8 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   if (cfg->shard_world < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_world)
     return fail(nullptr, FMX_E_ARG, "bad shard_rank/shard_world");
   if (cfg->shard_hash != 0 && cfg->shard_hash != 1) return fail(nullptr, FMX_E_ARG, "shard_hash must be 0 or 1");
+  if (cfg->place_candidates < 0 || cfg->place_candidates > 6) return fail(nullptr, FMX_E_ARG, "place_candidates must be 0 (default) .. 6");
+  if ((uint64_t)cfg->shard_world > cfg->num_attribute) return fail(nullptr, FMX_E_ARG, "more feature shards than features");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
@@ -254,34 +253,24 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
       fmx_destroy(h); return FMX_E_HIP; } } while (0)
   CREATE_CHK(hipSetDevice(dev));
   CREATE_CHK(hipGetDeviceProperties(&h->prop, dev));
-  // FMX_SCAN_CU=1 (experiment): reserve one CU for the side stream of the bias recurrence (stream2) and keep the launch
-  // streams off it -- the one-workgroup recurrence then does not share its SIMDs / LDS with gather wavefronts
-  const bool scan_cu = getenv("FMX_SCAN_CU") && atoi(getenv("FMX_SCAN_CU")) > 0;
-  uint32_t mask_main[8], mask_scan[8];
-  for (int i = 0; i < 8; i++) { mask_main[i] = 0xFFFFFFFFu; mask_scan[i] = 0u; }
-  mask_main[0] &= ~1u; mask_scan[0] = 1u;
-  if (scan_cu) CREATE_CHK(hipExtStreamCreateWithCUMask(&h->stream, 8, mask_main));
-  else CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_CHK(hipEventCreate(&h->ev0));
   CREATE_CHK(hipEventCreate(&h->ev1));
   {
-    // row layout: default = separate w[] array (FMX_WPAD=0).  FMX_WPAD=<floats> co-locates w behind the factors
-    // ([KP factors | w | padding]); measured on MI355X it does NOT pay: HBM fetches 64-B sectors, so a 4-B w
-    // costs one sector wherever it lives, and the unaligned rows cost more.
-    int wpad = 0;
-    if (const char* e = getenv("FMX_WPAD")) wpad = atoi(e);
-    if (wpad < 0 || (wpad % 4) != 0) wpad = 0;
-    h->tb.rs = (uint32_t)(h->KP + wpad);
-    // Placement of the parameter tables.  The rate of the step's random row gather + write-back depends on where in HBM the table's
-    // allocation landed (same size, same process, same kernel: two classes 11-20 % apart, stable for the life of the allocation;
-    // scripts/ubench/placement.hip, placement_w.hip) -- the one quantity that decided whether a process ran the
-    // bench at 16.4 or at 18-20 ms per step.  So a table of >= 256 MB is allocated up to `max_tries` (<= 6) times (the earlier candidates
-    // are held meanwhile, so that the later ones are other memory), each candidate is zeroed and timed under a probe with the step's
-    // traffic shape, the fastest is kept.  FMX_V_PLACE=0: first fit.
+    // row layout: V rows of KP floats, the linear weights in an array of their own (co-locating w_j behind its row was measured
+    // in rounds 1 and 2: HBM fetches 64-byte sectors, a 4-byte w costs one wherever it lives, and unaligned rows cost more)
+    h->tb.rs = (uint32_t)h->KP;
+    // Placement of the parameter tables.  The rate of the step's random row gather + write-back depends on WHICH physical memory a table
+    // landed in (same size, same process, same kernel: classes from 4.9 to 6.1 TB/s, stable for the life of the allocation;
+    // scripts/ubench/placement.hip).  What does NOT separate the classes (scripts/ubench/placement_vmm.hip, profiles/r03_placement_vmm.txt):
+    // the virtual alignment (2 MB .. 1 GB) and the size of the physically contiguous extents (tables built from 2 MB, 64 MB and 1 GB
+    // hipMemCreate chunks fall into both classes).  So a table of >= 256 MB is allocated up to fmx_config::place_candidates times
+    // (default 2; the earlier candidate is held meanwhile, so that the later one is other memory), each candidate is zeroed and
+    // timed under a probe with the step's traffic shape, the fastest is kept.  place_candidates = 1: first fit, no probe.
     auto alloc_placed = [&](float** out, size_t bytes, int max_tries, bool rows, const char* what) -> hipError_t {
       constexpr int MAXC = 6;
       int tries = 1;
-      if (bytes >= ((size_t)256 << 20) && !(getenv("FMX_V_PLACE") && atoi(getenv("FMX_V_PLACE")) == 0)) {
+      if (bytes >= ((size_t)256 << 20) && max_tries > 1) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
           tries = (int)std::min<size_t>((size_t)std::min(max_tries, MAXC), std::max<size_t>(1, free_b / (bytes + ((size_t)4 << 30))));   // candidates sit side by side
@@ -315,24 +304,15 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
         if (c >= 1 && ms_of[best] < 0.95f * worst) break;     // two classes seen: the fast one is in hand
       }
       if (er == hipSuccess && !cand[0]) er = hipMalloc(&cand[0], bytes);      // (reports the allocation failure)
-      if (getenv("FMX_DEBUG")) fprintf(stderr, "fmx: %s %zu bytes, %d candidate placement(s), probe %.3f / %.3f / %.3f / %.3f / %.3f / %.3f ms, kept #%d\n",
-                                       what, bytes, n_cand, ms_of[0], ms_of[1], ms_of[2], ms_of[3], ms_of[4], ms_of[5], best);
+      (void)what;
       for (int c = 0; c < MAXC; c++) if ((c != best || er != hipSuccess) && cand[c]) { hipFree(cand[c]); cand[c] = nullptr; }
       *out = cand[best];
       return er;
     };
-    CREATE_CHK(alloc_placed(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float), 6, true, "factor table"));
-    if (wpad == 0) {
-      // FMX_W_ALLOC (experiment, scripts/ubench/w_gather.hip): 1 = uncached, 2 = fine-grained allocation of the w array
-      const int walloc = getenv("FMX_W_ALLOC") ? atoi(getenv("FMX_W_ALLOC")) : 0;
-      if (walloc == 1)      CREATE_CHK(hipExtMallocWithFlags((void**)&h->w_sep, h->n_local * sizeof(float), hipDeviceMallocUncached));
-      else if (walloc == 2) CREATE_CHK(hipExtMallocWithFlags((void**)&h->w_sep, h->n_local * sizeof(float), hipDeviceMallocFinegrained));
-      else                  CREATE_CHK(alloc_placed(&h->w_sep, h->n_local * sizeof(float), 4, false, "linear weights"));
-      if (walloc) CREATE_CHK(hipMemsetAsync(h->w_sep, 0, h->n_local * sizeof(float), h->stream));
-      h->tb.w = h->w_sep; h->tb.ws = 1;
-    } else {
-      h->tb.w = h->tb.V + h->KP; h->tb.ws = h->tb.rs;
-    }
+    const int cand = cfg->place_candidates > 0 ? std::min(cfg->place_candidates, 6) : 2;
+    CREATE_CHK(alloc_placed(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float), cand, true, "factor table"));
+    CREATE_CHK(alloc_placed(&h->w_sep, h->n_local * sizeof(float), cand, false, "linear weights"));
+    h->tb.w = h->w_sep; h->tb.ws = 1;
   }
   CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
   CREATE_CHK(hipMalloc(&h->w0_pp, 8 * sizeof(double)));
@@ -340,11 +320,8 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
      // that its workgroup is placed as soon as any CU has room
     int lo = 0, hi = 0;
     CREATE_CHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    if (scan_cu) CREATE_CHK(hipExtStreamCreateWithCUMask(&h->stream2, 8, mask_scan));
-    else CREATE_CHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+    CREATE_CHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
   }
-  if (scan_cu) CREATE_CHK(hipExtStreamCreateWithCUMask(&h->stream3, 8, mask_main));
-  else CREATE_CHK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   h->num_cu = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
   CREATE_CHK(hipMalloc(&h->acc, 4 * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
@@ -368,12 +345,10 @@ int fmx_destroy(fmx_handle h) {
   if (h->w0) hipFree(h->w0);
   if (h->w0_pp) hipFree(h->w0_pp);
   if (h->stream2) hipStreamDestroy(h->stream2);
-  if (h->stream3) hipStreamDestroy(h->stream3);
   if (h->acc) hipFree(h->acc);
   if (h->partial) hipFree(h->partial);
   if (h->mult) hipFree(h->mult);
   if (h->rest) hipFree(h->rest);
-  if (h->fused_ctr) hipFree(h->fused_ctr);
   for (auto ev : h->ev_pool) hipEventDestroy(ev);
   for (auto ev : h->ev_sync) hipEventDestroy(ev);
   if (h->lag.ev_rest) hipEventDestroy(h->lag.ev_rest);

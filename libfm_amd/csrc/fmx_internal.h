@@ -46,8 +46,6 @@ struct Slot {
   uint32_t  ncseg = 0;
   uint32_t  fused_cap = 0;           // longest row the k_fused instance of this slot keeps in registers
   std::vector<uint32_t> cbatch;      // [n_batches+1] first cseg entry of every batch
-  uint32_t* order = nullptr;         // [n_rows] per batch: example order with the examples that touch a deferred feature of
-  std::vector<uint32_t> n_indep;     //          the PREVIOUS batch last; n_indep[b] = how many do not (FusedPrev)
   std::vector<struct BlockRows*> blocks;   // `-relation` blocks kept apart from these (main) rows; empty: plain / expanded rows
 };
 
@@ -117,11 +115,10 @@ struct fmx_context_s {
   int        device = 0;
   hipStream_t stream = nullptr;
   Tab        tb = {nullptr, nullptr, 0, 0};   // V rows (+ co-located w), see fmx_kernels.h
-  float*     w_sep = nullptr;    // separate w[] array (only when FMX_WPAD=0)
+  float*     w_sep = nullptr;    // the w[] array
   double*    w0 = nullptr;       // device scalar
   double*    w0_pp = nullptr;    // 8 doubles: ring of bias copies for the overlapped recurrence (hogwild, fused, bias lag)
   hipStream_t stream2 = nullptr; // side stream of the hogwild bias scan
-  hipStream_t stream3 = nullptr; // second launch stream of the hogwild macro-batches (odd launches)
   int        num_cu = 256;
   double*    acc = nullptr;      // 4 doubles of reduction scratch
   Slot       slots[FMX_MAX_SLOTS];
@@ -134,8 +131,6 @@ struct fmx_context_s {
   std::vector<hipEvent_t> ev_sync;   // untimed events ordering the two hogwild streams
   std::string err;
   hipDeviceProp_t prop;
-  uint32_t*   fused_ctr = nullptr;    // [2 * batches] work / completion counters of FusedPrev (FMX_APPLY_FUSED)
-  size_t      fused_ctr_cap = 0;
   // several GPUs (fmx_comm.hip)
   void*       comm = nullptr;         // ncclComm_t of a one-process-per-GPU job (fmx_comm_init_rank)
   struct fmx_group_s* group = nullptr;

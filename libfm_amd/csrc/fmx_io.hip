@@ -94,10 +94,18 @@ std::string read_matrix(const std::string& path, HostBuf& hb, Entry** ent_out, u
   XHeader h;
   if (fread(&h, sizeof(h), 1, f) != 1) { fclose(f); return path + ": truncated header"; }
   if (h.id != 2 || h.float_size != 4) { fclose(f); return path + ": not a libFM binary matrix (file id / float size; fmatrix.h:188-189)"; }
+  {  // the header's counts size the buffers: check them against the file before allocating (every row costs 4 bytes, every entry 8)
+    const long at = ftell(f);
+    fseek(f, 0, SEEK_END);
+    const uint64_t rest = (uint64_t)(ftell(f) - at);
+    fseek(f, at, SEEK_SET);
+    if (h.num_values > rest / sizeof(Entry) || (uint64_t)h.num_rows * 4u + h.num_values * sizeof(Entry) > rest) { fclose(f); return path + ": truncated (the header announces more than the file holds)"; }
+  }
   Entry* ent = (Entry*)hb.alloc(h.num_values * sizeof(Entry));
+  *ent_out = ent;                                                                    // owned by the caller from here on (also on failure below)
   uint64_t* ptr = (uint64_t*)hb.alloc(((size_t)h.num_rows + 1) * sizeof(uint64_t));
+  *ptr_out = ptr;
   if (!ent || !ptr) { fclose(f); return path + ": out of (page-locked) memory"; }
-  *ent_out = ent; *ptr_out = ptr;                                                    // owned by the caller from here on
   uint64_t pos = 0;
   ptr[0] = 0;
   for (uint32_t r = 0; r < h.num_rows; r++) {

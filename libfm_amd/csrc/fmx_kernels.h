@@ -782,40 +782,6 @@ k_seg_cbatch(const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ cfl
   }
 }
 
-// ---- which examples of batch b touch a feature that batch b-1 left deferred (FusedPrev) ------------------------------
-// one thread per segment: binary search of its feature in the previous batch's deferred list (ascending feature ids)
-static __global__ void __launch_bounds__(256)
-k_seg_dep(const uint64_t* __restrict__ keys, const TEntry* __restrict__ vals, const uint32_t* __restrict__ head, uint32_t nseg,
-          const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ batch_seg, const uint32_t* __restrict__ cbatch,
-          const uint32_t* __restrict__ cseg, uint32_t B, uint32_t* __restrict__ dep) {
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
-    const uint32_t a = head[s], b = head[s + 1];
-    const uint64_t key = keys[a];
-    const uint32_t bt = (uint32_t)(key >> 32), feat = (uint32_t)key;
-    if (bt == 0) continue;
-    const uint32_t s0 = batch_seg[bt - 1];
-    uint32_t lo = cbatch[bt - 1], hi = cbatch[bt];
-    while (lo < hi) {                                          // first listed feature >= feat
-      const uint32_t mid = (lo + hi) >> 1;
-      if (seg_feat[s0 + cseg[mid]] < feat) lo = mid + 1; else hi = mid;
-    }
-    if (lo < cbatch[bt] && seg_feat[s0 + cseg[lo]] == feat)
-      for (uint32_t i = a; i < b; i++) dep[(uint64_t)bt * B + vals[i].e] = 1u;
-  }
-}
-// cum = exclusive scan of dep over all rows (+ the total at [n_rows]); order: per batch, independent examples first
-static __global__ void __launch_bounds__(256)
-k_seg_order(const uint32_t* __restrict__ dep, const uint32_t* __restrict__ cum, uint32_t n_rows, uint32_t B,
-            uint32_t* __restrict__ order, uint32_t* __restrict__ n_indep) {
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
-    const uint32_t bt = r / B, r0 = bt * B, nb = min(B, n_rows - r0);
-    const uint32_t dep_before = cum[r] - cum[r0], n_dep = cum[r0 + nb] - cum[r0];
-    const uint32_t pos = dep[r] ? (nb - n_dep) + dep_before : (r - r0) - dep_before;
-    order[r0 + pos] = r - r0;
-    if (r == r0) n_indep[bt] = nb - n_dep;
-  }
-}
-
 // One wavefront owns blocks of 64 consecutive segments: the descriptors, first occurrences and their
 // multipliers are fetched lane-parallel (coalesced), then U segment groups at a time are broadcast and their
 // V rows + S rows gathered together (2*U row loads in flight per wavefront).
@@ -995,83 +961,20 @@ k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
 #ifndef FMX_FUSED_MIN_WAVES
 #define FMX_FUSED_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
-enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2, FUSED_APPLY = 3, FUSED_EXACT_MERGED = 4 };   // 4: EXACT + FusedPrev (FMX_FUSED_MERGE)
-constexpr int FUSED_PREV_SPW = 16;     // segments per claimed block of the deferred-feature work
-// FUSED_EXACT, what the launch of batch b carries along: the deferred features of batch b-1 (SegWork `prev`, n_items
-// blocks of 64 segments) are finished INSIDE this launch instead of by a kernel of their own between the two batches --
-// two kernel boundaries and the small kernel's ramp / drain per batch were ~8 % of the epoch.  Every workgroup first
-// claims blocks of that work from a counter (ctr[0]) until none is left, publishes its part (release fence, ctr[1] +=
-// blocks done) and then turns to its examples.  The examples of batch b that touch one of those features ("dependent":
-// known when the batches are bucketed) are ordered LAST in `order`; a wavefront reaching its first dependent example
-// waits until ctr[1] == n_items (acquire).  Claimed blocks are always being worked on by resident wavefronts that wait
-// for nothing, so the wait cannot deadlock; in practice it never spins (the blocks are done ~1 ms earlier).
-struct FusedPrev {
-  SegWork prev;             // deferred features of the previous batch (prev.nseg == 0: none)
-  uint32_t n_items;         // ceil(prev.nseg / FUSED_PREV_SPW)
-  uint32_t n_indep;         // the first n_indep entries of `order` do not touch the previous batch's deferred features
-  uint32_t* ctr;            // [0] next block to claim, [1] blocks finished (zeroed by the host before the launch)
-  const uint32_t* order;    // [n_rows] example order of this batch (nullptr: natural order, nothing deferred before)
-};
+enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2, FUSED_APPLY = 3 };
 template <int KP, int ZR, int VAR>
 __global__ void __launch_bounds__(256, FMX_FUSED_MIN_WAVES)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
         uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
-        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out, const FusedPrev fp) {
+        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
-  constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), PREV = (VAR == FUSED_EXACT_MERGED), EXACT = (VAR == FUSED_EXACT) || PREV,
-                 APPLY = (VAR == FUSED_APPLY), MASKED = EXACT || APPLY;
+  constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), EXACT = (VAR == FUSED_EXACT), APPLY = (VAR == FUSED_APPLY), MASKED = EXACT || APPLY;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   const float w0s = h.k0 ? (float)(*w0_ptr) : 0.f;
-  bool prev_done = true;
-  if constexpr (PREV) {
-    if (fp.n_items) {
-      // blocks of the previous batch's deferred features, claimed 4 at a time by a WORKGROUP (one returning atomic per
-      // claim, and none once the counter is exhausted: 10 000 wavefronts hitting one word at launch start cost more than
-      // the work itself), one block per wavefront; ONE release per workgroup publishes them
-      __shared__ uint32_t s_base;
-      prev_done = false;
-      const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-      uint32_t mine = 0;                                       // (thread 0) blocks this workgroup finished
-      for (;;) {
-        if (threadIdx.x == 0) {
-          uint32_t cur = __hip_atomic_load(fp.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (cur < fp.n_items) cur = __hip_atomic_fetch_add(fp.ctr, wpb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_base = cur;
-        }
-        __syncthreads();
-        const uint32_t base = s_base;
-        __syncthreads();                                       // everybody has read s_base before thread 0 claims again
-        if (base >= fp.n_items) break;
-        if (base + wib < fp.n_items) apply_seg_block<KP, 8, FUSED_PREV_SPW>(fp.prev, (base + wib) * (uint32_t)FUSED_PREV_SPW, tb, h);
-        if (threadIdx.x == 0) mine += min(wpb, fp.n_items - base);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wavefront's stores have left
-      __syncthreads();                                         // ... and those of the whole workgroup
-      if (threadIdx.x == 0 && mine) {                          // publish: L2 written back, then the count
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(fp.ctr + 1, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  for (uint32_t q = wave0; q < n_rows; q += nwaves) {
-    uint32_t e = q;
-    if constexpr (PREV) {
-      if (fp.order) e = fp.order[q];
-      if (!prev_done && q >= fp.n_indep) {                     // first dependent example of this wavefront
-        uint32_t done = 0;
-        do {
-          if (lane == 0) done = __hip_atomic_load(fp.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          done = __builtin_amdgcn_readfirstlane(done);
-          if (done < fp.n_items) __builtin_amdgcn_s_sleep(16);
-        } while (done < fp.n_items);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        prev_done = true;
-      }
-    }
+  for (uint32_t e = wave0; e < n_rows; e += nwaves) {
     const uint64_t a = row_ptr[row0 + e];
     const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
     const Entry* __restrict__ row = ent + a;

@@ -33,13 +33,11 @@ template <int KP> uint32_t fused_row_cap_kp(uint32_t max_row) {
 template <int KP, int VAR>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
                     const double* w0_in, float* rest_out, const uint64_t* cmask = nullptr, float* S_out = nullptr,
-                    float* mult_out = nullptr, const FusedPrev* prev = nullptr) {
-  FusedPrev fp;
-  if (prev) fp = *prev; else memset(&fp, 0, sizeof(fp));
+                    float* mult_out = nullptr) {
 #define FMX_LAUNCH_ZR(ZRV)                                                                                  \
   if constexpr (fused_zr_ok<KP>(ZRV)) {                                                                     \
     FMX_LAUNCH_WAVES((k_fused<KP, ZRV, VAR>), n_rows, st, s.ent, s.row_ptr, s.target, row0,                 \
-                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out, fp); }
+                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out); }
   switch (fused_zr_select<KP>(s.max_row)) {
     case 8:  FMX_LAUNCH_ZR(8);  break;
     case 16: FMX_LAUNCH_ZR(16); break;
@@ -135,7 +133,7 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   if (nnz >= (1ull << 31)) return fail(h, FMX_E_UNSUPPORTED, "segmented apply: nnz >= 2^31 in one slot (split the data set)");
   hipStream_t st = h->stream;
   uint64_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr, *d_cbatch = nullptr, *depbuf = nullptr;
+  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr, *d_cbatch = nullptr;
   uint32_t cap = 64;
   KP_SWITCH(h->KP, cap = fused_row_cap_kp<KP>(s.max_row));
   void* tmp = nullptr;
@@ -207,30 +205,6 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
       s.cbatch.resize((size_t)n_batches + 1);
       SEG_CHK(hipMemcpyAsync(s.cbatch.data(), d_cbatch, ((size_t)n_batches + 1) * 4, hipMemcpyDeviceToHost, st));
       SEG_CHK(hipStreamSynchronize(st));
-      // which examples of a batch touch a feature the PREVIOUS batch left deferred, and the per-batch example order that
-      // puts them last (FusedPrev)
-      if (n_batches > 1) {
-        SEG_CHK(hipMalloc(&depbuf, 2 * ((size_t)s.n_rows + 1) * 4));
-        uint32_t* dep = depbuf;
-        uint32_t* cum = dep + ((size_t)s.n_rows + 1);
-        uint32_t* d_nindep = d_cbatch;                                   // (copied to the host above)
-        SEG_CHK(hipMemsetAsync(dep, 0, ((size_t)s.n_rows + 1) * 4, st));
-        hipLaunchKernelGGL(k_seg_dep, dim3(2048), dim3(256), 0, st, keys_b, reinterpret_cast<const TEntry*>(vals_b), head, nseg,
-                           s.seg_feat, d_batch_seg, d_cbatch, s.cseg, B, dep);
-        SEG_CHK(hipGetLastError());
-        SEG_CHK(hipStreamSynchronize(st));                               // k_seg_dep read d_cbatch: done before it is overwritten below
-        hipFree(tmp); tmp = nullptr; tmp_bytes = 0;
-        SEG_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, dep, cum, (int)(s.n_rows + 1), st));
-        SEG_CHK(hipMalloc(&tmp, tmp_bytes));
-        SEG_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, dep, cum, (int)(s.n_rows + 1), st));
-        SEG_CHK(hipMalloc(&s.order, (size_t)s.n_rows * 4));
-        hipLaunchKernelGGL(k_seg_order, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, st, dep, cum, s.n_rows, B,
-                           s.order, d_nindep);
-        SEG_CHK(hipGetLastError());
-        s.n_indep.resize(n_batches);
-        SEG_CHK(hipMemcpyAsync(s.n_indep.data(), d_nindep, (size_t)n_batches * 4, hipMemcpyDeviceToHost, st));
-        SEG_CHK(hipStreamSynchronize(st));
-      }
     }
     s.t_ent = reinterpret_cast<TEntry*>(vals_b); vals_b = nullptr;      // payload layout == TEntry
   } else {
@@ -258,7 +232,6 @@ done:
   if (pos) hipFree(pos);
   if (d_batch_seg) hipFree(d_batch_seg);
   if (d_cbatch) hipFree(d_cbatch);
-  if (depbuf) hipFree(depbuf);
   if (tmp) hipFree(tmp);
   if (rc) free_segments(s);
   return rc;
@@ -361,11 +334,10 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
   // split step, library's choice (DEFAULT / FUSED): the features that occur once in the batch are written back example-major
   // (k_fused<FUSED_APPLY>: the wavefront holds S_e, no gather per occurrence), the others by their owner (k_apply_seg over the
   // batch's cseg list) -- the second half of what k_fused<EXACT> + k_apply_seg do in one pass on an unsharded handle.
-  // FMX_APPLY_SEGMENTED keeps the dense owner-per-feature pass.  FMX_SPLIT_DENSE=1: A/B knob (dense pass for DEFAULT too).
-  static const bool split_dense = getenv("FMX_SPLIT_DENSE") && atoi(getenv("FMX_SPLIT_DENSE"));
+  // FMX_APPLY_SEGMENTED keeps the dense owner-per-feature pass.
   // ... where rows are long enough to fill a wavefront's gather: measured per rank of a P-way sharded step (scripts/gpu_shard_probe.py,
   // dense vs example-major second pass): 32 entries per row +5 %, 16 entries -4 %, 8 entries -18 %, 4 entries -17 %.
-  const bool masked = (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) && s.cmask && !s.cbatch.empty() && !split_dense &&
+  const bool masked = (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) && s.cmask && !s.cbatch.empty() &&
                       s.nnz >= (uint64_t)24 * s.n_rows;
   if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) apply = FMX_APPLY_SEGMENTED;   // split step: same rule, two passes
   if (apply == FMX_APPLY_SEGMENTED && seg_batch < 0) return fail(h, FMX_E_STATE, "segmented apply needs batch-aligned rows");
@@ -486,19 +458,8 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   // ring of bias slots: what a batch reads does not depend on which stream wrote it.
   const bool side = B >= 32768u;
   if (side) while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
-  // FMX_FUSED_MERGE=1: the deferred features of batch b-1 ride along in the launch of batch b (FusedPrev) instead of a
-  // kernel of their own between the launches.  Bit-identical results (tests/test_gpu_fullsize.py), but MEASURED SLOWER
-  // (198 vs 207 M examples/s at batch 262 144, 187 vs 213 at 524 288, same box): kept as an A/B knob, off by default.
-  const bool merged = s.order != nullptr && getenv("FMX_FUSED_MERGE") && atoi(getenv("FMX_FUSED_MERGE")) > 0;
-  if (merged && h->fused_ctr_cap < 2 * n_batch) {
-    if (h->fused_ctr) hipFree(h->fused_ctr);
-    h->fused_ctr = nullptr; h->fused_ctr_cap = 0;
-    HIPCHK(h, hipMalloc(&h->fused_ctr, 2 * n_batch * sizeof(uint32_t)));
-    h->fused_ctr_cap = 2 * n_batch;
-  }
   hipStream_t st = h->stream;
   HIPCHK(h, hipEventRecord(h->ev0, st));                    // do not bill the one-time bucketing to the epoch
-  if (merged) HIPCHK(h, hipMemsetAsync(h->fused_ctr, 0, 2 * n_batch * sizeof(uint32_t), st));
   for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
   auto seg_work = [&](uint64_t b, SegWork* sw) {                 // the deferred features of batch b
     const uint32_t c0 = s.cbatch[(size_t)b], c1 = s.cbatch[(size_t)b + 1];
@@ -517,22 +478,11 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     float* mult = h->mult + (size_t)(b & 1) * Bc;
     if (side && b >= d) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (b - d) + 1], 0));   // recurrence of batch b - d is done
     const double* w0_in = h->w0_pp + ((b + 1) % d);         // written by the recurrence of batch b - d (initial bias for b < d)
-    FusedPrev fp;
-    memset(&fp, 0, sizeof(fp));
-    if (merged && b > 0) {
-      seg_work(b - 1, &fp.prev);
-      fp.n_items = (fp.prev.nseg + FUSED_PREV_SPW - 1) / FUSED_PREV_SPW;
-      fp.n_indep = s.n_indep[(size_t)b];
-      fp.ctr = h->fused_ctr + 2 * b;
-      fp.order = s.order + row0;
-      *deferred += fp.prev.nseg;
-    }
-    if (merged) { KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT_MERGED>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, &fp); }); }
-    else        { KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, nullptr); }); }
+    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult); });
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
     if (side) HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
-    if (!merged || b + 1 == n_batch) {                       // the last batch's (or, unmerged, every batch's) deferred features
+    {                                                          // the batch's deferred features
       SegWork sw;
       seg_work(b, &sw);
       if (sw.nseg) {
@@ -607,19 +557,13 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     rc = ensure_scratch(h, 0, (size_t)cap * 3);
     if (rc) return rc;
     const uint64_t n_launch = ((uint64_t)s.n_rows + M - 1) / M;
-    while (h->ev_sync.size() < 2 * n_launch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+    while (h->ev_sync.size() < 2 * n_launch) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
     for (int r = 0; r < 3; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    // even launches go to `stream`, odd ones to `stream3`: the drain of one macro-batch overlaps the ramp-up of
-    // the next (rows of different launches are as independent as rows of one launch)
-    const bool two_streams = getenv("FMX_HOGWILD_TWO_STREAMS") != nullptr;   // +6 % but launches overlap (timing per launch blurs)
-    hipEvent_t ev_start = h->ev_sync[2 * n_launch];
-    HIPCHK(h, hipEventRecord(ev_start, h->stream));
-    if (two_streams) HIPCHK(h, hipStreamWaitEvent(h->stream3, ev_start, 0));
     for (uint64_t i = 0; i < n_launch; i++) {
       const uint64_t row0 = i * M;
       const uint32_t nb = (uint32_t)std::min<uint64_t>(M, s.n_rows - row0);
       float* rest = h->rest + (size_t)(i % 3) * cap;
-      hipStream_t fs = (two_streams && (i & 1)) ? h->stream3 : h->stream;
+      hipStream_t fs = h->stream;
       if (i >= 3) HIPCHK(h, hipStreamWaitEvent(fs, h->ev_sync[2 * (i - 3) + 1], 0));   // scan i-3 done
       hipEvent_t ea = nullptr, eb = nullptr;
       // (no per-launch events here: a timing event between two launches costs ~13 % on this path; the epoch is

@@ -11,6 +11,13 @@ from common import Golden
 from conftest import golden_cases
 
 pytestmark = pytest.mark.gpu
+
+
+def _split(monkeypatch, v):
+    """fmx_config::als_split_min for the handles created from here on: "0" = never split (fused draws), "1" = every level, n = levels of >= n entries"""
+    from libfm_amd import capi as _c
+    monkeypatch.setattr(_c, "ALS_SPLIT_MIN", _c.ALS_SPLIT_NEVER if str(v) == "0" else int(v))
+
 CASES = [c for c in golden_cases() if c.startswith("als_")]
 
 
@@ -34,9 +41,9 @@ def make_learner(g, oracle):
 @pytest.fixture(params=["fused", "split"])
 def draw_form(request, monkeypatch):
     """fused: column sums, draw and {e, q} update in one launch per (family, level); split: the update as a row-ordered
-    stream (k_als_rows) -- the library's choice for levels of >= FMX_ALS_SPLIT_MIN entries (read at fmx_als_begin), forced
+    stream (k_als_rows) -- the library's choice for levels of >= fmx_config::als_split_min entries, forced
     here for every level so that the small fixtures run it too (duplicate ids in a row, ragged rows, groups, probit)."""
-    monkeypatch.setenv("FMX_ALS_SPLIT_MIN", "1" if request.param == "split" else "0")
+    _split(monkeypatch, "1" if request.param == "split" else "0")
     return request.param
 
 
@@ -122,7 +129,7 @@ def test_split_step_is_the_fused_step(oracle, monkeypatch, task, do_sample):
     ent2, rp2, y2 = datagen.onehot_fields(n, nnz, 2000, seed=32, classification=bool(task))
     res = []
     for split_min in ("0", "1", "20000"):                      # never / always / the big levels only (30 000 entries each)
-        monkeypatch.setenv("FMX_ALS_SPLIT_MIN", split_min)
+        _split(monkeypatch, split_min)
         fm = L.FMModel()
         fm.num_attribute, fm.num_factor = n, k
         fm.w0, fm.w, fm.v = 0.1, oracle.init_values(5, n, 1, 0.1)[0].copy(), oracle.init_values(4, n, k, 0.1).copy()

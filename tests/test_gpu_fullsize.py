@@ -124,31 +124,6 @@ def test_fused_minibatch_is_deterministic_at_bench_batch(capi):
     assert 0.02 * rows * NNZ < sums[0][2] < 0.06 * rows * NNZ   # ~4 % of the (batch, feature) pairs hold >= 2 occurrences
 
 
-def test_fused_merged_pass_equals_separate_pass(capi, monkeypatch):
-    """the deferred features of batch b-1 are finished by a kernel of their own between the launches (default) -- or, with
-    FMX_FUSED_MERGE=1, INSIDE the launch of batch b (FusedPrev: claimed blocks, release / acquire hand-off to the examples
-    that depend on them; measured slower, kept as a knob).  Same arithmetic, so the two schedules must agree BIT FOR BIT; a
-    dependent example that read a row (or a linear weight sharing a line with another feature's) before the hand-off would
-    show up here.  Bench configuration: n = 1e8, batch 262 144 -- ~10 % of a batch's examples depend on the previous batch."""
-    rows = 1 << 20
-    res = []
-    for merge in (None, "1"):
-        if merge:
-            monkeypatch.setenv("FMX_FUSED_MERGE", merge)
-        else:
-            monkeypatch.delenv("FMX_FUSED_MERGE", raising=False)
-        h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
-        h.init_params(0.0, 0.05, 3)
-        h.synth_rows(0, 78, 0, rows, NNZ)
-        for _ in range(2):
-            st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 262144, 0, 0, 2)
-        res.append((h.predict(0, rows).tobytes(), h.get_w0(), st.deferred_features))
-        h.close()
-    assert res[0][2] == res[1][2] > 0
-    assert res[0][1] == res[1][1]
-    assert res[0][0] == res[1][0]
-
-
 def test_hogwild_at_bench_size_is_the_batch_rule_off_collisions(capi, oracle):
     """HOGWILD where it is benchmarked (n = 1e8, one 65 536-row launch, bias frozen for the launch).  An example none of
     whose features occurs anywhere else in the launch is independent of every other example, so its parameter rows must

@@ -8,6 +8,13 @@ import pytest
 import datagen
 
 pytestmark = pytest.mark.gpu
+
+
+def _split(monkeypatch, v):
+    """fmx_config::als_split_min for the handles created from here on: "0" = never split (fused draws), "1" = every level, n = levels of >= n entries"""
+    from libfm_amd import capi as _c
+    monkeypatch.setattr(_c, "ALS_SPLIT_MIN", _c.ALS_SPLIT_NEVER if str(v) == "0" else int(v))
+
 RTOL = 1e-4
 
 
@@ -93,7 +100,7 @@ def test_random_shape_als_both_draw_forms(capi, oracle, seed, monkeypatch):
     wl, vl = float(rng.uniform(0.5, 3.0)), float(rng.uniform(1.0, 10.0))
     ref = None
     for split_min in ("0", "1"):
-        monkeypatch.setenv("FMX_ALS_SPLIT_MIN", split_min)
+        _split(monkeypatch, split_min)
         m = oracle.Model(n, k, k0, k1, 0.0, wl, vl)
         m.v[:] = oracle.init_values(31 + seed, n, k, 0.1)
         if k1:
@@ -211,7 +218,7 @@ def test_kept_blocks_equal_joined_rows_at_odd_factor_counts(capi, oracle, k, see
     n = offs[-1] + blocks[-1][2]
     res = []
     for keep, split, sample in ((True, "0", False), (False, "0", False), (True, "1", False), (True, "0", True), (False, "1", True)):
-        monkeypatch.setenv("FMX_ALS_SPLIT_MIN", split)
+        _split(monkeypatch, split)
         fm = L.FMModel()
         fm.num_attribute, fm.num_factor = n, k
         fm.w0, fm.w, fm.v = 0.0, oracle.init_values(71, n, 1, 0.1)[0].copy(), oracle.init_values(72, n, k, 0.1).copy()
@@ -334,7 +341,7 @@ def test_no_factors_at_all(capi, oracle, monkeypatch):
     ref = fresh()
     oracle.als_learn(ref, d, te, 0, 3, 1.0, 1.0, lo, hi)
     for world, split in ((1, "0"), (1, "1"), (3, "0")):
-        monkeypatch.setenv("FMX_ALS_SPLIT_MIN", split)
+        _split(monkeypatch, split)
         hs = [capi.Handle(n, 0, True, True, 0, 0.0, 1.0, 1.0, 0.0, lo, hi, device=0, shard_rank=r, shard_world=world, shard_hash=1)
               for r in range(world)]
         for h in hs:

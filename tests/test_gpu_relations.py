@@ -14,6 +14,13 @@ from common import Golden
 from conftest import golden_cases
 
 pytestmark = pytest.mark.gpu
+
+
+def _split(monkeypatch, v):
+    """fmx_config::als_split_min for the handles created from here on: "0" = never split (fused draws), "1" = every level, n = levels of >= n entries"""
+    from libfm_amd import capi as _c
+    monkeypatch.setattr(_c, "ALS_SPLIT_MIN", _c.ALS_SPLIT_NEVER if str(v) == "0" else int(v))
+
 CASES = [c for c in golden_cases() if c.startswith("rel_als_")]
 
 
@@ -68,7 +75,7 @@ def test_kept_blocks_predict_like_the_expanded_rows(oracle):
 @pytest.mark.parametrize("keep,split", [(True, False), (False, False), (True, True), (False, True)])
 @pytest.mark.parametrize("name", CASES)
 def test_als_on_relations_matches_reference(oracle, name, keep, split, monkeypatch):
-    monkeypatch.setenv("FMX_ALS_SPLIT_MIN", "1" if split else "0")   # main features: split / fused form of the draws
+    _split(monkeypatch, "1" if split else "0")   # main features: split / fused form of the draws
     from libfm_amd import data as D
     from libfm_amd import learner as L
     g = Golden(name)
