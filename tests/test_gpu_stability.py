@@ -185,3 +185,35 @@ def test_default_mode_lands_on_the_real_reference_config0():
     l.close()
     assert np.abs(lines[-1] - Z["stdout_iters"][-1]).max() <= 0.003, (lines[-1], Z["stdout_iters"][-1])
     assert np.abs(lines[2:] - Z["stdout_iters"][2:]).max() <= 0.01
+
+
+@pytest.mark.parametrize("k,n,rows,batch", [(64, 300_000, 32768, 8192), (64, 40_000, 12288, 4096), (128, 500_000, 16384, 8192), (200, 100_000, 8192, 4096)])
+def test_dense_collisions_one_pass_equals_two_pass_and_the_oracle(capi, oracle, k, n, rows, batch):
+    """dense id spaces at k >= 64: most features of a batch are met once to three times, partners a few hundred examples apart, rows
+    with several deferred entries.  The one-pass form (unique features in k_fused, the rest in k_apply_seg) against the oracle's
+    rule at 1e-4, and against the two-pass form (every feature through k_apply_seg) to fp32 rounding."""
+    O = oracle
+    nnz = 32
+    d = O.synth_rows(5, 0, rows, nnz, n)
+    m = O.Model(n, k, True, True, 0.0, 0.0005, 0.001)
+    m.v[:] = O.init_values(1, n, k, 0.05)
+    res = {}
+    for apply_ in (capi.APPLY_FUSED, capi.APPLY_SEGMENTED):
+        h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0005, 0.001, 0.004, -1.0, 1.0, device=0)
+        h.set_params(m.w0, m.w, m.v)
+        h.upload_rows(0, d.entries, d.row_ptr, d.target)
+        for _ in range(2):
+            st = h.sgd_epoch(0, capi.SGD_MINIBATCH, apply_, batch, 64, capi.FLAG_BIAS_LAG, 1)
+        if apply_ == capi.APPLY_FUSED:
+            assert st.deferred_features > 0.1 * rows * nnz
+        res[apply_] = h.get_params()
+        h.close()
+    for _ in range(2):
+        O.sgd_epoch_minibatch(m, d, 1, 0.004, -1.0, 1.0, batch, 64, bias_lag=1)
+    w0, w, v = res[capi.APPLY_FUSED]
+    np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(w, m.w, rtol=1e-4, atol=2e-5)
+    assert abs(w0 - m.w0) <= 1e-4 * abs(m.w0) + 2e-5
+    w0s, ws, vs = res[capi.APPLY_SEGMENTED]
+    np.testing.assert_allclose(v, vs, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(w, ws, rtol=2e-6, atol=1e-7)
