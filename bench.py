@@ -79,6 +79,33 @@ def cpu_baseline(n, k, nnz, rows):
             "seconds": round(sec, 3), "setup_seconds": round(setup, 1), "host_cores": cores}
 
 
+def cpu_baseline_rows(h, n, k, rows):
+    """cpu_baseline for a workload the host generators do not have (Criteo-shaped): the first `rows` rows are copied back from the
+    device and the restated reference loop (fm_model::predict + fm_SGD, fp64, factor-major V; oracle/fm_oracle.c) runs over them
+    once on one core."""
+    import ctypes as C
+    import numpy as np
+    from oracle import oracle as O
+    ent, rp, y = h.download_rows(0)
+    rows = min(rows, len(y))
+    d = O.Data(ent[:int(rp[rows])], rp[:rows + 1], y[:rows])
+    avail, n_cpu = mem_available_bytes(), n
+    if avail and (n * k * 8 + n * 8) * 1.25 > avail:
+        return {"error": "host RAM too small for the fp64 model of this workload"}
+    m = O.Model.__new__(O.Model)
+    m.n, m.k, m.k0, m.k1, m.reg0, m.regw, m.regv, m.w0 = int(n), int(k), True, True, 0.0, 0.0, 0.001, 0.0
+    m.w = np.empty(m.n, dtype=np.float64)
+    m.v = np.empty((m.k, m.n), dtype=np.float64)
+    cm = m._c()
+    O.lib().fmo_fill_params(C.byref(cm), 1, 0.01, min(os.cpu_count() or 1, 64))
+    t0 = time.time()
+    O.sgd_epoch_online(m, d, 1, 0.01, -1.0, 1.0)
+    sec = time.time() - t0
+    return {"value": round(rows / sec, 1), "unit": "examples/s", "cores": 1, "kind": "port",
+            "sample": "the first %d rows of the step's Criteo-shaped rows (copied back from the device), restated reference loop, "
+                      "n=%d k=%d, fp64 reference layout, 1 epoch" % (rows, n, k), "seconds": round(sec, 3), "host_cores": os.cpu_count() or 1}
+
+
 def v_read_fraction(value, k, nnz, world=1):
     """SURVEY section 8(d) fraction (1): examples/s x z*k*4 bytes of gathered V rows per GPU / HBM peak."""
     return round(value * nnz * k * 4 / world / 1e9 / HBM_PEAK_GBS, 4)
@@ -393,6 +420,8 @@ def main():
                     device=local_rank, shard_rank=rank, shard_world=world, shard_hash=1 if world > 1 else 0)
     h.init_params(0.0, 0.01, 1)
     h.synth_rows(0, 123, 0, args.rows, args.nnz, capi.SYNTH_CRITEO if criteo else capi.SYNTH_UNIFORM)
+    if criteo and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_rows(h, args.n, args.k, min(args.cpu_rows, 100_000))
     info = h.info()
     mode = capi.SGD_HOGWILD if args.mode == "hogwild" else capi.SGD_MINIBATCH
     apply_ = {"default": capi.APPLY_DEFAULT, "segmented": capi.APPLY_SEGMENTED, "atomic": capi.APPLY_ATOMIC,

@@ -864,30 +864,64 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
           for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, sf2[u][v], G[v]);
           A = fmaf(mx2, x2, A); Gw += mx2;
         }
-        // further occurrences of the feature in this batch, TL at a time: the descriptors, then the multipliers and S rows of all
-        // TL are issued before the first is used (a frequent feature of Criteo-shaped rows has dozens to thousands per batch; one
-        // at a time this was a chain of three dependent gathers per occurrence).  Added in occurrence order, as before.
-        constexpr int TL = (VEC <= 2) ? 8 : 4;
-        for (; i2 < b; i2 += TL) {
-          TEntry tt[TL]; float mm[TL]; float s2[TL][VEC];
+        // further occurrences of the feature in this batch (a frequent feature of Criteo-shaped rows has dozens to thousands per
+        // batch).  Added in occurrence order, so the result does not depend on how they are fetched:
+        if constexpr (EPI == 1) {
+          // one row per wave-wide load: the whole wavefront is here together.  64 descriptors and their multipliers arrive
+          // lane-parallel (one coalesced load + one gather), then the S rows TL at a time with the descriptors broadcast by
+          // v_readlane -- per TL occurrences ONE dependent round trip instead of three per occurrence.
+          constexpr int TL = (VEC == 1) ? 16 : 8;
+          for (uint32_t base = i2; base < b; base += 64) {
+            const uint32_t cc = min(64u, b - base);
+            TEntry te; te.e = 0; te.x = 0.f; float tm = 0.f;
+            if (lane < cc) { te = load_stream8(t_ent + base + lane); tm = mult[te.e]; }
+            for (uint32_t q0 = 0; q0 < cc; q0 += TL) {
+              float s2[TL][VEC];
 #pragma unroll
-          for (int q = 0; q < TL; q++) { tt[q].e = 0; tt[q].x = 0.f; if (i2 + q < b) tt[q] = t_ent[i2 + q]; }
+              for (int q = 0; q < TL; q++) {
+                const uint32_t e2 = bcast_u32<1>(te.e, (q0 + q) & 63u);
+                if (q0 + q < cc) load_vec<VEC>(S + (size_t)e2 * KP + f * VEC, s2[q]);
+                else {
 #pragma unroll
-          for (int q = 0; q < TL; q++) {
-            mm[q] = 0.f;
-            if (i2 + q < b) { mm[q] = mult[tt[q].e]; load_vec<VEC>(S + (size_t)tt[q].e * KP + f * VEC, s2[q]); }
-            else {
+                  for (int v = 0; v < VEC; v++) s2[q][v] = 0.f;
+                }
+              }
 #pragma unroll
-              for (int v = 0; v < VEC; v++) s2[q][v] = 0.f;
+              for (int q = 0; q < TL; q++) {
+                const float x2 = bcast_f32<1>(te.x, (q0 + q) & 63u), m2 = bcast_f32<1>(tm, (q0 + q) & 63u);
+                if (q0 + q < cc) {
+                  const float mx2 = m2 * x2;
+#pragma unroll
+                  for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[q][v], G[v]);
+                  A = fmaf(mx2, x2, A); Gw += mx2;
+                }
+              }
             }
           }
+        } else {
+          // several rows per wave-wide load (KP < 64): every lane group walks its own segment, TL occurrences at a time
+          constexpr int TL = 8;
+          for (; i2 < b; i2 += TL) {
+            TEntry tt[TL]; float mm[TL]; float s2[TL][VEC];
 #pragma unroll
-          for (int q = 0; q < TL; q++) {
-            if (i2 + q < b) {
-              const float mx2 = mm[q] * tt[q].x;
+            for (int q = 0; q < TL; q++) { tt[q].e = 0; tt[q].x = 0.f; if (i2 + q < b) tt[q] = t_ent[i2 + q]; }
 #pragma unroll
-              for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[q][v], G[v]);
-              A = fmaf(mx2, tt[q].x, A); Gw += mx2;
+            for (int q = 0; q < TL; q++) {
+              mm[q] = 0.f;
+              if (i2 + q < b) { mm[q] = mult[tt[q].e]; load_vec<VEC>(S + (size_t)tt[q].e * KP + f * VEC, s2[q]); }
+              else {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) s2[q][v] = 0.f;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < TL; q++) {
+              if (i2 + q < b) {
+                const float mx2 = mm[q] * tt[q].x;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[q][v], G[v]);
+                A = fmaf(mx2, tt[q].x, A); Gw += mx2;
+              }
             }
           }
         }
@@ -926,6 +960,61 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
       }
     }
   }
+}
+// the bias recurrence of a SMALL batch (the batches the stability cut leaves of rows with frequent features: a few hundred to a few
+// thousand examples) on one wavefront, straight from global memory -- k_scan's arithmetic (micro-chunks of `chunk` examples, every
+// example of a chunk sees the bias of the chunk start, fm_sgd.h:34-37 summed per chunk) without its LDS tiles
+struct ScanSmall { const float* rest; const float* target; const double* w0_in; double* w0_out; uint32_t n_rows, chunk; };
+__device__ __forceinline__ void scan_small(const ScanSmall sc, const Hyper& h) {
+  const uint32_t lane = threadIdx.x & 63u;
+  double w0 = *sc.w0_in;
+  if (sc.n_rows <= 1024u && (sc.chunk & 63u) == 0) {
+    // the whole batch in registers first (one round trip to memory, not one per micro-chunk): element c0 + i + 64 j of a chunk
+    // sits in lane i, register (c0 / 64 + j)
+    float r[16], y[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t i = (uint32_t)j * 64u + lane;
+      r[j] = (i < sc.n_rows) ? sc.rest[i] : 0.f;
+      y[j] = (i < sc.n_rows) ? sc.target[i] : 0.f;
+    }
+    const uint32_t per = sc.chunk >> 6;                        // registers per micro-chunk
+    for (uint32_t c0 = 0; c0 < sc.n_rows; c0 += sc.chunk) {
+      const uint32_t nc = min(sc.chunk, sc.n_rows - c0);
+      const float w0s = h.k0 ? (float)w0 : 0.f;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t i = (uint32_t)j * 64u + lane;
+        if ((uint32_t)j >= (c0 >> 6) && (uint32_t)j < (c0 >> 6) + per && i < sc.n_rows) acc += multiplier_fast(h, w0s + r[j], y[j]);
+      }
+      const float tot = wave_sum_dpp(acc);
+      if (h.k0) w0 -= (double)h.lr * ((double)tot + (double)nc * (double)h.reg0 * (double)w0s);
+    }
+  } else {
+    for (uint32_t c0 = 0; c0 < sc.n_rows; c0 += sc.chunk) {
+      const uint32_t nc = min(sc.chunk, sc.n_rows - c0);
+      const float w0s = h.k0 ? (float)w0 : 0.f;
+      float acc = 0.f;
+      for (uint32_t i = lane; i < nc; i += 64) acc += multiplier_fast(h, w0s + sc.rest[c0 + i], sc.target[c0 + i]);
+      const float tot = wave_sum_dpp(acc);
+      if (h.k0) w0 -= (double)h.lr * ((double)tot + (double)nc * (double)h.reg0 * (double)w0s);
+    }
+  }
+  if (lane == 0) *sc.w0_out = w0;
+}
+// k_apply_seg_scan: the deferred features of a small batch AND its bias recurrence in one launch (the last workgroup's first
+// wavefront runs the recurrence): a small batch is a few microseconds of work, every launch it needs costs as much again
+template <int KP, int U, int SPW>
+__global__ void __launch_bounds__(256)
+k_apply_seg_scan(const SegWork sw, const Tab tb, Hyper h, const ScanSmall sc) {
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x < 64 && h.k0) scan_small(sc, h);
+    return;
+  }
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = (gridDim.x - 1) * (blockDim.x >> 6);
+  for (uint32_t blk = wave0 * (uint32_t)SPW; blk < sw.nseg; blk += nwaves * (uint32_t)SPW) apply_seg_block<KP, U, SPW>(sw, blk, tb, h);
 }
 template <int KP, int U, int SPW>
 __global__ void __launch_bounds__(256)

@@ -482,24 +482,29 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
     if (side) HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
-    {                                                          // the batch's deferred features
-      SegWork sw;
-      seg_work(b, &sw);
+    SegWork sw;                                              // the batch's deferred features
+    seg_work(b, &sw);
+    *deferred += sw.nseg;
+    if (!side) {
+      // small batch: deferred features and bias recurrence in ONE launch (one workgroup per four segments + one for the recurrence)
+      const ScanSmall sc{rest, s.target + row0, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d), nb, chunk};
+      const uint32_t grid = (sw.nseg + 3) / 4 + 1;
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply_seg_scan<KP, 8, 1>), dim3(grid), dim3(256), 0, st, sw, h->tb, hy, sc));
+      HIPCHK(h, hipGetLastError());
+    } else {
       if (sw.nseg) {
         // segments per wavefront of the deferred-feature pass: 16 (measured best at the bench shape: 8 / 16 / 32 / 64 -> 244.5 / 245.0 /
-        // 243.0 / 241.0 M examples/s), fewer when the list is short (the small batches of rows with frequent features: a few
-        // hundred to a few thousand segments, many of them long) so that the pass still spreads over the chip
+        // 243.0 / 241.0 M examples/s), fewer when the list is short so that the pass still spreads over the chip
         if (sw.nseg >= 16u * 2048u)     { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 16>), ((uint64_t)sw.nseg + 15) / 16, st, sw, h->tb, hy)); }
         else if (sw.nseg >= 4u * 2048u) { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 4>), ((uint64_t)sw.nseg + 3) / 4, st, sw, h->tb, hy)); }
         else                            { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 1>), (uint64_t)sw.nseg, st, sw, h->tb, hy)); }
         HIPCHK(h, hipGetLastError());
-        *deferred += sw.nseg;
       }
+      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * b], 0));
+      rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d));
+      if (rc) return rc;
+      HIPCHK(h, hipEventRecord(h->ev_sync[2 * b + 1], h->stream2));
     }
-    if (side) HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * b], 0));
-    rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, side ? h->stream2 : st, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d));
-    if (rc) return rc;
-    if (side) HIPCHK(h, hipEventRecord(h->ev_sync[2 * b + 1], h->stream2));
     (*batches)++; (*launches)++;
   }
   if (side) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (n_batch - 1) + 1], 0));

@@ -3,10 +3,10 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r03b
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-( timeout 600 python -m pytest tests/test_gpu_stability.py tests/test_gpu_parity.py -q -m gpu 2>&1 | tail -20 ) > $OUT/stability.log 2>&1
-( timeout 300 python bench.py --workload criteo --rows 1048576 --steps 3 --warmup 1 2>&1 | tail -1 ) > $OUT/bench_criteo.log 2>&1
+( timeout 600 python -m pytest tests/test_gpu_stability.py tests/test_gpu_parity.py tests/test_gpu_bench.py -q -m gpu 2>&1 | tail -20 ) > $OUT/stability.log 2>&1
+( timeout 400 python bench.py --workload criteo --rows 1048576 --steps 3 --warmup 1 2>/dev/null | grep "^{" ) > $OUT/bench_criteo.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o criteo -- python $GRAFT_REPO_ROOT/bench.py --workload criteo --rows 262144 --steps 2 --warmup 1 2>&1 | tail -2 ) > $OUT/prof.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o criteo -- python $GRAFT_REPO_ROOT/bench.py --workload criteo --rows 262144 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -2 ) > $OUT/prof.log 2>&1
 cd $GRAFT_REPO_ROOT
 find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/criteo_kernel_stats.csv
 rm -rf $OUT/prof
