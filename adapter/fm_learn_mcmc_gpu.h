@@ -51,10 +51,10 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
       if (fmx_create(&c, &x) != FMX_OK) throw std::string(fmx_last_error(NULL));
       hs.push_back(x);
       if (r == 0) h = x;
-      if (fmx_set_params(x, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL) != FMX_OK) throw std::string(fmx_last_error(x));
       if (G > 1 && fmx_set_groups(x, (const uint32_t*)meta->attr_group.value, G) != FMX_OK) throw std::string(fmx_last_error(x));   // DVector<uint>, Data.h:41
     }
     if (fmx_group_create(&hs[0], world, &grp) != FMX_OK) throw std::string(fmx_last_error(hs[0]));
+    gcheck(fmx_group_set_params(grp, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));   // the block crosses PCIe once
     upload(0, train); upload(1, test);
     gcheck(fmx_group_als_begin(grp, 0));
     fmx_als_opts o;
@@ -179,7 +179,12 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
       rel[r].attr_offset = rd->attr_offset;
     }
     uint32_t how = (hs.size() > 1 || gpu_blocks_expand || rel.empty()) ? FMX_BLOCKS_EXPAND : FMX_BLOCKS_KEEP;   // shards sweep joined rows
-    for (size_t r = 0; r < hs.size(); r++)
+    if (rel.empty()) {                                                      // plain rows: across PCIe once, filtered per shard on its device
+      gcheck(fmx_group_upload_rows(grp, slot, main.ent.empty() ? NULL : &main.ent[0], (const uint64_t*)&main.row_ptr[0], d.target.value,
+                                   d.num_cases, main.ent.size()));
+      return;
+    }
+    for (size_t r = 0; r < hs.size(); r++)                                  // (a shard joins the blocks on the host and keeps its own features)
       if (fmx_upload_block_rows_ex(hs[r], slot, main.ent.empty() ? NULL : &main.ent[0], (const uint64_t*)&main.row_ptr[0], d.target.value,
                                    d.num_cases, main.ent.size(), rel.empty() ? NULL : &rel[0], (uint32_t)rel.size(), how) != FMX_OK)
         throw std::string(fmx_last_error(hs[r]));

@@ -82,10 +82,10 @@ class fmx_sgd_binding : public Base {
       if (fmx_create(&c, &x) != FMX_OK) throw std::string(fmx_last_error(NULL));
       hs.push_back(x);
       if (r == 0) h = x;
-      // every shard is handed the FULL block and keeps its own features
-      if (fmx_set_params(x, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL) != FMX_OK) throw std::string(fmx_last_error(x));
     }
     if (fmx_group_create(&hs[0], world, &grp) != FMX_OK) throw std::string(fmx_last_error(hs[0]));
+    // the block crosses PCIe once; every shard keeps its own features (fmx_group_set_params)
+    gcheck(fmx_group_set_params(grp, fm->w0, fm->w.value, fm->num_factor > 0 ? fm->v.value[0] : NULL));
   }
 
   void fetch_params() {                                    // main() reads fm afterwards (libfm.cpp:418-434)
@@ -108,9 +108,9 @@ class fmx_sgd_binding : public Base {
       ent.insert(ent.end(), r.data, r.data + r.size);
       row_ptr.push_back(ent.size());
     }
-    for (size_t r = 0; r < hs.size(); r++)                 // a shard keeps the entries of its own features
-      if (fmx_upload_rows(hs[r], (int)slots.size(), ent.empty() ? NULL : &ent[0], (const uint64_t*)&row_ptr[0],
-                          d.target.value, d.data->getNumRows(), ent.size()) != FMX_OK) throw std::string(fmx_last_error(hs[r]));
+    // the rows cross PCIe once; a shard keeps the entries of its own features (filtered on its device)
+    gcheck(fmx_group_upload_rows(grp, (int)slots.size(), ent.empty() ? NULL : &ent[0], (const uint64_t*)&row_ptr[0],
+                                 d.target.value, d.data->getNumRows(), ent.size()));
     slots.push_back(&d);
     return (int)slots.size() - 1;
   }

@@ -341,6 +341,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the all-reduce through the host (testing the N>1 path without RCCL)")
     ap.add_argument("--same-device", action="store_true", help="testing: every shard / rank on device 0 (several GPUs from one process: the loopback exchange)")
+    ap.add_argument("--multi-process", action="store_true",
+                    help="several GPUs: one process per GPU even with --same-device (testing the self-launch on a one-GPU box; needs "
+                         "--backend gloo --driver torch there: RCCL refuses two ranks on one device)")
     ap.add_argument("--one-process", action="store_true",
                     help="several GPUs: drive all shards from this process through fmx_group_* (one host thread) instead of one process per GPU")
     ap.add_argument("--driver", default="lib", choices=["lib", "torch"],
@@ -378,7 +381,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: either all shards from this process (fmx_group_*), or -- the default on N distinct
         # devices -- re-exec as one process per GPU, which is how the library's RCCL schedule keeps N host threads busy
-        if args.same_device or args.one_process:
+        if (args.same_device or args.one_process) and not args.multi_process:
             return bench_group(args, capi, criteo)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -438,9 +441,12 @@ def main():
         batch = h.sgd_batch_info(0, args.batch).batch if args.mode != "hogwild" else (args.batch or 262144)
         main_time, main_launches = 0.0, 0
 
+        setup_s = 0.0
+
         def step(timed):
-            nonlocal main_time, main_launches, deferred, batch_stats
+            nonlocal main_time, main_launches, deferred, batch_stats, setup_s
             st = h.sgd_epoch(0, mode, apply_, args.batch, args.w0_chunk, (capi.FLAG_TIME_MAIN_KERNEL if timed else 0) | lagf, bias_lag)
+            setup_s += st.setup_seconds
             if timed:
                 main_time += st.main_kernel_seconds
                 main_launches += st.main_kernel_launches
@@ -593,6 +599,12 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu_ref if (cpu_ref and "value" in cpu_ref) else cpu,
         }
+        if not sharded and args.mode != "hogwild":
+            # outside `value` and outside the timed steps: paid once per (data set, batch size) in the first warm-up step
+            out["one_time_setup"] = {"seconds": round(setup_s, 4), "equivalent_steps": round(setup_s / (elapsed / args.steps), 2),
+                                     "what": "collision mass of the rows + bucketing of the entries by (batch, feature) (device radix sort, "
+                                             "segment / mask / deferred-list build; fmx_epoch_stats::setup_seconds); libFM never shuffles "
+                                             "(fm_learn_sgd_element.h:56), so every later epoch reuses it"}
         if batch_stats is not None and args.mode != "hogwild":
             out["config"]["batch_rule"] = {"batch": batch_stats.batch_used, "collision_mass": round(batch_stats.collision_mass, 6),
                                            "gain": round(batch_stats.batch_gain, 4),

@@ -156,6 +156,10 @@ typedef struct fmx_epoch_stats {
                                rule follows the reference's online loop for <= 1, degrades above and diverges beyond ~2 */
   uint32_t status;          /* FMX_STAT_* */
   uint32_t reserved;
+  double   setup_seconds;   /* host wall-clock this call spent on ONE-TIME work for the slot (not part of device_seconds): the rows' collision mass
+                               and the bucketing of the entries by (batch, feature) -- the segments, masks and lists the MINIBATCH forms
+                               walk; libFM never shuffles (fm_learn_sgd_element.h:56), so they are built once per (slot, batch size).
+                               0 when everything was cached */
   double   phase_seconds[4]; /* fmx_group_sgd_epoch / feature shards with FMX_FLAG_TIME_MAIN_KERNEL, HIP events on the first local
                                shard's compute stream, summed over the epoch's batches: [0] partial sums of the batch (fmx_sgd_partial),
                                [1] exposed exchange (end of the sums -> the reduced sums are available: what the wire costs beyond
@@ -369,6 +373,13 @@ int fmx_comm_destroy(fmx_handle h);
 int fmx_group_create(fmx_handle *handles, int n, fmx_group *out);
 int fmx_group_destroy(fmx_group g);
 const char *fmx_group_last_error(fmx_group g);
+/* fmx_set_params / fmx_upload_rows for ALL shards of a group with the host data crossing PCIe ONCE: the fp64 block (51 GB at the
+ * north-star size) and the rows are staged on the first shard's device, reach the other devices over xGMI (hipMemcpyPeer), and
+ * every shard converts / filters its own features on its device (k_stage_in, k_shard_rows).  Same result as calling the
+ * per-handle functions on every shard with the full arrays.  Not for slots with `-relation` blocks. */
+int fmx_group_set_params(fmx_group g, double w0, const double *w, const double *v);
+int fmx_group_upload_rows(fmx_group g, int slot, const void *entries, const uint64_t *row_ptr, const float *target,
+                          uint32_t n_rows, uint64_t nnz);
 int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts *opts, fmx_epoch_stats *stats);
 int fmx_group_predict(fmx_group g, int slot, double *out);
 int fmx_group_evaluate(fmx_group g, int slot, fmx_eval *out);

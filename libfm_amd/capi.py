@@ -56,7 +56,7 @@ class EpochStats(C.Structure):
                 ("main_kernel_seconds", C.c_double), ("main_kernel_launches", C.c_uint64),
                 ("max_feature_count", C.c_uint32), ("batch_used", C.c_uint32), ("deferred_features", C.c_uint64),
                 ("collision_mass", C.c_double), ("batch_gain", C.c_double), ("status", C.c_uint32), ("reserved", C.c_uint32),
-                ("phase_seconds", C.c_double * 4)]
+                ("setup_seconds", C.c_double), ("phase_seconds", C.c_double * 4)]
 
 
 class BatchInfo(C.Structure):
@@ -142,6 +142,8 @@ SYMBOLS = [
     ("fmx_group_create", C.c_int, [C.POINTER(H), C.c_int, C.POINTER(H)]),
     ("fmx_group_destroy", C.c_int, [H]),
     ("fmx_group_last_error", C.c_char_p, [H]),
+    ("fmx_group_set_params", C.c_int, [H, C.c_double, C.c_void_p, C.c_void_p]),
+    ("fmx_group_upload_rows", C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     ("fmx_group_sgd_epoch", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(EpochStats)]),
     ("fmx_group_predict", C.c_int, [H, C.c_int, C.c_void_p]),
     ("fmx_group_evaluate", C.c_int, [H, C.c_int, C.POINTER(Eval)]),
@@ -490,6 +492,21 @@ class Group:
     def _chk(self, rc):
         if rc != FMX_OK:
             raise FmxError(rc, self.lib.fmx_group_last_error(self.g).decode())
+
+    def set_params(self, w0, w, v):
+        """the full fm_model block for every shard, crossing PCIe once (fmx_group_set_params)"""
+        h0 = self.handles[0]
+        w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        v = None if v is None else np.ascontiguousarray(v, dtype=np.float64)
+        self._chk(self.lib.fmx_group_set_params(self.g, float(w0), _ptr(w), _ptr(v) if h0.k > 0 else None))
+
+    def upload_rows(self, slot, entries, row_ptr, target):
+        """rows for every shard, crossing PCIe once; each shard filters its own features on its device (fmx_group_upload_rows)"""
+        entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        target = None if target is None else np.ascontiguousarray(target, dtype=np.float32)
+        self._chk(self.lib.fmx_group_upload_rows(self.g, slot, _ptr(entries) if len(entries) else None, _ptr(row_ptr), _ptr(target),
+                                                 len(row_ptr) - 1, len(entries)))
 
     def sgd_epoch(self, slot, mode=SGD_MINIBATCH, apply=APPLY_DEFAULT, batch=0, w0_chunk=0, flags=0, bias_lag=0):
         opts = SgdOpts(mode, apply, batch, w0_chunk, flags, bias_lag)

@@ -393,6 +393,158 @@ int fmx_group_destroy(fmx_group g) {
 
 const char* fmx_group_last_error(fmx_group g) { return g ? g->err.c_str() : fmx_last_error(nullptr); }
 
+// ---- parameters and rows for all shards of a group, the host arrays crossing PCIe once ------------------------------------
+// A block of `bytes` staged on the first shard's device reaches shard i's device: the same pointer when they share the device,
+// else a buffer there filled by hipMemcpyPeer (xGMI).  Blocking: this is set-up work.
+namespace {
+struct Staged {
+  std::vector<void*> buf;                 // per shard (buf[i] == buf[0] when it shares shard 0's device)
+  std::vector<bool> own;
+  ~Staged() { }
+};
+int staged_alloc(fmx_group g, size_t bytes, Staged* st) {
+  const size_t n = g->hs.size();
+  st->buf.assign(n, nullptr); st->own.assign(n, false);
+  for (size_t i = 0; i < n; i++) {
+    fmx_handle h = g->hs[i];
+    size_t same = n;
+    for (size_t j = 0; j < i; j++) if (g->hs[j]->device == h->device) { same = j; break; }
+    if (same < n) { st->buf[i] = st->buf[same]; continue; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMalloc(&st->buf[i], std::max<size_t>(bytes, 8)));
+    st->own[i] = true;
+  }
+  return FMX_OK;
+}
+void staged_free(fmx_group g, Staged* st) {
+  for (size_t i = 0; i < st->buf.size(); i++) if (st->own[i] && st->buf[i]) { hipSetDevice(g->hs[i]->device); hipFree(st->buf[i]); }
+  st->buf.clear(); st->own.clear();
+}
+// host -> first device, then to every other device that holds a copy of the stage
+int staged_fill(fmx_group g, Staged* st, const void* host, size_t bytes, size_t offset = 0) {
+  if (!bytes) return FMX_OK;
+  fmx_handle h0 = g->hs[0];
+  HIPCHK(h0, hipSetDevice(h0->device));
+  HIPCHK(h0, hipMemcpy((char*)st->buf[0] + offset, host, bytes, hipMemcpyHostToDevice));
+  for (size_t i = 1; i < st->buf.size(); i++)
+    if (st->own[i]) HIPCHK(g->hs[i], hipMemcpyPeer((char*)st->buf[i] + offset, g->hs[i]->device, (char*)st->buf[0] + offset, h0->device, bytes));
+  return FMX_OK;
+}
+}  // namespace
+
+int fmx_group_set_params(fmx_group g, double w0, const double* w, const double* v) {
+  if (!g) return FMX_E_ARG;
+  for (auto m : g->hs) if (!m) return gfail(g, FMX_E_STATE, "a member of the group was destroyed");
+  fmx_handle cur = g->hs[0];
+  const uint64_t n = cur->cfg.num_attribute;
+  const int k = cur->cfg.num_factor, KP = cur->KP;
+  if (k > 0 && !v) return gfail(g, FMX_E_ARG, "fmx_group_set_params: v is NULL but num_factor > 0");
+  for (auto m : g->hs) { cur = m; GCHK(g, lag_flush(m)); }
+  const uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 1u << 18);
+  Staged st;
+  int rc = staged_alloc(g, (size_t)chunk * (size_t)std::max(k, 1) * sizeof(double), &st);
+  for (uint64_t j0 = 0; j0 < n && rc == FMX_OK; j0 += chunk) {
+    const uint32_t cnt = (uint32_t)std::min<uint64_t>(chunk, n - j0);
+    if (w) {
+      rc = staged_fill(g, &st, w + j0, (size_t)cnt * sizeof(double));
+      for (size_t i = 0; i < g->hs.size() && rc == FMX_OK; i++) {
+        fmx_handle h = g->hs[i];
+        if (hipSetDevice(h->device) != hipSuccess) { rc = FMX_E_HIP; break; }
+        hipLaunchKernelGGL(k_w_in, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, (const double*)st.buf[i], j0, cnt, make_shard(h->cfg), h->tb);
+      }
+      for (size_t i = 0; i < g->hs.size() && rc == FMX_OK; i++) { hipSetDevice(g->hs[i]->device); if (hipStreamSynchronize(g->hs[i]->stream) != hipSuccess) rc = FMX_E_HIP; }
+    }
+    if (v && k > 0 && rc == FMX_OK) {
+      for (int f = 0; f < k && rc == FMX_OK; f++) rc = staged_fill(g, &st, v + (size_t)f * n + j0, (size_t)cnt * sizeof(double), (size_t)f * cnt * sizeof(double));
+      for (size_t i = 0; i < g->hs.size() && rc == FMX_OK; i++) {
+        fmx_handle h = g->hs[i];
+        if (hipSetDevice(h->device) != hipSuccess) { rc = FMX_E_HIP; break; }
+        const uint64_t total = (uint64_t)cnt * KP;
+        hipLaunchKernelGGL(k_stage_in, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream, (const double*)st.buf[i], j0, cnt, k, KP, make_shard(h->cfg), h->tb);
+      }
+      for (size_t i = 0; i < g->hs.size() && rc == FMX_OK; i++) { hipSetDevice(g->hs[i]->device); if (hipStreamSynchronize(g->hs[i]->stream) != hipSuccess) rc = FMX_E_HIP; }
+    }
+  }
+  for (size_t i = 0; i < g->hs.size() && rc == FMX_OK; i++) {
+    fmx_handle h = g->hs[i];
+    hipSetDevice(h->device);
+    if (hipMemcpy(h->w0, &w0, sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = FMX_E_HIP;
+  }
+  staged_free(g, &st);
+  if (rc) return gfail(g, rc, "fmx_group_set_params: staging failed (%s)", g->hs[0]->err.c_str());
+  return FMX_OK;
+}
+
+int fmx_group_upload_rows(fmx_group g, int slot, const void* entries, const uint64_t* row_ptr, const float* target, uint32_t n_rows, uint64_t nnz) {
+  if (!g) return FMX_E_ARG;
+  for (auto m : g->hs) if (!m) return gfail(g, FMX_E_STATE, "a member of the group was destroyed");
+  fmx_handle cur = g->hs[0];
+  if (g->hs.size() == 1 || g->kind == GROUP_SINGLE) { for (auto m : g->hs) { cur = m; GCHK(g, fmx_upload_rows(m, slot, entries, row_ptr, target, n_rows, nnz)); } return FMX_OK; }
+  if (slot < 0 || slot >= FMX_MAX_SLOTS) return gfail(g, FMX_E_ARG, "slot %d out of range", slot);
+  if (!row_ptr || (nnz > 0 && !entries)) return gfail(g, FMX_E_ARG, "fmx_group_upload_rows: null entries/row_ptr");
+  if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return gfail(g, FMX_E_ARG, "row_ptr[0] must be 0 and row_ptr[n_rows] == nnz");
+  for (auto m : g->hs) { cur = m; GCHK(g, slot_in_session(m, slot, "fmx_group_upload_rows")); }
+  Staged se, sp;
+  int rc = staged_alloc(g, nnz * sizeof(Entry), &se);
+  if (rc == FMX_OK) rc = staged_alloc(g, ((size_t)n_rows + 1) * sizeof(uint64_t), &sp);
+  if (rc == FMX_OK) rc = staged_fill(g, &se, entries, nnz * sizeof(Entry));
+  if (rc == FMX_OK) rc = staged_fill(g, &sp, row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t));
+  const uint64_t n = g->hs[0]->cfg.num_attribute;
+  for (size_t i = 0; i < g->hs.size() && rc == FMX_OK; i++) {
+    fmx_handle h = g->hs[i];
+    cur = h;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    free_slot(h->slots[slot]);
+    Slot s;
+    uint32_t* cnt = nullptr; void* tmp = nullptr;
+    uint32_t host_flags[2] = {0, 0};                           // [0] longest kept row, [1] bad id seen
+    hipError_t er = hipMalloc(&cnt, ((size_t)n_rows + 3) * sizeof(uint32_t));
+    uint32_t* d_flags = cnt ? cnt + n_rows + 1 : nullptr;
+    if (er == hipSuccess) er = hipMemsetAsync(cnt, 0, ((size_t)n_rows + 3) * sizeof(uint32_t), h->stream);
+    if (er == hipSuccess) er = hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t));
+    const dim3 grid(std::min<uint32_t>((n_rows + 255) / 256 + 1, 4096)), block(256);
+    const Shard sh = make_shard(h->cfg);
+    if (er == hipSuccess) {
+      hipLaunchKernelGGL(k_shard_rows, grid, block, 0, h->stream, (const Entry*)se.buf[i], (const uint64_t*)sp.buf[i], n_rows, n, sh, cnt, d_flags, d_flags + 1,
+                         (const uint64_t*)nullptr, (Entry*)nullptr);
+      er = hipGetLastError();
+    }
+    if (er == hipSuccess) {                                    // exclusive prefix sum u32 -> u64 over n_rows + 1 items (last = total)
+      size_t tmp_bytes = 0;
+      auto conv = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, uint32_t*>(cnt, hipcub::CastOp<uint64_t>());
+      er = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream);
+      if (er == hipSuccess) er = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 8));
+      if (er == hipSuccess) er = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream);
+    }
+    uint64_t total = 0;
+    if (er == hipSuccess) er = hipMemcpyAsync(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(host_flags, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+    if (er == hipSuccess && host_flags[1]) { if (cnt) hipFree(cnt); if (tmp) hipFree(tmp); free_slot(s); staged_free(g, &se); staged_free(g, &sp);
+      return gfail(g, FMX_E_ARG, "a feature id of the rows is >= num_attribute %llu", (unsigned long long)n); }
+    if (er == hipSuccess) er = hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry));
+    if (er == hipSuccess) {
+      hipLaunchKernelGGL(k_shard_rows, grid, block, 0, h->stream, (const Entry*)se.buf[i], (const uint64_t*)sp.buf[i], n_rows, n, sh, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                         (uint32_t*)nullptr, (const uint64_t*)s.row_ptr, s.ent);
+      er = hipGetLastError();
+    }
+    if (er == hipSuccess && target) {
+      er = hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float));
+      if (er == hipSuccess && n_rows) er = hipMemcpyAsync(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    }
+    if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+    if (cnt) hipFree(cnt);
+    if (tmp) hipFree(tmp);
+    if (er != hipSuccess) { free_slot(s); rc = fail(h, FMX_E_HIP, "fmx_group_upload_rows: %s", hipGetErrorString(er)); break; }
+    s.n_rows = n_rows; s.nnz = total; s.max_row = host_flags[0]; s.used = true;
+    h->slots[slot] = s;
+  }
+  staged_free(g, &se); staged_free(g, &sp);
+  if (rc) { g->err = fmx_last_error(cur); return rc; }
+  return FMX_OK;
+}
+
 // one epoch of the minibatch rule over feature shards:  per batch  partial sums on every shard -> ONE exchange ->
 // multipliers / bias recurrence (redundantly on every shard) + update of the local rows.
 //   exact (default): the batch rule of oracle fmo_sgd_epoch_minibatch_ex -- identical, shard count aside, to what a single
@@ -417,6 +569,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
   if (opts_in->apply == FMX_APPLY_FUSED) opts.flags |= FMX_FLAG_BIAS_LAG;       // FUSED implies the lag on one device: same rule here
   const bool pipeline = (opts.flags & FMX_FLAG_PIPELINE) != 0;
   const uint32_t n_rows = g->hs[0]->slots[slot].n_rows;
+  for (auto m : g->hs) m->setup_acc = 0.0;
   fmx_batch_info bi;                                              // the same batch as one unsharded handle would choose
   cur = g->hs[0];
   GCHK(g, sgd_resolve_batch(cur, cur->slots[slot], opts_in, &bi));
@@ -502,6 +655,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = n_batch;
     stats->max_feature_count = h0->slots[slot].max_seg_count;
     stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
+    for (auto m : g->hs) stats->setup_seconds = std::max(stats->setup_seconds, m->setup_acc);
     for (uint64_t b = 0; b < n_timed; b++) {
       float a = 0, x = 0, u = 0;
       HIPCHK(h0, hipEventElapsedTime(&a, h0->ev_pool[4 * b], h0->ev_pool[4 * b + 1]));

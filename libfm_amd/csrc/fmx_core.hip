@@ -166,6 +166,8 @@ int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* r
 int ensure_coll_mass(fmx_handle h, Slot& s) {
   if (s.coll_mass >= 0.0) return FMX_OK;
   if (s.nnz == 0 || s.n_rows == 0) { s.coll_mass = 0.0; return FMX_OK; }
+  struct Acc { fmx_handle h; std::chrono::steady_clock::time_point t0;
+               ~Acc() { h->setup_acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{h, std::chrono::steady_clock::now()};
   HIPCHK(h, hipSetDevice(h->device));
   const uint32_t M = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n_local, 1), 1ull << 27);
   float* hist = nullptr;

@@ -10,6 +10,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -109,6 +110,7 @@ struct fmx_context_s {
   SgdaState  sgda;
   LagState   lag;
   int        KP = 1;
+  double     setup_acc = 0.0;    // host seconds of one-time slot preparation since the epoch entry point last cleared it
   uint32_t*  grp = nullptr;      // [n_local] attribute -> group (fmx_set_groups); nullptr = one group
   uint32_t   num_groups = 1;
   uint64_t   n_local = 0;

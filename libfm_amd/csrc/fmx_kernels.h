@@ -1955,6 +1955,29 @@ static __global__ void k_synth(uint64_t seed, uint64_t row0, uint32_t n_rows, ui
   }
 }
 
+// ---- a feature shard's view of uploaded rows, filtered on the device (fmx_group_upload_rows): the entries whose feature the shard
+// owns, ids rewritten to local rows.  pass 1 (ent_out == nullptr): row_cnt[r] = kept entries (+ the longest kept row);
+// pass 2: fill at out_ptr[r].  `bad` is raised for an id >= num_attribute (the reference asserts it, fm_model.h:112).
+static __global__ void __launch_bounds__(256)
+k_shard_rows(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint64_t n, Shard sh,
+             uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ max_row, uint32_t* __restrict__ bad,
+             const uint64_t* __restrict__ out_ptr, Entry* __restrict__ ent_out) {
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
+    uint32_t c = 0;
+    uint64_t pos = out_ptr ? out_ptr[r] : 0;
+    for (uint64_t i = row_ptr[r]; i < row_ptr[r + 1]; i++) {
+      const Entry e = ent[i];
+      if ((uint64_t)e.id >= n) { if (bad) atomicOr(bad, 1u); continue; }
+      uint32_t jl;
+      if (sh.place(e.id, &jl)) {
+        if (ent_out) { Entry o; o.id = jl; o.value = e.value; ent_out[pos++] = o; }
+        c++;
+      }
+    }
+    if (row_cnt) { row_cnt[r] = c; if (c) atomicMax(max_row, c); }
+  }
+}
+
 // ---- collision mass of a row set: C = sum_j (sum_rows |x_j| / n_rows)^2 (fmx_sgd_opts::batch, fmx_sgd_batch_info) ------------
 // hist[id mod M] += |x| per entry (M = table size, or 2^27 buckets for larger tables: folding can only raise C, i.e. cut the batch more)
 static __global__ void __launch_bounds__(256)

@@ -128,6 +128,9 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
     int _rc = slot_in_session(h, (int)(&s - h->slots), "re-bucketing the rows for another batch size"); if (_rc) return _rc;
   }
   free_segments(s);
+  const auto t_setup0 = std::chrono::steady_clock::now();
+  struct Acc { fmx_handle h; std::chrono::steady_clock::time_point t0;
+               ~Acc() { h->setup_acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{h, t_setup0};
   const uint64_t nnz = s.nnz;
   const uint32_t n_batches = (s.n_rows + B - 1) / B;
   if (nnz >= (1ull << 31)) return fail(h, FMX_E_UNSUPPORTED, "segmented apply: nnz >= 2^31 in one slot (split the data set)");
@@ -522,6 +525,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   if (stats) memset(stats, 0, sizeof(*stats));
   if (s.n_rows == 0) return FMX_OK;
   if (!s.blocks.empty()) return fail(h, FMX_E_UNSUPPORTED, "relations are not supported with SGD");   // fm_learn_sgd.h:61-63
+  if (!(h->group && !h->owns_group)) h->setup_acc = 0.0;     // (a group clears its members' before the epoch)
   if (h->cfg.shard_world > 1 && opts->mode != FMX_SGD_MINIBATCH)
     return fail(h, FMX_E_UNSUPPORTED, "feature shards train with FMX_SGD_MINIBATCH (the split step)");
   if (h->cfg.shard_world > 1 || h->comm) return comm_sgd_epoch(h, slot, opts, stats);   // (a communicator of one rank drives the same schedule)
@@ -645,6 +649,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     if (opts->mode == FMX_SGD_MINIBATCH) {
       stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
     }
+    stats->setup_seconds = h->setup_acc;
     if (opts->mode == FMX_SGD_MINIBATCH && timed && opts->apply != FMX_APPLY_FUSED) {
       double tot = 0;
       for (size_t i = 0; i + 1 < ev_used; i += 2) {

@@ -46,3 +46,13 @@ def test_single_gpu_line_and_criteo_shape():
     br = out["config"]["batch_rule"]
     assert br["cut"] is True and br["unstable"] is False and br["gain"] <= 1.0 and br["batch"] <= 2048
     assert "Criteo-shaped" in out["config"]["workload"]
+
+
+def test_self_launch_one_process_per_rank():
+    """`python bench.py --gpus 2` re-executes itself under torch.distributed.run (one process per GPU: the default on N distinct
+    devices).  On a one-GPU box the two ranks share device 0 and exchange through gloo (RCCL refuses two ranks on one device); the
+    launcher, the rank environment, the barriers and rank 0's JSON line are the ones the 8-GPU run uses."""
+    out = run_bench("--gpus", 2, "--same-device", "--multi-process", "--backend", "gloo", "--driver", "torch", "--features", 2_000_000,
+                    "--rows", 65536, "--batch", 16384, "--steps", 2, "--warmup", 1)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["driver"] == "torch"
+    assert "2 shards" in out["config"]["sharding"] and out["exchange"]["backend"] == "gloo"

@@ -259,3 +259,43 @@ def test_sharded_mcmc_draws_what_the_unsharded_chain_draws(capi, oracle, name):
     # the statistics of the hyper-prior draws: residual sums from the replicated cache, parameter sums added over the shards
     np.testing.assert_allclose(four[5][0], one[5][0], rtol=1e-6)
     np.testing.assert_allclose(four[5][2], one[5][2], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("world,shard_hash", [(2, 1), (3, 0), (5, 1)])
+def test_group_staging_equals_per_shard_upload(capi, oracle, world, shard_hash):
+    """fmx_group_set_params / fmx_group_upload_rows (the host block and the rows cross PCIe once; every shard converts / filters its
+    own features on its device) leave every shard with exactly what the per-handle calls with the full arrays leave: same local
+    rows (ragged rows, empty rows, repeated ids), same parameters; ids beyond num_attribute are refused."""
+    ent, rp, y = datagen.ragged_real(500, 700, 9, seed=3, empty_every=6, duplicates=True)
+    n, k = 500, 12
+    m = oracle.Model(n, k, True, True, 0.0, 0.0, 0.001)
+    m.w0 = 0.25
+    m.w[:] = oracle.init_values(7, n, 1, 0.3)[0]
+    m.v[:] = oracle.init_values(8, n, k, 0.1)
+    a, ga = make_group(capi, world, [0] * world, n, k, capi.TASK_CLASSIFICATION, (0.0, 0.0, 0.001), 0.01, -1.0, 1.0, shard_hash)
+    b, gb = make_group(capi, world, [0] * world, n, k, capi.TASK_CLASSIFICATION, (0.0, 0.0, 0.001), 0.01, -1.0, 1.0, shard_hash)
+    for h in a:
+        h.set_params(m.w0, m.w, m.v)
+        h.upload_rows(0, ent, rp, y)
+    gb.set_params(m.w0, m.w, m.v)
+    gb.upload_rows(0, ent, rp, y)
+    for ha, hb in zip(a, b):
+        ea, ra, ya = ha.download_rows(0)
+        eb, rb, yb = hb.download_rows(0)
+        assert np.array_equal(ea, eb) and np.array_equal(ra, rb) and np.array_equal(ya, yb)
+    wa, wb = ga.get_params(), gb.get_params()
+    assert wa[0] == wb[0] and np.array_equal(wa[1], wb[1]) and np.array_equal(wa[2], wb[2])
+    np.testing.assert_allclose(wb[2], m.v, rtol=1e-6, atol=1e-7)
+    # and they train alike
+    sa = ga.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, 64, 16, capi.FLAG_BIAS_LAG, 1)
+    sb = gb.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, 64, 16, capi.FLAG_BIAS_LAG, 1)
+    pa, pb = ga.get_params(), gb.get_params()
+    assert np.array_equal(pa[2], pb[2]) and np.array_equal(pa[1], pb[1]) and sa.max_feature_count == sb.max_feature_count
+    bad = ent.copy()
+    bad["id"][5] = n + 3
+    with pytest.raises(capi.FmxError):
+        gb.upload_rows(1, bad, rp, y)
+    for g_ in (ga, gb):
+        g_.close()
+    for h in a + b:
+        h.close()
