@@ -352,7 +352,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="testing: drive the multi-GPU code path (ShardedSGD + all-reduce) even with one rank")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
-    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: 16384 at N=1, 262144 sharded); hogwild: rows per launch (0: 262144)")
+    ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: the library's choice -- 262144 cut to the stability bound of the rows, fmx_sgd_opts::batch); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default = 256 at lr 0.01, classification)")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true",
                     help="sharded: overlap the all-reduce of batch b+1 with the update of batch b (the one-batch-stale pipelined rule, "

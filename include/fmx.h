@@ -113,7 +113,7 @@ typedef struct fmx_sgd_opts {
                                same stale state, so the step along "what the rows have in common" is learn_rate * batch * C where
                                the reference (batch 1, fm_sgd.h:33-51) takes `batch` small steps.  Uniform ids over 1e8 features:
                                C = 1e-5, no cut; Criteo-shaped rows (100-id fields, Zipf heads): C = 1, batch 256 at
-                               learn_rate 0.01.  An explicit batch is honoured (fmx_epoch_stats::status reports FMX_STAT_UNSTABLE;
+                               learn_rate 0.01; never below 32).  An explicit batch is honoured (fmx_epoch_stats::status reports FMX_STAT_UNSTABLE;
                                with FMX_FLAG_REJECT_UNSTABLE the call fails with FMX_E_ARG instead of training).
                                HOGWILD: rows per launch during which w0 is frozen (macro-batch), 0 = 262144 */
   uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default: the largest power of two <= 256
@@ -457,7 +457,7 @@ int fmx_group_als_end(fmx_group g);
 int fmx_sgda_begin(fmx_handle h);
 int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, fmx_epoch_stats *stats);
 /* the learner in BATCH form (oracle fmo_sgda_epoch_minibatch; the online order above is one wavefront and slower than the
- * reference's CPU): per batch of `batch` train rows (0 = 16384) the theta steps as a minibatch rule -- this learner's
+ * reference's CPU): per batch of `batch` train rows (0 = the library's choice, as fmx_sgd_opts::batch, with this learner's doubled regression curvature) the theta steps as a minibatch rule -- this learner's
  * multiplier, reg_0 = 0, the learned regularisation 2 reg(g[,f]) theta per occurrence, the shadow gradient of a touched
  * parameter = the sum of its occurrences' gradients -- then, do_lambda_steps, the lambda steps of the next `batch` validation
  * rows (cyclic, :271-274), each as sgd_lambda_step (:201-248) with the regularisation of the batch start, their changes

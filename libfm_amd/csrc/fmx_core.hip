@@ -198,7 +198,8 @@ void resolve_batch(const fmx_config& cfg, double coll_mass, uint32_t requested, 
   if (!requested && per_row > 0.0 && (double)B * per_row > 1.0) {
     uint32_t cut = 1;
     while ((double)(cut * 2) * per_row <= 1.0 && cut * 2 <= dflt) cut *= 2;
-    B = cut; status |= FMX_STAT_BATCH_CUT;
+    B = std::max(cut, 32u);                                      // (rows that dense -- C in the hundreds -- are SEQUENTIAL's case: the gain says so)
+    status |= FMX_STAT_BATCH_CUT;
   }
   out->collision_mass = coll_mass;
   out->batch = B;

@@ -170,4 +170,4 @@ def stable_batch(lr, task, C, default=262144, curv_scale=1.0):
     b = 1
     while (b * 2) * per_row <= 1.0 and b * 2 <= default:
         b *= 2
-    return b
+    return max(b, 32)
