@@ -515,7 +515,7 @@ def main():
         elapsed = float(t.item())
 
     extras = {}
-    if rank == 0 and not sharded and not args.no_extras and not args.no_cpu_baseline and not criteo:
+    if rank == 0 and not sharded and not args.no_extras and not criteo:
         # secondary figures, never `value`: the asynchronous mode (metric-level parity only) and the two-pass form of the rule
         def timed_epochs(n, *a):
             h.sgd_epoch(0, *a)
