@@ -457,8 +457,8 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   if (rc) return rc;
   const uint64_t n_batch = ((uint64_t)s.n_rows + B - 1) / B;
   // small batches (what the stability cut leaves of data with frequent features): a batch is a few microseconds of work, so
-  // the recurrence goes on the launch stream itself -- no side stream, no events, three launches per batch.  Same rule, same
-  // ring of bias slots: what a batch reads does not depend on which stream wrote it.
+  // the recurrence leaves the side stream and rides in the launch of the deferred features (k_apply_seg_scan) -- no events, two
+  // launches per batch.  Same rule, same ring of bias slots: what a batch reads does not depend on which stream wrote it.
   const bool side = B >= 32768u;
   if (side) while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
   hipStream_t st = h->stream;
