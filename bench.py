@@ -436,6 +436,36 @@ def main():
     bias_lag = args.bias_lag if args.mode == "fused" else (1 if lagf else 0)
     deferred = 0
     batch_stats = None
+    # several GPUs, the library's own schedule (default): rank 0 creates the RCCL id, torch.distributed only carries it to the others.
+    # Every rank reports whether its binding came up (communicator + a first collective: the shards' shares of the rows' collision
+    # mass); if ANY rank failed, all of them fall back to the torch-driven schedule (libfm_amd/distributed.py) instead of dying.
+    use_lib = sharded and args.driver == "lib" and args.backend == "nccl"
+    if use_lib:
+        ok, why = 1, ""
+        try:
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [capi.comm_unique_id()]
+                except Exception as exc:                      # (the others must not hang in the broadcast)
+                    why = str(exc)
+            dist.broadcast_object_list(uid, src=0)
+            if uid[0] is None:
+                raise RuntimeError("rank 0 could not create an RCCL id: " + why)
+            h.comm_init_rank(uid[0], rank, world)
+            batch = h.sgd_batch_info(0, args.batch).batch
+        except Exception as exc:
+            ok, why = 0, str(exc)
+        agree = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0:
+            use_lib = False
+            args.driver = "torch"
+            if ok:
+                h.comm_destroy()
+            if rank == 0 or not ok:
+                print("bench.py: rank %d: the library's RCCL binding did not come up on every rank (%s): falling back to --driver torch"
+                      % (rank, why or "another rank failed"), file=sys.stderr, flush=True)
     if not sharded:
         # --batch 0: the library's choice (fmx_sgd_opts::batch = 0 -> 262144 cut to the rows' stability bound; hogwild: rows per launch)
         batch = h.sgd_batch_info(0, args.batch).batch if args.mode != "hogwild" else (args.batch or 262144)
@@ -454,14 +484,9 @@ def main():
                 batch_stats = st
         rows_per_launch = min(batch, args.rows)
         kind = "fused" if args.mode in ("hogwild", "fused") else "apply"
-    elif args.driver == "lib" and args.backend == "nccl":
-        # the library's own multi-GPU schedule: rank 0 creates the RCCL id, torch.distributed only carries it to the others
-        uid = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        h.comm_init_rank(uid[0], rank, world)
+    elif use_lib:
         lib_flags = lagf | (capi.FLAG_PIPELINE if args.pipeline else 0)
         lib_lag = args.bias_lag if lagf else 0
-        batch = h.sgd_batch_info(0, args.batch).batch           # (sums the shards' shares of the collision mass over RCCL)
         phases = [0.0, 0.0, 0.0]
 
         class _Drv:

@@ -440,6 +440,9 @@ class Handle:
         buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
         self._chk(self.lib.fmx_comm_init_rank(self.h, buf, int(rank), int(world)))
 
+    def comm_destroy(self):
+        self._chk(self.lib.fmx_comm_destroy(self.h))
+
     def info(self):
         inf = Info()
         self._chk(self.lib.fmx_get_info(self.h, C.byref(inf)))
