@@ -178,3 +178,50 @@ def test_cli_relation_flag(tmp_path, oracle):
     assert "#relations: 2" in buf.getvalue() and "#groups=5" in buf.getvalue()
     np.testing.assert_allclose(np.loadtxt(out), z["pred_out"], rtol=1e-4, atol=5e-5)
     assert os.path.exists(out)
+
+
+@pytest.mark.parametrize("world,shard_hash", [(2, 1), (3, 0)])
+def test_joined_blocks_on_feature_shards(oracle, world, shard_hash):
+    """`-relation` with gpu_devices (round-2 advisor finding: the upload used to fail on every shard).  FMX_BLOCKS_EXPAND on a feature
+    shard joins the rows on the host and keeps the shard's own features: every shard holds exactly what it holds after an upload of
+    the flat design matrix, a sharded ALS sweep over them is the unsharded sweep, and kept blocks are refused with a clear text."""
+    from libfm_amd import capi
+    (ent, rp, y), blocks, maps = datagen.block_structured(40, 25, 300, seed=5)
+    n_main = 7
+    flat_ent, flat_rp, offs = datagen.expand_blocks(ent, rp, blocks, maps, n_main)
+    n, k = offs[-1] + blocks[-1][2], 8
+    rel = [(be, bp, mp, off) for (be, bp, _), mp, off in zip(blocks, maps, offs)]
+    m = oracle.Model(n, k, True, True, 0.1, 1.0, 5.0)
+    m.v[:] = oracle.init_values(3, n, k, 0.1)
+    m.w[:] = oracle.init_values(4, n, 1, 0.1)[0]
+    lo, hi = float(y.min()), float(y.max())
+    hs = [capi.Handle(n, k, True, True, 0, 0.1, 1.0, 5.0, 0.0, lo, hi, device=0, shard_rank=r, shard_world=world, shard_hash=shard_hash)
+          for r in range(world)]
+    ref = [capi.Handle(n, k, True, True, 0, 0.1, 1.0, 5.0, 0.0, lo, hi, device=0, shard_rank=r, shard_world=world, shard_hash=shard_hash)
+           for r in range(world)]
+    for h, q in zip(hs, ref):
+        h.set_params(m.w0, m.w, m.v)
+        h.upload_block_rows(0, ent, rp, y, rel, keep=False)
+        q.upload_rows(0, flat_ent, flat_rp, y)
+        a, b = h.download_rows(0), q.download_rows(0)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        with pytest.raises(capi.FmxError, match="FMX_BLOCKS_EXPAND"):
+            h.upload_block_rows(1, ent, rp, y, rel, keep=True)
+    g = capi.Group(hs)
+    g.als_begin(0)
+    g.als_sweep(1.0, 5.0)
+    g.als_end()
+    one = capi.Handle(n, k, True, True, 0, 0.1, 1.0, 5.0, 0.0, lo, hi, device=0)
+    one.set_params(m.w0, m.w, m.v)
+    one.upload_block_rows(0, ent, rp, y, rel, keep=False)
+    one.als_begin(0)
+    one.als_sweep(1.0, 5.0)
+    one.als_end()
+    w0, w, v = g.get_params()
+    w0b, wb, vb = one.get_params()
+    np.testing.assert_allclose(v, vb, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(w, wb, rtol=1e-4, atol=2e-5)
+    assert abs(w0 - w0b) <= 1e-4 * abs(w0b) + 2e-5
+    g.close()
+    for h in hs + ref + [one]:
+        h.close()
