@@ -13,6 +13,7 @@ extern "C++" void als_free(fmx_handle h) {
   if (a.q) hipFree(a.q);
   if (a.seen) hipFree(a.seen);
   if (a.level_list) hipFree(a.level_list);
+  if (a.ldesc) hipFree(a.ldesc);
   if (a.prior) hipFree(a.prior);
   if (a.vt) hipFree(a.vt);
   if (a.delta) hipFree(a.delta);
@@ -327,6 +328,12 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
     HIPCHK(x, hipMemcpyAsync(a.prior, a.prior_host.data(), a.prior_host.size() * sizeof(double), hipMemcpyHostToDevice, x->stream));
     // lanes per column from the mean column length (one-hot data: a handful of rows per feature)
     const Slot& s = x->slots[a.slot];
+    if (!a.ldesc && s.nseg) {                                // the level-ordered column records, once per session
+      HIPCHK(x, hipMalloc(&a.ldesc, (size_t)s.nseg * sizeof(uint4)));
+      hipLaunchKernelGGL(k_als_ldesc, dim3(std::min<uint32_t>((s.nseg + 255) / 256, 8192)), dim3(256), 0, x->stream, a.level_list, s.nseg,
+                         s.seg_feat, s.seg_rel, s.nseg, (uint32_t)s.nnz, a.ldesc);
+      HIPCHK(x, hipGetLastError());
+    }
     const double avg_col = s.nseg ? (double)s.nnz / (double)s.nseg : 0.0;
     // (measured at 6.7 entries per column, inside one process: 4 lanes 161.4 ms per sweep, 8 lanes 164.4, 16 lanes 195)
     lanes[i] = avg_col <= 8.0 ? 4 : (avg_col <= 16.0 ? 8 : (avg_col <= 40.0 ? 16 : 64));
@@ -353,11 +360,10 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
       const int G = lanes[i];
       const Shard sh = make_shard(h->cfg);
       EQ* delta = sharded ? a.delta : nullptr;
-      const uint32_t nseg = s.nseg, nnz = (uint32_t)s.nnz;
       const uint32_t n_ent = (!sharded && a.split_min && a.r_row) ? a.lev_ent[l + 1] - a.lev_ent[l] : 0u;
       float2* dth = (n_ent && n_ent >= a.split_min) ? a.dth : nullptr;     // split step for this level?
       if (f < 0) {
-        FMX_ALS_DRAW(false, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+        FMX_ALS_DRAW(false, cnt, s.t_ent, a.ldesc + a.level_ptr[l], cnt,
                      h->tb.w, h->tb.ws, 0, 0u, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
                      opts->seed, (uint64_t)(a.iter * 1024 + 1000), sh, delta, dth);
         if (dth) hipLaunchKernelGGL((k_als_rows<false>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
@@ -366,11 +372,11 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
         const double* v_lambda = a.prior + (size_t)(1 + f) * 2 * NG;
         const double* v_mu = v_lambda + NG;
         if (a.vt)
-          FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+          FMX_ALS_DRAW(true, cnt, s.t_ent, a.ldesc + a.level_ptr[l], cnt,
                        a.vt + (size_t)f * a.vt_stride, 1u, 1, a.level_ptr[l], a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
                        opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta, dth);
         else
-          FMX_ALS_DRAW(true, cnt, s.t_ent, s.seg_feat, s.seg_rel, nseg, nnz, a.level_list + a.level_ptr[l], cnt,
+          FMX_ALS_DRAW(true, cnt, s.t_ent, a.ldesc + a.level_ptr[l], cnt,
                        h->tb.V + f, h->tb.rs, 0, 0u, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
                        opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta, dth);
         if (dth) hipLaunchKernelGGL((k_als_rows<true>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,

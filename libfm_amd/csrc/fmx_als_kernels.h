@@ -305,12 +305,16 @@ k_group_moments(const Tab tb, uint64_t n_local, int k1, const uint32_t* __restri
 }
 
 // counter-based N(0,1) for the sampling variant (MCMC): Box-Muller on two splitmix64 hashes of (seed, stream, index)
+// N(0,1) of a coordinate draw: counter hash -> Box-Muller in fp32 with the hardware log / cos (24-bit uniforms: tails to 5.8 sigma).
+// The draw is stored as an fp32 parameter anyway, and the parity of a sampled chain is statistical; in fp64
+// (software log / cos / sqrt, ~200 instructions) this was 40 % of k_als_draw and most of k_als_unseen_v at configs[4]'s shape
+// (3 M short columns per level, 1.2e10 prior draws per sweep).
 __device__ __forceinline__ double gauss_hash(uint64_t seed, uint64_t stream, uint64_t idx) {
   const uint64_t h1 = mix64(seed ^ (stream * 0x9E3779B97F4A7C15ULL) ^ (idx * 0xD6E8FEB86659FD93ULL + 0x632BE59BD9B4E019ULL));
   const uint64_t h2 = mix64(h1 + 0x9E3779B97F4A7C15ULL);
-  const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740992.0);    // (0,1]
-  const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
-  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+  const float u1 = ((float)(uint32_t)(h1 >> 40) + 1.0f) * (1.0f / 16777216.0f);    // (0,1]
+  const float u2 = (float)(uint32_t)(h2 >> 40) * (1.0f / 16777216.0f);             // [0,1)
+  return (double)(sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -400,10 +404,21 @@ k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict
 
 // param_by_pos: the coordinate of list entry li lives at param[(pos0 + li) * pstride] (the factor-major shadow) instead of
 // param[feature * pstride] (the table itself)
+// the columns of the sweep in LEVEL order: {feature, first entry, one past the last entry} of list position li.  k_als_draw reads them
+// as one coalesced 16-byte stream; through seg_list -> seg_feat / seg_rel they were three dependent 4-byte gathers per column, and
+// with the short columns of a wide id space (configs[4]: 1.4 entries per column) the draw was bound by exactly those requests.
+static __global__ void __launch_bounds__(256)
+k_als_ldesc(const uint32_t* __restrict__ seg_list, uint32_t n_list, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
+            uint32_t nseg_total, uint32_t nnz, uint4* __restrict__ out) {
+  for (uint32_t li = blockIdx.x * blockDim.x + threadIdx.x; li < n_list; li += gridDim.x * blockDim.x) {
+    const uint32_t s = seg_list[li];
+    out[li] = make_uint4(seg_feat[s], seg_rel[s], (s + 1 < nseg_total) ? seg_rel[s + 1] : nnz, s);
+  }
+}
+
 template <bool IS_V, int G>
 __global__ void __launch_bounds__(256)
-k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel,
-           uint32_t nseg_total, uint32_t nnz, const uint32_t* __restrict__ seg_list, uint32_t n_list,
+k_als_draw(const TEntry* __restrict__ t_ent, const uint4* __restrict__ ldesc, uint32_t n_list,
            float* __restrict__ param, uint32_t pstride, int param_by_pos, uint32_t pos0, EQ* __restrict__ eq,
            double alpha, const double* __restrict__ lambda_g, const double* __restrict__ mu_g, const uint32_t* __restrict__ attr_group,
            int do_sample, uint64_t seed, uint64_t stream, const Shard sh, EQ* __restrict__ delta, float2* __restrict__ dth) {
@@ -419,12 +434,12 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_fe
   for (uint32_t lw = wave0 * GPW; lw < n_list; lw += nwaves * GPW) {
     const uint32_t li = lw + grp;
     const bool have = li < n_list;                       // idle groups still take part in the shuffles
-    const uint32_t s = seg_list[have ? li : n_list - 1];
-    const uint32_t j = seg_feat[s];
+    const uint4 dsc = ldesc[have ? li : n_list - 1];
+    const uint32_t j = dsc.x;
     const uint32_t g = attr_group ? attr_group[j] : 0u;  // meta->attr_group(j): the prior of this coordinate (:464-466, :583-585)
     const double lambda = lambda_g[g], mu = mu_g[g];
-    const uint32_t a = seg_rel[s];
-    const uint32_t b = have ? ((s + 1 < nseg_total) ? seg_rel[s + 1] : nnz) : a;
+    const uint32_t a = dsc.y;
+    const uint32_t b = have ? dsc.z : a;
     float* pt = param + (size_t)(param_by_pos ? pos0 + (have ? li : n_list - 1) : j) * pstride;
     const double th = (double)(param_by_pos ? *pt : als_param_load(pt));
     double t_he = 0.0, t_hh = 0.0;

@@ -77,6 +77,7 @@ struct AlsState {
   double*   q = nullptr;          // [KP][N]
   uint8_t*  seen = nullptr;       // [n_local] feature has a training column
   uint32_t* level_list = nullptr; // segments ordered by level
+  uint4*    ldesc = nullptr;      // the same list as {feature, first entry, end entry, segment} records (k_als_ldesc)
   std::vector<uint32_t> level_ptr;
   uint64_t  iter = 0;
   std::vector<AlsBlock> blk;      // kept blocks of the train slot
