@@ -139,7 +139,18 @@ static int als_build_rows(fmx_handle h, const Slot& s, AlsState& a, const std::v
     ROW_CHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, ka, kb, va, vb, (int)nnz, 0, 32 + bits_level, st));
     hipLaunchKernelGGL(k_als_rowfill, gr, bl, 0, st, s.t_ent, s.seg_rel, nseg, nnz, d_pos, vb, a.r_row, a.r_pos, a.r_x);
     ROW_CHK(hipGetLastError());
-    ROW_CHK(hipStreamSynchronize(st));
+    {  // which levels hold every row exactly once, in order (one-hot fields)
+      const size_t nl = a.lev_ent.size() - 1;
+      a.lev_dense.assign(nl, 0);
+      std::vector<uint32_t> flags(nl, 1u);
+      ROW_CHK(hipMemsetAsync(d_lvl, 0, std::min<size_t>(nl, nseg) * 4, st));          // (d_lvl is free after the sort keys were made)
+      for (size_t l = 0; l < nl && l < nseg; l++)
+        if (a.lev_ent[l + 1] - a.lev_ent[l] == s.n_rows)
+          hipLaunchKernelGGL(k_als_rows_check_dense, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 4096)), bl, 0, st, a.r_row + a.lev_ent[l], s.n_rows, d_lvl + l);
+      ROW_CHK(hipMemcpyAsync(flags.data(), d_lvl, std::min<size_t>(nl, nseg) * 4, hipMemcpyDeviceToHost, st));
+      ROW_CHK(hipStreamSynchronize(st));
+      for (size_t l = 0; l < nl && l < nseg; l++) a.lev_dense[l] = (a.lev_ent[l + 1] - a.lev_ent[l] == s.n_rows && flags[l] == 0) ? 1 : 0;
+    }
   }
 done:
 #undef ROW_CHK
@@ -366,7 +377,9 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
         FMX_ALS_DRAW(false, cnt, s.t_ent, a.ldesc + a.level_ptr[l], cnt,
                      h->tb.w, h->tb.ws, 0, 0u, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
                      opts->seed, (uint64_t)(a.iter * 1024 + 1000), sh, delta, dth);
-        if (dth) hipLaunchKernelGGL((k_als_rows<false>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
+        if (dth && a.lev_dense[l]) hipLaunchKernelGGL((k_als_rows_dense<false>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
+                                    a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
+        else if (dth) hipLaunchKernelGGL((k_als_rows<false>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
                                     a.r_row + a.lev_ent[l], a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
       } else {
         const double* v_lambda = a.prior + (size_t)(1 + f) * 2 * NG;
@@ -379,7 +392,9 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
           FMX_ALS_DRAW(true, cnt, s.t_ent, a.ldesc + a.level_ptr[l], cnt,
                        h->tb.V + f, h->tb.rs, 0, 0u, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
                        opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta, dth);
-        if (dth) hipLaunchKernelGGL((k_als_rows<true>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
+        if (dth && a.lev_dense[l]) hipLaunchKernelGGL((k_als_rows_dense<true>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
+                                    a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
+        else if (dth) hipLaunchKernelGGL((k_als_rows<true>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
                                     a.r_row + a.lev_ent[l], a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
       }
       HIPCHK(h, hipGetLastError());

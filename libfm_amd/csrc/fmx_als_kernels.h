@@ -534,6 +534,30 @@ k_als_rows(const uint32_t* __restrict__ r_row, const uint32_t* __restrict__ r_po
     if (NT_EQ) { __builtin_nontemporal_store(c.e, &eq[row].e); __builtin_nontemporal_store(c.q, &eq[row].q); } else eq[row] = c;
   }
 }
+// the same for a level whose entries are the rows 0 .. N-1 in order, one each -- every level of one-hot field data: the row index is the
+// entry index (no r_row stream, no run detection), {e, q} is one 16-byte non-temporal load / store, and the load does not wait for the pair
+template <bool IS_V>
+__global__ void __launch_bounds__(256)
+k_als_rows_dense(const uint32_t* __restrict__ r_pos, const float* __restrict__ r_x, uint32_t n_ent, const float2* __restrict__ dth, EQ* __restrict__ eq) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_ent; t += gridDim.x * blockDim.x) {
+    const uint32_t pos = __builtin_nontemporal_load(r_pos + t);
+    const double x = (double)__builtin_nontemporal_load(r_x + t);
+    v2d c = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(eq + t));      // {e, q}
+    const float2 tt = dth[pos];
+    const double th = (double)tt.x, d = (double)tt.x - (double)tt.y;              // theta_old - theta
+    if (d == 0.0) continue;
+    if (IS_V) { const double h = x * (c.y - x * th); c.y -= x * d; c.x -= h * d; }
+    else c.x -= x * d;
+    __builtin_nontemporal_store(c, reinterpret_cast<v2d*>(eq + t));
+  }
+}
+// r_row[t] == t for the n entries of a level?  (flag raised otherwise)
+static __global__ void __launch_bounds__(256)
+k_als_rows_check_dense(const uint32_t* __restrict__ r_row, uint32_t n, uint32_t* __restrict__ flag) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+    if (r_row[t] != t) *flag = 1u;
+}
 // set-up of the row-ordered lists: key = (level of the entry's feature, row), value = entry index in X^T
 static __global__ void __launch_bounds__(256)
 k_als_rowkeys(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ seg_rel, uint32_t nseg, uint32_t nnz,
