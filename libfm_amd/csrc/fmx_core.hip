@@ -103,6 +103,8 @@ void free_segments(Slot& s) {
   if (s.seg_rel) hipFree(s.seg_rel);
   if (s.cmask) hipFree(s.cmask);
   if (s.cseg) hipFree(s.cseg);
+  if (s.cdesc) hipFree(s.cdesc);
+  s.cdesc = nullptr;
   s.t_ent = nullptr; s.seg_feat = nullptr; s.seg_rel = nullptr; s.seg_B = 0; s.nseg = 0;
   s.cmask = nullptr; s.cseg = nullptr; s.ncseg = 0; s.fused_cap = 0;
   s.batch_seg.clear(); s.batch_base.clear(); s.cbatch.clear();
@@ -739,7 +741,11 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
     local_ptr[n_rows] = local_ent.size();
     up_ent = local_ent.data(); up_ptr = local_ptr.data(); up_nnz = local_ent.size();
   }
-  for (uint32_t r = 0; r < n_rows; r++) max_row = std::max<uint32_t>(max_row, (uint32_t)(up_ptr[r + 1] - up_ptr[r]));
+  uint32_t min_row = n_rows ? 0xFFFFFFFFu : 0u;
+  for (uint32_t r = 0; r < n_rows; r++) {
+    const uint32_t sz = (uint32_t)(up_ptr[r + 1] - up_ptr[r]);
+    max_row = std::max(max_row, sz); min_row = std::min(min_row, sz);
+  }
   hipError_t er = hipSuccess;
   if (!s.ent) {
     er = hipMalloc(&s.ent, std::max<uint64_t>(up_nnz, 1) * sizeof(Entry));
@@ -754,6 +760,7 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
   if (hipStreamSynchronize(h->stream) != hipSuccess && er == hipSuccess) er = hipGetLastError();   // the host buffers may go away after return
   if (er != hipSuccess) { free_slot(s); return fail(h, FMX_E_HIP, "fmx_upload_rows: %s", hipGetErrorString(er)); }
   s.n_rows = n_rows; s.nnz = up_nnz; s.max_row = max_row; s.used = true;
+  s.fixed_nnz = (n_rows && min_row == max_row && max_row > 0) ? max_row : 0u;
   h->slots[slot] = s;
   return FMX_OK;
 }
@@ -991,6 +998,7 @@ int fmx_synth_rows_ex(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint
 #undef SYN_CHK
   hipFree(cnt);
   s.n_rows = n_rows; s.nnz = total; s.max_row = nnz; s.used = true;
+  s.fixed_nnz = (h->cfg.shard_world == 1) ? nnz : 0u;        // (a shard keeps a varying part of every row)
   h->slots[slot] = s;
   return FMX_OK;
 }

@@ -30,6 +30,7 @@ struct Slot {
   uint32_t  n_rows = 0;
   uint64_t  nnz = 0;
   uint32_t  max_row = 0;
+  uint32_t  fixed_nnz = 0;           // != 0: every row holds exactly this many entries (row r starts at r * fixed_nnz)
   bool      used = false;
   double    coll_mass = -1.0;        // collision mass of the rows (ensure_coll_mass); < 0: not computed yet
   // per-batch transposed rows for FMX_APPLY_SEGMENTED (built lazily for one batch size)
@@ -45,6 +46,7 @@ struct Slot {
   uint64_t* cmask = nullptr;         // [n_rows] bit i: entry i's feature occurs more than once in the row's batch
   uint32_t* cseg = nullptr;          // [ncseg] batch-local indices of the segments k_apply_seg finishes
   uint32_t  ncseg = 0;
+  uint4*    cdesc = nullptr;         // [ncseg] the same list as {feature, first entry, end entry, index} records
   uint32_t  fused_cap = 0;           // longest row the k_fused instance of this slot keeps in registers
   std::vector<uint32_t> cbatch;      // [n_batches+1] first cseg entry of every batch
   std::vector<struct BlockRows*> blocks;   // `-relation` blocks kept apart from these (main) rows; empty: plain / expanded rows

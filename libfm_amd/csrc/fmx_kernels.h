@@ -769,9 +769,20 @@ k_seg_mark(const uint64_t* __restrict__ keys, const TEntry* __restrict__ vals, c
 // compaction: cseg[cpos[s]] = batch-local index of the flagged segment s (cpos = exclusive scan of cflag)
 static __global__ void __launch_bounds__(256)
 k_seg_compact(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head, const uint32_t* __restrict__ cflag,
-              const uint32_t* __restrict__ cpos, uint32_t nseg, const uint32_t* __restrict__ batch_seg, uint32_t* __restrict__ cseg) {
+              const uint32_t* __restrict__ cpos, uint32_t nseg, const uint32_t* __restrict__ batch_seg, uint32_t* __restrict__ cseg,
+              const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel, const uint64_t* __restrict__ row_ptr,
+              uint32_t n_rows, uint32_t B, uint4* __restrict__ cdesc) {
+  // cdesc: the listed segment as ONE record {feature, first entry, end entry (both relative to the batch's entries), batch-local index}:
+  // the deferred pass reads the list as a coalesced 16-byte stream instead of an index followed by three dependent gathers
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x)
-    if (cflag[s]) cseg[cpos[s]] = s - batch_seg[(uint32_t)(keys[head[s]] >> 32)];
+    if (cflag[s]) {
+      const uint32_t bt = (uint32_t)(keys[head[s]] >> 32);
+      const uint32_t loc = s - batch_seg[bt];
+      cseg[cpos[s]] = loc;
+      const uint64_t r0 = (uint64_t)bt * B, r1 = min((uint64_t)(bt + 1) * B, (uint64_t)n_rows);
+      const uint32_t end = (s + 1 < batch_seg[bt + 1]) ? seg_rel[s + 1] : (uint32_t)(row_ptr[r1] - row_ptr[r0]);
+      cdesc[cpos[s]] = make_uint4(seg_feat[s], seg_rel[s], end, loc);
+    }
 }
 static __global__ void __launch_bounds__(256)
 k_seg_cbatch(const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ cflag, uint32_t nseg,
@@ -791,6 +802,7 @@ struct SegWork {
   const TEntry* t_ent; const uint32_t* seg_feat; const uint32_t* seg_rel; const uint32_t* seg_idx;
   uint32_t nseg, nseg_batch, batch_nnz;
   const float* S; const float* mult;
+  const uint4* cdesc;      // with seg_idx: the listed segments as {feature, first entry, end entry, index} records (nullptr: look them up)
 };
 // SPW = segments per wavefront-block (<= 64).  64 for the dense form (millions of segments: plenty of wavefronts); 16 for
 // the short list of deferred features (a few 100 000): with 64 the pass ran on ~5 000 wavefronts, each a serial chain of
@@ -811,10 +823,15 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
   const uint32_t cnt = min((uint32_t)SPW, sw.nseg - blk);
   uint32_t jl = 0, al = 0, bl = 0, el = 0, e2l = 0; float xl = 0.f, ml = 0.f, x2l = 0.f, m2l = 0.f;
   if (lane < cnt) {
-    const uint32_t s = sw.seg_idx ? sw.seg_idx[blk + lane] : blk + lane;
-    jl = sw.seg_feat[s];
-    al = sw.seg_rel[s];
-    bl = (s + 1 < sw.nseg_batch) ? sw.seg_rel[s + 1] : sw.batch_nnz;
+    if (sw.cdesc) {
+      const uint4 d = sw.cdesc[blk + lane];
+      jl = d.x; al = d.y; bl = d.z;
+    } else {
+      const uint32_t s = sw.seg_idx ? sw.seg_idx[blk + lane] : blk + lane;
+      jl = sw.seg_feat[s];
+      al = sw.seg_rel[s];
+      bl = (s + 1 < sw.nseg_batch) ? sw.seg_rel[s + 1] : sw.batch_nnz;
+    }
     const TEntry te = load_stream8(t_ent + al);
     el = te.e; xl = te.x;
     if (PRE2 && bl - al >= 2) { const TEntry t2 = load_stream8(t_ent + al + 1); e2l = t2.e; x2l = t2.x; m2l = mult[e2l]; }
@@ -1056,7 +1073,9 @@ __global__ void __launch_bounds__(256, FMX_FUSED_MIN_WAVES)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
         uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
-        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out) {
+        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out, uint32_t fixed_nnz) {
+  // fixed_nnz != 0: every row of the slot holds exactly that many entries (one-hot field data): the entry list of example e starts at
+  // (row0 + e) * fixed_nnz and the row_ptr round trip drops out of the chain row_ptr -> entries -> rows (what a small batch consists of)
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   constexpr bool ATOMIC = (VAR == FUSED_ATOMIC), EXACT = (VAR == FUSED_EXACT), APPLY = (VAR == FUSED_APPLY), MASKED = EXACT || APPLY;
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
@@ -1064,8 +1083,8 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   const float w0s = h.k0 ? (float)(*w0_ptr) : 0.f;
   for (uint32_t e = wave0; e < n_rows; e += nwaves) {
-    const uint64_t a = row_ptr[row0 + e];
-    const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
+    const uint64_t a = fixed_nnz ? (row0 + e) * (uint64_t)fixed_nnz : row_ptr[row0 + e];
+    const uint32_t size = fixed_nnz ? fixed_nnz : (uint32_t)(row_ptr[row0 + e + 1] - a);
     const Entry* __restrict__ row = ent + a;
     const float y = APPLY ? 0.f : target[row0 + e];
     uint64_t cm = 0;

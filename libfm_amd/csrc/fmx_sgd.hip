@@ -37,7 +37,7 @@ int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0,
 #define FMX_LAUNCH_ZR(ZRV)                                                                                  \
   if constexpr (fused_zr_ok<KP>(ZRV)) {                                                                     \
     FMX_LAUNCH_WAVES((k_fused<KP, ZRV, VAR>), n_rows, st, s.ent, s.row_ptr, s.target, row0,                 \
-                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out); }
+                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out, s.fixed_nnz); }
   switch (fused_zr_select<KP>(s.max_row)) {
     case 8:  FMX_LAUNCH_ZR(8);  break;
     case 16: FMX_LAUNCH_ZR(16); break;
@@ -202,7 +202,9 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
       SEG_CHK(hipStreamSynchronize(st));
       s.ncseg = last_pos + last_flag;
       SEG_CHK(hipMalloc(&s.cseg, (size_t)std::max<uint32_t>(s.ncseg, 1) * 4));
-      hipLaunchKernelGGL(k_seg_compact, dim3(2048), dim3(256), 0, st, keys_b, head, cflag, cpos, nseg, d_batch_seg, s.cseg);
+      SEG_CHK(hipMalloc(&s.cdesc, (size_t)std::max<uint32_t>(s.ncseg, 1) * sizeof(uint4)));
+      hipLaunchKernelGGL(k_seg_compact, dim3(2048), dim3(256), 0, st, keys_b, head, cflag, cpos, nseg, d_batch_seg, s.cseg,
+                         s.seg_feat, s.seg_rel, s.row_ptr, s.n_rows, B, s.cdesc);
       hipLaunchKernelGGL(k_seg_cbatch, dim3((n_batches + 256) / 256), dim3(256), 0, st, cpos, cflag, nseg, d_batch_seg, n_batches, d_cbatch);
       SEG_CHK(hipGetLastError());
       s.cbatch.resize((size_t)n_batches + 1);
@@ -216,6 +218,7 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
     s.cbatch.assign((size_t)n_batches + 1, 0);
     SEG_CHK(hipMalloc(&s.t_ent, 8));
     SEG_CHK(hipMalloc(&s.cseg, 4));
+    SEG_CHK(hipMalloc(&s.cdesc, sizeof(uint4)));
     SEG_CHK(hipStreamSynchronize(st));
   }
   {  // first entry of every batch (row_ptr sampled at multiples of B)
@@ -354,7 +357,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
     if (c1 > c0) {
       const uint32_t s0 = s.batch_seg[b], s1 = s.batch_seg[b + 1];
       const uint64_t base = s.batch_base[b];
-      SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, s.cseg + c0, c1 - c0, s1 - s0, (uint32_t)(s.batch_base[b + 1] - base), S, h->mult};
+      SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, s.cseg + c0, c1 - c0, s1 - s0, (uint32_t)(s.batch_base[b + 1] - base), S, h->mult, s.cdesc + c0};
       KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 16>), ((uint64_t)sw.nseg + 15) / 16, st, sw, h->tb, hy));
     }
   } else if (apply == FMX_APPLY_SEGMENTED) {
@@ -472,6 +475,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     sw->nseg = c1 - c0; sw->nseg_batch = s1 - s0; sw->batch_nnz = (uint32_t)(s.batch_base[(size_t)b + 1] - base);
     sw->S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
     sw->mult = h->mult + (size_t)(b & 1) * Bc;
+    sw->cdesc = s.cdesc + c0;
   };
   for (uint64_t b = 0; b < n_batch; b++) {
     const uint64_t row0 = b * B;
