@@ -53,7 +53,10 @@ enum {
   FMX_SGD_MINIBATCH = 1,   /* restated batch rule (oracle/fm_oracle.h fmo_sgd_epoch_minibatch):
                               partial sums -> [all-reduce] -> w0 micro-chunks + multipliers -> scatter-add */
   FMX_SGD_HOGWILD = 2      /* fused single pass per example (gather, predict, update in registers);
-                              asynchronous between wavefronts; single device only */
+                              asynchronous between wavefronts; single device only.  An update becomes visible when its wavefront
+                              retires, so the ~5 000 rows in flight act like a batch: on rows with frequent features (collision mass C,
+                              see fmx_sgd_opts::batch) it diverges where learn_rate * curvature * 5 120 * C > 2 -- fmx_epoch_stats
+                              reports the gain (batch_used = rows in flight) and FMX_STAT_UNSTABLE, FMX_FLAG_REJECT_UNSTABLE refuses */
 };
 
 enum {

@@ -544,6 +544,16 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
                                 "diverges (collision mass %.4g; batch 0 lets the library choose)", bi.batch, bi.batch_gain, bi.collision_mass);
     ropts.batch = bi.batch;
     opts = &ropts;
+  } else if (opts->mode == FMX_SGD_HOGWILD) {
+    // the asynchronous step freezes nothing, but an update becomes visible only when its wavefront retires: the rows in flight
+    // (5 wavefronts per SIMD x 4 SIMDs x CUs on this part, one example each) are the window the criterion of MINIBATCH applies to
+    rc = ensure_coll_mass(h, s);
+    if (rc) return rc;
+    const uint32_t in_flight = (uint32_t)std::min<uint64_t>(s.n_rows, (uint64_t)20 * (uint64_t)h->num_cu);
+    resolve_batch(h->cfg, s.coll_mass, in_flight, in_flight, 1.0, &bi);
+    if ((opts->flags & FMX_FLAG_REJECT_UNSTABLE) && (bi.status & FMX_STAT_UNSTABLE))
+      return fail(h, FMX_E_ARG, "HOGWILD on these rows: learn_rate * curvature * %u rows in flight * collision mass = %.3g > 2 -- the asynchronous "
+                                "step diverges (collision mass %.4g; use FMX_SGD_MINIBATCH with batch 0)", in_flight, bi.batch_gain, bi.collision_mass);
   }
   const bool timed = (opts->flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
   uint64_t batches = 0, main_launches = 0, deferred = 0;
@@ -650,7 +660,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     stats->device_seconds = ms * 1e-3;
     if (opts->mode == FMX_SGD_MINIBATCH && s.seg_B) stats->max_feature_count = s.max_seg_count;
     stats->deferred_features = deferred;
-    if (opts->mode == FMX_SGD_MINIBATCH) {
+    if (opts->mode == FMX_SGD_MINIBATCH || opts->mode == FMX_SGD_HOGWILD) {     // (HOGWILD: batch_used = the rows in flight)
       stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
     }
     stats->setup_seconds = h->setup_acc;

@@ -221,3 +221,21 @@ def test_dense_collisions_one_pass_equals_two_pass_and_the_oracle(capi, oracle, 
     w0s, ws, vs = res[capi.APPLY_SEGMENTED]
     np.testing.assert_allclose(v, vs, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(w, ws, rtol=2e-6, atol=1e-7)
+
+
+def test_hogwild_reports_its_window_too(capi):
+    """the asynchronous mode freezes nothing, but the rows in flight act like a batch: on Criteo-shaped rows the library says so
+    (status, gain) and refuses on request; on uniform ids over a wide table it has nothing to say"""
+    e, rp, y, n = criteo(12000)
+    h = capi.Handle(n, 8, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0)
+    h.upload_rows(0, e, rp, y)
+    with pytest.raises(capi.FmxError) as ei:
+        h.sgd_epoch(0, capi.SGD_HOGWILD, capi.APPLY_DEFAULT, 0, 0, capi.FLAG_REJECT_UNSTABLE)
+    assert ei.value.code == -1 and "in flight" in ei.value.text
+    h.close()
+    h = capi.Handle(10_000_000, 8, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0)
+    h.init_params(0.0, 0.01, 1)
+    h.synth_rows(0, 3, 0, 50000, 16)
+    st = h.sgd_epoch(0, capi.SGD_HOGWILD, capi.APPLY_DEFAULT, 0, 0, capi.FLAG_REJECT_UNSTABLE)
+    assert st.status == 0 and st.batch_gain < 0.1 and 1000 < st.batch_used <= 5120
+    h.close()
