@@ -153,8 +153,8 @@ typedef struct fmx_epoch_stats {
   uint32_t batch_used;      /* MINIBATCH: rows per batch this epoch ran with (the resolved fmx_sgd_opts::batch) */
   uint64_t deferred_features; /* FMX_APPLY_FUSED: (batch, feature) pairs finished by the segmented kernel, summed over the
                                * epoch's batches (features occurring more than once in their batch; the rest was one pass) */
-  double   collision_mass;  /* C of the slot's rows: sum over features j of (sum over rows of |x_j| / n_rows)^2 = the expected
-                               number of features two random rows share (value-weighted) */
+  double   collision_mass;  /* C of the slot's rows: the mean over pairs of DIFFERENT rows of sum_j |x_ej| |x_e'j| = the expected
+                               number of features two rows share (value-weighted) */
   double   batch_gain;      /* learn_rate * curvature * batch_used * C (curvature 1 regression, 1/4 classification): the batch
                                rule follows the reference's online loop for <= 1, degrades above and diverges beyond ~2 */
   uint32_t status;          /* FMX_STAT_* */

@@ -175,19 +175,22 @@ int ensure_coll_mass(fmx_handle h, Slot& s) {
   float* hist = nullptr;
   HIPCHK(h, hipMalloc(&hist, (size_t)M * sizeof(float)));
   hipError_t er = hipMemsetAsync(hist, 0, (size_t)M * sizeof(float), h->stream);
-  if (er == hipSuccess) er = hipMemsetAsync(h->acc, 0, sizeof(double), h->stream);
+  if (er == hipSuccess) er = hipMemsetAsync(h->acc, 0, 2 * sizeof(double), h->stream);
   if (er == hipSuccess) {
-    hipLaunchKernelGGL(k_coll_hist, dim3((unsigned)std::min<uint64_t>((s.nnz + 255) / 256, 8192)), dim3(256), 0, h->stream, s.ent, s.nnz, M, hist);
+    hipLaunchKernelGGL(k_coll_hist, dim3((unsigned)std::min<uint64_t>((s.nnz + 255) / 256, 8192)), dim3(256), 0, h->stream, s.ent, s.nnz, M, hist, h->acc + 1);
     hipLaunchKernelGGL(k_coll_sumsq, dim3((unsigned)std::min<uint64_t>(((uint64_t)M + 255) / 256, 4096)), dim3(256), 0, h->stream,
-                       (const float*)hist, M, 1.0 / (double)s.n_rows, h->acc);
+                       (const float*)hist, M, h->acc);
     er = hipGetLastError();
   }
-  double c = 0.0;
-  if (er == hipSuccess) er = hipMemcpyAsync(&c, h->acc, sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  double c[2] = {0.0, 0.0};
+  if (er == hipSuccess) er = hipMemcpyAsync(c, h->acc, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
   hipFree(hist);
   if (er != hipSuccess) return fail(h, FMX_E_HIP, "collision mass of the rows: %s", hipGetErrorString(er));
-  s.coll_mass = c;
+  // pairs of DIFFERENT rows: what a row shares with itself (sum of x^2 over its entries) is taken out.  On a feature shard this is
+  // the shard's share of the numerator over the same N (N - 1): the shares add up.
+  const double N = (double)s.n_rows;
+  s.coll_mass = (s.n_rows > 1) ? std::max(0.0, c[0] - c[1]) / (N * (N - 1.0)) : 0.0;
   return FMX_OK;
 }
 

@@ -1997,20 +1997,26 @@ k_shard_rows(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
   }
 }
 
-// ---- collision mass of a row set: C = sum_j (sum_rows |x_j| / n_rows)^2 (fmx_sgd_opts::batch, fmx_sgd_batch_info) ------------
+// ---- collision mass of a row set: C = mean over pairs of DIFFERENT rows of sum_j |x_ej| |x_e'j|
+//      = (sum_j (sum_rows |x_j|)^2 - sum_entries x^2) / (N (N - 1))      (fmx_sgd_opts::batch, fmx_sgd_batch_info) ------------
 // hist[id mod M] += |x| per entry (M = table size, or 2^27 buckets for larger tables: folding can only raise C, i.e. cut the batch more)
+// (sumsq: sum over the entries of x^2 -- what a row shares with ITSELF, taken out of the pair statistic afterwards)
 static __global__ void __launch_bounds__(256)
-k_coll_hist(const Entry* __restrict__ ent, uint64_t nnz, uint32_t M, float* __restrict__ hist) {
+k_coll_hist(const Entry* __restrict__ ent, uint64_t nnz, uint32_t M, float* __restrict__ hist, double* __restrict__ sumsq) {
+  double own = 0.0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x) {
     const Entry e = ent[i];
     unsafeAtomicAdd(hist + (e.id % M), fabsf(e.value));
+    own += (double)e.value * (double)e.value;
   }
+  own = wave_sum_d(own);
+  if ((threadIdx.x & 63u) == 0 && own != 0.0) unsafeAtomicAdd(sumsq, own);
 }
 static __global__ void __launch_bounds__(256)
-k_coll_sumsq(const float* __restrict__ hist, uint32_t M, double inv_rows, double* __restrict__ out) {
+k_coll_sumsq(const float* __restrict__ hist, uint32_t M, double* __restrict__ out) {
   double a = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (uint64_t)gridDim.x * blockDim.x) {
-    const double f = (double)hist[i] * inv_rows;
+    const double f = (double)hist[i];
     a += f * f;
   }
   a = wave_sum_d(a);

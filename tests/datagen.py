@@ -156,9 +156,11 @@ def criteo_shaped(n_rows, seed, n_dense=13, dense_ids=100, n_cat=26, cat_ids=500
 
 
 def collision_mass(entries, n_rows, n):
-    """C of fmx_sgd_opts::batch: sum over features of (sum over rows of |x_j| / n_rows)^2"""
-    cnt = np.bincount(entries["id"], weights=np.abs(entries["value"].astype(np.float64)), minlength=n)
-    return float(((cnt / n_rows) ** 2).sum())
+    """C of fmx_sgd_opts::batch: the mean over pairs of DIFFERENT rows of sum_j |x_ej| |x_e'j| (the expected number of features two
+    rows share, value-weighted) = (sum_j (sum_rows |x_j|)^2 - sum_entries x^2) / (N (N - 1))"""
+    x = np.abs(entries["value"].astype(np.float64))
+    cnt = np.bincount(entries["id"], weights=x, minlength=n)
+    return float(max(0.0, (cnt ** 2).sum() - (x ** 2).sum()) / (n_rows * (n_rows - 1.0)))
 
 
 def stable_batch(lr, task, C, default=262144, curv_scale=1.0):
