@@ -360,6 +360,8 @@ def main():
     ap.add_argument("--no-bias-lag", action="store_true", help="minibatch: keep the w0 recurrence on the critical path (exact chunk coupling)")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--place", type=int, default=0,
+                    help="fmx_config::place_candidates: 0 = the library's placement (big tables: chunks of two memory classes), 1 = first fit")
     ap.add_argument("--traffic", type=float, default=None,
                     help="PMC HBM bytes per launch of the dominant kernel (default: profiles/traffic.json if it matches)")
     ap.add_argument("--no-cpu-reference", dest="cpu_reference", action="store_false",
@@ -420,7 +422,8 @@ def main():
 
     lr, regv = 0.01, 0.001
     h = capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
-                    device=local_rank, shard_rank=rank, shard_world=world, shard_hash=1 if world > 1 else 0)
+                    device=local_rank, shard_rank=rank, shard_world=world, shard_hash=1 if world > 1 else 0,
+                    place_candidates=args.place)
     h.init_params(0.0, 0.01, 1)
     h.synth_rows(0, 123, 0, args.rows, args.nnz, capi.SYNTH_CRITEO if criteo else capi.SYNTH_UNIFORM)
     if criteo and rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -630,6 +633,11 @@ def main():
                                      "what": "collision mass of the rows + bucketing of the entries by (batch, feature) (device radix sort, "
                                              "segment / mask / deferred-list build; fmx_epoch_stats::setup_seconds); libFM never shuffles "
                                              "(fm_learn_sgd_element.h:56), so every later epoch reuses it"}
+        pi = h.place_info()
+        out["config"]["placement"] = {"method": {0: "plain allocations", 1: "best of candidate allocations",
+                                                 2: "arena of 1 GiB chunks from two memory classes"}.get(pi.method, str(pi.method)),
+                                      "chunks": pi.chunks, "per_class": [pi.per_class[0], pi.per_class[1]], "pool_probed": pi.pool,
+                                      "classes_seen": pi.classes_seen, "seconds": round(pi.seconds, 3)}
         if batch_stats is not None and args.mode != "hogwild":
             out["config"]["batch_rule"] = {"batch": batch_stats.batch_used, "collision_mass": round(batch_stats.collision_mass, 6),
                                            "gain": round(batch_stats.batch_gain, 4),

@@ -96,8 +96,11 @@ typedef struct fmx_config {
                                   PERMUTATION of [0, num_attribute) (4-round Feistel network, cycle-walked; north_star:
                                   "row-sharded by feature-id hash"): balanced whatever the structure of the ids, still a dense
                                   local table, and invertible, so the shard knows its features' global ids. */
-  int32_t  place_candidates;/* parameter tables of >= 256 MB are PLACED by measurement (see fmx_create): how many candidate allocations
-                               may be held side by side and probed.  0 = default (2), 1 = first fit (no probe, no transient memory), <= 6 */
+  int32_t  place_candidates;/* placement of the parameter tables (see fmx_create).  0 = default: tables of >= 2 GiB are built from 1 GiB
+                               chunks of TWO memory classes of the device, found by probing (transient pool of at most 3 tables' worth
+                               of chunks + 64 GiB, never more than half of the free memory); tables of 256 MB .. 2 GiB: best of 2 candidate
+                               allocations.  1 = first fit: plain allocations, no probe, no transient memory.  2 .. 6 = the bound of the
+                               transient pool in tables' worth (big tables) / the number of candidates (small ones) */
   uint32_t als_split_min;   /* ALS / MCMC: dependency levels with at least this many entries update {e, q} as a row-ordered stream
                                (the split step) instead of inside the fused draw.  0 = library default (65536),
                                1 = every level, 0xFFFFFFFF = never */
@@ -193,11 +196,26 @@ typedef struct fmx_eval {
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* replaces: fm_model fm; fm.init() allocation (fm_model.h:91-99) + new fm_learn_* (libfm.cpp:271-293)
- * Parameter tables of >= 256 MB are PLACED: up to fmx_config::place_candidates (default 2) candidate allocations are held side by
- * side for a few milliseconds, each timed under the training step's access pattern, the fastest kept -- which physical memory a
- * table lands in moves the step by 10-20 % on MI355X; the transient footprint is one extra table. */
+ * Parameter tables are PLACED (fmx_config::place_candidates): on MI355X physical memory falls into three classes of ~96 GB (what one
+ * would expect of the three ranks of the 12-high HBM3E stacks) and random row traffic inside ONE class runs at 4.9 TB/s, spread over
+ * two at 6.1 (scripts/ubench/placement_classes.hip) -- a plain allocation lands in one class or straddles two by
+ * luck, which moved the training step by 10-20 % from process to process.  fmx_create therefore takes 1 GiB chunks (hipMemCreate),
+ * classifies each by probing it together with a reference chunk, maps chunks of two classes alternately into one virtual range, puts
+ * V at its start and w across a chunk boundary behind it, and returns the chunks it does not need.  fmx_place_info reports what it
+ * found.  If the virtual-memory API is unavailable the tables are plain allocations (best of two candidates). */
 int fmx_create(const fmx_config *cfg, fmx_handle *out);
 int fmx_destroy(fmx_handle h);
+/* how the parameter tables of a handle were placed */
+typedef struct fmx_place_info {
+  int32_t  method;          /* 0 = plain allocations (small tables / first fit), 1 = best of several candidate allocations,
+                               2 = arena of chunks from two memory classes */
+  uint32_t chunks;          /* method 2: 1 GiB chunks the arena holds */
+  uint32_t per_class[2];    /*           ... of the first / the second class (equal up to one = balanced) */
+  uint32_t pool;            /*           chunks taken and probed to find them (the others were returned before fmx_create ended) */
+  uint32_t classes_seen;    /*           memory classes seen among the pool */
+  double   seconds;         /* host time of the placement */
+} fmx_place_info;
+int fmx_get_place_info(fmx_handle h, fmx_place_info *out);
 /* text of the last error on this handle (h may be NULL: last creation error). Never NULL. */
 const char *fmx_last_error(fmx_handle h);
 int fmx_abi_version(void);

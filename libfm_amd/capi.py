@@ -63,6 +63,11 @@ class BatchInfo(C.Structure):
     _fields_ = [("collision_mass", C.c_double), ("batch_gain", C.c_double), ("batch", C.c_uint32), ("status", C.c_uint32)]
 
 
+class PlaceInfo(C.Structure):
+    _fields_ = [("method", C.c_int32), ("chunks", C.c_uint32), ("per_class", C.c_uint32 * 2), ("pool", C.c_uint32),
+                ("classes_seen", C.c_uint32), ("seconds", C.c_double)]
+
+
 class Eval(C.Structure):
     _fields_ = [("rmse", C.c_double), ("mae", C.c_double), ("accuracy", C.c_double),
                 ("device_seconds", C.c_double), ("rows", C.c_uint64)]
@@ -130,6 +135,7 @@ SYMBOLS = [
     ("fmx_evaluate", C.c_int, [H, C.c_int, C.POINTER(Eval)]),
     ("fmx_sgd_epoch", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(EpochStats)]),
     ("fmx_sgd_batch_info", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(BatchInfo)]),
+    ("fmx_get_place_info", C.c_int, [H, C.POINTER(PlaceInfo)]),
     ("fmx_partial_floats", C.c_int, [H, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("fmx_sgd_partial", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_sgd_finish", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(SgdOpts), C.c_void_p]),
@@ -350,6 +356,12 @@ class Handle:
         bi = BatchInfo()
         self._chk(self.lib.fmx_sgd_batch_info(self.h, slot, C.byref(opts), C.byref(bi)))
         return bi
+
+    def place_info(self):
+        """how fmx_create placed the parameter tables (fmx_place_info)"""
+        pi = PlaceInfo()
+        self._chk(self.lib.fmx_get_place_info(self.h, C.byref(pi)))
+        return pi
 
     def partial_floats(self, batch):
         n = C.c_uint64(0)

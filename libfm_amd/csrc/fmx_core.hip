@@ -213,6 +213,174 @@ void resolve_batch(const fmx_config& cfg, double coll_mass, uint32_t requested, 
   out->status = status;
 }
 
+// ---- placement of big parameter tables: an arena of chunks from two memory classes ---------------------------------------------
+// scripts/ubench/placement_chunks / _order / _classes.hip (profiles/r03_placement_*.txt): the rate of random 256-byte row traffic is a
+// property of the PHYSICAL memory (the same chunks mapped elsewhere keep it) and of its SPREAD: any 1 GB piece of any table runs at
+// 4.9 TB/s, and so does a table whose pieces all come from one of three classes of ~96 GB the device's memory falls into; pieces of
+// two classes evenly mixed run at 6.1 (3 : 1 -> 5.8, 7 : 1 -> 5.4; three classes are no better than two).  A plain allocation lies in
+// one class or straddles two by luck.  Here: chunks are taken one at a time, each is classified by probing it together with the
+// reference chunk of every class seen so far (k_place_pair), until two classes can supply half of the arena each; those are mapped
+// alternately into one range, everything else goes back.  Any failure of the virtual-memory API leaves nothing behind and the caller
+// falls back to plain allocations.
+namespace {
+constexpr size_t ARENA_CHUNK = (size_t)1 << 30;
+struct ArenaPool {
+  void* va = nullptr; size_t cap = 0;                              // scratch range the pool's chunks are mapped into
+  std::vector<hipMemGenericAllocationHandle_t> hnd;                // chunk i is mapped at va + i * ARENA_CHUNK while mapped[i]
+  std::vector<char> mapped;
+  std::vector<int> cls;
+};
+void arena_pool_release(ArenaPool& P) {
+  for (size_t i = 0; i < P.hnd.size(); i++) {
+    if (P.mapped[i]) (void)hipMemUnmap((char*)P.va + i * ARENA_CHUNK, ARENA_CHUNK);
+    (void)hipMemRelease(P.hnd[i]);
+  }
+  if (P.va) (void)hipMemAddressFree(P.va, P.cap * ARENA_CHUNK);
+  P.hnd.clear(); P.mapped.clear(); P.cls.clear(); P.va = nullptr;
+}
+}  // namespace
+
+void arena_free(fmx_handle h) {
+  Arena& A = h->arena;
+  if (!A.va) return;
+  (void)hipMemUnmap(A.va, A.bytes);
+  (void)hipMemAddressFree(A.va, A.bytes);
+  A.va = nullptr; A.bytes = 0; A.n_chunks = 0;
+}
+
+// V (v_bytes) at the start of the arena, w (w_bytes) centred on a chunk boundary behind it (both classes under it too)
+static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int bound_tables, float** V_out, float** w_out) {
+  const auto t_start = std::chrono::steady_clock::now();
+  const size_t CH = ARENA_CHUNK;
+  const size_t w_half = ((w_bytes / 2) + 255) & ~(size_t)255;
+  const size_t boundary = (v_bytes + w_half + CH - 1) / CH;                       // w straddles the start of chunk `boundary`
+  const size_t w_off = boundary * CH - w_half;
+  const uint32_t T = (uint32_t)((w_off + w_bytes + CH - 1) / CH);
+  size_t free_b = 0, total_b = 0;
+  hipError_t er = hipMemGetInfo(&free_b, &total_b);
+  if (er != hipSuccess) return er;
+  if ((size_t)T * CH + ((size_t)2 << 30) > free_b) return hipErrorOutOfMemory;    // (the caller's plain allocation reports it properly)
+  // the pool: at most bound_tables arenas' worth + 64 chunks (a class comes in runs of up to 64 GB in allocation order), at most
+  // half of what is free beyond the arena itself
+  size_t max_pool = std::min<size_t>((size_t)bound_tables * T + 64, T + (free_b - (size_t)T * CH) / CH / 2);
+  max_pool = std::max<size_t>(max_pool, T);
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = h->device;
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice; acc.location.id = h->device; acc.flags = hipMemAccessFlagsProtReadWrite;
+  ArenaPool P;
+  P.cap = max_pool;
+  er = hipMemAddressReserve(&P.va, P.cap * CH, CH, nullptr, 0);
+  if (er != hipSuccess) { P.va = nullptr; return er; }
+  auto chunk_va = [&](size_t i) { return (float*)((char*)P.va + i * CH); };
+  const uint32_t rows_shift = 22;                                   // 1 GiB / 256 B
+  const uint32_t waves = 1u << 17;                                  // 2.1 GB of traffic per probe, ~0.4 ms
+  auto pair_ms = [&](size_t i, size_t j, float* ms) -> hipError_t {
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {                             // (first launch: page-table warm-up)
+      hipError_t e = hipEventRecord(h->ev0, h->stream);
+      hipLaunchKernelGGL(k_place_pair, dim3(waves / 4), dim3(256), 0, h->stream, chunk_va(i), chunk_va(j), rows_shift, waves, (uint64_t)rep * 7919 + 1);
+      if (e == hipSuccess) e = hipGetLastError();
+      if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
+      float t = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&t, h->ev0, h->ev1);
+      if (e != hipSuccess) return e;
+      if (rep && t < best) best = t;
+    }
+    *ms = best;
+    return hipSuccess;
+  };
+  std::vector<size_t> refs;                                          // first chunk of every class
+  std::vector<std::vector<size_t>> of;                               // chunks per class
+  float base_ms = 0.f;
+  auto enough = [&](size_t* x, size_t* y) -> bool {                  // two classes with ceil(T/2) and floor(T/2) chunks?
+    size_t a = SIZE_MAX, b = SIZE_MAX;
+    for (size_t k = 0; k < of.size(); k++) {
+      if (a == SIZE_MAX || of[k].size() > of[a].size()) { b = a; a = k; }
+      else if (b == SIZE_MAX || of[k].size() > of[b].size()) b = k;
+    }
+    *x = a; *y = b;
+    return a != SIZE_MAX && b != SIZE_MAX && of[a].size() >= (T + 1) / 2 && of[b].size() >= T / 2;
+  };
+  size_t cx = SIZE_MAX, cy = SIZE_MAX;
+  while (er == hipSuccess && P.hnd.size() < max_pool && !(T >= 2 && enough(&cx, &cy))) {
+    const size_t i = P.hnd.size();
+    hipMemGenericAllocationHandle_t hd;
+    er = hipMemCreate(&hd, CH, &prop, 0);
+    if (er != hipSuccess) { if (i >= T) { (void)hipGetLastError(); er = hipSuccess; } break; }   // memory ran out: go with the pool in hand
+    P.hnd.push_back(hd); P.mapped.push_back(0); P.cls.push_back(-1);
+    er = hipMemMap((char*)P.va + i * CH, CH, 0, hd, 0);
+    if (er != hipSuccess) break;
+    P.mapped[i] = 1;
+    er = hipMemSetAccess((char*)P.va + i * CH, CH, &acc, 1);
+    if (er == hipSuccess) er = hipMemsetAsync(chunk_va(i), 0, CH, h->stream);   // (a never-written allocation answers a probe in microseconds)
+    if (er != hipSuccess) break;
+    if (refs.empty()) {
+      er = pair_ms(i, i, &base_ms);                                  // the one-chunk rate
+      refs.push_back(i); of.push_back({i}); P.cls[i] = 0;
+      continue;
+    }
+    for (size_t k = 0; k < refs.size() && P.cls[i] < 0 && er == hipSuccess; k++) {
+      float ms = 0.f;
+      er = pair_ms(refs[k], i, &ms);
+      if (er == hipSuccess && ms > base_ms / 1.08f) { P.cls[i] = (int)k; of[k].push_back(i); }   // no faster together: same class
+    }
+    if (er == hipSuccess && P.cls[i] < 0) { refs.push_back(i); of.push_back({i}); P.cls[i] = (int)refs.size() - 1; }
+  }
+  if (er != hipSuccess || P.hnd.size() < T) { arena_pool_release(P); return er != hipSuccess ? er : hipErrorOutOfMemory; }
+  (void)enough(&cx, &cy);
+  // the arena's chunks in mapping order: the two best-stocked classes alternately; when the second runs short (pool bound reached)
+  // its chunks are spread evenly among the first's, then any other class fills up
+  std::vector<size_t> pick;
+  {
+    std::vector<size_t> X = of[cx], Y = (cy != SIZE_MAX) ? of[cy] : std::vector<size_t>();
+    std::vector<size_t> rest;
+    for (size_t k = 0; k < of.size(); k++) if (k != cx && k != cy) rest.insert(rest.end(), of[k].begin(), of[k].end());
+    const size_t ny = std::min<size_t>(Y.size(), T / 2);
+    size_t nx = std::min<size_t>(X.size(), T - ny);
+    size_t ix = 0, iy = 0, ir = 0, err_acc = 0;
+    for (uint32_t c = 0; c < T; c++) {
+      err_acc += ny;
+      if (iy < ny && err_acc >= T) { err_acc -= T; pick.push_back(Y[iy++]); }
+      else if (ix < nx) pick.push_back(X[ix++]);
+      else if (iy < Y.size()) pick.push_back(Y[iy++]);
+      else if (ir < rest.size()) pick.push_back(rest[ir++]);
+    }
+    if (pick.size() < T) { arena_pool_release(P); return hipErrorOutOfMemory; }
+    h->arena.per_class[0] = (uint32_t)ix; h->arena.per_class[1] = (uint32_t)iy;
+  }
+  void* va = nullptr;
+  er = hipMemAddressReserve(&va, (size_t)T * CH, CH, nullptr, 0);
+  if (er != hipSuccess) { arena_pool_release(P); return er; }
+  er = hipStreamSynchronize(h->stream);
+  uint32_t moved = 0;
+  for (; moved < T && er == hipSuccess; moved++) {
+    const size_t i = pick[moved];
+    er = hipMemUnmap((char*)P.va + i * CH, CH);
+    if (er != hipSuccess) break;
+    P.mapped[i] = 0;
+    er = hipMemMap((char*)va + (size_t)moved * CH, CH, 0, P.hnd[i], 0);
+  }
+  if (er == hipSuccess) er = hipMemSetAccess(va, (size_t)T * CH, &acc, 1);
+  if (er != hipSuccess) {
+    if (moved) (void)hipMemUnmap(va, (size_t)moved * CH);
+    (void)hipMemAddressFree(va, (size_t)T * CH);
+    arena_pool_release(P);
+    return er;
+  }
+  const uint32_t pool = (uint32_t)P.hnd.size();
+  arena_pool_release(P);                                             // the unused chunks go back; the mapped ones live on through their mapping
+  Arena& A = h->arena;
+  A.va = va; A.bytes = (size_t)T * CH; A.chunk_bytes = CH; A.n_chunks = T; A.pool = pool; A.classes_seen = (uint32_t)refs.size(); A.method = 2;
+  er = hipMemsetAsync(va, 0, A.bytes, h->stream);
+  if (er != hipSuccess) { arena_free(h); return er; }
+  *V_out = (float*)va;
+  *w_out = (float*)((char*)va + w_off);
+  A.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  return hipSuccess;
+}
+
 extern "C" {
 
 int fmx_abi_version(void) { return FMX_ABI_VERSION; }
@@ -268,13 +436,11 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     // row layout: V rows of KP floats, the linear weights in an array of their own (co-locating w_j behind its row was measured
     // in rounds 1 and 2: HBM fetches 64-byte sectors, a 4-byte w costs one wherever it lives, and unaligned rows cost more)
     h->tb.rs = (uint32_t)h->KP;
-    // Placement of the parameter tables.  The rate of the step's random row gather + write-back depends on WHICH physical memory a table
-    // landed in (same size, same process, same kernel: classes from 4.9 to 6.1 TB/s, stable for the life of the allocation;
-    // scripts/ubench/placement.hip).  What does NOT separate the classes (scripts/ubench/placement_vmm.hip, profiles/r03_placement_vmm.txt):
-    // the virtual alignment (2 MB .. 1 GB) and the size of the physically contiguous extents (tables built from 2 MB, 64 MB and 1 GB
-    // hipMemCreate chunks fall into both classes).  So a table of >= 256 MB is allocated up to fmx_config::place_candidates times
-    // (default 2; the earlier candidate is held meanwhile, so that the later one is other memory), each candidate is zeroed and
-    // timed under a probe with the step's traffic shape, the fastest is kept.  place_candidates = 1: first fit, no probe.
+    // Placement of the parameter tables: big ones (>= 2 GiB) in an arena of chunks from two memory classes (arena_build above).  Smaller
+    // ones, and every table when the virtual-memory API fails: a table of >= 256 MB is allocated up to fmx_config::place_candidates
+    // times (default 2; the earlier candidate is held meanwhile, so that the later one is other memory), each candidate is zeroed and
+    // timed under a probe with the step's traffic shape, the fastest is kept (a plain allocation straddles two classes or not, by
+    // luck).  place_candidates = 1: first fit, no probe.
     auto alloc_placed = [&](float** out, size_t bytes, int max_tries, bool rows, const char* what) -> hipError_t {
       constexpr int MAXC = 6;
       int tries = 1;
@@ -317,9 +483,21 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
       *out = cand[best];
       return er;
     };
-    const int cand = cfg->place_candidates > 0 ? std::min(cfg->place_candidates, 6) : 2;
-    CREATE_CHK(alloc_placed(&h->tb.V, h->n_local * (size_t)h->tb.rs * sizeof(float), cand, true, "factor table"));
-    CREATE_CHK(alloc_placed(&h->w_sep, h->n_local * sizeof(float), cand, false, "linear weights"));
+    const auto t_place = std::chrono::steady_clock::now();
+    const size_t v_bytes = h->n_local * (size_t)h->tb.rs * sizeof(float), w_bytes = h->n_local * sizeof(float);
+    bool placed = false;
+    if (cfg->place_candidates != 1 && v_bytes >= ((size_t)2 << 30)) {
+      // big tables: an arena of 1 GiB chunks from two memory classes (arena_build above); on any failure plain allocations below
+      const hipError_t ae = arena_build(h, v_bytes, w_bytes, cfg->place_candidates > 1 ? cfg->place_candidates : 3, &h->tb.V, &h->w_sep);
+      if (ae == hipSuccess) placed = true; else { (void)hipGetLastError(); h->tb.V = nullptr; h->w_sep = nullptr; }
+    }
+    if (!placed) {
+      const int cand = cfg->place_candidates > 0 ? std::min(cfg->place_candidates, 6) : 2;
+      CREATE_CHK(alloc_placed(&h->tb.V, v_bytes, cand, true, "factor table"));
+      CREATE_CHK(alloc_placed(&h->w_sep, w_bytes, cand, false, "linear weights"));
+      h->arena.method = (cand > 1 && v_bytes >= ((size_t)256 << 20)) ? 1 : 0;
+      h->arena.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_place).count();
+    }
     h->tb.w = h->w_sep; h->tb.ws = 1;
   }
   CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
@@ -339,6 +517,14 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   return FMX_OK;
 }
 
+int fmx_get_place_info(fmx_handle h, fmx_place_info* out) {
+  if (!h || !out) return FMX_E_ARG;
+  const Arena& A = h->arena;
+  out->method = A.method; out->chunks = A.n_chunks; out->per_class[0] = A.per_class[0]; out->per_class[1] = A.per_class[1];
+  out->pool = A.pool; out->classes_seen = A.classes_seen; out->seconds = A.seconds;
+  return FMX_OK;
+}
+
 int fmx_destroy(fmx_handle h) {
   if (!h) return FMX_OK;
   hipSetDevice(h->device);
@@ -348,8 +534,8 @@ int fmx_destroy(fmx_handle h) {
   sgda_free(h);
   for (auto& s : h->slots) free_slot(s);
   if (h->grp) hipFree(h->grp);
-  if (h->tb.V) hipFree(h->tb.V);
-  if (h->w_sep) hipFree(h->w_sep);
+  if (h->arena.va) arena_free(h);                              // (both tables are parts of it)
+  else { if (h->tb.V) hipFree(h->tb.V); if (h->w_sep) hipFree(h->w_sep); }
   if (h->w0) hipFree(h->w0);
   if (h->w0_pp) hipFree(h->w0_pp);
   if (h->stream2) hipStreamDestroy(h->stream2);

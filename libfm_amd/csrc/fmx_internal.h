@@ -108,6 +108,19 @@ struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping (split step):
 struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; double* dreg = nullptr;   // dreg: [workgroups][G][1 + KP] partial lambda changes
                    size_t dreg_cap = 0; };
 
+// The parameter tables of a big model live in an ARENA: one virtual range backed by 1 GiB physical chunks (hipMemCreate) taken
+// alternately from two memory classes of the device (fmx_create)
+struct Arena {
+  void*    va = nullptr;         // reserved range; chunk i is mapped at va + i * chunk_bytes
+  size_t   bytes = 0, chunk_bytes = 0;
+  uint32_t n_chunks = 0;
+  uint32_t per_class[2] = {0, 0};   // chunks of the two classes the tables are built from
+  uint32_t pool = 0;             // chunks that were taken and classified to get them (the others were returned)
+  uint32_t classes_seen = 0;
+  double   seconds = 0.0;        // host time of the whole placement
+  int      method = 0;           // fmx_place_info::method
+};
+
 struct fmx_context_s {
   fmx_config cfg;
   AlsState   als;
@@ -122,6 +135,7 @@ struct fmx_context_s {
   hipStream_t stream = nullptr;
   Tab        tb = {nullptr, nullptr, 0, 0};   // V rows (+ co-located w), see fmx_kernels.h
   float*     w_sep = nullptr;    // the w[] array
+  Arena      arena;              // when arena.va != nullptr both tables are parts of it (nothing to hipFree)
   double*    w0 = nullptr;       // device scalar
   double*    w0_pp = nullptr;    // 8 doubles: ring of bias copies for the overlapped recurrence (hogwild, fused, bias lag)
   hipStream_t stream2 = nullptr; // side stream of the hogwild bias scan

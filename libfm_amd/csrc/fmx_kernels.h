@@ -1221,6 +1221,25 @@ k_place_probe(float* __restrict__ tab, uint64_t n_rows, uint32_t row_floats, uin
   for (int t = 0; t < 32; t++) __builtin_nontemporal_store(v[t] * 0.999f, tab + at[t]);   // (a plain write-back of the loaded value is a no-op the
 }                                                                                           //  compiler removes together with the load; the table is zero)
 
+// k_place_pair: the probe that CLASSIFIES physical memory (fmx_create, scripts/ubench/placement_classes.hip): every wavefront reads 32
+// random 256-byte rows of the union of two equally sized pieces a and b (1 << rows_shift rows each; a == b: one piece alone) and
+// writes them back.  Two pieces of the same memory class run at the one-piece rate, pieces of different classes ~25 % faster.
+static __global__ void __launch_bounds__(256)
+k_place_pair(float* __restrict__ a, float* __restrict__ b, uint32_t rows_shift, uint32_t n_waves, uint64_t salt) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= n_waves) return;
+  float v[32]; float* at[32];
+#pragma unroll
+  for (int t = 0; t < 32; t++) {
+    const uint64_t r = mix64((uint64_t)wave * 32 + t + salt) >> (63 - rows_shift);          // rows_shift + 1 random bits
+    at[t] = ((r >> rows_shift) ? b : a) + (r & ((1ull << rows_shift) - 1)) * 64 + lane;
+    v[t] = __builtin_nontemporal_load(at[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < 32; t++) __builtin_nontemporal_store(v[t] * 0.999f, at[t]);
+}
+
 // the same for the linear weights: random 4-byte read-modify-writes of a zeroed table (32 w_j per example in the step)
 static __global__ void __launch_bounds__(256)
 k_place_probe_w(float* __restrict__ tab, uint64_t n, uint64_t total, uint64_t salt) {
