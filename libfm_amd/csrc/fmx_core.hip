@@ -293,7 +293,9 @@ static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int 
   };
   std::vector<size_t> refs;                                          // first chunk of every class
   std::vector<std::vector<size_t>> of;                               // chunks per class
-  float base_ms = 0.f;
+  std::vector<size_t> mixed;                                         // chunks that straddle a border between classes: fillers only
+  std::vector<float> alone;                                          // a chunk's time under the probe on its own
+  float slow_ms = 0.f;                                               // ... of a chunk that lies in ONE class (the median of the first eight)
   auto enough = [&](size_t* x, size_t* y) -> bool {                  // two classes with ceil(T/2) and floor(T/2) chunks?
     size_t a = SIZE_MAX, b = SIZE_MAX;
     for (size_t k = 0; k < of.size(); k++) {
@@ -303,40 +305,63 @@ static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int 
     *x = a; *y = b;
     return a != SIZE_MAX && b != SIZE_MAX && of[a].size() >= (T + 1) / 2 && of[b].size() >= T / 2;
   };
-  size_t cx = SIZE_MAX, cy = SIZE_MAX;
-  while (er == hipSuccess && P.hnd.size() < max_pool && !(T >= 2 && enough(&cx, &cy))) {
+  auto take = [&]() -> hipError_t {                                  // one more chunk: created, mapped into the pool's range, written, timed alone
     const size_t i = P.hnd.size();
     hipMemGenericAllocationHandle_t hd;
-    er = hipMemCreate(&hd, CH, &prop, 0);
-    if (er != hipSuccess) { if (i >= T) { (void)hipGetLastError(); er = hipSuccess; } break; }   // memory ran out: go with the pool in hand
-    P.hnd.push_back(hd); P.mapped.push_back(0); P.cls.push_back(-1);
-    er = hipMemMap((char*)P.va + i * CH, CH, 0, hd, 0);
-    if (er != hipSuccess) break;
+    hipError_t e = hipMemCreate(&hd, CH, &prop, 0);
+    if (e != hipSuccess) return e;
+    P.hnd.push_back(hd); P.mapped.push_back(0); P.cls.push_back(-1); alone.push_back(0.f);
+    e = hipMemMap((char*)P.va + i * CH, CH, 0, hd, 0);
+    if (e != hipSuccess) return e;
     P.mapped[i] = 1;
-    er = hipMemSetAccess((char*)P.va + i * CH, CH, &acc, 1);
-    if (er == hipSuccess) er = hipMemsetAsync(chunk_va(i), 0, CH, h->stream);   // (a never-written allocation answers a probe in microseconds)
-    if (er != hipSuccess) break;
-    if (refs.empty()) {
-      er = pair_ms(i, i, &base_ms);                                  // the one-chunk rate
-      refs.push_back(i); of.push_back({i}); P.cls[i] = 0;
-      continue;
-    }
-    for (size_t k = 0; k < refs.size() && P.cls[i] < 0 && er == hipSuccess; k++) {
+    e = hipMemSetAccess((char*)P.va + i * CH, CH, &acc, 1);
+    if (e == hipSuccess) e = hipMemsetAsync(chunk_va(i), 0, CH, h->stream);   // (a never-written allocation answers a probe in microseconds)
+    if (e == hipSuccess) e = pair_ms(i, i, &alone[i]);
+    return e;
+  };
+  // same class <=> the two chunks together are no faster than one alone; a chunk that is faster ALONE straddles a border (it must not
+  // become a reference: everything would look like its class)
+  auto classify = [&](size_t i) -> hipError_t {
+    if (alone[i] < 0.95f * slow_ms) { P.cls[i] = -2; mixed.push_back(i); return hipSuccess; }
+    for (size_t k = 0; k < refs.size() && P.cls[i] < 0; k++) {
       float ms = 0.f;
-      er = pair_ms(refs[k], i, &ms);
-      if (er == hipSuccess && ms > base_ms / 1.08f) { P.cls[i] = (int)k; of[k].push_back(i); }   // no faster together: same class
+      const hipError_t e = pair_ms(refs[k], i, &ms);
+      if (e != hipSuccess) return e;
+      if (ms > slow_ms / 1.08f) { P.cls[i] = (int)k; of[k].push_back(i); }
     }
-    if (er == hipSuccess && P.cls[i] < 0) { refs.push_back(i); of.push_back({i}); P.cls[i] = (int)refs.size() - 1; }
+    if (P.cls[i] < 0) { refs.push_back(i); of.push_back({i}); P.cls[i] = (int)refs.size() - 1; }
+    return hipSuccess;
+  };
+  size_t cx = SIZE_MAX, cy = SIZE_MAX;
+  bool out_of_memory = false;
+  const size_t first = std::min<size_t>(8, max_pool);
+  while (er == hipSuccess && P.hnd.size() < first) er = take();
+  if (er == hipSuccess) {
+    std::vector<float> srt(alone);
+    std::sort(srt.begin(), srt.end());
+    slow_ms = srt[srt.size() / 2];
+    for (size_t i = 0; i < first && er == hipSuccess; i++) er = classify(i);
   }
+  while (er == hipSuccess && P.hnd.size() < max_pool && !enough(&cx, &cy)) {
+    er = take();
+    if (er != hipSuccess) {                                           // memory ran out: go with the pool in hand
+      if (P.hnd.size() > T) { (void)hipGetLastError(); er = hipSuccess; out_of_memory = true;
+        if (!P.mapped.back()) { (void)hipMemRelease(P.hnd.back()); P.hnd.pop_back(); P.mapped.pop_back(); P.cls.pop_back(); alone.pop_back(); } }
+      break;
+    }
+    er = classify(P.hnd.size() - 1);
+  }
+  (void)out_of_memory;
   if (er != hipSuccess || P.hnd.size() < T) { arena_pool_release(P); return er != hipSuccess ? er : hipErrorOutOfMemory; }
   (void)enough(&cx, &cy);
   // the arena's chunks in mapping order: the two best-stocked classes alternately; when the second runs short (pool bound reached)
   // its chunks are spread evenly among the first's, then any other class fills up
   std::vector<size_t> pick;
   {
-    std::vector<size_t> X = of[cx], Y = (cy != SIZE_MAX) ? of[cy] : std::vector<size_t>();
+    std::vector<size_t> X = (cx != SIZE_MAX) ? of[cx] : std::vector<size_t>(), Y = (cy != SIZE_MAX) ? of[cy] : std::vector<size_t>();
     std::vector<size_t> rest;
     for (size_t k = 0; k < of.size(); k++) if (k != cx && k != cy) rest.insert(rest.end(), of[k].begin(), of[k].end());
+    rest.insert(rest.end(), mixed.begin(), mixed.end());
     const size_t ny = std::min<size_t>(Y.size(), T / 2);
     size_t nx = std::min<size_t>(X.size(), T - ny);
     size_t ix = 0, iy = 0, ir = 0, err_acc = 0;
