@@ -257,7 +257,8 @@ def bench_group(args, capi, criteo):
         raise SystemExit("--gpus %d but %d HIP device(s) visible (--same-device puts every shard on device 0)" % (N, ndev))
     lr, regv = 0.01, 0.001
     hs = [capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
-                      device=0 if args.same_device else r, shard_rank=r, shard_world=N, shard_hash=1) for r in range(N)]
+                      device=0 if args.same_device else r, shard_rank=r, shard_world=N, shard_hash=1, place_candidates=args.place)
+          for r in range(N)]
     for h in hs:
         h.init_params(0.0, 0.01, 1)
         h.synth_rows(0, 123, 0, args.rows, args.nnz, capi.SYNTH_CRITEO if criteo else capi.SYNTH_UNIFORM)
@@ -298,6 +299,8 @@ def bench_group(args, capi, criteo):
                    "pipeline": bool(args.pipeline), "sharding": "feature-id hash (permutation) over %d shards" % N,
                    "driver": "one process, fmx_group (%s)" % ("loopback: all shards on device 0" if args.same_device else "RCCL, one communicator per device"),
                    "batch_rule": {"batch": int(st.batch_used), "collision_mass": round(st.collision_mass, 6), "gain": round(st.batch_gain, 4)},
+                   "placement": [{"method": pi.method, "chunks": pi.chunks, "per_class": [pi.per_class[0], pi.per_class[1]], "pool_probed": pi.pool}
+                                 for pi in (h.place_info() for h in hs)],
                    "device": info.device_name.decode(), "arch": info.arch.decode()},
         "roofline": {"bound": "hbm", "kernel": "k_rowsums + update (whole step, per GPU)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "v_read_frac": v_read_fraction(value, args.k, args.nnz, N),

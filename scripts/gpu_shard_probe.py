@@ -1,6 +1,6 @@
 """probe: the per-rank compute side of the P-way feature-sharded step on ONE GPU (no exchange): rank 0 of `world`
 holds n/world features and sees every example restricted to them (about nnz/world entries per example)."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 sys.path.insert(0, "/root/repo")
 import torch
@@ -14,7 +14,9 @@ if len(sys.argv) > 4:
 chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 worlds = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8, 4, 2, 1]
 for world in worlds:
-    h = capi.Handle(n, k, True, True, 1, 0, 0, 0.001, 0.01, -1, 1, shard_rank=0, shard_world=world)
+    h = capi.Handle(n, k, True, True, 1, 0, 0, 0.001, 0.01, -1, 1, shard_rank=0, shard_world=world,
+                    place_candidates=int(os.environ.get("PLACE", "0")))     # fmx_config::place_candidates (1 = plain allocations)
+    pi = h.place_info()
     h.init_params(0, 0.01, 1)
     h.synth_rows(0, 123, 0, rows, nnz)
     kp1 = h.info().k_padded + 1
@@ -34,6 +36,7 @@ for world in worlds:
     for which in ("both", "partial", "finish"):
         epoch(which); st.synchronize(); h.synchronize()
         t0 = time.perf_counter(); epoch(which); st.synchronize(); h.synchronize(); res[which] = time.perf_counter() - t0
+    print("placement %d (%d chunks, %d + %d)  " % (pi.method, pi.chunks, pi.per_class[0], pi.per_class[1]), end="")
     print("k=%d B=%d chunk=%d " % (k, B, chunk) + "world=%d: gather+update %.1f Mex/s (gather alone %.1f, update alone %.1f) per rank"
           % (world, rows / res["both"] / 1e6, rows / res["partial"] / 1e6, rows / res["finish"] / 1e6), flush=True)
     h.close()
