@@ -37,7 +37,7 @@ def ragged_real(n_features, n_rows, max_nnz, seed, classification=True, empty_ev
     wtrue = rng.normal(0, 1, n_features)
     ids, vals, y = [], [], []
     for r in range(n_rows):
-        z = int(rng.integers(1, max_nnz + 1))
+        z = min(int(rng.integers(1, max_nnz + 1)), n_features)      # (distinct ids: a row cannot be longer than the feature space)
         if empty_every and r % empty_every == empty_every - 1:
             z = 0
         if duplicates and z >= 2:

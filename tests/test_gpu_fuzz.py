@@ -10,6 +10,16 @@ import datagen
 pytestmark = pytest.mark.gpu
 
 
+def _seeds(default):
+    """the seeds of a fuzz test: range(default), or FMX_FUZZ_SEEDS=lo:hi for a soak run over other seeds (scripts/gpu_fuzz_soak.sh)"""
+    import os
+    v = os.environ.get("FMX_FUZZ_SEEDS")
+    if not v:
+        return range(default)
+    lo, hi = (int(x) for x in v.split(":"))
+    return range(lo, hi)
+
+
 def _split(monkeypatch, v):
     """fmx_config::als_split_min for the handles created from here on: "0" = never split (fused draws), "1" = every level, n = levels of >= n entries"""
     from libfm_amd import capi as _c
@@ -25,6 +35,22 @@ def capi():
     if capi.load().fmx_device_count() == 0:
         pytest.fail("gpu-marked test without a HIP device")
     return capi
+
+
+def _floor(run):
+    """What no fp32 implementation of a rule can be held below on a given case: the oracle's own response to a change of the initial
+    factors by ONE fp32 rounding (6e-8 relative).  On well-conditioned cases it is far below the base tolerances; random step sizes on
+    random data also produce iterations that amplify a rounding a million-fold or leave the numbers altogether (soak runs over other
+    seeds, scripts/gpu_fuzz_soak.sh, hit a few per thousand) -- those are compared at eight times their own floor, or skipped.
+    run(pert) -> tuple of arrays / scalars; returns (floors | None, run(0))."""
+    a, b = run(0.0), run(6e-8)
+    out = []
+    for x, y in zip(a, b):
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        if not (np.isfinite(x).all() and np.isfinite(y).all()):
+            return None, a
+        out.append(float(np.abs(x - y).max()) if x.size else 0.0)
+    return out, a
 
 
 def _case(seed, als=False):
@@ -53,7 +79,7 @@ def _case(seed, als=False):
     return n, k, task, data, batch, chunk, lag, k0, k1
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _seeds(24))
 def test_random_shape_every_form_of_the_rule(capi, oracle, seed):
     n, k, task, (ent, rp, y), batch, chunk, lag, k0, k1 = _case(seed)
     lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
@@ -62,28 +88,34 @@ def test_random_shape_every_form_of_the_rule(capi, oracle, seed):
     forms = [(capi.APPLY_FUSED, 0, lag), (capi.APPLY_DEFAULT, capi.FLAG_BIAS_LAG, lag), (capi.APPLY_SEGMENTED, capi.FLAG_BIAS_LAG, lag),
              (capi.APPLY_DEFAULT, 0, 0)]                       # the last one: bias recurrence coupled exactly (no lag)
     for apply_, flags, lg in forms:
-        m = oracle.Model(n, k, k0, k1, 0.001 if k0 else 0.0, 0.002, 0.004)
-        m.v[:] = oracle.init_values(21 + seed, n, k, 0.05)
-        if k1:
-            m.w[:] = oracle.init_values(22 + seed, n, 1, 0.05)[0]
-        m.w0 = 0.02 if k0 else 0.0
-        h = capi.Handle(n, k, k0, k1, task, m.reg0, m.regw, m.regv, lr, lo, hi)
-        h.set_params(m.w0, m.w, m.v)
+        def run(pert):
+            m = oracle.Model(n, k, k0, k1, 0.001 if k0 else 0.0, 0.002, 0.004)
+            m.v[:] = oracle.init_values(21 + seed, n, k, 0.05) * (1.0 + pert)
+            if k1:
+                m.w[:] = oracle.init_values(22 + seed, n, 1, 0.05)[0]
+            m.w0 = 0.02 if k0 else 0.0
+            for _ in range(2):
+                oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=lg)
+            return m.w0, m.w.copy(), m.v.copy(), oracle.predict_raw(m, d)
+        what = "seed %d form (%d,%d,%d): n=%d k=%d batch=%d chunk=%d" % (seed, apply_, flags, lg, n, k, batch, chunk)
+        fl, (o_w0, o_w, o_v, o_p) = _floor(run)
+        if fl is None or fl[2] > 1e-3:
+            assert seed >= 24, what + ": a case of the suite's own seeds must be well-conditioned"
+            continue                                            # the iteration amplifies roundings beyond comparison (soak seeds only)
+        h = capi.Handle(n, k, k0, k1, task, 0.001 if k0 else 0.0, 0.002, 0.004, lr, lo, hi)
+        h.set_params(0.02 if k0 else 0.0, oracle.init_values(22 + seed, n, 1, 0.05)[0] if k1 else np.zeros(n), oracle.init_values(21 + seed, n, k, 0.05))
         h.upload_rows(0, ent, rp, y)
         for _ in range(2):
             h.sgd_epoch(0, capi.SGD_MINIBATCH, apply_, batch, chunk, flags, lg)
-            oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=lg)
         w0, w, v = h.get_params()
-        what = "seed %d form (%d,%d,%d): n=%d k=%d batch=%d chunk=%d" % (seed, apply_, flags, lg, n, k, batch, chunk)
-        assert np.isfinite(m.v).all() and np.abs(m.v).max() < 50, what
-        assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5, what
-        np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5, err_msg=what)
-        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5, err_msg=what)
-        np.testing.assert_allclose(h.predict(0, d.n_rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5, err_msg=what)
+        assert abs(w0 - o_w0) <= RTOL * abs(o_w0) + 1e-5 + 8 * fl[0], what
+        np.testing.assert_allclose(w, o_w, rtol=RTOL, atol=2e-5 + 8 * fl[1], err_msg=what)
+        np.testing.assert_allclose(v, o_v, rtol=RTOL, atol=2e-5 + 8 * fl[2], err_msg=what)
+        np.testing.assert_allclose(h.predict(0, d.n_rows), o_p, rtol=RTOL, atol=5e-5 + 8 * fl[3], err_msg=what)
         h.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _seeds(12))
 def test_random_shape_als_both_draw_forms(capi, oracle, seed, monkeypatch):
     """fm_learn_mcmc without sampling on random shapes: fused draws and the split step (forced for every level) against the oracle."""
     from libfm_amd import learner as L
@@ -125,7 +157,7 @@ def test_random_shape_als_both_draw_forms(capi, oracle, seed, monkeypatch):
         l.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_random_shape_feature_shards(capi, oracle, seed):
     """2 .. 5 loopback shards (hashed or plain ownership, exact or pipelined schedule) on random shapes against the oracle's rule."""
     n, k, task, (ent, rp, y), batch, chunk, lag, k0, k1 = _case(200 + seed)
@@ -134,33 +166,41 @@ def test_random_shape_feature_shards(capi, oracle, seed):
     lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
     lr = 0.003
     d = oracle.Data(ent, rp, y)
-    m = oracle.Model(n, k, k0, k1, 0.001 if k0 else 0.0, 0.002, 0.004)
-    m.v[:] = oracle.init_values(41 + seed, n, k, 0.05)
-    if k1:
-        m.w[:] = oracle.init_values(42 + seed, n, 1, 0.05)[0]
-    m.w0 = 0.02 if k0 else 0.0
-    hs = [capi.Handle(n, k, k0, k1, task, m.reg0, m.regw, m.regv, lr, lo, hi, device=0, shard_rank=r, shard_world=world,
+    w_init = oracle.init_values(42 + seed, n, 1, 0.05)[0] if k1 else np.zeros(n)
+
+    def run(pert):
+        m = oracle.Model(n, k, k0, k1, 0.001 if k0 else 0.0, 0.002, 0.004)
+        m.v[:] = oracle.init_values(41 + seed, n, k, 0.05) * (1.0 + pert)
+        m.w[:] = w_init
+        m.w0 = 0.02 if k0 else 0.0
+        for _ in range(2):
+            oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=lag, pipelined=pipeline)
+        return m.w0, m.w.copy(), m.v.copy(), oracle.predict_raw(m, d)
+    what = "seed %d: world=%d hash=%d pipeline=%d n=%d k=%d batch=%d chunk=%d lag=%d" % (seed, world, shard_hash, pipeline, n, k, batch, chunk, lag)
+    fl, (o_w0, o_w, o_v, o_p) = _floor(run)
+    if fl is None or fl[2] > 1e-3:
+        assert seed >= 8, what + ": a case of the suite's own seeds must be well-conditioned"
+        pytest.skip("the iteration amplifies roundings beyond comparison")
+    hs = [capi.Handle(n, k, k0, k1, task, 0.001 if k0 else 0.0, 0.002, 0.004, lr, lo, hi, device=0, shard_rank=r, shard_world=world,
                       shard_hash=shard_hash) for r in range(world)]
     for h in hs:
-        h.set_params(m.w0, m.w, m.v)
+        h.set_params(0.02 if k0 else 0.0, w_init, oracle.init_values(41 + seed, n, k, 0.05))
         h.upload_rows(0, ent, rp, y)
     grp = capi.Group(hs)
     flags = capi.FLAG_BIAS_LAG | (capi.FLAG_PIPELINE if pipeline else 0)
     for _ in range(2):
         grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, chunk, flags, lag)
-        oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=lag, pipelined=pipeline)
     w0, w, v = grp.get_params()
-    what = "seed %d: world=%d hash=%d pipeline=%d n=%d k=%d batch=%d chunk=%d lag=%d" % (seed, world, shard_hash, pipeline, n, k, batch, chunk, lag)
-    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5, what
-    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5, err_msg=what)
-    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5, err_msg=what)
-    np.testing.assert_allclose(grp.predict(0, d.n_rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5, err_msg=what)
+    assert abs(w0 - o_w0) <= RTOL * abs(o_w0) + 1e-5 + 8 * fl[0], what
+    np.testing.assert_allclose(w, o_w, rtol=RTOL, atol=2e-5 + 8 * fl[1], err_msg=what)
+    np.testing.assert_allclose(v, o_v, rtol=RTOL, atol=2e-5 + 8 * fl[2], err_msg=what)
+    np.testing.assert_allclose(grp.predict(0, d.n_rows), o_p, rtol=RTOL, atol=5e-5 + 8 * fl[3], err_msg=what)
     grp.close()
     for h in hs:
         h.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", _seeds(10))
 def test_random_shape_sgda_both_forms(capi, oracle, seed):
     """fm_learn_sgd_element_adapt_reg on random shapes (odd factor counts, 1 .. 4 attribute groups): the device learner in
     reference order against the restated online loop, the batch form against its restated rule."""
@@ -178,10 +218,18 @@ def test_random_shape_sgda_both_forms(capi, oracle, seed):
     va_rp = rp[:n_val + 1].copy()
     tr, va = oracle.Data(ent, rp, y), oracle.Data(ent[:int(va_rp[-1])].copy(), va_rp, y[:n_val].copy())
     for b in (None, batch):                                    # None: the reference's online order
-        m = oracle.Model(n, k, True, True, 0.0, 0.0, 0.0)
-        m.v[:] = oracle.init_values(51 + seed, n, k, 0.05)
+        def run(pert):
+            m = oracle.Model(n, k, True, True, 0.0, 0.0, 0.0)
+            m.v[:] = oracle.init_values(51 + seed, n, k, 0.05) * (1.0 + pert)
+            st = oracle.sgda_learn(m, tr, va, task, lr, lo, hi, 3, group, batch=b, w0_chunk=chunk)
+            return m.w0, m.w.copy(), m.v.copy(), np.array(st.reg_w, dtype=np.float64), np.array(st.reg_v, dtype=np.float64)[:, :k]
+        what = "seed %d batch %s: n=%d k=%d task=%d G=%d chunk=%d" % (seed, b, n, k, task, G, chunk)
+        fl, (o_w0, o_w, o_v, o_rw, o_rv) = _floor(run)
+        if fl is None or fl[2] > 1e-3:
+            assert seed >= 10, what + ": a case of the suite's own seeds must be well-conditioned"
+            continue                                            # the iteration amplifies roundings beyond comparison (soak seeds only)
         h = capi.Handle(n, k, True, True, task, 0.0, 0.0, 0.0, lr, lo, hi)
-        h.set_params(m.w0, m.w, m.v)
+        h.set_params(0.0, np.zeros(n), oracle.init_values(51 + seed, n, k, 0.05))
         if group is not None:
             h.set_groups(group)
         h.upload_rows(0, tr.entries, tr.row_ptr, tr.target)
@@ -196,13 +244,11 @@ def test_random_shape_sgda_both_forms(capi, oracle, seed):
         w0, w, v = h.get_params()
         h.sgda_end()
         h.close()
-        st = oracle.sgda_learn(m, tr, va, task, lr, lo, hi, 3, group, batch=b, w0_chunk=chunk)
-        what = "seed %d batch %s: n=%d k=%d task=%d G=%d chunk=%d" % (seed, b, n, k, task, G, chunk)
-        assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 2e-5, what
-        np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5, err_msg=what)
-        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5, err_msg=what)
-        np.testing.assert_allclose(reg[:, 0], st.reg_w, rtol=1e-3, atol=1e-7, err_msg=what)
-        np.testing.assert_allclose(reg[:, 1:1 + k], st.reg_v[:, :k], rtol=1e-3, atol=1e-7, err_msg=what)
+        assert abs(w0 - o_w0) <= RTOL * abs(o_w0) + 2e-5 + 8 * fl[0], what
+        np.testing.assert_allclose(w, o_w, rtol=RTOL, atol=2e-5 + 8 * fl[1], err_msg=what)
+        np.testing.assert_allclose(v, o_v, rtol=RTOL, atol=2e-5 + 8 * fl[2], err_msg=what)
+        np.testing.assert_allclose(reg[:, 0], o_rw, rtol=1e-3, atol=1e-7 + 8 * fl[3], err_msg=what)
+        np.testing.assert_allclose(reg[:, 1:1 + k], o_rv, rtol=1e-3, atol=1e-7 + 8 * fl[4], err_msg=what)
 
 
 @pytest.mark.parametrize("k,seed", [(1, 0), (5, 1), (33, 2), (70, 3)])
