@@ -216,6 +216,9 @@ typedef struct fmx_place_info {
   double   seconds;         /* host time of the placement */
 } fmx_place_info;
 int fmx_get_place_info(fmx_handle h, fmx_place_info *out);
+/* the layout of that arena for tables of v_bytes and w_bytes (host arithmetic, no device needed): V at offset 0, w at *w_offset --
+ * centred on a chunk boundary --, *chunks chunks of *chunk_bytes */
+int fmx_place_layout(uint64_t v_bytes, uint64_t w_bytes, uint64_t *chunk_bytes, uint32_t *chunks, uint64_t *w_offset);
 /* text of the last error on this handle (h may be NULL: last creation error). Never NULL. */
 const char *fmx_last_error(fmx_handle h);
 int fmx_abi_version(void);

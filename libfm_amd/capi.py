@@ -136,6 +136,7 @@ SYMBOLS = [
     ("fmx_sgd_epoch", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(EpochStats)]),
     ("fmx_sgd_batch_info", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(BatchInfo)]),
     ("fmx_get_place_info", C.c_int, [H, C.POINTER(PlaceInfo)]),
+    ("fmx_place_layout", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     ("fmx_partial_floats", C.c_int, [H, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("fmx_sgd_partial", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("fmx_sgd_finish", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(SgdOpts), C.c_void_p]),
@@ -462,6 +463,15 @@ class Handle:
 
     def synchronize(self):
         self._chk(self.lib.fmx_synchronize(self.h))
+
+
+def place_layout(v_bytes, w_bytes):
+    """(chunk_bytes, chunks, w_offset) of the arena fmx_create builds for tables of these sizes (fmx_place_layout; host arithmetic)"""
+    ch, t, off = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+    rc = load().fmx_place_layout(int(v_bytes), int(w_bytes), C.byref(ch), C.byref(t), C.byref(off))
+    if rc != 0:
+        raise FmxError(rc, "fmx_place_layout: bad argument")
+    return ch.value, t.value, off.value
 
 
 def shard_place(n, world, shard_hash, ids):

@@ -252,10 +252,9 @@ void arena_free(fmx_handle h) {
 static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int bound_tables, float** V_out, float** w_out) {
   const auto t_start = std::chrono::steady_clock::now();
   const size_t CH = ARENA_CHUNK;
-  const size_t w_half = ((w_bytes / 2) + 255) & ~(size_t)255;
-  const size_t boundary = (v_bytes + w_half + CH - 1) / CH;                       // w straddles the start of chunk `boundary`
-  const size_t w_off = boundary * CH - w_half;
-  const uint32_t T = (uint32_t)((w_off + w_bytes + CH - 1) / CH);
+  uint64_t ch_ = 0, w_off_ = 0; uint32_t T = 0;
+  if (fmx_place_layout(v_bytes, w_bytes, &ch_, &T, &w_off_) != FMX_OK) return hipErrorInvalidValue;
+  const size_t w_off = (size_t)w_off_;
   size_t free_b = 0, total_b = 0;
   hipError_t er = hipMemGetInfo(&free_b, &total_b);
   if (er != hipSuccess) return er;
@@ -539,6 +538,20 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   CREATE_CHK(hipStreamSynchronize(h->stream));
 #undef CREATE_CHK
   *out = h;
+  return FMX_OK;
+}
+
+// the arena of a model: V from offset 0, w centred on the first chunk boundary behind it (half of it in either chunk: chunks alternate
+// between two memory classes, so w lies in both like V does), whole chunks.  Host arithmetic, no device needed.
+int fmx_place_layout(uint64_t v_bytes, uint64_t w_bytes, uint64_t* chunk_bytes, uint32_t* chunks, uint64_t* w_offset) {
+  if (!chunk_bytes || !chunks || !w_offset || v_bytes == 0) return FMX_E_ARG;
+  const uint64_t CH = ARENA_CHUNK;
+  const uint64_t w_half = ((w_bytes / 2) + 255) & ~(uint64_t)255;                // (256-byte granules: w stays aligned like V's rows)
+  const uint64_t boundary = (v_bytes + w_half + CH - 1) / CH;                     // w straddles the start of chunk `boundary`
+  const uint64_t w_off = boundary * CH - w_half;
+  const uint64_t T = (w_off + w_bytes + CH - 1) / CH;
+  if (T > 0xFFFFFFFFull) return FMX_E_ARG;
+  *chunk_bytes = CH; *chunks = (uint32_t)T; *w_offset = w_off;
   return FMX_OK;
 }
 
