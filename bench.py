@@ -363,13 +363,17 @@ def main():
     ap.add_argument("--no-bias-lag", action="store_true", help="minibatch: keep the w0 recurrence on the critical path (exact chunk coupling)")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--place", type=int, default=0,
-                    help="fmx_config::place_candidates: 0 = the library's placement (big tables: chunks of two memory classes), 1 = first fit")
+    ap.add_argument("--place", type=int, default=None,
+                    help="fmx_config::place_candidates: 0 = the library's placement (big tables: chunks of two memory classes), 1 = plain "
+                         "allocations.  Default 0; with --same-device 1 (shards SHARING a device are the one case measured faster out of "
+                         "plain allocations, 123 vs 113 M ex/s at two shards: profiles/r03_place_two_shards_one_device.txt)")
     ap.add_argument("--traffic", type=float, default=None,
                     help="PMC HBM bytes per launch of the dominant kernel (default: profiles/traffic.json if it matches)")
     ap.add_argument("--no-cpu-reference", dest="cpu_reference", action="store_false",
                     help="skip timing the REAL reference code (oracle/_ref/ref_harness time_sgd, largest n it can allocate)")
     args = ap.parse_args()
+    if args.place is None:
+        args.place = 1 if (args.same_device and args.gpus > 1) else 0
 
     criteo = args.workload == "criteo"
     if args.n is None:
