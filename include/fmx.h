@@ -72,7 +72,7 @@ enum {
                               batch is gathered, used and written back by its own example's wavefront (V read once, written
                               once -- the algorithmic minimum); the features that occur more than once in the batch are
                               finished by the segmented kernel from the factor sums their examples leave behind.
-                              Deterministic, bit-for-bit the result of FMX_APPLY_SEGMENTED with the same bias_lag. */
+                              Deterministic; the result of FMX_APPLY_SEGMENTED with the same bias_lag to fp32 rounding. */
 };
 
 typedef struct fmx_context_s *fmx_handle;

@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fmx {
 
@@ -538,38 +539,39 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
   if (lane == 0) *w0_out = w0;
 }
 
-// k_scan4: the same recurrence with FOUR wavefronts (one per SIMD of a CU, each <= 32 VGPRs so that they still fit next
-// to a chip-filling gather).  Inside a micro-chunk every multiplier uses the same bias, so the wavefronts evaluate a
-// PART-example piece of the chunk in parallel (PART / 4 examples each) and only the piece's sum crosses wavefronts
-// (LDS, one barrier per piece).  PART = 1024 for chunks that are multiples of 1024 (4 examples per lane), PART = 256 for
-// the other multiples of 256 -- the default chunk -- (1 example per lane: the per-chunk chain LDS read -> exp -> rcp ->
-// DPP reduction is a quarter as long as in one wavefront, paid for with one LDS exchange).  A single wavefront is
-// VALU-bound at ~1.1 ns per example, which capped a P = 8 rank and short-row shapes at ~0.9 G examples/s.
-// Summation order: per wavefront as in k_scan, then the four partial sums in wavefront order (deterministic).
-constexpr int SCAN4_BUFS = 4;                                   // tile buffers of k_scan4: tiles t+1 .. t+3 in flight while t is scanned
-constexpr size_t SCAN4_LDS_BYTES = (size_t)(SCAN4_BUFS * 2 * SCAN_TILE + 8) * sizeof(float);   // 128 KiB + the partial sums
-template <bool WRITE_MULT, int TASK, int PART>
+// tile pipeline of k_scan1: four buffers of the 160 KiB LDS, tiles t+1 .. t+3 in flight while t is scanned.  Under a chip-filling
+// gather an LDS-DMA tile takes ~10-15 us to land while 4096 examples are scanned in a few, so one tile of prefetch left the recurrence
+// DMA-latency-bound (its kernel time tracked the gather's, ~1 ms per 262 144 examples against 0.3 ms alone).
+constexpr int SCAN4_BUFS = 4;
+constexpr size_t SCAN4_LDS_BYTES = (size_t)(SCAN4_BUFS * 2 * SCAN_TILE + 8) * sizeof(float);   // 128 KiB (+ 32 spare bytes)
+// k_scan1: the recurrence for micro-chunks that are multiples of 256 examples.  Four wavefronts fetch a quarter of every tile by LDS-DMA
+// (three tiles in flight); ONE wavefront evaluates the chain -- a piece of 256 examples is four CONTIGUOUS examples per lane (one
+// ds_read_b128 per array), so nothing crosses wavefronts.  (Round 2's k_scan4 spread a piece over the four wavefronts: its LDS exchange +
+// barrier per piece cost more than the three quarters of the transcendentals they took off the chain -- 329 vs 174 ns per micro-chunk of 256,
+// profiles/r03_scan_chain.txt; removed.)  What does not depend on the
+// bias is taken off the chain: the operands of piece p+1 are read while piece p is reduced, and for classification the multiplier
+//   -y (1 - 1/(1 + e^(-y p))) = -y / (1 + e^(y p)) = -y / (1 + 2^(a w0 + b)),  a = y log2(e), b = a rest   (fm_learn_sgd_element.h:61-65)
+// leaves fma -> v_exp -> add -> v_rcp -> fma on the chain, a and b prepared ahead.  Summation order: the four examples of a lane
+// pairwise, the lanes by DPP, pieces of a chunk in order (deterministic; not bit-identical to k_scan / k_scan4, which no result is
+// compared with bit by bit across kernels).  60 VGPRs: fits next to five 85-VGPR gather wavefronts per SIMD.
+template <bool WRITE_MULT, int TASK, bool CH256>                  // CH256: the micro-chunk IS 256 examples (the default): every piece ends one
 __global__ void __launch_bounds__(256)
-k_scan4(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
+k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
         Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
-  // Under a chip-filling gather an LDS-DMA tile takes ~10-15 us to land while 4096 examples are scanned in ~4 us, so one
-  // tile of prefetch left the recurrence DMA-latency-bound (its kernel time tracked the gather's, ~1 ms per 262 144
-  // examples against 0.3 ms alone).  Four buffers of the 160 KiB LDS keep three tiles in flight.
   extern __shared__ float scan_lds[];
-  float* const s_part = scan_lds + SCAN4_BUFS * 2 * SCAN_TILE;   // [2][4]
   __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the tile arithmetic in SGPRs
-  constexpr uint32_t QT = SCAN_TILE / 4;                         // every wavefront fetches its quarter of a tile
-  constexpr uint32_t D = SCAN4_BUFS - 1;                         // prefetch distance in tiles
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr uint32_t QT = SCAN_TILE / 4;
+  constexpr uint32_t D = SCAN4_BUFS - 1;
   const uint32_t n_tiles = (n_rows + SCAN_TILE - 1) / SCAN_TILE;
-  // a full tile whose arrays are 16-byte aligned costs exactly 8 DMA instructions per wavefront (4 per array): only
-  // then can "tile t has landed" be expressed as an s_waitcnt with the later tiles still in flight
   const bool aligned = ((((uintptr_t)rest) | ((uintptr_t)target)) & 15u) == 0;
-  double w0 = *w0_in;
-  float w0s = h.k0 ? (float)w0 : 0.f;
+  const bool mult16 = WRITE_MULT && ((((uintptr_t)mult) & 15u) == 0);
+  double w0 = *w0_in;                                            // (launched only for models with a bias: h.k0)
+  float w0s = (float)w0;
+  const double reg0_d = (double)h.reg0, neg_lr_d = -(double)h.lr;
   float chunk_acc = 0.f;
-  uint32_t chunk_pos = 0, pb = 0;
+  uint32_t chunk_pos = 0;
   auto fetch = [&](uint32_t t) {
     const uint32_t buf = t % SCAN4_BUFS;
     const uint32_t t0 = t * SCAN_TILE;
@@ -579,45 +581,83 @@ k_scan4(const float* __restrict__ rest, const float* __restrict__ target, uint32
     if (q0 < tn) scan_fetch_tile(rest + t0 + q0, target + t0 + q0, min(QT, tn - q0), sr + q0, sr + SCAN_TILE + q0, lane);
   };
   for (uint32_t t = 0; t < D && t < n_tiles; t++) fetch(t);
+  constexpr float LOG2E = 1.4426950408889634f;
   for (uint32_t t = 0; t < n_tiles; t++) {
     const uint32_t t0 = t * SCAN_TILE;
     const uint32_t tn = min((uint32_t)SCAN_TILE, n_rows - t0);
-    // tiles t+1 .. last_issued are in flight behind tile t; all of them standard (full + aligned) -> counted wait
     const uint32_t last_issued = min(t + D - 1, n_tiles - 1);
     const uint32_t later = last_issued - t;
     const bool counted = !WRITE_MULT && aligned && ((uint64_t)(last_issued + 1) * SCAN_TILE <= n_rows);
     if (counted && later == 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (counted && later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's quarter of tile t has landed
-    __syncthreads();                                             // ... and everybody else's; tile t-1 is no longer read
-    if (t + D < n_tiles) fetch(t + D);                           // into the buffer of tile t-1
+    else                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                             // tile t has landed for everybody; tile t-1 is no longer read
+    if (t + D < n_tiles) fetch(t + D);
+    if (wv != 0) continue;                                       // (the other wavefronts only fetch)
     const float* sr = scan_lds + (t % SCAN4_BUFS) * 2 * SCAN_TILE;
     const float* sy = sr + SCAN_TILE;
-    for (uint32_t c0 = 0; c0 < tn; c0 += PART) {
-      const uint32_t n_here = min((uint32_t)PART, tn - c0);
-      const uint32_t q = c0 + wv * (PART / 4) + lane;
-      float acc = 0.f;
-      if constexpr (PART == 1024) {                           // two pairs, not four at once: <= 32 VGPRs (placement, see k_scan)
-#pragma unroll 1
-        for (uint32_t u = 0; u < 256; u += 128) {
-          float m0 = 0.f, m1 = 0.f;
-          if (q + u < tn)      { m0 = multiplier_task<TASK>(h, w0s + sr[q + u], sy[q + u]);           if (WRITE_MULT) mult[t0 + q + u] = m0; }
-          if (q + u + 64 < tn) { m1 = multiplier_task<TASK>(h, w0s + sr[q + u + 64], sy[q + u + 64]); if (WRITE_MULT) mult[t0 + q + u + 64] = m1; }
-          acc += m0 + m1;
+    // One piece = 256 examples, four contiguous ones per lane.  The chain is bound by the NUMBER of instructions one wavefront issues per
+    // piece (scripts/ubench/scan_chain.hip: 300 ns per piece for classification AND for regression before this was counted), so a full
+    // piece carries no bounds masks, the loop is unrolled (no copies between the operand sets of consecutive pieces) and everything
+    // that does not depend on the bias (LDS reads, a = y log2 e, b = a rest) is free to move ahead of the previous piece's reduction.
+    float4 rN = *reinterpret_cast<const float4*>(sr + 4 * lane), yN = *reinterpret_cast<const float4*>(sy + 4 * lane);
+    // tnc: the tile's length as the piece sees it -- the literal SCAN_TILE on the unrolled path of a full tile, so that "is there a next
+    // piece" and "is this piece full" fold away and the 16 pieces are ONE basic block the scheduler can move the LDS reads through
+    auto piece = [&](uint32_t c0, uint32_t tnc, auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      const uint32_t q = c0 + 4 * lane;
+      const float4 r4 = rN, y4 = yN;
+      if (c0 + 256 < tnc) {                                      // the next piece's operands leave LDS while this one is evaluated
+        rN = *reinterpret_cast<const float4*>(sr + q + 256);
+        yN = *reinterpret_cast<const float4*>(sy + q + 256);
+      }
+      float rr[4] = {r4.x, r4.y, r4.z, r4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+      if constexpr (!FULL) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const bool ok = q + j < tnc; rr[j] = ok ? rr[j] : 0.f; yy[j] = ok ? yy[j] : 0.f; }
+      }
+      float m[4];
+      if constexpr (TASK == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float a = LOG2E * yy[j];                          // (y = 0 past the end: a = b = 0, multiplier -0 * 1/2 = 0)
+          const float u = __builtin_amdgcn_exp2f(fmaf(a, w0s, a * rr[j]));
+          m[j] = -yy[j] * __builtin_amdgcn_rcpf(1.0f + u);
         }
       } else {
-        if (q < tn) { acc = multiplier_task<TASK>(h, w0s + sr[q], sy[q]); if (WRITE_MULT) mult[t0 + q] = acc; }
+        const float gs = h.sgda ? 2.0f : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float pc = fmaxf(h.min_target, fminf(h.max_target, w0s + rr[j]));
+          m[j] = gs * (pc - yy[j]);
+          if constexpr (!FULL) m[j] = (q + j < tnc) ? m[j] : 0.f;
+        }
       }
-      const float part = wave_sum_dpp(acc);
-      if (lane == 0) s_part[pb * 4 + wv] = part;
-      __syncthreads();
-      chunk_acc += (s_part[pb * 4] + s_part[pb * 4 + 1]) + (s_part[pb * 4 + 2] + s_part[pb * 4 + 3]);
-      pb ^= 1u;
+      if constexpr (WRITE_MULT) {
+        if (mult16 && (FULL || q + 4 <= tnc)) *reinterpret_cast<float4*>(mult + t0 + q) = make_float4(m[0], m[1], m[2], m[3]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) if (FULL || q + j < tnc) mult[t0 + q + j] = m[j];
+        }
+      }
+      const float tot = wave_sum_dpp((m[0] + m[1]) + (m[2] + m[3]));
+      const uint32_t n_here = FULL ? 256u : min(256u, tnc - c0);
+      chunk_acc += tot;
       chunk_pos += n_here;
-      if (chunk_pos == chunk || t0 + c0 + n_here == n_rows) {
-        if (h.k0) w0 -= (double)h.lr * ((double)chunk_acc + (double)chunk_pos * (double)h.reg0 * (double)w0s);
-        w0s = h.k0 ? (float)w0 : 0.f;
+      if ((CH256 && FULL) || chunk_pos == chunk || t0 + c0 + n_here == n_rows) {
+        double term = (double)chunk_acc;
+        term = fma((double)chunk_pos * reg0_d, (double)w0s, term);
+        w0 = fma(neg_lr_d, term, w0);
+        w0s = (float)w0;
         chunk_acc = 0.f; chunk_pos = 0;
+      }
+    };
+    if (tn == SCAN_TILE) {
+#pragma unroll
+      for (uint32_t c0 = 0; c0 < SCAN_TILE; c0 += 256) piece(c0, (uint32_t)SCAN_TILE, std::true_type());
+    } else {
+      for (uint32_t c0 = 0; c0 < tn; c0 += 256) {
+        if (c0 + 256 <= tn) piece(c0, tn, std::true_type()); else piece(c0, tn, std::false_type());
       }
     }
   }

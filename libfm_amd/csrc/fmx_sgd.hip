@@ -248,22 +248,22 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
   if (hy.k0) {
     const double* wi = w0_in ? w0_in : h->w0;
     double* wo = w0_out ? w0_out : h->w0;
-    // micro-chunks that are multiples of 256 examples: four wavefronts share a chunk (k_scan4, pieces of 1024 or 256
-    // examples), else one wavefront
-    // (batches of a few thousand rows: the 128 KiB-LDS workgroup costs more to place than the recurrence takes)
-    const int part = (n_rows <= 8192u || (chunk % 256u) != 0) ? 0 : ((chunk % 1024u) == 0 ? 1024 : 256);
+    // micro-chunks that are multiples of 256 examples: k_scan1 (one wavefront on the chain, four contiguous examples per lane, a 128 KiB
+    // tile pipeline fed by the workgroup's four wavefronts); else, and for
+    // batches of a few thousand rows (the 128 KiB-LDS workgroup costs more to place than the recurrence takes): one plain wavefront
+    const bool tiled = n_rows > 8192u && (chunk % 256u) == 0;
     // (function attributes are per-device state: the 128 KiB dynamic-LDS limit is raised once per handle, not per process)
-#define FMX_SCAN4(WM, TK, PT) do { auto kf = k_scan4<WM, TK, PT>;                                                                \
+#define FMX_SCAN1(WM, TK, C256) do { auto kf = k_scan1<WM, TK, C256>;                                                              \
       if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCAN4_LDS_BYTES)); h->lds_raised.insert((const void*)kf); } \
       hipLaunchKernelGGL(kf, dim3(1), dim3(256), SCAN4_LDS_BYTES, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
 #define FMX_SCAN(WM, TK) do { \
-      if (part == 1024)     FMX_SCAN4(WM, TK, 1024); \
-      else if (part == 256) FMX_SCAN4(WM, TK, 256); \
-      else                  hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
+      if (tiled && chunk == 256u) FMX_SCAN1(WM, TK, true); \
+      else if (tiled)             FMX_SCAN1(WM, TK, false); \
+      else                        hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
     if (hy.task == 0) { if (mult) FMX_SCAN(true, 0); else FMX_SCAN(false, 0); }
     else              { if (mult) FMX_SCAN(true, 1); else FMX_SCAN(false, 1); }
 #undef FMX_SCAN
-#undef FMX_SCAN4
+#undef FMX_SCAN1
   } else if (mult) {
     hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
                        (const double*)nullptr, mult);
