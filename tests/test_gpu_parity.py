@@ -143,9 +143,9 @@ def test_minibatch_matches_restated_rule(capi, oracle, name, batch, chunk):
                                                   (0, 9001, 4096, False), (1, 1500, 1024, True),
                                                   (1, 5000, 256, False), (0, 3000, 768, True), (1, 9001, 256, True), (0, 700, 512, False)])
 def test_minibatch_kilo_chunks(capi, oracle, task, batch, chunk, lag):
-    """micro-chunks that are multiples of 256 examples take the four-wavefront recurrence kernel (k_scan4, pieces of
-    1024 or 256 examples): ragged batch tails, batches that are not multiples of the tile (4096) or of the chunk, both
-    tasks, with / without bias-lag."""
+    """micro-chunks that are multiples of 256 examples: ragged batch tails, batches that are not multiples of the tile (4096) or of the
+    chunk, both tasks, with / without bias-lag (batches of more than 8192 rows take the tiled recurrence kernel k_scan1, the others the
+    plain one-wavefront k_scan)."""
     n, nnz, rows, k = 4000, 6, 9001, 8
     ent, row_ptr, y = datagen.onehot_fields(n - n % nnz, nnz, rows, seed=17 + batch, classification=(task == 1))
     if task == 0:
@@ -162,6 +162,38 @@ def test_minibatch_kilo_chunks(capi, oracle, task, batch, chunk, lag):
     for _ in range(2):
         h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, chunk, capi.FLAG_BIAS_LAG if lag else 0)
         oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, lag)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    h.close()
+
+
+@pytest.mark.parametrize("task", [0, 1])
+@pytest.mark.parametrize("batch,chunk", [(9001, 256), (8193, 256), (12325, 512), (20000, 1024), (16384, 256), (9001, 768)])
+@pytest.mark.parametrize("apply_name", ["fused", "segmented"])
+def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name):
+    """k_scan1 (batches of more than 8192 rows, micro-chunks of multiples of 256): the default micro-chunk (every piece ends one) and longer
+    ones, whole and ragged tiles, a batch that starts at a row that is not a multiple of four (the dword path of the tile fetch), with the
+    multipliers written (two-pass form) and without (one-pass form), regression with the clamp active and classification -- against the
+    oracle's rule."""
+    n, nnz, rows, k = 3996, 6, 20000, 8
+    ent, row_ptr, y = datagen.onehot_fields(n, nnz, rows, seed=400 + batch + chunk, classification=(task == 1))
+    if task == 0:
+        y = (y * 0.5 + 0.1).astype(np.float32)
+    d = oracle.Data(ent, row_ptr, y)
+    lo, hi = (float(np.quantile(y, 0.1)), float(np.quantile(y, 0.9))) if task == 0 else (-1.0, 1.0)     # (regression: the clamp bites)
+    lr = min(0.01, 0.9 / (chunk * (1.0 if task == 0 else 0.25)))
+    m = oracle.Model(n, k, True, True, 0.002, 0.001, 0.003)
+    m.v[:] = oracle.init_values(5, n, k, 0.05)
+    m.w0 = 0.05
+    h = capi.Handle(n, k, True, True, task, 0.002, 0.001, 0.003, lr, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, row_ptr, y)
+    ap = capi.APPLY_FUSED if apply_name == "fused" else capi.APPLY_SEGMENTED
+    for _ in range(2):
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, ap, batch, chunk, capi.FLAG_BIAS_LAG, 1)
+        oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=1)
     w0, w, v = h.get_params()
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
