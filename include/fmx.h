@@ -353,6 +353,10 @@ int fmx_evaluate(fmx_handle h, int slot, fmx_eval *out);
 /* ---- fm_learn_sgd_element::learn, one epoch (fm_learn_sgd_element.h:56-67) -------------------- */
 int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_epoch_stats *stats);
 int fmx_sgd_batch_info(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_batch_info *out);
+/* the same decision as host arithmetic (no device needed): the batch fmx_sgd_epoch runs with for rows of the given collision mass --
+ * requested != 0: that batch, with its gain and status; requested == 0: 262144 cut to the largest power of two (never below 32) with
+ * learn_rate * curvature * batch * collision_mass <= 1 (curvature 1 for regression, 1/4 for classification) */
+int fmx_batch_rule(int32_t task, double learn_rate, double collision_mass, uint32_t requested, fmx_batch_info *out);
 
 /* ---- minibatch step split at the exchange point, for one-process-per-GPU drivers --------------
  * partial: floats per batch = fmx_partial_floats(h, batch): [batch][KP] partial factor sums followed by

@@ -136,6 +136,7 @@ SYMBOLS = [
     ("fmx_sgd_epoch", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(EpochStats)]),
     ("fmx_sgd_batch_info", C.c_int, [H, C.c_int, C.POINTER(SgdOpts), C.POINTER(BatchInfo)]),
     ("fmx_get_place_info", C.c_int, [H, C.POINTER(PlaceInfo)]),
+    ("fmx_batch_rule", C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_uint32, C.POINTER(BatchInfo)]),
     ("fmx_place_layout", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     ("fmx_partial_floats", C.c_int, [H, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("fmx_sgd_partial", C.c_int, [H, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
@@ -463,6 +464,15 @@ class Handle:
 
     def synchronize(self):
         self._chk(self.lib.fmx_synchronize(self.h))
+
+
+def batch_rule(task, learn_rate, collision_mass, requested=0):
+    """the batch fmx_sgd_epoch would run with for rows of this collision mass (fmx_batch_rule; host arithmetic)"""
+    bi = BatchInfo()
+    rc = load().fmx_batch_rule(int(task), float(learn_rate), float(collision_mass), int(requested), C.byref(bi))
+    if rc != 0:
+        raise FmxError(rc, "fmx_batch_rule: bad argument")
+    return bi
 
 
 def place_layout(v_bytes, w_bytes):

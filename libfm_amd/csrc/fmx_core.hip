@@ -555,6 +555,14 @@ int fmx_place_layout(uint64_t v_bytes, uint64_t w_bytes, uint64_t* chunk_bytes, 
   return FMX_OK;
 }
 
+int fmx_batch_rule(int32_t task, double learn_rate, double collision_mass, uint32_t requested, fmx_batch_info* out) {
+  if (!out || (task != FMX_TASK_REGRESSION && task != FMX_TASK_CLASSIFICATION) || !(learn_rate >= 0.0) || !(collision_mass >= 0.0)) return FMX_E_ARG;
+  fmx_config c = {};
+  c.task = task; c.learn_rate = learn_rate;
+  resolve_batch(c, collision_mass, requested, FMX_DEFAULT_BATCH, 1.0, out);
+  return FMX_OK;
+}
+
 int fmx_get_place_info(fmx_handle h, fmx_place_info* out) {
   if (!h || !out) return FMX_E_ARG;
   const Arena& A = h->arena;
