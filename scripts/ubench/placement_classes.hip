@@ -49,6 +49,26 @@ static double probe(const std::vector<uint32_t>& list, uint32_t n_ex = 1u << 18,
   }
   return (double)n_ex * 32 * 512 / (sum / rounds * 1e-3) / 1e12;
 }
+// a STREAM instead of random rows: copy `n4` float4 from src to dst (grid-stride, non-temporal) -- does a sequential read + write mix care
+// which classes the two arrays lie in?
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_copy(const f4* __restrict__ src, f4* __restrict__ dst, uint64_t n4) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
+    const f4 v = __builtin_nontemporal_load(src + i);
+    __builtin_nontemporal_store(v, dst + i);
+  }
+}
+static double copy_rate(const float* src, float* dst, size_t bytes) {
+  double sum = 0;
+  for (int r = 0; r < 4; r++) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_copy, dim3(256 * 16), dim3(256), 0, 0, (const f4*)src, (f4*)dst, (uint64_t)(bytes / 16));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r) sum += ms;
+  }
+  return 2.0 * bytes / (sum / 3 * 1e-3) / 1e12;                          // TB/s read + written
+}
 int main(int argc, char** argv) {
   const size_t leave = (size_t)(argc > 1 ? atoi(argv[1]) : 12) << 30;
   const size_t chunk = (size_t)(argc > 2 ? atoi(argv[2]) : 1024) << 20;
@@ -139,6 +159,15 @@ int main(int argc, char** argv) {
   }
   if (of.size() >= 6) compose({1, 1, 1, 1, 1, 1}, "A .. F evenly");
   if (of.size() >= 8) compose({1, 1, 1, 1, 1, 1, 1, 1}, "A .. H evenly");
+  // streams: a 1 GB chunk copied into another chunk of the same class / of another class
+  if (of.size() >= 2 && of[0].size() >= 3 && of[1].size() >= 2) {
+    auto at = [&](uint32_t c) { return tab + (size_t)c * rows_per_chunk * 64; };
+    printf("copy of one chunk (1 GB read + 1 GB written), TB/s:  A -> A %.2f   A -> B %.2f   B -> B %.2f   B -> A %.2f\n",
+           copy_rate(at(of[0][0]), at(of[0][1]), chunk), copy_rate(at(of[0][0]), at(of[1][0]), chunk),
+           copy_rate(at(of[1][0]), at(of[1][1]), chunk), copy_rate(at(of[1][1]), at(of[0][2]), chunk));
+    // the same amount of data as two half-chunk copies running over chunks of both classes at once: [A lo -> A' lo] then interleaved is not
+    // expressible with one kernel; instead: source = first halves of an A and a B chunk alternately is what a balanced buffer looks like
+  }
   { std::vector<uint32_t> all(got); for (int c = 0; c < got; c++) all[c] = (uint32_t)c; printf("%-40s %.2f TB/s\n", "the whole pool", probe(all, 1u << 20, 3)); }
   return 0;
 }
