@@ -129,6 +129,89 @@ def cpu_reference(n, k, nnz, rows):
                       % (rows, n_ref, n, k, nnz), "seconds": round(d["seconds"], 3), "host_cores": os.cpu_count() or 1}
 
 
+def cpu_reference_rows(h, n, k, rows, lr=0.01, regv=0.001, stdev=0.01):
+    """cpu_baseline for rows only the device generator has (Criteo-shaped, BASELINE configs[2]): the first `rows` rows of slot 0 are
+    copied back and the REAL reference's fm_model::predict + fm_SGD (oracle/_ref/ref_harness time_sgd_rows) runs over them once on one
+    core.  Needs k * n < 2^32 (matrix.h:167-169): 3.3e7 x 64 fits."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(exe) or k * n >= 2 ** 32:
+        return None
+    avail = mem_available_bytes()
+    if avail and (n * k * 8 + n * 8) * 1.2 > avail:
+        return {"error": "host RAM too small for the reference's fp64 model of this workload"}
+    ent, rp, y = h.download_rows(0)
+    rows = min(rows, len(y))
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "rows.bin")
+        with open(path, "wb") as f:
+            np.array([rows, 0], dtype=np.uint32).tofile(f)
+            np.array([int(rp[rows])], dtype=np.uint64).tofile(f)
+            rp[:rows + 1].astype(np.uint64).tofile(f)
+            ent[:int(rp[rows])].tofile(f)
+            y[:rows].astype(np.float32).tofile(f)
+        r = subprocess.run([exe, "time_sgd_rows", path, str(n), str(k), repr(lr), repr(regv), repr(stdev)], capture_output=True, text=True)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-200:]}
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": round(d["examples_per_sec"], 1), "unit": "examples/s", "cores": 1, "kind": "reference",
+            "sample": "the first %d of the step's rows (copied back from the device) through the reference's own fm_model::predict + fm_SGD "
+                      "(oracle/_ref/ref_harness time_sgd_rows), n=%d k=%d, 1 epoch" % (rows, n, k),
+            "seconds": round(d["seconds"], 3), "host_cores": os.cpu_count() or 1}
+
+
+def run_sgd_config(capi, name, n, k, nnz, rows, criteo, steps, warmup, with_cpu, cpu_rows):
+    """a BASELINE config other than the headline's on one GPU, same one-pass batch rule, the library's batch (fmx_sgd_opts::batch = 0):
+    one step = one epoch over `rows` rows; returns the figure as a dict (an extra key of the line, never `value`)"""
+    lr, regv = 0.01, 0.001
+    h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0, device=0)
+    h.init_params(0.0, 0.01, 1)
+    h.synth_rows(0, 123, 0, rows, nnz, capi.SYNTH_CRITEO if criteo else capi.SYNTH_UNIFORM)
+    cpu = None
+    if with_cpu:
+        cpu = cpu_reference_rows(h, n, k, cpu_rows, lr, regv) if criteo else cpu_reference(n, k, nnz, cpu_rows)
+    setup = 0.0
+    for _ in range(warmup):
+        setup += h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, 2).setup_seconds
+    h.synchronize()
+    dev, launches, deferred, st = 0.0, 0, 0, None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, capi.FLAG_TIME_MAIN_KERNEL, 2)
+        dev += st.main_kernel_seconds
+        launches += st.main_kernel_launches
+        deferred += st.deferred_features
+    h.synchronize()
+    elapsed = time.perf_counter() - t0
+    value = steps * rows / elapsed
+    per_ex = algorithmic_bytes(k, nnz, "fused")
+    per_launch = min(int(st.batch_used), rows)
+    avg = dev / max(launches, 1)
+    achieved = per_ex * per_launch / avg / 1e9
+    info = h.info()
+    out = {"metric": "SGD training examples/sec at k=%d, nnz=%d, %.1e feat (%s)" % (k, nnz, n, name),
+           "value": round(value, 1), "unit": "examples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": "f32", "data": "synthetic",
+           "config": {"workload": ("Criteo-shaped (13 fields of <= 100 ids + %d Zipf(1.05) fields)" % (nnz - 13) if criteo else "synthetic one-hot fields")
+                                  + " n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g" % (n, k, nnz, rows, lr, regv),
+                      "mode": "fused", "bias_lag": 2,
+                      "batch_rule": {"batch": int(st.batch_used), "collision_mass": round(st.collision_mass, 6), "gain": round(st.batch_gain, 4),
+                                     "cut": bool(st.status & capi.STAT_BATCH_CUT)},
+                      "device": info.device_name.decode()},
+           "roofline": {"bound": "hbm", "kernel": "k_fused<%d,EXACT> + deferred features, per batch" % info.k_padded,
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "v_read_frac": v_read_fraction(per_launch / avg, k, nnz), "traffic": None,
+                        "bytes_per_example": per_ex, "examples_per_launch": per_launch, "avg_launch_ms": round(avg * 1e3, 4),
+                        "launches": launches, "deferred_features_per_example": round(deferred / (steps * rows), 4),
+                        "launch_time": "epoch HIP-event time / batches"},
+           "one_time_setup_seconds": round(setup, 4),
+           "cpu_baseline": cpu}
+    h.close()
+    return out
+
+
 def committed_traffic(kernel, examples_per_launch, k, nnz):
     """HBM bytes per launch from the committed PMC profile (profiles/traffic.json), if it is for this kernel/shape."""
     try:
@@ -153,7 +236,7 @@ def als_bytes_per_sweep(n_rows, nnz_total, n_seen, k):
     return fam + loadq + eterms + n_rows * 36
 
 
-def cpu_reference_mcmc(method, k, nnz, rows=150000, n=1500000):
+def cpu_reference_mcmc(method, k, nnz, rows=150000, n=1500000, gpu_leg="n=1e7 and 100x the rows"):
     """cpu_baseline of the als / mcmc figures: the REAL reference's fm_learn_mcmc::learn (src/libfm/src/fm_learn_mcmc.h:430-641,
     1160-1201 through fm_learn_mcmc_simultaneous.h:56-270; oracle/_ref/ref_harness als | mcmc), one thread, ONE iteration on a
     bounded sample of the same synthetic rows (fewer rows and features than the GPU leg: the reference needs ~27 ns per entry and
@@ -182,11 +265,11 @@ def cpu_reference_mcmc(method, k, nnz, rows=150000, n=1500000):
     t = json.loads(line[-1])
     return {"value": round(t["rows"] * t["iters"] / t["learn_seconds"], 1), "unit": "examples/s", "cores": 1, "kind": "reference",
             "sample": "1 iteration of the reference's fm_learn_mcmc (%s) over %d synthetic rows, n=%d k=%d nnz=%d (oracle/_ref/ref_harness %s); "
-                      "the GPU leg runs n=1e7 and 100x the rows" % ("do_sample" if method == "mcmc" else "ALS", t["rows"], n, k, nnz, method),
+                      "the GPU leg runs %s" % ("do_sample" if method == "mcmc" else "ALS", t["rows"], n, k, nnz, method, gpu_leg),
             "seconds": round(t["learn_seconds"], 3), "host_cores": os.cpu_count() or 1}
 
 
-def run_als(capi, method, n, k, nnz, rows, steps, warmup, with_cpu):
+def run_als(capi, method, n, k, nnz, rows, steps, warmup, with_cpu, cpu_kw=None):
     """one step = one sweep (fmx_als_sweep) over `rows` examples, one GPU; returns the figure as a dict"""
     sample = method == "mcmc"
     h = capi.Handle(n, k, True, True, capi.TASK_REGRESSION, 0.0, 1.0, 10.0, 0.0, -1.0, 1.0, device=0)
@@ -222,7 +305,7 @@ def run_als(capi, method, n, k, nnz, rows, steps, warmup, with_cpu):
                         "note": "bound by the fabric's random-request rate, not by bytes: the column sums gather one 16-byte {e,q} "
                                 "per entry at 48 G requests/s (55 G/s is what a random 4..16-byte read gets on this part, "
                                 "scripts/ubench/w_gather); the update runs as a row-ordered stream (DESIGN.md section 4b)"},
-           "cpu_baseline": cpu_reference_mcmc(method, k, nnz) if with_cpu else None}
+           "cpu_baseline": cpu_reference_mcmc(method, k, nnz, **(cpu_kw or {})) if with_cpu else None}
     h.als_end()
     h.close()
     return out
@@ -450,6 +533,7 @@ def main():
     # Every rank reports whether its binding came up (communicator + a first collective: the shards' shares of the rows' collision
     # mass); if ANY rank failed, all of them fall back to the torch-driven schedule (libfm_amd/distributed.py) instead of dying.
     use_lib = sharded and args.driver == "lib" and args.backend == "nccl"
+    fallback_reason = None
     if use_lib:
         ok, why = 1, ""
         try:
@@ -471,6 +555,7 @@ def main():
         if int(agree.item()) == 0:
             use_lib = False
             args.driver = "torch"
+            fallback_reason = "the library's RCCL binding did not come up on every rank (%s): torch-driven schedule (libfm_amd/distributed.py)" % (why or "another rank failed")
             if ok:
                 h.comm_destroy()
             if rank == 0 or not ok:
@@ -634,6 +719,19 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu_ref if (cpu_ref and "value" in cpu_ref) else cpu,
         }
+        if fallback_reason:
+            out["driver_fallback"] = fallback_reason          # (loud: the line says which driver ran and why, not only stderr)
+        if not sharded and args.mode == "fused" and not criteo:
+            # how far the headline rule ends from the reference's ONLINE loop at this shape (the committed CPU measurement of the oracle's
+            # two loops; asserted with the device in place of the rule by tests/test_gpu_configs.py)
+            try:
+                pv = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_vs_online.json")))
+                if (pv["n"], pv["k"], pv["nnz"], pv["batch"], pv["bias_lag"]) == (args.n, args.k, args.nnz, batch, bias_lag):
+                    out["parity_vs_online"] = {kk: pv[kk] for kk in ("rows", "epochs", "pred_rms", "pred_mean_abs", "pred_max_abs", "w0_abs",
+                                                                     "pred_max_rel_to_rms_without_bias", "v_max_abs", "v_max_rel_to_vmax", "w_max_abs")}
+                    out["parity_vs_online"]["source"] = "profiles/r04_parity_vs_online.json (scripts/cpu_online_vs_rule.py: oracle rule vs oracle online loop, sub-model of the rows' features); the device equals the rule at 1e-4"
+            except (OSError, ValueError, KeyError):
+                pass
         if not sharded and args.mode != "hogwild":
             # outside `value` and outside the timed steps: paid once per (data set, batch size) in the first warm-up step
             out["one_time_setup"] = {"seconds": round(setup_s, 4), "equivalent_steps": round(setup_s / (elapsed / args.steps), 2),
@@ -663,12 +761,29 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and not sharded and not args.no_extras and not criteo and args.mode == "fused":
         # the other two learners north_star names (BASELINE configs[3] / [4] shapes on one GPU): one line each, never `value`
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "cpu_baseline")
         for method in ("als", "mcmc"):
             try:
                 o = run_als(capi, method, 10_000_000, 64, 16, 1 << 22, 2, 1, not args.no_cpu_baseline)
-                out[method] = {kk: o[kk] for kk in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "cpu_baseline")}
+                out[method] = {kk: o[kk] for kk in keep}
             except Exception as exc:                             # a secondary figure must not take the headline down
                 out[method] = {"error": str(exc)[:200]}
+        # the BASELINE configs the headline does not cover, each on one GPU with its own roofline and CPU baseline (round-3 verdict, item 2):
+        #   c2       configs[1]  n = 1e7, k = 32, 16 entries/row, SGD
+        #   criteo   configs[2]  n = 3.3e7, k = 64, 39 entries/row, Criteo-shaped ids: the library cuts the batch (fmx_sgd_opts::batch = 0)
+        #   mcmc_c5  configs[4]  MCMC (Gibbs draws), k = 128, n = 1e8, 16 entries/row -- a 51 GB table on ONE GPU; its CPU baseline is the
+        #            reference's chain at the largest n that keeps the leg inside ~20 s (it draws all n * k coordinates per iteration)
+        legs = (("c2", lambda: run_sgd_config(capi, "BASELINE configs[1]", 10_000_000, 32, 16, 1 << 23, False, 5, 2, not args.no_cpu_baseline, args.cpu_rows)),
+                ("criteo", lambda: run_sgd_config(capi, "BASELINE configs[2], Criteo-shaped ids", 33_000_000, 64, 39, 1 << 20, True, 3, 1, not args.no_cpu_baseline, 100_000)),
+                ("mcmc_c5", lambda: run_als(capi, "mcmc", 100_000_000, 128, 16, 1 << 22, 2, 1, not args.no_cpu_baseline,
+                                            {"rows": 100_000, "n": 1_000_000, "gpu_leg": "n=1e8 (the stock containers stop at k*n < 2^32, i.e. n <= 3.3e7 at k=128, and "
+                                             "the chain draws all n*k coordinates per iteration: n=1e6 keeps this leg near 20 s) and 42x the rows"})))
+        for key, leg in legs:
+            try:
+                o = leg()
+                out[key] = {kk: o[kk] for kk in keep + ("one_time_setup_seconds",) if kk in o}
+            except Exception as exc:
+                out[key] = {"error": str(exc)[:200]}
     if rank == 0:
         # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION): flush it first so that the JSON
         # line is the LAST line on stdout

@@ -139,8 +139,14 @@ typedef struct fmx_sgd_opts {
 #define FMX_FLAG_PIPELINE 4u          /* fmx_group_sgd_epoch: gather the sums of batch b+1 BEFORE the update of batch b lands, so that
                                          their exchange runs under that update (one batch stale; oracle
                                          fmo_sgd_epoch_minibatch_pipelined) */
-#define FMX_FLAG_REJECT_UNSTABLE 8u    /* MINIBATCH with an explicit batch: fail with FMX_E_ARG when learn_rate * curvature * batch * C > 2
-                                         (the batch rule diverges there; tests/test_oracle_stability.py) instead of training */
+#define FMX_FLAG_REJECT_UNSTABLE 8u    /* MINIBATCH: fail with FMX_E_ARG when learn_rate * curvature * batch * C > 2 (the batch rule diverges
+                                         there; tests/test_oracle_stability.py) instead of training -- for an explicit batch, and for batch 0
+                                         when even the library's floor of 32 rows is unstable (rows with C in the hundreds: the message then
+                                         names FMX_SGD_SEQUENTIAL / a lower learn_rate, not "batch 0") */
+#define FMX_FLAG_EVENT_SYNC 16u        /* FMX_APPLY_FUSED at batches >= 32768: order the launch stream and the recurrence's side stream with
+                                         events (four queue packets per batch) instead of the device-side hand-off (bias slots that start as
+                                         "pending" + a completion counter: DESIGN.md section 4).  Same numbers either way; the environment
+                                         variable FMX_HANDOFF=0 at fmx_create selects events for every epoch of the handle */
 #define FMX_FLAG_BIAS_LAG 2u          /* MINIBATCH: the multipliers of a batch use the w0 of the batch START; w0 itself still
                                          advances through the micro-chunk recurrence, which then runs on a side stream
                                          overlapped with the next batch (oracle: fmo_sgd_epoch_minibatch_ex, bias_lag = 1) */
@@ -352,6 +358,9 @@ int fmx_evaluate(fmx_handle h, int slot, fmx_eval *out);
 
 /* ---- fm_learn_sgd_element::learn, one epoch (fm_learn_sgd_element.h:56-67) -------------------- */
 int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_epoch_stats *stats);
+/* On a handle that is one rank of a communicator (fmx_comm_init_rank, one process per GPU) this call is COLLECTIVE the first time it
+ * runs for a slot: the shards' shares of the collision mass are summed over RCCL, so every rank must make it (fmx_sgd_epoch does);
+ * the sum is cached per slot afterwards. */
 int fmx_sgd_batch_info(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_batch_info *out);
 /* the same decision as host arithmetic (no device needed): the batch fmx_sgd_epoch runs with for rows of the given collision mass --
  * requested != 0: that batch, with its gain and status; requested == 0: 262144 cut to the largest power of two (never below 32) with

@@ -18,6 +18,7 @@ FLAG_TIME_MAIN_KERNEL = 1
 FLAG_BIAS_LAG = 2
 FLAG_PIPELINE = 4
 FLAG_REJECT_UNSTABLE = 8
+FLAG_EVENT_SYNC = 16
 STAT_BATCH_CUT, STAT_UNSTABLE = 1, 2
 SYNTH_UNIFORM, SYNTH_CRITEO = 0, 1
 BLOCKS_EXPAND, BLOCKS_KEEP = 0, 1

@@ -315,6 +315,7 @@ int fmx_comm_init_rank(fmx_handle h, const void* id128, int rank, int world) {
   ncclComm_t c = nullptr;
   NCCLCHK(h, R->CommInitRank(&c, world, id, rank));
   h->comm = c;
+  for (auto& sl : h->slots) sl.coll_mass_world = -1.0;               // (summed over THIS communicator on first use)
   return FMX_OK;
 }
 
@@ -325,6 +326,7 @@ int fmx_comm_destroy(fmx_handle h) {
     hipStreamSynchronize(h->stream);
     if (Rccl* R = rccl()) R->CommDestroy((ncclComm_t)h->comm);
     h->comm = nullptr;
+    for (auto& sl : h->slots) sl.coll_mass_world = -1.0;
   }
   return FMX_OK;
 }
@@ -659,7 +661,16 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     for (uint64_t b = 0; b < n_timed; b++) {
       float a = 0, x = 0, u = 0;
       HIPCHK(h0, hipEventElapsedTime(&a, h0->ev_pool[4 * b], h0->ev_pool[4 * b + 1]));
-      HIPCHK(h0, hipEventElapsedTime(&x, h0->ev_pool[4 * b + 1], h0->ev_pool[4 * b + 2]));
+      // exposed exchange = the wait right in front of update(b).  Exact schedule: from the end of the batch's own sums.  Pipelined:
+      // gather(b + 1) is enqueued between update(b - 1) and update(b), so the wait starts where THAT ends (mark 1 of b + 1) -- measured
+      // from mark 1 of b it would contain the whole update of batch b - 1 (round-3 advisor finding)
+      hipEvent_t from = h0->ev_pool[4 * b + 1];
+      if (pipeline) {
+        if (b + 1 < n_timed && b + 1 < n_batch) from = h0->ev_pool[4 * (b + 1) + 1];
+        else if (b > 0) from = h0->ev_pool[4 * (b - 1) + 3];
+      }
+      HIPCHK(h0, hipEventElapsedTime(&x, from, h0->ev_pool[4 * b + 2]));
+      if (x < 0.f) x = 0.f;
       HIPCHK(h0, hipEventElapsedTime(&u, h0->ev_pool[4 * b + 2], h0->ev_pool[4 * b + 3]));
       stats->phase_seconds[0] += a * 1e-3; stats->phase_seconds[1] += x * 1e-3; stats->phase_seconds[2] += u * 1e-3;
     }

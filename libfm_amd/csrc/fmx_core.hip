@@ -172,14 +172,14 @@ int ensure_coll_mass(fmx_handle h, Slot& s) {
                ~Acc() { h->setup_acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{h, std::chrono::steady_clock::now()};
   HIPCHK(h, hipSetDevice(h->device));
   const uint32_t M = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n_local, 1), 1ull << 27);
-  float* hist = nullptr;
-  HIPCHK(h, hipMalloc(&hist, (size_t)M * sizeof(float)));
-  hipError_t er = hipMemsetAsync(hist, 0, (size_t)M * sizeof(float), h->stream);
+  double* hist = nullptr;
+  HIPCHK(h, hipMalloc(&hist, (size_t)M * sizeof(double)));
+  hipError_t er = hipMemsetAsync(hist, 0, (size_t)M * sizeof(double), h->stream);
   if (er == hipSuccess) er = hipMemsetAsync(h->acc, 0, 2 * sizeof(double), h->stream);
   if (er == hipSuccess) {
     hipLaunchKernelGGL(k_coll_hist, dim3((unsigned)std::min<uint64_t>((s.nnz + 255) / 256, 8192)), dim3(256), 0, h->stream, s.ent, s.nnz, M, hist, h->acc + 1);
     hipLaunchKernelGGL(k_coll_sumsq, dim3((unsigned)std::min<uint64_t>(((uint64_t)M + 255) / 256, 4096)), dim3(256), 0, h->stream,
-                       (const float*)hist, M, h->acc);
+                       (const double*)hist, M, h->acc);
     er = hipGetLastError();
   }
   double c[2] = {0.0, 0.0};
@@ -243,7 +243,11 @@ void arena_pool_release(ArenaPool& P) {
 void arena_free(fmx_handle h) {
   Arena& A = h->arena;
   if (!A.va) return;
-  (void)hipMemUnmap(A.va, A.bytes);
+  // chunk by chunk, as mapped: a failing unmap must not keep the other chunks (and the handle's error text says so)
+  for (size_t c = 0; c < A.n_chunks; c++) {
+    const hipError_t e = hipMemUnmap((char*)A.va + c * A.chunk_bytes, A.chunk_bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); h->err = std::string("arena_free: hipMemUnmap failed: ") + hipGetErrorString(e); }
+  }
   (void)hipMemAddressFree(A.va, A.bytes);
   A.va = nullptr; A.bytes = 0; A.n_chunks = 0;
 }
@@ -378,17 +382,18 @@ static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int 
   er = hipMemAddressReserve(&va, (size_t)T * CH, CH, nullptr, 0);
   if (er != hipSuccess) { arena_pool_release(P); return er; }
   er = hipStreamSynchronize(h->stream);
-  uint32_t moved = 0;
-  for (; moved < T && er == hipSuccess; moved++) {
+  uint32_t moved = 0;                                                // chunks mapped into the arena's range so far (counted AFTER a successful map)
+  while (moved < T && er == hipSuccess) {
     const size_t i = pick[moved];
     er = hipMemUnmap((char*)P.va + i * CH, CH);
     if (er != hipSuccess) break;
     P.mapped[i] = 0;
     er = hipMemMap((char*)va + (size_t)moved * CH, CH, 0, P.hnd[i], 0);
+    if (er == hipSuccess) moved++;
   }
   if (er == hipSuccess) er = hipMemSetAccess(va, (size_t)T * CH, &acc, 1);
   if (er != hipSuccess) {
-    if (moved) (void)hipMemUnmap(va, (size_t)moved * CH);
+    for (uint32_t c = 0; c < moved; c++) (void)hipMemUnmap((char*)va + (size_t)c * CH, CH);   // chunk by chunk: exactly what was mapped
     (void)hipMemAddressFree(va, (size_t)T * CH);
     arena_pool_release(P);
     return er;
@@ -526,6 +531,13 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   }
   CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
   CREATE_CHK(hipMalloc(&h->w0_pp, 8 * sizeof(double)));
+  {  // device-side hand-off of the bias (fmx_sgd.hip: sgd_epoch_fused): a counter + an error word, both start at 0
+    CREATE_CHK(hipMalloc(&h->handoff_ctr, 2 * sizeof(unsigned long long)));
+    h->handoff_err = reinterpret_cast<uint32_t*>(h->handoff_ctr + 1);
+    CREATE_CHK(hipMemsetAsync(h->handoff_ctr, 0, 2 * sizeof(unsigned long long), h->stream));
+    const char* e = getenv("FMX_HANDOFF");
+    h->handoff = !(e && e[0] == '0');
+  }
   {  // the side stream runs the one-workgroup bias recurrence next to chip-filling gathers: give it priority so
      // that its workgroup is placed as soon as any CU has room
     int lo = 0, hi = 0;
@@ -584,6 +596,8 @@ int fmx_destroy(fmx_handle h) {
   else { if (h->tb.V) hipFree(h->tb.V); if (h->w_sep) hipFree(h->w_sep); }
   if (h->w0) hipFree(h->w0);
   if (h->w0_pp) hipFree(h->w0_pp);
+  if (h->handoff_ctr) hipFree(h->handoff_ctr);
+  if (h->w0_slots) hipFree(h->w0_slots);
   if (h->stream2) hipStreamDestroy(h->stream2);
   if (h->acc) hipFree(h->acc);
   if (h->partial) hipFree(h->partial);

@@ -33,6 +33,7 @@ struct Slot {
   uint32_t  fixed_nnz = 0;           // != 0: every row holds exactly this many entries (row r starts at r * fixed_nnz)
   bool      used = false;
   double    coll_mass = -1.0;        // collision mass of the rows (ensure_coll_mass); < 0: not computed yet
+  double    coll_mass_world = -1.0;  // one process per GPU: the shards' shares summed over the communicator (one collective per slot)
   // per-batch transposed rows for FMX_APPLY_SEGMENTED (built lazily for one batch size)
   uint32_t  seg_B = 0;
   TEntry*   t_ent = nullptr;
@@ -139,6 +140,14 @@ struct fmx_context_s {
   double*    w0 = nullptr;       // device scalar
   double*    w0_pp = nullptr;    // 8 doubles: ring of bias copies for the overlapped recurrence (hogwild, fused, bias lag)
   hipStream_t stream2 = nullptr; // side stream of the hogwild bias scan
+  // device-side hand-off of the bias between the two streams (one-pass batch rule at large batches; fmx_kernels.h)
+  bool        handoff = true;               // FMX_HANDOFF=0 in the environment of fmx_create: events instead
+  double*     w0_slots = nullptr;           // [w0_slots_cap] bias after every batch of the running epoch
+  uint64_t    w0_slots_cap = 0;
+  unsigned long long* handoff_ctr = nullptr;   // device: batches whose k_fused has completed (monotonic over the handle's life)
+  unsigned long long  handoff_seq = 0;         // host: value of the counter before the running epoch
+  uint32_t*   handoff_err = nullptr;        // device: a wait ran into its bound
+  uint32_t    handoff_err_host = 0;
   int        num_cu = 256;
   double*    acc = nullptr;      // 4 doubles of reduction scratch
   Slot       slots[FMX_MAX_SLOTS];

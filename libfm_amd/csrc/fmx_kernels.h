@@ -272,6 +272,50 @@ __device__ __forceinline__ float multiplier_fast(const Hyper& h, float p, float 
 }
 
 // ----------------------------------------------------------------------------------------------
+// Device-side hand-off between the launch stream and the recurrence's side stream (the one-pass batch rule at large batches).
+// The bias a batch's multipliers use is produced by the one-workgroup recurrence of an EARLIER batch on another stream.  Ordering the
+// two streams with events costs four queue packets per batch (record + wait on either side, ~10 us of idle chip between the launches of
+// a 1 ms batch); here the data itself is the signal:
+//   * the bias slots W[b] (one per batch of the epoch) start as W0_PENDING; the recurrence publishes its result with ONE agent-scope
+//     8-byte store and a reader that still finds the sentinel waits (bounded; a time-out raises the handle's error flag);
+//   * "k_fused of batch b has completed" is a counter the first workgroup of the NEXT launch on the same stream (the deferred-feature
+//     pass of batch b) advances: that launch starts only after k_fused retired (in-order stream), and the recurrence kernel -- resident
+//     on its own stream since the previous one finished -- polls it, then invalidates its caches (agent-scope acquire) and reads rest[].
+// ----------------------------------------------------------------------------------------------
+constexpr unsigned long long W0_PENDING = 0x7FF8DEADBEEF0001ull;       // a quiet NaN no recurrence produces
+constexpr uint32_t HANDOFF_SPINS = 1u << 21;                           // x ~1 us per poll: seconds, then the error flag instead of a hang
+__device__ __forceinline__ unsigned long long handoff_peek(const double* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double handoff_wait(const double* p, unsigned long long u, uint32_t* err) {
+  for (uint32_t t = 0; u == W0_PENDING && t < HANDOFF_SPINS; t++) { __builtin_amdgcn_s_sleep(16); u = handoff_peek(p); }
+  if (u == W0_PENDING) { atomicOr(err, 1u); u = 0ull; }
+  return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ void handoff_publish(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// counter side: the waiter is ONE thread of the recurrence workgroup (the others sit at the barrier behind it)
+struct Handoff { const unsigned long long* ctr; unsigned long long need; uint32_t* err; };
+__device__ __forceinline__ void handoff_wait_counter(const Handoff hw) {
+  if (!hw.ctr) return;
+  if (threadIdx.x == 0) {
+    unsigned long long c = __hip_atomic_load(hw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t t = 0; c < hw.need && t < HANDOFF_SPINS * 4u; t++) { __builtin_amdgcn_s_sleep(32); c = __hip_atomic_load(hw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (c < hw.need) atomicOr(hw.err, 2u);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // what the launch stream wrote before the counter moved
+}
+static __global__ void k_handoff_signal(unsigned long long* ctr, unsigned long long val) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(ctr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __global__ void k_handoff_arm(double* W, uint32_t n) {         // W[1 .. n] = pending
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    reinterpret_cast<unsigned long long*>(W)[1 + i] = W0_PENDING;
+}
+
+// ----------------------------------------------------------------------------------------------
 // pass 1 of a row: the sums of fm_model.h:110-125.
 //   sum[v]  : sum_f for the lane's factors (complete over the row only AFTER subgroup_allsum when EPI>1)
 //   sq      : this lane's share of  sum_f sum_i (v x)^2
@@ -484,9 +528,10 @@ __device__ __forceinline__ void scan_fetch_tile(const float* __restrict__ g_rest
 template <bool WRITE_MULT, int TASK>
 __global__ void __launch_bounds__(64)
 k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
-       Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
+       Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult, const Handoff hw) {
   __shared__ float s_rest[2][SCAN_TILE];
   __shared__ float s_y[2][SCAN_TILE];
+  handoff_wait_counter(hw);
   // as the youngest wavefront on its SIMD it would only get leftover issue slots: raise the priority
   __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = threadIdx.x;
@@ -536,7 +581,7 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
       }
     }
   }
-  if (lane == 0) *w0_out = w0;
+  if (lane == 0) { if (hw.ctr) handoff_publish(w0_out, w0); else *w0_out = w0; }
 }
 
 // tile pipeline of k_scan1: four buffers of the 160 KiB LDS, tiles t+1 .. t+3 in flight while t is scanned.  Under a chip-filling
@@ -557,8 +602,9 @@ constexpr size_t SCAN4_LDS_BYTES = (size_t)(SCAN4_BUFS * 2 * SCAN_TILE + 8) * si
 template <bool WRITE_MULT, int TASK, bool CH256>                  // CH256: the micro-chunk IS 256 examples (the default): every piece ends one
 __global__ void __launch_bounds__(256)
 k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
-        Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult) {
+        Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult, const Handoff hw) {
   extern __shared__ float scan_lds[];
+  handoff_wait_counter(hw);                                        // (device hand-off: resident and polling until its batch's rest[] is complete)
   __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -661,7 +707,7 @@ k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32
       }
     }
   }
-  if (threadIdx.x == 0) *w0_out = w0;
+  if (threadIdx.x == 0) { if (hw.ctr) handoff_publish(w0_out, w0); else *w0_out = w0; }
 }
 
 // no bias: the multipliers are independent of each other
@@ -843,6 +889,7 @@ struct SegWork {
   uint32_t nseg, nseg_batch, batch_nnz;
   const float* S; const float* mult;
   const uint4* cdesc;      // with seg_idx: the listed segments as {feature, first entry, end entry, index} records (nullptr: look them up)
+  unsigned long long* done_ctr; unsigned long long done_val;   // device hand-off: "everything before this launch on its stream has completed"
 };
 // SPW = segments per wavefront-block (<= 64).  64 for the dense form (millions of segments: plenty of wavefronts); 16 for
 // the short list of deferred features (a few 100 000): with 64 the pass ran on ~5 000 wavefronts, each a serial chain of
@@ -1076,6 +1123,7 @@ k_apply_seg_scan(const SegWork sw, const Tab tb, Hyper h, const ScanSmall sc) {
 template <int KP, int U, int SPW>
 __global__ void __launch_bounds__(256)
 k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
+  if (sw.done_ctr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sw.done_ctr, sw.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   for (uint32_t blk = wave0 * (uint32_t)SPW; blk < sw.nseg; blk += nwaves * (uint32_t)SPW) apply_seg_block<KP, U, SPW>(sw, blk, tb, h);
@@ -1113,7 +1161,10 @@ __global__ void __launch_bounds__(256, FMX_FUSED_MIN_WAVES)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
         uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
-        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out, uint32_t fixed_nnz) {
+        const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out, uint32_t fixed_nnz,
+        uint32_t* __restrict__ handoff_err) {
+  // handoff_err != nullptr: *w0_ptr is a hand-off slot (published by the recurrence kernel of an earlier batch on the side stream, possibly
+  // still W0_PENDING): read it past the caches, and wait -- only where the multiplier needs it, behind the row gathers -- if it is not there yet
   // fixed_nnz != 0: every row of the slot holds exactly that many entries (one-hot field data): the entry list of example e starts at
   // (row0 + e) * fixed_nnz and the row_ptr round trip drops out of the chain row_ptr -> entries -> rows (what a small batch consists of)
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
@@ -1121,7 +1172,13 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
   const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  const float w0s = h.k0 ? (float)(*w0_ptr) : 0.f;
+  float w0s = 0.f;
+  unsigned long long w0u = 0ull;
+  bool w0_late = false;                                          // the bias is still to be taken out of w0u (hand-off)
+  if (h.k0) {
+    if (handoff_err) { w0u = handoff_peek(w0_ptr); w0_late = true; }
+    else w0s = (float)(*w0_ptr);
+  }
   for (uint32_t e = wave0; e < n_rows; e += nwaves) {
     const uint64_t a = fixed_nnz ? (row0 + e) * (uint64_t)fixed_nnz : row_ptr[row0 + e];
     const uint32_t size = fixed_nnz ? fixed_nnz : (uint32_t)(row_ptr[row0 + e + 1] - a);
@@ -1136,6 +1193,9 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         en = load_stream8(row + lane);
         if (h.k1) wv = load_w(tb.w + (size_t)en.id * tb.ws);
       }
+      // hand-off: the bias slot was asked for before the entry list, so it is here when the entries are (loads return in order) and leaves
+      // its registers before the row slots fill; a slot that is still pending (never, at bias_lag >= 2) is waited for here
+      if (w0_late) { w0s = (float)handoff_wait(w0_ptr, w0u, handoff_err); w0_late = false; }
       // phase A: issue every gather of the row back-to-back (ids / values are re-broadcast later instead of
       // being kept: with EPI == 1 they are wave-uniform and live in SGPRs for the duration of one use).
       // Every cross-lane broadcast below runs with ALL lanes active (outside the idx < size guards): a ds_bpermute
@@ -1215,6 +1275,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         }
       }
     } else if constexpr (!APPLY) {                             // (APPLY: such a row is deferred as a whole, cm == ~0)
+      if (w0_late) { w0s = (float)handoff_wait(w0_ptr, w0u, handoff_err); w0_late = false; }
       float sum[VEC], sq, lin;
       row_sums<KP, 8>(row, size, tb, h.k1, sum, sq, lin);
 #pragma unroll
@@ -2061,21 +2122,24 @@ k_shard_rows(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
 // hist[id mod M] += |x| per entry (M = table size, or 2^27 buckets for larger tables: folding can only raise C, i.e. cut the batch more)
 // (sumsq: sum over the entries of x^2 -- what a row shares with ITSELF, taken out of the pair statistic afterwards)
 static __global__ void __launch_bounds__(256)
-k_coll_hist(const Entry* __restrict__ ent, uint64_t nnz, uint32_t M, float* __restrict__ hist, double* __restrict__ sumsq) {
+k_coll_hist(const Entry* __restrict__ ent, uint64_t nnz, uint32_t M, double* __restrict__ hist, double* __restrict__ sumsq) {
+  // fp64 buckets (native atomic add on gfx950): an fp32 bucket of unit values stops growing at 2^24 occurrences -- a bias-like column of a
+  // slot of >= 16.7 M rows would then UNDER-estimate C, i.e. the very divergence the cut is there to prevent (round-3 advisor finding);
+  // with 53 bits the sums of the usual 0/1 and small-integer values are exact, so C is also the same from run to run
   double own = 0.0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x) {
     const Entry e = ent[i];
-    unsafeAtomicAdd(hist + (e.id % M), fabsf(e.value));
+    unsafeAtomicAdd(hist + (e.id % M), (double)fabsf(e.value));
     own += (double)e.value * (double)e.value;
   }
   own = wave_sum_d(own);
   if ((threadIdx.x & 63u) == 0 && own != 0.0) unsafeAtomicAdd(sumsq, own);
 }
 static __global__ void __launch_bounds__(256)
-k_coll_sumsq(const float* __restrict__ hist, uint32_t M, double* __restrict__ out) {
+k_coll_sumsq(const double* __restrict__ hist, uint32_t M, double* __restrict__ out) {
   double a = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (uint64_t)gridDim.x * blockDim.x) {
-    const double f = (double)hist[i];
+    const double f = hist[i];
     a += f * f;
   }
   a = wave_sum_d(a);

@@ -33,11 +33,11 @@ template <int KP> uint32_t fused_row_cap_kp(uint32_t max_row) {
 template <int KP, int VAR>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
                     const double* w0_in, float* rest_out, const uint64_t* cmask = nullptr, float* S_out = nullptr,
-                    float* mult_out = nullptr) {
+                    float* mult_out = nullptr, uint32_t* handoff_err = nullptr) {
 #define FMX_LAUNCH_ZR(ZRV)                                                                                  \
   if constexpr (fused_zr_ok<KP>(ZRV)) {                                                                     \
     FMX_LAUNCH_WAVES((k_fused<KP, ZRV, VAR>), n_rows, st, s.ent, s.row_ptr, s.target, row0,                 \
-                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out, s.fixed_nnz); }
+                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out, s.fixed_nnz, handoff_err); }
   switch (fused_zr_select<KP>(s.max_row)) {
     case 8:  FMX_LAUNCH_ZR(8);  break;
     case 16: FMX_LAUNCH_ZR(16); break;
@@ -107,7 +107,10 @@ extern "C++" int sgd_resolve_batch(fmx_handle h, Slot& s, const fmx_sgd_opts* op
     int rc = ensure_coll_mass(h, s);
     if (rc) return rc;
     C = s.coll_mass;
-    if (h->comm && h->cfg.shard_world > 1) { rc = comm_sum_double(h, &C); if (rc) return rc; }   // one process per GPU
+    if (h->comm && h->cfg.shard_world > 1) {                 // one process per GPU: a collective, once per slot (include/fmx.h)
+      if (s.coll_mass_world < 0.0) { rc = comm_sum_double(h, &C); if (rc) return rc; s.coll_mass_world = C; }
+      C = s.coll_mass_world;
+    }
   }
   resolve_batch(h->cfg, C, opts ? opts->batch : 0u, FMX_DEFAULT_BATCH, 1.0, bi);
   return FMX_OK;
@@ -244,7 +247,8 @@ done:
 }
 
 static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
-                       const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr) {
+                       const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr,
+                       const Handoff hw = Handoff{nullptr, 0ull, nullptr}) {
   if (hy.k0) {
     const double* wi = w0_in ? w0_in : h->w0;
     double* wo = w0_out ? w0_out : h->w0;
@@ -255,11 +259,11 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     // (function attributes are per-device state: the 128 KiB dynamic-LDS limit is raised once per handle, not per process)
 #define FMX_SCAN1(WM, TK, C256) do { auto kf = k_scan1<WM, TK, C256>;                                                              \
       if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCAN4_LDS_BYTES)); h->lds_raised.insert((const void*)kf); } \
-      hipLaunchKernelGGL(kf, dim3(1), dim3(256), SCAN4_LDS_BYTES, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
+      hipLaunchKernelGGL(kf, dim3(1), dim3(256), SCAN4_LDS_BYTES, st, rest, target, n_rows, chunk, hy, wi, wo, mult, hw); } while (0)
 #define FMX_SCAN(WM, TK) do { \
       if (tiled && chunk == 256u) FMX_SCAN1(WM, TK, true); \
       else if (tiled)             FMX_SCAN1(WM, TK, false); \
-      else                        hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult); } while (0)
+      else                        hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult, hw); } while (0)
     if (hy.task == 0) { if (mult) FMX_SCAN(true, 0); else FMX_SCAN(false, 0); }
     else              { if (mult) FMX_SCAN(true, 1); else FMX_SCAN(false, 1); }
 #undef FMX_SCAN
@@ -456,17 +460,38 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   int rc = ensure_segments(h, s, B);
   if (rc) return rc;
   const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
-  rc = ensure_scratch(h, (size_t)Bc * 2, (size_t)Bc * d);       // S / mult of two consecutive batches, d rest buffers
+  rc = ensure_scratch(h, (size_t)Bc * 2, (size_t)Bc * (d + 1));       // S / mult of two consecutive batches, d (+ 1: hand-off) rest buffers
   if (rc) return rc;
   const uint64_t n_batch = ((uint64_t)s.n_rows + B - 1) / B;
   // small batches (what the stability cut leaves of data with frequent features): a batch is a few microseconds of work, so
   // the recurrence leaves the side stream and rides in the launch of the deferred features (k_apply_seg_scan) -- no events, two
   // launches per batch.  Same rule, same ring of bias slots: what a batch reads does not depend on which stream wrote it.
   const bool side = B >= 32768u;
-  if (side) while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+  // large batches: the recurrence runs on the side stream.  handoff (default; FMX_HANDOFF=0 at fmx_create goes back to events): the two
+  // streams are ordered by the DATA -- bias slots W[0 .. n_batch] that start as "pending", a counter the deferred-feature launch of a batch
+  // advances (fmx_kernels.h: "Device-side hand-off") -- instead of four event packets per batch; W[i] = the bias after the recurrence of batch
+  // i - 1, k_fused of batch b reads W[max(0, b - d + 1)], the recurrence of batch b reads W[b] and publishes W[b + 1].
+  const bool handoff = side && h->handoff && hy.k0 && !(opts->flags & FMX_FLAG_EVENT_SYNC);
+  double* W = nullptr;
+  unsigned long long hbase = 0;
+  if (handoff) {
+    if (h->w0_slots_cap < n_batch + 1) {
+      if (h->w0_slots) HIPCHK(h, hipFree(h->w0_slots));
+      h->w0_slots = nullptr; h->w0_slots_cap = 0;
+      HIPCHK(h, hipMalloc(&h->w0_slots, (size_t)(n_batch + 1) * sizeof(double)));
+      h->w0_slots_cap = n_batch + 1;
+    }
+    W = h->w0_slots;
+    hbase = h->handoff_seq; h->handoff_seq += n_batch + 1;           // the counter only grows: no reset to order against the side stream
+  }
+  if (side && !handoff) while (h->ev_sync.size() < 2 * n_batch + 1) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
   hipStream_t st = h->stream;
   HIPCHK(h, hipEventRecord(h->ev0, st));                    // do not bill the one-time bucketing to the epoch
   for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (handoff) {
+    hipLaunchKernelGGL(k_handoff_arm, dim3((unsigned)std::min<uint64_t>((n_batch + 255) / 256, 64)), dim3(256), 0, st, W, (uint32_t)n_batch);
+    HIPCHK(h, hipMemcpyAsync(W, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
   auto seg_work = [&](uint64_t b, SegWork* sw) {                 // the deferred features of batch b
     const uint32_t c0 = s.cbatch[(size_t)b], c1 = s.cbatch[(size_t)b + 1];
     const uint32_t s0 = s.batch_seg[(size_t)b], s1 = s.batch_seg[(size_t)b + 1];
@@ -476,19 +501,24 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     sw->S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
     sw->mult = h->mult + (size_t)(b & 1) * Bc;
     sw->cdesc = s.cdesc + c0;
+    sw->done_ctr = nullptr; sw->done_val = 0ull;
   };
   for (uint64_t b = 0; b < n_batch; b++) {
     const uint64_t row0 = b * B;
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
-    float* rest = h->rest + (size_t)(b % d) * Bc;
+    // rest buffers: with events the launch of batch b waits for the recurrence of batch b - d, which was the last reader of buffer b % d;
+    // with the hand-off k_fused writes rest[] BEFORE it asks for that bias, so it takes a buffer whose reader (batch b - d - 1) is known
+    // to be done: every wavefront of the previous launch has consumed its result
+    float* rest = h->rest + (size_t)(handoff ? b % (d + 1) : b % d) * Bc;
     float* S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
     float* mult = h->mult + (size_t)(b & 1) * Bc;
-    if (side && b >= d) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (b - d) + 1], 0));   // recurrence of batch b - d is done
-    const double* w0_in = h->w0_pp + ((b + 1) % d);         // written by the recurrence of batch b - d (initial bias for b < d)
-    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult); });
+    if (side && !handoff && b >= d) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (b - d) + 1], 0));   // recurrence of batch b - d is done
+    const double* w0_in = handoff ? W + (b + 1 >= d ? b + 1 - d : 0)
+                                  : h->w0_pp + ((b + 1) % d);  // written by the recurrence of batch b - d (initial bias for b < d)
+    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, handoff ? h->handoff_err : nullptr); });
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
-    if (side) HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
+    if (side && !handoff) HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
     SegWork sw;                                              // the batch's deferred features
     seg_work(b, &sw);
     *deferred += sw.nseg;
@@ -499,6 +529,8 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply_seg_scan<KP, 8, 1>), dim3(grid), dim3(256), 0, st, sw, h->tb, hy, sc));
       HIPCHK(h, hipGetLastError());
     } else {
+      if (handoff) { sw.done_ctr = h->handoff_ctr; sw.done_val = hbase + b + 1; }
+      if (handoff && !sw.nseg) hipLaunchKernelGGL(k_handoff_signal, dim3(1), dim3(64), 0, st, h->handoff_ctr, hbase + b + 1);
       if (sw.nseg) {
         // segments per wavefront of the deferred-feature pass: 16 (measured best at the bench shape: 8 / 16 / 32 / 64 -> 244.5 / 245.0 /
         // 243.0 / 241.0 M examples/s), fewer when the list is short so that the pass still spreads over the chip
@@ -507,12 +539,26 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
         else                            { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 1>), (uint64_t)sw.nseg, st, sw, h->tb, hy)); }
         HIPCHK(h, hipGetLastError());
       }
-      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * b], 0));
-      rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d));
-      if (rc) return rc;
-      HIPCHK(h, hipEventRecord(h->ev_sync[2 * b + 1], h->stream2));
+      if (handoff) {
+        rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, W + b, W + b + 1,
+                         Handoff{h->handoff_ctr, hbase + b + 1, h->handoff_err});
+        if (rc) return rc;
+      } else {
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_sync[2 * b], 0));
+        rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, nullptr, h->stream2, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d));
+        if (rc) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_sync[2 * b + 1], h->stream2));
+      }
     }
     (*batches)++; (*launches)++;
+  }
+  if (handoff) {                                              // ONE event per epoch: the last recurrence, then the bias goes home
+    if (h->ev_sync.empty()) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }
+    HIPCHK(h, hipEventRecord(h->ev_sync[0], h->stream2));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[0], 0));
+    HIPCHK(h, hipMemcpyAsync(h->w0, W + n_batch, sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(&h->handoff_err_host, h->handoff_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    return FMX_OK;
   }
   if (side) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (n_batch - 1) + 1], 0));
   if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_batch % d), sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -539,9 +585,14 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   if (opts->mode == FMX_SGD_MINIBATCH) {
     rc = sgd_resolve_batch(h, s, opts, &bi);
     if (rc) return rc;
-    if ((opts->flags & FMX_FLAG_REJECT_UNSTABLE) && (bi.status & FMX_STAT_UNSTABLE))
+    if ((opts->flags & FMX_FLAG_REJECT_UNSTABLE) && (bi.status & FMX_STAT_UNSTABLE)) {
+      if (opts->batch == 0)       // the library's own choice is at its floor and still unstable: say THAT, not "let the library choose"
+        return fail(h, FMX_E_ARG, "these rows are too dense for the batch rule: at the smallest batch the library takes (%u rows) learn_rate * "
+                                  "curvature * batch * collision mass = %.3g > 2 (collision mass %.4g) -- lower learn_rate or train with "
+                                  "FMX_SGD_SEQUENTIAL", bi.batch, bi.batch_gain, bi.collision_mass);
       return fail(h, FMX_E_ARG, "batch %u on these rows: learn_rate * curvature * batch * collision mass = %.3g > 2 -- the batch rule "
                                 "diverges (collision mass %.4g; batch 0 lets the library choose)", bi.batch, bi.batch_gain, bi.collision_mass);
+    }
     ropts.batch = bi.batch;
     opts = &ropts;
   } else if (opts->mode == FMX_SGD_HOGWILD) {
@@ -650,6 +701,13 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
+  if (h->handoff_err_host) {                                  // a hand-off wait ran into its bound (never seen; a hang would be worse)
+    const uint32_t e = h->handoff_err_host;
+    h->handoff_err_host = 0;
+    (void)hipMemset(h->handoff_err, 0, sizeof(uint32_t));
+    return fail(h, FMX_E_HIP, "the bias hand-off between the launch stream and the recurrence timed out (flags %u): the parameters of this "
+                              "epoch are not valid; FMX_HANDOFF=0 orders the streams with events instead", e);
+  }
   rc = lag_flush(h);
   if (rc) return rc;
   if (stats) {

@@ -112,7 +112,7 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
  * in step 2 -- inside a micro-chunk every example sees w0 and the hot w_j of the chunk start, p_e = w0 + rest_e with the hot
  * part of rest_e re-evaluated from them; after the chunk w_j -= lr * sum_{e in chunk, j in e}(mult_e * x + regw * w_j)
  * (fm_sgd.h:38-43 per occurrence) -- and step 3 leaves them alone.  Readers that lag the bias (bias_lag) see the hot weights
- * with the same lag.  Everything else (V of all features, w of the others) is the rule above.  GPU: fmx_sgd_opts::hot_count. */
+ * with the same lag.  Everything else (V of all features, w of the others) is the rule above.  An instrument of DESIGN.md section 3a (it shows why the linear weights alone are not enough); no product mode runs it. */
 void fmo_sgd_epoch_minibatch_hot(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                                  double min_target, double max_target,
                                  uint32_t batch, uint32_t w0_chunk, int bias_lag, const uint8_t *hot);

@@ -231,7 +231,7 @@ def sgd_epoch_minibatch(m, d, task, lr, min_target, max_target, batch, w0_chunk,
 
 
 def hot_features(d, n, batch, hot_count):
-    """the hot set of a data set as the library defines it (fmx_sgd_opts::hot_count): features that occur at least hot_count
+    """a hot set for fmo_sgd_epoch_minibatch_hot (an instrument of DESIGN.md section 3a, no product mode): features that occur at least hot_count
     times per batch on average, i.e. count_j * batch >= hot_count * n_rows (batch clipped to the data set)."""
     cnt = np.bincount(d.entries["id"], minlength=n).astype(np.int64)
     b = min(int(batch), d.n_rows) if batch else d.n_rows
@@ -249,6 +249,20 @@ def synth_rows(seed, row0, n_rows, nnz, n):
 def init_values(seed, n, k, stdev):
     """fmo_init_value for every (j, f), vectorised in numpy (bit-identical to the C function)."""
     j = np.arange(n, dtype=np.uint64)[None, :]
+    f = np.arange(k, dtype=np.uint64)[:, None]
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) ^ (j * np.uint64(0x9E3779B97F4A7C15) + f * np.uint64(0xD6E8FEB86659FD93) + np.uint64(0x1234567))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return stdev * (2.0 * u - 1.0) * 1.7320508075688772
+
+
+def init_values_ids(seed, ids, k, stdev):
+    """fmo_init_value(seed, j, f, stdev) for the features `ids` only ([k][len(ids)]): the start values of a SUB-model of a table
+    too large for the host (what fmx_init_params leaves in the rows `ids`, before their rounding to fp32)."""
+    j = np.asarray(ids, dtype=np.uint64)[None, :]
     f = np.arange(k, dtype=np.uint64)[:, None]
     with np.errstate(over="ignore"):
         x = np.uint64(seed) ^ (j * np.uint64(0x9E3779B97F4A7C15) + f * np.uint64(0xD6E8FEB86659FD93) + np.uint64(0x1234567))

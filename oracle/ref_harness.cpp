@@ -22,6 +22,7 @@
 //   ref_harness mcmc <train> <test> <task r|c> <k0> <k1> <k> <iters> <init_stdev> <seed> <out_prefix>
 //   ref_harness time_sgd <n> <k> <nnz> <rows> <seed>        (CPU baseline: reference fm_model::predict + fm_SGD on
 //                                                             the synthetic workload of oracle/fm_oracle.c, 1 thread)
+//   ref_harness time_sgd_rows <rows.bin> <n> <k> <lr> <regv> <init_stdev>   (the same loop over rows from a file)
 // environment: FMX_META=<file>  attribute groups (`-meta`, one group id per line, Data.h:85-97);
 //              FMX_GROUP_REG=w_1,..,w_G,v_1,..,v_G  per-group lambdas for als (the tail of `-regular`, libfm.cpp:353-363)
 //              FMX_RELATIONS=<prefix>[,<prefix>]  block-structured data for als / mcmc (`-relation`, libfm.cpp:172-196)
@@ -127,10 +128,47 @@ static int run_time_sgd(int argc, char** argv) {
   return 0;
 }
 
+// time_sgd_rows <rows.bin> <n> <k> <lr> <regv> <init_stdev>: the same loop over rows handed over in a file (bench.py: the
+// Criteo-shaped rows of BASELINE configs[2], copied back from the device).  File: u32 n_rows, u32 pad, u64 nnz,
+// u64 row_ptr[n_rows + 1], {u32 id; f32 value}[nnz], f32 target[n_rows].
+static int run_time_sgd_rows(int argc, char** argv) {
+  if (argc < 8) { fprintf(stderr, "time_sgd_rows <rows.bin> <n> <k> <lr> <regv> <init_stdev>\n"); return 2; }
+  unsigned long long n = strtoull(argv[3], 0, 10);
+  int k = atoi(argv[4]);
+  const double lr = atof(argv[5]), regv = atof(argv[6]), stdev = atof(argv[7]);
+  if ((unsigned long long)k * n >= (1ULL << 32)) { fprintf(stderr, "k*n >= 2^32: the stock reference cannot allocate this (matrix.h:167-169)\n"); return 3; }
+  FILE* f = fopen(argv[2], "rb");
+  if (!f) { perror(argv[2]); return 2; }
+  uint32_t hdr[2]; uint64_t nnz = 0;
+  if (fread(hdr, 4, 2, f) != 2 || fread(&nnz, 8, 1, f) != 1) { fprintf(stderr, "short file\n"); return 2; }
+  const uint32_t rows = hdr[0];
+  std::vector<uint64_t> rp((size_t)rows + 1); std::vector<fmo_entry> ent(nnz); std::vector<float> y(rows);
+  if (fread(rp.data(), 8, rp.size(), f) != rp.size() || fread(ent.data(), 8, nnz, f) != nnz || fread(y.data(), 4, rows, f) != rows) { fprintf(stderr, "short file\n"); return 2; }
+  fclose(f);
+  fm_model fm;
+  fm.num_attribute = (uint)n; fm.num_factor = k; fm.k0 = true; fm.k1 = true;
+  fm.init_stdev = 0; fm.init_mean = 0;
+  fm.init();
+  fm.regv = regv;
+  for (int q = 0; q < k; q++) for (unsigned long long j = 0; j < n; j += 1) fm.v.value[q][j] = stdev * (((j * 2654435761ULL + q * 40503ULL) & 1023) / 512.0 - 1.0);
+  DVector<double> sum, sum_sqr; sum.setSize(k); sum_sqr.setSize(k);
+  double t0 = wall();
+  for (uint r = 0; r < rows; r++) {
+    sparse_row<FM_FLOAT> row; row.data = (sparse_entry<FM_FLOAT>*)&ent[rp[r]]; row.size = (uint)(rp[r + 1] - rp[r]);
+    double p = fm.predict(row, sum, sum_sqr);
+    double mult = -y[r] * (1.0 - 1.0 / (1.0 + exp(-y[r] * p)));           // fm_learn_sgd_element.h:61-65
+    fm_SGD(&fm, lr, row, mult, sum);
+  }
+  double t1 = wall();
+  printf("{\"rows\": %u, \"seconds\": %.6f, \"examples_per_sec\": %.3f, \"w0\": %.17g}\n", rows, t1 - t0, rows / (t1 - t0), fm.w0);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "see header of ref_harness.cpp\n"); return 2; }
   std::string mode = argv[1];
   if (mode == "time_sgd") return run_time_sgd(argc, argv);
+  if (mode == "time_sgd_rows") return run_time_sgd_rows(argc, argv);
   try {
     int a = 2;
     std::string train_file = argv[a++], test_file = argv[a++], task = argv[a++];

@@ -109,18 +109,21 @@ def test_fused_minibatch_at_the_bench_batch_against_oracle(capi, oracle):
 
 
 def test_fused_minibatch_is_deterministic_at_bench_batch(capi):
-    """two runs of the bench configuration (batch 262 144, bias_lag 2) give bit-identical predictions and bias"""
+    """two runs of the bench configuration (batch 262 144, bias_lag 2) give bit-identical predictions and bias -- and so does a third
+    one that orders the launch stream and the recurrence's side stream with events instead of the device-side hand-off
+    (FMX_FLAG_EVENT_SYNC): the hand-off moves no number"""
     rows = 1 << 20
     sums = []
-    for _ in range(2):
+    for flags in (0, 0, capi.FLAG_EVENT_SYNC):
         h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
         h.init_params(0.0, 0.05, 3)
         h.synth_rows(0, 77, 0, rows, NNZ)
-        st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 262144, 0, 0, 2)
+        for _ in range(2):                                        # (second epoch: the hand-off counter carries on, the slots are re-armed)
+            st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 262144, 0, flags, 2)
         p = h.predict(0, rows)
         sums.append((p.tobytes(), h.get_w0(), st.deferred_features))
         h.close()
-    assert sums[0] == sums[1]
+    assert sums[0] == sums[1] == sums[2]
     assert 0.02 * rows * NNZ < sums[0][2] < 0.06 * rows * NNZ   # ~4 % of the (batch, feature) pairs hold >= 2 occurrences
 
 

@@ -201,6 +201,38 @@ def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name):
     h.close()
 
 
+@pytest.mark.parametrize("task", [0, 1])
+@pytest.mark.parametrize("batch,chunk,lag", [(32768, 256, 2), (32768, 768, 1), (40001, 256, 3), (36000, 1024, 2)])
+@pytest.mark.parametrize("events", [False, True])
+def test_side_stream_recurrence_of_the_one_pass_form(capi, oracle, task, batch, chunk, lag, events):
+    """the one-pass form at batches >= 32 768: the recurrence runs on the side stream WITHOUT writing multipliers (k_scan1<false, ...>: the
+    counted s_waitcnt path of the tile pipeline, ragged last tiles, micro-chunks that are not the default, a short last batch) under
+    both orderings of the two streams -- the device-side hand-off (bias slots + completion counter) and events (FMX_FLAG_EVENT_SYNC) --
+    against the oracle's rule.  (Round-3 advisor: the fused legs of test_tiled_recurrence_kernel stay below 32 768 and never got here.)"""
+    n, nnz, rows, k = 39996, 6, 90001, 8
+    ent, row_ptr, y = datagen.onehot_fields(n, nnz, rows, seed=900 + chunk + lag, classification=(task == 1))
+    if task == 0:
+        y = (y * 0.5 + 0.1).astype(np.float32)
+    d = oracle.Data(ent, row_ptr, y)
+    lo, hi = (float(np.quantile(y, 0.1)), float(np.quantile(y, 0.9))) if task == 0 else (-1.0, 1.0)
+    lr = min(0.01, 0.9 / (chunk * (1.0 if task == 0 else 0.25)))
+    m = oracle.Model(n, k, True, True, 0.002, 0.001, 0.003)
+    m.v[:] = oracle.init_values(5, n, k, 0.05)
+    m.w0 = 0.05
+    h = capi.Handle(n, k, True, True, task, 0.002, 0.001, 0.003, lr, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, row_ptr, y)
+    for _ in range(2):
+        st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, chunk, capi.FLAG_EVENT_SYNC if events else 0, lag)
+        assert st.batches == (rows + batch - 1) // batch
+        oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=lag)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    h.close()
+
+
 @pytest.mark.parametrize("name,batch,chunk", [("sgd_reg_ml", 64, 16), ("sgd_cls_ragged", 32, 8), ("sgd_cls_zipf_k32", 100, 10),
                                               ("sgd_reg_ml", 1, 1), ("sgd_cls_k64", 300, 64)])
 def test_minibatch_bias_lag_matches_restated_rule(capi, oracle, name, batch, chunk):

@@ -52,6 +52,28 @@ def test_batch_info_is_the_collision_mass_rule(capi):
     h.close()
 
 
+def test_collision_mass_of_a_feature_in_more_than_2_pow_24_rows(capi):
+    """a bias-like column in 20 M rows: an fp32 histogram bucket of unit values stops at 2^24 = 16.7 M and C comes out at 0.70 instead of
+    1.0 -- too lax a cut exactly where the rule diverges (round-3 advisor, medium).  The buckets are fp64 now: C is the formula's."""
+    rows = 20_000_000
+    rng = np.random.default_rng(3)
+    ent = np.zeros(rows * 2, dtype=capi.ENTRY_DTYPE)
+    ent["id"][0::2] = 0                                           # the frequent feature: every row
+    ent["id"][1::2] = rng.integers(1, 1_000_000, rows, dtype=np.uint32)
+    ent["value"] = 1.0
+    rp = np.arange(rows + 1, dtype=np.uint64) * np.uint64(2)
+    y = np.ones(rows, dtype=np.float32)
+    cnt = np.bincount(ent["id"], minlength=1_000_000).astype(np.float64)
+    C = (float((cnt ** 2).sum()) - 2.0 * rows) / (float(rows) * (rows - 1.0))
+    assert 1.0 < C < 1.001
+    h = capi.Handle(1_000_000, 2, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0)
+    h.upload_rows(0, ent, rp, y)
+    bi = h.sgd_batch_info(0)
+    assert abs(bi.collision_mass - C) <= 1e-9 * C                 # (sums of ones: exact in fp64, whatever the order of the atomics)
+    assert bi.batch == 256 and bi.status & capi.STAT_BATCH_CUT
+    h.close()
+
+
 def test_shards_add_up_to_the_same_batch(capi):
     e, rp, y, n = criteo(8000)
     h = capi.Handle(n, 8, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0)
