@@ -291,6 +291,15 @@ def run_als(capi, method, n, k, nnz, rows, steps, warmup, with_cpu, cpu_kw=None)
     n_seen = min(n, nnz_total)
     per_sweep = als_bytes_per_sweep(rows, nnz_total, n_seen, k)
     achieved = per_sweep / (dev / steps) / 1e9
+    traffic, tsrc, req = None, None, None
+    try:                                  # counter bytes / requests of the sweep's two kernels: the committed PMC passes, if they are for this shape
+        ta = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["als_sweep"]
+        if ta["shape"] == {"n": n, "k": k, "nnz": nnz, "rows": rows}:
+            traffic, tsrc = ta["hbm_bytes_per_sweep"], "committed profile: " + ta["source"]
+            req = {"k_als_draw_fabric_read_requests_per_s": ta["per_launch"]["k_als_draw<true,4>"]["fabric_read_requests_per_s"],
+                   "random_request_ceiling_per_s": "52e9 .. 55e9 (scripts/ubench/w_gather)"}
+    except (OSError, ValueError, KeyError):
+        pass
     out = {"metric": "%s (fm_learn_mcmc%s) training examples/sec per sweep at k=%d, nnz=%d, %.0e feat"
                      % (method.upper(), ", do_sample" if sample else "", k, nnz, n),
            "value": round(steps * rows / elapsed, 1), "unit": "examples/s", "n_gpus": 1, "steps": steps,
@@ -301,7 +310,7 @@ def run_als(capi, method, n, k, nnz, rows, steps, warmup, with_cpu, cpu_kw=None)
                       "method": method, "levels": st.levels, "device": info.device_name.decode(), "arch": info.arch.decode()},
            "roofline": {"bound": "hbm", "kernel": "k_als_draw<v> + k_als_rows<v> (80 % of the sweep) + re-prediction; whole sweep",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "bytes_per_sweep": per_sweep, "avg_sweep_ms": round(dev / steps * 1e3, 3),
+                        "traffic": traffic, "traffic_source": tsrc, "requests": req, "bytes_per_sweep": per_sweep, "avg_sweep_ms": round(dev / steps * 1e3, 3),
                         "note": "bound by the fabric's random-request rate, not by bytes: the column sums gather one 16-byte {e,q} "
                                 "per entry at 48 G requests/s (55 G/s is what a random 4..16-byte read gets on this part, "
                                 "scripts/ubench/w_gather); the update runs as a row-ordered stream (DESIGN.md section 4b)"},

@@ -194,6 +194,110 @@ void fmo_sgd_epoch_minibatch_pipelined(fmo_model *m, const fmo_data *d, int task
   minibatch_impl(m, d, task, learn_rate, min_target, max_target, batch, w0_chunk, bias_lag, 1, NULL);
 }
 
+/* the two-level rule (fm_oracle.h): fm_sgd.h:33-51 per occurrence; hot features frozen per window, cold ones per batch */
+void fmo_sgd_epoch_twolevel(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                            double min_target, double max_target,
+                            uint32_t batch, uint32_t window, uint32_t w0_chunk, int bias_lag, const uint8_t *hot) {
+  const int k = m->k;
+  const size_t n = (size_t)m->n;
+  const size_t kk = (size_t)(k > 0 ? k : 1);
+  if (batch == 0 || batch > d->n_rows) batch = d->n_rows;
+  if (window == 0 || window > batch) window = batch;
+  if (w0_chunk == 0 || w0_chunk > window) w0_chunk = window;
+  if (bias_lag > 8) bias_lag = 8;
+  double *S = (double *)malloc(sizeof(double) * (size_t)window * kk);
+  double *rest = (double *)malloc(sizeof(double) * window);
+  double *mult = (double *)malloc(sizeof(double) * window);
+  /* accumulated changes: cold features until the batch ends, hot ones until the window ends (separate arrays so that a window's end
+   * touches the hot features only; `touched` lists keep both applications proportional to the entries) */
+  double *dw = (double *)calloc(n ? n : 1, sizeof(double));
+  double *dv = (double *)calloc((n * kk) > 0 ? n * kk : 1, sizeof(double));
+  uint32_t *t_hot = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)window * 64 + 1)), n_thot = 0, cap_hot = window * 64u;
+  uint8_t *mark = (uint8_t *)calloc(n ? n : 1, 1);               /* 1: in t_hot, 2: in t_cold */
+  size_t cap_cold = 1024, n_tcold = 0;
+  uint32_t *t_cold = (uint32_t *)malloc(sizeof(uint32_t) * cap_cold);
+  double w0_hist[8];
+  uint32_t wno = 0;
+  for (uint32_t r0 = 0; r0 < d->n_rows; r0 += batch) {
+    const uint32_t nb = (d->n_rows - r0 < batch) ? (d->n_rows - r0) : batch;
+    for (uint32_t q0 = 0; q0 < nb; q0 += window) {
+      const uint32_t nw = (nb - q0 < window) ? (nb - q0) : window;
+      /* sums: cold rows have not moved since the batch started, hot rows since the window started -- the model as it stands */
+      for (uint32_t e = 0; e < nw; e++) {
+        const fmo_entry *row = d->entries + d->row_ptr[r0 + q0 + e];
+        const uint32_t size = (uint32_t)(d->row_ptr[r0 + q0 + e + 1] - d->row_ptr[r0 + q0 + e]);
+        double res = 0;
+        if (m->k1) for (uint32_t i = 0; i < size; i++) res += m->w[row[i].id] * row[i].value;
+        for (int f = 0; f < k; f++) {
+          double s = 0, q = 0;
+          for (uint32_t i = 0; i < size; i++) { const double dd = V(m, f, row[i].id) * row[i].value; s += dd; q += dd * dd; }
+          S[(size_t)e * kk + f] = s;
+          res += 0.5 * (s * s - q);
+        }
+        rest[e] = res;
+      }
+      /* bias: micro-chunks inside the window; the multipliers of the updates see it lagged by bias_lag windows */
+      w0_hist[wno % 8] = m->k0 ? m->w0 : 0.0;
+      const uint32_t lag_w = (bias_lag > 0 && wno + 1 >= (uint32_t)bias_lag) ? wno + 1 - (uint32_t)bias_lag : 0;
+      const double w0_lag = w0_hist[lag_w % 8];
+      wno++;
+      for (uint32_t c0 = 0; c0 < nw; c0 += w0_chunk) {
+        const uint32_t nc = (nw - c0 < w0_chunk) ? (nw - c0) : w0_chunk;
+        const double w0s = m->k0 ? m->w0 : 0.0;
+        double acc = 0;
+        for (uint32_t e = c0; e < c0 + nc; e++) {
+          const double y = (double)d->target[r0 + q0 + e];
+          const double me = fmo_multiplier(task, w0s + rest[e], y, min_target, max_target);
+          mult[e] = bias_lag ? fmo_multiplier(task, w0_lag + rest[e], y, min_target, max_target) : me;
+          acc += me + m->reg0 * w0s;
+          if (nc == 1 && m->k0) m->w0 -= learn_rate * (me + m->reg0 * m->w0);
+        }
+        if (m->k0 && nc != 1) m->w0 -= learn_rate * acc;
+      }
+      /* per-occurrence changes from the values the sums used (fm_sgd.h:38-50) */
+      for (uint32_t e = 0; e < nw; e++) {
+        const fmo_entry *row = d->entries + d->row_ptr[r0 + q0 + e];
+        const uint32_t size = (uint32_t)(d->row_ptr[r0 + q0 + e + 1] - d->row_ptr[r0 + q0 + e]);
+        for (uint32_t i = 0; i < size; i++) {
+          const uint32_t j = row[i].id;
+          const double x = row[i].value;
+          if (!mark[j]) {
+            if (hot && hot[j]) {
+              if (n_thot == cap_hot) { cap_hot *= 2; t_hot = (uint32_t *)realloc(t_hot, sizeof(uint32_t) * ((size_t)cap_hot + 1)); }
+              mark[j] = 1; t_hot[n_thot++] = j;
+            } else {
+              if (n_tcold == cap_cold) { cap_cold *= 2; t_cold = (uint32_t *)realloc(t_cold, sizeof(uint32_t) * cap_cold); }
+              mark[j] = 2; t_cold[n_tcold++] = j;
+            }
+          }
+          if (m->k1) dw[j] += -(learn_rate * (mult[e] * x + m->regw * m->w[j]));
+          for (int f = 0; f < k; f++) {
+            const double v = V(m, f, j);
+            dv[(size_t)f * n + j] += -(learn_rate * (mult[e] * (S[(size_t)e * kk + f] * x - v * x * x) + m->regv * v));
+          }
+        }
+      }
+      /* the window ends: its hot features move */
+      for (uint32_t t = 0; t < n_thot; t++) {
+        const uint32_t j = t_hot[t];
+        if (m->k1) { m->w[j] += dw[j]; dw[j] = 0.0; }
+        for (int f = 0; f < k; f++) { V(m, f, j) += dv[(size_t)f * n + j]; dv[(size_t)f * n + j] = 0.0; }
+        mark[j] = 0;
+      }
+      n_thot = 0;
+    }
+    /* the batch ends: its cold features move */
+    for (size_t t = 0; t < n_tcold; t++) {
+      const uint32_t j = t_cold[t];
+      if (m->k1) { m->w[j] += dw[j]; dw[j] = 0.0; }
+      for (int f = 0; f < k; f++) { V(m, f, j) += dv[(size_t)f * n + j]; dv[(size_t)f * n + j] = 0.0; }
+      mark[j] = 0;
+    }
+    n_tcold = 0;
+  }
+  free(S); free(rest); free(mult); free(dw); free(dv); free(t_hot); free(t_cold); free(mark);
+}
+
 static void minibatch_impl(fmo_model *m, const fmo_data *d, int task, double learn_rate, double min_target, double max_target,
                            uint32_t batch, uint32_t w0_chunk, int bias_lag, int stale, const uint8_t *hot) {
   const int k = m->k;

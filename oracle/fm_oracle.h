@@ -116,6 +116,26 @@ void fmo_sgd_epoch_minibatch_ex(fmo_model *m, const fmo_data *d, int task, doubl
 void fmo_sgd_epoch_minibatch_hot(fmo_model *m, const fmo_data *d, int task, double learn_rate,
                                  double min_target, double max_target,
                                  uint32_t batch, uint32_t w0_chunk, int bias_lag, const uint8_t *hot);
+/* The TWO-LEVEL batch rule (round 4; what FMX_APPLY_FUSED runs when the rows' collision mass cuts the batch -- data with frequent
+ * features, BASELINE configs[2]).  The batch rule freezes every parameter for one batch, and the stability bound
+ *   learn_rate * curvature * batch * C <= 1,   C = sum_j (sum_e |x_ej|)^2 / N^2  (collision mass)
+ * is set by a handful of FREQUENT features (a 100-id field, the head of a Zipf field): C = C_hot + C_cold over any split of the
+ * features, and the frozen window a parameter tolerates depends on ITS share.  So the frozen window is chosen per class:
+ *   - HOT features (hot[j] != 0) are frozen for one WINDOW of `window` rows: read at window-start values, the sum of the window's
+ *     occurrences (each computed from the window-start value, fm_sgd.h:38-50) applied at the window's end;
+ *   - COLD features are frozen for one BATCH of `batch` rows (a multiple of the window): read at batch-start values, the sum of the
+ *     batch's occurrences applied at the batch's end;
+ *   - an example's sums (fm_model.h:110-125) take hot rows as they are at ITS window's start and cold rows as they are at its
+ *     batch's start; its multiplier uses the bias lagged by `bias_lag` WINDOWS (>= 1: the bias at the start of window
+ *     w - bias_lag + 1; 0: the micro-chunk's own bias, as in the plain rule), and the bias advances in micro-chunks of w0_chunk
+ *     examples inside every window (fm_sgd.h:34-37 summed per chunk).
+ * Limits: hot = everything (or window == batch) is fmo_sgd_epoch_minibatch_ex at batch = window; hot = NULL (nothing) is that rule
+ * at batch = `batch` with the bias lag counted in windows; batch = window = w0_chunk = 1 is the reference's online loop.
+ * Stable while  learn_rate * curvature * (window * C_hot + batch * C_cold) <= 1  (tests/test_oracle_stability.py). */
+void fmo_sgd_epoch_twolevel(fmo_model *m, const fmo_data *d, int task, double learn_rate,
+                            double min_target, double max_target,
+                            uint32_t batch, uint32_t window, uint32_t w0_chunk, int bias_lag, const uint8_t *hot);
+
 /* the pipelined multi-GPU schedule: step 1 of batch b reads the parameters as they were BEFORE the update of batch
  * b-1 was applied (the gather of batch b overlaps the exchange / update of batch b-1); everything else as above. */
 void fmo_sgd_epoch_minibatch_pipelined(fmo_model *m, const fmo_data *d, int task, double learn_rate,

@@ -70,6 +70,8 @@ def lib():
         L.fmo_sgd_epoch_minibatch_ex.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_int]
         L.fmo_sgd_epoch_minibatch_pipelined.argtypes = L.fmo_sgd_epoch_minibatch_ex.argtypes
         L.fmo_sgd_epoch_minibatch_hot.argtypes = L.fmo_sgd_epoch_minibatch_ex.argtypes + [C.c_void_p]
+        L.fmo_sgd_epoch_twolevel.argtypes = [C.POINTER(_Model), C.POINTER(_Data), C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_int, C.c_void_p]
         L.fmo_multiplier.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.fmo_multiplier.restype = C.c_double
         L.fmo_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -227,6 +229,18 @@ def sgd_epoch_minibatch(m, d, task, lr, min_target, max_target, batch, w0_chunk,
     else:
         fn = lib().fmo_sgd_epoch_minibatch_pipelined if pipelined else lib().fmo_sgd_epoch_minibatch_ex
         fn(C.byref(cm), C.byref(cd), task, lr, min_target, max_target, batch, w0_chunk, int(bias_lag))
+    m.w0 = cm.w0
+
+
+def sgd_epoch_twolevel(m, d, task, lr, min_target, max_target, batch, window, w0_chunk, bias_lag, hot):
+    """the two-level batch rule (fm_oracle.h fmo_sgd_epoch_twolevel): hot features (hot[j] != 0) frozen per `window` rows, cold ones
+    per `batch` rows; bias lag counted in windows.  hot=None: no hot feature."""
+    cm, cd = m._c(), d._c()
+    if hot is not None:
+        hot = np.ascontiguousarray(hot, dtype=np.uint8)
+        assert hot.shape == (m.n,)
+    lib().fmo_sgd_epoch_twolevel(C.byref(cm), C.byref(cd), task, lr, min_target, max_target, int(batch), int(window), int(w0_chunk),
+                                 int(bias_lag), hot.ctypes.data if hot is not None else None)
     m.w0 = cm.w0
 
 
