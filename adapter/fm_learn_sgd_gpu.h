@@ -137,7 +137,7 @@ class fm_learn_sgd_gpu : public fmx_sgd_binding<fm_learn_sgd> {
 
   // defaults: the batch rule in one pass (FMX_APPLY_FUSED, bias lag 2), batch chosen by the library from the rows' collision
   // mass (fmx_sgd_opts::batch = 0), an explicit batch the rule diverges at is refused (FMX_E_ARG -> thrown like any error)
-  fm_learn_sgd_gpu() : gpu_mode(FMX_SGD_MINIBATCH), gpu_apply(FMX_APPLY_FUSED), gpu_batch(0), gpu_w0_chunk(0), gpu_flags(FMX_FLAG_REJECT_UNSTABLE), gpu_bias_lag(2) {}
+  fm_learn_sgd_gpu() : gpu_mode(FMX_SGD_MINIBATCH), gpu_apply(FMX_APPLY_FUSED), gpu_batch(0), gpu_w0_chunk(0), gpu_flags(FMX_FLAG_REJECT_UNSTABLE | FMX_FLAG_KEEP_WSIDE), gpu_bias_lag(2) {}   // (learn() evaluates the train set after every epoch, fm_learn_sgd_element.h:69-70: the epochs keep the slot's weight side stream for it)
 
   virtual void init() {                                   // fm_learn_sgd_element::init (:40-46)
     fm_learn_sgd::init();

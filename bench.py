@@ -656,14 +656,34 @@ def main():
             return round(n * args.rows / (time.perf_counter() - t1), 1)
         # the V-gather on its own: fm_model::predict over the same rows (k_rowsums + fused evaluation), the kernel north_star's
         # ">= 60 % of the HBM-read roofline on the V-gather" is about; v_read_frac = rows/s x nnz*k*4 B / 8 TB/s
-        ev_s = 0.0
-        h.evaluate(0)
-        for _ in range(5):
-            ev_s += h.evaluate(0).device_seconds
-        rps = 5 * args.rows / ev_s
-        extras["predict"] = {"mode": "fm_model::predict + evaluate over the step's rows (k_rowsums), the full model incl. linear weights",
+        def eval_rate():
+            ev_s, fl = 0.0, 0
+            h.evaluate(0)
+            for _ in range(5):
+                ev = h.evaluate(0)
+                ev_s += ev.device_seconds
+                fl = ev.flags
+            return 5 * args.rows / ev_s, bool(fl & capi.EVAL_WSIDE)
+        rps_plain, _ = eval_rate()
+        # the same pass after an epoch that kept the slot's weight side stream (FMX_FLAG_KEEP_WSIDE: what a learner that evaluates its train
+        # set after every epoch runs, fm_learn_sgd_element.h:69-70): w_j of an entry's last occurrence in the slot comes out of a 4-byte stream
+        # instead of a 64-byte fabric request.  Same numbers (tests/test_gpu_parity.py); the epoch itself writes 128 more bytes per example.
+        t1 = time.perf_counter()
+        h.sgd_epoch(0, mode, apply_, args.batch, args.w0_chunk, lagf | capi.FLAG_KEEP_WSIDE, bias_lag)
+        h.sgd_epoch(0, mode, apply_, args.batch, args.w0_chunk, lagf | capi.FLAG_KEEP_WSIDE, bias_lag)
+        h.synchronize()
+        t2 = time.perf_counter()
+        h.sgd_epoch(0, mode, apply_, args.batch, args.w0_chunk, lagf | capi.FLAG_KEEP_WSIDE, bias_lag)
+        h.synchronize()
+        keep_ms = (time.perf_counter() - t2) * 1e3
+        rps, streamed = eval_rate() if args.mode == "fused" else (rps_plain, False)
+        extras["predict"] = {"mode": "fm_model::predict + evaluate over the step's rows (k_rowsums), the full model incl. linear weights"
+                                     + ("; linear weights out of the slot's side stream where the entry is the feature's last occurrence (FMX_FLAG_KEEP_WSIDE)" if streamed else ""),
                              "value": round(rps, 1), "unit": "rows/s", "v_read_frac": v_read_fraction(rps, args.k, args.nnz),
-                             "frac": round(rps * (args.nnz * (4 * args.k + 12) + 4) / 1e9 / HBM_PEAK_GBS, 4)}
+                             "frac": round(rps * (args.nnz * (4 * args.k + 12) + 4) / 1e9 / HBM_PEAK_GBS, 4),
+                             "weight_side_stream": streamed,
+                             "without_side_stream": {"value": round(rps_plain, 1), "v_read_frac": v_read_fraction(rps_plain, args.k, args.nnz)},
+                             "epoch_keeping_the_stream_ms": round(keep_ms, 3)}
         if args.mode != "hogwild":
             extras["hogwild"] = {"mode": "hogwild (asynchronous one-pass step; parity only metric-level -- NOT the headline)",
                                  "batch": 262144, "value": timed_epochs(5, capi.SGD_HOGWILD, capi.APPLY_DEFAULT, 262144, args.w0_chunk, 0),

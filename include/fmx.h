@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 4
+#define FMX_ABI_VERSION 5
 
 enum {
   FMX_OK = 0,
@@ -143,6 +143,13 @@ typedef struct fmx_sgd_opts {
                                          there; tests/test_oracle_stability.py) instead of training -- for an explicit batch, and for batch 0
                                          when even the library's floor of 32 rows is unstable (rows with C in the hundreds: the message then
                                          names FMX_SGD_SEQUENTIAL / a lower learn_rate, not "batch 0") */
+#define FMX_FLAG_KEEP_WSIDE 32u        /* FMX_APPLY_FUSED on an unsharded handle: this epoch keeps the slot's WEIGHT SIDE STREAM current -- per entry
+                                         the new w_j where the entry is the last occurrence of its feature in the slot and its own example
+                                         updates it, "gather" otherwise (+128 coalesced bytes per example, 4 bytes per entry of memory).
+                                         fmx_predict / fmx_evaluate on that slot then take those weights out of a 4-byte stream instead of one
+                                         64-byte fabric request each (fm_model.h:110-115's loop over w: a third of the pass's requests) until
+                                         anything else changes w.  For learners that evaluate the train set after every epoch, as
+                                         fm_learn_sgd_element::learn does (fm_learn_sgd_element.h:69-70); same numbers either way */
 #define FMX_FLAG_EVENT_SYNC 16u        /* FMX_APPLY_FUSED at batches >= 32768: order the launch stream and the recurrence's side stream with
                                          events (four queue packets per batch) instead of the device-side hand-off (bias slots that start as
                                          "pending" + a completion counter: DESIGN.md section 4).  Same numbers either way; the environment
@@ -198,7 +205,10 @@ typedef struct fmx_eval {
   double   accuracy;        /* classification: sign agreement (p>=0 vs y>=0) */
   double   device_seconds;
   uint64_t rows;
+  uint32_t flags;           /* FMX_EVAL_WSIDE: the linear weights came out of the slot's weight side stream (FMX_FLAG_KEEP_WSIDE) */
+  uint32_t reserved;
 } fmx_eval;
+#define FMX_EVAL_WSIDE 1u
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* replaces: fm_model fm; fm.init() allocation (fm_model.h:91-99) + new fm_learn_* (libfm.cpp:271-293)
@@ -211,6 +221,10 @@ typedef struct fmx_eval {
  * found.  If the virtual-memory API is unavailable the tables are plain allocations (best of two candidates). */
 int fmx_create(const fmx_config *cfg, fmx_handle *out);
 int fmx_destroy(fmx_handle h);
+/* fmx_destroy keeps ONE placed arena per device alive for the next fmx_create on that device (which then takes it over without
+ * probing: fmx_place_info::pool = 0) -- the memory of the largest arena destroyed so far stays allocated until it is reused, this call
+ * returns it, a later placement runs short of memory, or the process ends.  FMX_ARENA_CACHE=0 in the environment turns this off. */
+int fmx_release_cached_memory(void);
 /* how the parameter tables of a handle were placed */
 typedef struct fmx_place_info {
   int32_t  method;          /* 0 = plain allocations (small tables / first fit), 1 = best of several candidate allocations,

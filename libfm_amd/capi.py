@@ -19,6 +19,8 @@ FLAG_BIAS_LAG = 2
 FLAG_PIPELINE = 4
 FLAG_REJECT_UNSTABLE = 8
 FLAG_EVENT_SYNC = 16
+FLAG_KEEP_WSIDE = 32
+EVAL_WSIDE = 1
 STAT_BATCH_CUT, STAT_UNSTABLE = 1, 2
 SYNTH_UNIFORM, SYNTH_CRITEO = 0, 1
 BLOCKS_EXPAND, BLOCKS_KEEP = 0, 1
@@ -71,7 +73,7 @@ class PlaceInfo(C.Structure):
 
 class Eval(C.Structure):
     _fields_ = [("rmse", C.c_double), ("mae", C.c_double), ("accuracy", C.c_double),
-                ("device_seconds", C.c_double), ("rows", C.c_uint64)]
+                ("device_seconds", C.c_double), ("rows", C.c_uint64), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Relation(C.Structure):
@@ -110,6 +112,7 @@ SYMBOLS = [
     ("fmx_destroy", C.c_int, [H]),
     ("fmx_last_error", C.c_char_p, [H]),
     ("fmx_abi_version", C.c_int, []),
+    ("fmx_release_cached_memory", C.c_int, []),
     ("fmx_device_count", C.c_int, []),
     ("fmx_set_params", C.c_int, [H, C.c_double, C.c_void_p, C.c_void_p]),
     ("fmx_get_params", C.c_int, [H, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
@@ -465,6 +468,11 @@ class Handle:
 
     def synchronize(self):
         self._chk(self.lib.fmx_synchronize(self.h))
+
+
+def release_cached_memory():
+    """fmx_release_cached_memory: the placed arena fmx_destroy keeps per device for the next fmx_create goes back to the device"""
+    load().fmx_release_cached_memory()
 
 
 def batch_rule(task, learn_rate, collision_mass, requested=0):

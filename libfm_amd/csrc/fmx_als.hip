@@ -32,6 +32,7 @@ extern "C++" void als_free(fmx_handle h) {
 }
 
 int fmx_als_end(fmx_handle h) {
+  touch_w(h);
   if (!h) return FMX_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -165,6 +166,7 @@ int fmx_als_begin(fmx_handle h, int train_slot) {
   return rc;
 }
 static int als_begin_impl(fmx_handle h, int train_slot) {
+  touch_w(h);
   int rc = check_slot(h, train_slot, true);
   if (rc) return rc;
   { int _rc = lag_flush(h); if (_rc) return _rc; }
@@ -277,6 +279,7 @@ int fmx_als_moments(fmx_handle h, double* out) {
 // version").  The levels are GLOBAL (fmx_group_als_begin), so the sweep is the reference's Gauss-Seidel order whatever
 // the number of shards.
 static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, const fmx_als_opts* opts, fmx_als_stats* stats) {
+  for (fmx_handle m : hs) touch_w(m);
   fmx_handle h = hs[0];
   const size_t P = hs.size();
   const bool sharded = g != nullptr && P > 1;

@@ -50,6 +50,11 @@ struct Slot {
   uint4*    cdesc = nullptr;         // [ncseg] the same list as {feature, first entry, end entry, index} records
   uint32_t  fused_cap = 0;           // longest row the k_fused instance of this slot keeps in registers
   std::vector<uint32_t> cbatch;      // [n_batches+1] first cseg entry of every batch
+  // weight side stream (fmx_kernels.h row_sums; FMX_FLAG_KEEP_WSIDE): wside[i] = w[id of entry i] or NaN, lmask[row] = which entries are
+  // the last occurrence of their feature in the slot; current while wside_version == the handle's w_version
+  float*    wside = nullptr;
+  uint64_t* lmask = nullptr;
+  uint64_t  wside_version = 0;
   std::vector<struct BlockRows*> blocks;   // `-relation` blocks kept apart from these (main) rows; empty: plain / expanded rows
 };
 
@@ -114,6 +119,7 @@ struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullp
 struct Arena {
   void*    va = nullptr;         // reserved range; chunk i is mapped at va + i * chunk_bytes
   size_t   bytes = 0, chunk_bytes = 0;
+  size_t   reserved_bytes = 0;   // size of the virtual range (>= bytes: a range taken over from the per-device cache may be longer)
   uint32_t n_chunks = 0;
   uint32_t per_class[2] = {0, 0};   // chunks of the two classes the tables are built from
   uint32_t pool = 0;             // chunks that were taken and classified to get them (the others were returned)
@@ -148,6 +154,7 @@ struct fmx_context_s {
   unsigned long long  handoff_seq = 0;         // host: value of the counter before the running epoch
   uint32_t*   handoff_err = nullptr;        // device: a wait ran into its bound
   uint32_t    handoff_err_host = 0;
+  uint64_t    w_version = 1;                // bumped by every entry point that may change a linear weight (a slot's side stream is valid for ONE value)
   int        num_cu = 256;
   double*    acc = nullptr;      // 4 doubles of reduction scratch
   Slot       slots[FMX_MAX_SLOTS];
@@ -190,6 +197,8 @@ void free_slot(Slot& s);
 int launch_rest(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n, float* rest, hipStream_t st);
 int ensure_segments(fmx_handle h, Slot& s, uint32_t B);                 // fmx_sgd.hip
 int ensure_coll_mass(fmx_handle h, Slot& s);                             // fmx_core.hip
+int ensure_wside(fmx_handle h, Slot& s);                                 // fmx_core.hip
+inline void touch_w(fmx_handle h) { if (h) h->w_version++; }
 void resolve_batch(const fmx_config& cfg, double coll_mass, uint32_t requested, uint32_t dflt, double curv_scale, fmx_batch_info* out);
 constexpr uint32_t FMX_DEFAULT_BATCH = 262144u;                          // fmx_sgd_opts::batch = 0, before the stability cut
 int sgd_resolve_batch(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, fmx_batch_info* bi);   // fmx_sgd.hip: + the shards' shares

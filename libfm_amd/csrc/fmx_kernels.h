@@ -321,10 +321,14 @@ static __global__ void k_handoff_arm(double* W, uint32_t n) {         // W[1 .. 
 //   sq      : this lane's share of  sum_f sum_i (v x)^2
 //   lin     : this lane's share of  sum_i w[id_i] x_i
 // ----------------------------------------------------------------------------------------------
+// wside (optional): the row's slice of the slot's WEIGHT SIDE STREAM -- wside[i] is either w[id_i] as it stands or NaN ("gather it").
+// A 4-byte w_j out of its own array costs a 64-byte fabric request per entry (a third of a predict pass's requests for 1.5 % of its
+// bytes); the stream costs 4 coalesced bytes.  Maintained by k_fused<EXACT> for the entries that are the LAST occurrence of their
+// feature in the slot and are updated by their own example (FMX_FLAG_KEEP_WSIDE; fmx_sgd.hip), NaN for everything else.
 template <int KP, int U>
 __device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t size,
                                          const Tab tb, int k1,
-                                         float (&sum)[Map<KP>::VEC], float& sq, float& lin) {
+                                         float (&sum)[Map<KP>::VEC], float& sq, float& lin, const float* __restrict__ wside = nullptr) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane / LPR, f = lane % LPR;
@@ -336,7 +340,11 @@ __device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t
     Entry e; e.id = 0; e.value = 0.f;
     if (lane < cnt) {
       e = load_stream8(ent + base + lane);
-      if (k1) lin += load_w(tb.w + (size_t)e.id * tb.ws) * e.value;
+      if (k1) {
+        float wv = wside ? __builtin_nontemporal_load(wside + base + lane) : __builtin_nanf("");
+        if (wv != wv) wv = load_w(tb.w + (size_t)e.id * tb.ws);
+        lin += wv * e.value;
+      }
     }
     for (uint32_t i = 0; i < cnt; i += EPI * U) {
       float vr[U][VEC]; float xs[U];
@@ -426,7 +434,7 @@ template <int KP, bool WRITE_S, bool FINISH>
 __global__ void __launch_bounds__(256)
 k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t n_rows,
           const Tab tb, int k1,
-          float* __restrict__ S, float* __restrict__ scal) {
+          float* __restrict__ S, float* __restrict__ scal, const float* __restrict__ wside) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -435,7 +443,7 @@ k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, u
     const uint64_t a = row_ptr[row0 + e];
     const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
     float sum[VEC], sq, lin;
-    row_sums<KP, 8>(ent + a, size, tb, k1, sum, sq, lin);
+    row_sums<KP, 8>(ent + a, size, tb, k1, sum, sq, lin, wside ? wside + a : nullptr);
 #pragma unroll
     for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
     if (WRITE_S && lane < LPR) store_vec<VEC>(S + (size_t)e * KP + lane * VEC, sum);
@@ -815,6 +823,30 @@ k_seg_max_count(const uint32_t* __restrict__ head, uint32_t nseg, uint32_t* __re
   if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
 }
 
+// ---- weight side stream (row_sums): which entries are the LAST occurrence of their feature in the slot's row order ----------------
+// last[id mod M] = max over the entries of (entry index + 1); an entry is flagged when the table holds ITS index (a folded table --
+// M < n -- only loses flags: two features sharing a bucket flag the later one's last entry, which is a last occurrence all the same)
+static __global__ void __launch_bounds__(256)
+k_wside_last(const Entry* __restrict__ ent, uint64_t nnz, uint32_t M, uint32_t* __restrict__ last) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x)
+    atomicMax(last + (ent[i].id % M), (uint32_t)i + 1u);
+}
+static __global__ void __launch_bounds__(256)
+k_wside_mask(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint32_t M, const uint32_t* __restrict__ last,
+             uint64_t* __restrict__ lmask, float* __restrict__ wside) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t r = wave0; r < n_rows; r += nwaves) {
+    const uint64_t a = row_ptr[r], b = row_ptr[r + 1];
+    bool flag = false;
+    if (a + lane < b) flag = last[ent[a + lane].id % M] == (uint32_t)(a + lane) + 1u;
+    const uint64_t bits = __ballot(flag);
+    if (lane == 0) lmask[r] = bits;                             // (entries beyond the 64th of a row are never streamed)
+    for (uint64_t i = a + lane; i < b; i += 64) wside[i] = __builtin_nanf("");   // nothing is known yet: every entry gathers
+  }
+}
+
 // ---- what FUSED_EXACT needs to know about a batch (built once with the segments) ----------------------------------
 // rows that do not fit the register path of k_fused are deferred as a whole
 static __global__ void __launch_bounds__(256)
@@ -974,7 +1006,9 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
           // one row per wave-wide load: the whole wavefront is here together.  64 descriptors and their multipliers arrive
           // lane-parallel (one coalesced load + one gather), then the S rows TL at a time with the descriptors broadcast by
           // v_readlane -- per TL occurrences ONE dependent round trip instead of three per occurrence.
-          constexpr int TL = (VEC == 1) ? 16 : 8;
+          // (one wavefront per segment -- the small-batch path, where a batch is a latency chain and the dense fields' segments hold
+          //  dozens of occurrences: 32 rows per round trip; elsewhere 16 / 8 keep the registers of the 16-segment blocks down)
+          constexpr int TL = (VEC == 1) ? (SPW == 1 ? 32 : 16) : 8;
           for (uint32_t base = i2; base < b; base += 64) {
             const uint32_t cc = min(64u, b - base);
             TEntry te; te.e = 0; te.x = 0.f; float tm = 0.f;
@@ -1162,7 +1196,10 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
         const uint64_t* __restrict__ cmask, float* __restrict__ S_out, float* __restrict__ mult_out, uint32_t fixed_nnz,
-        uint32_t* __restrict__ handoff_err) {
+        uint32_t* __restrict__ handoff_err, const uint64_t* __restrict__ lmask, float* __restrict__ wside) {
+  // wside != nullptr (FUSED_EXACT, FMX_FLAG_KEEP_WSIDE): the slot's weight side stream is kept current -- entry i of a row gets the NEW
+  // w_j when lmask says it is the last occurrence of its feature in the slot and this wavefront is the one that updates it (not deferred),
+  // NaN otherwise: 128 coalesced bytes per example (see row_sums)
   // handoff_err != nullptr: *w0_ptr is a hand-off slot (published by the recurrence kernel of an earlier batch on the side stream, possibly
   // still W0_PENDING): read it past the caches, and wait -- only where the multiplier needs it, behind the row gathers -- if it is not there yet
   // fixed_nnz != 0: every row of the slot holds exactly that many entries (one-hot field data): the entry list of example e starts at
@@ -1184,8 +1221,9 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
     const uint32_t size = fixed_nnz ? fixed_nnz : (uint32_t)(row_ptr[row0 + e + 1] - a);
     const Entry* __restrict__ row = ent + a;
     const float y = APPLY ? 0.f : target[row0 + e];
-    uint64_t cm = 0;
+    uint64_t cm = 0, lm = 0;
     if constexpr (MASKED) cm = cmask[row0 + e];
+    if constexpr (EXACT) { if (wside) lm = lmask[row0 + e]; }   // (with the mask: one round trip, long before it is needed)
     if (size <= (uint32_t)(ZR * EPI) && size <= 64u) {
       Entry en; en.id = 0; en.value = 0.f;
       float wv = 0.f;
@@ -1251,9 +1289,21 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
           if (lane == 0) mult_out[e] = mult;
         }
       }
+      float w_keep = __builtin_nanf("");
       if (h.k1 && lane < size && !(MASKED && ((cm >> lane) & 1ull))) {            // fm_sgd.h:38-43
         const float dw = -h.lr * (mult * en.value + h.regw * wv);
-        if (ATOMIC) unsafeAtomicAdd(tb.w + (size_t)en.id * tb.ws, dw); else tb.w[(size_t)en.id * tb.ws] = wv + dw;
+#ifndef FMX_W_STORE
+#define FMX_W_STORE 0                                             // experiments: 1 = non-temporal store of the new w_j
+#endif
+        if (ATOMIC) unsafeAtomicAdd(tb.w + (size_t)en.id * tb.ws, dw);
+        else if (FMX_W_STORE == 1) __builtin_nontemporal_store(wv + dw, tb.w + (size_t)en.id * tb.ws);
+        else tb.w[(size_t)en.id * tb.ws] = wv + dw;
+        w_keep = wv + dw;
+      }
+      if constexpr (EXACT) {
+        if (wside && lane < size) {
+          __builtin_nontemporal_store(((lm >> lane) & 1ull) ? w_keep : __builtin_nanf(""), wside + a + lane);
+        }
       }
       // phase C: fm_sgd.h:44-50 on the register-resident rows, written straight back
 #pragma unroll

@@ -33,11 +33,12 @@ template <int KP> uint32_t fused_row_cap_kp(uint32_t max_row) {
 template <int KP, int VAR>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
                     const double* w0_in, float* rest_out, const uint64_t* cmask = nullptr, float* S_out = nullptr,
-                    float* mult_out = nullptr, uint32_t* handoff_err = nullptr) {
+                    float* mult_out = nullptr, uint32_t* handoff_err = nullptr, bool keep_wside = false) {
 #define FMX_LAUNCH_ZR(ZRV)                                                                                  \
   if constexpr (fused_zr_ok<KP>(ZRV)) {                                                                     \
     FMX_LAUNCH_WAVES((k_fused<KP, ZRV, VAR>), n_rows, st, s.ent, s.row_ptr, s.target, row0,                 \
-                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out, s.fixed_nnz, handoff_err); }
+                     n_rows, h->tb, hy, w0_in, rest_out, cmask, S_out, mult_out, s.fixed_nnz, handoff_err,                  \
+                     (const uint64_t*)(keep_wside ? s.lmask : nullptr), keep_wside ? s.wside : (float*)nullptr); }
   switch (fused_zr_select<KP>(s.max_row)) {
     case 8:  FMX_LAUNCH_ZR(8);  break;
     case 16: FMX_LAUNCH_ZR(16); break;
@@ -77,7 +78,7 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
   float* S = d_partial;
   float* c = d_partial + (size_t)n_rows * h->KP;
   KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st,
-                                     s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c));
+                                     s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c, (const float*)nullptr));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
 }
@@ -86,7 +87,7 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
 // fmx_group_sgd_epoch enqueues the all-reduce of one run while the next one is being summed
 extern "C++" int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st) {
   if (n_rows == 0) return FMX_OK;
-  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st, s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c));
+  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st, s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c, (const float*)nullptr));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
 }
@@ -389,6 +390,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
 
 int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const float* d_partial,
                    const fmx_sgd_opts* opts, void* stream) {
+  touch_w(h);
   int rc = check_slot(h, slot, true);
   if (rc) return rc;
   Slot& s = h->slots[slot];
@@ -452,13 +454,18 @@ int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, fl
 // fmo_sgd_epoch_minibatch_ex with bias_lag = d): the recurrence of batch b (k_scan, one workgroup) runs on the side stream
 // under the launches of batches b+1 .. b+d-1 and only the launch of batch b+d waits for it.
 static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, const Hyper& hy, uint64_t* batches,
-                           uint64_t* launches, uint64_t* deferred) {
+                           uint64_t* launches, uint64_t* deferred, bool* kept_wside) {
   const uint32_t B = opts->batch;                           // resolved by the caller (sgd_resolve_batch)
   const uint32_t d = opts->bias_lag ? opts->bias_lag : 1u;
   if (d > 4) return fail(h, FMX_E_ARG, "bias_lag %u: at most 4 batches", d);
   const uint32_t chunk = opts->w0_chunk ? opts->w0_chunk : default_w0_chunk(h->cfg);
   int rc = ensure_segments(h, s, B);
   if (rc) return rc;
+  // FMX_FLAG_KEEP_WSIDE: this epoch keeps the slot's weight side stream current (for the evaluation passes that follow it)
+  const bool keep_wside = (opts->flags & FMX_FLAG_KEEP_WSIDE) && hy.k1 && h->cfg.shard_world == 1 && s.blocks.empty();
+  if (keep_wside) { rc = ensure_wside(h, s); if (rc) return rc; }
+  const bool keep = keep_wside && s.wside != nullptr;
+  *kept_wside = keep;
   const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
   rc = ensure_scratch(h, (size_t)Bc * 2, (size_t)Bc * (d + 1));       // S / mult of two consecutive batches, d (+ 1: hand-off) rest buffers
   if (rc) return rc;
@@ -515,7 +522,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     if (side && !handoff && b >= d) HIPCHK(h, hipStreamWaitEvent(st, h->ev_sync[2 * (b - d) + 1], 0));   // recurrence of batch b - d is done
     const double* w0_in = handoff ? W + (b + 1 >= d ? b + 1 - d : 0)
                                   : h->w0_pp + ((b + 1) % d);  // written by the recurrence of batch b - d (initial bias for b < d)
-    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, handoff ? h->handoff_err : nullptr); });
+    KP_SWITCH(h->KP, { rc = launch_fused_zr<KP, FUSED_EXACT>(h, s, hy, row0, nb, st, w0_in, rest, s.cmask, S, mult, handoff ? h->handoff_err : nullptr, keep); });
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
     if (side && !handoff) HIPCHK(h, hipEventRecord(h->ev_sync[2 * b], st));
@@ -608,6 +615,8 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   }
   const bool timed = (opts->flags & FMX_FLAG_TIME_MAIN_KERNEL) != 0;
   uint64_t batches = 0, main_launches = 0, deferred = 0;
+  bool kept_wside = false;
+  touch_w(h);                                                // (every side stream is stale from here on; this epoch may re-validate ITS slot's)
   size_t ev_used = 0;
   auto get_event = [&](hipEvent_t* ev) -> hipError_t {
     if (ev_used == h->ev_pool.size()) { hipEvent_t e; hipError_t er = hipEventCreate(&e); if (er != hipSuccess) return er; h->ev_pool.push_back(e); }
@@ -662,7 +671,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sync[2 * (n_launch - 1) + 1], 0));
     if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_launch % 3), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   } else if (opts->mode == FMX_SGD_MINIBATCH && opts->apply == FMX_APPLY_FUSED) {
-    rc = sgd_epoch_fused(h, s, opts, hy, &batches, &main_launches, &deferred);
+    rc = sgd_epoch_fused(h, s, opts, hy, &batches, &main_launches, &deferred, &kept_wside);
     if (rc) return rc;
   } else if (opts->mode == FMX_SGD_MINIBATCH) {
     const uint32_t B = opts->batch;
@@ -685,7 +694,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
       float* S = h->partial + (size_t)pslot * Bc * (size_t)(h->KP + 1);
       float* rest = S + (size_t)nb * h->KP;
       KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, h->stream,
-                                         s.ent, s.row_ptr, row0, nb, h->tb, h->cfg.k1, S, rest));
+                                         s.ent, s.row_ptr, row0, nb, h->tb, h->cfg.k1, S, rest, (const float*)nullptr));
       hipEvent_t ea = nullptr, eb = nullptr;
       if (timed) { HIPCHK(h, get_event(&ea)); HIPCHK(h, get_event(&eb)); main_launches++; }
       rc = sgd_finish_impl(h, s, row0, nb, S, rest, opts, h->stream, ea, eb, segmented ? (int64_t)(row0 / B) : -1);
@@ -710,6 +719,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   }
   rc = lag_flush(h);
   if (rc) return rc;
+  if (kept_wside) s.wside_version = h->w_version;            // the epoch is complete: the stream holds this w
   if (stats) {
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -759,6 +769,7 @@ int fmx_sgda_end(fmx_handle h) {
 }
 
 int fmx_sgda_begin(fmx_handle h) {
+  touch_w(h);
   if (!h) return FMX_E_ARG;
   if (h->cfg.shard_world > 1) return fail(h, FMX_E_UNSUPPORTED, "SGDA on a feature shard is not implemented");
   { int _rc = lag_flush(h); if (_rc) return _rc; }
@@ -792,6 +803,7 @@ int fmx_sgda_get_reg(fmx_handle h, double* reg) {
 }
 
 int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, fmx_epoch_stats* stats) {
+  touch_w(h);
   int rc = check_slot(h, train_slot, true);
   if (rc) return rc;
   rc = check_slot(h, validation_slot, true);
@@ -835,6 +847,7 @@ int fmx_sgda_epoch(fmx_handle h, int train_slot, int validation_slot, int do_lam
 // minibatch rule, then -- do_lambda_steps -- the lambda steps of the next `batch` validation rows, summed and applied once
 int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, int do_lambda_steps, uint32_t batch,
                              uint32_t w0_chunk, fmx_epoch_stats* stats) {
+  touch_w(h);
   int rc = check_slot(h, train_slot, true);
   if (rc) return rc;
   rc = check_slot(h, validation_slot, true);
@@ -882,7 +895,7 @@ int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, 
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
     float* S = h->partial;
     float* rest = S + (size_t)nb * h->KP;
-    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, st, s.ent, s.row_ptr, row0, nb, h->tb, h->cfg.k1, S, rest));
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, st, s.ent, s.row_ptr, row0, nb, h->tb, h->cfg.k1, S, rest, (const float*)nullptr));
     rc = launch_scan(h, rest, s.target + row0, nb, chunk, hy, h->mult, st);
     if (rc) return rc;
     const size_t bi = (size_t)(row0 / B);

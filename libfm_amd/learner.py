@@ -175,6 +175,7 @@ class FMLearnSGD:
             if self.mode != "minibatch" and apply_ == capi.APPLY_FUSED:
                 apply_ = capi.APPLY_DEFAULT
             flags = capi.FLAG_REJECT_UNSTABLE if (self.reject_unstable and self.mode == "minibatch") else 0
+            flags |= capi.FLAG_KEEP_WSIDE                # the train set is evaluated after every epoch (fm_learn_sgd_element.h:69-70)
             stats = self._h.sgd_epoch(st, self.MODES[self.mode], apply_, self.batch, self.w0_chunk, flags,
                                       self.bias_lag if apply_ == capi.APPLY_FUSED else 0)
             if i == 0 and self.mode == "minibatch" and (stats.status & capi.STAT_BATCH_CUT):

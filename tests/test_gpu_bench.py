@@ -56,3 +56,24 @@ def test_self_launch_one_process_per_rank():
                     "--rows", 65536, "--batch", 16384, "--steps", 2, "--warmup", 1)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["driver"] == "torch"
     assert "2 shards" in out["config"]["sharding"] and out["exchange"]["backend"] == "gloo"
+
+
+def test_eight_shards_and_the_pipelined_schedule_as_typed():
+    """`python bench.py --gpus 8 --same-device` and `--gpus 4 --same-device --pipeline` at the bench's own shape (n = 1e8, 4 194 304 rows per
+    step): what the driver's 8-GPU run types, on one device (loopback exchange).  The line carries the phase times, the exchange and the
+    SAME batch rule as N = 1 (batch 262 144, nothing to cut); the pipelined schedule reports its exposed exchange from the right events
+    (round-3 advisor: it used to contain the previous batch's update)."""
+    one = run_bench("--steps", 1, "--warmup", 1, "--no-cpu-baseline", "--no-extras")
+    rule1 = one["config"]["batch_rule"]
+    assert rule1["batch"] == 262144 and rule1["cut"] is False
+    for argv, n in ((("--gpus", 8, "--same-device"), 8), (("--gpus", 4, "--same-device", "--pipeline"), 4)):
+        out = run_bench(*argv, "--steps", 2, "--warmup", 1)
+        assert out["n_gpus"] == n and out["value"] > 0 and "%d shards" % n in out["config"]["sharding"]
+        assert out["config"]["pipeline"] is ("--pipeline" in argv)
+        br = out["config"]["batch_rule"]
+        assert br["batch"] == rule1["batch"] and abs(br["collision_mass"] - rule1["collision_mass"]) <= 0.05 * rule1["collision_mass"] + 1e-7
+        assert out["exchange"]["bytes_per_example"] == 4 * 65 and out["exchange"]["pipelined"] is ("--pipeline" in argv)
+        ph = out["phases_ms_per_batch"]
+        assert ph["sums"] > 0 and ph["update"] > 0 and 0 <= ph["exchange_exposed"] <= ph["device_total"]
+        assert ph["sums"] + ph["exchange_exposed"] + ph["update"] <= 1.2 * ph["device_total"] + 0.05
+        assert "driver_fallback" not in out

@@ -665,3 +665,69 @@ def test_model_file_from_the_device_table(capi, oracle, name, tmp_path):
     with pytest.raises(capi.FmxError, match="malformed model file"):
         h.load_model(str(tmp_path / "missing.model"))
     h.close()
+
+
+@pytest.mark.parametrize("shape", ["fields", "ragged_dups", "long_rows"])
+def test_weight_side_stream_moves_no_number_and_goes_stale_safely(capi, oracle, shape):
+    """FMX_FLAG_KEEP_WSIDE: after a one-pass epoch that kept the slot's weight side stream, fmx_predict / fmx_evaluate take w_j out of the
+    stream where the entry is flagged (last occurrence of its feature in the slot, updated by its own example) and gather the rest --
+    bit for bit the predictions of a twin handle that never heard of the stream; anything else that changes w (another epoch without
+    the flag, a HOGWILD epoch, fmx_set_params, an ALS sweep, an epoch on ANOTHER slot) makes the stream stale and the pass gathers again.
+    Shapes: one-hot fields whose ids repeat across batches; ragged rows with empty ones and repeated ids inside a row; rows longer than
+    the register path (their entries are never streamed)."""
+    k, lr = 16, 0.01
+    if shape == "fields":
+        n, nnz, rows = 4800, 12, 6000
+        ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed=77, zipf=0.7)
+    elif shape == "ragged_dups":
+        n, rows = 3000, 5000
+        ent, rp, y = datagen.ragged_real(n, rows, 20, seed=78, empty_every=7, duplicates=True)
+    else:
+        n, rows = 9000, 1500
+        ent, rp, y = datagen.ragged_real(n, rows, 90, seed=79)
+    d = oracle.Data(ent, rp, y)
+    m = oracle.Model(n, k, True, True, 0.0, 0.001, 0.002)
+    m.v[:] = oracle.init_values(9, n, k, 0.05)
+    m.w[:] = oracle.init_values(10, n, 1, 0.05)[0]
+    hs = []
+    for _ in range(2):
+        h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.001, 0.002, lr, -1.0, 1.0)
+        h.set_params(m.w0, m.w, m.v)
+        h.upload_rows(0, ent, rp, y)
+        h.upload_rows(1, ent[:int(rp[rows // 2])], rp[:rows // 2 + 1], y[:rows // 2])
+        hs.append(h)
+    keep, plain = hs
+    B, chunk = 512, 64
+    for ep in range(2):
+        keep.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, B, chunk, capi.FLAG_KEEP_WSIDE, 2)
+        plain.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, B, chunk, 0, 2)
+        oracle.sgd_epoch_minibatch(m, d, 1, lr, -1.0, 1.0, B, chunk, bias_lag=2)
+        ev = keep.evaluate(0)
+        assert ev.flags & capi.EVAL_WSIDE and not (plain.evaluate(0).flags & capi.EVAL_WSIDE)
+        p_keep, p_plain = keep.predict(0, rows), plain.predict(0, rows)
+        assert p_keep.tobytes() == p_plain.tobytes()                 # the stream holds exactly the floats the table holds
+        np.testing.assert_allclose(p_keep, oracle.predict_raw(m, d), rtol=1e-4, atol=2e-5)
+        assert not (keep.evaluate(1).flags & capi.EVAL_WSIDE)         # another slot has no stream of its own
+    # everything that moves w without keeping the stream makes it stale: the next pass gathers (and is still right)
+    def stale_and_right():
+        assert not (keep.evaluate(0).flags & capi.EVAL_WSIDE)
+        assert keep.predict(0, rows).tobytes() == plain.predict(0, rows).tobytes()
+    for h in hs:
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, B, chunk, 0, 2)           # the same epoch without the flag
+    stale_and_right()
+    keep.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, B, chunk, capi.FLAG_KEEP_WSIDE, 2)
+    plain.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, B, chunk, 0, 2)
+    assert keep.evaluate(0).flags & capi.EVAL_WSIDE                   # ... and one epoch with it brings it back
+    for h in hs:
+        h.sgd_epoch(1, capi.SGD_MINIBATCH, capi.APPLY_FUSED, B, chunk, capi.FLAG_KEEP_WSIDE, 2)   # an epoch on the OTHER slot (which keeps ITS stream)
+    stale_and_right()
+    assert keep.evaluate(1).flags & capi.EVAL_WSIDE
+    w0, w, v = plain.get_params()
+    for h in hs:
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, B, chunk, capi.FLAG_KEEP_WSIDE if h is keep else 0, 2)
+    assert keep.evaluate(0).flags & capi.EVAL_WSIDE
+    for h in hs:
+        h.set_params(w0, w * 1.5, v)                                  # new weights from the host
+    stale_and_right()
+    for h in hs:
+        h.close()

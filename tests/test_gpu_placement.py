@@ -30,6 +30,7 @@ def _run(capi, place):
 
 
 def test_arena_placement_is_reported_and_changes_no_result(capi):
+    capi.release_cached_memory()                                       # (an arena an earlier test left behind would be taken over: pool = 0)
     pi0, out0 = _run(capi, 0)
     pi1, out1 = _run(capi, 1)
     assert pi1.method == 0 and pi1.chunks == 0
@@ -45,16 +46,40 @@ def test_arena_placement_is_reported_and_changes_no_result(capi):
 def test_arena_gives_its_memory_back(capi):
     """ten handles in a row: leaked chunks (4 GiB each, plus the pool) would show"""
     import torch
+    capi.release_cached_memory()
     free0 = torch.cuda.mem_get_info()[0]
-    for _ in range(10):
+    for i in range(10):
         h = capi.Handle(N, K, place_candidates=0)
-        assert h.place_info().method == 2
+        pi = h.place_info()
+        assert pi.method == 2 and pi.chunks == 4
+        assert (pi.pool == 0) == (i > 0)                              # from the second handle on: the previous one's arena, nothing probed
         h.close()
-    free1 = torch.cuda.mem_get_info()[0]
-    assert free0 - free1 < (1 << 30)
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert (3 << 30) < held < (5 << 30)                               # exactly one arena is kept for the next fmx_create on this device ...
+    capi.release_cached_memory()
+    assert free0 - torch.cuda.mem_get_info()[0] < (1 << 30)           # ... until it is asked back
+
+
+def test_a_cached_arena_serves_a_smaller_table_and_moves_no_number(capi):
+    """a handle of 8 chunks, destroyed; the next handle needs 4: it takes the first four chunks of that arena (a prefix of an alternating
+    sequence alternates), the other four go back to the device; its results are the ones of a freshly probed arena"""
+    import torch
+    capi.release_cached_memory()
+    _, fresh = _run(capi, 0)
+    capi.release_cached_memory()
+    free0 = torch.cuda.mem_get_info()[0]
+    big = capi.Handle(2 * N + N // 2, K, place_candidates=0)
+    assert big.place_info().chunks >= 7
+    big.close()
+    pi, out = _run(capi, 0)
+    assert pi.method == 2 and pi.chunks == 4 and pi.pool == 0 and pi.per_class[0] == 2 and pi.per_class[1] == 2
+    assert out == fresh
+    assert (3 << 30) < free0 - torch.cuda.mem_get_info()[0] < (5 << 30)
+    capi.release_cached_memory()
 
 
 def test_candidate_bound_is_honoured(capi):
+    capi.release_cached_memory()
     h = capi.Handle(N, K, place_candidates=2)
     pi = h.place_info()
     assert pi.method == 2 and pi.pool <= 2 * pi.chunks + 64
