@@ -1006,9 +1006,9 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
           // one row per wave-wide load: the whole wavefront is here together.  64 descriptors and their multipliers arrive
           // lane-parallel (one coalesced load + one gather), then the S rows TL at a time with the descriptors broadcast by
           // v_readlane -- per TL occurrences ONE dependent round trip instead of three per occurrence.
-          // (one wavefront per segment -- the small-batch path, where a batch is a latency chain and the dense fields' segments hold
-          //  dozens of occurrences: 32 rows per round trip; elsewhere 16 / 8 keep the registers of the 16-segment blocks down)
-          constexpr int TL = (VEC == 1) ? (SPW == 1 ? 32 : 16) : 8;
+          // (32 rows per round for the one-segment-per-wavefront path was measured in round 4: k_apply_seg_scan 7.6 -> 8.1 us per
+          //  512-row batch of Criteo-shaped rows -- most segments there hold ~8 occurrences and pay for the longer unrolled round)
+          constexpr int TL = (VEC == 1) ? 16 : 8;
           for (uint32_t base = i2; base < b; base += 64) {
             const uint32_t cc = min(64u, b - base);
             TEntry te; te.e = 0; te.x = 0.f; float tm = 0.f;

@@ -90,3 +90,59 @@ def test_hot_rule_collapses_to_the_reference_at_batch_one(oracle):
     np.testing.assert_allclose(b.v, a.v, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(b.w, a.w, rtol=1e-10, atol=1e-13)
     assert abs(a.w0 - b.w0) < 1e-12
+
+
+def test_two_level_rule_limits_and_stability(oracle):
+    """the two-level batch rule (oracle fmo_sgd_epoch_twolevel; DESIGN.md section 9 -- restated and checked on the CPU, no device kernel
+    runs it yet): hot features frozen per window, cold ones per batch.
+      * limits: every feature hot == the plain rule at batch = window; no hot feature and window == batch == the plain rule at that batch;
+        batch = window = chunk = 1 == the online loop;
+      * stability: on Criteo-shaped rows, with the features that carry the collision mass hot (window 256) and the rest frozen for the
+        WHOLE data set, the rule ends where the online loop ends -- where the plain rule at a batch of 8 192 has long diverged: the
+        bound is  lr * curvature * (window * C_hot + batch * C_cold) <= 1,  C = C_hot + C_cold."""
+    O = oracle
+    e, rp, y, n = DG.criteo_shaped(36000, 5, cat_ids=2000)
+    z = 39
+    tr, te = O.Data(e[:30000 * z], rp[:30001], y[:30000]), O.Data(e[30000 * z:], rp[30000:] - rp[30000], y[30000:])
+    lr = 0.01
+
+    def fresh():
+        m = O.Model(n, 8, True, True, 0.0, 0.0005, 0.001)
+        m.v[:] = O.init_values(1, n, 8, 0.01)
+        return m
+    small = O.Data(tr.entries[:3000 * z], tr.row_ptr[:3001], tr.target[:3000])
+    a, b = fresh(), fresh()
+    O.sgd_epoch_twolevel(a, small, 1, lr, -1.0, 1.0, 1024, 128, 32, 2, np.ones(n, dtype=np.uint8))
+    O.sgd_epoch_minibatch(b, small, 1, lr, -1.0, 1.0, 128, 32, bias_lag=2)
+    np.testing.assert_allclose(a.v, b.v, rtol=1e-12, atol=1e-15); np.testing.assert_allclose(a.w, b.w, rtol=1e-12, atol=1e-15)
+    assert abs(a.w0 - b.w0) < 1e-14
+    a, b = fresh(), fresh()
+    O.sgd_epoch_twolevel(a, small, 1, lr, -1.0, 1.0, 512, 512, 64, 1, None)
+    O.sgd_epoch_minibatch(b, small, 1, lr, -1.0, 1.0, 512, 64, bias_lag=1)
+    np.testing.assert_allclose(a.v, b.v, rtol=1e-12, atol=1e-15); np.testing.assert_allclose(a.w, b.w, rtol=1e-12, atol=1e-15)
+    tiny = O.Data(tr.entries[:200 * z], tr.row_ptr[:201], tr.target[:200])
+    a, b = fresh(), fresh()
+    O.sgd_epoch_twolevel(a, tiny, 1, lr, -1.0, 1.0, 1, 1, 1, 0, None)
+    O.sgd_epoch_online(b, tiny, 1, lr, -1.0, 1.0)
+    np.testing.assert_allclose(a.v, b.v, rtol=1e-10, atol=1e-14); np.testing.assert_allclose(a.w, b.w, rtol=1e-10, atol=1e-14)
+    # stability: hot = the most frequent features until the rest's share of C, times the WHOLE data set, stays below 1/2
+    cnt = np.bincount(tr.entries["id"], minlength=n).astype(np.float64)
+    p2 = (cnt / tr.n_rows) ** 2
+    order = np.argsort(-p2)
+    tail = p2.sum() - np.cumsum(p2[order])
+    n_hot = int(np.argmax(lr * 0.25 * tr.n_rows * tail <= 0.5)) + 1
+    hot = np.zeros(n, dtype=np.uint8)
+    hot[order[:n_hot]] = 1
+    C_hot = float(p2[order[:n_hot]].sum())
+    assert n_hot < 0.2 * n and lr * 0.25 * 256 * C_hot <= 1.0
+
+    def run(step):
+        m = fresh()
+        for _ in range(3):
+            step(m)
+        return logloss(O, m, te)
+    ref = run(lambda m: O.sgd_epoch_online(m, tr, 1, lr, -1.0, 1.0))
+    two = run(lambda m: O.sgd_epoch_twolevel(m, tr, 1, lr, -1.0, 1.0, tr.n_rows, 256, 256, 1, hot))
+    plain = run(lambda m: O.sgd_epoch_minibatch(m, tr, 1, lr, -1.0, 1.0, 8192, 256, bias_lag=2))
+    assert abs(two - ref) <= 0.02, (two, ref)
+    assert not np.isfinite(plain) or plain > ref + 0.1, (plain, ref)
