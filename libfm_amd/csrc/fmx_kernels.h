@@ -1285,7 +1285,23 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       }
       if constexpr (EXACT) {
         if (cm != 0) {                                         // some feature of this example is finished by k_apply_seg
-          if (lane < LPR) store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
+#ifndef FMX_S_PUBLISH
+#define FMX_S_PUBLISH 0       // experiments (what an in-launch hand-off of S_e would cost): 1 = agent-scope (sc1) dword stores, 2 = sc1 16-byte stores
+#endif
+          if constexpr (FMX_S_PUBLISH == 1 && VEC == 1) {
+            __hip_atomic_store(S_out + (size_t)e * KP + lane, sum[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if constexpr (FMX_S_PUBLISH == 2 && VEC == 1 && KP == 64) {
+            // four lanes' factors gathered into one lane: sixteen 16-byte write-through stores instead of sixty-four 4-byte ones
+            const float a0 = __shfl(sum[0], (int)((lane & 15u) * 4u)), a1 = __shfl(sum[0], (int)((lane & 15u) * 4u + 1u));
+            const float a2 = __shfl(sum[0], (int)((lane & 15u) * 4u + 2u)), a3 = __shfl(sum[0], (int)((lane & 15u) * 4u + 3u));
+            if (lane < 16) {
+              typedef float v4f __attribute__((ext_vector_type(4)));
+              v4f t; t.x = a0; t.y = a1; t.z = a2; t.w = a3;
+              asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(S_out + (size_t)e * KP + lane * 4), "v"(t) : "memory");
+            }
+          } else {
+            if (lane < LPR) store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
+          }
           if (lane == 0) mult_out[e] = mult;
         }
       }

@@ -124,3 +124,46 @@ def test_group_moments(n, k, G):
     e = yhat - np.array([1.0, -1.0])
     np.testing.assert_allclose([se2, se], [(e ** 2).sum(), e.sum()], rtol=1e-5)
     h.close()
+
+
+def test_the_device_normal_generator_is_standard_normal():
+    """the N(0,1) behind every Gibbs draw (counter hash -> fp32 Box-Muller, fmx_als_kernels.h gauss_hash; round 3 moved it from fp64 to the
+    hardware log / cos) on its own, where nothing else enters: a feature WITHOUT a training column is drawn from its prior
+    (fm_learn_mcmc.h:467-476, :586-595), theta = mu + N(0,1) / sqrt(lambda) -- 2 M such draws per coordinate family of one sweep.
+    Moments to their standard errors, the tail out to 5 sigma, no correlation between factors / sweeps / neighbouring features, and a
+    Kolmogorov distance that a 24-bit uniform source must meet.  (Round-3 verdict: the generator was only covered by the k = 8 bands.)"""
+    from libfm_amd import capi
+    from scipy import stats
+    n, k, rows = 2_000_000, 4, 64
+    h = capi.Handle(n, k, True, True, capi.TASK_REGRESSION, 0.0, 1.0, 1.0, 0.0, -1.0, 1.0)
+    h.init_params(0.0, 0.0, 1)
+    ent = np.zeros(rows, dtype=capi.ENTRY_DTYPE)
+    ent["id"] = np.arange(rows, dtype=np.uint32)                 # features 0 .. 63 have a column; the other ~2 M do not
+    ent["value"] = 1.0
+    h.upload_rows(0, ent, np.arange(rows + 1, dtype=np.uint64), np.zeros(rows, dtype=np.float32))
+    mu, lam = 0.25, 4.0
+    h.als_begin(0)
+    sweeps = []
+    for it in range(2):
+        h.als_sweep(lam, lam, alpha=1.0, w_mu=mu, v_mu=mu, do_sample=True, seed=1234 + it)
+        _, w, v = h.get_params()
+        sweeps.append(np.concatenate([w[None, rows:], v[:, rows:]]).copy())      # [1 + k][unseen]
+    h.als_end()
+    h.close()
+    z = (sweeps[0] - mu) * np.sqrt(lam)                          # standard normal, if the generator is
+    N = z.shape[1]
+    for f in range(1 + k):
+        x = z[f]
+        assert abs(x.mean()) < 5.0 / np.sqrt(N), (f, x.mean())
+        assert abs(x.var() - 1.0) < 5.0 * np.sqrt(2.0 / N), (f, x.var())
+        assert abs(stats.skew(x)) < 5.0 * np.sqrt(6.0 / N) and abs(stats.kurtosis(x)) < 5.0 * np.sqrt(24.0 / N), (f, stats.skew(x), stats.kurtosis(x))
+        assert stats.kstest(x, "norm").statistic < 2.0 / np.sqrt(N), f            # (1.36 / sqrt(N) is the 5 % point)
+        for t in (3.0, 4.0):                                       # the tails: counts against the normal law, 5 sigma of the Poisson count
+            expect = 2.0 * stats.norm.sf(t) * N
+            assert abs((np.abs(x) > t).sum() - expect) < 5.0 * np.sqrt(expect) + 3, (f, t)
+        assert np.abs(x).max() < 5.9                               # 24-bit uniforms end at 5.77 sigma
+    c = np.corrcoef(z)                                             # factor f and factor g of the same feature: independent streams
+    assert np.abs(c - np.eye(1 + k)).max() < 5.0 / np.sqrt(N)
+    z2 = (sweeps[1] - mu) * np.sqrt(lam)
+    assert abs(np.corrcoef(z[1], z2[1])[0, 1]) < 5.0 / np.sqrt(N)                  # sweep to sweep
+    assert abs(np.corrcoef(z[1, :-1], z[1, 1:])[0, 1]) < 5.0 / np.sqrt(N)           # feature j and j + 1
