@@ -191,6 +191,13 @@ def run_sgd_config(capi, name, n, k, nnz, rows, criteo, steps, warmup, with_cpu,
     avg = dev / max(launches, 1)
     achieved = per_ex * per_launch / avg / 1e9
     info = h.info()
+    traffic, tsrc = None, None
+    try:                                  # counter bytes of the dominant kernel from the committed PMC passes, if they are for this shape
+        for e in json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).values():
+            if (e.get("n"), e.get("k"), e.get("nnz"), e.get("examples_per_launch")) == (n, k, nnz, per_launch):
+                traffic, tsrc = e["hbm_bytes_per_launch"] + e.get("deferred_pass_bytes_per_launch", 0), "committed profile: " + e["source"]
+    except (OSError, ValueError, KeyError):
+        pass
     out = {"metric": "SGD training examples/sec at k=%d, nnz=%d, %.1e feat (%s)" % (k, nnz, n, name),
            "value": round(value, 1), "unit": "examples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": "f32", "data": "synthetic",
@@ -202,7 +209,7 @@ def run_sgd_config(capi, name, n, k, nnz, rows, criteo, steps, warmup, with_cpu,
                       "device": info.device_name.decode()},
            "roofline": {"bound": "hbm", "kernel": "k_fused<%d,EXACT> + deferred features, per batch" % info.k_padded,
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "v_read_frac": v_read_fraction(per_launch / avg, k, nnz), "traffic": None,
+                        "v_read_frac": v_read_fraction(per_launch / avg, k, nnz), "traffic": traffic, "traffic_source": tsrc,
                         "bytes_per_example": per_ex, "examples_per_launch": per_launch, "avg_launch_ms": round(avg * 1e3, 4),
                         "launches": launches, "deferred_features_per_example": round(deferred / (steps * rows), 4),
                         "launch_time": "epoch HIP-event time / batches"},

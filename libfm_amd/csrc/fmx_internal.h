@@ -47,7 +47,7 @@ struct Slot {
   uint64_t* cmask = nullptr;         // [n_rows] bit i: entry i's feature occurs more than once in the row's batch
   uint32_t* cseg = nullptr;          // [ncseg] batch-local indices of the segments k_apply_seg finishes
   uint32_t  ncseg = 0;
-  uint4*    cdesc = nullptr;         // [ncseg] the same list as {feature, first entry, end entry, index} records
+  CDesc*    cdesc = nullptr;         // [ncseg] the same list as 32-byte records {feature, first entry, end entry, index, first two occurrences}
   uint32_t  fused_cap = 0;           // longest row the k_fused instance of this slot keeps in registers
   std::vector<uint32_t> cbatch;      // [n_batches+1] first cseg entry of every batch
   // weight side stream (fmx_kernels.h row_sums; FMX_FLAG_KEEP_WSIDE): wside[i] = w[id of entry i] or NaN, lmask[row] = which entries are

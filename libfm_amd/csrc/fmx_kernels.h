@@ -758,6 +758,10 @@ k_apply(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uin
 //   w_new = w0 - lr*( sum_e mult_e*x_e + n_occ*regw*w0 )                                     (fm_sgd.h:38-43)
 // ----------------------------------------------------------------------------------------------
 struct TEntry { uint32_t e; float x; };     // (example index inside its batch, value)
+// one listed (deferred) segment as a 32-byte record: where it is AND its first two occurrences, so that the deferred pass reads the list as one
+// coalesced stream and goes straight to the multipliers / sums of those occurrences -- through the index it was descriptor -> {entry, entry} ->
+// {multiplier, sums}: one dependent round trip and two 64-byte requests per segment more (97 % of the bench's deferred features are pairs)
+struct CDesc { uint32_t feat, a, b, loc; uint32_t e0; float x0; uint32_t e1; float x1; };
 
 // sort keys: (batch << 32) | feature id ; payload: (value bits << 32) | example-in-batch  (== TEntry in memory)
 static __global__ void __launch_bounds__(256)
@@ -889,7 +893,7 @@ static __global__ void __launch_bounds__(256)
 k_seg_compact(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head, const uint32_t* __restrict__ cflag,
               const uint32_t* __restrict__ cpos, uint32_t nseg, const uint32_t* __restrict__ batch_seg, uint32_t* __restrict__ cseg,
               const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel, const uint64_t* __restrict__ row_ptr,
-              uint32_t n_rows, uint32_t B, uint4* __restrict__ cdesc) {
+              uint32_t n_rows, uint32_t B, CDesc* __restrict__ cdesc, const TEntry* __restrict__ vals) {
   // cdesc: the listed segment as ONE record {feature, first entry, end entry (both relative to the batch's entries), batch-local index}:
   // the deferred pass reads the list as a coalesced 16-byte stream instead of an index followed by three dependent gathers
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x)
@@ -899,7 +903,13 @@ k_seg_compact(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ he
       cseg[cpos[s]] = loc;
       const uint64_t r0 = (uint64_t)bt * B, r1 = min((uint64_t)(bt + 1) * B, (uint64_t)n_rows);
       const uint32_t end = (s + 1 < batch_seg[bt + 1]) ? seg_rel[s + 1] : (uint32_t)(row_ptr[r1] - row_ptr[r0]);
-      cdesc[cpos[s]] = make_uint4(seg_feat[s], seg_rel[s], end, loc);
+      CDesc d;
+      d.feat = seg_feat[s]; d.a = seg_rel[s]; d.b = end; d.loc = loc;
+      const uint32_t h0 = head[s];                               // sorted position of the segment's first entry (== its entry in t_ent)
+      const TEntry t0 = vals[h0];
+      d.e0 = t0.e; d.x0 = t0.x; d.e1 = 0u; d.x1 = 0.f;
+      if (end - d.a >= 2u) { const TEntry t1 = vals[h0 + 1]; d.e1 = t1.e; d.x1 = t1.x; }
+      cdesc[cpos[s]] = d;
     }
 }
 static __global__ void __launch_bounds__(256)
@@ -920,7 +930,7 @@ struct SegWork {
   const TEntry* t_ent; const uint32_t* seg_feat; const uint32_t* seg_rel; const uint32_t* seg_idx;
   uint32_t nseg, nseg_batch, batch_nnz;
   const float* S; const float* mult;
-  const uint4* cdesc;      // with seg_idx: the listed segments as {feature, first entry, end entry, index} records (nullptr: look them up)
+  const CDesc* cdesc;      // with seg_idx: the listed segments as 32-byte records incl. their first two occurrences (nullptr: look them up)
   unsigned long long* done_ctr; unsigned long long done_val;   // device hand-off: "everything before this launch on its stream has completed"
 };
 // SPW = segments per wavefront-block (<= 64).  64 for the dense form (millions of segments: plenty of wavefronts); 16 for
@@ -943,18 +953,28 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
   uint32_t jl = 0, al = 0, bl = 0, el = 0, e2l = 0; float xl = 0.f, ml = 0.f, x2l = 0.f, m2l = 0.f;
   if (lane < cnt) {
     if (sw.cdesc) {
-      const uint4 d = sw.cdesc[blk + lane];
+      const uint4* rec = reinterpret_cast<const uint4*>(sw.cdesc + blk + lane);
+      const uint4 d = rec[0], o = rec[1];
       jl = d.x; al = d.y; bl = d.z;
+      el = o.x; xl = __uint_as_float(o.y);
+      if (PRE2 && bl - al >= 2) { e2l = o.z; x2l = __uint_as_float(o.w); m2l = mult[e2l]; }
     } else {
       const uint32_t s = sw.seg_idx ? sw.seg_idx[blk + lane] : blk + lane;
       jl = sw.seg_feat[s];
       al = sw.seg_rel[s];
       bl = (s + 1 < sw.nseg_batch) ? sw.seg_rel[s + 1] : sw.batch_nnz;
+      const TEntry te = load_stream8(t_ent + al);
+      el = te.e; xl = te.x;
+      if (PRE2 && bl - al >= 2) { const TEntry t2 = load_stream8(t_ent + al + 1); e2l = t2.e; x2l = t2.x; m2l = mult[e2l]; }
     }
-    const TEntry te = load_stream8(t_ent + al);
-    el = te.e; xl = te.x;
-    if (PRE2 && bl - al >= 2) { const TEntry t2 = load_stream8(t_ent + al + 1); e2l = t2.e; x2l = t2.x; m2l = mult[e2l]; }
     ml = mult[el];
+  }
+  // one segment per wavefront (the small-batch path, where a batch is a latency chain): the third and later occurrences -- the dense fields'
+  // ids are met ~8-47 times per 512 rows -- are asked for NOW, with the first two's rows and sums, not a round trip later
+  TEntry te_pre; te_pre.e = 0; te_pre.x = 0.f; float tm_pre = 0.f;
+  if constexpr (SPW == 1 && EPI == 1 && PRE2) {
+    const uint32_t a0 = bcast_u32<1>(al, 0), b0 = bcast_u32<1>(bl, 0);
+    if (cnt && a0 + 2u + lane < b0) { te_pre = load_stream8(t_ent + a0 + 2u + lane); tm_pre = mult[te_pre.e]; }
   }
   for (uint32_t i = 0; i < cnt; i += EPI * U) {
     float v0[U][VEC], sf[U][VEC], sf2[PRE2 ? U : 1][VEC];
@@ -1012,7 +1032,8 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
           for (uint32_t base = i2; base < b; base += 64) {
             const uint32_t cc = min(64u, b - base);
             TEntry te; te.e = 0; te.x = 0.f; float tm = 0.f;
-            if (lane < cc) { te = load_stream8(t_ent + base + lane); tm = mult[te.e]; }
+            if (SPW == 1 && PRE2 && base == i2) { te = te_pre; tm = tm_pre; }          // (asked for with the descriptor, above)
+            else if (lane < cc) { te = load_stream8(t_ent + base + lane); tm = mult[te.e]; }
             for (uint32_t q0 = 0; q0 < cc; q0 += TL) {
               float s2[TL][VEC];
 #pragma unroll

@@ -206,9 +206,9 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
       SEG_CHK(hipStreamSynchronize(st));
       s.ncseg = last_pos + last_flag;
       SEG_CHK(hipMalloc(&s.cseg, (size_t)std::max<uint32_t>(s.ncseg, 1) * 4));
-      SEG_CHK(hipMalloc(&s.cdesc, (size_t)std::max<uint32_t>(s.ncseg, 1) * sizeof(uint4)));
+      SEG_CHK(hipMalloc(&s.cdesc, (size_t)std::max<uint32_t>(s.ncseg, 1) * sizeof(CDesc)));
       hipLaunchKernelGGL(k_seg_compact, dim3(2048), dim3(256), 0, st, keys_b, head, cflag, cpos, nseg, d_batch_seg, s.cseg,
-                         s.seg_feat, s.seg_rel, s.row_ptr, s.n_rows, B, s.cdesc);
+                         s.seg_feat, s.seg_rel, s.row_ptr, s.n_rows, B, s.cdesc, reinterpret_cast<const TEntry*>(vals_b));
       hipLaunchKernelGGL(k_seg_cbatch, dim3((n_batches + 256) / 256), dim3(256), 0, st, cpos, cflag, nseg, d_batch_seg, n_batches, d_cbatch);
       SEG_CHK(hipGetLastError());
       s.cbatch.resize((size_t)n_batches + 1);
@@ -222,7 +222,7 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
     s.cbatch.assign((size_t)n_batches + 1, 0);
     SEG_CHK(hipMalloc(&s.t_ent, 8));
     SEG_CHK(hipMalloc(&s.cseg, 4));
-    SEG_CHK(hipMalloc(&s.cdesc, sizeof(uint4)));
+    SEG_CHK(hipMalloc(&s.cdesc, sizeof(CDesc)));
     SEG_CHK(hipStreamSynchronize(st));
   }
   {  // first entry of every batch (row_ptr sampled at multiples of B)
