@@ -21,6 +21,7 @@ extern "C++" void als_free(fmx_handle h) {
   if (a.r_row) hipFree(a.r_row);
   if (a.r_pos) hipFree(a.r_pos);
   if (a.r_x) hipFree(a.r_x);
+  if (a.t_row) hipFree(a.t_row);
   if (a.dth) hipFree(a.dth);
   for (AlsBlock& b : a.blk) {
     if (b.level_list) hipFree(b.level_list);
@@ -147,10 +148,22 @@ static int als_build_rows(fmx_handle h, const Slot& s, AlsState& a, const std::v
       ROW_CHK(hipMemsetAsync(d_lvl, 0, std::min<size_t>(nl, nseg) * 4, st));          // (d_lvl is free after the sort keys were made)
       for (size_t l = 0; l < nl && l < nseg; l++)
         if (a.lev_ent[l + 1] - a.lev_ent[l] == s.n_rows)
-          hipLaunchKernelGGL(k_als_rows_check_dense, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 4096)), bl, 0, st, a.r_row + a.lev_ent[l], s.n_rows, d_lvl + l);
+          hipLaunchKernelGGL(k_als_rows_check_dense, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 4096)), bl, 0, st, a.r_row + a.lev_ent[l],
+                             a.r_x + a.lev_ent[l], s.n_rows, d_lvl + l);
       ROW_CHK(hipMemcpyAsync(flags.data(), d_lvl, std::min<size_t>(nl, nseg) * 4, hipMemcpyDeviceToHost, st));
       ROW_CHK(hipStreamSynchronize(st));
-      for (size_t l = 0; l < nl && l < nseg; l++) a.lev_dense[l] = (a.lev_ent[l + 1] - a.lev_ent[l] == s.n_rows && flags[l] == 0) ? 1 : 0;
+      bool any_unit = false;
+      for (size_t l = 0; l < nl && l < nseg; l++) {
+        const bool dense = a.lev_ent[l + 1] - a.lev_ent[l] == s.n_rows && (flags[l] & 1u) == 0;
+        a.lev_dense[l] = dense ? ((flags[l] & 2u) ? 1 : 2) : 0;
+        any_unit = any_unit || a.lev_dense[l] == 2;
+      }
+      if (any_unit) {                                                // the row-only stream of X^T for the levels of unit values
+        ROW_CHK(hipMalloc(&a.t_row, (size_t)nnz * 4));
+        hipLaunchKernelGGL(k_als_trow, gr, bl, 0, st, s.t_ent, (uint32_t)nnz, a.t_row);
+        ROW_CHK(hipGetLastError());
+        ROW_CHK(hipStreamSynchronize(st));
+      }
     }
   }
 done:
@@ -376,27 +389,30 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
       EQ* delta = sharded ? a.delta : nullptr;
       const uint32_t n_ent = (!sharded && a.split_min && a.r_row) ? a.lev_ent[l + 1] - a.lev_ent[l] : 0u;
       float2* dth = (n_ent && n_ent >= a.split_min) ? a.dth : nullptr;     // split step for this level?
+      const bool unit = dth && l < a.lev_dense.size() && a.lev_dense[l] == 2 && a.t_row;   // every value of the level is 1: 4-byte streams
+      const uint32_t* unit_rows = unit ? a.t_row : nullptr;
+      const float* lev_x = unit ? nullptr : a.r_x + a.lev_ent[l];
       if (f < 0) {
-        FMX_ALS_DRAW(false, cnt, s.t_ent, a.ldesc + a.level_ptr[l], cnt,
+        FMX_ALS_DRAW(false, cnt, s.t_ent, unit_rows, a.ldesc + a.level_ptr[l], cnt,
                      h->tb.w, h->tb.ws, 0, 0u, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
                      opts->seed, (uint64_t)(a.iter * 1024 + 1000), sh, delta, dth);
         if (dth && a.lev_dense[l]) hipLaunchKernelGGL((k_als_rows_dense<false>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
-                                    a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
+                                    a.r_pos + a.lev_ent[l], lev_x, n_ent, dth, a.e);
         else if (dth) hipLaunchKernelGGL((k_als_rows<false>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
                                     a.r_row + a.lev_ent[l], a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
       } else {
         const double* v_lambda = a.prior + (size_t)(1 + f) * 2 * NG;
         const double* v_mu = v_lambda + NG;
         if (a.vt)
-          FMX_ALS_DRAW(true, cnt, s.t_ent, a.ldesc + a.level_ptr[l], cnt,
+          FMX_ALS_DRAW(true, cnt, s.t_ent, unit_rows, a.ldesc + a.level_ptr[l], cnt,
                        a.vt + (size_t)f * a.vt_stride, 1u, 1, a.level_ptr[l], a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
                        opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta, dth);
         else
-          FMX_ALS_DRAW(true, cnt, s.t_ent, a.ldesc + a.level_ptr[l], cnt,
+          FMX_ALS_DRAW(true, cnt, s.t_ent, unit_rows, a.ldesc + a.level_ptr[l], cnt,
                        h->tb.V + f, h->tb.rs, 0, 0u, a.e, opts->alpha, v_lambda, v_mu, h->grp, opts->do_sample,
                        opts->seed, (uint64_t)(a.iter * 1024 + f), sh, delta, dth);
         if (dth && a.lev_dense[l]) hipLaunchKernelGGL((k_als_rows_dense<true>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
-                                    a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
+                                    a.r_pos + a.lev_ent[l], lev_x, n_ent, dth, a.e);
         else if (dth) hipLaunchKernelGGL((k_als_rows<true>), dim3(std::min<uint32_t>((n_ent + 255) / 256, 16384)), dim3(256), 0, st,
                                     a.r_row + a.lev_ent[l], a.r_pos + a.lev_ent[l], a.r_x + a.lev_ent[l], n_ent, dth, a.e);
       }

@@ -418,7 +418,7 @@ k_als_ldesc(const uint32_t* __restrict__ seg_list, uint32_t n_list, const uint32
 
 template <bool IS_V, int G>
 __global__ void __launch_bounds__(256)
-k_als_draw(const TEntry* __restrict__ t_ent, const uint4* __restrict__ ldesc, uint32_t n_list,
+k_als_draw(const TEntry* __restrict__ t_ent, const uint32_t* __restrict__ t_row, const uint4* __restrict__ ldesc, uint32_t n_list,
            float* __restrict__ param, uint32_t pstride, int param_by_pos, uint32_t pos0, EQ* __restrict__ eq,
            double alpha, const double* __restrict__ lambda_g, const double* __restrict__ mu_g, const uint32_t* __restrict__ attr_group,
            int do_sample, uint64_t seed, uint64_t stream, const Shard sh, EQ* __restrict__ delta, float2* __restrict__ dth) {
@@ -426,6 +426,8 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint4* __restrict__ ldesc, ui
   // one draws.  delta != nullptr (feature shards): {e, q} are left alone and the change is recorded instead.
   // dth != nullptr (split step): only the column sums and the draw happen here; {old, new} value of list entry li goes to
   // dth[li] and k_als_rows applies the change to {e, q} in ROW order (streams instead of a second random pass).
+  // t_row != nullptr: every value of this level's columns is 1 (one-hot fields): the column is read as a 4-byte row stream (the kernel is
+  // bound by fabric REQUESTS -- 52.7 G/s, DESIGN.md section 4b --: half the stream's bytes are 6 % fewer requests)
   constexpr uint32_t GPW = 64 / G;                      // feature groups per wavefront
   const uint32_t lane = (threadIdx.x & 63u) % G;         // lane inside its group
   const uint32_t grp = (threadIdx.x & 63u) / G;
@@ -444,7 +446,8 @@ k_als_draw(const TEntry* __restrict__ t_ent, const uint4* __restrict__ ldesc, ui
     const double th = (double)(param_by_pos ? *pt : als_param_load(pt));
     double t_he = 0.0, t_hh = 0.0;
     for (uint32_t i = a + lane; i < b; i += G) {
-      const TEntry te = als_stream8(t_ent + i);
+      TEntry te;
+      if (t_row) { te.e = __builtin_nontemporal_load(t_row + i); te.x = 1.f; } else te = als_stream8(t_ent + i);
       const double x = (double)te.x;
       const EQ c = eq[te.e];                                       // one 16-byte gather: e and q of the row
       double h;
@@ -542,7 +545,7 @@ k_als_rows_dense(const uint32_t* __restrict__ r_pos, const float* __restrict__ r
   typedef double v2d __attribute__((ext_vector_type(2)));
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_ent; t += gridDim.x * blockDim.x) {
     const uint32_t pos = __builtin_nontemporal_load(r_pos + t);
-    const double x = (double)__builtin_nontemporal_load(r_x + t);
+    const double x = r_x ? (double)__builtin_nontemporal_load(r_x + t) : 1.0;       // (r_x == nullptr: a level of unit values)
     v2d c = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(eq + t));      // {e, q}
     const float2 tt = dth[pos];
     const double th = (double)tt.x, d = (double)tt.x - (double)tt.y;              // theta_old - theta
@@ -554,9 +557,16 @@ k_als_rows_dense(const uint32_t* __restrict__ r_pos, const float* __restrict__ r
 }
 // r_row[t] == t for the n entries of a level?  (flag raised otherwise)
 static __global__ void __launch_bounds__(256)
-k_als_rows_check_dense(const uint32_t* __restrict__ r_row, uint32_t n, uint32_t* __restrict__ flag) {
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
-    if (r_row[t] != t) *flag = 1u;
+k_als_rows_check_dense(const uint32_t* __restrict__ r_row, const float* __restrict__ r_x, uint32_t n, uint32_t* __restrict__ flag) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    if (r_row[t] != t) atomicOr(flag, 1u);                          // bit 0: not "row t at position t"
+    if (r_x[t] != 1.0f) atomicOr(flag, 2u);                         // bit 1: a value other than 1
+  }
+}
+// the rows of X^T's entries alone (for the levels of unit values)
+static __global__ void __launch_bounds__(256)
+k_als_trow(const TEntry* __restrict__ t_ent, uint32_t nnz, uint32_t* __restrict__ t_row) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) t_row[i] = t_ent[i].e;
 }
 // set-up of the row-ordered lists: key = (level of the entry's feature, row), value = entry index in X^T
 static __global__ void __launch_bounds__(256)

@@ -97,7 +97,8 @@ struct AlsState {
   uint32_t* r_row = nullptr; uint32_t* r_pos = nullptr; float* r_x = nullptr;   // [nnz], level after level
   float2*   dth = nullptr;        // [largest level]
   std::vector<uint32_t> lev_ent;  // [n_levels + 1] entry range of each level in r_*
-  std::vector<uint8_t> lev_dense; // [n_levels] the level's entries are the rows 0 .. N-1 in order (k_als_rows_dense)
+  std::vector<uint8_t> lev_dense; // [n_levels] the level's entries are the rows 0 .. N-1 in order (k_als_rows_dense); 2: ... and every value is 1
+  uint32_t* t_row = nullptr;      // [nnz] the rows of X^T's entries alone: what a level of unit values streams instead of {row, value}
   uint32_t  split_min = 0;        // levels with at least this many entries take the split step (0: none)
   double*   prior = nullptr;      // [1 + k][2][G]: per coordinate family (row 0 = w, 1+f = v_f) lambda[G] then mu[G]
   std::vector<double> prior_host;
