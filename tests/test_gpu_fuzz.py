@@ -483,3 +483,54 @@ def test_empty_and_single_row_data_sets(capi, oracle):
     h.als_sweep(1.0, 2.0)
     h.als_end()
     h.close()
+
+
+@pytest.mark.parametrize("seed", _seeds(8))
+def test_random_shape_large_batches_hand_off_and_side_stream(capi, oracle, seed):
+    """the one-pass form where a batch holds >= 32 768 rows (the recurrence on the side stream): random rows / batch / micro-chunk / lag,
+    the two orderings of the streams (device-side hand-off, events) and the weight side stream kept or not, at random -- parameters and
+    the predictions of the pass that follows (out of the side stream when it was kept) against the oracle's rule."""
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.choice([4, 8, 16, 33, 64]))
+    task = int(rng.integers(0, 2))
+    rows = int(rng.integers(66000, 120000))
+    if rng.integers(0, 2):
+        nnz = int(rng.choice([4, 9, 16]))
+        n = nnz * int(rng.integers(2000, 40000))
+        ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed, zipf=float(rng.choice([0.0, 0.9])), classification=bool(task))
+    else:
+        n = int(rng.integers(20000, 200000))
+        ent, rp, y = datagen.ragged_real(n, rows, int(rng.integers(3, 20)), seed, classification=bool(task), empty_every=int(rng.choice([0, 13])))
+    batch = int(rng.choice([32768, 33001, 50000, 65536]))
+    chunk = int(rng.choice([64, 256, 300, 512]))
+    lag = int(rng.integers(1, 5))
+    flags = (capi.FLAG_EVENT_SYNC if rng.integers(0, 2) else 0) | (capi.FLAG_KEEP_WSIDE if rng.integers(0, 2) else 0)
+    lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
+    lr = min(0.004, 0.9 / (chunk * (1.0 if task == 0 else 0.25)))
+    d = oracle.Data(ent, rp, y)
+    what = "seed %d: n=%d k=%d rows=%d batch=%d chunk=%d lag=%d flags=%d" % (seed, n, k, rows, batch, chunk, lag, flags)
+
+    def run(pert):
+        m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.004)
+        m.v[:] = oracle.init_values(31 + seed, n, k, 0.05) * (1.0 + pert)
+        m.w[:] = oracle.init_values(32 + seed, n, 1, 0.05)[0]
+        m.w0 = 0.02
+        for _ in range(2):
+            oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=lag)
+        return m.w0, m.w.copy(), m.v.copy(), oracle.predict_raw(m, d)
+    fl, (o_w0, o_w, o_v, o_p) = _floor(run)
+    if fl is None or fl[2] > 1e-3:
+        assert seed >= 8, what + ": a case of the suite's own seeds must be well-conditioned"
+        return
+    h = capi.Handle(n, k, True, True, task, 0.001, 0.002, 0.004, lr, lo, hi)
+    h.set_params(0.02, oracle.init_values(32 + seed, n, 1, 0.05)[0], oracle.init_values(31 + seed, n, k, 0.05))
+    h.upload_rows(0, ent, rp, y)
+    for _ in range(2):
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, chunk, flags, lag)
+    assert bool(h.evaluate(0).flags & capi.EVAL_WSIDE) == bool(flags & capi.FLAG_KEEP_WSIDE), what
+    np.testing.assert_allclose(h.predict(0, d.n_rows), o_p, rtol=RTOL, atol=5e-5 + 8 * fl[3], err_msg=what)
+    w0, w, v = h.get_params()
+    assert abs(w0 - o_w0) <= RTOL * abs(o_w0) + 1e-5 + 8 * fl[0], what
+    np.testing.assert_allclose(w, o_w, rtol=RTOL, atol=2e-5 + 8 * fl[1], err_msg=what)
+    np.testing.assert_allclose(v, o_v, rtol=RTOL, atol=2e-5 + 8 * fl[2], err_msg=what)
+    h.close()
