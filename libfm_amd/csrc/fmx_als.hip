@@ -391,7 +391,7 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
       float2* dth = (n_ent && n_ent >= a.split_min) ? a.dth : nullptr;     // split step for this level?
       const bool unit = dth && l < a.lev_dense.size() && a.lev_dense[l] == 2 && a.t_row;   // every value of the level is 1: 4-byte streams
       const uint32_t* unit_rows = unit ? a.t_row : nullptr;
-      const float* lev_x = unit ? nullptr : a.r_x + a.lev_ent[l];
+      const float* lev_x = (dth && !unit) ? a.r_x + a.lev_ent[l] : nullptr;   // (no split step: the row-ordered lists do not exist)
       if (f < 0) {
         FMX_ALS_DRAW(false, cnt, s.t_ent, unit_rows, a.ldesc + a.level_ptr[l], cnt,
                      h->tb.w, h->tb.ws, 0, 0u, a.e, opts->alpha, a.prior, a.prior + NG, h->grp, opts->do_sample,
