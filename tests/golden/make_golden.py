@@ -135,15 +135,23 @@ MCMC_CASES = {
     "mcmc_cls_fields": dict(gen="onehot_fields", train=dict(n_features=600, nnz=6, n_rows=4000, seed=41),
                             test=dict(n_features=600, nnz=6, n_rows=1000, seed=41, _skip=4000),
                             cfg=dict(task="c", k0=1, k1=1, k=4, iters=40, init_stdev=0.1, seed=1)),
+    # round 4: the bench's factor count (the bands above are k = 4 / 8): generated and banded on its own, `--mcmc-only mcmc_reg_ml_k64`
+    "mcmc_reg_ml_k64": dict(gen="movielens_shaped", train=dict(n_users=300, n_items=200, n_rows=6000, seed=17),
+                            test=dict(n_users=300, n_items=200, n_rows=1500, seed=17, _skip=6000),
+                            cfg=dict(task="r", k0=1, k1=1, k=64, iters=40, init_stdev=0.1, seed=42)),
     "mcmc_reg_ml_groups": dict(gen="movielens_shaped", train=dict(n_users=300, n_items=200, n_rows=6000, seed=13),
                                test=dict(n_users=300, n_items=200, n_rows=1500, seed=13, _skip=6000), groups=("split", 300), n_nominal=500,
                                cfg=dict(task="r", k0=1, k1=1, k=8, iters=40, init_stdev=0.1, seed=42)),
 }
 
 
-def make_mcmc():
+def make_mcmc(only=None):
     """statistical fixtures: the reference's MCMC (libc rand() stream) on a train/test split of ONE planted model."""
     for name, case in MCMC_CASES.items():
+        if only and name not in only:
+            continue
+        if not only and name == "mcmc_reg_ml_k64":
+            continue                                          # (added in round 4 without touching the round-1 fixtures)
         gen = getattr(datagen, case["gen"])
         kw = dict(case["train"])
         n_tr, n_te = kw["n_rows"], case["test"]["n_rows"]
@@ -382,12 +390,17 @@ def main():
         print("%-22s n=%d k=%d rows=%d/%d  eval[-1]=%s" % (name, init.n, init.k, tr.n_rows, te.n_rows, ev[-1]))
 
 
-def make_mcmc_seed_band(seeds=range(101, 113)):
+def make_mcmc_seed_band(seeds=range(101, 113), only=None):
     """the REFERENCE's own seed-to-seed distribution on the MCMC fixtures: -seed changes its libc rand() stream (initial
     model AND every draw).  Per fixture: the test metric (RMSE / accuracy) of the posterior-mean prediction for each seed
     and the seed-averaged prediction.  tests/test_gpu_mcmc.py holds the mean and spread of OUR chains to this band."""
     out = {}
+    band_file = os.path.join(HERE, "mcmc_ref_seed_band.npz")
+    if only:                                                  # add / refresh single fixtures, keep the rest of the band file as it is
+        out = dict(np.load(band_file))
     for name, case in MCMC_CASES.items():
+        if (only and name not in only) or (not only and name == "mcmc_reg_ml_k64"):
+            continue
         z = np.load(os.path.join(HERE, name + ".npz"))
         cfg = case["cfg"]
         tr = O.Data(z["train_entries"], z["train_row_ptr"], z["train_target"])
@@ -424,7 +437,11 @@ def make_mcmc_seed_band(seeds=range(101, 113)):
 
 
 if __name__ == "__main__":
-    if "--mcmc-seed-band" in sys.argv:
+    if "--mcmc-only" in sys.argv:    # one MCMC fixture + its 12-seed band, nothing else touched
+        names = sys.argv[sys.argv.index("--mcmc-only") + 1].split(",")
+        make_mcmc(only=names)
+        make_mcmc_seed_band(only=names)
+    elif "--mcmc-seed-band" in sys.argv:
         make_mcmc_seed_band()        # does not touch the other fixtures
     else:
         main()
