@@ -197,7 +197,13 @@ template <int VEC, int BIT> __device__ __forceinline__ void load_row(const float
     load_vec<VEC>(p, out);
   }
 }
+#ifndef FMX_V_SC1
+#define FMX_V_SC1 0          // experiments: 1 = the one-pass kernel's row stores write through (agent scope) instead of staying dirty in L2 until the launch ends
+#endif
 template <int VEC, int BIT> __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&in)[VEC]) {
+  if constexpr (FMX_V_SC1 == 1 && BIT == 2 && VEC == 1) {
+    __hip_atomic_store(p, in[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else
   if constexpr ((FMX_V_NT & BIT) != 0) {
     if constexpr (VEC == 1) { __builtin_nontemporal_store(in[0], p); }
     else if constexpr (VEC == 2) {

@@ -506,9 +506,14 @@ def test_random_shape_large_batches_hand_off_and_side_stream(capi, oracle, seed)
     lag = int(rng.integers(1, 5))
     flags = (capi.FLAG_EVENT_SYNC if rng.integers(0, 2) else 0) | (capi.FLAG_KEEP_WSIDE if rng.integers(0, 2) else 0)
     lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
-    lr = min(0.004, 0.9 / (chunk * (1.0 if task == 0 else 0.25)))
+    curv = 1.0 if task == 0 else 0.25
+    # a step size the batch rule is STABLE at on these rows (lr * curvature * batch * C <= 1/2): beyond it the iteration
+    # amplifies every fp32 rounding and no implementation can be held to the fp64 oracle (soak seeds 233 / 248: Zipf ids, batch 33 001 --
+    # one-pass and two-pass forms alike 1e-2 off, side stream and hand-off identical to the plain forms)
+    C = datagen.collision_mass(ent, rows, n)
+    lr = min(0.004, 0.9 / (chunk * curv), 0.5 / (curv * batch * max(C, 1e-12)))
     d = oracle.Data(ent, rp, y)
-    what = "seed %d: n=%d k=%d rows=%d batch=%d chunk=%d lag=%d flags=%d" % (seed, n, k, rows, batch, chunk, lag, flags)
+    what = "seed %d: n=%d k=%d rows=%d batch=%d chunk=%d lag=%d flags=%d lr=%.3g" % (seed, n, k, rows, batch, chunk, lag, flags, lr)
 
     def run(pert):
         m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.004)
