@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 5
+#define FMX_ABI_VERSION 6
 
 enum {
   FMX_OK = 0,
@@ -122,10 +122,12 @@ typedef struct fmx_sgd_opts {
                                learn_rate 0.01; never below 32).  An explicit batch is honoured (fmx_epoch_stats::status reports FMX_STAT_UNSTABLE;
                                with FMX_FLAG_REJECT_UNSTABLE the call fails with FMX_E_ARG instead of training).
                                HOGWILD: rows per launch during which w0 is frozen (macro-batch), 0 = 262144 */
-  uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default: the largest power of two <= 256
-                             * with learn_rate * chunk * curvature <= 1 (curvature 1 for regression, 1/4 for classification).
-                             * The reference moves w0 after every example (fm_sgd.h:34-37); a chunk is one batch step of
-                             * size learn_rate * chunk on the bias and oscillates when that product exceeds 2 / curvature. */
+  uint32_t w0_chunk;        /* w0 micro-chunk of the bias recurrence; 0 = library default (fmx_default_w0_chunk): the largest power
+                             * of two <= FMX_W0_CHUNK_CAP with learn_rate * chunk * curvature <= 1 (curvature 1 for regression, 1/4
+                             * for classification).  The reference moves w0 after every example (fm_sgd.h:34-37); a chunk is one
+                             * batch step of size learn_rate * chunk on the bias and oscillates when that product exceeds
+                             * 2 / curvature -- and the smaller the chunk, the closer the rule's bias follows the reference's path
+                             * (chunk 1 IS the reference's bias path).  fmx_epoch_stats::w0_chunk_used reports the value used. */
   uint32_t flags;           /* FMX_FLAG_* */
   uint32_t bias_lag;        /* with FMX_FLAG_BIAS_LAG / FMX_APPLY_FUSED: the multipliers of batch b use the bias as it was after
                                the recurrence of batch b - bias_lag (0 = 1 = the bias of the batch start).  fmx_sgd_epoch with
@@ -174,7 +176,7 @@ typedef struct fmx_epoch_stats {
   double   batch_gain;      /* learn_rate * curvature * batch_used * C (curvature 1 regression, 1/4 classification): the batch
                                rule follows the reference's online loop for <= 1, degrades above and diverges beyond ~2 */
   uint32_t status;          /* FMX_STAT_* */
-  uint32_t reserved;
+  uint32_t w0_chunk_used;   /* MINIBATCH / HOGWILD: the micro-chunk of the bias recurrence this epoch ran with */
   double   setup_seconds;   /* host wall-clock this call spent on ONE-TIME work for the slot (not part of device_seconds): the rows' collision mass
                                and the bucketing of the entries by (batch, feature) -- the segments, masks and lists the MINIBATCH forms
                                walk; libFM never shuffles (fm_learn_sgd_element.h:56), so they are built once per (slot, batch size).
@@ -223,7 +225,8 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out);
 int fmx_destroy(fmx_handle h);
 /* fmx_destroy keeps ONE placed arena per device alive for the next fmx_create on that device (which then takes it over without
  * probing: fmx_place_info::pool = 0) -- the memory of the largest arena destroyed so far stays allocated until it is reused, this call
- * returns it, a later placement runs short of memory, or the process ends.  FMX_ARENA_CACHE=0 in the environment turns this off. */
+ * returns it, ANY device allocation of the library runs short of memory (it is then given back and the allocation retried once), or
+ * the process ends.  Other processes on the device do not see it as free before that.  FMX_ARENA_CACHE=0 in the environment turns this off. */
 int fmx_release_cached_memory(void);
 /* how the parameter tables of a handle were placed */
 typedef struct fmx_place_info {
@@ -242,6 +245,11 @@ int fmx_place_layout(uint64_t v_bytes, uint64_t w_bytes, uint64_t *chunk_bytes, 
 /* text of the last error on this handle (h may be NULL: last creation error). Never NULL. */
 const char *fmx_last_error(fmx_handle h);
 int fmx_abi_version(void);
+/* fmx_sgd_opts::w0_chunk = 0 resolves to this (host arithmetic; task = FMX_TASK_*): the largest power of two <= FMX_W0_CHUNK_CAP with
+ * learn_rate * chunk * curvature <= 1.  Until ABI 5 the cap was 256; the reference advances the bias per example (fm_sgd.h:34-37) and the
+ * finer recurrence ends 17x closer to its bias path at the bench shape. */
+#define FMX_W0_CHUNK_CAP 32
+uint32_t fmx_default_w0_chunk(double learn_rate, int task);
 /* number of visible HIP devices (0 when none / no driver) */
 int fmx_device_count(void);
 
@@ -372,9 +380,10 @@ int fmx_evaluate(fmx_handle h, int slot, fmx_eval *out);
 
 /* ---- fm_learn_sgd_element::learn, one epoch (fm_learn_sgd_element.h:56-67) -------------------- */
 int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_epoch_stats *stats);
-/* On a handle that is one rank of a communicator (fmx_comm_init_rank, one process per GPU) this call is COLLECTIVE the first time it
- * runs for a slot: the shards' shares of the collision mass are summed over RCCL, so every rank must make it (fmx_sgd_epoch does);
- * the sum is cached per slot afterwards. */
+/* On a handle that is one rank of a communicator (fmx_comm_init_rank, one process per GPU) this call is COLLECTIVE, every time: the
+ * shards' shares of the collision mass are summed over RCCL (one 8-byte all-reduce), so every rank must make it -- and fmx_sgd_epoch,
+ * which resolves its batch through it, is collective in the same sense.  (Until ABI 5 the sum was cached per rank, which made the
+ * decision to enter the collective per rank too: a rank that re-uploaded its slot entered alone.) */
 int fmx_sgd_batch_info(fmx_handle h, int slot, const fmx_sgd_opts *opts, fmx_batch_info *out);
 /* the same decision as host arithmetic (no device needed): the batch fmx_sgd_epoch runs with for rows of the given collision mass --
  * requested != 0: that batch, with its gain and status; requested == 0: 262144 cut to the largest power of two (never below 32) with

@@ -58,7 +58,7 @@ class EpochStats(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("batches", C.c_uint64), ("device_seconds", C.c_double),
                 ("main_kernel_seconds", C.c_double), ("main_kernel_launches", C.c_uint64),
                 ("max_feature_count", C.c_uint32), ("batch_used", C.c_uint32), ("deferred_features", C.c_uint64),
-                ("collision_mass", C.c_double), ("batch_gain", C.c_double), ("status", C.c_uint32), ("reserved", C.c_uint32),
+                ("collision_mass", C.c_double), ("batch_gain", C.c_double), ("status", C.c_uint32), ("w0_chunk_used", C.c_uint32),
                 ("setup_seconds", C.c_double), ("phase_seconds", C.c_double * 4)]
 
 
@@ -112,6 +112,7 @@ SYMBOLS = [
     ("fmx_destroy", C.c_int, [H]),
     ("fmx_last_error", C.c_char_p, [H]),
     ("fmx_abi_version", C.c_int, []),
+    ("fmx_default_w0_chunk", C.c_uint32, [C.c_double, C.c_int]),
     ("fmx_release_cached_memory", C.c_int, []),
     ("fmx_device_count", C.c_int, []),
     ("fmx_set_params", C.c_int, [H, C.c_double, C.c_void_p, C.c_void_p]),
@@ -197,6 +198,11 @@ def load():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def default_w0_chunk(learn_rate, task):
+    """what fmx_sgd_opts::w0_chunk = 0 resolves to (host arithmetic inside libfmx.so; no device needed)"""
+    return int(load().fmx_default_w0_chunk(float(learn_rate), int(task)))
 
 
 def _ptr(a):

@@ -441,7 +441,8 @@ int fmx_group_set_params(fmx_group g, double w0, const double* w, const double* 
   const uint64_t n = cur->cfg.num_attribute;
   const int k = cur->cfg.num_factor, KP = cur->KP;
   if (k > 0 && !v) return gfail(g, FMX_E_ARG, "fmx_group_set_params: v is NULL but num_factor > 0");
-  for (auto m : g->hs) { cur = m; GCHK(g, lag_flush(m)); }
+  for (auto m : g->hs) { cur = m; GCHK(g, lag_flush(m)); touch_w(m); }   // (new linear weights: every slot's weight side stream is stale -- a
+                                                                          //  one-handle group forwards FMX_FLAG_KEEP_WSIDE / predict to its member)
   const uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 1u << 18);
   Staged st;
   int rc = staged_alloc(g, (size_t)chunk * (size_t)std::max(k, 1) * sizeof(double), &st);
@@ -657,6 +658,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     stats->main_kernel_seconds = stats->device_seconds; stats->main_kernel_launches = n_batch;
     stats->max_feature_count = h0->slots[slot].max_seg_count;
     stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
+    stats->w0_chunk_used = opts.w0_chunk ? opts.w0_chunk : fmx_default_w0_chunk(h0->cfg.learn_rate, h0->cfg.task);
     for (auto m : g->hs) stats->setup_seconds = std::max(stats->setup_seconds, m->setup_acc);
     for (uint64_t b = 0; b < n_timed; b++) {
       float a = 0, x = 0, u = 0;

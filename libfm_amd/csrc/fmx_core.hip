@@ -338,12 +338,29 @@ static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int 
   if (h->device >= 0 && h->device < 16) {                            // an arena this device's previous handle left behind?
     std::lock_guard<std::mutex> lk(g_arena_mu);
     ArenaCacheEntry& c = g_arena_cache[h->device];
+    // a PREFIX of the cached chunk order serves a smaller model only if it still spreads both tables over both classes: the order is a
+    // Bresenham spread (X X Y X Y ... for odd T or a short second class), so the prefix is recounted, never assumed to alternate
+    auto prefix_ok = [&](const Arena& A) -> bool {
+      if (A.cls.size() < T) return false;
+      auto both = [&](size_t c0, size_t c1) {                        // chunks [c0, c1]: one chunk cannot span two classes; more must
+        if (c1 <= c0) return true;
+        bool s0 = false, s1 = false;
+        for (size_t k = c0; k <= c1 && k < T; k++) { s0 |= A.cls[k] == 0; s1 |= A.cls[k] == 1; }
+        return s0 && s1;
+      };
+      const size_t v_last = v_bytes ? (v_bytes - 1) / CH : 0;
+      const size_t w_first = w_off / CH, w_last = w_bytes ? (w_off + w_bytes - 1) / CH : w_first;
+      return both(0, v_last) && both(w_first, w_last);
+    };
+    if (c.full && c.a.chunk_bytes == CH && c.a.n_chunks >= T && !prefix_ok(c.a)) { arena_release(c.a, nullptr); c.full = false; }   // probe again
     if (c.full && c.a.chunk_bytes == CH && c.a.n_chunks >= T) {
       Arena A = c.a;
       c.a = Arena(); c.full = false;
       for (size_t k = T; k < A.n_chunks; k++) (void)hipMemUnmap((char*)A.va + k * CH, CH);   // the tail goes back to the device
       A.n_chunks = T; A.bytes = (size_t)T * CH;
-      A.per_class[0] = (T + 1) / 2; A.per_class[1] = T / 2;         // (a prefix of the alternating sequence)
+      A.cls.resize(T);
+      A.per_class[0] = A.per_class[1] = 0;
+      for (uint8_t cc : A.cls) if (cc < 2) A.per_class[cc]++;       // (recounted from the prefix actually taken)
       A.pool = 0;                                                    // nothing probed this time
       er = hipMemsetAsync(A.va, 0, A.bytes, h->stream);
       if (er == hipSuccess) {
@@ -467,6 +484,7 @@ static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int 
   // the arena's chunks in mapping order: the two best-stocked classes alternately; when the second runs short (pool bound reached)
   // its chunks are spread evenly among the first's, then any other class fills up
   std::vector<size_t> pick;
+  std::vector<uint8_t> pick_cls;
   {
     std::vector<size_t> X = (cx != SIZE_MAX) ? of[cx] : std::vector<size_t>(), Y = (cy != SIZE_MAX) ? of[cy] : std::vector<size_t>();
     std::vector<size_t> rest;
@@ -477,10 +495,10 @@ static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int 
     size_t ix = 0, iy = 0, ir = 0, err_acc = 0;
     for (uint32_t c = 0; c < T; c++) {
       err_acc += ny;
-      if (iy < ny && err_acc >= T) { err_acc -= T; pick.push_back(Y[iy++]); }
-      else if (ix < nx) pick.push_back(X[ix++]);
-      else if (iy < Y.size()) pick.push_back(Y[iy++]);
-      else if (ir < rest.size()) pick.push_back(rest[ir++]);
+      if (iy < ny && err_acc >= T) { err_acc -= T; pick.push_back(Y[iy++]); pick_cls.push_back(1); }
+      else if (ix < nx) { pick.push_back(X[ix++]); pick_cls.push_back(0); }
+      else if (iy < Y.size()) { pick.push_back(Y[iy++]); pick_cls.push_back(1); }
+      else if (ir < rest.size()) { pick.push_back(rest[ir++]); pick_cls.push_back(2); }
     }
     if (pick.size() < T) { arena_pool_release(P); return hipErrorOutOfMemory; }
     h->arena.per_class[0] = (uint32_t)ix; h->arena.per_class[1] = (uint32_t)iy;
@@ -509,6 +527,7 @@ static hipError_t arena_build(fmx_handle h, size_t v_bytes, size_t w_bytes, int 
   arena_pool_release(P);                                             // the unused chunks go back; the mapped ones live on through their mapping
   Arena& A = h->arena;
   A.va = va; A.bytes = (size_t)T * CH; A.reserved_bytes = A.bytes; A.chunk_bytes = CH; A.n_chunks = T; A.pool = pool; A.classes_seen = (uint32_t)refs.size(); A.method = 2;
+  A.cls = pick_cls;
   er = hipMemsetAsync(va, 0, A.bytes, h->stream);
   if (er != hipSuccess) { arena_free(h); return er; }
   *V_out = (float*)va;

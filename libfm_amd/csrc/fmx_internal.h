@@ -127,6 +127,8 @@ struct Arena {
   uint32_t classes_seen = 0;
   double   seconds = 0.0;        // host time of the whole placement
   int      method = 0;           // fmx_place_info::method
+  std::vector<uint8_t> cls;      // [n_chunks] which class chunk i came from (0 / 1: the two the tables are built from, 2: a filler) -- what a
+                                 // later, smaller model that takes over a PREFIX of this arena recounts per_class from (arena_build)
 };
 
 struct fmx_context_s {
@@ -221,6 +223,21 @@ int group_allreduce_f64(fmx_group_s* g, const std::vector<double*>& bufs, size_t
 void comm_free(fmx_handle h);                                            // fmx_comm.hip: communicator, group membership, exchange buffers
 int comm_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats);   // fmx_comm.hip
 int comm_sum_double(fmx_handle h, double* v);                            // fmx_comm.hip
+
+// Device allocations of the library go through this: one classified arena per device outlives its handle (fmx_core.hip, "arena cache") and
+// can hold tens of GB that nothing uses; an allocation that runs out of memory gives that cache back and tries once more (round-4 advisor:
+// slot uploads, scratch, ALS state, the weight side stream, the collision histogram all failed with OOM next to the idle cache).
+void arena_cache_drop(int device);                                       // fmx_core.hip
+inline hipError_t fmx_malloc_retry(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess) { arena_cache_drop(d); e = hipMalloc(p, bytes); }
+  }
+  return e;
+}
+#define hipMalloc(p, n) fmx_malloc_retry((void**)(p), (size_t)(n))
 
 #define HIPCHK(h, expr)                                                                         \
   do {                                                                                          \

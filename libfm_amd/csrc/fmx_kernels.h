@@ -131,6 +131,22 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
 #undef FMX_DPP_ADD
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
+// sum over ONE group of C consecutive lanes (C = 16 / 32 / 64; group `sub` = lanes [sub*C, sub*C + C)), returned wave-uniform: the four
+// intra-row steps of wave_sum_dpp leave every lane with its DPP row's sum, row_bcast15 / 31 then fold rows into halves / the wavefront.
+// What the sub-piece form of the bias recurrence reduces a micro-chunk of 16 / 32 / 64 examples with (k_scan1, scan_small).
+template <int C> __device__ __forceinline__ float group_sum_dpp(float x, uint32_t sub) {
+  static_assert(C == 16 || C == 32 || C == 64, "one DPP row, half a wavefront or the wavefront");
+#define FMX_DPP_ADD(ctrl, rmask)                                                                        \
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false))
+  FMX_DPP_ADD(0xB1, 0xf);    // quad_perm(1,0,3,2)
+  FMX_DPP_ADD(0x4E, 0xf);    // quad_perm(2,3,0,1)
+  FMX_DPP_ADD(0x124, 0xf);   // row_ror:4
+  FMX_DPP_ADD(0x128, 0xf);   // row_ror:8
+  if constexpr (C >= 32) FMX_DPP_ADD(0x142, 0xa);   // row_bcast:15 -> rows 1,3 hold rows 0+1, 2+3
+  if constexpr (C >= 64) FMX_DPP_ADD(0x143, 0xc);   // row_bcast:31 -> row 3 holds everything
+#undef FMX_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (int)(sub * (uint32_t)C + (uint32_t)C - 1u)));
+}
 // all-reduce over the EPI sub-groups that hold the same factor (lane bits >= log2(LPR))
 template <int LPR> __device__ __forceinline__ float subgroup_allsum(float x) {
 #pragma unroll
@@ -613,7 +629,13 @@ constexpr size_t SCAN4_LDS_BYTES = (size_t)(SCAN4_BUFS * 2 * SCAN_TILE + 8) * si
 // leaves fma -> v_exp -> add -> v_rcp -> fma on the chain, a and b prepared ahead.  Summation order: the four examples of a lane
 // pairwise, the lanes by DPP, pieces of a chunk in order (deterministic; not bit-identical to k_scan / k_scan4, which no result is
 // compared with bit by bit across kernels).  60 VGPRs: fits next to five 85-VGPR gather wavefronts per SIMD.
-template <bool WRITE_MULT, int TASK, bool CH256>                  // CH256: the micro-chunk IS 256 examples (the default): every piece ends one
+// CH: 256 = the micro-chunk IS one piece (every piece ends one); 0 = any multiple of 256; 16 / 32 / 64 / 128 = the SUB-PIECE form (round 5):
+// the reference moves w0 after every example (fm_sgd.h:34-37) and how finely the recurrence follows that path is what sets the batch rule's
+// distance from the online loop (micro-chunk 256 ends 0.025 from the online bias, 32 ends 0.0014), so the default
+// micro-chunk is now below one piece.  A piece is then read as four 64-example vectors (element j of lane l = example 64 j + l: conflict-free
+// dword reads, coalesced multiplier stores) and a micro-chunk is one DPP row (16), half a wavefront (32), a vector (64) or two (128): per
+// micro-chunk the chain is fma -> v_exp -> add -> v_rcp -> mul -> 4-6 DPP adds -> v_readlane -> two fp64 fma -> cvt, ~60 ns.
+template <bool WRITE_MULT, int TASK, int CH>
 __global__ void __launch_bounds__(256)
 k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
         Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult, const Handoff hw) {
@@ -704,7 +726,7 @@ k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32
       const uint32_t n_here = FULL ? 256u : min(256u, tnc - c0);
       chunk_acc += tot;
       chunk_pos += n_here;
-      if ((CH256 && FULL) || chunk_pos == chunk || t0 + c0 + n_here == n_rows) {
+      if ((CH == 256 && FULL) || chunk_pos == chunk || t0 + c0 + n_here == n_rows) {
         double term = (double)chunk_acc;
         term = fma((double)chunk_pos * reg0_d, (double)w0s, term);
         w0 = fma(neg_lr_d, term, w0);
@@ -712,12 +734,75 @@ k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32
         chunk_acc = 0.f; chunk_pos = 0;
       }
     };
+    if constexpr (CH == 0 || CH == 256) {
     if (tn == SCAN_TILE) {
 #pragma unroll
       for (uint32_t c0 = 0; c0 < SCAN_TILE; c0 += 256) piece(c0, (uint32_t)SCAN_TILE, std::true_type());
     } else {
       for (uint32_t c0 = 0; c0 < tn; c0 += 256) {
         if (c0 + 256 <= tn) piece(c0, tn, std::true_type()); else piece(c0, tn, std::false_type());
+      }
+    }
+    } else {
+      // ---- sub-piece form: micro-chunks of CH = 16 / 32 / 64 / 128 examples ------------------------------------------------
+      constexpr int CL = (CH >= 64) ? 64 : CH;                   // lanes of one micro-chunk
+      constexpr int NS = 64 / CL;                                // micro-chunks per 64-example vector
+      constexpr int EPC = (CH >= 64) ? CH / 64 : 1;              // vectors per micro-chunk (CH = 128: two)
+      float rS[4], yS[4];                                        // the operands of the NEXT piece (read off the chain)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { rS[j] = sr[64 * j + lane]; yS[j] = sy[64 * j + lane]; }
+      auto piece_sub = [&](uint32_t c0, uint32_t tnc, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        float rr[4], yy[4]; bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          ok[j] = FULL || (c0 + 64u * (uint32_t)j + lane < tnc);
+          rr[j] = ok[j] ? rS[j] : 0.f; yy[j] = ok[j] ? yS[j] : 0.f;    // (past the batch: stale tile contents, never NaN into the sums)
+        }
+        if (c0 + 256 < tnc) {                                    // (c0 + 511 < SCAN_TILE: inside the tile buffer)
+#pragma unroll
+          for (int j = 0; j < 4; j++) { rS[j] = sr[c0 + 256 + 64 * j + lane]; yS[j] = sy[c0 + 256 + 64 * j + lane]; }
+        }
+        float aa[4], bb[4];
+        if constexpr (TASK == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { aa[j] = LOG2E * yy[j]; bb[j] = aa[j] * rr[j]; }
+        }
+        const float gs = h.sgda ? 2.0f : 1.0f;
+#pragma unroll
+        for (int j0 = 0; j0 < 4; j0 += EPC) {
+#pragma unroll
+          for (int sb = 0; sb < NS; sb++) {
+            float m[EPC]; float msum = 0.f;
+#pragma unroll
+            for (int q = 0; q < EPC; q++) {
+              const int j = j0 + q;
+              if constexpr (TASK == 1) {
+                m[q] = -yy[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(aa[j], w0s, bb[j])));   // (y = 0 past the end: -0)
+              } else {
+                const float pc = fmaxf(h.min_target, fminf(h.max_target, w0s + rr[j]));
+                m[q] = ok[j] ? gs * (pc - yy[j]) : 0.f;
+              }
+              msum += m[q];
+            }
+            if constexpr (WRITE_MULT) {
+#pragma unroll
+              for (int q = 0; q < EPC; q++)
+                if (ok[j0 + q] && (NS == 1 || lane / (uint32_t)CL == (uint32_t)sb)) mult[t0 + c0 + 64u * (uint32_t)(j0 + q) + lane] = m[q];
+            }
+            const float tot = group_sum_dpp<CL>(msum, (uint32_t)sb);
+            const uint32_t lo = c0 + 64u * (uint32_t)j0 + (uint32_t)(sb * CL);       // first example of this micro-chunk inside the tile
+            const uint32_t n_here = FULL ? (uint32_t)CH : (lo < tnc ? min((uint32_t)CH, tnc - lo) : 0u);
+            double term = (double)tot;                             // (n_here = 0: every multiplier was masked, the bias stays)
+            term = fma((double)n_here * reg0_d, (double)w0s, term);
+            w0 = fma(neg_lr_d, term, w0);
+            w0s = (float)w0;
+          }
+        }
+      };
+#pragma unroll 1
+      for (uint32_t c0 = 0; c0 < tn; c0 += 256) {
+        if (c0 + 256 <= tn) piece_sub(c0, tn, std::true_type()); else piece_sub(c0, tn, std::false_type());
       }
     }
   }
@@ -1133,7 +1218,7 @@ struct ScanSmall { const float* rest; const float* target; const double* w0_in; 
 __device__ __forceinline__ void scan_small(const ScanSmall sc, const Hyper& h) {
   const uint32_t lane = threadIdx.x & 63u;
   double w0 = *sc.w0_in;
-  if (sc.n_rows <= 1024u && (sc.chunk & 63u) == 0) {
+  if (sc.n_rows <= 1024u && ((sc.chunk & 63u) == 0 || sc.chunk == 32u || sc.chunk == 16u)) {
     // the whole batch in registers first (one round trip to memory, not one per micro-chunk): element c0 + i + 64 j of a chunk
     // sits in lane i, register (c0 / 64 + j)
     float r[16], y[16];
@@ -1142,6 +1227,26 @@ __device__ __forceinline__ void scan_small(const ScanSmall sc, const Hyper& h) {
       const uint32_t i = (uint32_t)j * 64u + lane;
       r[j] = (i < sc.n_rows) ? sc.rest[i] : 0.f;
       y[j] = (i < sc.n_rows) ? sc.target[i] : 0.f;
+    }
+    if (sc.chunk < 64u) {
+      // micro-chunks of 16 / 32 examples (the default since round 5): a DPP row / half of the 64-example register vector at a time
+      const uint32_t C = sc.chunk, ns = 64u / C;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        if ((uint32_t)j * 64u < sc.n_rows) {                     // (wave-uniform)
+          const uint32_t i = (uint32_t)j * 64u + lane;
+          for (uint32_t sb = 0; sb < ns; sb++) {
+            const float w0s = h.k0 ? (float)w0 : 0.f;
+            const float m = (i < sc.n_rows) ? multiplier_fast(h, w0s + r[j], y[j]) : 0.f;
+            const float tot = (C == 32u) ? group_sum_dpp<32>(m, sb) : group_sum_dpp<16>(m, sb);
+            const uint32_t lo = (uint32_t)j * 64u + sb * C;
+            const uint32_t nc = (lo < sc.n_rows) ? min(C, sc.n_rows - lo) : 0u;
+            if (h.k0 && nc) w0 -= (double)h.lr * ((double)tot + (double)nc * (double)h.reg0 * (double)w0s);
+          }
+        }
+      }
+      if (lane == 0) *sc.w0_out = w0;
+      return;
     }
     const uint32_t per = sc.chunk >> 6;                        // registers per micro-chunk
     for (uint32_t c0 = 0; c0 < sc.n_rows; c0 += sc.chunk) {

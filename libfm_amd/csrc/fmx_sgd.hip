@@ -7,14 +7,11 @@ namespace {
 // multipliers of a chunk and applying them at once is a batch step of size lr * chunk on a coordinate whose curvature is
 // up to 1 (regression) or 1/4 (logistic) PER EXAMPLE, so lr * chunk * curvature must stay below 2 or the bias
 // oscillates with growing amplitude (observed: classification, lr = 0.02, chunk = 1024 -> w0 = +-3..6, accuracy 0.50).
-// Default: the largest power of two with lr * chunk * curvature <= 1, capped at 256.  An explicit w0_chunk is honoured.
-uint32_t default_w0_chunk(const fmx_config& c) {
-  const double curv = (c.task == FMX_TASK_REGRESSION) ? 1.0 : 0.25;
-  const double lim = (c.learn_rate > 0) ? 1.0 / (c.learn_rate * curv) : 256.0;
-  uint32_t chunk = 1;
-  while (chunk < 256u && (double)(chunk * 2) <= lim) chunk *= 2;
-  return chunk;
-}
+// Default: the largest power of two with lr * chunk * curvature <= 1, capped at FMX_W0_CHUNK_CAP.  The cap is what sets how
+// closely the batch rule follows the reference's bias PATH (and through it the reference's predictions): at the bench shape the
+// rule's bias ends 0.025 from the online loop's at chunk 256 and 0.0014 at chunk 32, so the cap went from
+// 256 to 32 in round 5 -- k_scan1's sub-piece form evaluates such chunks at ~60 ns each.  An explicit w0_chunk is honoured.
+uint32_t default_w0_chunk(const fmx_config& c) { return fmx_default_w0_chunk(c.learn_rate, c.task); }
 
 // row slots (ZR) of the k_fused instance used for a slot: the smallest instance whose registers hold the longest row
 template <int KP> constexpr bool fused_zr_ok(int zr) { return Map<KP>::VEC * zr <= 128; }
@@ -57,6 +54,13 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------
 // SGD
 // ---------------------------------------------------------------------------------------------
+uint32_t fmx_default_w0_chunk(double learn_rate, int task) {
+  const double curv = (task == FMX_TASK_REGRESSION) ? 1.0 : 0.25;
+  const double lim = (learn_rate > 0) ? 1.0 / (learn_rate * curv) : (double)FMX_W0_CHUNK_CAP;
+  uint32_t chunk = 1;
+  while (chunk < (uint32_t)FMX_W0_CHUNK_CAP && (double)(chunk * 2) <= lim) chunk *= 2;
+  return chunk;
+}
 int fmx_partial_floats(fmx_handle h, uint32_t batch, uint64_t* n_floats) {
   if (!h || !n_floats) return FMX_E_ARG;
   *n_floats = (uint64_t)batch * (uint64_t)(h->KP + 1);
@@ -108,9 +112,10 @@ extern "C++" int sgd_resolve_batch(fmx_handle h, Slot& s, const fmx_sgd_opts* op
     int rc = ensure_coll_mass(h, s);
     if (rc) return rc;
     C = s.coll_mass;
-    if (h->comm && h->cfg.shard_world > 1) {                 // one process per GPU: a collective, once per slot (include/fmx.h)
-      if (s.coll_mass_world < 0.0) { rc = comm_sum_double(h, &C); if (rc) return rc; s.coll_mass_world = C; }
-      C = s.coll_mass_world;
+    if (h->comm && h->cfg.shard_world > 1) {                 // one process per GPU: a collective on EVERY call (include/fmx.h) -- a per-rank
+      rc = comm_sum_double(h, &C);                            // cache made the decision to enter it per-rank too: a rank that re-uploaded its
+      if (rc) return rc;                                      // slot entered alone and the job hung (round-4 advisor).  8 bytes per epoch.
+      s.coll_mass_world = C;
     }
   }
   resolve_batch(h->cfg, C, opts ? opts->batch : 0u, FMX_DEFAULT_BATCH, 1.0, bi);
@@ -256,14 +261,20 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     // micro-chunks that are multiples of 256 examples: k_scan1 (one wavefront on the chain, four contiguous examples per lane, a 128 KiB
     // tile pipeline fed by the workgroup's four wavefronts); else, and for
     // batches of a few thousand rows (the 128 KiB-LDS workgroup costs more to place than the recurrence takes): one plain wavefront
-    const bool tiled = n_rows > 8192u && (chunk % 256u) == 0;
+    // ... or, round 5, the sub-piece form of the same kernel for micro-chunks of 16 / 32 / 64 / 128 examples (the default is now below 256)
+    const bool sub = chunk == 16u || chunk == 32u || chunk == 64u || chunk == 128u;
+    const bool tiled = n_rows > 8192u && ((chunk % 256u) == 0 || sub);
     // (function attributes are per-device state: the 128 KiB dynamic-LDS limit is raised once per handle, not per process)
 #define FMX_SCAN1(WM, TK, C256) do { auto kf = k_scan1<WM, TK, C256>;                                                              \
       if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCAN4_LDS_BYTES)); h->lds_raised.insert((const void*)kf); } \
       hipLaunchKernelGGL(kf, dim3(1), dim3(256), SCAN4_LDS_BYTES, st, rest, target, n_rows, chunk, hy, wi, wo, mult, hw); } while (0)
 #define FMX_SCAN(WM, TK) do { \
-      if (tiled && chunk == 256u) FMX_SCAN1(WM, TK, true); \
-      else if (tiled)             FMX_SCAN1(WM, TK, false); \
+      if (tiled && chunk == 256u) FMX_SCAN1(WM, TK, 256); \
+      else if (tiled && chunk == 128u) FMX_SCAN1(WM, TK, 128); \
+      else if (tiled && chunk == 64u)  FMX_SCAN1(WM, TK, 64); \
+      else if (tiled && chunk == 32u)  FMX_SCAN1(WM, TK, 32); \
+      else if (tiled && chunk == 16u)  FMX_SCAN1(WM, TK, 16); \
+      else if (tiled)             FMX_SCAN1(WM, TK, 0); \
       else                        hipLaunchKernelGGL((k_scan<WM, TK>), dim3(1), dim3(64), 0, st, rest, target, n_rows, chunk, hy, wi, wo, mult, hw); } while (0)
     if (hy.task == 0) { if (mult) FMX_SCAN(true, 0); else FMX_SCAN(false, 0); }
     else              { if (mult) FMX_SCAN(true, 1); else FMX_SCAN(false, 1); }
@@ -478,7 +489,9 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   // streams are ordered by the DATA -- bias slots W[0 .. n_batch] that start as "pending", a counter the deferred-feature launch of a batch
   // advances (fmx_kernels.h: "Device-side hand-off") -- instead of four event packets per batch; W[i] = the bias after the recurrence of batch
   // i - 1, k_fused of batch b reads W[max(0, b - d + 1)], the recurrence of batch b reads W[b] and publishes W[b + 1].
-  const bool handoff = side && h->handoff && hy.k0 && !(opts->flags & FMX_FLAG_EVENT_SYNC);
+  // (bias_lag 1 keeps the events: there every wavefront of k_fused WAITS for a slot the one-workgroup recurrence of the previous batch
+  //  publishes, and nothing guarantees that kernel a CU once k_fused has filled the chip -- round-4 advisor; at lag >= 2 the slot is a batch old)
+  const bool handoff = side && h->handoff && hy.k0 && d >= 2 && !(opts->flags & FMX_FLAG_EVENT_SYNC);
   double* W = nullptr;
   unsigned long long hbase = 0;
   if (handoff) {
@@ -732,6 +745,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
       stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
     }
     stats->setup_seconds = h->setup_acc;
+    if (opts->mode != FMX_SGD_SEQUENTIAL) stats->w0_chunk_used = opts->w0_chunk ? opts->w0_chunk : default_w0_chunk(h->cfg);
     if (opts->mode == FMX_SGD_MINIBATCH && timed && opts->apply != FMX_APPLY_FUSED) {
       double tot = 0;
       for (size_t i = 0; i + 1 < ev_used; i += 2) {

@@ -56,7 +56,7 @@ def test_config1_sgd_n1e7_k32_nnz16(capi, oracle):
     st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)
     assert st.batch_used == 262144 and st.status == 0 and st.batches == 2
     assert st.deferred_features > 1.5 * rows                      # most examples leave their sums behind at this shape
-    oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, 262144, 256, bias_lag=lag)
+    oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, 262144, st.w0_chunk_used, bias_lag=lag)
     assert_rows(h, m, ids)
     np.testing.assert_allclose(h.predict(0, rows), oracle.predict_raw(m, d), rtol=1e-4, atol=2e-5)
     h.close()
@@ -78,7 +78,7 @@ def test_config2_sgd_criteo_shaped_at_size(capi, oracle):
     for _ in range(2):                                            # second epoch: every frequent feature has moved
         st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)
         assert st.batch_used == bi.batch and st.batches >= 64 and st.deferred_features > rows
-        oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, bi.batch, min(256, bi.batch), bias_lag=lag)
+        oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, bi.batch, st.w0_chunk_used, bias_lag=lag)
     assert_rows(h, m, ids, atol=2e-5)
     np.testing.assert_allclose(h.predict(0, rows), oracle.predict_raw(m, d), rtol=1e-4, atol=5e-5)
     h.close()
@@ -147,7 +147,7 @@ def test_headline_rule_vs_the_online_loop_at_the_bench_shape(capi, oracle):
     m_on = m_rule.copy()
     h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)
     oracle.sgd_epoch_online(m_on, d, 1, 0.01, -1.0, 1.0)
-    oracle.sgd_epoch_minibatch(m_rule, d, 1, 0.01, -1.0, 1.0, 262144, 256, bias_lag=lag)
+    oracle.sgd_epoch_minibatch(m_rule, d, 1, 0.01, -1.0, 1.0, 262144, capi.default_w0_chunk(0.01, 1), bias_lag=lag)
     assert_rows(h, m_rule, ids)                                   # the device IS the rule ...
     m_dev = m_rule.copy()
     m_dev.w[:], m_dev.v[:] = h.get_param_rows(ids)

@@ -97,9 +97,9 @@ def test_fused_minibatch_at_the_bench_batch_against_oracle(capi, oracle):
     h = capi.Handle(N, K, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
     h.init_params(0.0, 0.05, 11)
     h.synth_rows(0, 2024, 40_000_000, rows, NNZ)
-    d, m, ids = submodel_minibatch(capi, oracle, h, 2024, 40_000_000, rows, batch, 256, lag)
+    d, m, ids = submodel_minibatch(capi, oracle, h, 2024, 40_000_000, rows, batch, capi.default_w0_chunk(0.01, 1), lag)
     st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)       # batch 0 / chunk 0: what bench.py passes
-    assert st.batch_used == batch and st.status == 0 and st.batches == 2
+    assert st.batch_used == batch and st.status == 0 and st.batches == 2 and st.w0_chunk_used == capi.default_w0_chunk(0.01, 1) <= 64
     assert 1.0 * rows < st.deferred_features < 1.5 * rows
     w, v = h.get_param_rows(ids)
     np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=1e-6)

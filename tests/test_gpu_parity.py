@@ -170,7 +170,9 @@ def test_minibatch_kilo_chunks(capi, oracle, task, batch, chunk, lag):
 
 
 @pytest.mark.parametrize("task", [0, 1])
-@pytest.mark.parametrize("batch,chunk", [(9001, 256), (8193, 256), (12325, 512), (20000, 1024), (16384, 256), (9001, 768)])
+@pytest.mark.parametrize("batch,chunk", [(9001, 256), (8193, 256), (12325, 512), (20000, 1024), (16384, 256), (9001, 768),
+                                         # round 5, the sub-piece form (micro-chunks below one 256-example piece; 32 is the library default):
+                                         (9001, 32), (8193, 16), (12325, 64), (20000, 128), (16384, 32), (9007, 64), (8200, 128), (19999, 16)])
 @pytest.mark.parametrize("apply_name", ["fused", "segmented"])
 def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name):
     """k_scan1 (batches of more than 8192 rows, micro-chunks of multiples of 256): the default micro-chunk (every piece ends one) and longer
@@ -202,7 +204,8 @@ def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name):
 
 
 @pytest.mark.parametrize("task", [0, 1])
-@pytest.mark.parametrize("batch,chunk,lag", [(32768, 256, 2), (32768, 768, 1), (40001, 256, 3), (36000, 1024, 2)])
+@pytest.mark.parametrize("batch,chunk,lag", [(32768, 256, 2), (32768, 768, 1), (40001, 256, 3), (36000, 1024, 2),
+                                             (32768, 32, 2), (40001, 64, 1), (36000, 16, 3), (33000, 128, 2), (40001, 0, 2)])   # (0: the default)
 @pytest.mark.parametrize("events", [False, True])
 def test_side_stream_recurrence_of_the_one_pass_form(capi, oracle, task, batch, chunk, lag, events):
     """the one-pass form at batches >= 32 768: the recurrence runs on the side stream WITHOUT writing multipliers (k_scan1<false, ...>: the
@@ -215,17 +218,18 @@ def test_side_stream_recurrence_of_the_one_pass_form(capi, oracle, task, batch, 
         y = (y * 0.5 + 0.1).astype(np.float32)
     d = oracle.Data(ent, row_ptr, y)
     lo, hi = (float(np.quantile(y, 0.1)), float(np.quantile(y, 0.9))) if task == 0 else (-1.0, 1.0)
-    lr = min(0.01, 0.9 / (chunk * (1.0 if task == 0 else 0.25)))
+    lr = min(0.01, 0.9 / (max(chunk, 1) * (1.0 if task == 0 else 0.25)))
     m = oracle.Model(n, k, True, True, 0.002, 0.001, 0.003)
     m.v[:] = oracle.init_values(5, n, k, 0.05)
     m.w0 = 0.05
     h = capi.Handle(n, k, True, True, task, 0.002, 0.001, 0.003, lr, lo, hi)
     h.set_params(m.w0, m.w, m.v)
     h.upload_rows(0, ent, row_ptr, y)
+    used = chunk or capi.default_w0_chunk(lr, task)
     for _ in range(2):
         st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, chunk, capi.FLAG_EVENT_SYNC if events else 0, lag)
-        assert st.batches == (rows + batch - 1) // batch
-        oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=lag)
+        assert st.batches == (rows + batch - 1) // batch and st.w0_chunk_used == used
+        oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, used, bias_lag=lag)
     w0, w, v = h.get_params()
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
@@ -309,7 +313,10 @@ def test_fused_equals_segmented(capi, oracle, name, batch, chunk):
 
 
 @pytest.mark.parametrize("task,batch,chunk,lag", [(1, 3000, 1024, 1), (0, 4096, 1024, 2), (1, 1500, 256, 3), (1, 9001, 256, 2),
-                                                  (0, 700, 512, 2), (1, 2048, 64, 4)])
+                                                  (0, 700, 512, 2), (1, 2048, 64, 4),
+                                                  # round 5: micro-chunks of 16 / 32 on the small-batch recurrence (scan_small's register path up to
+                                                  # 1024 rows, its loop beyond) -- what batch-cut rows with frequent features run by default
+                                                  (1, 512, 32, 2), (0, 700, 16, 1), (1, 1000, 32, 1), (1, 1024, 16, 2), (1, 3000, 32, 2), (0, 520, 32, 3)])
 def test_fused_minibatch_many_batches_and_lags(capi, oracle, task, batch, chunk, lag):
     """several batches per epoch with every bias-lag depth: the ring of bias slots / rest buffers, ragged last batch, the
     four-wavefront recurrence kernel, collisions inside and across batches (4000 features, 54 000 entries)"""

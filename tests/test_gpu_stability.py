@@ -112,7 +112,7 @@ def test_default_batch_on_criteo_shaped_rows_is_the_oracle_rule(capi, oracle, ap
         else:
             st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 0, 0, 0, 0)
         assert st.batch_used == B and st.status == capi.STAT_BATCH_CUT and st.batch_gain <= 1.0
-        O.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, B, min(256, B), bias_lag=lag)
+        O.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, B, st.w0_chunk_used, bias_lag=lag)
     w0, w, v = h.get_params()
     np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(w, m.w, rtol=1e-4, atol=2e-5)
