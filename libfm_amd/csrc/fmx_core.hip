@@ -669,6 +669,11 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     CREATE_CHK(hipMemsetAsync(h->handoff_ctr, 0, 2 * sizeof(unsigned long long), h->stream));
     const char* e = getenv("FMX_HANDOFF");
     h->handoff = !(e && e[0] == '0');
+    CREATE_CHK(hipMalloc(&h->pit_ctr, (PIT_MAX_IT + 1) * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc(&h->pit_slots, (size_t)2 * PIT_MAX_WG * 4 * sizeof(double)));
+    CREATE_CHK(hipMemsetAsync(h->pit_slots, 0, (size_t)2 * PIT_MAX_WG * 4 * sizeof(double), h->stream));
+    const char* sc = getenv("FMX_SCAN");
+    h->scan_pit = !(sc && strcmp(sc, "serial") == 0);
   }
   {  // the side stream runs the one-workgroup bias recurrence next to chip-filling gathers: give it priority so
      // that its workgroup is placed as soon as any CU has room
@@ -729,6 +734,8 @@ int fmx_destroy(fmx_handle h) {
   if (h->w0) hipFree(h->w0);
   if (h->w0_pp) hipFree(h->w0_pp);
   if (h->handoff_ctr) hipFree(h->handoff_ctr);
+  if (h->pit_ctr) hipFree(h->pit_ctr);
+  if (h->pit_slots) hipFree(h->pit_slots);
   if (h->w0_slots) hipFree(h->w0_slots);
   if (h->stream2) hipStreamDestroy(h->stream2);
   if (h->acc) hipFree(h->acc);
@@ -763,7 +770,7 @@ int fmx_synchronize(fmx_handle h) {
   { int _rc = lag_flush(h); if (_rc) return _rc; }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return FMX_OK;
+  return scan_error_check(h);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -157,6 +157,11 @@ struct fmx_context_s {
   unsigned long long  handoff_seq = 0;         // host: value of the counter before the running epoch
   uint32_t*   handoff_err = nullptr;        // device: a wait ran into its bound
   uint32_t    handoff_err_host = 0;
+  // the parallel-in-time bias recurrence (k_scan_pit): arrival counters of its grid-wide exchanges + the workgroups' slots
+  bool        scan_pit = true;              // FMX_SCAN=serial in the environment of fmx_create: the one-wavefront chain (k_scan1 / k_scan) instead
+  unsigned long long* pit_ctr = nullptr;    // [PIT_MAX_IT + 1], zeroed on the launch's stream before every launch
+  double*     pit_slots = nullptr;          // [2][PIT_MAX_WG][4]
+  bool        pit_used = false;             // a launch since the error word was last read
   uint64_t    w_version = 1;                // bumped by every entry point that may change a linear weight (a slot's side stream is valid for ONE value)
   int        num_cu = 256;
   double*    acc = nullptr;      // 4 doubles of reduction scratch
@@ -207,6 +212,7 @@ constexpr uint32_t FMX_DEFAULT_BATCH = 262144u;                          // fmx_
 int sgd_resolve_batch(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, fmx_batch_info* bi);   // fmx_sgd.hip: + the shards' shares
 int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st);   // fmx_sgd.hip
 int lag_flush(fmx_handle h);                                             // fmx_sgd.hip
+int scan_error_check(fmx_handle h);                                      // fmx_sgd.hip: the device's error word after k_scan_pit launches (streams drained)
 void sgda_free(fmx_handle h);                                            // fmx_sgd.hip
 void als_free(fmx_handle h);                                             // fmx_als.hip
 enum { GROUP_SINGLE = 0, GROUP_LOOPBACK = 1, GROUP_RCCL = 2 };

@@ -479,6 +479,186 @@ k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, u
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// SHORT rows (round 5): several examples per wavefront.  A feature shard of P GPUs sees nnz / P entries per example -- 4 at P = 8 -- and a
+// wavefront that gathers 4 rows, reduces, stores and retires keeps 4 x 256 B in flight where the one-pass kernel of a full row keeps 32:
+// k_rowsums ran at 3.2 TB/s on a P = 8 shard (profiles/r04_shard_probe_p8_kernel_stats.csv).  Here a wavefront takes G CONSECUTIVE examples
+// (G ~ 24 / mean row length): their entries are one contiguous run of the CSR, gathered 32 rows at a time into registers exactly like
+// k_fused does for one long row; lane l holds entry l and the example it belongs to, the factor sums are accumulated entry by entry (ids,
+// values, example indices broadcast by v_readlane) and an example is flushed -- S row, scalar -- when the next one begins.  Empty examples
+// flush zeros.  Needs one row per wave-wide load (KP >= 64).
+// ----------------------------------------------------------------------------------------------
+constexpr int MULTI_ZR = 32;                                           // row slots per round
+constexpr int MULTI_GMAX = 16;                                         // examples per wavefront, at most
+template <int KP, bool WRITE_S, bool FINISH>
+__global__ void __launch_bounds__(256)
+k_rowsums_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t n_rows,
+                const Tab tb, int k1, float* __restrict__ S, float* __restrict__ scal, uint32_t G) {
+  constexpr int VEC = Map<KP>::VEC;
+  static_assert(Map<KP>::EPI == 1, "one row per wave-wide load");
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t e0 = wave0 * G; e0 < n_rows; e0 += nwaves * G) {
+    const uint32_t ge = min(G, n_rows - e0);                          // examples of this group
+    const uint64_t rp = row_ptr[row0 + e0 + min(lane, ge)];            // lane j <= ge: where example e0 + j begins (lane ge: where the group ends)
+    const uint64_t a0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
+    const uint32_t rel = (uint32_t)(rp - a0);                          // ... relative to the group's first entry
+    const uint32_t total = bcast_u32<1>(rel, ge);
+    float sum[VEC]; float sq = 0.f, lin = 0.f;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) sum[v] = 0.f;
+    uint32_t cur = 0;                                                  // the example being accumulated
+    auto flush = [&]() {
+      const size_t e = (size_t)e0 + cur;
+      if (WRITE_S) store_vec<VEC>(S + e * KP + lane * VEC, sum);
+      float part = -0.5f * sq;
+      if (FINISH) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      }
+      part = wave_sum_dpp(part);
+      if (lane == 0) scal[e] = part + lin;
+#pragma unroll
+      for (int v = 0; v < VEC; v++) sum[v] = 0.f;
+      sq = 0.f; lin = 0.f; cur++;
+    };
+    for (uint32_t base = 0; base < total; base += MULTI_ZR) {
+      const uint32_t cnt = min((uint32_t)MULTI_ZR, total - base);
+      Entry en; en.id = 0; en.value = 0.f;
+      float wl = 0.f;
+      if (lane < cnt) {
+        en = load_stream8(ent + a0 + base + lane);
+        if (k1) wl = load_w(tb.w + (size_t)en.id * tb.ws) * en.value;
+      }
+      uint32_t ex = 0;                                                 // which example entry base + lane belongs to: the begins at or before it
+      for (uint32_t j = 1; j < ge; j++) ex += (base + lane >= bcast_u32<1>(rel, j)) ? 1u : 0u;
+      float vr[MULTI_ZR][VEC];
+#pragma unroll
+      for (int t = 0; t < MULTI_ZR; t++) {
+        const uint32_t id = bcast_u32<1>(en.id, t);
+        if ((uint32_t)t < cnt) load_row<VEC, 4>(tb.V + (size_t)id * tb.rs + lane * VEC, vr[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < MULTI_ZR; t++) {
+        const uint32_t ex_t = bcast_u32<1>(ex, t);
+        const float x = bcast_f32<1>(en.value, t), wx = bcast_f32<1>(wl, t);
+        if ((uint32_t)t < cnt) {
+          while (cur < ex_t) flush();                                  // (wave-uniform) the examples that ended before this entry, empty ones included
+          lin += wx;
+#pragma unroll
+          for (int v = 0; v < VEC; v++) { const float d = vr[t][v] * x; sum[v] += d; sq = fmaf(d, d, sq); }
+        }
+      }
+    }
+    while (cur < ge) flush();
+  }
+}
+
+// The UPDATE of a shard's short rows, example-major: the second half of the step for the features that occur ONCE in their batch (the others
+// are k_apply_seg's, like in k_fused<FUSED_APPLY>).  The dense owner pass (k_apply_seg over ALL segments) re-reads the 256-byte S_e per ENTRY
+// -- feature order scatters an example's entries -- which is a third of its traffic at 4 entries per example; here S_e is read once per
+// example: the wavefront stages the reduced sums of its G examples in LDS (a per-lane column store: lane f only ever reads what lane f
+// wrote, no barrier) and every entry picks its example's row by a wave-uniform index.
+// FUSED (bias-lag schedule): rest_e = c_e + 1/2 sum_f S_ef^2 and the multiplier are computed HERE from the reduced buffer -- the launches of
+// k_rest_from_partial and k_mult and their round trips through rest[] / mult[] drop out; rest[] and mult[] are still written (the bias
+// recurrence reads rest[], the deferred-feature pass reads mult[]).
+template <int KP, bool FUSED>
+__global__ void __launch_bounds__(256)
+k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint64_t row0, uint32_t n_rows,
+              const Tab tb, Hyper h, const double* __restrict__ w0_ptr, const float* __restrict__ S, const float* __restrict__ cpart,
+              float* __restrict__ rest_out, float* __restrict__ mult, const uint64_t* __restrict__ cmask, uint32_t G) {
+  constexpr int VEC = Map<KP>::VEC;
+  static_assert(Map<KP>::EPI == 1, "one row per wave-wide load");
+  __shared__ float s_S[4][MULTI_GMAX][KP];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  float (*sS)[KP] = s_S[wib];
+  const float w0s = (FUSED && h.k0) ? (float)(*w0_ptr) : 0.f;
+  for (uint32_t e0 = wave0 * G; e0 < n_rows; e0 += nwaves * G) {
+    const uint32_t ge = min(G, n_rows - e0);
+    const uint64_t rp = row_ptr[row0 + e0 + min(lane, ge)];
+    const uint64_t a0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
+    const uint32_t rel = (uint32_t)(rp - a0);
+    const uint32_t total = bcast_u32<1>(rel, ge);
+    // the examples' reduced sums: lane f keeps column f of every example in LDS; multipliers: lane j holds example j's
+    float sv[MULTI_GMAX][VEC];
+#pragma unroll
+    for (int j = 0; j < MULTI_GMAX; j++)
+      if ((uint32_t)j < ge) load_vec<VEC>(S + ((size_t)e0 + j) * KP + lane * VEC, sv[j]);
+    float mreg = 0.f, creg = 0.f, yreg = 0.f, rreg = 0.f;
+    if (lane < ge) {
+      if (FUSED) { creg = cpart[e0 + lane]; yreg = target[row0 + e0 + lane]; }
+      else mreg = mult[e0 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < MULTI_GMAX; j++) {
+      if ((uint32_t)j < ge) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) sS[j][lane * VEC + v] = sv[j][v];
+        if (FUSED) {
+          float part = 0.f;
+#pragma unroll
+          for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sv[j][v], sv[j][v], part);
+          const float rest = wave_sum_dpp(part) + bcast_f32<1>(creg, j);
+          const float m = multiplier(h, w0s + rest, bcast_f32<1>(yreg, j));
+          if (lane == (uint32_t)j) { mreg = m; rreg = rest; }
+        }
+      }
+    }
+    if (FUSED && lane < ge) { rest_out[e0 + lane] = rreg; mult[e0 + lane] = mreg; }
+    for (uint32_t base = 0; base < total; base += MULTI_ZR) {
+      const uint32_t cnt = min((uint32_t)MULTI_ZR, total - base);
+      Entry en; en.id = 0; en.value = 0.f;
+      if (lane < cnt) en = load_stream8(ent + a0 + base + lane);
+      uint32_t ex = 0, st = 0;                                         // the entry's example and where that example begins
+      for (uint32_t j = 1; j < ge; j++) {
+        const uint32_t rj = bcast_u32<1>(rel, j);
+        if (base + lane >= rj) { ex++; st = rj; }
+      }
+      bool def = false;                                                // the entry's feature occurs more than once in the batch: k_apply_seg's
+      if (lane < cnt) {
+        const uint64_t cm = cmask[row0 + e0 + ex];
+        const uint32_t pos = base + lane - st;
+        def = pos >= 64u || ((cm >> pos) & 1ull);
+      }
+      const uint64_t defm = __ballot(def);
+      const float ml = __shfl(mreg, (int)ex);                          // (all lanes: the source lane is the example's)
+      if (h.k1 && lane < cnt && !def) {                                // fm_sgd.h:38-43
+        float* pw = tb.w + (size_t)en.id * tb.ws;
+        const float wv = load_w(pw);
+        *pw = wv - h.lr * (ml * en.value + h.regw * wv);
+      }
+      float vr[MULTI_ZR][VEC];
+#pragma unroll
+      for (int t = 0; t < MULTI_ZR; t++) {
+        const uint32_t id = bcast_u32<1>(en.id, t);
+        if ((uint32_t)t < cnt && !((defm >> t) & 1ull)) load_row<VEC, 8>(tb.V + (size_t)id * tb.rs + lane * VEC, vr[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < MULTI_ZR; t++) {
+        const uint32_t id = bcast_u32<1>(en.id, t);
+        const uint32_t ex_t = bcast_u32<1>(ex, t);
+        const float x = bcast_f32<1>(en.value, t);
+        const float m = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mreg), (int)ex_t));
+        if ((uint32_t)t < cnt && !((defm >> t) & 1ull)) {
+          float* pv = tb.V + (size_t)id * tb.rs + lane * VEC;
+          float nv[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {                               // fm_sgd.h:44-50
+            const float vv = vr[t][v];
+            const float grad = sS[ex_t][lane * VEC + v] * x - vv * x * x;
+            nv[v] = vv - h.lr * (m * grad + h.regv * vv);
+          }
+          store_row<VEC, 8>(pv, nv);
+        }
+      }
+    }
+  }
+}
+
 // after the all-reduce of a feature-sharded partial buffer: rest_e = c_e + 0.5 * sum_f S_ef^2
 template <int KP>
 __global__ void __launch_bounds__(256)
@@ -807,6 +987,233 @@ k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32
     }
   }
   if (threadIdx.x == 0) { if (hw.ctr) handoff_publish(w0_out, w0); else *w0_out = w0; }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_scan_pit: the bias recurrence of a batch solved PARALLEL IN TIME (round 5).
+// The recurrence  w_{c+1} = w_c - lr (sum_{i in chunk c} m_i(w_c) + n_c reg0 w_c)   (fm_sgd.h:34-37 summed per micro-chunk; m_i the loss
+// multiplier of fm_learn_sgd_element.h:58-65 at p_i = w + rest_i) is a chain of B / chunk dependent steps: ~60 ns each on one wavefront,
+// whatever the chip does -- 0.5 ms per 262 144 examples at micro-chunk 32, a ceiling of 0.5 G examples/s that no number of GPUs lifts.
+// Newton's method on the WHOLE path removes the chain: with d_c the path (offset from the batch-start bias) of the previous iterate, every
+// chunk's step is linearised around d_c,
+//     d'_{c+1} = A_c d'_c + B_c,   A_c = 1 - lr D_c,   B_c = -lr (F_c - D_c d_c),   F_c = sum m_i + n_c reg0 (w + d_c),  D_c = sum m_i' + n_c reg0,
+// an AFFINE recurrence -- composition of affine maps is associative, so the new path is a parallel prefix scan -- and the iteration converges
+// quadratically (the linearised chain is a contraction: 0 < A_c <= 1 in the stable regime lr chunk curvature <= 1): path changes of
+// 3e-1, 7e-4, 4e-7 on a 262 144-example batch from a constant first guess.  The converged path IS the serial recurrence to fp32 rounding (~1e-8
+// on a bias of 0.05; scripts/cpu_pit_check.py holds the arithmetic against the serial loop) whatever the micro-chunk -- so the micro-chunk can
+// be as small as the reference's own (1 example) at no cost.
+// Layout: up to 32 workgroups of 256 threads, each keeps 8192 examples' {rest, y} in LDS (one DMA round trip) + its chunks' path; a wavefront
+// owns 2048 contiguous examples (32 vectors of 64).  One Newton iteration = sweep 1 (every wavefront composes the maps of its examples at the
+// current path into one), ONE grid-wide exchange of the workgroups' composites (a slot array + arrival counter in HBM, agent scope; bounded
+// spin), sweep 2 (every wavefront replays its maps from its incoming value and stores the new path).  The exchange also carries the largest
+// path change of the previous sweep 2, so all workgroups take the same decision to stop; then the composite applied to 0 is the bias change
+// of the batch.  If Newton does not settle (PIT_MAX_IT; the serial recurrence itself is then oscillating) workgroup 0 evaluates the chain
+// serially -- same result as k_scan.
+// ----------------------------------------------------------------------------------------------
+constexpr uint32_t PIT_SEG = 8192;                                    // examples per workgroup
+constexpr uint32_t PIT_WAVE = PIT_SEG / 4;                            // ... per wavefront
+constexpr uint32_t PIT_MAX_WG = 32;
+constexpr uint32_t PIT_MAX_ROWS = PIT_SEG * PIT_MAX_WG;               // 262 144: the default batch
+constexpr uint32_t PIT_MAX_CHUNK = PIT_WAVE;                          // a micro-chunk never straddles two wavefronts
+constexpr uint32_t PIT_MAX_IT = 12;
+constexpr float    PIT_TOL = 5e-4f;                                   // the path moved less than this: the NEXT iterate is exact to ~tol^2
+constexpr size_t   PIT_LDS_BYTES = (size_t)(3 * PIT_SEG) * sizeof(float);
+struct PitSync { unsigned long long* ctr; double* slots; uint32_t* err; };   // ctr[PIT_MAX_IT + 1] zeroed before the launch; slots[2][PIT_MAX_WG][4]
+struct AMap { float a, b; };                                          // x -> a x + b
+// max that does NOT drop a NaN (fmaxf does): a path that left the numbers must read as "not converged", never as "no change"
+__device__ __forceinline__ float nanmax(float a, float b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ AMap amap_after(const AMap first, const AMap then) { return AMap{then.a * first.a, fmaf(then.a, first.b, then.b)}; }
+
+template <bool WRITE_MULT, int TASK>
+__global__ void __launch_bounds__(256)
+k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
+           Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult, const Handoff hw, const PitSync ps) {
+  extern __shared__ float pit_lds[];
+  float* s_r = pit_lds;
+  float* s_y = pit_lds + PIT_SEG;
+  float* s_d = pit_lds + 2 * PIT_SEG;                                 // path offset at the start of every chunk of the segment
+  __shared__ float s_map[4][2];                                       // the wavefronts' composite maps
+  __shared__ float s_chg[4];
+  __shared__ double s_bcast[4];                                       // [0] incoming value of the workgroup, [1] value after the last one, [2] largest change
+  handoff_wait_counter(hw);                                           // (device hand-off: resident and polling until its batch's rest[] is complete)
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t g = blockIdx.x, nwg = gridDim.x;
+  const uint32_t s0 = g * PIT_SEG;
+  const uint32_t sn = (s0 < n_rows) ? min(PIT_SEG, n_rows - s0) : 0u;  // examples of this workgroup
+  const uint32_t q0 = wv * PIT_WAVE;
+  const double w0 = *w0_in;                                           // (launched only for models with a bias: h.k0)
+  const float w0s = (float)w0;
+  const uint32_t lc = 31u - (uint32_t)__builtin_clz(chunk);            // chunk = 1 << lc
+  constexpr float LOG2E = 1.4426950408889634f;
+  // the segment into LDS: one DMA round trip for everything this workgroup will ever read
+  if (q0 < sn) scan_fetch_tile(rest + s0 + q0, target + s0 + q0, min(PIT_WAVE, sn - q0), s_r + q0, s_y + q0, lane);
+  for (uint32_t c = threadIdx.x; c < (PIT_SEG >> lc); c += 256u) s_d[c] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // one vector (64 consecutive examples, lane = example) at the current path: multiplier and its derivative per lane
+  auto eval = [&](uint32_t i, float d, float& m, float& dm) {
+    const bool ok = i < sn;
+    const float r = ok ? s_r[i] : 0.f, y = ok ? s_y[i] : 0.f;
+    const float p = (w0s + d) + r;
+    if constexpr (TASK == 1) {
+      const float inv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(LOG2E * y * p));   // 1 / (1 + e^{y p})
+      m = -y * inv;                                                   // fm_learn_sgd_element.h:64 (y = 0 past the end: 0)
+      dm = (y * y) * inv * (1.0f - inv);                              // d m / d p = e^{yp} / (1 + e^{yp})^2
+    } else {
+      const float gs = h.sgda ? 2.0f : 1.0f;
+      const float pc = fmaxf(h.min_target, fminf(h.max_target, p));
+      m = ok ? gs * (pc - y) : 0.f;                                   // fm_learn_sgd_element.h:60-62
+      dm = (ok && p > h.min_target && p < h.max_target) ? gs : 0.f;
+    }
+  };
+  // the affine map of one chunk from its sums
+  auto chunk_map = [&](float F, float D, float d, uint32_t cstart) -> AMap {
+    const float nc = (cstart < sn) ? (float)min(chunk, sn - cstart) : 0.f;
+    F = fmaf(nc * h.reg0, w0s + d, F);
+    D = fmaf(nc, h.reg0, D);
+    return AMap{1.0f - h.lr * D, -h.lr * (F - D * d)};
+  };
+  // SWEEP over the wavefront's 32 vectors.  REPLAY = false: compose all chunk maps into `acc` (sweep 1).  REPLAY = true: x enters as the value
+  // at the wavefront's first chunk; every chunk's start value is stored as the new path, the largest change is returned (sweep 2).
+  auto sweep = [&](auto replay_tag, AMap& acc, float& x, float& chg) {
+    constexpr bool REPLAY = decltype(replay_tag)::value;
+    if (chunk <= 64u) {
+      for (uint32_t v = 0; v < PIT_WAVE / 64u; v++) {
+        const uint32_t i = q0 + 64u * v + lane;
+        if (q0 + 64u * v >= sn) break;                                // (wave-uniform: nothing left in this sub-segment)
+        const uint32_t c = i >> lc;
+        const float d = s_d[c];
+        float m, dm;
+        eval(i, d, m, dm);
+        for (uint32_t o = 1; o < chunk; o <<= 1) { m += __shfl_xor(m, (int)o); dm += __shfl_xor(dm, (int)o); }   // chunk sums in every lane of the chunk
+        AMap mp = chunk_map(m, dm, d, c << lc);
+        AMap ex = AMap{1.f, 0.f};                                     // composite of the vector's chunks BEFORE this lane's
+        for (uint32_t off = chunk; off < 64u; off <<= 1) {            // inclusive scan over the chunks of the vector (stride = chunk lanes)
+          const float pa = __shfl_up(mp.a, off), pb = __shfl_up(mp.b, off);
+          if (lane >= off) mp = amap_after(AMap{pa, pb}, mp);
+        }
+        if constexpr (REPLAY) {
+          const float ea = __shfl_up(mp.a, chunk), eb = __shfl_up(mp.b, chunk);
+          if (lane >= chunk) ex = AMap{ea, eb};
+          const float dn = fmaf(ex.a, x, ex.b);                       // the value this lane's chunk starts from
+          if (i < sn) chg = nanmax(fabsf(dn - d), chg);
+          if ((i & (chunk - 1u)) == 0u && i < sn) s_d[c] = dn;
+        }
+        const float va = __shfl(mp.a, 63), vb = __shfl(mp.b, 63);     // the vector's composite
+        if constexpr (REPLAY) x = fmaf(va, x, vb);
+        else acc = amap_after(acc, AMap{va, vb});
+      }
+    } else {
+      const uint32_t vpc = chunk >> 6;                                // vectors per chunk
+      float F = 0.f, D = 0.f;
+      for (uint32_t v = 0; v < PIT_WAVE / 64u; v++) {
+        const uint32_t i = q0 + 64u * v + lane;
+        if (q0 + 64u * v >= sn) break;
+        const uint32_t c = (q0 + 64u * v) >> lc;                      // (uniform)
+        const float d = s_d[c];
+        float m, dm;
+        eval(i, d, m, dm);
+        F += wave_sum_dpp(m); D += wave_sum_dpp(dm);
+        const bool last = ((v + 1u) % vpc) == 0u || q0 + 64u * (v + 1u) >= sn;
+        if (last) {
+          const AMap mp = chunk_map(F, D, d, c << lc);
+          if constexpr (REPLAY) {
+            chg = nanmax(fabsf(x - d), chg);
+            if (lane == 0) s_d[c] = x;
+            x = fmaf(mp.a, x, mp.b);
+          } else acc = amap_after(acc, mp);
+          F = 0.f; D = 0.f;
+        }
+      }
+    }
+  };
+  float my_chg = 3.0e38f;                                             // largest change of this workgroup's last sweep 2 (nothing yet)
+  bool converged = false;
+  double x_end = 0.0;
+  uint32_t it = 0;
+  for (; it < PIT_MAX_IT; it++) {
+    AMap acc = AMap{1.f, 0.f}; float xx = 0.f, cc = 0.f;
+    sweep(std::false_type(), acc, xx, cc);
+    if (lane == 0) { s_map[wv][0] = acc.a; s_map[wv][1] = acc.b; }
+    __syncthreads();
+    // ---- the exchange: publish this workgroup's composite + its last change, wait for everybody's ----
+    double* slot = ps.slots + (size_t)(it & 1u) * PIT_MAX_WG * 4;
+    if (threadIdx.x == 0) {
+      double A = 1.0, B = 0.0;
+      for (int w = 0; w < 4; w++) { B = (double)s_map[w][0] * B + (double)s_map[w][1]; A = (double)s_map[w][0] * A; }
+      __hip_atomic_store(slot + 4 * g + 0, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(slot + 4 * g + 1, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float wc = nanmax(nanmax(s_chg[0], s_chg[1]), nanmax(s_chg[2], s_chg[3]));
+      if (it == 0) wc = my_chg;
+      __hip_atomic_store(slot + 4 * g + 2, (double)wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nwg > 1) {
+        __hip_atomic_fetch_add(ps.ctr + it, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long cnt = __hip_atomic_load(ps.ctr + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t t = 0; cnt < (unsigned long long)nwg && t < HANDOFF_SPINS; t++) { __builtin_amdgcn_s_sleep(2); cnt = __hip_atomic_load(ps.ctr + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (cnt < (unsigned long long)nwg) atomicOr(ps.err, 4u);       // (a workgroup never arrived: flagged, the epoch fails instead of hanging)
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (wv == 0) {                                                    // lane j holds workgroup j's composite: an inclusive scan across the lanes
+      double A = 1.0, B = 0.0, C = 0.0;
+      if (lane < nwg) {
+        A = __hip_atomic_load(slot + 4 * lane + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        B = __hip_atomic_load(slot + 4 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        C = __hip_atomic_load(slot + 4 * lane + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (uint32_t off = 1; off < 32u; off <<= 1) {
+        const double pa = __shfl_up(A, off), pb = __shfl_up(B, off), pc = __shfl_up(C, off);
+        if (lane >= off) { B = fma(A, pb, B); A = A * pa; C = nanmax(pc, C); }
+      }
+      const double b_prev = __shfl_up(B, 1u);                          // value after the workgroups before lane's
+      const double b_mine = __shfl(b_prev, (int)g), b_all = __shfl(B, (int)(nwg - 1u)), c_all = __shfl(C, (int)(nwg - 1u));
+      if (lane == 0) { s_bcast[0] = g ? b_mine : 0.0; s_bcast[1] = b_all; s_bcast[2] = c_all; }
+    }
+    __syncthreads();
+    if (s_bcast[2] < (double)PIT_TOL && s_bcast[1] - s_bcast[1] == 0.0) { converged = true; x_end = s_bcast[1]; break; }   // (and the end value is a number)   // the path these composites were taken at had settled
+    // ---- sweep 2: the new path ----
+    float x = (float)s_bcast[0];
+    for (uint32_t w = 0; w < wv; w++) x = fmaf(s_map[w][0], x, s_map[w][1]);
+    float chg = 0.f;
+    AMap dummy = AMap{1.f, 0.f};
+    sweep(std::true_type(), dummy, x, chg);
+    for (int o = 32; o > 0; o >>= 1) chg = nanmax(__shfl_xor(chg, o), chg);
+    __syncthreads();                                                  // (s_map / s_bcast were read by everybody)
+    if (lane == 0) s_chg[wv] = chg;
+  }
+  if (!converged) {
+    // Newton did not settle: the serial chain, by one wavefront of workgroup 0 straight from global memory (k_scan's arithmetic)
+    if (g != 0 || wv != 0) return;
+    double w = w0;
+    for (uint32_t c0 = 0; c0 < n_rows; c0 += chunk) {
+      const uint32_t nc = min(chunk, n_rows - c0);
+      const float ws = (float)w;
+      float a = 0.f;
+      for (uint32_t i = lane; i < nc; i += 64u) {
+        const float m = multiplier_task<TASK>(h, ws + rest[c0 + i], target[c0 + i]);
+        if constexpr (WRITE_MULT) mult[c0 + i] = m;
+        a += m;
+      }
+      const float tot = wave_sum_dpp(a);
+      w -= (double)h.lr * ((double)tot + (double)nc * (double)h.reg0 * (double)ws);
+    }
+    if (lane == 0) { if (hw.ctr) handoff_publish(w0_out, w); else *w0_out = w; }
+    return;
+  }
+  if constexpr (WRITE_MULT) {                                         // the multipliers at the settled path (two-pass form of the rule)
+    for (uint32_t v = 0; v < PIT_WAVE / 64u; v++) {
+      const uint32_t i = q0 + 64u * v + lane;
+      if (i < sn) {
+        float m, dm;
+        eval(i, s_d[i >> lc], m, dm);
+        mult[s0 + i] = m;
+      }
+    }
+  }
+  if (g == 0 && threadIdx.x == 0) { const double w = w0 + x_end; if (hw.ctr) handoff_publish(w0_out, w); else *w0_out = w; }
 }
 
 // no bias: the multipliers are independent of each other

@@ -27,6 +27,17 @@ template <int KP> uint32_t fused_row_cap_kp(uint32_t max_row) {
   return std::min<uint32_t>(64u, (uint32_t)fused_zr_select<KP>(max_row) * (uint32_t)Map<KP>::EPI);
 }
 
+// SHORT rows (a feature shard of P GPUs sees nnz / P entries per example): examples per wavefront of k_rowsums_multi / k_apply_multi --
+// about 24 entries per 32-slot round (mean + 1.7 sigma of a shard's binomial row lengths stays inside one round); 0 = rows are long enough
+// for the one-example-per-wavefront kernels (or KP < 64: several rows per wave-wide load, not built)
+uint32_t multi_group_size(const Slot& s, int KP) {
+  if (KP < 64 || s.n_rows == 0) return 0;
+  const double avg = (double)s.nnz / (double)s.n_rows;
+  if (avg > 12.0) return 0;
+  const double g = avg > 0.0 ? 24.0 / avg : (double)MULTI_GMAX;
+  return (uint32_t)std::max(2.0, std::min((double)MULTI_GMAX, std::floor(g)));
+}
+
 template <int KP, int VAR>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
                     const double* w0_in, float* rest_out, const uint64_t* cmask = nullptr, float* S_out = nullptr,
@@ -81,16 +92,19 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   float* S = d_partial;
   float* c = d_partial + (size_t)n_rows * h->KP;
-  KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st,
-                                     s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c, (const float*)nullptr));
-  HIPCHK(h, hipGetLastError());
-  return FMX_OK;
+  return sgd_partial_rows(h, s, row0, n_rows, S, c, st);
 }
 
 // a run of rows of a batch into the batch's partial buffer (S: [batch rows][KP], c: [batch rows]) -- the chunked exchange of
 // fmx_group_sgd_epoch enqueues the all-reduce of one run while the next one is being summed
 extern "C++" int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st) {
   if (n_rows == 0) return FMX_OK;
+  if (const uint32_t G = multi_group_size(s, h->KP)) {          // short rows: several examples per wavefront
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_rowsums_multi<KP, true, false>), ((uint64_t)n_rows + G - 1) / G, st,
+                                                                  s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c, G); } });
+    HIPCHK(h, hipGetLastError());
+    return FMX_OK;
+  }
   KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, false>), n_rows, st, s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c, (const float*)nullptr));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
@@ -252,12 +266,43 @@ done:
   return rc;
 }
 
+// the device's error word after launches of k_scan_pit whose streams have been drained by the caller
+extern "C++" int scan_error_check(fmx_handle h) {
+  if (!h->pit_used) return FMX_OK;
+  h->pit_used = false;
+  uint32_t e = 0;
+  HIPCHK(h, hipMemcpy(&e, h->handoff_err, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (e & 4u) {
+    (void)hipMemset(h->handoff_err, 0, sizeof(uint32_t));
+    return fail(h, FMX_E_HIP, "the grid-wide exchange of the parallel bias recurrence timed out (flags %u): the parameters of this epoch are "
+                              "not valid; FMX_SCAN=serial takes the one-wavefront chain instead", e);
+  }
+  return FMX_OK;
+}
+
 static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
                        const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr,
                        const Handoff hw = Handoff{nullptr, 0ull, nullptr}) {
   if (hy.k0) {
     const double* wi = w0_in ? w0_in : h->w0;
     double* wo = w0_out ? w0_out : h->w0;
+    // round 5: the recurrence solved parallel in time (k_scan_pit: Newton on the whole path, affine prefix scans; up to 32 workgroups) for
+    // micro-chunks that are powers of two up to 2048 on batches of 4097 .. 262 144 examples -- every default.  Same result as the chain to
+    // fp32 rounding; ~40 us per 262 144 examples whatever the micro-chunk where the chain takes 0.18 ms (256) .. 0.5 ms (32).
+    if (h->scan_pit && n_rows > 4096u && n_rows <= PIT_MAX_ROWS && chunk <= PIT_MAX_CHUNK && (chunk & (chunk - 1u)) == 0u) {
+      const uint32_t nwg = (n_rows + PIT_SEG - 1) / PIT_SEG;
+      HIPCHK(h, hipMemsetAsync(h->pit_ctr, 0, (PIT_MAX_IT + 1) * sizeof(unsigned long long), st));
+      const PitSync ps{h->pit_ctr, h->pit_slots, h->handoff_err};
+#define FMX_PIT(WM, TK) do { auto kf = k_scan_pit<WM, TK>;                                                                       \
+      if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIT_LDS_BYTES)); h->lds_raised.insert((const void*)kf); } \
+      hipLaunchKernelGGL(kf, dim3(nwg), dim3(256), PIT_LDS_BYTES, st, rest, target, n_rows, chunk, hy, wi, wo, mult, hw, ps); } while (0)
+      if (hy.task == 0) { if (mult) FMX_PIT(true, 0); else FMX_PIT(false, 0); }
+      else              { if (mult) FMX_PIT(true, 1); else FMX_PIT(false, 1); }
+#undef FMX_PIT
+      h->pit_used = true;
+      HIPCHK(h, hipGetLastError());
+      return FMX_OK;
+    }
     // micro-chunks that are multiples of 256 examples: k_scan1 (one wavefront on the chain, four contiguous examples per lane, a 128 KiB
     // tile pipeline fed by the workgroup's four wavefronts); else, and for
     // batches of a few thousand rows (the 128 KiB-LDS workgroup costs more to place than the recurrence takes): one plain wavefront
@@ -321,37 +366,105 @@ static int lag_prepare(fmx_handle h, hipStream_t st, uint32_t depth, int* slot) 
 }
 // call AFTER `rest` is complete on `st`: starts the recurrence on the side stream and leaves the multipliers of
 // this batch (lagged bias) in h->mult on `st`
-static int lag_step(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
-                    const Hyper& hy, hipStream_t st) {
+// the three pieces of a lagged step: `st` waits for the recurrence whose bias this batch's multipliers use; where that bias lives; the
+// recurrence of THIS batch goes to the side stream behind whatever produced rest[] on `st`
+static int lag_wait_bias(fmx_handle h, const Hyper& hy, hipStream_t st) {
+  LagState& L = h->lag;
+  if (hy.k0 && L.step >= L.depth) HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[(L.step - L.depth) % LagState::RING], 0));   // recurrence of batch b - d
+  return FMX_OK;
+}
+static const double* lag_bias_slot(fmx_handle h) {
+  const LagState& L = h->lag;
+  const uint32_t R = L.depth + 1;
+  return h->w0_pp + ((L.step + R - L.depth + 1) % R);
+}
+static int lag_start_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk, const Hyper& hy, hipStream_t st) {
   LagState& L = h->lag;
   const uint64_t b = L.step;
-  const uint32_t d = L.depth, R = d + 1;
+  const uint32_t R = L.depth + 1;
   if (hy.k0) {
     HIPCHK(h, hipEventRecord(L.ev_rest, st));
     HIPCHK(h, hipStreamWaitEvent(h->stream2, L.ev_rest, 0));
     int rc = launch_scan(h, rest, target, n_rows, chunk, hy, nullptr, h->stream2, h->w0_pp + (b % R), h->w0_pp + ((b + 1) % R));
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(L.ev_scan[b % LagState::RING], h->stream2));
-    if (b >= d) HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[(b - d) % LagState::RING], 0));   // recurrence of batch b - d
   }
+  return FMX_OK;
+}
+static int lag_step(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
+                    const Hyper& hy, hipStream_t st) {
+  int rc = lag_start_scan(h, rest, target, n_rows, chunk, hy, st);
+  if (rc) return rc;
+  rc = lag_wait_bias(h, hy, st);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_mult, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048)), dim3(256), 0, st, rest, target, n_rows, hy,
-                     (const double*)(h->w0_pp + ((b + R - d + 1) % R)), h->mult);
+                     lag_bias_slot(h), h->mult);
   HIPCHK(h, hipGetLastError());
-  L.step++;
+  h->lag.step++;
   return FMX_OK;
 }
 
 // steps 2 and 3 of the minibatch rule for rows [row0,row0+n_rows); `seg_batch` = batch index when the rows are
 // exactly one batch of the slot's segment structure (else -1: per-example apply only)
+// short rows (a feature shard), library's choice of the update: example-major over the batch-unique features (k_apply_multi: several examples
+// per wavefront, S_e read once per example) + k_apply_seg over the batch's deferred list
+static bool short_row_update(fmx_handle h, const Slot& s, const fmx_sgd_opts* opts, int64_t seg_batch) {
+  const int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
+  return (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_FUSED) && seg_batch >= 0 && s.cmask && !s.cbatch.empty() &&
+         multi_group_size(s, h->KP) != 0;
+}
+static int launch_deferred(fmx_handle h, const Slot& s, const Hyper& hy, const float* S, size_t b, hipStream_t st) {
+  const uint32_t c0 = s.cbatch[b], c1 = s.cbatch[b + 1];
+  if (c1 > c0) {
+    const uint32_t s0 = s.batch_seg[b], s1 = s.batch_seg[b + 1];
+    const uint64_t base = s.batch_base[b];
+    SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, s.cseg + c0, c1 - c0, s1 - s0, (uint32_t)(s.batch_base[b + 1] - base), S, h->mult, s.cdesc + c0};
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 16>), ((uint64_t)sw.nseg + 15) / 16, st, sw, h->tb, hy));
+  }
+  return FMX_OK;
+}
+// cpart != nullptr: `rest` has NOT been computed -- the short-row update derives it (and the multipliers) from S and cpart itself
 static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, const float* S,
-                           const float* rest, const fmx_sgd_opts* opts, hipStream_t st,
-                           hipEvent_t ev_a, hipEvent_t ev_b, int64_t seg_batch) {
+                           float* rest, const fmx_sgd_opts* opts, hipStream_t st,
+                           hipEvent_t ev_a, hipEvent_t ev_b, int64_t seg_batch, const float* cpart = nullptr) {
   const Hyper hy = make_hyper(h->cfg);
   const uint32_t chunk = (opts && opts->w0_chunk) ? opts->w0_chunk : default_w0_chunk(h->cfg);
   const bool lag = opts && (opts->flags & FMX_FLAG_BIAS_LAG);
-  int rc = lag ? lag_step(h, rest, s.target + row0, n_rows, chunk, hy, st)
-               : launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
+  int rc = FMX_OK;
+  if (cpart) {
+    // fused short-row step (bias-lag schedule on a feature shard): [wait for the bias of batch b - d] -> k_apply_multi<FUSED> (rest, multipliers,
+    // update of the batch-unique features) -> the recurrence of this batch starts on the side stream -> the deferred features
+    const uint32_t G = multi_group_size(s, h->KP);
+    rc = lag_wait_bias(h, hy, st);
+    if (rc) return rc;
+    if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_apply_multi<KP, true>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
+                                                                  h->tb, hy, lag_bias_slot(h), S, cpart, rest, h->mult, (const uint64_t*)s.cmask, G); } });
+    HIPCHK(h, hipGetLastError());
+    rc = lag_start_scan(h, rest, s.target + row0, n_rows, chunk, hy, st);
+    if (rc) return rc;
+    h->lag.step++;
+    rc = launch_deferred(h, s, hy, S, (size_t)seg_batch, st);
+    if (rc) return rc;
+    if (ev_b) HIPCHK(h, hipEventRecord(ev_b, st));
+    HIPCHK(h, hipGetLastError());
+    return FMX_OK;
+  }
+  rc = lag ? lag_step(h, rest, s.target + row0, n_rows, chunk, hy, st)
+           : launch_scan(h, rest, s.target + row0, n_rows, chunk, hy, h->mult, st);
   if (rc) return rc;
+  if (short_row_update(h, s, opts, seg_batch)) {                // (exact chunk coupling: the multipliers came out of the recurrence)
+    const uint32_t G = multi_group_size(s, h->KP);
+    if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_apply_multi<KP, false>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
+                                                                  h->tb, hy, (const double*)h->w0, S, (const float*)nullptr, (float*)nullptr, h->mult, (const uint64_t*)s.cmask, G); } });
+    HIPCHK(h, hipGetLastError());
+    rc = launch_deferred(h, s, hy, S, (size_t)seg_batch, st);
+    if (rc) return rc;
+    if (ev_b) HIPCHK(h, hipEventRecord(ev_b, st));
+    HIPCHK(h, hipGetLastError());
+    return FMX_OK;
+  }
   int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
   // split step, library's choice (DEFAULT / FUSED): the features that occur once in the batch are written back example-major
   // (k_fused<FUSED_APPLY>: the wavefront holds S_e, no gather per occurrence), the others by their owner (k_apply_seg over the
@@ -423,9 +536,6 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   float* rest_buf = h->rest + (size_t)rslot * Bcap;
   const float* S = d_partial;
   const float* c = d_partial + (size_t)n_rows * h->KP;
-  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n_rows + Map<KP>::EPI - 1) / Map<KP>::EPI)),
-                                        dim3(256), 0, st, S, c, n_rows, rest_buf));
-  HIPCHK(h, hipGetLastError());
   int64_t seg_batch = -1;
   const int apply = opts ? opts->apply : FMX_APPLY_DEFAULT;
   if (apply == FMX_APPLY_DEFAULT || apply == FMX_APPLY_SEGMENTED || apply == FMX_APPLY_FUSED) {
@@ -437,6 +547,12 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
     if (rc) return rc;
     seg_batch = (int64_t)(row0 / B);
   }
+  // short rows under the bias-lag schedule: rest_e and the multipliers come out of the update kernel itself (no k_rest_from_partial, no k_mult)
+  if (lag && short_row_update(h, s, opts, seg_batch))
+    return sgd_finish_impl(h, s, row0, n_rows, S, rest_buf, opts, st, nullptr, nullptr, seg_batch, c);
+  KP_SWITCH(h->KP, hipLaunchKernelGGL((k_rest_from_partial<KP>), dim3(wave_grid((n_rows + Map<KP>::EPI - 1) / Map<KP>::EPI)),
+                                        dim3(256), 0, st, S, c, n_rows, rest_buf));
+  HIPCHK(h, hipGetLastError());
   return sgd_finish_impl(h, s, row0, n_rows, S, rest_buf, opts, st, nullptr, nullptr, seg_batch);
 }
 
@@ -731,6 +847,8 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
                               "epoch are not valid; FMX_HANDOFF=0 orders the streams with events instead", e);
   }
   rc = lag_flush(h);
+  if (rc) return rc;
+  rc = scan_error_check(h);
   if (rc) return rc;
   if (kept_wside) s.wside_version = h->w_version;            // the epoch is complete: the stream holds this w
   if (stats) {

@@ -61,6 +61,52 @@ def test_group_trains_the_unsharded_model(capi, oracle, name, world, shard_hash,
         h.close()
 
 
+@pytest.mark.parametrize("k", [64, 128, 70])
+@pytest.mark.parametrize("world,lag,flags_lag", [(4, 1, True), (8, 2, True), (4, 0, False), (8, 3, True), (3, 1, True)])
+@pytest.mark.parametrize("task", [0, 1])
+def test_short_rows_of_a_shard_several_examples_per_wavefront(capi, oracle, k, world, lag, flags_lag, task):
+    """round 5: a shard of P GPUs sees nnz / P entries per example; at one row per wave-wide load (k >= 64) its sums and its update then run
+    several examples per wavefront (k_rowsums_multi, k_apply_multi: S_e staged once per example, rest_e and the multiplier computed in the
+    update kernel under the bias-lag schedule) + k_apply_seg over the batch's deferred list.  Ragged rows incl. empty ones and some longer than
+    one 32-slot round, ids that repeat inside a batch and inside a row, a ragged last batch, padded factors (k = 70), exact chunk coupling
+    (no lag: the multipliers come out of the recurrence) -- the oracle's rule at 1e-4, as every other form of the step."""
+    rng = np.random.default_rng(100 * k + world + task)
+    n, rows, batch, chunk = 6000, 1900, 512, 32
+    sizes = rng.integers(0, 40, rows)
+    sizes[rng.random(rows) < 0.05] = 0
+    sizes[:3] = (150, 70, 33)                                         # (every shard sees rows beyond one round / beyond the mask's 64 entries)
+    rp = np.zeros(rows + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum(sizes)
+    ent = np.zeros(int(rp[-1]), dtype=capi.ENTRY_DTYPE)
+    ent["id"] = (rng.zipf(1.3, len(ent)) % n).astype(np.uint32)        # a head of frequent ids: many deferred features per batch
+    far = rng.random(len(ent)) < 0.6
+    ent["id"][far] = rng.integers(0, n, int(far.sum()))
+    ent["value"] = rng.choice([1.0, 0.5, -1.0, 2.0], len(ent)).astype(np.float32)
+    y = (np.where(rng.random(rows) < 0.6, 1.0, -1.0) if task == 1 else rng.normal(0.2, 0.6, rows)).astype(np.float32)
+    lo, hi = (-1.0, 1.0) if task == 1 else (float(np.quantile(y, 0.05)), float(np.quantile(y, 0.95)))
+    lr, reg = 0.002, (0.0, 0.001, 0.002)
+    d = oracle.Data(ent, rp, y)
+    m = oracle.Model(n, k, True, True, *reg)
+    m.v[:] = oracle.init_values(3, n, k, 0.03)
+    m.w[:] = oracle.init_values(4, n, 1, 0.03)[0]
+    m.w0 = 0.02
+    hs, grp = make_group(capi, world, [0] * world, n, k, task, reg, lr, lo, hi, 1)
+    grp.set_params(m.w0, m.w, m.v)
+    grp.upload_rows(0, ent, rp, y)
+    flags = capi.FLAG_BIAS_LAG if flags_lag else 0
+    for _ in range(2):
+        grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, chunk, flags, lag)
+        oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=lag if flags_lag else 0)
+    w0, w, v = grp.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(grp.predict(0, rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5)
+    grp.close()
+    for h in hs:
+        h.close()
+
+
 def test_hashed_ownership_balances_structured_ids(capi):
     """ids that are all multiples of 8 (or all inside one residue class of any small modulus) land on ONE shard under
     `j mod P`; the permutation spreads them"""

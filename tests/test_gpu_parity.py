@@ -172,13 +172,18 @@ def test_minibatch_kilo_chunks(capi, oracle, task, batch, chunk, lag):
 @pytest.mark.parametrize("task", [0, 1])
 @pytest.mark.parametrize("batch,chunk", [(9001, 256), (8193, 256), (12325, 512), (20000, 1024), (16384, 256), (9001, 768),
                                          # round 5, the sub-piece form (micro-chunks below one 256-example piece; 32 is the library default):
-                                         (9001, 32), (8193, 16), (12325, 64), (20000, 128), (16384, 32), (9007, 64), (8200, 128), (19999, 16)])
+                                         (9001, 32), (8193, 16), (12325, 64), (20000, 128), (16384, 32), (9007, 64), (8200, 128), (19999, 16),
+                                         # ... and what only the parallel-in-time form makes affordable: the reference's own micro-chunk
+                                         (9001, 1), (20000, 2), (12325, 8), (16385, 2048), (5000, 4)])
 @pytest.mark.parametrize("apply_name", ["fused", "segmented"])
-def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name):
-    """k_scan1 (batches of more than 8192 rows, micro-chunks of multiples of 256): the default micro-chunk (every piece ends one) and longer
-    ones, whole and ragged tiles, a batch that starts at a row that is not a multiple of four (the dword path of the tile fetch), with the
-    multipliers written (two-pass form) and without (one-pass form), regression with the clamp active and classification -- against the
-    oracle's rule."""
+@pytest.mark.parametrize("scan", ["pit", "serial"])
+def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name, scan, monkeypatch):
+    """the bias recurrence of batches beyond one wavefront's reach, in both device forms -- parallel in time (k_scan_pit: micro-chunks that are
+    powers of two up to 2048 on batches of 4097 .. 262 144 rows) and the one-wavefront chain (FMX_SCAN=serial: k_scan1 for multiples of 256 and,
+    sub-piece form, 16 .. 128; k_scan otherwise): whole and ragged segments / tiles, a batch that starts at a row that is not a multiple of four
+    (the dword path of the LDS-DMA fetch), with the multipliers written (two-pass form) and without (one-pass form), regression with the clamp
+    active and classification -- against the oracle's rule."""
+    monkeypatch.setenv("FMX_SCAN", scan)                                # (read by fmx_create)
     n, nnz, rows, k = 3996, 6, 20000, 8
     ent, row_ptr, y = datagen.onehot_fields(n, nnz, rows, seed=400 + batch + chunk, classification=(task == 1))
     if task == 0:
@@ -205,13 +210,16 @@ def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name):
 
 @pytest.mark.parametrize("task", [0, 1])
 @pytest.mark.parametrize("batch,chunk,lag", [(32768, 256, 2), (32768, 768, 1), (40001, 256, 3), (36000, 1024, 2),
-                                             (32768, 32, 2), (40001, 64, 1), (36000, 16, 3), (33000, 128, 2), (40001, 0, 2)])   # (0: the default)
+                                             (32768, 32, 2), (40001, 64, 1), (36000, 16, 3), (33000, 128, 2), (40001, 0, 2),   # (0: the default)
+                                             (40001, 1, 2), (65536, 4, 2)])
 @pytest.mark.parametrize("events", [False, True])
-def test_side_stream_recurrence_of_the_one_pass_form(capi, oracle, task, batch, chunk, lag, events):
+@pytest.mark.parametrize("scan", ["pit", "serial"])
+def test_side_stream_recurrence_of_the_one_pass_form(capi, oracle, task, batch, chunk, lag, events, scan, monkeypatch):
     """the one-pass form at batches >= 32 768: the recurrence runs on the side stream WITHOUT writing multipliers (k_scan1<false, ...>: the
     counted s_waitcnt path of the tile pipeline, ragged last tiles, micro-chunks that are not the default, a short last batch) under
     both orderings of the two streams -- the device-side hand-off (bias slots + completion counter) and events (FMX_FLAG_EVENT_SYNC) --
     against the oracle's rule.  (Round-3 advisor: the fused legs of test_tiled_recurrence_kernel stay below 32 768 and never got here.)"""
+    monkeypatch.setenv("FMX_SCAN", scan)
     n, nnz, rows, k = 39996, 6, 90001, 8
     ent, row_ptr, y = datagen.onehot_fields(n, nnz, rows, seed=900 + chunk + lag, classification=(task == 1))
     if task == 0:
@@ -575,6 +583,35 @@ def test_errors(capi, oracle):
     ent["id"] = 10                                         # id >= num_attribute (reference asserts, fm_model.h:112)
     with pytest.raises(capi.FmxError):
         h.upload_rows(0, ent, np.array([0, 1], dtype=np.uint64), np.zeros(1, dtype=np.float32))
+    h.close()
+
+
+@pytest.mark.parametrize("apply_name", ["fused", "segmented"])
+def test_parallel_recurrence_where_newton_does_not_settle(capi, oracle, apply_name):
+    """regression started far below min_target (libFM's own start on rating data: w0 = 0, targets 1..5): every clamped prediction has a
+    multiplier of derivative 0, the linearised chain of k_scan_pit does not see the clamp release and Newton runs into its iteration bound
+    (tests/test_pit_arithmetic.py) -- the kernel then evaluates the chain serially: still the oracle's rule, batch after batch, until the
+    bias has climbed into the range and Newton takes over."""
+    n, nnz, rows, k, batch, chunk, lr = 3996, 6, 30000, 8, 10000, 32, 0.01
+    ent, row_ptr, y = datagen.onehot_fields(n, nnz, rows, seed=77, classification=False)
+    y = (3.0 + y).astype(np.float32)
+    lo, hi = 2.5, 3.5                                                 # (the clamp bites on both sides once the bias is there)
+    d = oracle.Data(ent, row_ptr, y)
+    m = oracle.Model(n, k, True, True, 0.0, 0.001, 0.003)
+    m.v[:] = oracle.init_values(5, n, k, 0.05)
+    m.w0 = -40.0                                                      # thousands of examples below min_target
+    h = capi.Handle(n, k, True, True, 0, 0.0, 0.001, 0.003, lr, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, row_ptr, y)
+    ap = capi.APPLY_FUSED if apply_name == "fused" else capi.APPLY_SEGMENTED
+    for _ in range(2):
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, ap, batch, chunk, capi.FLAG_BIAS_LAG, 1)
+        oracle.sgd_epoch_minibatch(m, d, 0, lr, lo, hi, batch, chunk, bias_lag=1)
+    w0, w, v = h.get_params()
+    assert m.w0 > lo - 1.0                                            # (the bias did travel: 40 units in steps of <= 0.01 * (y - 2.5))
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
     h.close()
 
 
