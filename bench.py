@@ -219,6 +219,59 @@ def run_sgd_config(capi, name, n, k, nnz, rows, criteo, steps, warmup, with_cpu,
     return out
 
 
+def shard_probe(capi, n, k, nnz, single_gpu_value, rows=1 << 21, batch=262144, worlds=(2, 4, 8), lag=2):
+    """what ONE rank of a P-way feature-sharded step computes, measured on this GPU: rank 0 of P holds n / P features and sees every example
+    restricted to them (about nnz / P entries per example); per batch its sums (fmx_sgd_partial), then -- the exchange left out -- its
+    update (fmx_sgd_finish: multipliers, bias recurrence on the side stream, write-back).  The library's own kernels and schedule (bias lag
+    `lag`, default micro-chunk and batch).  The WIRE is not measured (one GPU): `modelled` holds the arithmetic of DESIGN.md section 6 -- a
+    direct reduce-scatter + all-gather of the [batch][k + 1] fp32 sums over the P - 1 xGMI links of a GPU at 58 GB/s per link and
+    direction -- and what a step would then take; every figure under `modelled` is arithmetic, not a measurement."""
+    import torch
+    out = {"what": "per-rank compute of the feature-sharded step on ONE GPU (rank 0 of P, no exchange); wire and speed-up are MODELLED",
+           "batch": batch, "bias_lag": lag, "rows": rows, "ranks": {}}
+    for world in worlds:
+        h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0, shard_rank=0, shard_world=world,
+                        shard_hash=1)
+        try:
+            h.init_params(0.0, 0.01, 1)
+            h.synth_rows(0, 123, 0, rows, nnz)
+            kp1 = h.info().k_padded + 1
+            st = torch.cuda.Stream()
+            bufs = [torch.empty(batch * kp1, dtype=torch.float32, device="cuda") for _ in range(2)]
+
+            def epoch(which):
+                for i, row0 in enumerate(range(0, rows, batch)):
+                    nb = min(batch, rows - row0)
+                    buf = bufs[i & 1]
+                    if which != "finish":
+                        h.sgd_partial(0, row0, nb, buf.data_ptr(), st.cuda_stream)
+                    if which != "partial":
+                        h.sgd_finish(0, row0, nb, buf.data_ptr(), capi.APPLY_DEFAULT, 0, st.cuda_stream, batch, capi.FLAG_BIAS_LAG, lag)
+            res = {}
+            for which in ("both", "partial", "finish"):
+                epoch(which); st.synchronize(); h.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    epoch(which)
+                st.synchronize(); h.synchronize()
+                res[which] = (time.perf_counter() - t0) / 2 / ((rows + batch - 1) // batch)       # seconds per batch
+            payload = batch * kp1 * 4
+            wire = (2.0 / world) * payload / 58e9
+            exact = max(res["partial"], wire) + res["finish"]
+            piped = max(res["partial"] + res["finish"], wire)
+            out["ranks"]["P%d" % world] = {
+                "per_rank_examples_per_s": round(batch / res["both"], 1), "sums_ms_per_batch": round(res["partial"] * 1e3, 4),
+                "update_ms_per_batch": round(res["finish"] * 1e3, 4), "step_ms_per_batch": round(res["both"] * 1e3, 4),
+                "frac_of_hbm_peak": round(batch / res["both"] * (algorithmic_bytes(k, nnz, "rowsums") + algorithmic_bytes(k, nnz, "apply")) / world / 1e9 / HBM_PEAK_GBS, 4),
+                "modelled": {"wire_ms_per_batch": round(wire * 1e3, 4), "exact_rule_examples_per_s": round(batch / exact, 1),
+                             "one_batch_stale_examples_per_s": round(batch / piped, 1),
+                             "speedup_vs_1_gpu_exact": round(batch / exact / single_gpu_value, 3) if single_gpu_value else None,
+                             "speedup_vs_1_gpu_one_batch_stale": round(batch / piped / single_gpu_value, 3) if single_gpu_value else None}}
+        finally:
+            h.close()
+    return out
+
+
 def committed_traffic(kernel, examples_per_launch, k, nnz):
     """HBM bytes per launch from the committed PMC profile (profiles/traffic.json), if it is for this kernel/shape."""
     try:
@@ -394,7 +447,7 @@ def bench_group(args, capi, criteo):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                % ("Criteo-shaped" if criteo else "synthetic one-hot fields", args.n, args.k, args.nnz, args.rows, lr, regv),
-                   "mode": "minibatch (split step)", "batch": int(st.batch_used), "w0_chunk": args.w0_chunk or 256, "bias_lag": lag,
+                   "mode": "minibatch (split step)", "batch": int(st.batch_used), "w0_chunk": int(st.w0_chunk_used), "bias_lag": lag,
                    "pipeline": bool(args.pipeline), "sharding": "feature-id hash (permutation) over %d shards" % N,
                    "driver": "one process, fmx_group (%s)" % ("loopback: all shards on device 0" if args.same_device else "RCCL, one communicator per device"),
                    "batch_rule": {"batch": int(st.batch_used), "collision_mass": round(st.collision_mass, 6), "gain": round(st.batch_gain, 4)},
@@ -455,7 +508,7 @@ def main():
                     help="testing: drive the multi-GPU code path (ShardedSGD + all-reduce) even with one rank")
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: the library's choice -- 262144 cut to the stability bound of the rows, fmx_sgd_opts::batch); hogwild: rows per launch (0: 262144)")
-    ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default = 256 at lr 0.01, classification)")
+    ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default, fmx_default_w0_chunk)")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true",
                     help="sharded: overlap the all-reduce of batch b+1 with the update of batch b (the one-batch-stale pipelined rule, "
                          "oracle fmo_sgd_epoch_minibatch_pipelined).  Default OFF: every N runs the SAME rule as N = 1")
@@ -749,7 +802,8 @@ def main():
                                    "synthetic one-hot fields n=%d k=%d nnz=%d, %d examples/step, task=c lr=%g regv=%g"
                                    % (args.n, args.k, args.nnz, args.rows, lr, regv),
                        "mode": args.mode, "apply": args.apply, "batch": batch,
-                       "w0_chunk": args.w0_chunk or 256, "bias_lag": bias_lag, "pipeline": bool(args.pipeline) if sharded else False, "sharding": "feature-id hash (permutation) over %d shards" % world if world > 1 else "none",
+                       "w0_chunk": int(batch_stats.w0_chunk_used) if batch_stats is not None and batch_stats.w0_chunk_used else (args.w0_chunk or capi.default_w0_chunk(lr, capi.TASK_CLASSIFICATION)),
+                       "bias_lag": bias_lag, "pipeline": bool(args.pipeline) if sharded else False, "sharding": "feature-id hash (permutation) over %d shards" % world if world > 1 else "none",
                        "driver": (args.driver if sharded else "single handle"),
                        "device": info.device_name.decode(), "arch": info.arch.decode()},
             "roofline": roof,
@@ -761,11 +815,11 @@ def main():
             # how far the headline rule ends from the reference's ONLINE loop at this shape (the committed CPU measurement of the oracle's
             # two loops; asserted with the device in place of the rule by tests/test_gpu_configs.py)
             try:
-                pv = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_vs_online.json")))
-                if (pv["n"], pv["k"], pv["nnz"], pv["batch"], pv["bias_lag"]) == (args.n, args.k, args.nnz, batch, bias_lag):
-                    out["parity_vs_online"] = {kk: pv[kk] for kk in ("rows", "epochs", "pred_rms", "pred_mean_abs", "pred_max_abs", "w0_abs",
+                pv = json.load(open(os.path.join(ROOT, "profiles", "r05_parity_vs_online.json")))
+                if (pv["n"], pv["k"], pv["nnz"], pv["batch"], pv["bias_lag"], pv["chunk"]) == (args.n, args.k, args.nnz, batch, bias_lag, out["config"]["w0_chunk"]):
+                    out["parity_vs_online"] = {kk: pv[kk] for kk in ("rows", "epochs", "chunk", "pred_rms", "pred_mean_abs", "pred_max_abs", "w0_abs",
                                                                      "pred_max_rel_to_rms_without_bias", "v_max_abs", "v_max_rel_to_vmax", "w_max_abs")}
-                    out["parity_vs_online"]["source"] = "profiles/r04_parity_vs_online.json (scripts/cpu_online_vs_rule.py: oracle rule vs oracle online loop, sub-model of the rows' features); the device equals the rule at 1e-4"
+                    out["parity_vs_online"]["source"] = "NOT measured in this run: profiles/r05_parity_vs_online.json (scripts/cpu_online_vs_rule.py, ~45 CPU-minutes: oracle rule vs oracle online loop on the sub-model of the rows' features); the device equals the rule at 1e-4 (tests/test_gpu_configs.py)"
             except (OSError, ValueError, KeyError):
                 pass
         if not sharded and args.mode != "hogwild":
@@ -792,6 +846,20 @@ def main():
                 out["phases_ms_per_batch"] = {"sums": round(phases[0] / nb * 1e3, 4), "exchange_exposed": round(phases[1] / nb * 1e3, 4),
                                               "update": round(phases[2] / nb * 1e3, 4), "rank": 0}
         out.update(extras)
+        if roof is not None and "predict" in extras:
+            # what north_star scores, as flat numbers inside `roofline` (the driver's record keeps only the NAMES of the extra keys)
+            pr = extras["predict"]
+            roof["predict"] = {"v_read_frac": pr["v_read_frac"], "v_read_frac_cold": pr["without_side_stream"]["v_read_frac"],
+                               "rows_per_s": pr["value"], "rows_per_s_cold": pr["without_side_stream"]["value"],
+                               "cold": "no weight side stream (a pass that no epoch on the slot preceded)"}
+        if roof is not None and roof.get("traffic") and not sharded:
+            try:
+                e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(roof["kernel"], {})
+                step_bytes = roof["traffic"] + e.get("deferred_pass_bytes_per_launch", 0)
+                roof["step_traffic_ratio"] = round(step_bytes / (roof["bytes_per_example"] * roof["examples_per_launch"]), 4)
+                roof["step_traffic_ratio_source"] = roof["traffic_source"] + " (+ the deferred-feature pass); counter bytes / algorithmic bytes of one batch"
+            except (OSError, ValueError, KeyError):
+                pass
     h.close()
     if sharded:
         dist.destroy_process_group()
@@ -820,6 +888,17 @@ def main():
                 out[key] = {kk: o[kk] for kk in keep + ("one_time_setup_seconds",) if kk in o}
             except Exception as exc:
                 out[key] = {"error": str(exc)[:200]}
+        # the per-rank compute side of the sharded step at P = 2 / 4 / 8 (the only part of the 1/2/4/8-GPU metric one GPU can measure)
+        try:
+            out["shard_probe"] = shard_probe(capi, args.n, args.k, args.nnz, out["value"])
+        except Exception as exc:
+            out["shard_probe"] = {"error": str(exc)[:200]}
+        if out.get("roofline") is not None:
+            out["roofline"]["per_config"] = {kk: (out[kk].get("roofline") or {}).get("frac") for kk in ("c2", "criteo", "als", "mcmc", "mcmc_c5")
+                                             if isinstance(out.get(kk), dict)}
+            sp = out.get("shard_probe", {}).get("ranks", {})
+            out["roofline"]["shard_probe"] = {pk: {"per_rank_examples_per_s": pv["per_rank_examples_per_s"], "frac": pv["frac_of_hbm_peak"],
+                                                   "modelled_speedup_exact": pv["modelled"]["speedup_vs_1_gpu_exact"]} for pk, pv in sp.items()}
     if rank == 0:
         # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION): flush it first so that the JSON
         # line is the LAST line on stdout

@@ -383,8 +383,8 @@ class Handle:
     def sgd_partial(self, slot, row0, n_rows, d_partial_ptr, stream=None):
         self._chk(self.lib.fmx_sgd_partial(self.h, slot, row0, n_rows, d_partial_ptr, stream))
 
-    def sgd_finish(self, slot, row0, n_rows, d_partial_ptr, apply=APPLY_DEFAULT, w0_chunk=0, stream=None, batch=0, flags=0):
-        opts = SgdOpts(SGD_MINIBATCH, apply, batch or n_rows, w0_chunk, flags, 0)
+    def sgd_finish(self, slot, row0, n_rows, d_partial_ptr, apply=APPLY_DEFAULT, w0_chunk=0, stream=None, batch=0, flags=0, bias_lag=0):
+        opts = SgdOpts(SGD_MINIBATCH, apply, batch or n_rows, w0_chunk, flags, bias_lag)
         self._chk(self.lib.fmx_sgd_finish(self.h, slot, row0, n_rows, d_partial_ptr, C.byref(opts), stream))
 
     def predict_finish(self, n_rows, d_partial_ptr, d_yhat_ptr, stream=None):
