@@ -180,11 +180,6 @@ template <int VEC> __device__ __forceinline__ void store_vec(float* __restrict__
       reinterpret_cast<float4*>(p)[c] = make_float4(in[4 * c], in[4 * c + 1], in[4 * c + 2], in[4 * c + 3]);
   }
 }
-// load of one linear weight w[j] (a 4-byte gather).  FMX_W_LOAD selects the cache policy for experiments:
-// 0 plain, 1 non-temporal, 2 sc1 (agent-scope relaxed atomic load).
-#ifndef FMX_W_LOAD
-#define FMX_W_LOAD 0
-#endif
 // V-row accesses with a non-temporal hint.  The 4*KP-byte rows stream through (every row is touched once per example
 // and the table is far larger than any cache): without the hint they are allocated in -- and later evicted from -- the
 // L2 / Infinity Cache path for nothing, and push out the lines that do have reuse (the 128-B lines holding w_j, the
@@ -213,13 +208,7 @@ template <int VEC, int BIT> __device__ __forceinline__ void load_row(const float
     load_vec<VEC>(p, out);
   }
 }
-#ifndef FMX_V_SC1
-#define FMX_V_SC1 0          // experiments: 1 = the one-pass kernel's row stores write through (agent scope) instead of staying dirty in L2 until the launch ends
-#endif
 template <int VEC, int BIT> __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&in)[VEC]) {
-  if constexpr (FMX_V_SC1 == 1 && BIT == 2 && VEC == 1) {
-    __hip_atomic_store(p, in[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else
   if constexpr ((FMX_V_NT & BIT) != 0) {
     if constexpr (VEC == 1) { __builtin_nontemporal_store(in[0], p); }
     else if constexpr (VEC == 2) {
@@ -238,29 +227,14 @@ template <int VEC, int BIT> __device__ __forceinline__ void store_row(float* __r
   }
 }
 
-// the row entries ({id, value}, 8 bytes) are a pure stream as well (read once per pass)
-#ifndef FMX_E_NT
-#define FMX_E_NT 0
-#endif
+// the row entries ({id, value}, 8 bytes) and the 4-byte gathers of a linear weight: plain loads.  (Non-temporal / agent-scope variants of
+// both, write-through row stores, a sixth wavefront per SIMD and the in-launch publish of S_e were measured in rounds 1-4 and lost or
+// bought nothing: scripts/experiments/r04_variants.patch re-creates them, DESIGN.md section 4 has the numbers.)
 template <class T> __device__ __forceinline__ T load_stream8(const T* p) {
   static_assert(sizeof(T) == 8, "8-byte records");
-#if FMX_E_NT
-  const uint64_t u = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(p));
-  T t; __builtin_memcpy(&t, &u, 8); return t;
-#else
   return *p;
-#endif
 }
-
-__device__ __forceinline__ float load_w(const float* p) {
-#if FMX_W_LOAD == 1
-  return __builtin_nontemporal_load(p);
-#elif FMX_W_LOAD == 2
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  return *p;
-#endif
-}
+__device__ __forceinline__ float load_w(const float* p) { return *p; }
 // loss multiplier, fm_learn_sgd_element.h:58-65
 __device__ __forceinline__ float multiplier(const Hyper& h, float p, float y) {
   if (h.task == 0) {
@@ -1725,12 +1699,9 @@ k_apply_seg(const SegWork sw, const Tab tb, Hyper h) {
 //       complete sums S_e and the multiplier are GIVEN (S_out / mult_out are read), nothing is predicted; the rows of the
 //       batch-unique features are gathered, updated and written back, the others are left to k_apply_seg as above.
 // ----------------------------------------------------------------------------------------------
-#ifndef FMX_FUSED_MIN_WAVES
-#define FMX_FUSED_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for (A/B knob)
-#endif
 enum { FUSED_STORE = 0, FUSED_ATOMIC = 1, FUSED_EXACT = 2, FUSED_APPLY = 3 };
 template <int KP, int ZR, int VAR>
-__global__ void __launch_bounds__(256, FMX_FUSED_MIN_WAVES)
+__global__ void __launch_bounds__(256)
 k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
         uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
         const double* __restrict__ w0_ptr, float* __restrict__ rest_out,
@@ -1824,34 +1795,14 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       }
       if constexpr (EXACT) {
         if (cm != 0) {                                         // some feature of this example is finished by k_apply_seg
-#ifndef FMX_S_PUBLISH
-#define FMX_S_PUBLISH 0       // experiments (what an in-launch hand-off of S_e would cost): 1 = agent-scope (sc1) dword stores, 2 = sc1 16-byte stores
-#endif
-          if constexpr (FMX_S_PUBLISH == 1 && VEC == 1) {
-            __hip_atomic_store(S_out + (size_t)e * KP + lane, sum[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else if constexpr (FMX_S_PUBLISH == 2 && VEC == 1 && KP == 64) {
-            // four lanes' factors gathered into one lane: sixteen 16-byte write-through stores instead of sixty-four 4-byte ones
-            const float a0 = __shfl(sum[0], (int)((lane & 15u) * 4u)), a1 = __shfl(sum[0], (int)((lane & 15u) * 4u + 1u));
-            const float a2 = __shfl(sum[0], (int)((lane & 15u) * 4u + 2u)), a3 = __shfl(sum[0], (int)((lane & 15u) * 4u + 3u));
-            if (lane < 16) {
-              typedef float v4f __attribute__((ext_vector_type(4)));
-              v4f t; t.x = a0; t.y = a1; t.z = a2; t.w = a3;
-              asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(S_out + (size_t)e * KP + lane * 4), "v"(t) : "memory");
-            }
-          } else {
-            if (lane < LPR) store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
-          }
+          if (lane < LPR) store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
           if (lane == 0) mult_out[e] = mult;
         }
       }
       float w_keep = __builtin_nanf("");
       if (h.k1 && lane < size && !(MASKED && ((cm >> lane) & 1ull))) {            // fm_sgd.h:38-43
         const float dw = -h.lr * (mult * en.value + h.regw * wv);
-#ifndef FMX_W_STORE
-#define FMX_W_STORE 0                                             // experiments: 1 = non-temporal store of the new w_j
-#endif
         if (ATOMIC) unsafeAtomicAdd(tb.w + (size_t)en.id * tb.ws, dw);
-        else if (FMX_W_STORE == 1) __builtin_nontemporal_store(wv + dw, tb.w + (size_t)en.id * tb.ws);
         else tb.w[(size_t)en.id * tb.ws] = wv + dw;
         w_keep = wv + dw;
       }
