@@ -409,7 +409,8 @@ def bench_group(args, capi, criteo):
         raise SystemExit("--gpus %d but %d HIP device(s) visible (--same-device puts every shard on device 0)" % (N, ndev))
     lr, regv = 0.01, 0.001
     hs = [capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
-                      device=0 if args.same_device else r, shard_rank=r, shard_world=N, shard_hash=1, place_candidates=args.place)
+                      device=0 if args.same_device else r, shard_rank=r, shard_world=N, shard_hash=1, place_candidates=args.place,
+                      exchange_algo=1 if args.exchange == "rsag" else 0)
           for r in range(N)]
     for h in hs:
         h.init_params(0.0, 0.01, 1)
@@ -457,7 +458,9 @@ def bench_group(args, capi, criteo):
         "roofline": {"bound": "hbm", "kernel": "k_rowsums + update (whole step, per GPU)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "v_read_frac": v_read_fraction(value, args.k, args.nnz, N),
                      "traffic": None, "bytes_per_example": per_ex, "examples_per_launch": int(st.batch_used)},
-        "exchange": {"collective": "all_reduce(sum) fp32, one per batch" + (", in 4 runs of rows overlapped with the sums" if not args.same_device else " (local reduction kernel)"),
+        "exchange": {"collective": ("reduce_scatter + all_gather (sum) fp32" if args.exchange == "rsag" else "all_reduce(sum) fp32, one per batch")
+                                   + (", in 4 runs of rows overlapped with the sums" if not args.same_device else " (local reduction kernel%s)" % ("s, two-phase" if args.exchange == "rsag" else "")),
+                     "algo": args.exchange,
                      "bytes_per_example": wire, "payload_MB_per_batch": round(wire * min(int(st.batch_used), args.rows) / 1e6, 2),
                      "algbw_GBps": round(value * wire / 1e9, 2), "pipelined": bool(args.pipeline),
                      "backend": "loopback" if args.same_device else "rccl"},
@@ -509,6 +512,9 @@ def main():
     ap.add_argument("--apply", default="default", choices=["default", "segmented", "atomic", "store"])
     ap.add_argument("--batch", type=int, default=0, help="minibatch rows (0: the library's choice -- 262144 cut to the stability bound of the rows, fmx_sgd_opts::batch); hogwild: rows per launch (0: 262144)")
     ap.add_argument("--w0-chunk", type=int, default=0, help="micro-chunk of the bias recurrence (0: library default, fmx_default_w0_chunk)")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rsag"],
+                    help="several GPUs: the per-batch exchange as ONE all-reduce (ncclAllReduce) or as reduce-scatter + all-gather "
+                         "(fmx_config::exchange_algo: on a fully connected xGMI node every GPU reduces its slice over all its links)")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true",
                     help="sharded: overlap the all-reduce of batch b+1 with the update of batch b (the one-batch-stale pipelined rule, "
                          "oracle fmo_sgd_epoch_minibatch_pipelined).  Default OFF: every N runs the SAME rule as N = 1")
@@ -582,7 +588,7 @@ def main():
     lr, regv = 0.01, 0.001
     h = capi.Handle(args.n, args.k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, regv, lr, -1.0, 1.0,
                     device=local_rank, shard_rank=rank, shard_world=world, shard_hash=1 if world > 1 else 0,
-                    place_candidates=args.place)
+                    place_candidates=args.place, exchange_algo=1 if args.exchange == "rsag" else 0)
     h.init_params(0.0, 0.01, 1)
     h.synth_rows(0, 123, 0, args.rows, args.nnz, capi.SYNTH_CRITEO if criteo else capi.SYNTH_UNIFORM)
     if criteo and rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -788,7 +794,8 @@ def main():
                     "bytes_per_example": per_ex, "examples_per_launch": rows_per_launch}
             # wire side: ONE all-reduce of [batch][KP + 1] fp32 per batch; algbw = payload bytes reduced per second
             wire = 4 * (info.k_padded + 1)
-            exchange = {"collective": "all_reduce(sum) fp32, one per batch", "bytes_per_example": wire,
+            exchange = {"collective": ("reduce_scatter + all_gather (sum) fp32, per run of rows" if args.exchange == "rsag" else "all_reduce(sum) fp32, one per batch"),
+                        "algo": args.exchange, "bytes_per_example": wire,
                         "payload_MB_per_batch": round(wire * rows_per_launch / 1e6, 2),
                         "algbw_GBps": round(value * wire / 1e9, 2), "pipelined": bool(args.pipeline), "backend": args.backend}
         out = {

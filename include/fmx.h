@@ -106,8 +106,15 @@ typedef struct fmx_config {
                                1 = every level, 0xFFFFFFFF = never */
   uint32_t exchange_runs;   /* several GPUs over RCCL: a batch's partial sums are exchanged in this many runs of rows, the all-reduce of
                                one run travelling while the next is summed.  0 = default (4), 1 = one all-reduce per batch */
-  uint32_t reserved;
+  uint32_t exchange_algo;   /* several GPUs: how the per-batch exchange of the partial sums is carried.  FMX_EXCHANGE_ALLREDUCE (0): one
+                               all-reduce (ncclAllReduce; RCCL picks ring / tree).  FMX_EXCHANGE_RS_AG (1): reduce-scatter + all-gather --
+                               on a fully connected xGMI node every GPU reduces its 1/P slice over its P - 1 direct links and broadcasts it
+                               back over the same links, instead of a ring that is bound by ONE link.  Pieces whose length
+                               is not a multiple of the shard count fall back to the all-reduce.  Same sums either way (the loopback exchange
+                               of shards sharing a device adds in the same order: bit-identical). */
 } fmx_config;
+#define FMX_EXCHANGE_ALLREDUCE 0u
+#define FMX_EXCHANGE_RS_AG     1u
 
 typedef struct fmx_sgd_opts {
   int32_t  mode;            /* FMX_SGD_* */

@@ -42,7 +42,7 @@ class Config(C.Structure):
                 ("task", C.c_int32), ("reg0", C.c_double), ("regw", C.c_double), ("regv", C.c_double),
                 ("learn_rate", C.c_double), ("min_target", C.c_double), ("max_target", C.c_double),
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_hash", C.c_int32),
-                ("place_candidates", C.c_int32), ("als_split_min", C.c_uint32), ("exchange_runs", C.c_uint32), ("reserved", C.c_uint32)]
+                ("place_candidates", C.c_int32), ("als_split_min", C.c_uint32), ("exchange_runs", C.c_uint32), ("exchange_algo", C.c_uint32)]
 
 
 ALS_SPLIT_NEVER = 0xFFFFFFFF
@@ -214,12 +214,12 @@ class Handle:
 
     def __init__(self, num_attribute, num_factor, k0=True, k1=True, task=TASK_REGRESSION, reg0=0.0, regw=0.0, regv=0.0,
                  learn_rate=0.0, min_target=0.0, max_target=0.0, device=-1, shard_rank=0, shard_world=1, shard_hash=0,
-                 place_candidates=0, als_split_min=None, exchange_runs=0):
+                 place_candidates=0, als_split_min=None, exchange_runs=0, exchange_algo=0):
         self.lib = load()
         self.cfg = Config(int(num_attribute), int(num_factor), int(bool(k0)), int(bool(k1)), int(task),
                           float(reg0), float(regw), float(regv), float(learn_rate), float(min_target),
                           float(max_target), int(device), int(shard_rank), int(shard_world), int(shard_hash),
-                          int(place_candidates), int(ALS_SPLIT_MIN if als_split_min is None else als_split_min), int(exchange_runs), 0)
+                          int(place_candidates), int(ALS_SPLIT_MIN if als_split_min is None else als_split_min), int(exchange_runs), int(exchange_algo))
         self.h = H()
         rc = self.lib.fmx_create(C.byref(self.cfg), C.byref(self.h))
         if rc != FMX_OK:

@@ -17,6 +17,8 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -39,7 +41,8 @@ Rccl* rccl() {                                   // bound once per process; null
 #define BIND(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym)); \
   if (!r.field) { r.err = std::string("librccl lacks ") + sym; r.lib = nullptr; return nullptr; }
   BIND(GetUniqueId, "ncclGetUniqueId") BIND(CommInitRank, "ncclCommInitRank") BIND(CommDestroy, "ncclCommDestroy")
-  BIND(AllReduce, "ncclAllReduce") BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
+  BIND(AllReduce, "ncclAllReduce") BIND(ReduceScatter, "ncclReduceScatter") BIND(AllGather, "ncclAllGather")
+  BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
   BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
   return &r;
@@ -71,6 +74,30 @@ __global__ void __launch_bounds__(256) k_sum_shards(BufList bufs, size_t n4, siz
   }
 }
 
+// the same sum as reduce-scatter + all-gather (fmx_config::exchange_algo = FMX_EXCHANGE_RS_AG on shards that share a device): shard r
+// reduces slice r of everybody's buffer into its own (same order of addition as k_sum_shards: bit-identical), then every shard copies
+// slice r from shard r.  n4 = float4s per slice.
+__global__ void __launch_bounds__(256) k_rs_shards(BufList bufs, size_t n4) {
+  for (int r = 0; r < bufs.n; r++)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+      const size_t at = (size_t)r * n4 + i;
+      float4 a = reinterpret_cast<const float4*>(bufs.p[0])[at];
+      for (int q = 1; q < bufs.n; q++) {
+        const float4 b = reinterpret_cast<const float4*>(bufs.p[q])[at];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      reinterpret_cast<float4*>(bufs.p[r])[at] = a;                 // (slice r of shard r only: nobody else's slice r is read after this)
+    }
+}
+__global__ void __launch_bounds__(256) k_ag_shards(BufList bufs, size_t n4) {
+  for (int r = 0; r < bufs.n; r++)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+      const size_t at = (size_t)r * n4 + i;
+      const float4 a = reinterpret_cast<const float4*>(bufs.p[r])[at];
+      for (int q = 0; q < bufs.n; q++) if (q != r) reinterpret_cast<float4*>(bufs.p[q])[at] = a;
+    }
+}
+
 }  // namespace
 
 static int gfail(fmx_group g, int code, const char* fmt, ...) {
@@ -97,6 +124,58 @@ static int ensure_xbuf(fmx_handle h, size_t floats) {
   return FMX_OK;
 }
 
+// the sum of one piece [b, b + cnt) over the communicator, on the members' comm streams (callers bracket the events): ncclAllReduce, or --
+// fmx_config::exchange_algo = FMX_EXCHANGE_RS_AG and cnt a multiple of the shard count -- ncclReduceScatter + ncclAllGather in place (rank r
+// reduces slice r, then gathers the others')
+static int rccl_sum_piece(fmx_group g, int which, size_t off, size_t cnt, size_t off2 = 0, size_t cnt2 = 0) {
+  Rccl* R = rccl();
+  const size_t n = g->hs.size();
+  const uint32_t W = (uint32_t)g->hs[0]->cfg.shard_world;
+  if (g->hs[0]->cfg.exchange_algo != FMX_EXCHANGE_RS_AG) {          // all-reduce: both pieces of a run in ONE group (one fused launch)
+    if (n > 1 || cnt2) NCCLCHK(g->hs[0], R->GroupStart());
+    for (size_t i = 0; i < n; i++) {
+      fmx_handle h = g->hs[i];
+      HIPCHK(h, hipSetDevice(h->device));
+      float* b = h->xbuf[which];
+      NCCLCHK(h, R->AllReduce(b + off, b + off, cnt, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
+      if (cnt2) NCCLCHK(h, R->AllReduce(b + off2, b + off2, cnt2, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
+    }
+    if (n > 1 || cnt2) NCCLCHK(g->hs[0], R->GroupEnd());
+    return FMX_OK;
+  }
+  if (cnt2) { int prc = rccl_sum_piece(g, which, off2, cnt2); if (prc) return prc; }
+  const bool rsag = cnt % W == 0 && cnt > 0;
+  if (!rsag) {
+    if (n > 1) NCCLCHK(g->hs[0], R->GroupStart());
+    for (size_t i = 0; i < n; i++) {
+      fmx_handle h = g->hs[i];
+      HIPCHK(h, hipSetDevice(h->device));
+      float* b = h->xbuf[which] + off;
+      NCCLCHK(h, R->AllReduce(b, b, cnt, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
+    }
+    if (n > 1) NCCLCHK(g->hs[0], R->GroupEnd());
+    return FMX_OK;
+  }
+  const size_t sl = cnt / W;
+  if (n > 1) NCCLCHK(g->hs[0], R->GroupStart());
+  for (size_t i = 0; i < n; i++) {
+    fmx_handle h = g->hs[i];
+    HIPCHK(h, hipSetDevice(h->device));
+    float* b = h->xbuf[which] + off;
+    NCCLCHK(h, R->ReduceScatter(b, b + (size_t)h->cfg.shard_rank * sl, sl, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
+  }
+  if (n > 1) NCCLCHK(g->hs[0], R->GroupEnd());
+  if (n > 1) NCCLCHK(g->hs[0], R->GroupStart());
+  for (size_t i = 0; i < n; i++) {
+    fmx_handle h = g->hs[i];
+    HIPCHK(h, hipSetDevice(h->device));
+    float* b = h->xbuf[which] + off;
+    NCCLCHK(h, R->AllGather(b + (size_t)h->cfg.shard_rank * sl, b, sl, ncclFloat32, (ncclComm_t)g->comms[i], h->stream_comm));
+  }
+  if (n > 1) NCCLCHK(g->hs[0], R->GroupEnd());
+  return FMX_OK;
+}
+
 // the exchange of one partial buffer: sum over the shards.  exchange_begin is called right after the partial sums were
 // enqueued on every shard's stream; exchange_end makes every shard's stream wait for the result (sum_of()).
 //   RCCL: in-place all-reduce on the shard's own COMM stream (ordered behind the gather by an event), so that it can run
@@ -112,13 +191,7 @@ static int exchange_begin(fmx_group g, int which, size_t count) {
       HIPCHK(h, hipEventRecord(h->ev_x[which], h->stream));
       HIPCHK(h, hipStreamWaitEvent(h->stream_comm, h->ev_x[which], 0));
     }
-    if (n > 1) NCCLCHK(g->hs[0], R->GroupStart());
-    for (size_t i = 0; i < n; i++) {
-      fmx_handle h = g->hs[i];
-      HIPCHK(h, hipSetDevice(h->device));
-      NCCLCHK(h, R->AllReduce(h->xbuf[which], h->xbuf[which], count, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
-    }
-    if (n > 1) NCCLCHK(g->hs[0], R->GroupEnd());
+    { int prc = rccl_sum_piece(g, which, 0, count); if (prc) return prc; }
     for (size_t i = 0; i < n; i++) {
       fmx_handle h = g->hs[i];
       HIPCHK(h, hipSetDevice(h->device));
@@ -132,6 +205,12 @@ static int exchange_begin(fmx_group g, int which, size_t count) {
       bl.p[i] = g->hs[i]->xbuf[which];
       if (i) { HIPCHK(h0, hipEventRecord(g->ev_part[i], g->hs[i]->stream)); HIPCHK(h0, hipStreamWaitEvent(h0->stream, g->ev_part[i], 0)); }
     }
+    if (h0->cfg.exchange_algo == FMX_EXCHANGE_RS_AG && count % (4 * n) == 0 && count > 0) {       // the two-phase form of the same sum
+      const size_t n4 = count / 4 / n;
+      const dim3 grid((unsigned)std::min<size_t>((n4 + 255) / 256, 2048));
+      hipLaunchKernelGGL(k_rs_shards, grid, dim3(256), 0, h0->stream, bl, n4);
+      hipLaunchKernelGGL(k_ag_shards, grid, dim3(256), 0, h0->stream, bl, n4);
+    } else
     hipLaunchKernelGGL(k_sum_shards, dim3((unsigned)std::min<size_t>((count / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, h0->stream,
                        bl, count / 4, count);
     HIPCHK(h0, hipGetLastError());
@@ -152,15 +231,7 @@ static int exchange_rows(fmx_group g, int which, size_t off_s, size_t cnt_s, siz
     HIPCHK(h, hipEventRecord(h->ev_x[which], h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream_comm, h->ev_x[which], 0));
   }
-  NCCLCHK(g->hs[0], R->GroupStart());
-  for (size_t i = 0; i < n; i++) {
-    fmx_handle h = g->hs[i];
-    HIPCHK(h, hipSetDevice(h->device));
-    float* b = h->xbuf[which];
-    NCCLCHK(h, R->AllReduce(b + off_s, b + off_s, cnt_s, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
-    NCCLCHK(h, R->AllReduce(b + off_c, b + off_c, cnt_c, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream_comm));
-  }
-  NCCLCHK(g->hs[0], R->GroupEnd());
+  { int prc = rccl_sum_piece(g, which, off_s, cnt_s, off_c, cnt_c); if (prc) return prc; }
   if (last)
     for (size_t i = 0; i < n; i++) {
       fmx_handle h = g->hs[i];

@@ -168,8 +168,9 @@ def test_sharded_params_round_trip_and_rows(capi, oracle, shard_hash):
         h.close()
 
 
+@pytest.mark.parametrize("algo", [0, 1])              # fmx_config::exchange_algo: ncclAllReduce | ncclReduceScatter + ncclAllGather
 @pytest.mark.parametrize("world,lag,pipeline", [(1, 2, False), (1, 1, True), (2, 2, False), (4, 1, False)])
-def test_library_rccl_schedule_matches_the_oracle_rule(capi, oracle, world, lag, pipeline):
+def test_library_rccl_schedule_matches_the_oracle_rule(capi, oracle, world, lag, pipeline, algo):
     """the schedule a libFM process runs on several GPUs (fmx_comm_init_rank / a group of handles on distinct devices ->
     fmx_sgd_epoch): partial sums and their all-reduce in RUNS of rows (the wire works while the next run is summed), then the
     update.  world = 1: one rank through the RCCL binding (the all-reduce is the identity, every offset of the chunked
@@ -186,7 +187,7 @@ def test_library_rccl_schedule_matches_the_oracle_rule(capi, oracle, world, lag,
     m.w0 = 0.05
     d = oracle.Data(ent, rp, y)
     hs = [capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.002, 0.01, 0.004, -1.0, 1.0, device=r, shard_rank=r,
-                      shard_world=world, shard_hash=1) for r in range(world)]
+                      shard_world=world, shard_hash=1, exchange_algo=algo) for r in range(world)]
     for h in hs:
         h.set_params(m.w0, m.w, m.v)
         h.upload_rows(0, ent, rp, y)
@@ -210,6 +211,28 @@ def test_library_rccl_schedule_matches_the_oracle_rule(capi, oracle, world, lag,
         grp.close()
     for h in hs:
         h.close()
+
+
+def test_reduce_scatter_all_gather_is_the_same_sum_on_loopback_shards(capi):
+    """fmx_config::exchange_algo = FMX_EXCHANGE_RS_AG on shards that share a device: the two-phase reduction (every shard reduces its slice,
+    then everybody copies the slices) leaves the same floats as the one-kernel all-reduce -- the trained models are bit-identical"""
+    n, k, nnz, rows, batch, world = 200_000, 64, 16, 40_000, 8192, 4
+    res = []
+    for algo in (0, 1):
+        hs = [capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0, shard_rank=r, shard_world=world,
+                          shard_hash=1, exchange_algo=algo) for r in range(world)]
+        for x in hs:
+            x.init_params(0.0, 0.05, 3)
+            x.synth_rows(0, 11, 0, rows, nnz)
+        grp = capi.Group(hs)
+        for _ in range(2):
+            grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, 0, capi.FLAG_BIAS_LAG, 2)
+        res.append((grp.predict(0, rows), hs[0].get_w0()))
+        grp.close()
+        for x in hs:
+            x.close()
+    assert res[0][0].tobytes() == res[1][0].tobytes() and res[0][1] == res[1][1]
+    assert np.abs(res[0][0]).max() > 1e-3
 
 
 def test_group_at_bench_shape_matches_single_handle(capi):
