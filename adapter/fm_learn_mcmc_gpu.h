@@ -20,6 +20,8 @@
 #define FM_LEARN_MCMC_GPU_H_
 
 #include <cstring>
+#include <ctime>
+#include <sstream>
 #include <vector>
 #include <string>
 #include "fmx.h"
@@ -64,11 +66,28 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
     std::vector<double> mom(2 + (size_t)2 * G * (1 + k));
     std::vector<double> p(test.num_cases);
     for (uint i = 0; i < num_iter; i++) {
+      double iteration_time = getusertime();                                 // _learn :85-87
+      clock_t iteration_time3 = clock();
+      double iteration_time4 = getusertime4();
       if (do_multilevel) {                                                   // the prior draws of draw_all (:433-452, :519-527)
         gcheck(fmx_group_als_moments(grp, &mom[0]));
         draw_priors_from_moments(mom, train.num_cases);
       } else {
         alpha = alpha_0; w_mu.init(mu_0); if (k > 0) v_mu.init(mu_0);        // draw_alpha / draw_*_mu without multilevel
+      }
+      if (log != NULL) {                                                     // what draw_all logs (:434-436, :446-451, :518-525)
+        std::ostringstream ss;
+        log->log("alpha", alpha);
+        for (uint g = 0; g < G; g++) {
+          if (fm->k1) {
+            ss.str(""); ss << "wmu[" << g << "]"; log->log(ss.str(), w_mu(g));
+            ss.str(""); ss << "wlambda[" << g << "]"; log->log(ss.str(), w_lambda(g));
+          }
+          for (int f = 0; f < k; f++) {
+            ss.str(""); ss << "vmu[" << g << "," << f << "]"; log->log(ss.str(), v_mu(g, f));
+            ss.str(""); ss << "vlambda[" << g << "," << f << "]"; log->log(ss.str(), v_lambda(g, f));
+          }
+        }
       }
       o.alpha = alpha; o.do_sample = do_sample ? 1 : 0; o.seed = (uint64_t)gpu_seed;
       o.w_mu = w_mu(0); o.w_lambda = w_lambda(0);
@@ -82,24 +101,52 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
       fmx_als_stats st;
       gcheck(fmx_group_als_sweep(grp, &o, &st));
       gcheck(fmx_group_predict(grp, 1, p.empty() ? NULL : &p[0]));
-      double rmse_or_acc = 0;
       for (uint c2 = 0; c2 < test.num_cases; c2++) {                       // _learn :127-138 / :151-161
         double v = p[c2];
         if (task == TASK_REGRESSION) {
           pred_this(c2) = v;
           v = std::min(max_target, v); v = std::max(min_target, v);
-          pred_sum_all(c2) += v;
-          double err = pred_sum_all(c2) / (i + 1) - test.target(c2);
-          rmse_or_acc += err * err;
         } else {
           v = cdf_gaussian(v);
           pred_this(c2) = v;
-          pred_sum_all(c2) += v;
-          if (((pred_sum_all(c2) / (i + 1) >= 0.5) && (test.target(c2) >= 0)) || ((pred_sum_all(c2) / (i + 1) < 0.5) && (test.target(c2) < 0))) rmse_or_acc += 1;
+        }
+        pred_sum_all(c2) += v;
+        if (i >= 5) pred_sum_all_but5(c2) += v;
+      }
+      iteration_time = (getusertime() - iteration_time);                     // :199-206
+      iteration_time3 = clock() - iteration_time3;
+      iteration_time4 = (getusertime4() - iteration_time4);
+      if (log != NULL) {
+        log->log("time_learn", iteration_time);
+        log->log("time_learn2", (double)iteration_time3 / CLOCKS_PER_SEC);
+        log->log("time_learn4", (double)iteration_time4);
+      }
+      // the test metrics over the first num_eval_cases cases (:209-264): this iteration's prediction, the running mean over all iterations
+      // and over all but the first five -- the reference's own normalisers, 1.0 / (i - 5 + 1) in unsigned arithmetic for i < 5 included
+      if (task == TASK_REGRESSION) {
+        double rmse_this, mae_this, rmse_all, mae_all, rmse_but5, mae_but5;
+        eval_regression(pred_this, test.target, 1.0, rmse_this, mae_this, num_eval_cases);
+        eval_regression(pred_sum_all, test.target, 1.0 / (i + 1), rmse_all, mae_all, num_eval_cases);
+        eval_regression(pred_sum_all_but5, test.target, 1.0 / (i - 5 + 1), rmse_but5, mae_but5, num_eval_cases);
+        std::cout << "#Iter=" << std::setw(3) << i << "\tTrain=" << st.train_metric << "\tTest=" << rmse_all << std::endl;
+        if (log != NULL) {
+          log->log("rmse", rmse_all); log->log("mae", mae_all);
+          log->log("rmse_mcmc_this", rmse_this); log->log("rmse_mcmc_all", rmse_all); log->log("rmse_mcmc_all_but5", rmse_but5);
+          log->newLine();
+        }
+      } else {
+        double acc_this, acc_all, acc_but5, ll_this, ll_all, ll_but5;
+        eval_classification(pred_this, test.target, 1.0, acc_this, ll_this, num_eval_cases);
+        eval_classification(pred_sum_all, test.target, 1.0 / (i + 1), acc_all, ll_all, num_eval_cases);
+        eval_classification(pred_sum_all_but5, test.target, 1.0 / (i - 5 + 1), acc_but5, ll_but5, num_eval_cases);
+        std::cout << "#Iter=" << std::setw(3) << i << "\tTrain=" << st.train_metric << "\tTest=" << acc_all << "\tTest(ll)=" << ll_all << std::endl;
+        if (log != NULL) {
+          log->log("accuracy", acc_all);
+          log->log("acc_mcmc_this", acc_this); log->log("acc_mcmc_all", acc_all); log->log("acc_mcmc_all_but5", acc_but5);
+          log->log("ll_mcmc_this", ll_this); log->log("ll_mcmc_all", ll_all); log->log("ll_mcmc_all_but5", ll_but5);
+          log->newLine();
         }
       }
-      rmse_or_acc = (task == TASK_REGRESSION) ? std::sqrt(rmse_or_acc / test.num_cases) : rmse_or_acc / test.num_cases;
-      std::cout << "#Iter=" << std::setw(3) << i << "\tTrain=" << st.train_metric << "\tTest=" << rmse_or_acc << std::endl;
     }
     gcheck(fmx_group_als_end(grp));
     for (size_t r = 0; r < hs.size(); r++)                   // every shard writes its own features into the host block
@@ -110,6 +157,33 @@ class fm_learn_als_gpu : public fm_learn_mcmc {
   fmx_handle h;                                            // shard 0 (the only handle without gpu_devices)
   std::vector<fmx_handle> hs;
   fmx_group grp;
+  // fm_learn_mcmc_simultaneous::_evaluate / _evaluate_class (fm_learn_mcmc_simultaneous.h:272-313) over the cases [0, num_eval_cases): the
+  // scaled prediction clamped to the target range -> RMSE, MAE; the scaled probability -> accuracy at 0.5 and the base-10 log-likelihood of
+  // the probability clipped to [0.01, 0.99]
+  void eval_regression(DVector<double>& pred, DVector<DATA_FLOAT>& target, double normalizer, double& rmse, double& mae, uint upto) {
+    double se = 0, ae = 0; uint cnt = 0;
+    for (uint c = 0; c < std::min((uint)pred.dim, upto); c++) {
+      double q = pred(c) * normalizer;
+      q = std::min(max_target, q); q = std::max(min_target, q);
+      const double err = q - target(c);
+      se += err * err; ae += std::abs((double)err); cnt++;
+    }
+    rmse = std::sqrt(se / cnt); mae = ae / cnt;
+  }
+  void eval_classification(DVector<double>& pred, DVector<DATA_FLOAT>& target, double normalizer, double& accuracy, double& loglikelihood, uint upto) {
+    double ll = 0; uint acc = 0, cnt = 0;
+    for (uint c = 0; c < std::min((uint)pred.dim, upto); c++) {
+      const double q = pred(c) * normalizer;
+      if (((q >= 0.5) && (target(c) > 0.0)) || ((q < 0.5) && (target(c) < 0.0))) acc++;
+      const double m = (target(c) + 1.0) * 0.5;
+      double pll = q;
+      if (pll > 0.99) pll = 0.99;
+      if (pll < 0.01) pll = 0.01;
+      ll -= m * log10(pll) + (1 - m) * log10(1 - pll);
+      cnt++;
+    }
+    loglikelihood = ll / cnt; accuracy = (double)acc / cnt;
+  }
   void check(int rc) { if (rc != FMX_OK) throw std::string(fmx_last_error(h)); }
   void gcheck(int rc) { if (rc != FMX_OK) throw std::string(fmx_group_last_error(grp)); }
 

@@ -342,12 +342,16 @@ int main(int argc, char** argv) {
       fml->validation = NULL;
       fml->num_iter = iters;
       fml->num_eval_cases = test.num_cases;
+      if (const char* e = getenv("FMX_NUM_EVAL_CASES")) fml->num_eval_cases = (uint)atoi(e);   // -num_eval_cases, libfm.cpp:286
       fml->do_sample = !is_als;                                // libfm.cpp:135-139
       fml->do_multilevel = !is_als;
       fml->fm = &fm; fml->max_target = train.max_target; fml->min_target = train.min_target; fml->meta = &meta;
       set_task(fml, task, train, test);
       fml->log = NULL;
+      RLog* rlog = NULL;                                       // -rlog, libfm.cpp:311-324: the learner registers its fields in init()
+      if (const char* e = getenv("FMX_RLOG")) { rlog = new RLog(new std::ofstream(e)); fml->log = rlog; }
       fml->init();
+      if (rlog) rlog->init();                                  // libfm.cpp:405-407: the header line
       fm.reg0 = reg0; fm.regw = regw; fm.regv = regv;         // libfm.cpp:346-352
       fml->w_lambda.init(fm.regw); fml->v_lambda.init(fm.regv);
       if (getenv("FMX_GROUP_REG")) {                           // -regular 'r0,w_1..w_G,v_1..v_G', libfm.cpp:353-363

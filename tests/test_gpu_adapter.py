@@ -89,6 +89,65 @@ def test_reference_driver_with_gpu_als_learner(oracle, name, devices):
     np.testing.assert_allclose(pred_out, z["pred_out"], rtol=1e-4, atol=5e-5)
 
 
+def _run_mcmc_harness(O, z, g, td, mode, gpu, eval_cases):
+    trf, tef = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm")
+    if not os.path.exists(trf):
+        O.Data(z["train_entries"], z["train_row_ptr"], z["train_target"]).write_libsvm(trf)
+        O.Data(z["test_entries"], z["test_row_ptr"], z["test_target"]).write_libsvm(tef)
+    pre = os.path.join(td, "out_%s_%d" % (mode, gpu))
+    exe = HARNESS if gpu else os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    cfg = [mode + ("_gpu" if gpu else ""), trf, tef, str(z["task"]), int(z["k0"]), int(z["k1"]), int(z["k"]), 8]
+    if mode == "als":
+        cfg += [repr(g.reg[0]), repr(g.reg[1]), repr(g.reg[2])]
+    cfg += [repr(float(z["init_stdev"])), int(z["seed"]), pre]
+    env = dict(os.environ, FMX_RLOG=pre + ".rlog", FMX_NUM_EVAL_CASES=str(eval_cases))
+    r = subprocess.run([exe] + [str(c) for c in cfg], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("#Iter=")]
+    rl = [ln.split("\t") for ln in open(pre + ".rlog").read().splitlines()]
+    return lines, rl
+
+
+@pytest.mark.parametrize("name,mode", [("als_cls_ragged", "als"), ("als_reg_ml", "als"), ("als_cls_ragged", "mcmc")])
+def test_gpu_als_learner_prints_and_logs_what_the_reference_does(oracle, tmp_path, name, mode):
+    """round-4 verdict: the ALS / MCMC adapter's OUTPUT is the reference's (fm_learn_mcmc_simultaneous.h:199-264) -- the progress line
+    (`#Iter= ..\tTrain=..\tTest=..` and, for classification, `\tTest(ll)=..`), the -rlog header the learner registers in init() and one row
+    per iteration with every field the stock learner fills (alpha, the prior tables, time_learn*, rmse / mae / rmse_mcmc_* or accuracy /
+    acc_mcmc_* / ll_mcmc_*, incl. the all-but-the-first-five running means), over the first num_eval_cases test cases.  ALS is deterministic:
+    the numbers agree to 1e-4; the sampled chain agrees in form (its numbers are held by tests/test_gpu_mcmc.py)."""
+    stock = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not (os.path.exists(HARNESS) and os.path.exists(stock)):
+        pytest.skip("oracle/_ref harnesses not built (need /root/reference at build time)")
+    g = Golden(name)
+    z = g.z
+    n_test = len(z["test_target"])
+    eval_cases = max(1, n_test // 2)
+    ref_lines, ref_log = _run_mcmc_harness(oracle, z, g, str(tmp_path), mode, 0, eval_cases)
+    gpu_lines, gpu_log = _run_mcmc_harness(oracle, z, g, str(tmp_path), mode, 1, eval_cases)
+    assert len(ref_lines) == len(gpu_lines) == 8
+    assert gpu_log[0] == ref_log[0] and len(gpu_log) == len(ref_log) == 9      # same header (fields and order), one row per iteration
+    cls = g.task == 1
+    for a, b in zip(ref_lines, gpu_lines):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert [x.split("=")[0] for x in fa] == [x.split("=")[0] for x in fb] == (["#Iter", "Train", "Test"] + (["Test(ll)"] if cls else []))
+        assert fa[0] == fb[0]
+        if mode == "als":
+            for x, y in zip(fa[1:], fb[1:]):
+                xv, yv = float(x.split("=")[1]), float(y.split("=")[1])
+                assert abs(xv - yv) <= 2e-4 * abs(xv) + (2.0 / n_test if cls else 1e-5), (a, b)
+    hdr = ref_log[0]
+    timing = {i for i, f in enumerate(hdr) if f.startswith("time_learn")}
+    for ra, rb in zip(ref_log[1:], gpu_log[1:]):
+        assert len(ra) == len(rb) == len(hdr)
+        for i, (x, y) in enumerate(zip(ra, rb)):
+            if i in timing:
+                continue
+            xv, yv = float(x), float(y)
+            assert np.isnan(xv) == np.isnan(yv), (hdr[i], x, y)       # the same fields are filled (all_but5 included, from iteration 5 on)
+            if mode == "als" and not np.isnan(xv):
+                assert abs(xv - yv) <= 2e-4 * abs(xv) + (2.0 / eval_cases if hdr[i].startswith("acc") else 2e-5), (hdr[i], x, y)
+
+
 @pytest.mark.parametrize("blocks", ["keep", "expand"])
 def test_reference_driver_with_gpu_als_learner_on_relations(oracle, tmp_path, blocks):
     """block-structured data through the reference's own RelationData / RelationJoin loaders (FMX_RELATIONS = `-relation`)
