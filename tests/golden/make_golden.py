@@ -139,6 +139,10 @@ MCMC_CASES = {
     "mcmc_reg_ml_k64": dict(gen="movielens_shaped", train=dict(n_users=300, n_items=200, n_rows=6000, seed=17),
                             test=dict(n_users=300, n_items=200, n_rows=1500, seed=17, _skip=6000),
                             cfg=dict(task="r", k0=1, k1=1, k=64, iters=40, init_stdev=0.1, seed=42)),
+    # round 5: BASELINE configs[4]'s factor count (k = 128: two floats per lane, the VEC = 2 path of the draws WITH noise), `--mcmc-only mcmc_reg_ml_k128`
+    "mcmc_reg_ml_k128": dict(gen="movielens_shaped", train=dict(n_users=300, n_items=200, n_rows=6000, seed=19),
+                             test=dict(n_users=300, n_items=200, n_rows=1500, seed=19, _skip=6000),
+                             cfg=dict(task="r", k0=1, k1=1, k=128, iters=40, init_stdev=0.1, seed=42)),
     "mcmc_reg_ml_groups": dict(gen="movielens_shaped", train=dict(n_users=300, n_items=200, n_rows=6000, seed=13),
                                test=dict(n_users=300, n_items=200, n_rows=1500, seed=13, _skip=6000), groups=("split", 300), n_nominal=500,
                                cfg=dict(task="r", k0=1, k1=1, k=8, iters=40, init_stdev=0.1, seed=42)),
@@ -150,8 +154,8 @@ def make_mcmc(only=None):
     for name, case in MCMC_CASES.items():
         if only and name not in only:
             continue
-        if not only and name == "mcmc_reg_ml_k64":
-            continue                                          # (added in round 4 without touching the round-1 fixtures)
+        if not only and name in ("mcmc_reg_ml_k64", "mcmc_reg_ml_k128"):
+            continue                                          # (added in rounds 4 / 5 without touching the round-1 fixtures)
         gen = getattr(datagen, case["gen"])
         kw = dict(case["train"])
         n_tr, n_te = kw["n_rows"], case["test"]["n_rows"]
@@ -399,7 +403,7 @@ def make_mcmc_seed_band(seeds=range(101, 113), only=None):
     if only:                                                  # add / refresh single fixtures, keep the rest of the band file as it is
         out = dict(np.load(band_file))
     for name, case in MCMC_CASES.items():
-        if (only and name not in only) or (not only and name == "mcmc_reg_ml_k64"):
+        if (only and name not in only) or (not only and name in ("mcmc_reg_ml_k64", "mcmc_reg_ml_k128")):
             continue
         z = np.load(os.path.join(HERE, name + ".npz"))
         cfg = case["cfg"]

@@ -121,6 +121,45 @@ def test_config4_sweep_k128_n1e8(capi, oracle):
     als_sub_model_sweeps(capi, oracle, 100_000_000, 128, 16, 98304, 7, 1)
 
 
+def test_config4_eight_shards_k128_n1e8_equal_one_handle(capi):
+    """BASELINE configs[4] as it is worded: 'k = 128, 1e8 features, V sharded across 8': the sweep through fmx_group_als_* over EIGHT feature
+    shards (on one GPU: the loopback exchange; 8 x 6.4 GB of tables next to the single handle's 51 GB) against the single-handle sweep
+    on the same rows and start values -- without sampling and WITH (do_sample: the draws are keyed by the GLOBAL feature id, so a
+    shard draws what the unsharded handle draws).  The shards re-predict from all-reduced fp64 caches; agreement is to fp32 rounding."""
+    n, k, nnz, rows, world = 100_000_000, 128, 16, 65536, 8
+    w_lambda, v_lambda = 1.0, 10.0
+    res = {}
+    for tag in ("one", "eight"):
+        W = 1 if tag == "one" else world
+        hs = [capi.Handle(n, k, True, True, capi.TASK_REGRESSION, 0.0, w_lambda, v_lambda, 0.0, -1.0, 1.0, device=0, shard_rank=r, shard_world=W,
+                          shard_hash=1 if W > 1 else 0) for r in range(W)]
+        for h in hs:
+            h.init_params(0.0, 0.05, 7)
+            h.synth_rows(0, 4242, 2_000_000, rows, nnz)
+        out = []
+        if W == 1:
+            h = hs[0]
+            h.als_begin(0)
+            out.append(h.als_sweep(w_lambda, v_lambda).train_metric)
+            out.append(h.als_sweep(w_lambda, v_lambda, alpha=1.5, do_sample=True, seed=99).train_metric)
+            p = h.predict(0, rows)
+            h.als_end()
+        else:
+            grp = capi.Group(hs)
+            grp.als_begin(0)
+            out.append(grp.als_sweep(w_lambda, v_lambda).train_metric)
+            out.append(grp.als_sweep(w_lambda, v_lambda, alpha=1.5, do_sample=True, seed=99).train_metric)
+            p = grp.predict(0, rows)
+            grp.als_end()
+            grp.close()
+        res[tag] = (np.array(out), p)
+        for h in hs:
+            h.close()
+    np.testing.assert_allclose(res["eight"][0], res["one"][0], rtol=1e-4)
+    np.testing.assert_allclose(res["eight"][1], res["one"][1], rtol=1e-4, atol=5e-5)
+    assert np.abs(res["one"][1]).max() > 1e-3
+
+
 # the band DESIGN.md section 3 states (measured on the CPU with the oracle's two loops: scripts/cpu_online_vs_rule.py, and asserted
 # here with the DEVICE in place of the oracle's rule)
 # measured (profiles/r04_parity_vs_online.json): bias 0.0247 apart, predictions of the epoch's rows (rms 0.20) mean 0.024 / max 0.049 apart

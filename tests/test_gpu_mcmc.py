@@ -88,6 +88,18 @@ def test_mcmc_regression_posterior_mean_k64(oracle):
     assert runs[0][1].v_lambda_last.shape[-1] == 64
 
 
+def test_mcmc_regression_posterior_mean_k128(oracle):
+    """BASELINE configs[4]'s factor count (round-4 verdict, row C5): 8 sampled chains at k = 128 -- two factors per lane (VEC = 2) through the
+    noise generator, the factor-major shadow and 128 per-factor hyper-priors -- against the reference's own 12-seed band on the same data
+    (tests/golden/make_golden.py --mcmc-only mcmc_reg_ml_k128)"""
+    g = Golden("mcmc_reg_ml_k128")
+    assert g.k == 128
+    runs = [run_chain(g, oracle, seed=500 + i) for i in range(N_SEEDS)]
+    check_against_band(g.name, [p for p, _ in runs], g.test_target.astype(np.float64), 0)
+    assert runs[0][1].v_lambda_last.shape[-1] == 128
+    assert not np.array_equal(runs[0][0], runs[1][0])
+
+
 def test_mcmc_classification_posterior_mean(oracle):
     g = Golden("mcmc_cls_fields")
     preds = [run_chain(g, oracle, seed=200 + i)[0] for i in range(N_SEEDS)]
