@@ -984,29 +984,54 @@ k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32
 // of the batch.  If Newton does not settle (PIT_MAX_IT; the serial recurrence itself is then oscillating) workgroup 0 evaluates the chain
 // serially -- same result as k_scan.
 // ----------------------------------------------------------------------------------------------
-constexpr uint32_t PIT_SEG = 8192;                                    // examples per workgroup
-constexpr uint32_t PIT_WAVE = PIT_SEG / 4;                            // ... per wavefront
-constexpr uint32_t PIT_MAX_WG = 32;
-constexpr uint32_t PIT_MAX_ROWS = PIT_SEG * PIT_MAX_WG;               // 262 144: the default batch
-constexpr uint32_t PIT_MAX_CHUNK = PIT_WAVE;                          // a micro-chunk never straddles two wavefronts
+constexpr uint32_t PIT_SEG = 8192;                                    // examples per workgroup (4096 at micro-chunk 1: the chunk maps need the room)
+constexpr uint32_t PIT_MAX_WG = 64;
+constexpr uint32_t PIT_MAX_ROWS = 262144;                             // the default batch: 32 workgroups x 8192 (64 x 4096 at micro-chunk 1)
+constexpr uint32_t PIT_MAX_CHUNK = 1024;                              // a micro-chunk never straddles two wavefronts
 constexpr uint32_t PIT_MAX_IT = 12;
 constexpr float    PIT_TOL = 5e-4f;                                   // the path moved less than this: the NEXT iterate is exact to ~tol^2
-constexpr size_t   PIT_LDS_BYTES = (size_t)(3 * PIT_SEG) * sizeof(float);
+// LDS: {rest, y} of the segment + per chunk {path offset, map a, map b}: 8192 x 8 + 4096 x 12 (chunk >= 2) or 4096 x 8 + 4096 x 12 (chunk 1)
+constexpr size_t   PIT_LDS_BYTES = (size_t)(2 * PIT_SEG + 3 * (PIT_SEG / 2)) * sizeof(float);
+__host__ __device__ __forceinline__ uint32_t pit_seg(uint32_t chunk) { return chunk == 1u ? PIT_SEG / 2 : PIT_SEG; }
 struct PitSync { unsigned long long* ctr; double* slots; uint32_t* err; };   // ctr[PIT_MAX_IT + 1] zeroed before the launch; slots[2][PIT_MAX_WG][4]
 struct AMap { float a, b; };                                          // x -> a x + b
+__device__ __forceinline__ AMap amap_after(const AMap first, const AMap then) { return AMap{then.a * first.a, fmaf(then.a, first.b, then.b)}; }
 // max that does NOT drop a NaN (fmaxf does): a path that left the numbers must read as "not converged", never as "no change"
 __device__ __forceinline__ float nanmax(float a, float b) { return (a > b || a != a) ? a : b; }
 __device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
-__device__ __forceinline__ AMap amap_after(const AMap first, const AMap then) { return AMap{then.a * first.a, fmaf(then.a, first.b, then.b)}; }
+#define FMX_DPP_F(old, x, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), ctrl, rmask, 0xf, false))
+// the sum over the lane's group of C consecutive lanes, in EVERY lane of the group (C = 1 .. 64)
+template <int C> __device__ __forceinline__ float seg_allsum(float x, uint32_t lane) {
+  if constexpr (C >= 2)  x += FMX_DPP_F(0.f, x, 0xB1, 0xf);            // quad_perm(1,0,3,2)
+  if constexpr (C >= 4)  x += FMX_DPP_F(0.f, x, 0x4E, 0xf);            // quad_perm(2,3,0,1)
+  if constexpr (C >= 8)  x += FMX_DPP_F(0.f, x, 0x141, 0xf);           // row_half_mirror: the other quad of the half row
+  if constexpr (C >= 16) x += FMX_DPP_F(0.f, x, 0x140, 0xf);           // row_mirror: the other half of the row
+  if constexpr (C >= 32) {
+    const float s0 = bcast_f32<1>(x, 0), s1 = bcast_f32<1>(x, 16), s2 = bcast_f32<1>(x, 32), s3 = bcast_f32<1>(x, 48);
+    if constexpr (C == 32) x = (lane < 32u) ? s0 + s1 : s2 + s3; else x = (s0 + s1) + (s2 + s3);
+  }
+  return x;
+}
+// inclusive scan of 64 affine maps across the lanes (lane order = order of application): the DPP prefix pattern (row_shr 1/2/4/8, then the
+// row broadcasts); a lane without a source keeps its map (old = the identity)
+__device__ __forceinline__ void amap_scan64(float& a, float& b) {
+#define FMX_AMAP_STEP(ctrl, rmask) { const float pa = FMX_DPP_F(1.0f, a, ctrl, rmask), pb = FMX_DPP_F(0.0f, b, ctrl, rmask); b = fmaf(a, pb, b); a = a * pa; }
+  FMX_AMAP_STEP(0x111, 0xf) FMX_AMAP_STEP(0x112, 0xf) FMX_AMAP_STEP(0x114, 0xf) FMX_AMAP_STEP(0x118, 0xf)
+  FMX_AMAP_STEP(0x142, 0xa) FMX_AMAP_STEP(0x143, 0xc)
+#undef FMX_AMAP_STEP
+}
 
 template <bool WRITE_MULT, int TASK>
 __global__ void __launch_bounds__(256)
 k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
            Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult, const Handoff hw, const PitSync ps) {
   extern __shared__ float pit_lds[];
+  const uint32_t SEG = pit_seg(chunk), WSEG = SEG / 4u;               // examples per workgroup / per wavefront
   float* s_r = pit_lds;
-  float* s_y = pit_lds + PIT_SEG;
-  float* s_d = pit_lds + 2 * PIT_SEG;                                 // path offset at the start of every chunk of the segment
+  float* s_y = pit_lds + SEG;
+  float* s_d = pit_lds + 2 * SEG;                                      // per chunk of the segment: path offset at its start,
+  float* s_ma = s_d + PIT_SEG / 2;                                     // its affine map (after the scan: the composite of the wavefront's
+  float* s_mb = s_ma + PIT_SEG / 2;                                    // chunks BEFORE it)
   __shared__ float s_map[4][2];                                       // the wavefronts' composite maps
   __shared__ float s_chg[4];
   __shared__ double s_bcast[4];                                       // [0] incoming value of the workgroup, [1] value after the last one, [2] largest change
@@ -1014,19 +1039,20 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t g = blockIdx.x, nwg = gridDim.x;
-  const uint32_t s0 = g * PIT_SEG;
-  const uint32_t sn = (s0 < n_rows) ? min(PIT_SEG, n_rows - s0) : 0u;  // examples of this workgroup
-  const uint32_t q0 = wv * PIT_WAVE;
+  const uint32_t s0 = g * SEG;
+  const uint32_t sn = (s0 < n_rows) ? min(SEG, n_rows - s0) : 0u;      // examples of this workgroup
+  const uint32_t q0 = wv * WSEG;
   const double w0 = *w0_in;                                           // (launched only for models with a bias: h.k0)
   const float w0s = (float)w0;
   const uint32_t lc = 31u - (uint32_t)__builtin_clz(chunk);            // chunk = 1 << lc
+  const uint32_t wch = WSEG >> lc, c_w0 = q0 >> lc;                    // chunks per wavefront, the wavefront's first chunk
   constexpr float LOG2E = 1.4426950408889634f;
   // the segment into LDS: one DMA round trip for everything this workgroup will ever read
-  if (q0 < sn) scan_fetch_tile(rest + s0 + q0, target + s0 + q0, min(PIT_WAVE, sn - q0), s_r + q0, s_y + q0, lane);
-  for (uint32_t c = threadIdx.x; c < (PIT_SEG >> lc); c += 256u) s_d[c] = 0.f;
+  if (q0 < sn) scan_fetch_tile(rest + s0 + q0, target + s0 + q0, min(WSEG, sn - q0), s_r + q0, s_y + q0, lane);
+  for (uint32_t c = threadIdx.x; c < (SEG >> lc); c += 256u) s_d[c] = 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // one vector (64 consecutive examples, lane = example) at the current path: multiplier and its derivative per lane
+  // one example at the current path: multiplier and its derivative
   auto eval = [&](uint32_t i, float d, float& m, float& dm) {
     const bool ok = i < sn;
     const float r = ok ? s_r[i] : 0.f, y = ok ? s_y[i] : 0.f;
@@ -1049,68 +1075,77 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
     D = fmaf(nc, h.reg0, D);
     return AMap{1.0f - h.lr * D, -h.lr * (F - D * d)};
   };
-  // SWEEP over the wavefront's 32 vectors.  REPLAY = false: compose all chunk maps into `acc` (sweep 1).  REPLAY = true: x enters as the value
-  // at the wavefront's first chunk; every chunk's start value is stored as the new path, the largest change is returned (sweep 2).
-  auto sweep = [&](auto replay_tag, AMap& acc, float& x, float& chg) {
-    constexpr bool REPLAY = decltype(replay_tag)::value;
-    if (chunk <= 64u) {
-      for (uint32_t v = 0; v < PIT_WAVE / 64u; v++) {
-        const uint32_t i = q0 + 64u * v + lane;
-        if (q0 + 64u * v >= sn) break;                                // (wave-uniform: nothing left in this sub-segment)
-        const uint32_t c = i >> lc;
-        const float d = s_d[c];
-        float m, dm;
-        eval(i, d, m, dm);
-        for (uint32_t o = 1; o < chunk; o <<= 1) { m += __shfl_xor(m, (int)o); dm += __shfl_xor(dm, (int)o); }   // chunk sums in every lane of the chunk
-        AMap mp = chunk_map(m, dm, d, c << lc);
-        AMap ex = AMap{1.f, 0.f};                                     // composite of the vector's chunks BEFORE this lane's
-        for (uint32_t off = chunk; off < 64u; off <<= 1) {            // inclusive scan over the chunks of the vector (stride = chunk lanes)
-          const float pa = __shfl_up(mp.a, off), pb = __shfl_up(mp.b, off);
-          if (lane >= off) mp = amap_after(AMap{pa, pb}, mp);
-        }
-        if constexpr (REPLAY) {
-          const float ea = __shfl_up(mp.a, chunk), eb = __shfl_up(mp.b, chunk);
-          if (lane >= chunk) ex = AMap{ea, eb};
-          const float dn = fmaf(ex.a, x, ex.b);                       // the value this lane's chunk starts from
-          if (i < sn) chg = nanmax(fabsf(dn - d), chg);
-          if ((i & (chunk - 1u)) == 0u && i < sn) s_d[c] = dn;
-        }
-        const float va = __shfl(mp.a, 63), vb = __shfl(mp.b, 63);     // the vector's composite
-        if constexpr (REPLAY) x = fmaf(va, x, vb);
-        else acc = amap_after(acc, AMap{va, vb});
+  // EVAL: every chunk of the wavefront gets its map at the current path (independent vectors: four in flight)
+  auto eval_small = [&](auto ctag) {                                  // chunk <= 64: the lanes of a chunk sum by DPP
+    constexpr int C = decltype(ctag)::value;
+    constexpr int U = 4;
+    for (uint32_t v = 0; v < WSEG / 64u; v += U) {
+      if (q0 + 64u * v >= sn) break;                                   // (wave-uniform: nothing left in this sub-segment)
+      float m[U], dm[U], d[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t i = q0 + 64u * (v + u) + lane;
+        d[u] = s_d[i >> lc];
+        eval(i, d[u], m[u], dm[u]);
       }
-    } else {
-      const uint32_t vpc = chunk >> 6;                                // vectors per chunk
-      float F = 0.f, D = 0.f;
-      for (uint32_t v = 0; v < PIT_WAVE / 64u; v++) {
-        const uint32_t i = q0 + 64u * v + lane;
-        if (q0 + 64u * v >= sn) break;
-        const uint32_t c = (q0 + 64u * v) >> lc;                      // (uniform)
-        const float d = s_d[c];
-        float m, dm;
-        eval(i, d, m, dm);
-        F += wave_sum_dpp(m); D += wave_sum_dpp(dm);
-        const bool last = ((v + 1u) % vpc) == 0u || q0 + 64u * (v + 1u) >= sn;
-        if (last) {
-          const AMap mp = chunk_map(F, D, d, c << lc);
-          if constexpr (REPLAY) {
-            chg = nanmax(fabsf(x - d), chg);
-            if (lane == 0) s_d[c] = x;
-            x = fmaf(mp.a, x, mp.b);
-          } else acc = amap_after(acc, mp);
-          F = 0.f; D = 0.f;
-        }
+#pragma unroll
+      for (int u = 0; u < U; u++) { m[u] = seg_allsum<C>(m[u], lane); dm[u] = seg_allsum<C>(dm[u], lane); }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t i = q0 + 64u * (v + u) + lane;
+        const AMap mp = chunk_map(m[u], dm[u], d[u], (i >> lc) << lc);
+        if ((i & (uint32_t)(C - 1)) == 0u) { s_ma[i >> lc] = mp.a; s_mb[i >> lc] = mp.b; }
       }
     }
   };
-  float my_chg = 3.0e38f;                                             // largest change of this workgroup's last sweep 2 (nothing yet)
+  auto eval_large = [&]() {                                           // chunk >= 128: vectors of a chunk accumulate (wave-uniform sums)
+    const uint32_t vpc = chunk >> 6;
+    float F = 0.f, D = 0.f;
+    for (uint32_t v = 0; v < WSEG / 64u; v++) {
+      const uint32_t c = (q0 + 64u * v) >> lc;
+      const float d = s_d[c];
+      float m, dm;
+      eval(q0 + 64u * v + lane, d, m, dm);
+      F += wave_sum_dpp(m); D += wave_sum_dpp(dm);
+      if (((v + 1u) % vpc) == 0u) {
+        const AMap mp = chunk_map(F, D, d, c << lc);                   // (a chunk past the batch: the identity)
+        if (lane == 0) { s_ma[c] = mp.a; s_mb[c] = mp.b; }
+        F = 0.f; D = 0.f;
+      }
+    }
+  };
+  auto eval_all = [&]() {
+    switch (lc) {
+      case 0: eval_small(std::integral_constant<int, 1>()); break;
+      case 1: eval_small(std::integral_constant<int, 2>()); break;
+      case 2: eval_small(std::integral_constant<int, 4>()); break;
+      case 3: eval_small(std::integral_constant<int, 8>()); break;
+      case 4: eval_small(std::integral_constant<int, 16>()); break;
+      case 5: eval_small(std::integral_constant<int, 32>()); break;
+      case 6: eval_small(std::integral_constant<int, 64>()); break;
+      default: eval_large(); break;
+    }
+  };
+  float my_chg = 3.0e38f;                                             // largest change of this workgroup's last path update (nothing yet)
   bool converged = false;
   double x_end = 0.0;
-  uint32_t it = 0;
-  for (; it < PIT_MAX_IT; it++) {
-    AMap acc = AMap{1.f, 0.f}; float xx = 0.f, cc = 0.f;
-    sweep(std::false_type(), acc, xx, cc);
-    if (lane == 0) { s_map[wv][0] = acc.a; s_map[wv][1] = acc.b; }
+  for (uint32_t it = 0; it < PIT_MAX_IT; it++) {
+    eval_all();
+    // SCAN: the wavefront's chunk maps, 64 at a time (lane = chunk): each is replaced by the composite of the wavefront's chunks BEFORE it;
+    // `run` ends as the composite of all of them.  (A chunk whose examples lie past the batch was never evaluated: the identity.)
+    AMap run = AMap{1.f, 0.f};
+    for (uint32_t cb = 0; cb < wch; cb += 64u) {
+      const uint32_t c = c_w0 + cb + lane;
+      const bool have = cb + lane < wch && (c << lc) < sn;
+      float a = have ? s_ma[c] : 1.f, b = have ? s_mb[c] : 0.f;
+      amap_scan64(a, b);                                               // inclusive over the 64 chunks of this round
+      const float ea = __shfl_up(a, 1u), eb = __shfl_up(b, 1u);
+      AMap ex = (lane == 0u) ? AMap{1.f, 0.f} : AMap{ea, eb};          // exclusive
+      ex = amap_after(run, ex);                                        // ... behind what the wavefront did before this round
+      if (cb + lane < wch) { s_ma[c] = ex.a; s_mb[c] = ex.b; }
+      run = amap_after(run, AMap{bcast_f32<1>(a, 63), bcast_f32<1>(b, 63)});
+    }
+    if (lane == 0) { s_map[wv][0] = run.a; s_map[wv][1] = run.b; }
     __syncthreads();
     // ---- the exchange: publish this workgroup's composite + its last change, wait for everybody's ----
     double* slot = ps.slots + (size_t)(it & 1u) * PIT_MAX_WG * 4;
@@ -1125,7 +1160,7 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
       if (nwg > 1) {
         __hip_atomic_fetch_add(ps.ctr + it, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long cnt = __hip_atomic_load(ps.ctr + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t t = 0; cnt < (unsigned long long)nwg && t < HANDOFF_SPINS; t++) { __builtin_amdgcn_s_sleep(2); cnt = __hip_atomic_load(ps.ctr + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        for (uint32_t t = 0; cnt < (unsigned long long)nwg && t < HANDOFF_SPINS; t++) { __builtin_amdgcn_s_sleep(1); cnt = __hip_atomic_load(ps.ctr + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         if (cnt < (unsigned long long)nwg) atomicOr(ps.err, 4u);       // (a workgroup never arrived: flagged, the epoch fails instead of hanging)
       }
     }
@@ -1138,7 +1173,7 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
         B = __hip_atomic_load(slot + 4 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         C = __hip_atomic_load(slot + 4 * lane + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      for (uint32_t off = 1; off < 32u; off <<= 1) {
+      for (uint32_t off = 1; off < 64u; off <<= 1) {
         const double pa = __shfl_up(A, off), pb = __shfl_up(B, off), pc = __shfl_up(C, off);
         if (lane >= off) { B = fma(A, pb, B); A = A * pa; C = nanmax(pc, C); }
       }
@@ -1147,13 +1182,19 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
       if (lane == 0) { s_bcast[0] = g ? b_mine : 0.0; s_bcast[1] = b_all; s_bcast[2] = c_all; }
     }
     __syncthreads();
-    if (s_bcast[2] < (double)PIT_TOL && s_bcast[1] - s_bcast[1] == 0.0) { converged = true; x_end = s_bcast[1]; break; }   // (and the end value is a number)   // the path these composites were taken at had settled
-    // ---- sweep 2: the new path ----
+    if (s_bcast[2] < (double)PIT_TOL && s_bcast[1] - s_bcast[1] == 0.0) { converged = true; x_end = s_bcast[1]; break; }   // the path these maps were taken at had settled (and the end value is a number)
+    // ---- APPLY: the new path, every chunk at once ----
     float x = (float)s_bcast[0];
     for (uint32_t w = 0; w < wv; w++) x = fmaf(s_map[w][0], x, s_map[w][1]);
     float chg = 0.f;
-    AMap dummy = AMap{1.f, 0.f};
-    sweep(std::true_type(), dummy, x, chg);
+    for (uint32_t cb = lane; cb < wch; cb += 64u) {
+      const uint32_t c = c_w0 + cb;
+      if ((c << lc) < sn) {
+        const float dn = fmaf(s_ma[c], x, s_mb[c]);
+        chg = nanmax(fabsf(dn - s_d[c]), chg);
+        s_d[c] = dn;
+      }
+    }
     for (int o = 32; o > 0; o >>= 1) chg = nanmax(__shfl_xor(chg, o), chg);
     __syncthreads();                                                  // (s_map / s_bcast were read by everybody)
     if (lane == 0) s_chg[wv] = chg;
@@ -1178,7 +1219,7 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
     return;
   }
   if constexpr (WRITE_MULT) {                                         // the multipliers at the settled path (two-pass form of the rule)
-    for (uint32_t v = 0; v < PIT_WAVE / 64u; v++) {
+    for (uint32_t v = 0; v < WSEG / 64u; v++) {
       const uint32_t i = q0 + 64u * v + lane;
       if (i < sn) {
         float m, dm;

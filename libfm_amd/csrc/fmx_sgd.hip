@@ -34,7 +34,8 @@ uint32_t multi_group_size(const Slot& s, int KP) {
   if (KP < 64 || s.n_rows == 0) return 0;
   const double avg = (double)s.nnz / (double)s.n_rows;
   if (avg > 12.0) return 0;
-  const double g = avg > 0.0 ? 24.0 / avg : (double)MULTI_GMAX;
+  static const double fill = []() { const char* e = getenv("FMX_MULTI_FILL"); const double f = e ? atof(e) : 0.0; return (f >= 8.0 && f <= 32.0) ? f : 24.0; }();
+  const double g = avg > 0.0 ? fill / avg : (double)MULTI_GMAX;   // (FMX_MULTI_FILL: A/B knob for the probe, 8 .. 32)
   return (uint32_t)std::max(2.0, std::min((double)MULTI_GMAX, std::floor(g)));
 }
 
@@ -290,7 +291,7 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     // micro-chunks that are powers of two up to 2048 on batches of 4097 .. 262 144 examples -- every default.  Same result as the chain to
     // fp32 rounding; ~40 us per 262 144 examples whatever the micro-chunk where the chain takes 0.18 ms (256) .. 0.5 ms (32).
     if (h->scan_pit && n_rows > 4096u && n_rows <= PIT_MAX_ROWS && chunk <= PIT_MAX_CHUNK && (chunk & (chunk - 1u)) == 0u) {
-      const uint32_t nwg = (n_rows + PIT_SEG - 1) / PIT_SEG;
+      const uint32_t nwg = (n_rows + pit_seg(chunk) - 1) / pit_seg(chunk);
       HIPCHK(h, hipMemsetAsync(h->pit_ctr, 0, (PIT_MAX_IT + 1) * sizeof(unsigned long long), st));
       const PitSync ps{h->pit_ctr, h->pit_slots, h->handoff_err};
 #define FMX_PIT(WM, TK) do { auto kf = k_scan_pit<WM, TK>;                                                                       \

@@ -101,7 +101,10 @@ def test_short_rows_of_a_shard_several_examples_per_wavefront(capi, oracle, k, w
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=3e-5)          # (head ids met dozens of times per batch with values up to 2: fp32 sums)
     np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=3e-5)
-    np.testing.assert_allclose(grp.predict(0, rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5)
+    # (rows of up to 150 entries with values up to 2: a prediction is a sum of 64 squares of 150-term sums -- the parameters' 3e-5 arrives as ~1e-3)
+    np.testing.assert_allclose(grp.predict(0, rows), oracle.predict_raw(m, d), rtol=RTOL, atol=2e-3)
+    short = np.flatnonzero(sizes <= 12)                              # ... and on the short rows it stays at the usual band
+    np.testing.assert_allclose(grp.predict(0, rows)[short], oracle.predict_raw(m, d)[short], rtol=RTOL, atol=1e-4)
     grp.close()
     for h in hs:
         h.close()
