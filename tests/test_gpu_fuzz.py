@@ -485,8 +485,9 @@ def test_empty_and_single_row_data_sets(capi, oracle):
     h.close()
 
 
+@pytest.mark.parametrize("regime", ["stable", "marginal"])
 @pytest.mark.parametrize("seed", _seeds(8))
-def test_random_shape_large_batches_hand_off_and_side_stream(capi, oracle, seed):
+def test_random_shape_large_batches_hand_off_and_side_stream(capi, oracle, seed, regime):
     """the one-pass form where a batch holds >= 32 768 rows (the recurrence on the side stream): random rows / batch / micro-chunk / lag,
     the two orderings of the streams (device-side hand-off, events) and the weight side stream kept or not, at random -- parameters and
     the predictions of the pass that follows (out of the side stream when it was kept) against the oracle's rule."""
@@ -502,7 +503,7 @@ def test_random_shape_large_batches_hand_off_and_side_stream(capi, oracle, seed)
         n = int(rng.integers(20000, 200000))
         ent, rp, y = datagen.ragged_real(n, rows, int(rng.integers(3, 20)), seed, classification=bool(task), empty_every=int(rng.choice([0, 13])))
     batch = int(rng.choice([32768, 33001, 50000, 65536]))
-    chunk = int(rng.choice([64, 256, 300, 512]))
+    chunk = int(rng.choice([64, 256, 300, 512, 32, 1]))          # (powers of two: the parallel-in-time recurrence; 300: the one-wavefront chain)
     lag = int(rng.integers(1, 5))
     flags = (capi.FLAG_EVENT_SYNC if rng.integers(0, 2) else 0) | (capi.FLAG_KEEP_WSIDE if rng.integers(0, 2) else 0)
     lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
@@ -510,10 +511,14 @@ def test_random_shape_large_batches_hand_off_and_side_stream(capi, oracle, seed)
     # a step size the batch rule is STABLE at on these rows (lr * curvature * batch * C <= 1/2): beyond it the iteration
     # amplifies every fp32 rounding and no implementation can be held to the fp64 oracle (soak seeds 233 / 248: Zipf ids, batch 33 001 --
     # one-pass and two-pass forms alike 1e-2 off, side stream and hand-off identical to the plain forms)
+    # "marginal" (round-4 verdict, housekeeping): the region between gain 1/2 and 2 that the cap above had left unprobed -- the rule degrades
+    # there but is defined, and the device must still follow the fp64 oracle to within the oracle's OWN response to one fp32 rounding of the
+    # start values (the floor below; a case whose floor has left 1e-3 is not a statement about any implementation and is skipped)
     C = datagen.collision_mass(ent, rows, n)
-    lr = min(0.004, 0.9 / (chunk * curv), 0.5 / (curv * batch * max(C, 1e-12)))
+    gain = 0.5 if regime == "stable" else float(rng.uniform(0.6, 1.8))
+    lr = min(0.004 if regime == "stable" else 0.02, 0.9 / (chunk * curv), gain / (curv * batch * max(C, 1e-12)))
     d = oracle.Data(ent, rp, y)
-    what = "seed %d: n=%d k=%d rows=%d batch=%d chunk=%d lag=%d flags=%d lr=%.3g" % (seed, n, k, rows, batch, chunk, lag, flags, lr)
+    what = "seed %d (%s): n=%d k=%d rows=%d batch=%d chunk=%d lag=%d flags=%d lr=%.3g gain=%.2f" % (seed, regime, n, k, rows, batch, chunk, lag, flags, lr, lr * curv * batch * C)
 
     def run(pert):
         m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.004)
@@ -525,8 +530,8 @@ def test_random_shape_large_batches_hand_off_and_side_stream(capi, oracle, seed)
         return m.w0, m.w.copy(), m.v.copy(), oracle.predict_raw(m, d)
     fl, (o_w0, o_w, o_v, o_p) = _floor(run)
     if fl is None or fl[2] > 1e-3:
-        assert seed >= 8, what + ": a case of the suite's own seeds must be well-conditioned"
-        return
+        assert seed >= 8 or regime == "marginal", what + ": a stable case of the suite's own seeds must be well-conditioned"
+        pytest.skip(what + ": the oracle itself amplifies one fp32 rounding beyond 1e-3 here")
     h = capi.Handle(n, k, True, True, task, 0.001, 0.002, 0.004, lr, lo, hi)
     h.set_params(0.02, oracle.init_values(32 + seed, n, 1, 0.05)[0], oracle.init_values(31 + seed, n, k, 0.05))
     h.upload_rows(0, ent, rp, y)
