@@ -463,24 +463,7 @@ k_rowsums(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, u
 // flush zeros.  Needs one row per wave-wide load (KP >= 64).
 // ----------------------------------------------------------------------------------------------
 constexpr int MULTI_ZR = 32;                                           // row slots per round
-constexpr int MULTI_GMAX = 8;                                          // examples per wavefront, at most (their S rows pass through registers: 8 keeps k_apply_multi<64> at 6 wavefronts per SIMD)
-// (Both kernels are SOFTWARE-PIPELINED over the groups a wavefront handles: a group costs three dependent round trips -- row offsets ->
-// {entries, masks} -> rows -- where the one-pass kernel of a long row has two, and at the ~7 us a load takes under this traffic that, not
-// bytes, bounded them: 4.8 TB/s.  So the launch is sized to the resident wavefronts, and while a group's rows are in flight the wavefront
-// already holds the NEXT group's row offsets and asks for its entries / masks: per group one round trip is left on the critical path.)
-struct MultiHdr { uint64_t a0; uint32_t ge, rel, total; };             // a group: first entry, examples, lane j's begin (relative), entries
-__device__ __forceinline__ uint64_t multi_hdr_load(const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t e0, uint32_t n_rows, uint32_t G, uint32_t lane) {
-  const uint32_t ge = min(G, n_rows - e0);
-  return row_ptr[row0 + e0 + min(lane, ge)];                           // lane j <= ge: where example e0 + j begins (lane ge: where the group ends)
-}
-__device__ __forceinline__ MultiHdr multi_hdr(uint64_t rp, uint32_t e0, uint32_t n_rows, uint32_t G) {
-  MultiHdr hd;
-  hd.a0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
-  hd.ge = min(G, n_rows - e0);
-  hd.rel = (uint32_t)(rp - hd.a0);
-  hd.total = bcast_u32<1>(hd.rel, hd.ge);
-  return hd;
-}
+constexpr int MULTI_GMAX = 16;                                         // examples per wavefront, at most
 template <int KP, bool WRITE_S, bool FINISH>
 __global__ void __launch_bounds__(256)
 k_rowsums_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t n_rows,
@@ -489,26 +472,13 @@ k_rowsums_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_
   static_assert(Map<KP>::EPI == 1, "one row per wave-wide load");
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t stride = gridDim.x * (blockDim.x >> 6) * G;
-  uint32_t e0 = wave0 * G;
-  if (e0 >= n_rows) return;
-  auto ent_load = [&](const MultiHdr& hd, uint32_t base, Entry& en, float& wl) {
-    en.id = 0; en.value = 0.f; wl = 0.f;
-    if (base < hd.total && lane < min((uint32_t)MULTI_ZR, hd.total - base)) {
-      en = load_stream8(ent + hd.a0 + base + lane);
-      if (k1) wl = load_w(tb.w + (size_t)en.id * tb.ws) * en.value;
-    }
-  };
-  MultiHdr hd = multi_hdr(multi_hdr_load(row_ptr, row0, e0, n_rows, G, lane), e0, n_rows, G);
-  Entry en; float wl;
-  ent_load(hd, 0, en, wl);
-  for (;;) {
-    const uint32_t e1 = e0 + stride;
-    const bool more = e1 < n_rows;                                     // (wave-uniform)
-    uint64_t rp_n = 0;
-    if (more) rp_n = multi_hdr_load(row_ptr, row0, e1, n_rows, G, lane);   // asked for now, looked at behind this group's row loads
-    MultiHdr hn = hd; Entry en_n; en_n.id = 0; en_n.value = 0.f; float wl_n = 0.f;
-    bool fetched = false;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t e0 = wave0 * G; e0 < n_rows; e0 += nwaves * G) {
+    const uint32_t ge = min(G, n_rows - e0);                          // examples of this group
+    const uint64_t rp = row_ptr[row0 + e0 + min(lane, ge)];            // lane j <= ge: where example e0 + j begins (lane ge: where the group ends)
+    const uint64_t a0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
+    const uint32_t rel = (uint32_t)(rp - a0);                          // ... relative to the group's first entry
+    const uint32_t total = bcast_u32<1>(rel, ge);
     float sum[VEC]; float sq = 0.f, lin = 0.f;
 #pragma unroll
     for (int v = 0; v < VEC; v++) sum[v] = 0.f;
@@ -527,21 +497,21 @@ k_rowsums_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_
       for (int v = 0; v < VEC; v++) sum[v] = 0.f;
       sq = 0.f; lin = 0.f; cur++;
     };
-    for (uint32_t base = 0; base < hd.total; base += MULTI_ZR) {
-      if (base) ent_load(hd, base, en, wl);                            // (a group beyond one round: rare by construction of G)
-      const uint32_t cnt = min((uint32_t)MULTI_ZR, hd.total - base);
+    for (uint32_t base = 0; base < total; base += MULTI_ZR) {
+      const uint32_t cnt = min((uint32_t)MULTI_ZR, total - base);
+      Entry en; en.id = 0; en.value = 0.f;
+      float wl = 0.f;
+      if (lane < cnt) {
+        en = load_stream8(ent + a0 + base + lane);
+        if (k1) wl = load_w(tb.w + (size_t)en.id * tb.ws) * en.value;
+      }
       uint32_t ex = 0;                                                 // which example entry base + lane belongs to: the begins at or before it
-      for (uint32_t j = 1; j < hd.ge; j++) ex += (base + lane >= bcast_u32<1>(hd.rel, j)) ? 1u : 0u;
+      for (uint32_t j = 1; j < ge; j++) ex += (base + lane >= bcast_u32<1>(rel, j)) ? 1u : 0u;
       float vr[MULTI_ZR][VEC];
 #pragma unroll
       for (int t = 0; t < MULTI_ZR; t++) {
         const uint32_t id = bcast_u32<1>(en.id, t);
         if ((uint32_t)t < cnt) load_row<VEC, 4>(tb.V + (size_t)id * tb.rs + lane * VEC, vr[t]);
-      }
-      if (!fetched && more) {                                          // the next group's header has arrived behind the entries: ask for ITS entries
-        hn = multi_hdr(rp_n, e1, n_rows, G);
-        ent_load(hn, 0, en_n, wl_n);
-        fetched = true;
       }
 #pragma unroll
       for (int t = 0; t < MULTI_ZR; t++) {
@@ -555,10 +525,7 @@ k_rowsums_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_
         }
       }
     }
-    if (!fetched && more) { hn = multi_hdr(rp_n, e1, n_rows, G); ent_load(hn, 0, en_n, wl_n); }   // (a group without entries)
-    while (cur < hd.ge) flush();
-    if (!more) break;
-    e0 = e1; hd = hn; en = en_n; wl = wl_n;
+    while (cur < ge) flush();
   }
 }
 
@@ -581,37 +548,15 @@ k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const uint32_t stride = gridDim.x * (blockDim.x >> 6) * G;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   float (*sS)[KP] = s_S[wib];
   const float w0s = (FUSED && h.k0) ? (float)(*w0_ptr) : 0.f;
-  uint32_t e0 = wave0 * G;
-  if (e0 >= n_rows) return;
-  // one round's entries + which of them are k_apply_seg's (their feature occurs more than once in the batch, or the row is beyond the mask)
-  auto ent_load = [&](const MultiHdr& hd, uint32_t eg, uint32_t base, Entry& en, bool& def) {
-    en.id = 0; en.value = 0.f; def = false;
-    uint32_t ex = 0, st = 0;                                           // the entry's example and where that example begins
-    for (uint32_t j = 1; j < hd.ge; j++) {
-      const uint32_t rj = bcast_u32<1>(hd.rel, j);
-      if (base + lane >= rj) { ex++; st = rj; }
-    }
-    if (base < hd.total && lane < min((uint32_t)MULTI_ZR, hd.total - base)) {
-      en = load_stream8(ent + hd.a0 + base + lane);
-      const uint64_t cm = cmask[row0 + eg + ex];
-      const uint32_t pos = base + lane - st;
-      def = pos >= 64u || ((cm >> pos) & 1ull);
-    }
-  };
-  MultiHdr hd = multi_hdr(multi_hdr_load(row_ptr, row0, e0, n_rows, G, lane), e0, n_rows, G);
-  Entry en; bool def;
-  ent_load(hd, e0, 0, en, def);
-  for (;;) {
-    const uint32_t e1 = e0 + stride;
-    const bool more = e1 < n_rows;
-    uint64_t rp_n = 0;
-    if (more) rp_n = multi_hdr_load(row_ptr, row0, e1, n_rows, G, lane);
-    MultiHdr hn = hd; Entry en_n; en_n.id = 0; en_n.value = 0.f; bool def_n = false;
-    bool fetched = false;
-    const uint32_t ge = hd.ge;
+  for (uint32_t e0 = wave0 * G; e0 < n_rows; e0 += nwaves * G) {
+    const uint32_t ge = min(G, n_rows - e0);
+    const uint64_t rp = row_ptr[row0 + e0 + min(lane, ge)];
+    const uint64_t a0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
+    const uint32_t rel = (uint32_t)(rp - a0);
+    const uint32_t total = bcast_u32<1>(rel, ge);
     // the examples' reduced sums: lane f keeps column f of every example in LDS; multipliers: lane j holds example j's
     float sv[MULTI_GMAX][VEC];
 #pragma unroll
@@ -638,11 +583,21 @@ k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
       }
     }
     if (FUSED && lane < ge) { rest_out[e0 + lane] = rreg; mult[e0 + lane] = mreg; }
-    for (uint32_t base = 0; base < hd.total; base += MULTI_ZR) {
-      if (base) ent_load(hd, e0, base, en, def);
-      const uint32_t cnt = min((uint32_t)MULTI_ZR, hd.total - base);
-      uint32_t ex = 0;
-      for (uint32_t j = 1; j < ge; j++) ex += (base + lane >= bcast_u32<1>(hd.rel, j)) ? 1u : 0u;
+    for (uint32_t base = 0; base < total; base += MULTI_ZR) {
+      const uint32_t cnt = min((uint32_t)MULTI_ZR, total - base);
+      Entry en; en.id = 0; en.value = 0.f;
+      if (lane < cnt) en = load_stream8(ent + a0 + base + lane);
+      uint32_t ex = 0, st = 0;                                         // the entry's example and where that example begins
+      for (uint32_t j = 1; j < ge; j++) {
+        const uint32_t rj = bcast_u32<1>(rel, j);
+        if (base + lane >= rj) { ex++; st = rj; }
+      }
+      bool def = false;                                                // the entry's feature occurs more than once in the batch: k_apply_seg's
+      if (lane < cnt) {
+        const uint64_t cm = cmask[row0 + e0 + ex];
+        const uint32_t pos = base + lane - st;
+        def = pos >= 64u || ((cm >> pos) & 1ull);
+      }
       const uint64_t defm = __ballot(def);
       const float ml = __shfl(mreg, (int)ex);                          // (all lanes: the source lane is the example's)
       if (h.k1 && lane < cnt && !def) {                                // fm_sgd.h:38-43
@@ -655,11 +610,6 @@ k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
       for (int t = 0; t < MULTI_ZR; t++) {
         const uint32_t id = bcast_u32<1>(en.id, t);
         if ((uint32_t)t < cnt && !((defm >> t) & 1ull)) load_row<VEC, 8>(tb.V + (size_t)id * tb.rs + lane * VEC, vr[t]);
-      }
-      if (!fetched && more) {                                          // behind this group's row loads: the next group's entries and masks
-        hn = multi_hdr(rp_n, e1, n_rows, G);
-        ent_load(hn, e1, 0, en_n, def_n);
-        fetched = true;
       }
 #pragma unroll
       for (int t = 0; t < MULTI_ZR; t++) {
@@ -680,9 +630,6 @@ k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
         }
       }
     }
-    if (!fetched && more) { hn = multi_hdr(rp_n, e1, n_rows, G); ent_load(hn, e1, 0, en_n, def_n); }
-    if (!more) break;
-    e0 = e1; hd = hn; en = en_n; def = def_n;
   }
 }
 

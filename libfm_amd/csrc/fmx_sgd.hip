@@ -39,12 +39,6 @@ uint32_t multi_group_size(const Slot& s, int KP) {
   return (uint32_t)std::max(2.0, std::min((double)MULTI_GMAX, std::floor(g)));
 }
 
-// the short-row kernels are software-pipelined over the groups of a wavefront: the launch is sized to the RESIDENT wavefronts (x FMX_MULTI_OVER,
-// default 1; A/B knob) so that every wavefront walks several groups
-int multi_over() { static const int v = []() { const char* e = getenv("FMX_MULTI_OVER"); const int x = e ? atoi(e) : 0; return x >= 1 ? x : 1; }(); return v; }
-#define FMX_LAUNCH_MULTI(kfn, waves, st, ...)                                                        \
-  do { auto _k = kfn; hipLaunchKernelGGL(_k, dim3(resident_grid(h, (const void*)_k, (waves), multi_over())), dim3(256), 0, st, __VA_ARGS__); } while (0)
-
 template <int KP, int VAR>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
                     const double* w0_in, float* rest_out, const uint64_t* cmask = nullptr, float* S_out = nullptr,
@@ -107,7 +101,7 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
 extern "C++" int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st) {
   if (n_rows == 0) return FMX_OK;
   if (const uint32_t G = multi_group_size(s, h->KP)) {          // short rows: several examples per wavefront
-    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_MULTI((k_rowsums_multi<KP, true, false>), ((uint64_t)n_rows + G - 1) / G, st,
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_rowsums_multi<KP, true, false>), ((uint64_t)n_rows + G - 1) / G, st,
                                                                   s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c, G); } });
     HIPCHK(h, hipGetLastError());
     return FMX_OK;
@@ -445,7 +439,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
     rc = lag_wait_bias(h, hy, st);
     if (rc) return rc;
     if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
-    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_MULTI((k_apply_multi<KP, true>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_apply_multi<KP, true>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
                                                                   h->tb, hy, lag_bias_slot(h), S, cpart, rest, h->mult, (const uint64_t*)s.cmask, G); } });
     HIPCHK(h, hipGetLastError());
     rc = lag_start_scan(h, rest, s.target + row0, n_rows, chunk, hy, st);
@@ -463,7 +457,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
   if (short_row_update(h, s, opts, seg_batch)) {                // (exact chunk coupling: the multipliers came out of the recurrence)
     const uint32_t G = multi_group_size(s, h->KP);
     if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
-    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_MULTI((k_apply_multi<KP, false>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_apply_multi<KP, false>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
                                                                   h->tb, hy, (const double*)h->w0, S, (const float*)nullptr, (float*)nullptr, h->mult, (const uint64_t*)s.cmask, G); } });
     HIPCHK(h, hipGetLastError());
     rc = launch_deferred(h, s, hy, S, (size_t)seg_batch, st);
