@@ -557,6 +557,20 @@ k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
     const uint64_t a0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
     const uint32_t rel = (uint32_t)(rp - a0);
     const uint32_t total = bcast_u32<1>(rel, ge);
+    // everything that depends only on the row offsets is asked for TOGETHER -- the examples' reduced sums, their scalars, the first round's
+    // entries and masks: one round trip, not one per kind (the stores of rest[] / mult[] below would otherwise hold the entry loads back)
+    auto entry_place = [&](uint32_t base, uint32_t& ex, uint32_t& st) {   // which example entry base + lane belongs to, and where that one begins
+      ex = 0; st = 0;
+      for (uint32_t j = 1; j < ge; j++) {
+        const uint32_t rj = bcast_u32<1>(rel, j);
+        if (base + lane >= rj) { ex++; st = rj; }
+      }
+    };
+    uint32_t ex0, st0;
+    entry_place(0, ex0, st0);
+    Entry en0; en0.id = 0; en0.value = 0.f;
+    uint64_t cm0 = 0;
+    if (lane < min((uint32_t)MULTI_ZR, total)) { en0 = load_stream8(ent + a0 + lane); cm0 = cmask[row0 + e0 + ex0]; }
     // the examples' reduced sums: lane f keeps column f of every example in LDS; multipliers: lane j holds example j's
     float sv[MULTI_GMAX][VEC];
 #pragma unroll
@@ -585,32 +599,34 @@ k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
     if (FUSED && lane < ge) { rest_out[e0 + lane] = rreg; mult[e0 + lane] = mreg; }
     for (uint32_t base = 0; base < total; base += MULTI_ZR) {
       const uint32_t cnt = min((uint32_t)MULTI_ZR, total - base);
-      Entry en; en.id = 0; en.value = 0.f;
-      if (lane < cnt) en = load_stream8(ent + a0 + base + lane);
-      uint32_t ex = 0, st = 0;                                         // the entry's example and where that example begins
-      for (uint32_t j = 1; j < ge; j++) {
-        const uint32_t rj = bcast_u32<1>(rel, j);
-        if (base + lane >= rj) { ex++; st = rj; }
+      Entry en = en0;
+      uint32_t ex = ex0, st = st0;
+      uint64_t cm = cm0;
+      if (base) {                                                      // (a group beyond one round: rare by construction of G)
+        entry_place(base, ex, st);
+        en.id = 0; en.value = 0.f; cm = 0;
+        if (lane < cnt) { en = load_stream8(ent + a0 + base + lane); cm = cmask[row0 + e0 + ex]; }
       }
       bool def = false;                                                // the entry's feature occurs more than once in the batch: k_apply_seg's
       if (lane < cnt) {
-        const uint64_t cm = cmask[row0 + e0 + ex];
         const uint32_t pos = base + lane - st;
         def = pos >= 64u || ((cm >> pos) & 1ull);
       }
       const uint64_t defm = __ballot(def);
       const float ml = __shfl(mreg, (int)ex);                          // (all lanes: the source lane is the example's)
-      if (h.k1 && lane < cnt && !def) {                                // fm_sgd.h:38-43
-        float* pw = tb.w + (size_t)en.id * tb.ws;
-        const float wv = load_w(pw);
-        *pw = wv - h.lr * (ml * en.value + h.regw * wv);
-      }
+      // the linear weight is ASKED FOR before the rows and WRITTEN after they have been asked for: a store to w[] between the two would
+      // hold the row loads back (w and V may alias for the compiler) -- one dependent round trip more per round
+      const bool upd_w = h.k1 && lane < cnt && !def;
+      float* pw = tb.w + (size_t)en.id * tb.ws;
+      float wv = 0.f;
+      if (upd_w) wv = load_w(pw);
       float vr[MULTI_ZR][VEC];
 #pragma unroll
       for (int t = 0; t < MULTI_ZR; t++) {
         const uint32_t id = bcast_u32<1>(en.id, t);
         if ((uint32_t)t < cnt && !((defm >> t) & 1ull)) load_row<VEC, 8>(tb.V + (size_t)id * tb.rs + lane * VEC, vr[t]);
       }
+      if (upd_w) *pw = wv - h.lr * (ml * en.value + h.regw * wv);      // fm_sgd.h:38-43
 #pragma unroll
       for (int t = 0; t < MULTI_ZR; t++) {
         const uint32_t id = bcast_u32<1>(en.id, t);
