@@ -1507,14 +1507,17 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
   }
   for (uint32_t i = 0; i < cnt; i += EPI * U) {
     float v0[U][VEC], sf[U][VEC], sf2[PRE2 ? U : 1][VEC];
-#pragma unroll
+    float wv0[U];                                                // the segments' linear weights: asked for WITH their rows (read after the row stores
+#pragma unroll                                                   // they cost one more dependent round trip per round)
     for (int u = 0; u < U; u++) {
       const uint32_t idx = i + u * EPI + g;
       const uint32_t j = bcast_u32<EPI>(jl, idx & 63u);
       const uint32_t e = bcast_u32<EPI>(el, idx & 63u);
       uint32_t e2 = 0, n2 = 0;
       if (PRE2) { e2 = bcast_u32<EPI>(e2l, idx & 63u); n2 = bcast_u32<EPI>(bl - al, idx & 63u); }
+      wv0[u] = 0.f;
       if (idx < cnt) {
+        if (h.k1 && f == 0) wv0[u] = tb.w[(size_t)j * tb.ws];
         load_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, v0[u]);
         load_vec<VEC>(S + (size_t)e * KP + f * VEC, sf[u]);
         if (PRE2) {
@@ -1628,7 +1631,7 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
           store_vec<VEC>(sx.gv + (size_t)j * tb.rs + f * VEC, sh);
           if (h.k1 && f == 0) {
             float* pw = tb.w + (size_t)j * tb.ws;
-            const float wv = *pw;
+            const float wv = wv0[u];
             sx.gw[j] = Gw;                                       // :153
             *pw = wv - h.lr * (Gw + nocc * 2.0f * (float)rg[0] * wv);
           }
@@ -1641,7 +1644,7 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
           store_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
           if (h.k1 && f == 0) {
             float* pw = tb.w + (size_t)j * tb.ws;
-            const float wv = *pw;
+            const float wv = wv0[u];
             *pw = wv - h.lr * (Gw + nocc * h.regw * wv);
           }
         }
