@@ -162,9 +162,10 @@ def test_config4_eight_shards_k128_n1e8_equal_one_handle(capi):
 
 # the band DESIGN.md section 3 states (measured on the CPU with the oracle's two loops: scripts/cpu_online_vs_rule.py, and asserted
 # here with the DEVICE in place of the oracle's rule)
-# measured (profiles/r04_parity_vs_online.json): bias 0.0247 apart, predictions of the epoch's rows (rms 0.20) mean 0.024 / max 0.049 apart
-# -- 0.025 / 0.13 of the rms with the two bias paths taken out --, factors max 1.6e-4 = 0.8 % of max |v|, linear weights max 1.1e-3
-ONLINE_BAND = {"w0_abs": 0.05, "pred_mean_abs": 0.04, "pred_max_abs": 0.08, "pred_max_rel_to_rms_without_bias": 0.2,
+# measured over these 278 528 rows (1.06 batches): micro-chunk 256 (round 4, profiles/r04_parity_vs_online.json) bias 0.0247 apart, predictions (rms 0.20)
+# mean 0.024 / max 0.049; micro-chunk 32 (the default since round 5; the round-4 verdict's run of scripts/cpu_online_vs_rule.py) bias 0.0014, predictions
+# mean 0.0056 / max 0.027, factors and weights as before (max 1.6e-4 = 0.8 % of max |v|, 1.1e-3).  The band is that x 1.6-2.
+ONLINE_BAND = {"w0_abs": 0.0028, "pred_mean_abs": 0.0095, "pred_max_abs": 0.045, "pred_max_rel_to_rms_without_bias": 0.2,
                "v_max_rel_to_vmax": 0.016, "w_max_abs": 0.002}
 
 
