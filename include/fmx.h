@@ -228,6 +228,9 @@ typedef struct fmx_eval {
  * classifies each by probing it together with a reference chunk, maps chunks of two classes alternately into one virtual range, puts
  * V at its start and w across a chunk boundary behind it, and returns the chunks it does not need.  fmx_place_info reports what it
  * found.  If the virtual-memory API is unavailable the tables are plain allocations (best of two candidates). */
+/* Environment read by fmx_create (A/B knobs; none changes a result beyond fp32 rounding): FMX_HANDOFF=0 (events instead of the device-side
+ * bias hand-off), FMX_SCAN=serial (the bias recurrence as a one-wavefront chain instead of parallel in time), FMX_ARENA_CACHE=0 (no arena
+ * kept for the next handle), FMX_MULTI_FILL=8..32 (entries per 32-slot round the short-row shard kernels group examples for; default 24). */
 int fmx_create(const fmx_config *cfg, fmx_handle *out);
 int fmx_destroy(fmx_handle h);
 /* fmx_destroy keeps ONE placed arena per device alive for the next fmx_create on that device (which then takes it over without
