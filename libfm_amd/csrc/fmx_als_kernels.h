@@ -802,6 +802,21 @@ k_als_unseen_v(const uint8_t* __restrict__ seen, uint64_t n_local, const Tab tb,
   const uint32_t lane = threadIdx.x & 63u, sub = lane / LPR, fl = lane % LPR;
   const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  // one attribute group (no `-meta`): a lane's factors have ONE prior each for the whole table -- sigma and mu are taken once, not per feature
+  // (the fp64 divide + square root per coordinate made this stream compute-bound at configs[4]'s shape: 26 ms for 25 GB, round 5)
+  const bool one_group = (grp == nullptr);
+  double sd1[VEC], mu1[VEC]; bool zero1[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; v++) {
+    const int f = (int)fl * VEC + v;
+    sd1[v] = 0.0; mu1[v] = 0.0; zero1[v] = false;
+    if (one_group && f < k) {
+      const double* row = prior + (size_t)(1 + f) * 2 * G;
+      const double sigma_sqr = 1.0 / row[0];
+      zero1[v] = isnan(sigma_sqr) || isinf(sigma_sqr);
+      sd1[v] = sqrt(sigma_sqr); mu1[v] = row[G];
+    }
+  }
   for (uint64_t j0 = wave0 * EPI; j0 < n_local; j0 += nwaves * EPI) {
     const uint64_t j = j0 + sub;
     if (j >= n_local || seen[j]) continue;
@@ -810,12 +825,17 @@ k_als_unseen_v(const uint8_t* __restrict__ seen, uint64_t n_local, const Tab tb,
     for (int v = 0; v < VEC; v++) {
       const int f = (int)fl * VEC + v;
       if (f >= k) continue;
-      const double* row = prior + (size_t)(1 + f) * 2 * G;
-      const double lambda = row[g], mu = row[G + g];
-      const double sigma_sqr = 1.0 / lambda;
       double nt;
-      if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
-      else nt = do_sample ? mu + sqrt(sigma_sqr) * gauss_hash(seed, stream0 + (uint64_t)f, sh.global(j)) : mu;
+      if (one_group) {
+        if (zero1[v]) nt = 0.0;
+        else nt = do_sample ? mu1[v] + sd1[v] * gauss_hash(seed, stream0 + (uint64_t)f, sh.global(j)) : mu1[v];
+      } else {
+        const double* row = prior + (size_t)(1 + f) * 2 * G;
+        const double lambda = row[g], mu = row[G + g];
+        const double sigma_sqr = 1.0 / lambda;
+        if (isnan(sigma_sqr) || isinf(sigma_sqr)) nt = 0.0;
+        else nt = do_sample ? mu + sqrt(sigma_sqr) * gauss_hash(seed, stream0 + (uint64_t)f, sh.global(j)) : mu;
+      }
       if (isnan(nt) || isinf(nt)) continue;
       tb.V[(size_t)j * tb.rs + f] = (float)nt;
     }
