@@ -377,10 +377,28 @@ k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict
   const uint32_t tid = threadIdx.x;
   for (uint32_t p0 = blockIdx.x * 64u; p0 < nseg; p0 += gridDim.x * 64u) {
     const uint32_t np = min(64u, nseg - p0);
+    // the table side, a wavefront per 16 positions: the features' ids are looked up ONCE (two dependent 4-byte loads per position, not per
+    // float), then whole rows move -- EPI rows per wave-wide access, all of a wavefront's rows in flight together (round 5: at configs[4]'s
+    // shape the element-wise form ran at 1.5 TB/s packing and 0.8 TB/s unpacking, 48 ms of a 494 ms sweep)
+    constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI, STEPS = 16 / (EPI < 16 ? EPI : 16);
+    const uint32_t lane = tid & 63u, wv = tid >> 6, sub = lane / LPR, fl = lane % LPR;
+    uint32_t feat_l = 0;
+    if (lane < 16u && wv * 16u + lane < np) feat_l = seg_feat[level_list[p0 + wv * 16u + lane]];
     if (PACK) {
-      for (uint32_t i = tid; i < np * KP; i += 256) {             // rows: KP consecutive floats each (coalesced)
-        const uint32_t r = i / KP, f = i % KP;
-        tile[r][f] = tb.V[(size_t)seg_feat[level_list[p0 + r]] * tb.rs + f];
+      float vals[STEPS][VEC];
+#pragma unroll
+      for (int st = 0; st < STEPS; st++) {
+        const uint32_t q = (uint32_t)st * EPI + sub;               // position inside the wavefront's 16
+        const uint32_t feat = (uint32_t)__shfl((int)feat_l, (int)(q & 15u));
+        if (q < 16u && wv * 16u + q < np) load_vec<VEC>(tb.V + (size_t)feat * tb.rs + fl * VEC, vals[st]);
+      }
+#pragma unroll
+      for (int st = 0; st < STEPS; st++) {
+        const uint32_t q = (uint32_t)st * EPI + sub;
+        if (q < 16u && wv * 16u + q < np) {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) tile[wv * 16u + q][fl * VEC + v] = vals[st][v];
+        }
       }
       __syncthreads();
       for (uint32_t i = tid; i < k * 64u; i += 256) {             // per factor 64 consecutive positions
@@ -393,9 +411,23 @@ k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict
         if (r < np) tile[r][f] = vt[(size_t)f * vt_stride + p0 + r];
       }
       __syncthreads();
-      for (uint32_t i = tid; i < np * KP; i += 256) {
-        const uint32_t r = i / KP, f = i % KP;
-        if (f < k) tb.V[(size_t)seg_feat[level_list[p0 + r]] * tb.rs + f] = tile[r][f];   // (the padding columns stay zero)
+#pragma unroll
+      for (int st = 0; st < STEPS; st++) {
+        const uint32_t q = (uint32_t)st * EPI + sub;
+        const uint32_t feat = (uint32_t)__shfl((int)feat_l, (int)(q & 15u));
+        if (q < 16u && wv * 16u + q < np) {
+          float* row = tb.V + (size_t)feat * tb.rs + fl * VEC;
+          if (k == (uint32_t)KP) {
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) o[v] = tile[wv * 16u + q][fl * VEC + v];
+            store_vec<VEC>(row, o);
+          } else {
+#pragma unroll
+            for (int v = 0; v < VEC; v++)
+              if (fl * VEC + v < k) row[v] = tile[wv * 16u + q][fl * VEC + v];   // (the padding columns stay zero)
+          }
+        }
       }
     }
     __syncthreads();
