@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--regv", type=float, default=0.001)
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--order-noise", action="store_true",
+                    help="instead of the batch rule: the reference's ONLINE loop over the same rows with every two neighbours swapped -- how far the "
+                         "reference's own result moves under the smallest change of row order (the yardstick for the rule's distance)")
     a = ap.parse_args()
     from oracle import oracle as O
     t0 = time.time()
@@ -62,10 +65,20 @@ def main():
     m0 = O.Model(len(ids), a.k, True, True, 0.0, 0.0, a.regv)
     m0.v[:] = O.init_values_ids(1, ids, a.k, a.stdev).astype(np.float32)       # (the device holds fp32)
     m_rule, m_on = m0, m0.copy()          # (two fp64 sub-models: 1.18 M rows touch 37 M features = 19 GB each)
+    ds_swapped = None
+    if a.order_noise:                     # rows 2i and 2i + 1 change places (fixed row length: the entries move as blocks)
+        nrow = a.rows - a.rows % 2
+        perm = np.arange(a.rows)
+        perm[0:nrow:2], perm[1:nrow:2] = np.arange(1, nrow, 2), np.arange(0, nrow, 2)
+        ent2 = ent.reshape(a.rows, a.nnz)[perm].reshape(-1).copy()
+        ds_swapped = O.Data(ent2, d.row_ptr, d.target[perm].copy())
     for _ in range(a.epochs):
         O.sgd_epoch_online(m_on, ds, 1, a.lr, -1.0, 1.0)
-        O.sgd_epoch_minibatch(m_rule, ds, 1, a.lr, -1.0, 1.0, a.batch, a.chunk, bias_lag=a.lag)
-    out = {"rows": a.rows, "n": a.n, "k": a.k, "nnz": a.nnz, "batch": a.batch, "chunk": a.chunk, "bias_lag": a.lag, "epochs": a.epochs,
+        if a.order_noise:
+            O.sgd_epoch_online(m_rule, ds_swapped, 1, a.lr, -1.0, 1.0)
+        else:
+            O.sgd_epoch_minibatch(m_rule, ds, 1, a.lr, -1.0, 1.0, a.batch, a.chunk, bias_lag=a.lag)
+    out = {"what": "online loop vs online loop over pair-swapped rows" if a.order_noise else "batch rule vs online loop", "rows": a.rows, "n": a.n, "k": a.k, "nnz": a.nnz, "batch": a.batch, "chunk": a.chunk, "bias_lag": a.lag, "epochs": a.epochs,
            "stdev": a.stdev, "touched_features": int(len(ids)), "seconds": None}
     out.update(deviation(O, m_rule, m_on, ds))
     out["seconds"] = round(time.time() - t0, 1)
