@@ -826,12 +826,16 @@ def main():
                 if (pv["n"], pv["k"], pv["nnz"], pv["batch"], pv["bias_lag"], pv["chunk"]) == (args.n, args.k, args.nnz, batch, bias_lag, out["config"]["w0_chunk"]):
                     out["parity_vs_online"] = {kk: pv[kk] for kk in ("rows", "epochs", "chunk", "pred_rms", "pred_mean_abs", "pred_max_abs", "w0_abs",
                                                                      "pred_max_rel_to_rms_without_bias", "v_max_abs", "v_max_rel_to_vmax", "w_max_abs")}
-                    try:       # the yardstick: how far the reference's OWN result moves when every two neighbouring rows change places
-                        on = json.load(open(os.path.join(ROOT, "profiles", "r05_order_noise.json")))
-                        if (on["n"], on["k"], on["nnz"], on["rows"]) == (pv["n"], pv["k"], pv["nnz"], pv["rows"]):
-                            out["parity_vs_online"]["reference_vs_itself_with_neighbouring_rows_swapped"] = {kk: on[kk] for kk in ("pred_mean_abs", "pred_max_abs", "w0_abs", "v_max_rel_to_vmax", "w_max_abs")}
-                    except (OSError, ValueError, KeyError):
-                        pass
+                    # the yardsticks: how far the reference's OWN online result moves (same rows, same start) when every two neighbouring rows
+                    # change places, and when the rows inside every batch-sized window come in another order
+                    for key, fn in (("reference_vs_itself_with_neighbouring_rows_swapped", "r05_order_noise.json"),
+                                    ("reference_vs_itself_with_rows_shuffled_inside_batch_sized_windows", "r05_order_noise_window262144.json")):
+                        try:
+                            on = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                            if (on["n"], on["k"], on["nnz"], on["rows"]) == (pv["n"], pv["k"], pv["nnz"], pv["rows"]):
+                                out["parity_vs_online"][key] = {kk: on[kk] for kk in ("pred_mean_abs", "pred_max_abs", "w0_abs", "v_max_rel_to_vmax", "w_max_abs")}
+                        except (OSError, ValueError, KeyError):
+                            pass
                     out["parity_vs_online"]["source"] = "NOT measured in this run: profiles/r05_parity_vs_online.json (scripts/cpu_online_vs_rule.py, ~45 CPU-minutes: oracle rule vs oracle online loop on the sub-model of the rows' features); the device equals the rule at 1e-4 (tests/test_gpu_configs.py)"
             except (OSError, ValueError, KeyError):
                 pass

@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--order-noise", action="store_true",
                     help="instead of the batch rule: the reference's ONLINE loop over the same rows with every two neighbours swapped -- how far the "
                          "reference's own result moves under the smallest change of row order (the yardstick for the rule's distance)")
+    ap.add_argument("--order-window", type=int, default=0,
+                    help="with --order-noise: instead of swapping neighbours, shuffle the rows randomly inside windows of this many rows "
+                         "(262144: what the ORDER of the rows inside one batch is worth to the reference itself)")
     a = ap.parse_args()
     from oracle import oracle as O
     t0 = time.time()
@@ -70,6 +73,9 @@ def main():
         nrow = a.rows - a.rows % 2
         perm = np.arange(a.rows)
         perm[0:nrow:2], perm[1:nrow:2] = np.arange(1, nrow, 2), np.arange(0, nrow, 2)
+        if a.order_window > 1:
+            rng = np.random.default_rng(7)
+            perm = np.concatenate([w0 + rng.permutation(min(a.order_window, a.rows - w0)) for w0 in range(0, a.rows, a.order_window)])
         ent2 = ent.reshape(a.rows, a.nnz)[perm].reshape(-1).copy()
         ds_swapped = O.Data(ent2, d.row_ptr, d.target[perm].copy())
     for _ in range(a.epochs):
@@ -78,7 +84,7 @@ def main():
             O.sgd_epoch_online(m_rule, ds_swapped, 1, a.lr, -1.0, 1.0)
         else:
             O.sgd_epoch_minibatch(m_rule, ds, 1, a.lr, -1.0, 1.0, a.batch, a.chunk, bias_lag=a.lag)
-    out = {"what": "online loop vs online loop over pair-swapped rows" if a.order_noise else "batch rule vs online loop", "rows": a.rows, "n": a.n, "k": a.k, "nnz": a.nnz, "batch": a.batch, "chunk": a.chunk, "bias_lag": a.lag, "epochs": a.epochs,
+    out = {"what": ("online loop vs online loop over rows shuffled inside windows of %d" % a.order_window if a.order_window > 1 else "online loop vs online loop over pair-swapped rows") if a.order_noise else "batch rule vs online loop", "rows": a.rows, "n": a.n, "k": a.k, "nnz": a.nnz, "batch": a.batch, "chunk": a.chunk, "bias_lag": a.lag, "epochs": a.epochs,
            "stdev": a.stdev, "touched_features": int(len(ids)), "seconds": None}
     out.update(deviation(O, m_rule, m_on, ds))
     out["seconds"] = round(time.time() - t0, 1)
