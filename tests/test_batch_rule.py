@@ -54,3 +54,28 @@ def test_bad_arguments(capi):
         capi.batch_rule(7, 0.01, 0.1)
     with pytest.raises(capi.FmxError):
         capi.batch_rule(0, -1.0, 0.1)
+
+
+def test_default_micro_chunk_of_the_bias_recurrence(capi):
+    """fmx_default_w0_chunk (host arithmetic): the largest power of two <= FMX_W0_CHUNK_CAP = 32 with learn_rate * chunk * curvature <= 1
+    (curvature 1 regression, 1/4 classification).  The cap -- 256 until ABI 5 -- sets how finely the rule follows the reference's per-example
+    bias step (fm_sgd.h:34-37); the stability bound sets everything below it."""
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fmx.h")).read()
+    cap = int(re.search(r"#define\s+FMX_W0_CHUNK_CAP\s+(\d+)", hdr).group(1))
+    assert cap == 32
+    assert capi.default_w0_chunk(0.01, capi.TASK_CLASSIFICATION) == 32           # the bench: 1 / (0.01 * 1/4) = 400 -> capped
+    assert capi.default_w0_chunk(0.01, capi.TASK_REGRESSION) == 32               # 100 -> capped
+    assert capi.default_w0_chunk(0.1, capi.TASK_REGRESSION) == 8                 # 10 -> 8
+    assert capi.default_w0_chunk(0.2, capi.TASK_CLASSIFICATION) == 16            # 20 -> 16
+    assert capi.default_w0_chunk(2.0, capi.TASK_REGRESSION) == 1                 # never below the reference's own step
+    assert capi.default_w0_chunk(0.0, capi.TASK_REGRESSION) == cap
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        task = int(rng.integers(0, 2))
+        lr = float(10 ** rng.uniform(-4, 0.5))
+        c = capi.default_w0_chunk(lr, task)
+        curv = 1.0 if task == capi.TASK_REGRESSION else 0.25
+        assert c >= 1 and c & (c - 1) == 0 and c <= cap
+        assert c == 1 or lr * c * curv <= 1.0 + 1e-12
+        assert c == cap or lr * (2 * c) * curv > 1.0
