@@ -10,7 +10,8 @@ namespace {
 // Default: the largest power of two with lr * chunk * curvature <= 1, capped at FMX_W0_CHUNK_CAP.  The cap is what sets how
 // closely the batch rule follows the reference's bias PATH (and through it the reference's predictions): at the bench shape the
 // rule's bias ends 0.025 from the online loop's at chunk 256 and 0.0014 at chunk 32, so the cap went from
-// 256 to 32 in round 5 -- k_scan1's sub-piece form evaluates such chunks at ~60 ns each.  An explicit w0_chunk is honoured.
+// 256 to 32 in round 5 -- the recurrence is solved parallel in time (k_scan_pit) at 40-80 us per 262 144 examples whatever the chunk; as a
+// one-wavefront chain (k_scan1's sub-piece form, FMX_SCAN=serial) such chunks cost ~60 ns each.  An explicit w0_chunk is honoured.
 uint32_t default_w0_chunk(const fmx_config& c) { return fmx_default_w0_chunk(c.learn_rate, c.task); }
 
 // row slots (ZR) of the k_fused instance used for a slot: the smallest instance whose registers hold the longest row
@@ -287,9 +288,10 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
   if (hy.k0) {
     const double* wi = w0_in ? w0_in : h->w0;
     double* wo = w0_out ? w0_out : h->w0;
-    // round 5: the recurrence solved parallel in time (k_scan_pit: Newton on the whole path, affine prefix scans; up to 32 workgroups) for
-    // micro-chunks that are powers of two up to 2048 on batches of 4097 .. 262 144 examples -- every default.  Same result as the chain to
-    // fp32 rounding; ~40 us per 262 144 examples whatever the micro-chunk where the chain takes 0.18 ms (256) .. 0.5 ms (32).
+    // round 5: the recurrence solved parallel in time (k_scan_pit: Newton on the whole path, affine prefix scans; up to 64 workgroups) for
+    // micro-chunks that are powers of two up to 1024 on batches of 4097 .. 262 144 examples -- every default.  Same result as the chain to
+    // fp32 rounding; 40-80 us per 262 144 examples whatever the micro-chunk where the chain takes 0.18 ms (256) .. 0.5 ms (32).
+    // (the arrival counters of its exchanges are zeroed on the launch's own stream, in front of it)
     if (h->scan_pit && n_rows > 4096u && n_rows <= PIT_MAX_ROWS && chunk <= PIT_MAX_CHUNK && (chunk & (chunk - 1u)) == 0u) {
       const uint32_t nwg = (n_rows + pit_seg(chunk) - 1) / pit_seg(chunk);
       HIPCHK(h, hipMemsetAsync(h->pit_ctr, 0, (PIT_MAX_IT + 1) * sizeof(unsigned long long), st));
