@@ -839,6 +839,10 @@ def main():
                     out["parity_vs_online"]["source"] = "NOT measured in this run: profiles/r05_parity_vs_online.json (scripts/cpu_online_vs_rule.py, ~45 CPU-minutes: oracle rule vs oracle online loop on the sub-model of the rows' features); the device equals the rule at 1e-4 (tests/test_gpu_configs.py)"
             except (OSError, ValueError, KeyError):
                 pass
+        if not sharded and args.mode != "hogwild" and roof is not None:
+            # the same as flat scalars of `roofline`: the one-time preparation and what a 20-epoch run (BASELINE configs[0]'s count) delivers end to end
+            roof["setup_seconds"] = round(setup_s, 4)
+            roof["end_to_end_20_epochs_examples_per_s"] = round(20 * args.rows / (setup_s + 20 * elapsed / args.steps), 1)
         if not sharded and args.mode != "hogwild":
             # outside `value` and outside the timed steps: paid once per (data set, batch size) in the first warm-up step
             out["one_time_setup"] = {"seconds": round(setup_s, 4), "equivalent_steps": round(setup_s / (elapsed / args.steps), 2),
@@ -866,6 +870,11 @@ def main():
         if roof is not None and "predict" in extras:
             # what north_star scores, as flat numbers inside `roofline` (the driver's record keeps only the NAMES of the extra keys)
             pr = extras["predict"]
+            # ... and once more as FLAT scalars: the driver's record keeps scalars only
+            roof["predict_v_read_frac"] = pr["v_read_frac"]
+            roof["predict_v_read_frac_cold"] = pr["without_side_stream"]["v_read_frac"]
+            roof["predict_rows_per_s"] = pr["value"]
+            roof["predict_rows_per_s_cold"] = pr["without_side_stream"]["value"]
             roof["predict"] = {"v_read_frac": pr["v_read_frac"], "v_read_frac_cold": pr["without_side_stream"]["v_read_frac"],
                                "rows_per_s": pr["value"], "rows_per_s_cold": pr["without_side_stream"]["value"],
                                "cold": "no weight side stream (a pass that no epoch on the slot preceded)"}
@@ -913,7 +922,16 @@ def main():
         if out.get("roofline") is not None:
             out["roofline"]["per_config"] = {kk: (out[kk].get("roofline") or {}).get("frac") for kk in ("c2", "criteo", "als", "mcmc", "mcmc_c5")
                                              if isinstance(out.get(kk), dict)}
+            for kk, fv in out["roofline"]["per_config"].items():   # flat scalars (the driver's record drops nested objects)
+                out["roofline"]["frac_" + kk] = fv
+            for kk in ("c2", "criteo", "als", "mcmc", "mcmc_c5", "criteo_8shard"):
+                if isinstance(out.get(kk), dict) and "value" in out[kk]:
+                    out["roofline"]["examples_per_s_" + kk] = out[kk]["value"]
             sp = out.get("shard_probe", {}).get("ranks", {})
+            if "P8" in sp:
+                out["roofline"]["shard_p8_rank_examples_per_s"] = sp["P8"]["per_rank_examples_per_s"]
+                out["roofline"]["modelled_speedup_p8_exact"] = sp["P8"]["modelled"]["speedup_vs_1_gpu_exact"]
+                out["roofline"]["modelled_speedup_p8_stale"] = sp["P8"]["modelled"].get("speedup_vs_1_gpu_one_batch_stale")
             out["roofline"]["shard_probe"] = {pk: {"per_rank_examples_per_s": pv["per_rank_examples_per_s"], "frac": pv["frac_of_hbm_peak"],
                                                    "modelled_speedup_exact": pv["modelled"]["speedup_vs_1_gpu_exact"]} for pk, pv in sp.items()}
     if rank == 0:

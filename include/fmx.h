@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 6
+#define FMX_ABI_VERSION 7
 
 enum {
   FMX_OK = 0,
@@ -197,6 +197,18 @@ typedef struct fmx_epoch_stats {
 
 #define FMX_STAT_BATCH_CUT 1u   /* batch = 0 resolved below the 262144 default because of the rows' collision mass */
 #define FMX_STAT_UNSTABLE  2u   /* batch_gain > 2: an explicit batch the rule is not stable at on this data */
+/* (ABI 7) how the epoch's bias recurrences and stream ordering actually ran -- same numbers in every form; for tests and diagnosis: */
+#define FMX_STAT_SCAN_PIT      4u  /* at least one batch's recurrence was solved parallel in time (k_scan_pit) */
+#define FMX_STAT_SCAN_SERIAL   8u  /* at least one ran as the one-wavefront chain (k_scan1 / k_scan / the small-batch form) */
+#define FMX_STAT_SCAN_FALLBACK 16u /* a grid-wide exchange of k_scan_pit ran into its bound (a workgroup was not resident: the device is
+                                      shared with work the library cannot see); one workgroup evaluated that batch's chain serially -- the
+                                      result is still the rule's -- and the handle uses the one-wavefront chain from now on */
+#define FMX_STAT_EVENT_SYNC    32u /* the launch stream and the recurrence's side stream were ordered by events, not by the device-side
+                                      hand-off: requested (FMX_FLAG_EVENT_SYNC / FMX_HANDOFF=0), bias_lag 1, or the handle found that its two
+                                      streams do not run concurrently (serialised dispatch: a counter-collecting profiler, AMD_SERIALIZE_KERNEL) */
+#define FMX_STAT_HANDOFF_TIMEOUT 64u /* a device-side hand-off wait ran into its bound all the same: the examples concerned took NO step
+                                      (multiplier 0; a recurrence that never saw its batch handed the bias on unchanged), every parameter is a
+                                      valid number, the call returns FMX_E_HIP with this status set, and the handle orders by events from now on */
 
 /* what fmx_sgd_epoch would use for `batch` on this slot (no training): the rows' collision mass (computed once per slot on the
  * device: one histogram pass over the entries), the resolved batch and its gain.  opts may be NULL (= batch 0). */

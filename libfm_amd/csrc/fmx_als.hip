@@ -9,25 +9,25 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------
 extern "C++" void als_free(fmx_handle h) {
   AlsState& a = h->als;
-  if (a.e) hipFree(a.e);
-  if (a.q) hipFree(a.q);
-  if (a.seen) hipFree(a.seen);
-  if (a.level_list) hipFree(a.level_list);
-  if (a.ldesc) hipFree(a.ldesc);
-  if (a.prior) hipFree(a.prior);
-  if (a.vt) hipFree(a.vt);
-  if (a.delta) hipFree(a.delta);
-  if (a.epart) hipFree(a.epart);
-  if (a.r_row) hipFree(a.r_row);
-  if (a.r_pos) hipFree(a.r_pos);
-  if (a.r_x) hipFree(a.r_x);
-  if (a.t_row) hipFree(a.t_row);
-  if (a.dth) hipFree(a.dth);
+  if (a.e) fmx_dev_free(a.e);
+  if (a.q) fmx_dev_free(a.q);
+  if (a.seen) fmx_dev_free(a.seen);
+  if (a.level_list) fmx_dev_free(a.level_list);
+  if (a.ldesc) fmx_dev_free(a.ldesc);
+  if (a.prior) fmx_dev_free(a.prior);
+  if (a.vt) fmx_dev_free(a.vt);
+  if (a.delta) fmx_dev_free(a.delta);
+  if (a.epart) fmx_dev_free(a.epart);
+  if (a.r_row) fmx_dev_free(a.r_row);
+  if (a.r_pos) fmx_dev_free(a.r_pos);
+  if (a.r_x) fmx_dev_free(a.r_x);
+  if (a.t_row) fmx_dev_free(a.t_row);
+  if (a.dth) fmx_dev_free(a.dth);
   for (AlsBlock& b : a.blk) {
-    if (b.level_list) hipFree(b.level_list);
-    if (b.cache) hipFree(b.cache);
-    if (b.qb_all) hipFree(b.qb_all);
-    if (b.cpart) hipFree(b.cpart);
+    if (b.level_list) fmx_dev_free(b.level_list);
+    if (b.cache) fmx_dev_free(b.cache);
+    if (b.qb_all) fmx_dev_free(b.qb_all);
+    if (b.cpart) fmx_dev_free(b.cpart);
   }
   a = AlsState();
 }
@@ -85,7 +85,7 @@ static int build_levels(fmx_handle h, const Slot& s, std::vector<uint32_t>& leve
   if (lev_ent) for (uint32_t l = 0; l < n_levels; l++) (*lev_ent)[l + 1] += (*lev_ent)[l];
   if (seg_level) seg_level->swap(lvl);
   if (seen) for (uint32_t sg = 0; sg < nseg; sg++) (*seen)[(size_t)id_offset + seg_feat[sg]] = 1;
-  HIPCHK(h, hipMalloc(d_level_list, list.size() * 4));
+  HIPCHK(h, fmx_dev_alloc(d_level_list, list.size() * 4));
   HIPCHK(h, hipMemcpy(*d_level_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
   return FMX_OK;
 }
@@ -128,16 +128,16 @@ static int als_build_rows(fmx_handle h, const Slot& s, AlsState& a, const std::v
     int bits_level = 1; while ((1ull << bits_level) < a.level_ptr.size()) bits_level++;
     size_t tmp_bytes = 0;
     const dim3 gr(std::min<uint32_t>((nnz + 255) / 256, 8192)), bl(256);
-    ROW_CHK(hipMalloc(&ka, (size_t)nnz * 8)); ROW_CHK(hipMalloc(&kb, (size_t)nnz * 8));
-    ROW_CHK(hipMalloc(&va, (size_t)nnz * 4)); ROW_CHK(hipMalloc(&vb, (size_t)nnz * 4));
-    ROW_CHK(hipMalloc(&d_lvl, (size_t)nseg * 4)); ROW_CHK(hipMalloc(&d_pos, (size_t)nseg * 4));
-    ROW_CHK(hipMalloc(&a.r_row, (size_t)nnz * 4)); ROW_CHK(hipMalloc(&a.r_pos, (size_t)nnz * 4)); ROW_CHK(hipMalloc(&a.r_x, (size_t)nnz * 4));
-    ROW_CHK(hipMalloc(&a.dth, (size_t)big * sizeof(float2)));
+    ROW_CHK(fmx_dev_alloc(&ka, (size_t)nnz * 8)); ROW_CHK(fmx_dev_alloc(&kb, (size_t)nnz * 8));
+    ROW_CHK(fmx_dev_alloc(&va, (size_t)nnz * 4)); ROW_CHK(fmx_dev_alloc(&vb, (size_t)nnz * 4));
+    ROW_CHK(fmx_dev_alloc(&d_lvl, (size_t)nseg * 4)); ROW_CHK(fmx_dev_alloc(&d_pos, (size_t)nseg * 4));
+    ROW_CHK(fmx_dev_alloc(&a.r_row, (size_t)nnz * 4)); ROW_CHK(fmx_dev_alloc(&a.r_pos, (size_t)nnz * 4)); ROW_CHK(fmx_dev_alloc(&a.r_x, (size_t)nnz * 4));
+    ROW_CHK(fmx_dev_alloc(&a.dth, (size_t)big * sizeof(float2)));
     ROW_CHK(hipMemcpyAsync(d_lvl, seg_level.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, st));
     ROW_CHK(hipMemcpyAsync(d_pos, seg_pos.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_als_rowkeys, gr, bl, 0, st, s.t_ent, s.seg_rel, nseg, nnz, d_lvl, ka, va);
     ROW_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ka, kb, va, vb, (int)nnz, 0, 32 + bits_level, st));
-    ROW_CHK(hipMalloc(&tmp, tmp_bytes));
+    ROW_CHK(fmx_dev_alloc(&tmp, tmp_bytes));
     ROW_CHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, ka, kb, va, vb, (int)nnz, 0, 32 + bits_level, st));
     hipLaunchKernelGGL(k_als_rowfill, gr, bl, 0, st, s.t_ent, s.seg_rel, nseg, nnz, d_pos, vb, a.r_row, a.r_pos, a.r_x);
     ROW_CHK(hipGetLastError());
@@ -159,7 +159,7 @@ static int als_build_rows(fmx_handle h, const Slot& s, AlsState& a, const std::v
         any_unit = any_unit || a.lev_dense[l] == 2;
       }
       if (any_unit) {                                                // the row-only stream of X^T for the levels of unit values
-        ROW_CHK(hipMalloc(&a.t_row, (size_t)nnz * 4));
+        ROW_CHK(fmx_dev_alloc(&a.t_row, (size_t)nnz * 4));
         hipLaunchKernelGGL(k_als_trow, gr, bl, 0, st, s.t_ent, (uint32_t)nnz, a.t_row);
         ROW_CHK(hipGetLastError());
         ROW_CHK(hipStreamSynchronize(st));
@@ -168,7 +168,7 @@ static int als_build_rows(fmx_handle h, const Slot& s, AlsState& a, const std::v
   }
 done:
 #undef ROW_CHK
-  for (void* p : {(void*)ka, (void*)kb, (void*)va, (void*)vb, (void*)d_lvl, (void*)d_pos, tmp}) if (p) hipFree(p);
+  for (void* p : {(void*)ka, (void*)kb, (void*)va, (void*)vb, (void*)d_lvl, (void*)d_pos, tmp}) if (p) fmx_dev_free(p);
   return rc;
 }
 
@@ -219,22 +219,22 @@ static int als_begin_impl(fmx_handle h, int train_slot) {
     if (rc) return rc;
     rc = build_levels(h, br.rows, ab.level_ptr, &ab.level_list, &seen, br.attr_offset);
     if (rc) return rc;
-    HIPCHK(h, hipMalloc(&ab.cache, (size_t)7 * std::max<uint32_t>(B, 1) * sizeof(double)));
+    HIPCHK(h, fmx_dev_alloc(&ab.cache, (size_t)7 * std::max<uint32_t>(B, 1) * sizeof(double)));
     HIPCHK(h, hipMemsetAsync(ab.cache, 0, (size_t)7 * std::max<uint32_t>(B, 1) * sizeof(double), h->stream));
-    HIPCHK(h, hipMalloc(&ab.qb_all, (size_t)h->KP * std::max<uint32_t>(B, 1) * sizeof(double)));
-    HIPCHK(h, hipMalloc(&ab.cpart, (size_t)std::max<uint32_t>(B, 1) * sizeof(double)));
+    HIPCHK(h, fmx_dev_alloc(&ab.qb_all, (size_t)h->KP * std::max<uint32_t>(B, 1) * sizeof(double)));
+    HIPCHK(h, fmx_dev_alloc(&ab.cpart, (size_t)std::max<uint32_t>(B, 1) * sizeof(double)));
     const double avg_col = br.rows.nseg ? (double)br.rows.nnz / (double)br.rows.nseg : 0.0;
     ab.lanes = avg_col <= 5.0 ? 4 : (avg_col <= 12.0 ? 8 : (avg_col <= 40.0 ? 16 : 64));
   }
   const uint32_t nseg = s.nseg;
-  HIPCHK(h, hipMalloc(&a.seen, seen.size()));
+  HIPCHK(h, fmx_dev_alloc(&a.seen, seen.size()));
   HIPCHK(h, hipMemcpy(a.seen, seen.data(), seen.size(), hipMemcpyHostToDevice));
-  if (!s.blocks.empty()) HIPCHK(h, hipMalloc(&a.epart, (size_t)N * sizeof(double)));
-  HIPCHK(h, hipMalloc(&a.e, (size_t)N * sizeof(EQ)));
-  HIPCHK(h, hipMalloc(&a.q, (size_t)N * (size_t)h->KP * sizeof(double)));
+  if (!s.blocks.empty()) HIPCHK(h, fmx_dev_alloc(&a.epart, (size_t)N * sizeof(double)));
+  HIPCHK(h, fmx_dev_alloc(&a.e, (size_t)N * sizeof(EQ)));
+  HIPCHK(h, fmx_dev_alloc(&a.q, (size_t)N * (size_t)h->KP * sizeof(double)));
   if (h->cfg.num_factor > 0 && nseg > 0) {      // (the env switch is the A/B knob of the profile)
     a.vt_stride = ((size_t)nseg + 63) & ~(size_t)63;
-    HIPCHK(h, hipMalloc(&a.vt, (size_t)h->cfg.num_factor * a.vt_stride * sizeof(float)));
+    HIPCHK(h, fmx_dev_alloc(&a.vt, (size_t)h->cfg.num_factor * a.vt_stride * sizeof(float)));
   }
   // ---- first prediction and e -= target (fm_learn_mcmc_simultaneous.h:69-86)
   rc = als_repredict(h, s, a);
@@ -255,7 +255,7 @@ int fmx_als_moments(fmx_handle h, double* out) {
   const uint32_t G = h->num_groups;
   const size_t cells = (size_t)(1 + h->KP) * G * 2;              // device block [1 + KP][G][2]
   double* d = nullptr;
-  HIPCHK(h, hipMalloc(&d, (2 + cells) * sizeof(double)));
+  HIPCHK(h, fmx_dev_alloc(&d, (2 + cells) * sizeof(double)));
   hipStream_t st = h->stream;
   hipError_t er = hipMemsetAsync(d, 0, (2 + cells) * sizeof(double), st);
   const dim3 b1(256), ge(std::min<uint32_t>((s.n_rows + 255) / 256, 2048));
@@ -278,7 +278,7 @@ int fmx_als_moments(fmx_handle h, double* out) {
   if (er == hipSuccess) er = hipGetLastError();
   if (er == hipSuccess) er = hipMemcpyAsync(host.data(), d, (2 + cells) * sizeof(double), hipMemcpyDeviceToHost, st);
   if (er == hipSuccess) er = hipStreamSynchronize(st);
-  hipFree(d);
+  fmx_dev_free(d);
   if (er != hipSuccess) return fail(h, FMX_E_HIP, "fmx_als_moments: %s", hipGetErrorString(er));
   out[0] = host[1]; out[1] = host[0];                                          // documented order: sum e^2 first
   memcpy(out + 2, host.data() + 2, (size_t)(1 + k) * G * 2 * sizeof(double)); // rows 0..k of [1 + KP][G][2]
@@ -351,12 +351,12 @@ static int als_sweep_shards(const std::vector<fmx_handle>& hs, fmx_group g, cons
         row[NG + gg] = (tabs && opts->v_mu_gf) ? opts->v_mu_gf[(size_t)gg * kf + f] : (opts->v_mu_f ? opts->v_mu_f[f] : opts->v_mu);
       }
     }
-    if (!a.prior) HIPCHK(x, hipMalloc(&a.prior, a.prior_host.size() * sizeof(double)));
+    if (!a.prior) HIPCHK(x, fmx_dev_alloc(&a.prior, a.prior_host.size() * sizeof(double)));
     HIPCHK(x, hipMemcpyAsync(a.prior, a.prior_host.data(), a.prior_host.size() * sizeof(double), hipMemcpyHostToDevice, x->stream));
     // lanes per column from the mean column length (one-hot data: a handful of rows per feature)
     const Slot& s = x->slots[a.slot];
     if (!a.ldesc && s.nseg) {                                // the level-ordered column records, once per session
-      HIPCHK(x, hipMalloc(&a.ldesc, (size_t)s.nseg * sizeof(uint4)));
+      HIPCHK(x, fmx_dev_alloc(&a.ldesc, (size_t)s.nseg * sizeof(uint4)));
       hipLaunchKernelGGL(k_als_ldesc, dim3(std::min<uint32_t>((s.nseg + 255) / 256, 8192)), dim3(256), 0, x->stream, a.level_list, s.nseg,
                          s.seg_feat, s.seg_rel, s.nseg, (uint32_t)s.nnz, a.ldesc);
       HIPCHK(x, hipGetLastError());
@@ -629,18 +629,18 @@ int fmx_group_als_begin(fmx_group g, int train_slot) {
     std::vector<uint8_t> seen((size_t)x->n_local, 0);
     for (uint32_t sg = 0; sg < nseg; sg++) seen[seg_feat[i][sg]] = 1;
     hipError_t er = hipSetDevice(x->device);
-    if (er == hipSuccess) er = hipMalloc(&a.level_list, list.size() * 4);
+    if (er == hipSuccess) er = fmx_dev_alloc(&a.level_list, list.size() * 4);
     if (er == hipSuccess) er = hipMemcpy(a.level_list, list.data(), list.size() * 4, hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMalloc(&a.seen, seen.size());
+    if (er == hipSuccess) er = fmx_dev_alloc(&a.seen, seen.size());
     if (er == hipSuccess) er = hipMemcpy(a.seen, seen.data(), seen.size(), hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMalloc(&a.e, (size_t)N * sizeof(EQ));
-    if (er == hipSuccess) er = hipMalloc(&a.q, (size_t)N * (size_t)x->KP * sizeof(double));
-    if (er == hipSuccess) er = hipMalloc(&a.delta, (size_t)N * sizeof(EQ));
+    if (er == hipSuccess) er = fmx_dev_alloc(&a.e, (size_t)N * sizeof(EQ));
+    if (er == hipSuccess) er = fmx_dev_alloc(&a.q, (size_t)N * (size_t)x->KP * sizeof(double));
+    if (er == hipSuccess) er = fmx_dev_alloc(&a.delta, (size_t)N * sizeof(EQ));
     if (er == hipSuccess) er = hipMemsetAsync(a.delta, 0, (size_t)N * sizeof(EQ), x->stream);
-    if (er == hipSuccess) er = hipMalloc(&a.epart, (size_t)N * sizeof(double));
+    if (er == hipSuccess) er = fmx_dev_alloc(&a.epart, (size_t)N * sizeof(double));
     if (er == hipSuccess && x->cfg.num_factor > 0 && nseg > 0) {
       a.vt_stride = ((size_t)nseg + 63) & ~(size_t)63;
-      er = hipMalloc(&a.vt, (size_t)x->cfg.num_factor * a.vt_stride * sizeof(float));
+      er = fmx_dev_alloc(&a.vt, (size_t)x->cfg.num_factor * a.vt_stride * sizeof(float));
     }
     if (er != hipSuccess) return bail(fail(x, FMX_E_HIP, "fmx_group_als_begin: %s", hipGetErrorString(er)), x);
     // first prediction (fm_learn_mcmc_simultaneous.h:69-86): partial sums of this shard

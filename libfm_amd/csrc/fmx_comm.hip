@@ -41,13 +41,17 @@ Rccl* rccl() {                                   // bound once per process; null
 #define BIND(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym)); \
   if (!r.field) { r.err = std::string("librccl lacks ") + sym; r.lib = nullptr; return nullptr; }
   BIND(GetUniqueId, "ncclGetUniqueId") BIND(CommInitRank, "ncclCommInitRank") BIND(CommDestroy, "ncclCommDestroy")
-  BIND(AllReduce, "ncclAllReduce") BIND(ReduceScatter, "ncclReduceScatter") BIND(AllGather, "ncclAllGather")
+  BIND(AllReduce, "ncclAllReduce")
   BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
   BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
+  // the second exchange path's two symbols are optional: only FMX_EXCHANGE_RS_AG needs them (rccl_has_rsag; round-5 advisor)
+  r.ReduceScatter = reinterpret_cast<decltype(r.ReduceScatter)>(dlsym(r.lib, "ncclReduceScatter"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
   return &r;
 }
 const char* rccl_why() { return g_rccl.err.c_str(); }
+bool rccl_has_rsag() { Rccl* R = rccl(); return R && R->ReduceScatter && R->AllGather; }
 
 #define NCCLCHK(h, expr)                                                                                        \
   do { ncclResult_t _r = (expr); if (_r != ncclSuccess)                                                         \
@@ -117,9 +121,9 @@ static int ensure_xbuf(fmx_handle h, size_t floats) {
   if (floats <= h->xcap) return FMX_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream_comm));
-  for (auto& b : h->xbuf) { if (b) hipFree(b); b = nullptr; }
+  for (auto& b : h->xbuf) { if (b) fmx_dev_free(b); b = nullptr; }
   h->xcap = 0;
-  for (auto& b : h->xbuf) HIPCHK(h, hipMalloc(&b, floats * sizeof(float)));
+  for (auto& b : h->xbuf) HIPCHK(h, fmx_dev_alloc(&b, floats * sizeof(float)));
   h->xcap = floats;
   return FMX_OK;
 }
@@ -309,7 +313,7 @@ void comm_free(fmx_handle h) {
     else { for (auto& x : g->hs) if (x == h) x = nullptr; h->group = nullptr; }
   }
   fmx_comm_destroy(h);
-  for (auto& b : h->xbuf) { if (b) hipFree(b); b = nullptr; }
+  for (auto& b : h->xbuf) { if (b) fmx_dev_free(b); b = nullptr; }
   h->xcap = 0;
   if (h->stream_comm) { hipStreamDestroy(h->stream_comm); h->stream_comm = nullptr; }
   for (auto& e : h->ev_x) { if (e) hipEventDestroy(e); e = nullptr; }
@@ -381,11 +385,21 @@ int fmx_comm_init_rank(fmx_handle h, const void* id128, int rank, int world) {
   if (h->comm) return fail(h, FMX_E_STATE, "fmx_comm_init_rank: the handle already has a communicator");
   Rccl* R = rccl();
   if (!R) return fail(h, FMX_E_UNSUPPORTED, "fmx_comm_init_rank: %s", rccl_why());
+  if (h->cfg.exchange_algo == FMX_EXCHANGE_RS_AG && !rccl_has_rsag())
+    return fail(h, FMX_E_UNSUPPORTED, "fmx_comm_init_rank: exchange_algo = FMX_EXCHANGE_RS_AG but librccl lacks ncclReduceScatter / ncclAllGather");
   HIPCHK(h, hipSetDevice(h->device));
   ncclUniqueId id; memcpy(&id, id128, sizeof(id));
   ncclComm_t c = nullptr;
   NCCLCHK(h, R->CommInitRank(&c, world, id, rank));
   h->comm = c;
+  {  // every rank must issue the SAME collectives per batch: the ranks' exchange_algo compared in one 16-byte all-reduce (max of {a, -a})
+    double v[2] = {(double)h->cfg.exchange_algo, -(double)h->cfg.exchange_algo};
+    HIPCHK(h, hipMemcpyAsync(h->acc, v, sizeof(v), hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(h, R->AllReduce(h->acc, h->acc, 2, ncclFloat64, ncclMax, c, h->stream));
+    HIPCHK(h, hipMemcpyAsync(v, h->acc, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (v[0] != -v[1]) { fmx_comm_destroy(h); return fail(h, FMX_E_ARG, "fmx_comm_init_rank: the ranks disagree on fmx_config::exchange_algo (%g .. %g)", -v[1], v[0]); }
+  }
   for (auto& sl : h->slots) sl.coll_mass_world = -1.0;               // (summed over THIS communicator on first use)
   return FMX_OK;
 }
@@ -412,6 +426,8 @@ int fmx_group_create(fmx_handle* handles, int n, fmx_group* out) {
       return fail(h, FMX_E_ARG, "fmx_group_create: handle %d must be shard %d of %d (is %d of %d)", i, i, n, h->cfg.shard_rank, h->cfg.shard_world);
     if (h->KP != handles[0]->KP || h->cfg.num_attribute != handles[0]->cfg.num_attribute || h->cfg.shard_hash != handles[0]->cfg.shard_hash)
       return fail(h, FMX_E_ARG, "fmx_group_create: the shards describe different models");
+    if (h->cfg.exchange_algo != handles[0]->cfg.exchange_algo)       // (members issuing different collectives would wait for each other for ever)
+      return fail(h, FMX_E_ARG, "fmx_group_create: handle %d has exchange_algo %u, handle 0 has %u", i, h->cfg.exchange_algo, handles[0]->cfg.exchange_algo);
     if (h->group) return fail(h, FMX_E_STATE, "fmx_group_create: handle %d already belongs to a group", i);
   }
   fmx_group g = new fmx_group_s();
@@ -484,13 +500,13 @@ int staged_alloc(fmx_group g, size_t bytes, Staged* st) {
     for (size_t j = 0; j < i; j++) if (g->hs[j]->device == h->device) { same = j; break; }
     if (same < n) { st->buf[i] = st->buf[same]; continue; }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMalloc(&st->buf[i], std::max<size_t>(bytes, 8)));
+    HIPCHK(h, fmx_dev_alloc(&st->buf[i], std::max<size_t>(bytes, 8)));
     st->own[i] = true;
   }
   return FMX_OK;
 }
 void staged_free(fmx_group g, Staged* st) {
-  for (size_t i = 0; i < st->buf.size(); i++) if (st->own[i] && st->buf[i]) { hipSetDevice(g->hs[i]->device); hipFree(st->buf[i]); }
+  for (size_t i = 0; i < st->buf.size(); i++) if (st->own[i] && st->buf[i]) { hipSetDevice(g->hs[i]->device); fmx_dev_free(st->buf[i]); }
   st->buf.clear(); st->own.clear();
 }
 // host -> first device, then to every other device that holds a copy of the stage
@@ -573,10 +589,10 @@ int fmx_group_upload_rows(fmx_group g, int slot, const void* entries, const uint
     Slot s;
     uint32_t* cnt = nullptr; void* tmp = nullptr;
     uint32_t host_flags[2] = {0, 0};                           // [0] longest kept row, [1] bad id seen
-    hipError_t er = hipMalloc(&cnt, ((size_t)n_rows + 3) * sizeof(uint32_t));
+    hipError_t er = fmx_dev_alloc(&cnt, ((size_t)n_rows + 3) * sizeof(uint32_t));
     uint32_t* d_flags = cnt ? cnt + n_rows + 1 : nullptr;
     if (er == hipSuccess) er = hipMemsetAsync(cnt, 0, ((size_t)n_rows + 3) * sizeof(uint32_t), h->stream);
-    if (er == hipSuccess) er = hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t));
+    if (er == hipSuccess) er = fmx_dev_alloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t));
     const dim3 grid(std::min<uint32_t>((n_rows + 255) / 256 + 1, 4096)), block(256);
     const Shard sh = make_shard(h->cfg);
     if (er == hipSuccess) {
@@ -588,28 +604,28 @@ int fmx_group_upload_rows(fmx_group g, int slot, const void* entries, const uint
       size_t tmp_bytes = 0;
       auto conv = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, uint32_t*>(cnt, hipcub::CastOp<uint64_t>());
       er = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream);
-      if (er == hipSuccess) er = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 8));
+      if (er == hipSuccess) er = fmx_dev_alloc(&tmp, std::max<size_t>(tmp_bytes, 8));
       if (er == hipSuccess) er = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream);
     }
     uint64_t total = 0;
     if (er == hipSuccess) er = hipMemcpyAsync(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream);
     if (er == hipSuccess) er = hipMemcpyAsync(host_flags, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
-    if (er == hipSuccess && host_flags[1]) { if (cnt) hipFree(cnt); if (tmp) hipFree(tmp); free_slot(s); staged_free(g, &se); staged_free(g, &sp);
+    if (er == hipSuccess && host_flags[1]) { if (cnt) fmx_dev_free(cnt); if (tmp) fmx_dev_free(tmp); free_slot(s); staged_free(g, &se); staged_free(g, &sp);
       return gfail(g, FMX_E_ARG, "a feature id of the rows is >= num_attribute %llu", (unsigned long long)n); }
-    if (er == hipSuccess) er = hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry));
+    if (er == hipSuccess) er = fmx_dev_alloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry));
     if (er == hipSuccess) {
       hipLaunchKernelGGL(k_shard_rows, grid, block, 0, h->stream, (const Entry*)se.buf[i], (const uint64_t*)sp.buf[i], n_rows, n, sh, (uint32_t*)nullptr, (uint32_t*)nullptr,
                          (uint32_t*)nullptr, (const uint64_t*)s.row_ptr, s.ent);
       er = hipGetLastError();
     }
     if (er == hipSuccess && target) {
-      er = hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float));
+      er = fmx_dev_alloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float));
       if (er == hipSuccess && n_rows) er = hipMemcpyAsync(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice, h->stream);
     }
     if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
-    if (cnt) hipFree(cnt);
-    if (tmp) hipFree(tmp);
+    if (cnt) fmx_dev_free(cnt);
+    if (tmp) fmx_dev_free(tmp);
     if (er != hipSuccess) { free_slot(s); rc = fail(h, FMX_E_HIP, "fmx_group_upload_rows: %s", hipGetErrorString(er)); break; }
     s.n_rows = n_rows; s.nnz = total; s.max_row = host_flags[0]; s.used = true;
     h->slots[slot] = s;
@@ -643,7 +659,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
   if (opts_in->apply == FMX_APPLY_FUSED) opts.flags |= FMX_FLAG_BIAS_LAG;       // FUSED implies the lag on one device: same rule here
   const bool pipeline = (opts.flags & FMX_FLAG_PIPELINE) != 0;
   const uint32_t n_rows = g->hs[0]->slots[slot].n_rows;
-  for (auto m : g->hs) m->setup_acc = 0.0;
+  for (auto m : g->hs) { m->setup_acc = 0.0; m->run_status = 0; }
   fmx_batch_info bi;                                              // the same batch as one unsharded handle would choose
   cur = g->hs[0];
   GCHK(g, sgd_resolve_batch(cur, cur->slots[slot], opts_in, &bi));
@@ -730,7 +746,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     stats->max_feature_count = h0->slots[slot].max_seg_count;
     stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
     stats->w0_chunk_used = opts.w0_chunk ? opts.w0_chunk : fmx_default_w0_chunk(h0->cfg.learn_rate, h0->cfg.task);
-    for (auto m : g->hs) stats->setup_seconds = std::max(stats->setup_seconds, m->setup_acc);
+    for (auto m : g->hs) { stats->setup_seconds = std::max(stats->setup_seconds, m->setup_acc); stats->status |= m->run_status; }
     for (uint64_t b = 0; b < n_timed; b++) {
       float a = 0, x = 0, u = 0;
       HIPCHK(h0, hipEventElapsedTime(&a, h0->ev_pool[4 * b], h0->ev_pool[4 * b + 1]));
@@ -767,7 +783,7 @@ int fmx_group_predict(fmx_group g, int slot, double* out) {
   for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, ensure_xbuf(cur, (size_t)tmp.size() * kp1)); }
   float* d_y = nullptr;
   HIPCHK(h0, hipSetDevice(h0->device));
-  HIPCHK(h0, hipMalloc(&d_y, tmp.size() * sizeof(float)));
+  HIPCHK(h0, fmx_dev_alloc(&d_y, tmp.size() * sizeof(float)));
   int rc = FMX_OK;
   for (uint64_t r0 = 0; r0 < n_rows && rc == FMX_OK; r0 += chunk) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(chunk, n_rows - r0);
@@ -780,7 +796,7 @@ int fmx_group_predict(fmx_group g, int slot, double* out) {
     if (rc == FMX_OK) for (uint32_t r = 0; r < nb; r++) out[r0 + r] = (double)tmp[r];
   }
   hipSetDevice(h0->device);
-  hipFree(d_y);
+  fmx_dev_free(d_y);
   if (rc) { g->err = fmx_last_error(cur); return rc; }
   return FMX_OK;
 }

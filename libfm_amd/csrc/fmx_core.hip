@@ -66,17 +66,17 @@ uint32_t resident_grid(fmx_handle h, const void* kernel, uint64_t n_waves_wanted
 }
 int ensure_scratch(fmx_handle h, size_t batch_cap, size_t rest_cap) {
   if (batch_cap > h->cap) {
-    if (h->partial) hipFree(h->partial);
-    if (h->mult) hipFree(h->mult);
+    if (h->partial) fmx_dev_free(h->partial);
+    if (h->mult) fmx_dev_free(h->mult);
     h->partial = nullptr; h->mult = nullptr; h->cap = 0;
-    HIPCHK(h, hipMalloc(&h->partial, batch_cap * (size_t)(h->KP + 1) * sizeof(float)));
-    HIPCHK(h, hipMalloc(&h->mult, batch_cap * sizeof(float)));
+    HIPCHK(h, fmx_dev_alloc(&h->partial, batch_cap * (size_t)(h->KP + 1) * sizeof(float)));
+    HIPCHK(h, fmx_dev_alloc(&h->mult, batch_cap * sizeof(float)));
     h->cap = batch_cap;
   }
   if (rest_cap > h->cap_rest) {
-    if (h->rest) hipFree(h->rest);
+    if (h->rest) fmx_dev_free(h->rest);
     h->rest = nullptr; h->cap_rest = 0;
-    HIPCHK(h, hipMalloc(&h->rest, rest_cap * sizeof(float)));
+    HIPCHK(h, fmx_dev_alloc(&h->rest, rest_cap * sizeof(float)));
     h->cap_rest = rest_cap;
   }
   return FMX_OK;
@@ -99,13 +99,16 @@ int slot_in_session(fmx_handle h, int slot, const char* what) {
 }
 
 void free_segments(Slot& s) {
-  if (s.t_ent) hipFree(s.t_ent);
-  if (s.seg_feat) hipFree(s.seg_feat);
-  if (s.seg_rel) hipFree(s.seg_rel);
-  if (s.cmask) hipFree(s.cmask);
-  if (s.cseg) hipFree(s.cseg);
-  if (s.cdesc) hipFree(s.cdesc);
-  s.cdesc = nullptr;
+  if (s.t_ent) fmx_dev_free(s.t_ent);
+  if (s.seg_feat) fmx_dev_free(s.seg_feat);
+  if (s.seg_rel) fmx_dev_free(s.seg_rel);
+  if (s.cmask) fmx_dev_free(s.cmask);
+  if (s.cseg) fmx_dev_free(s.cseg);
+  if (s.cdesc) fmx_dev_free(s.cdesc);
+  if (s.d_batch_seg) fmx_dev_free(s.d_batch_seg);
+  if (s.d_cbatch) fmx_dev_free(s.d_cbatch);
+  if (s.d_batch_base) fmx_dev_free(s.d_batch_base);
+  s.cdesc = nullptr; s.d_batch_seg = nullptr; s.d_cbatch = nullptr; s.d_batch_base = nullptr;
   s.t_ent = nullptr; s.seg_feat = nullptr; s.seg_rel = nullptr; s.seg_B = 0; s.nseg = 0;
   s.cmask = nullptr; s.cseg = nullptr; s.ncseg = 0; s.fused_cap = 0;
   s.batch_seg.clear(); s.batch_base.clear(); s.cbatch.clear();
@@ -114,10 +117,10 @@ void free_segments(Slot& s) {
 void free_block(BlockRows* b) {
   if (!b) return;
   free_slot(b->rows);
-  if (b->map) hipFree(b->map);
-  if (b->brow_ptr) hipFree(b->brow_ptr);
-  if (b->brow_list) hipFree(b->brow_list);
-  if (b->pbuf) hipFree(b->pbuf);
+  if (b->map) fmx_dev_free(b->map);
+  if (b->brow_ptr) fmx_dev_free(b->brow_ptr);
+  if (b->brow_list) fmx_dev_free(b->brow_list);
+  if (b->pbuf) fmx_dev_free(b->pbuf);
   delete b;
 }
 
@@ -125,11 +128,11 @@ void free_slot(Slot& s) {
   for (BlockRows* b : s.blocks) free_block(b);
   s.blocks.clear();
   free_segments(s);
-  if (s.ent) hipFree(s.ent);
-  if (s.row_ptr) hipFree(s.row_ptr);
-  if (s.target) hipFree(s.target);
-  if (s.wside) hipFree(s.wside);
-  if (s.lmask) hipFree(s.lmask);
+  if (s.ent) fmx_dev_free(s.ent);
+  if (s.row_ptr) fmx_dev_free(s.row_ptr);
+  if (s.target) fmx_dev_free(s.target);
+  if (s.wside) fmx_dev_free(s.wside);
+  if (s.lmask) fmx_dev_free(s.lmask);
   s = Slot();
 }
 
@@ -143,9 +146,9 @@ int ensure_wside(fmx_handle h, Slot& s) {
                ~Acc() { h->setup_acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{h, std::chrono::steady_clock::now()};
   const uint32_t M = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n_local, 1), 1ull << 27);
   uint32_t* last = nullptr;
-  hipError_t er = hipMalloc(&last, (size_t)M * 4);
-  if (er == hipSuccess) er = hipMalloc(&s.wside, (size_t)s.nnz * 4);
-  if (er == hipSuccess) er = hipMalloc(&s.lmask, (size_t)s.n_rows * 8);
+  hipError_t er = fmx_dev_alloc(&last, (size_t)M * 4);
+  if (er == hipSuccess) er = fmx_dev_alloc(&s.wside, (size_t)s.nnz * 4);
+  if (er == hipSuccess) er = fmx_dev_alloc(&s.lmask, (size_t)s.n_rows * 8);
   if (er == hipSuccess) er = hipMemsetAsync(last, 0, (size_t)M * 4, h->stream);
   if (er == hipSuccess) {
     hipLaunchKernelGGL(k_wside_last, dim3((unsigned)std::min<uint64_t>((s.nnz + 255) / 256, 8192)), dim3(256), 0, h->stream, s.ent, s.nnz, M, last);
@@ -154,14 +157,15 @@ int ensure_wside(fmx_handle h, Slot& s) {
     er = hipGetLastError();
   }
   if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
-  if (last) hipFree(last);
+  if (last) fmx_dev_free(last);
   if (er != hipSuccess) {
-    if (s.wside) hipFree(s.wside);
-    if (s.lmask) hipFree(s.lmask);
+    if (s.wside) fmx_dev_free(s.wside);
+    if (s.lmask) fmx_dev_free(s.lmask);
     s.wside = nullptr; s.lmask = nullptr;
     return fail(h, FMX_E_HIP, "weight side stream of the slot: %s", hipGetErrorString(er));
   }
   s.wside_version = 0;
+  if (getenv("FMX_TRACE_SETUP")) fprintf(stderr, "[fmx setup] weight side stream %8.3f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - acc_.t0).count());
   return FMX_OK;
 }
 
@@ -211,7 +215,7 @@ int ensure_coll_mass(fmx_handle h, Slot& s) {
   HIPCHK(h, hipSetDevice(h->device));
   const uint32_t M = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n_local, 1), 1ull << 27);
   double* hist = nullptr;
-  HIPCHK(h, hipMalloc(&hist, (size_t)M * sizeof(double)));
+  HIPCHK(h, fmx_dev_alloc(&hist, (size_t)M * sizeof(double)));
   hipError_t er = hipMemsetAsync(hist, 0, (size_t)M * sizeof(double), h->stream);
   if (er == hipSuccess) er = hipMemsetAsync(h->acc, 0, 2 * sizeof(double), h->stream);
   if (er == hipSuccess) {
@@ -223,12 +227,13 @@ int ensure_coll_mass(fmx_handle h, Slot& s) {
   double c[2] = {0.0, 0.0};
   if (er == hipSuccess) er = hipMemcpyAsync(c, h->acc, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
-  hipFree(hist);
+  fmx_dev_free(hist);
   if (er != hipSuccess) return fail(h, FMX_E_HIP, "collision mass of the rows: %s", hipGetErrorString(er));
   // pairs of DIFFERENT rows: what a row shares with itself (sum of x^2 over its entries) is taken out.  On a feature shard this is
   // the shard's share of the numerator over the same N (N - 1): the shares add up.
   const double N = (double)s.n_rows;
   s.coll_mass = (s.n_rows > 1) ? std::max(0.0, c[0] - c[1]) / (N * (N - 1.0)) : 0.0;
+  if (getenv("FMX_TRACE_SETUP")) fprintf(stderr, "[fmx setup] collision mass     %8.3f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - acc_.t0).count());
   return FMX_OK;
 }
 
@@ -540,6 +545,111 @@ extern "C" {
 
 int fmx_abi_version(void) { return FMX_ABI_VERSION; }
 
+
+// ---- device allocations (fmx_internal.h: fmx_dev_alloc / fmx_dev_free) -----------------------------------------------------------
+namespace {
+struct BigAlloc { size_t reserved = 0; int device = 0; std::vector<hipMemGenericAllocationHandle_t> hnd; std::vector<size_t> sz; };
+std::mutex g_big_mu;
+std::unordered_map<void*, BigAlloc> g_big;
+constexpr size_t BIG_MIN = (size_t)768 << 20, BIG_CHUNK = (size_t)1 << 30, BIG_ALIGN = (size_t)2 << 20;
+bool big_alloc_on() { static const bool on = []() { const char* e = getenv("FMX_BIG_ALLOC"); return !(e && e[0] == '0'); }(); return on; }
+
+hipError_t plain_alloc(void** p, size_t bytes) {          // hipMalloc; out of memory: the idle arena cache of the device goes back, once
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess) { arena_cache_drop(d); e = hipMalloc(p, bytes); }
+  }
+  return e;
+}
+void big_release(void* va, BigAlloc& b) {
+  size_t off = 0;
+  for (size_t i = 0; i < b.hnd.size(); i++) { (void)hipMemUnmap((char*)va + off, b.sz[i]); (void)hipMemRelease(b.hnd[i]); off += b.sz[i]; }
+  if (va) (void)hipMemAddressFree(va, b.reserved);
+}
+// one virtual range backed by physical chunks of at most 1 GiB; false: nothing is left behind and the caller takes hipMalloc
+bool big_alloc(void** p, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+  BigAlloc b; b.device = dev;
+  b.reserved = (bytes + BIG_ALIGN - 1) / BIG_ALIGN * BIG_ALIGN;
+  void* va = nullptr;
+  static const bool trace = getenv("FMX_TRACE_ALLOC") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&]() { return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  if (hipMemAddressReserve(&va, b.reserved, BIG_ALIGN, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const double t_res = ms();
+  bool ok = true;
+  for (size_t off = 0; off < b.reserved && ok; off += BIG_CHUNK) {
+    const size_t sz = std::min(BIG_CHUNK, b.reserved - off);
+    hipMemGenericAllocationHandle_t hd;
+    if (hipMemCreate(&hd, sz, &prop, 0) != hipSuccess) { ok = false; break; }
+    if (hipMemMap((char*)va + off, sz, 0, hd, 0) != hipSuccess) { (void)hipMemRelease(hd); ok = false; break; }
+    b.hnd.push_back(hd); b.sz.push_back(sz);
+  }
+  const double t_map = ms();
+  if (ok) {
+    // read / write for the owning device and -- where the runtime grants it -- for its peers (fmx_group_upload_rows copies staged rows
+    // between devices); a peer the runtime refuses is not an error here
+    int ndev = 0; (void)hipGetDeviceCount(&ndev);
+    hipMemAccessDesc acc = {}; acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+    ok = hipMemSetAccess(va, b.reserved, &acc, 1) == hipSuccess;
+    for (int d = 0; ok && d < ndev; d++) {
+      if (d == dev) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, d, dev) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+      acc.location.id = d;
+      if (hipMemSetAccess(va, b.reserved, &acc, 1) != hipSuccess) (void)hipGetLastError();
+    }
+  }
+  if (trace) fprintf(stderr, "[fmx alloc] big %zu bytes: reserve %.3f ms, create+map %.3f ms, access %.3f ms\n", bytes, t_res, t_map - t_res, ms() - t_map);
+  if (!ok) { (void)hipGetLastError(); big_release(va, b); return false; }
+  { std::lock_guard<std::mutex> lk(g_big_mu); g_big.emplace(va, std::move(b)); }
+  *p = va;
+  return true;
+}
+}  // namespace
+
+static hipError_t dev_alloc_untraced(void** p, size_t bytes);
+extern "C++" hipError_t fmx_dev_alloc_bytes(void** p, size_t bytes) {
+  static const bool trace = getenv("FMX_TRACE_ALLOC") != nullptr;
+  if (!trace) return dev_alloc_untraced(p, bytes);
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = dev_alloc_untraced(p, bytes);
+  const double ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (ms > 0.5) fprintf(stderr, "[fmx alloc] %12zu bytes %9.3f ms%s\n", bytes, ms, e == hipSuccess ? "" : " FAILED");
+  return e;
+}
+static hipError_t dev_alloc_untraced(void** p, size_t bytes) {
+  if (!p) return hipErrorInvalidValue;
+  *p = nullptr;
+  if (bytes >= BIG_MIN && big_alloc_on()) {
+    if (big_alloc(p, bytes)) return hipSuccess;
+    int d = 0;                                               // (out of memory next to an idle cached arena? give it back and try once more)
+    if (hipGetDevice(&d) == hipSuccess) { arena_cache_drop(d); if (big_alloc(p, bytes)) return hipSuccess; }
+  }
+  return plain_alloc(p, bytes);
+}
+extern "C++" hipError_t fmx_dev_free(void* p) {
+  if (!p) return hipSuccess;
+  BigAlloc b; bool big = false;
+  {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    auto it = g_big.find(p);
+    if (it != g_big.end()) { b = std::move(it->second); g_big.erase(it); big = true; }
+  }
+  if (!big) return hipFree(p);
+  int cur = 0; (void)hipGetDevice(&cur);
+  if (cur != b.device) (void)hipSetDevice(b.device);
+  (void)hipDeviceSynchronize();                              // (hipFree waits for the device's work too: nothing may still read the range)
+  big_release(p, b);
+  if (cur != b.device) (void)hipSetDevice(cur);
+  return hipSuccess;
+}
+
 int fmx_release_cached_memory(void) { arena_cache_drop(-1); return FMX_OK; }
 
 int fmx_device_count(void) {
@@ -563,6 +673,8 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     return fail(nullptr, FMX_E_ARG, "bad shard_rank/shard_world");
   if (cfg->shard_hash != 0 && cfg->shard_hash != 1) return fail(nullptr, FMX_E_ARG, "shard_hash must be 0 or 1");
   if (cfg->place_candidates < 0 || cfg->place_candidates > 6) return fail(nullptr, FMX_E_ARG, "place_candidates must be 0 (default) .. 6");
+  if (cfg->exchange_algo != FMX_EXCHANGE_ALLREDUCE && cfg->exchange_algo != FMX_EXCHANGE_RS_AG)
+    return fail(nullptr, FMX_E_ARG, "exchange_algo %u: FMX_EXCHANGE_ALLREDUCE (0) or FMX_EXCHANGE_RS_AG (1)", cfg->exchange_algo);
   if ((uint64_t)cfg->shard_world > cfg->num_attribute) return fail(nullptr, FMX_E_ARG, "more feature shards than features");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -611,7 +723,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
       int n_cand = 0, best = 0;
       hipError_t er = hipSuccess;
       for (int c = 0; c < tries && er == hipSuccess; c++) {
-        if (hipMalloc(&cand[c], bytes) != hipSuccess) { (void)hipGetLastError(); cand[c] = nullptr; break; }
+        if (plain_alloc((void**)&cand[c], bytes) != hipSuccess) { (void)hipGetLastError(); cand[c] = nullptr; break; }
         n_cand = c + 1;
         er = hipMemsetAsync(cand[c], 0, bytes, h->stream);   // (also: a never-written allocation answers the probe in 30 us)
         if (tries == 1 || er != hipSuccess) break;
@@ -636,11 +748,11 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
       }
       if (er == hipSuccess && !cand[0]) {                                    // out of memory: whatever the arena cache holds goes back first
         arena_cache_drop(h->device);
-        er = hipMalloc(&cand[0], bytes);                                     // (reports the allocation failure)
+        er = plain_alloc((void**)&cand[0], bytes);                                   // (reports the allocation failure)
         if (er == hipSuccess) er = hipMemsetAsync(cand[0], 0, bytes, h->stream);
       }
       (void)what;
-      for (int c = 0; c < MAXC; c++) if ((c != best || er != hipSuccess) && cand[c]) { hipFree(cand[c]); cand[c] = nullptr; }
+      for (int c = 0; c < MAXC; c++) if ((c != best || er != hipSuccess) && cand[c]) { fmx_dev_free(cand[c]); cand[c] = nullptr; }
       *out = cand[best];
       return er;
     };
@@ -661,19 +773,21 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     }
     h->tb.w = h->w_sep; h->tb.ws = 1;
   }
-  CREATE_CHK(hipMalloc(&h->w0, sizeof(double)));
-  CREATE_CHK(hipMalloc(&h->w0_pp, 8 * sizeof(double)));
+  CREATE_CHK(fmx_dev_alloc(&h->w0, sizeof(double)));
+  CREATE_CHK(fmx_dev_alloc(&h->w0_pp, 8 * sizeof(double)));
   {  // device-side hand-off of the bias (fmx_sgd.hip: sgd_epoch_fused): a counter + an error word, both start at 0
-    CREATE_CHK(hipMalloc(&h->handoff_ctr, 2 * sizeof(unsigned long long)));
+    CREATE_CHK(fmx_dev_alloc(&h->handoff_ctr, 2 * sizeof(unsigned long long)));
     h->handoff_err = reinterpret_cast<uint32_t*>(h->handoff_ctr + 1);
     CREATE_CHK(hipMemsetAsync(h->handoff_ctr, 0, 2 * sizeof(unsigned long long), h->stream));
     const char* e = getenv("FMX_HANDOFF");
     h->handoff = !(e && e[0] == '0');
-    CREATE_CHK(hipMalloc(&h->pit_ctr, (PIT_MAX_IT + 1) * sizeof(unsigned long long)));
-    CREATE_CHK(hipMalloc(&h->pit_slots, (size_t)2 * PIT_MAX_WG * 4 * sizeof(double)));
+    CREATE_CHK(fmx_dev_alloc(&h->pit_ctr, (PIT_MAX_IT + 1) * sizeof(unsigned long long)));
+    CREATE_CHK(fmx_dev_alloc(&h->pit_slots, (size_t)2 * PIT_MAX_WG * 4 * sizeof(double)));
     CREATE_CHK(hipMemsetAsync(h->pit_slots, 0, (size_t)2 * PIT_MAX_WG * 4 * sizeof(double), h->stream));
     const char* sc = getenv("FMX_SCAN");
     h->scan_pit = !(sc && strcmp(sc, "serial") == 0);
+    const char* sp = getenv("FMX_DEBUG_PIT_SPINS");
+    h->pit_spins = sp ? (uint32_t)strtoul(sp, nullptr, 10) : HANDOFF_SPINS;
   }
   {  // the side stream runs the one-workgroup bias recurrence next to chip-filling gathers: give it priority so
      // that its workgroup is placed as soon as any CU has room
@@ -682,7 +796,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     CREATE_CHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
   }
   h->num_cu = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
-  CREATE_CHK(hipMalloc(&h->acc, 4 * sizeof(double)));
+  CREATE_CHK(fmx_dev_alloc(&h->acc, 4 * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->w0, 0, sizeof(double), h->stream));
   CREATE_CHK(hipStreamSynchronize(h->stream));
 #undef CREATE_CHK
@@ -728,20 +842,22 @@ int fmx_destroy(fmx_handle h) {
   als_free(h);
   sgda_free(h);
   for (auto& s : h->slots) free_slot(s);
-  if (h->grp) hipFree(h->grp);
+  if (h->grp) fmx_dev_free(h->grp);
   if (h->arena.va) arena_free(h);                              // (both tables are parts of it)
-  else { if (h->tb.V) hipFree(h->tb.V); if (h->w_sep) hipFree(h->w_sep); }
-  if (h->w0) hipFree(h->w0);
-  if (h->w0_pp) hipFree(h->w0_pp);
-  if (h->handoff_ctr) hipFree(h->handoff_ctr);
-  if (h->pit_ctr) hipFree(h->pit_ctr);
-  if (h->pit_slots) hipFree(h->pit_slots);
-  if (h->w0_slots) hipFree(h->w0_slots);
+  else { if (h->tb.V) fmx_dev_free(h->tb.V); if (h->w_sep) fmx_dev_free(h->w_sep); }
+  if (h->w0) fmx_dev_free(h->w0);
+  if (h->w0_pp) fmx_dev_free(h->w0_pp);
+  if (h->handoff_ctr) fmx_dev_free(h->handoff_ctr);
+  if (h->pit_ctr) fmx_dev_free(h->pit_ctr);
+  if (h->probe_flags) fmx_dev_free(h->probe_flags);
+  if (h->pit_tmp) fmx_dev_free(h->pit_tmp);
+  if (h->pit_slots) fmx_dev_free(h->pit_slots);
+  if (h->w0_slots) fmx_dev_free(h->w0_slots);
   if (h->stream2) hipStreamDestroy(h->stream2);
-  if (h->acc) hipFree(h->acc);
-  if (h->partial) hipFree(h->partial);
-  if (h->mult) hipFree(h->mult);
-  if (h->rest) hipFree(h->rest);
+  if (h->acc) fmx_dev_free(h->acc);
+  if (h->partial) fmx_dev_free(h->partial);
+  if (h->mult) fmx_dev_free(h->mult);
+  if (h->rest) fmx_dev_free(h->rest);
   for (auto ev : h->ev_pool) hipEventDestroy(ev);
   for (auto ev : h->ev_sync) hipEventDestroy(ev);
   if (h->lag.ev_rest) hipEventDestroy(h->lag.ev_rest);
@@ -790,7 +906,7 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
   }
   const uint32_t chunk = (uint32_t)std::min<uint64_t>(n, 1u << 18);
   double* stage = nullptr;
-  HIPCHK(h, hipMalloc(&stage, (size_t)chunk * (size_t)std::max(k, 1) * sizeof(double)));
+  HIPCHK(h, fmx_dev_alloc(&stage, (size_t)chunk * (size_t)std::max(k, 1) * sizeof(double)));
   int rc = FMX_OK;
 #define STAGE_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     rc = fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); goto done; } } while (0)
@@ -834,7 +950,7 @@ static int stage_params(fmx_handle h, bool to_device, double* w0, double* w, dou
   STAGE_CHK(hipStreamSynchronize(h->stream));
 done:
 #undef STAGE_CHK
-  hipFree(stage);
+  fmx_dev_free(stage);
   return rc;
 }
 
@@ -866,8 +982,8 @@ int fmx_get_param_rows(fmx_handle h, const uint32_t* ids, uint32_t count, double
   HIPCHK(h, hipSetDevice(h->device));
   uint32_t* d_ids = nullptr; double* d_out = nullptr;
   const size_t nout = (size_t)count * (size_t)(k + 1);
-  HIPCHK(h, hipMalloc(&d_ids, (size_t)count * 4));
-  HIPCHK(h, hipMalloc(&d_out, nout * sizeof(double)));
+  HIPCHK(h, fmx_dev_alloc(&d_ids, (size_t)count * 4));
+  HIPCHK(h, fmx_dev_alloc(&d_out, nout * sizeof(double)));
   hipError_t er = hipMemcpyAsync(d_ids, ids, (size_t)count * 4, hipMemcpyHostToDevice, h->stream);
   if (er == hipSuccess) {
     hipLaunchKernelGGL(k_fetch_rows, dim3((uint32_t)((nout + 255) / 256)), dim3(256), 0, h->stream, d_ids, count, k,
@@ -877,7 +993,7 @@ int fmx_get_param_rows(fmx_handle h, const uint32_t* ids, uint32_t count, double
   if (er == hipSuccess) er = hipMemcpyAsync(w_out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (er == hipSuccess && k > 0) er = hipMemcpyAsync(v_out, d_out + count, (size_t)count * k * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
-  hipFree(d_ids); hipFree(d_out);
+  fmx_dev_free(d_ids); fmx_dev_free(d_out);
   if (er != hipSuccess) return fail(h, FMX_E_HIP, "fmx_get_param_rows: %s", hipGetErrorString(er));
   return FMX_OK;
 }
@@ -1042,7 +1158,7 @@ int fmx_set_groups(fmx_handle h, const uint32_t* group_of_feature, uint32_t num_
   if (h->als.slot >= 0 || h->sgda.reg) return fail(h, FMX_E_STATE, "fmx_set_groups while an ALS / SGDA session is open");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->grp) { hipFree(h->grp); h->grp = nullptr; }
+  if (h->grp) { fmx_dev_free(h->grp); h->grp = nullptr; }
   h->num_groups = 1;
   if (!group_of_feature || num_groups <= 1) return FMX_OK;
   // the array is indexed by GLOBAL feature id ([num_attribute]); a shard keeps the entries of its own features
@@ -1054,7 +1170,7 @@ int fmx_set_groups(fmx_handle h, const uint32_t* group_of_feature, uint32_t num_
     if (local[jl] >= num_groups)
       return fail(h, FMX_E_ARG, "fmx_set_groups: feature %u has group %u >= num_groups %u", j, local[jl], num_groups);
   }
-  HIPCHK(h, hipMalloc(&h->grp, h->n_local * sizeof(uint32_t)));
+  HIPCHK(h, fmx_dev_alloc(&h->grp, h->n_local * sizeof(uint32_t)));
   HIPCHK(h, hipMemcpy(h->grp, local.data(), h->n_local * sizeof(uint32_t), hipMemcpyHostToDevice));
   h->num_groups = num_groups;
   return FMX_OK;
@@ -1109,15 +1225,15 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
   // page-locked, e.g. from fmx_read_binary) and check the ids on the host while it runs
   Slot s;
   if (W == 1) {
-    HIPCHK(h, hipMalloc(&s.ent, std::max<uint64_t>(nnz, 1) * sizeof(Entry)));
+    HIPCHK(h, fmx_dev_alloc(&s.ent, std::max<uint64_t>(nnz, 1) * sizeof(Entry)));
     if (nnz && hipMemcpyAsync(s.ent, src, nnz * sizeof(Entry), hipMemcpyHostToDevice, h->stream) != hipSuccess) {
-      hipFree(s.ent); return fail(h, FMX_E_HIP, "fmx_upload_rows: copy of the entries failed");
+      fmx_dev_free(s.ent); return fail(h, FMX_E_HIP, "fmx_upload_rows: copy of the entries failed");
     }
   }
   // bound check: the reference asserts id < num_attribute (fm_model.h:112)
   for (uint64_t i = 0; i < nnz; i++)
     if (src[i].id >= n) {
-      if (s.ent) { hipStreamSynchronize(h->stream); hipFree(s.ent); }
+      if (s.ent) { hipStreamSynchronize(h->stream); fmx_dev_free(s.ent); }
       return fail(h, FMX_E_ARG, "feature id %u >= num_attribute %llu (row entry %llu)", src[i].id,
                   (unsigned long long)n, (unsigned long long)i);
     }
@@ -1139,13 +1255,13 @@ int fmx_upload_rows(fmx_handle h, int slot, const void* entries, const uint64_t*
   }
   hipError_t er = hipSuccess;
   if (!s.ent) {
-    er = hipMalloc(&s.ent, std::max<uint64_t>(up_nnz, 1) * sizeof(Entry));
+    er = fmx_dev_alloc(&s.ent, std::max<uint64_t>(up_nnz, 1) * sizeof(Entry));
     if (er == hipSuccess && up_nnz) er = hipMemcpyAsync(s.ent, up_ent, up_nnz * sizeof(Entry), hipMemcpyHostToDevice, h->stream);
   }
-  if (er == hipSuccess) er = hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t));
+  if (er == hipSuccess) er = fmx_dev_alloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t));
   if (er == hipSuccess) er = hipMemcpyAsync(s.row_ptr, up_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
   if (er == hipSuccess && target) {
-    er = hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float));
+    er = fmx_dev_alloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float));
     if (er == hipSuccess && n_rows) er = hipMemcpyAsync(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice, h->stream);
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess && er == hipSuccess) er = hipGetLastError();   // the host buffers may go away after return
@@ -1175,17 +1291,17 @@ static int upload_blocks_kept(fmx_handle h, int slot, const void* entries, const
       for (uint32_t c = 0; c < n_rows; c++) list[fill[q.data_row_to_relation_row[c]]++] = c; }   // ascending main row inside a block row
     uint32_t max_row = 0;
     for (uint32_t i = 0; i < q.n_rows; i++) max_row = std::max<uint32_t>(max_row, (uint32_t)(q.row_ptr[i + 1] - q.row_ptr[i]));
-    hipError_t er = hipMalloc(&b->rows.ent, std::max<uint64_t>(q.nnz, 1) * sizeof(Entry));
+    hipError_t er = fmx_dev_alloc(&b->rows.ent, std::max<uint64_t>(q.nnz, 1) * sizeof(Entry));
     if (er == hipSuccess && q.nnz) er = hipMemcpy(b->rows.ent, q.entries, q.nnz * sizeof(Entry), hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMalloc(&b->rows.row_ptr, ((size_t)q.n_rows + 1) * sizeof(uint64_t));
+    if (er == hipSuccess) er = fmx_dev_alloc(&b->rows.row_ptr, ((size_t)q.n_rows + 1) * sizeof(uint64_t));
     if (er == hipSuccess) er = hipMemcpy(b->rows.row_ptr, q.row_ptr, ((size_t)q.n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMalloc(&b->map, std::max<uint32_t>(n_rows, 1) * sizeof(uint32_t));
+    if (er == hipSuccess) er = fmx_dev_alloc(&b->map, std::max<uint32_t>(n_rows, 1) * sizeof(uint32_t));
     if (er == hipSuccess && n_rows) er = hipMemcpy(b->map, q.data_row_to_relation_row, (size_t)n_rows * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMalloc(&b->brow_ptr, cnt.size() * sizeof(uint32_t));
+    if (er == hipSuccess) er = fmx_dev_alloc(&b->brow_ptr, cnt.size() * sizeof(uint32_t));
     if (er == hipSuccess) er = hipMemcpy(b->brow_ptr, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMalloc(&b->brow_list, list.size() * sizeof(uint32_t));
+    if (er == hipSuccess) er = fmx_dev_alloc(&b->brow_list, list.size() * sizeof(uint32_t));
     if (er == hipSuccess) er = hipMemcpy(b->brow_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMalloc(&b->pbuf, std::max<size_t>((size_t)q.n_rows, 1) * (size_t)(h->KP + 1) * sizeof(float));
+    if (er == hipSuccess) er = fmx_dev_alloc(&b->pbuf, std::max<size_t>((size_t)q.n_rows, 1) * (size_t)(h->KP + 1) * sizeof(float));
     if (er != hipSuccess) { free_slot(s); return fail(h, FMX_E_HIP, "fmx_upload_block_rows_ex: %s", hipGetErrorString(er)); }
     b->rows.n_rows = q.n_rows; b->rows.nnz = q.nnz; b->rows.max_row = max_row; b->rows.used = true;
   }
@@ -1254,14 +1370,14 @@ int fmx_upload_block_rows_ex(fmx_handle h, int slot, const void* entries, const 
   std::vector<void*> tmp;                                     // staging buffers, freed on every exit path
   auto up = [&](const void* p, size_t bytes) -> void* {
     void* d = nullptr;
-    if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+    if (fmx_dev_alloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
     tmp.push_back(d);
     if (bytes && hipMemcpy(d, p, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     return d;
   };
   Slot s;
   bool committed = false;
-  auto cleanup = [&]() { for (void* d : tmp) hipFree(d); if (!committed) free_slot(s); };
+  auto cleanup = [&]() { for (void* d : tmp) fmx_dev_free(d); if (!committed) free_slot(s); };
 #define BLK_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
 #define BLK_UP(dst, type, p, bytes) do { dst = (type)up((p), (bytes)); if (!dst) { cleanup(); return fail(h, FMX_E_HIP, "fmx_upload_block_rows: staging %s failed", #p); } } while (0)
   const Entry* d_ent; const uint64_t* d_ptr;
@@ -1278,15 +1394,15 @@ int fmx_upload_block_rows_ex(fmx_handle h, int slot, const void* entries, const 
     rels.r[r].attr_offset = (uint32_t)q.attr_offset;
   }
   uint64_t* sizes = nullptr;
-  BLK_CHK(hipMalloc(&sizes, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  BLK_CHK(fmx_dev_alloc(&sizes, ((size_t)n_rows + 1) * sizeof(uint64_t)));
   tmp.push_back(sizes);
-  BLK_CHK(hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  BLK_CHK(fmx_dev_alloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
   const dim3 g1(std::min<uint32_t>((n_rows + 256) / 256, 2048)), b1(256);
   hipLaunchKernelGGL(k_block_sizes, g1, b1, 0, h->stream, d_ptr, n_rows, rels, sizes);
   size_t scan_bytes = 0;
   BLK_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, sizes, s.row_ptr, (int)(n_rows + 1), h->stream));
   void* scan_tmp = nullptr;
-  BLK_CHK(hipMalloc(&scan_tmp, std::max<size_t>(scan_bytes, 8)));
+  BLK_CHK(fmx_dev_alloc(&scan_tmp, std::max<size_t>(scan_bytes, 8)));
   tmp.push_back(scan_tmp);
   BLK_CHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, sizes, s.row_ptr, (int)(n_rows + 1), h->stream));
   std::vector<uint64_t> hs((size_t)n_rows + 1);
@@ -1296,11 +1412,11 @@ int fmx_upload_block_rows_ex(fmx_handle h, int slot, const void* entries, const 
   BLK_CHK(hipStreamSynchronize(h->stream));
   uint32_t max_row = 0;
   for (uint32_t c = 0; c < n_rows; c++) max_row = std::max<uint32_t>(max_row, (uint32_t)hs[c]);
-  BLK_CHK(hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
+  BLK_CHK(fmx_dev_alloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
   hipLaunchKernelGGL(k_block_fill, g1, b1, 0, h->stream, d_ent, d_ptr, n_rows, rels, s.row_ptr, s.ent);
   BLK_CHK(hipGetLastError());
   if (target) {
-    BLK_CHK(hipMalloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float)));
+    BLK_CHK(fmx_dev_alloc(&s.target, std::max<uint32_t>(n_rows, 1) * sizeof(float)));
     if (n_rows) BLK_CHK(hipMemcpy(s.target, target, (size_t)n_rows * sizeof(float), hipMemcpyHostToDevice));
   }
   BLK_CHK(hipStreamSynchronize(h->stream));
@@ -1361,12 +1477,12 @@ int fmx_synth_rows_ex(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint
   void* tmp = nullptr;
   uint64_t total = 0;
   // every error path releases what was allocated so far
-#define SYN_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { if (cnt) hipFree(cnt); if (tmp) hipFree(tmp); free_slot(s); \
+#define SYN_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { if (cnt) fmx_dev_free(cnt); if (tmp) fmx_dev_free(tmp); free_slot(s); \
     return fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
-  SYN_CHK(hipMalloc(&cnt, ((size_t)n_rows + 1) * sizeof(uint32_t)));
+  SYN_CHK(fmx_dev_alloc(&cnt, ((size_t)n_rows + 1) * sizeof(uint32_t)));
   SYN_CHK(hipMemsetAsync(cnt, 0, ((size_t)n_rows + 1) * sizeof(uint32_t), h->stream));
-  SYN_CHK(hipMalloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
-  SYN_CHK(hipMalloc(&s.target, (size_t)n_rows * sizeof(float)));
+  SYN_CHK(fmx_dev_alloc(&s.row_ptr, ((size_t)n_rows + 1) * sizeof(uint64_t)));
+  SYN_CHK(fmx_dev_alloc(&s.target, (size_t)n_rows * sizeof(float)));
   const dim3 grid((n_rows + 255) / 256), block(256);
   hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, shape, sh, cnt,
                      (const uint64_t*)nullptr, (Entry*)nullptr, s.target);
@@ -1375,19 +1491,19 @@ int fmx_synth_rows_ex(fmx_handle h, int slot, uint64_t seed, uint64_t row0, uint
     size_t tmp_bytes = 0;
     auto conv = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, uint32_t*>(cnt, hipcub::CastOp<uint64_t>());
     SYN_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
-    SYN_CHK(hipMalloc(&tmp, tmp_bytes));
+    SYN_CHK(fmx_dev_alloc(&tmp, tmp_bytes));
     SYN_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, conv, s.row_ptr, (int)(n_rows + 1), h->stream));
     SYN_CHK(hipStreamSynchronize(h->stream));
-    hipFree(tmp); tmp = nullptr;
+    fmx_dev_free(tmp); tmp = nullptr;
   }
   SYN_CHK(hipMemcpy(&total, s.row_ptr + n_rows, sizeof(uint64_t), hipMemcpyDeviceToHost));
-  SYN_CHK(hipMalloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
+  SYN_CHK(fmx_dev_alloc(&s.ent, std::max<uint64_t>(total, 1) * sizeof(Entry)));
   hipLaunchKernelGGL(k_synth, grid, block, 0, h->stream, seed, row0, n_rows, nnz, fs, shape, sh, (uint32_t*)nullptr,
                      (const uint64_t*)s.row_ptr, s.ent, (float*)nullptr);
   SYN_CHK(hipGetLastError());
   SYN_CHK(hipStreamSynchronize(h->stream));
 #undef SYN_CHK
-  hipFree(cnt);
+  fmx_dev_free(cnt);
   s.n_rows = n_rows; s.nnz = total; s.max_row = nnz; s.used = true;
   s.fixed_nnz = (h->cfg.shard_world == 1) ? nnz : 0u;        // (a shard keeps a varying part of every row)
   h->slots[slot] = s;

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <random>
 #include <string>
 #include <unordered_map>
@@ -50,6 +51,9 @@ struct Slot {
   CDesc*    cdesc = nullptr;         // [ncseg] the same list as 32-byte records {feature, first entry, end entry, index, first two occurrences}
   uint32_t  fused_cap = 0;           // longest row the k_fused instance of this slot keeps in registers
   std::vector<uint32_t> cbatch;      // [n_batches+1] first cseg entry of every batch
+  uint32_t* d_batch_seg = nullptr;   // the three per-batch tables on the device (same contents as batch_seg / cbatch / batch_base)
+  uint32_t* d_cbatch = nullptr;
+  uint64_t* d_batch_base = nullptr;
   // weight side stream (fmx_kernels.h row_sums; FMX_FLAG_KEEP_WSIDE): wside[i] = w[id of entry i] or NaN, lmask[row] = which entries are
   // the last occurrence of their feature in the slot; current while wside_version == the handle's w_version
   float*    wside = nullptr;
@@ -162,6 +166,12 @@ struct fmx_context_s {
   unsigned long long* pit_ctr = nullptr;    // [PIT_MAX_IT + 1], zeroed on the launch's stream before every launch
   double*     pit_slots = nullptr;          // [2][PIT_MAX_WG][4]
   bool        pit_used = false;             // a launch since the error word was last read
+  uint32_t    run_status = 0;               // FMX_STAT_SCAN_* / _EVENT_SYNC / _HANDOFF_TIMEOUT of the running epoch (launch_scan, sgd_epoch_fused)
+  int         concurrent = -1;              // do the handle's two streams run concurrently? -1: not probed yet (streams_concurrent)
+  unsigned*   probe_flags = nullptr;        // device: 4 words of k_concurrency_probe
+  uint32_t    pit_spins = 0;                // bound of a grid-wide exchange's wait (fmx_create: HANDOFF_SPINS, or FMX_DEBUG_PIT_SPINS from the environment)
+  int         pit_occ = -1;                 // workgroups of k_scan_pit the device holds at once (occupancy x CUs); -1: not asked yet
+  double*     pit_tmp = nullptr;            // bias between the pieces of a batch longer than PIT_MAX_ROWS
   uint64_t    w_version = 1;                // bumped by every entry point that may change a linear weight (a slot's side stream is valid for ONE value)
   int        num_cu = 256;
   double*    acc = nullptr;      // 4 doubles of reduction scratch
@@ -213,6 +223,7 @@ int sgd_resolve_batch(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, fmx_batch
 int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st);   // fmx_sgd.hip
 int lag_flush(fmx_handle h);                                             // fmx_sgd.hip
 int scan_error_check(fmx_handle h);                                      // fmx_sgd.hip: the device's error word after k_scan_pit launches (streams drained)
+bool streams_concurrent(fmx_handle h);                                   // fmx_sgd.hip: probed once per handle
 void sgda_free(fmx_handle h);                                            // fmx_sgd.hip
 void als_free(fmx_handle h);                                             // fmx_als.hip
 enum { GROUP_SINGLE = 0, GROUP_LOOPBACK = 1, GROUP_RCCL = 2 };
@@ -230,20 +241,18 @@ void comm_free(fmx_handle h);                                            // fmx_
 int comm_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats);   // fmx_comm.hip
 int comm_sum_double(fmx_handle h, double* v);                            // fmx_comm.hip
 
-// Device allocations of the library go through this: one classified arena per device outlives its handle (fmx_core.hip, "arena cache") and
-// can hold tens of GB that nothing uses; an allocation that runs out of memory gives that cache back and tries once more (round-4 advisor:
-// slot uploads, scratch, ALS state, the weight side stream, the collision histogram all failed with OOM next to the idle cache).
+// Device allocations of the library go through fmx_dev_alloc / fmx_dev_free (fmx_core.hip), never through hipMalloc directly:
+//   * one classified arena per device outlives its handle (fmx_core.hip, "arena cache") and can hold tens of GB that nothing uses; an
+//     allocation that runs out of memory gives that cache back and tries once more (round-4 advisor);
+//   * allocations of 768 MiB and more are built from <= 1 GiB physical chunks through the virtual-memory API (hipMemCreate + hipMemMap):
+//     once a process has taken and returned a pool of chunks (what the table placement of fmx_create does), a plain hipMalloc of more
+//     than 1 GiB takes 0.5 - 1.6 SECONDS on this part (scripts/ubench/alloc_cost.hip, profiles/r06_alloc_cost.txt: 4 GiB 1566 ms, through
+//     the virtual-memory API 0.05 ms) -- that was 96 % of the 1.3 - 2.5 s of one-time slot preparation the round-5 verdict found.
+// fmx_dev_free takes either kind (and nullptr).
 void arena_cache_drop(int device);                                       // fmx_core.hip
-inline hipError_t fmx_malloc_retry(void** p, size_t bytes) {
-  hipError_t e = hipMalloc(p, bytes);
-  if (e == hipErrorOutOfMemory) {
-    (void)hipGetLastError();
-    int d = 0;
-    if (hipGetDevice(&d) == hipSuccess) { arena_cache_drop(d); e = hipMalloc(p, bytes); }
-  }
-  return e;
-}
-#define hipMalloc(p, n) fmx_malloc_retry((void**)(p), (size_t)(n))
+hipError_t fmx_dev_alloc_bytes(void** p, size_t bytes);                  // fmx_core.hip
+hipError_t fmx_dev_free(void* p);                                        // fmx_core.hip
+template <class T> inline hipError_t fmx_dev_alloc(T** p, size_t bytes) { return fmx_dev_alloc_bytes(reinterpret_cast<void**>(p), bytes); }
 
 #define HIPCHK(h, expr)                                                                         \
   do {                                                                                          \

@@ -283,9 +283,11 @@ constexpr uint32_t HANDOFF_SPINS = 1u << 21;                           // x ~1 u
 __device__ __forceinline__ unsigned long long handoff_peek(const double* p) {
   return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double handoff_wait(const double* p, unsigned long long u, uint32_t* err) {
+// *timed_out: the slot never arrived (bounded wait): the error word gets bit 1 and the CALLER takes no step with it (k_fused: multiplier 0
+// for the example -- the parameters stay valid numbers, the epoch reports FMX_STAT_HANDOFF_TIMEOUT and the handle falls back to events)
+__device__ __forceinline__ double handoff_wait(const double* p, unsigned long long u, uint32_t* err, bool* timed_out) {
   for (uint32_t t = 0; u == W0_PENDING && t < HANDOFF_SPINS; t++) { __builtin_amdgcn_s_sleep(16); u = handoff_peek(p); }
-  if (u == W0_PENDING) { atomicOr(err, 1u); u = 0ull; }
+  if (u == W0_PENDING) { atomicOr(err, 1u); u = 0ull; *timed_out = true; }
   return __longlong_as_double((long long)u);
 }
 __device__ __forceinline__ void handoff_publish(double* p, double v) {
@@ -293,15 +295,35 @@ __device__ __forceinline__ void handoff_publish(double* p, double v) {
 }
 // counter side: the waiter is ONE thread of the recurrence workgroup (the others sit at the barrier behind it)
 struct Handoff { const unsigned long long* ctr; unsigned long long need; uint32_t* err; };
-__device__ __forceinline__ void handoff_wait_counter(const Handoff hw) {
-  if (!hw.ctr) return;
+// returns false when the counter never arrived (bounded wait; error bit 2): rest[] of the batch may be incomplete then, and the caller
+// must NOT evaluate the recurrence on it -- it hands the incoming bias on unchanged (handoff_pass_on) so that nothing downstream waits
+__device__ __forceinline__ bool handoff_wait_counter(const Handoff hw) {
+  if (!hw.ctr) return true;
+  __shared__ uint32_t s_handoff_ok;
   if (threadIdx.x == 0) {
     unsigned long long c = __hip_atomic_load(hw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t t = 0; c < hw.need && t < HANDOFF_SPINS * 4u; t++) { __builtin_amdgcn_s_sleep(32); c = __hip_atomic_load(hw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     if (c < hw.need) atomicOr(hw.err, 2u);
+    s_handoff_ok = (c >= hw.need) ? 1u : 0u;
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // what the launch stream wrote before the counter moved
+  return s_handoff_ok != 0u;
+}
+// the recurrence of a batch whose hand-off timed out: the bias goes on as it came (one thread of the first workgroup)
+__device__ __forceinline__ void handoff_pass_on(const double* w0_in, double* w0_out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) handoff_publish(w0_out, *w0_in);
+}
+// Do two kernels on two streams of this process run CONCURRENTLY right now?  Each sets its own flag and waits (bounded, ~20 ms) for the
+// other's: both succeed only when both are resident at the same time.  Under a profiler that serialises dispatches (rocprofv3 --pmc),
+// AMD_SERIALIZE_KERNEL or a partitioned device one of them runs into its bound -- then the device-side hand-off (whose waits are satisfied
+// by LATER launches) must not be used and the streams are ordered by events.  flags[0 / 1]: "I am here", flags[2 / 3]: result (1 = met).
+static __global__ void k_concurrency_probe(unsigned* flags, unsigned me) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __hip_atomic_store(flags + me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned other = 0;
+  for (uint32_t t = 0; t < 20000u && !other; t++) { __builtin_amdgcn_s_sleep(16); other = __hip_atomic_load(flags + (me ^ 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __hip_atomic_store(flags + 2u + me, other ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 static __global__ void k_handoff_signal(unsigned long long* ctr, unsigned long long val) {
   if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(ctr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -731,7 +753,7 @@ k_scan(const float* __restrict__ rest, const float* __restrict__ target, uint32_
        Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult, const Handoff hw) {
   __shared__ float s_rest[2][SCAN_TILE];
   __shared__ float s_y[2][SCAN_TILE];
-  handoff_wait_counter(hw);
+  if (!handoff_wait_counter(hw)) { handoff_pass_on(w0_in, w0_out); return; }
   // as the youngest wavefront on its SIMD it would only get leftover issue slots: raise the priority
   __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = threadIdx.x;
@@ -810,7 +832,7 @@ __global__ void __launch_bounds__(256)
 k_scan1(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n_rows, uint32_t chunk,
         Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, float* __restrict__ mult, const Handoff hw) {
   extern __shared__ float scan_lds[];
-  handoff_wait_counter(hw);                                        // (device hand-off: resident and polling until its batch's rest[] is complete)
+  if (!handoff_wait_counter(hw)) { handoff_pass_on(w0_in, w0_out); return; }   // (device hand-off: resident and polling until its batch's rest[] is complete)
   __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1009,7 +1031,8 @@ constexpr float    PIT_TOL = 5e-4f;                                   // the pat
 // LDS: {rest, y} of the segment + per chunk {path offset, map a, map b}: 8192 x 8 + 4096 x 12 (chunk >= 2) or 4096 x 8 + 4096 x 12 (chunk 1)
 constexpr size_t   PIT_LDS_BYTES = (size_t)(2 * PIT_SEG + 3 * (PIT_SEG / 2)) * sizeof(float);
 __host__ __device__ __forceinline__ uint32_t pit_seg(uint32_t chunk) { return chunk == 1u ? PIT_SEG / 2 : PIT_SEG; }
-struct PitSync { unsigned long long* ctr; double* slots; uint32_t* err; };   // ctr[PIT_MAX_IT + 1] zeroed before the launch; slots[2][PIT_MAX_WG][4]
+struct PitSync { unsigned long long* ctr; double* slots; uint32_t* err; uint32_t spins; };   // ctr[PIT_MAX_IT + 1] zeroed before the launch ([PIT_MAX_IT]: who took the serial
+                                                                     // fall-back); slots[2][PIT_MAX_WG][4]; spins: bound of an exchange's wait (HANDOFF_SPINS; tests shorten it)
 struct AMap { float a, b; };                                          // x -> a x + b
 __device__ __forceinline__ AMap amap_after(const AMap first, const AMap then) { return AMap{then.a * first.a, fmaf(then.a, first.b, then.b)}; }
 // max that does NOT drop a NaN (fmaxf does): a path that left the numbers must read as "not converged", never as "no change"
@@ -1051,7 +1074,8 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
   __shared__ float s_map[4][2];                                       // the wavefronts' composite maps
   __shared__ float s_chg[4];
   __shared__ double s_bcast[4];                                       // [0] incoming value of the workgroup, [1] value after the last one, [2] largest change
-  handoff_wait_counter(hw);                                           // (device hand-off: resident and polling until its batch's rest[] is complete)
+  __shared__ uint32_t s_abort;                                        // an exchange ran into its bound (or another workgroup's did)
+  if (!handoff_wait_counter(hw)) { handoff_pass_on(w0_in, w0_out); return; }   // (device hand-off: resident and polling until its batch's rest[] is complete)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t g = blockIdx.x, nwg = gridDim.x;
@@ -1143,7 +1167,9 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
     }
   };
   float my_chg = 3.0e38f;                                             // largest change of this workgroup's last path update (nothing yet)
-  bool converged = false;
+  bool converged = false, aborted = false;
+  unsigned long long* const claim = ps.ctr + PIT_MAX_IT;               // zeroed with the arrival counters before every launch
+  if (threadIdx.x == 0) s_abort = 0u;
   double x_end = 0.0;
   for (uint32_t it = 0; it < PIT_MAX_IT; it++) {
     eval_all();
@@ -1174,13 +1200,23 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
       if (it == 0) wc = my_chg;
       __hip_atomic_store(slot + 4 * g + 2, (double)wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (nwg > 1) {
+        // every workgroup of the grid must be RESIDENT for this to complete (the host gates the launch on the occupancy of the device,
+        // launch_scan); if one never arrives all the same -- the chip is shared with launches the host cannot see -- the wait is bounded, the
+        // error word gets bit 4, and ONE of the workgroups that are here evaluates the chain serially (below): the batch's bias is still
+        // the rule's, the epoch reports FMX_STAT_SCAN_FALLBACK and the handle stops using this kernel
         __hip_atomic_fetch_add(ps.ctr + it, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long cnt = __hip_atomic_load(ps.ctr + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t t = 0; cnt < (unsigned long long)nwg && t < HANDOFF_SPINS; t++) { __builtin_amdgcn_s_sleep(1); cnt = __hip_atomic_load(ps.ctr + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        if (cnt < (unsigned long long)nwg) atomicOr(ps.err, 4u);       // (a workgroup never arrived: flagged, the epoch fails instead of hanging)
+        bool gone = false;
+        for (uint32_t t = 0; cnt < (unsigned long long)nwg && t < ps.spins && !gone; t++) {
+          __builtin_amdgcn_s_sleep(1);
+          cnt = __hip_atomic_load(ps.ctr + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((t & 255u) == 255u) gone = __hip_atomic_load(claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;   // somebody gave up already
+        }
+        if (cnt < (unsigned long long)nwg) { atomicOr(ps.err, 4u); s_abort = 1u; }
       }
     }
     __syncthreads();
+    if (s_abort) { aborted = true; break; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (wv == 0) {                                                    // lane j holds workgroup j's composite: an inclusive scan across the lanes
       double A = 1.0, B = 0.0, C = 0.0;
@@ -1216,8 +1252,15 @@ k_scan_pit(const float* __restrict__ rest, const float* __restrict__ target, uin
     if (lane == 0) s_chg[wv] = chg;
   }
   if (!converged) {
-    // Newton did not settle: the serial chain, by one wavefront of workgroup 0 straight from global memory (k_scan's arithmetic)
-    if (g != 0 || wv != 0) return;
+    // Newton did not settle: the serial chain, by one wavefront of workgroup 0 straight from global memory (k_scan's arithmetic) -- or an
+    // exchange timed out: by one wavefront of the first workgroup to claim it
+    bool owner = g == 0;
+    if (aborted) {
+      if (threadIdx.x == 0) s_abort = (atomicCAS(claim, 0ull, 1ull + g) == 0ull) ? 2u : 1u;
+      __syncthreads();
+      owner = s_abort == 2u;
+    }
+    if (!owner || wv != 0) return;
     double w = w0;
     for (uint32_t c0 = 0; c0 < n_rows; c0 += chunk) {
       const uint32_t nc = min(chunk, n_rows - c0);
@@ -1292,16 +1335,18 @@ struct TEntry { uint32_t e; float x; };     // (example index inside its batch, 
 // {multiplier, sums}: one dependent round trip and two 64-byte requests per segment more (97 % of the bench's deferred features are pairs)
 struct CDesc { uint32_t feat, a, b, loc; uint32_t e0; float x0; uint32_t e1; float x1; };
 
-// sort keys: (batch << 32) | feature id ; payload: (value bits << 32) | example-in-batch  (== TEntry in memory)
+// sort keys: (batch << fbits) | feature id, fbits = bits of the largest local feature id (the radix sort then runs over fbits + bits of the
+// batch count: 31 bits = 4 passes at the bench shape, where a 32-bit feature field took 5) ; payload: (value bits << 32) | example-in-batch
+// (== TEntry in memory)
 static __global__ void __launch_bounds__(256)
-k_seg_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint32_t B,
+k_seg_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint32_t B, uint32_t fbits,
            uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   for (uint32_t r = wave0; r < n_rows; r += nwaves) {
     const uint64_t a = row_ptr[r], b = row_ptr[r + 1];
-    const uint64_t hi = (uint64_t)(r / B) << 32;
+    const uint64_t hi = (uint64_t)(r / B) << fbits;
     const uint32_t eb = r % B;
     for (uint64_t i = a + lane; i < b; i += 64) {
       const Entry e = ent[i];
@@ -1318,23 +1363,25 @@ k_seg_heads(const uint64_t* __restrict__ keys, uint64_t nnz, uint32_t* __restric
 // pos = inclusive scan of flags (1-based segment number of every entry)
 static __global__ void __launch_bounds__(256)
 k_seg_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
-           uint64_t nnz, const uint64_t* __restrict__ row_ptr, uint32_t B,
+           uint64_t nnz, const uint64_t* __restrict__ row_ptr, uint32_t B, uint32_t fbits,
            uint32_t* __restrict__ seg_feat, uint32_t* __restrict__ seg_rel) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x)
     if (flags[i]) {
       const uint32_t s = pos[i] - 1;
       const uint64_t key = keys[i];
-      seg_feat[s] = (uint32_t)key;
-      seg_rel[s] = (uint32_t)(i - row_ptr[(uint64_t)(key >> 32) * B]);   // offset inside the batch's entries
+      seg_feat[s] = (uint32_t)(key & ((1ull << fbits) - 1ull));
+      seg_rel[s] = (uint32_t)(i - row_ptr[(uint64_t)(key >> fbits) * B]);   // offset inside the batch's entries
     }
 }
 static __global__ void __launch_bounds__(256)
-k_seg_batches(const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t nseg, const uint64_t* __restrict__ row_ptr,
-              uint32_t n_rows, uint32_t B, uint32_t n_batches, uint32_t* __restrict__ batch_seg) {
+k_seg_batches(const uint32_t* __restrict__ pos, uint64_t nnz, const uint64_t* __restrict__ row_ptr,
+              uint32_t n_rows, uint32_t B, uint32_t n_batches, uint32_t* __restrict__ batch_seg, uint64_t* __restrict__ batch_base) {
+  const uint32_t nseg = nnz ? pos[nnz - 1] : 0u;
   for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= n_batches; b += gridDim.x * blockDim.x) {
     const uint64_t r = min((uint64_t)b * B, (uint64_t)n_rows);
     const uint64_t p = row_ptr[r];
     batch_seg[b] = (p < nnz) ? pos[p] - 1 : nseg;
+    batch_base[b] = p;                                            // first entry of every batch (row_ptr sampled at multiples of B)
   }
 }
 
@@ -1342,14 +1389,16 @@ k_seg_batches(const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t nseg, con
 // contributions to the feature at once (a step of lr * count on it), which the caller should keep well below the
 // curvature bound (fmx_epoch_stats::max_feature_count).  head[s] = sorted position of the segment's first entry.
 static __global__ void __launch_bounds__(256)
-k_seg_head_pos(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t nseg, uint32_t* __restrict__ head) {
+k_seg_head_pos(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t* __restrict__ head) {
+  const uint32_t nseg = nnz ? pos[nnz - 1] : 0u;                   // (read on the device: the host learns the counts in ONE read-back, later)
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nnz; i += (uint64_t)gridDim.x * blockDim.x) {
     if (i == nnz) head[nseg] = (uint32_t)nnz;
     else if (flags[i]) head[pos[i] - 1] = (uint32_t)i;
   }
 }
 static __global__ void __launch_bounds__(256)
-k_seg_max_count(const uint32_t* __restrict__ head, uint32_t nseg, uint32_t* __restrict__ out) {
+k_seg_max_count(const uint32_t* __restrict__ head, const uint32_t* __restrict__ pos, uint64_t nnz, uint32_t* __restrict__ out) {
+  const uint32_t nseg = nnz ? pos[nnz - 1] : 0u;
   uint32_t m = 0;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) m = max(m, head[s + 1] - head[s]);
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
@@ -1391,15 +1440,19 @@ k_seg_slow_rows(const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint32_t 
 // row; for multi-occurrence features the bit of every occurrence is set in its row's mask (the row is searched for the
 // id: <= 64 entries, one-time cost).  keys / vals are the sorted (batch, feature) keys and {example, value} payloads.
 static __global__ void __launch_bounds__(256)
-k_seg_mark(const uint64_t* __restrict__ keys, const TEntry* __restrict__ vals, const uint32_t* __restrict__ head, uint32_t nseg,
-           const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t B, uint32_t cap,
+k_seg_mark(const uint64_t* __restrict__ keys, const TEntry* __restrict__ vals, const uint32_t* __restrict__ head, const uint32_t* __restrict__ pos, uint64_t nnz,
+           const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t B, uint32_t fbits, uint32_t cap, uint32_t long_rows,
            uint64_t* __restrict__ cmask, uint32_t* __restrict__ cflag) {
+  // long_rows == 0: no row of the slot exceeds the register path (max_row <= cap) -- a feature that occurs once is never deferred and the two
+  // random row_ptr reads per segment drop out (they were 17 GB of 64-byte sectors for the bench's 134 M segments: most of this kernel)
+  const uint32_t nseg = nnz ? pos[nnz - 1] : 0u;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
     const uint32_t a = head[s], b = head[s + 1];
-    const uint64_t key = keys[a];
-    const uint64_t rbase = (uint64_t)(key >> 32) * B;
-    const uint32_t feat = (uint32_t)key;
     bool coll = (b - a) > 1;
+    if (!coll && !long_rows) { cflag[s] = 0u; continue; }
+    const uint64_t key = keys[a];
+    const uint64_t rbase = (uint64_t)(key >> fbits) * B;
+    const uint32_t feat = (uint32_t)(key & ((1ull << fbits) - 1ull));
     if (!coll) {
       const uint64_t r = rbase + vals[a].e;
       coll = (uint32_t)(row_ptr[r + 1] - row_ptr[r]) > cap;
@@ -1422,12 +1475,12 @@ static __global__ void __launch_bounds__(256)
 k_seg_compact(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head, const uint32_t* __restrict__ cflag,
               const uint32_t* __restrict__ cpos, uint32_t nseg, const uint32_t* __restrict__ batch_seg, uint32_t* __restrict__ cseg,
               const uint32_t* __restrict__ seg_feat, const uint32_t* __restrict__ seg_rel, const uint64_t* __restrict__ row_ptr,
-              uint32_t n_rows, uint32_t B, CDesc* __restrict__ cdesc, const TEntry* __restrict__ vals) {
+              uint32_t n_rows, uint32_t B, uint32_t fbits, CDesc* __restrict__ cdesc, const TEntry* __restrict__ vals) {
   // cdesc: the listed segment as ONE record {feature, first entry, end entry (both relative to the batch's entries), batch-local index}:
   // the deferred pass reads the list as a coalesced 16-byte stream instead of an index followed by three dependent gathers
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x)
     if (cflag[s]) {
-      const uint32_t bt = (uint32_t)(keys[head[s]] >> 32);
+      const uint32_t bt = (uint32_t)(keys[head[s]] >> fbits);
       const uint32_t loc = s - batch_seg[bt];
       cseg[cpos[s]] = loc;
       const uint64_t r0 = (uint64_t)bt * B, r1 = min((uint64_t)(bt + 1) * B, (uint64_t)n_rows);
@@ -1440,6 +1493,16 @@ k_seg_compact(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ he
       if (end - d.a >= 2u) { const TEntry t1 = vals[h0 + 1]; d.e1 = t1.e; d.x1 = t1.x; }
       cdesc[cpos[s]] = d;
     }
+}
+// the three counts the host needs to size the slot's arrays, in one place: {segments, deferred segments, longest segment}
+static __global__ void k_seg_counts(const uint32_t* __restrict__ pos, uint64_t nnz, const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ cflag,
+                                    const uint32_t* __restrict__ max_count, uint32_t* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint32_t nseg = nnz ? pos[nnz - 1] : 0u;
+    out[0] = nseg;
+    out[1] = nseg ? cpos[nseg - 1] + cflag[nseg - 1] : 0u;
+    out[2] = *max_count;
+  }
 }
 static __global__ void __launch_bounds__(256)
 k_seg_cbatch(const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ cflag, uint32_t nseg,
@@ -1782,6 +1845,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
   float w0s = 0.f;
   unsigned long long w0u = 0ull;
   bool w0_late = false;                                          // the bias is still to be taken out of w0u (hand-off)
+  bool w0_bad = false;                                           // ... and never arrived: the examples of this wavefront take no step
   if (h.k0) {
     if (handoff_err) { w0u = handoff_peek(w0_ptr); w0_late = true; }
     else w0s = (float)(*w0_ptr);
@@ -1803,7 +1867,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       }
       // hand-off: the bias slot was asked for before the entry list, so it is here when the entries are (loads return in order) and leaves
       // its registers before the row slots fill; a slot that is still pending (never, at bias_lag >= 2) is waited for here
-      if (w0_late) { w0s = (float)handoff_wait(w0_ptr, w0u, handoff_err); w0_late = false; }
+      if (w0_late) { w0s = (float)handoff_wait(w0_ptr, w0u, handoff_err, &w0_bad); w0_late = false; }
       // phase A: issue every gather of the row back-to-back (ids / values are re-broadcast later instead of
       // being kept: with EPI == 1 they are wave-uniform and live in SGPRs for the duration of one use).
       // Every cross-lane broadcast below runs with ALL lanes active (outside the idx < size guards): a ds_bpermute
@@ -1851,7 +1915,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       }
       const float rest = wave_sum_dpp(part);
       if (lane == 0) rest_out[e] = rest;
-      mult = multiplier(h, w0s + rest, y);
+      mult = w0_bad ? 0.f : multiplier(h, w0s + rest, y);
       }
       if constexpr (EXACT) {
         if (cm != 0) {                                         // some feature of this example is finished by k_apply_seg
@@ -1891,7 +1955,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         }
       }
     } else if constexpr (!APPLY) {                             // (APPLY: such a row is deferred as a whole, cm == ~0)
-      if (w0_late) { w0s = (float)handoff_wait(w0_ptr, w0u, handoff_err); w0_late = false; }
+      if (w0_late) { w0s = (float)handoff_wait(w0_ptr, w0u, handoff_err, &w0_bad); w0_late = false; }
       float sum[VEC], sq, lin;
       row_sums<KP, 8>(row, size, tb, h.k1, sum, sq, lin);
 #pragma unroll
@@ -1903,7 +1967,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
       }
       const float rest = wave_sum_dpp(part);
       if (lane == 0) rest_out[e] = rest;
-      const float mult = multiplier(h, w0s + rest, y);
+      const float mult = w0_bad ? 0.f : multiplier(h, w0s + rest, y);
       if constexpr (EXACT) {                                   // the whole row is deferred (cmask = all ones)
         if (lane < LPR) store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
         if (lane == 0) mult_out[e] = mult;

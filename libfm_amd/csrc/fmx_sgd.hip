@@ -146,7 +146,11 @@ int fmx_sgd_batch_info(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_bat
   return sgd_resolve_batch(h, h->slots[slot], opts, out);
 }
 
-// builds the (batch, feature) segments of a slot for batch size B (device radix sort; once per data set)
+// builds the (batch, feature) segments of a slot for batch size B (device radix sort; once per data set).
+// Round 6: ONE scratch allocation (fmx_dev_alloc: built from <= 1 GiB chunks, see fmx_internal.h -- ten plain allocations of > 1 GiB were 2.4 s
+// of a 2.46 s preparation), the temporary-storage sizes of the three hipCUB calls asked for once, the counts read back ONCE, every per-batch
+// table (first segment / first deferred segment / first entry of a batch) computed on the device and read back together: two host
+// synchronisations instead of seven, no copy of row_ptr to the host.  FMX_TRACE_SETUP=1 prints where the time goes.
 extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   if (s.seg_B == B && s.t_ent) return FMX_OK;
   if (&s >= h->slots && &s < h->slots + FMX_MAX_SLOTS) {          // (the rows of a kept `-relation` block are bucketed by their own session)
@@ -154,132 +158,174 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
   }
   free_segments(s);
   const auto t_setup0 = std::chrono::steady_clock::now();
+  static const bool trace = getenv("FMX_TRACE_SETUP") != nullptr;
+  auto tp = [&](const char* what) { if (trace) { (void)hipStreamSynchronize(h->stream); fprintf(stderr, "[fmx setup] segments %-22s %8.3f ms\n", what,
+                                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count()); } };
   struct Acc { fmx_handle h; std::chrono::steady_clock::time_point t0;
                ~Acc() { h->setup_acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{h, t_setup0};
   const uint64_t nnz = s.nnz;
   const uint32_t n_batches = (s.n_rows + B - 1) / B;
   if (nnz >= (1ull << 31)) return fail(h, FMX_E_UNSUPPORTED, "segmented apply: nnz >= 2^31 in one slot (split the data set)");
   hipStream_t st = h->stream;
-  uint64_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-  uint32_t *flags = nullptr, *pos = nullptr, *d_batch_seg = nullptr, *d_cbatch = nullptr;
   uint32_t cap = 64;
   KP_SWITCH(h->KP, cap = fused_row_cap_kp<KP>(s.max_row));
-  void* tmp = nullptr;
+  uint32_t fbits = 1; while (fbits < 32 && (1ull << fbits) < std::max<uint64_t>(h->n_local, 2)) fbits++;   // bits of a local feature id
+  int bits_batch = 1; while ((1ull << bits_batch) < n_batches) bits_batch++;
+  char* scratch = nullptr;
   int rc = FMX_OK;
   const size_t cnt = (size_t)std::max<uint64_t>(nnz, 1);
+  const size_t nb1 = (size_t)n_batches + 1;
 #define SEG_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     rc = fail(h, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); goto done; } } while (0)
-  SEG_CHK(hipMalloc(&keys_a, cnt * 8)); SEG_CHK(hipMalloc(&keys_b, cnt * 8));
-  SEG_CHK(hipMalloc(&vals_a, cnt * 8)); SEG_CHK(hipMalloc(&vals_b, cnt * 8));
-  SEG_CHK(hipMalloc(&flags, cnt * 4)); SEG_CHK(hipMalloc(&pos, cnt * 4));
-  SEG_CHK(hipMalloc(&d_batch_seg, ((size_t)n_batches + 2) * 4));          // [n_batches + 1] is the max-count cell
-  SEG_CHK(hipMalloc(&d_cbatch, ((size_t)n_batches + 1) * 4));
-  SEG_CHK(hipMalloc(&s.cmask, (size_t)std::max<uint32_t>(s.n_rows, 1) * 8));
-  hipLaunchKernelGGL(k_seg_slow_rows, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, st, s.row_ptr, s.n_rows, cap, s.cmask);
-  s.fused_cap = cap;
-  if (nnz) {
-    hipLaunchKernelGGL(k_seg_keys, dim3(wave_grid(s.n_rows)), dim3(256), 0, st, s.ent, s.row_ptr, s.n_rows, B, keys_a, vals_a);
-    int bits_batch = 1; while ((1ull << bits_batch) < n_batches) bits_batch++;
-    size_t tmp_bytes = 0;
-    SEG_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (int)nnz, 0, 32 + bits_batch, st));
-    SEG_CHK(hipMalloc(&tmp, tmp_bytes));
-    SEG_CHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (int)nnz, 0, 32 + bits_batch, st));
-    hipLaunchKernelGGL(k_seg_heads, dim3(2048), dim3(256), 0, st, keys_b, nnz, flags);
-    SEG_CHK(hipStreamSynchronize(st));
-    hipFree(tmp); tmp = nullptr; tmp_bytes = 0;
-    SEG_CHK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, flags, pos, (int)nnz, st));
-    SEG_CHK(hipMalloc(&tmp, tmp_bytes));
-    SEG_CHK(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, flags, pos, (int)nnz, st));
-    uint32_t nseg = 0;
-    SEG_CHK(hipMemcpyAsync(&nseg, pos + (nnz - 1), 4, hipMemcpyDeviceToHost, st));
-    SEG_CHK(hipStreamSynchronize(st));
-    s.nseg = nseg;
-    SEG_CHK(hipMalloc(&s.seg_feat, (size_t)nseg * 4));
-    SEG_CHK(hipMalloc(&s.seg_rel, (size_t)nseg * 4));
-    hipLaunchKernelGGL(k_seg_fill, dim3(2048), dim3(256), 0, st, keys_b, flags, pos, nnz, s.row_ptr, B, s.seg_feat, s.seg_rel);
-    hipLaunchKernelGGL(k_seg_batches, dim3((n_batches + 256) / 256), dim3(256), 0, st, pos, nnz, nseg, s.row_ptr,
-                       s.n_rows, B, n_batches, d_batch_seg);
-    SEG_CHK(hipGetLastError());
-    s.batch_seg.resize((size_t)n_batches + 1);
-    SEG_CHK(hipMemcpyAsync(s.batch_seg.data(), d_batch_seg, ((size_t)n_batches + 1) * 4, hipMemcpyDeviceToHost, st));
-    SEG_CHK(hipStreamSynchronize(st));
-    {  // longest segment (reported through fmx_epoch_stats::max_feature_count); keys_a is free after the sort
-      uint32_t* head = reinterpret_cast<uint32_t*>(keys_a);            // [nseg + 1] <= 8 bytes per entry
-      uint32_t* d_max = d_batch_seg + n_batches + 1;
-      SEG_CHK(hipMemsetAsync(d_max, 0, 4, st));
-      hipLaunchKernelGGL(k_seg_head_pos, dim3(2048), dim3(256), 0, st, flags, pos, nnz, nseg, head);
-      hipLaunchKernelGGL(k_seg_max_count, dim3(2048), dim3(256), 0, st, head, nseg, d_max);
-      SEG_CHK(hipMemcpyAsync(&s.max_seg_count, d_max, 4, hipMemcpyDeviceToHost, st));
-      SEG_CHK(hipStreamSynchronize(st));
-      // what the one-pass kernel (FMX_APPLY_FUSED) must leave to k_apply_seg: features occurring more than once in
-      // their batch + rows too long for its registers.  flags / pos are free now: cflag = flags, cpos = pos.
-      uint32_t *cflag = flags, *cpos = pos;
-      hipLaunchKernelGGL(k_seg_mark, dim3(2048), dim3(256), 0, st, keys_b, reinterpret_cast<const TEntry*>(vals_b), head, nseg,
-                         s.ent, s.row_ptr, B, cap, s.cmask, cflag);
+  {
+    // temporary storage of the three hipCUB calls (a size query touches no memory)
+    size_t tmp_sort = 0, tmp_scan = 0, tmp_xscan = 0;
+    SEG_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                                               (int)cnt, 0, (int)fbits + bits_batch, st));
+    SEG_CHK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)cnt, st));
+    SEG_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_xscan, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)cnt, st));
+    const size_t tmp_bytes = std::max<size_t>(std::max(tmp_sort, std::max(tmp_scan, tmp_xscan)), 256);
+    // scratch layout (256-byte aligned pieces): keys_a | keys_b | vals_a | flags | pos | cflag | cpos | counts | hipCUB temp
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t off = 0;
+    const size_t o_ka = off; off += al(cnt * 8);
+    const size_t o_kb = off; off += al(cnt * 8);
+    const size_t o_va = off; off += al(cnt * 8);
+    const size_t o_fl = off; off += al(cnt * 4);
+    const size_t o_po = off; off += al(cnt * 4);
+    const size_t o_cf = off; off += al(cnt * 4);
+    const size_t o_cp = off; off += al(cnt * 4);
+    const size_t o_ct = off; off += 256;
+    const size_t o_tmp = off; off += al(tmp_bytes);
+    SEG_CHK(fmx_dev_alloc(&scratch, off));
+    uint64_t* keys_a = (uint64_t*)(scratch + o_ka); uint64_t* keys_b = (uint64_t*)(scratch + o_kb); uint64_t* vals_a = (uint64_t*)(scratch + o_va);
+    uint32_t* flags = (uint32_t*)(scratch + o_fl); uint32_t* pos = (uint32_t*)(scratch + o_po);
+    uint32_t* cflag = (uint32_t*)(scratch + o_cf); uint32_t* cpos = (uint32_t*)(scratch + o_cp);
+    uint32_t* d_counts = (uint32_t*)(scratch + o_ct);            // {segments, deferred segments, longest segment, -}
+    void* tmp = scratch + o_tmp;
+    uint64_t* vals_b = nullptr;                                    // the sort's output payload IS t_ent (payload layout == TEntry): allocated on its own, kept
+    SEG_CHK(fmx_dev_alloc(&vals_b, cnt * 8));
+    s.t_ent = reinterpret_cast<TEntry*>(vals_b);
+    SEG_CHK(fmx_dev_alloc(&s.cmask, (size_t)std::max<uint32_t>(s.n_rows, 1) * 8));
+    SEG_CHK(fmx_dev_alloc(&s.d_batch_seg, nb1 * 4));
+    SEG_CHK(fmx_dev_alloc(&s.d_cbatch, nb1 * 4));
+    SEG_CHK(fmx_dev_alloc(&s.d_batch_base, nb1 * 8));
+    tp("allocations");
+    hipLaunchKernelGGL(k_seg_slow_rows, dim3(std::min<uint32_t>((s.n_rows + 255) / 256, 2048)), dim3(256), 0, st, s.row_ptr, s.n_rows, cap, s.cmask);
+    s.fused_cap = cap;
+    SEG_CHK(hipMemsetAsync(d_counts, 0, 16, st));
+    if (nnz) {
+      hipLaunchKernelGGL(k_seg_keys, dim3(wave_grid(s.n_rows)), dim3(256), 0, st, s.ent, s.row_ptr, s.n_rows, B, fbits, keys_a, vals_a);
+      size_t tb_ = tmp_bytes;
+      SEG_CHK(hipcub::DeviceRadixSort::SortPairs(tmp, tb_, keys_a, keys_b, vals_a, vals_b, (int)nnz, 0, (int)fbits + bits_batch, st));
+      hipLaunchKernelGGL(k_seg_heads, dim3(2048), dim3(256), 0, st, keys_b, nnz, flags);
+      tp("keys + sort + heads");
+      tb_ = tmp_bytes;
+      SEG_CHK(hipcub::DeviceScan::InclusiveSum(tmp, tb_, flags, pos, (int)nnz, st));
+      // per-batch tables on the device (kept: the persistent small-batch kernel and the group driver's captured graphs read them there)
+      hipLaunchKernelGGL(k_seg_batches, dim3((n_batches + 256) / 256), dim3(256), 0, st, pos, nnz, s.row_ptr, s.n_rows, B, n_batches, s.d_batch_seg, s.d_batch_base);
+      // longest segment (fmx_epoch_stats::max_feature_count); keys_a is free after the sort: head[nseg + 1] <= 8 bytes per entry
+      uint32_t* head = reinterpret_cast<uint32_t*>(keys_a);
+      hipLaunchKernelGGL(k_seg_head_pos, dim3(2048), dim3(256), 0, st, flags, pos, nnz, head);
+      hipLaunchKernelGGL(k_seg_max_count, dim3(2048), dim3(256), 0, st, head, pos, nnz, d_counts + 2);
+      // what the one-pass kernel (FMX_APPLY_FUSED) must leave to k_apply_seg: features occurring more than once in their batch + rows too
+      // long for its registers
+      hipLaunchKernelGGL(k_seg_mark, dim3(2048), dim3(256), 0, st, keys_b, reinterpret_cast<const TEntry*>(vals_b), head, pos, nnz,
+                         s.ent, s.row_ptr, B, fbits, cap, (uint32_t)(s.max_row > cap ? 1u : 0u), s.cmask, cflag);
       SEG_CHK(hipGetLastError());
-      hipFree(tmp); tmp = nullptr; tmp_bytes = 0;
-      SEG_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cflag, cpos, (int)nseg, st));
-      SEG_CHK(hipMalloc(&tmp, tmp_bytes));
-      SEG_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cflag, cpos, (int)nseg, st));
-      uint32_t last_pos = 0, last_flag = 0;
-      SEG_CHK(hipMemcpyAsync(&last_pos, cpos + (nseg - 1), 4, hipMemcpyDeviceToHost, st));
-      SEG_CHK(hipMemcpyAsync(&last_flag, cflag + (nseg - 1), 4, hipMemcpyDeviceToHost, st));
-      SEG_CHK(hipStreamSynchronize(st));
-      s.ncseg = last_pos + last_flag;
-      SEG_CHK(hipMalloc(&s.cseg, (size_t)std::max<uint32_t>(s.ncseg, 1) * 4));
-      SEG_CHK(hipMalloc(&s.cdesc, (size_t)std::max<uint32_t>(s.ncseg, 1) * sizeof(CDesc)));
-      hipLaunchKernelGGL(k_seg_compact, dim3(2048), dim3(256), 0, st, keys_b, head, cflag, cpos, nseg, d_batch_seg, s.cseg,
-                         s.seg_feat, s.seg_rel, s.row_ptr, s.n_rows, B, s.cdesc, reinterpret_cast<const TEntry*>(vals_b));
-      hipLaunchKernelGGL(k_seg_cbatch, dim3((n_batches + 256) / 256), dim3(256), 0, st, cpos, cflag, nseg, d_batch_seg, n_batches, d_cbatch);
+      tb_ = tmp_bytes;
+      SEG_CHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb_, cflag, cpos, (int)nnz, st));   // (over nnz >= nseg elements: the tail is never read)
+      hipLaunchKernelGGL(k_seg_counts, dim3(1), dim3(64), 0, st, pos, nnz, cpos, cflag, d_counts + 2, d_counts);
+      uint32_t counts[4] = {0, 0, 0, 0};
+      SEG_CHK(hipMemcpyAsync(counts, d_counts, 16, hipMemcpyDeviceToHost, st));
+      SEG_CHK(hipStreamSynchronize(st));                         // host synchronisation 1 of 2: the sizes of the slot's arrays
+      tp("scan + mark + counts");
+      const uint32_t nseg = counts[0];
+      s.nseg = nseg; s.ncseg = counts[1]; s.max_seg_count = counts[2];
+      SEG_CHK(fmx_dev_alloc(&s.seg_feat, (size_t)std::max<uint32_t>(nseg, 1) * 4));
+      SEG_CHK(fmx_dev_alloc(&s.seg_rel, (size_t)std::max<uint32_t>(nseg, 1) * 4));
+      SEG_CHK(fmx_dev_alloc(&s.cseg, (size_t)std::max<uint32_t>(s.ncseg, 1) * 4));
+      SEG_CHK(fmx_dev_alloc(&s.cdesc, (size_t)std::max<uint32_t>(s.ncseg, 1) * sizeof(CDesc)));
+      hipLaunchKernelGGL(k_seg_fill, dim3(2048), dim3(256), 0, st, keys_b, flags, pos, nnz, s.row_ptr, B, fbits, s.seg_feat, s.seg_rel);
+      hipLaunchKernelGGL(k_seg_compact, dim3(2048), dim3(256), 0, st, keys_b, head, cflag, cpos, nseg, s.d_batch_seg, s.cseg,
+                         s.seg_feat, s.seg_rel, s.row_ptr, s.n_rows, B, fbits, s.cdesc, reinterpret_cast<const TEntry*>(vals_b));
+      hipLaunchKernelGGL(k_seg_cbatch, dim3((n_batches + 256) / 256), dim3(256), 0, st, cpos, cflag, nseg, s.d_batch_seg, n_batches, s.d_cbatch);
       SEG_CHK(hipGetLastError());
-      s.cbatch.resize((size_t)n_batches + 1);
-      SEG_CHK(hipMemcpyAsync(s.cbatch.data(), d_cbatch, ((size_t)n_batches + 1) * 4, hipMemcpyDeviceToHost, st));
-      SEG_CHK(hipStreamSynchronize(st));
+    } else {
+      s.nseg = 0; s.ncseg = 0; s.max_seg_count = 0;
+      SEG_CHK(hipMemsetAsync(s.d_batch_seg, 0, nb1 * 4, st));
+      SEG_CHK(hipMemsetAsync(s.d_cbatch, 0, nb1 * 4, st));
+      SEG_CHK(hipMemsetAsync(s.d_batch_base, 0, nb1 * 8, st));
+      SEG_CHK(fmx_dev_alloc(&s.seg_feat, 4)); SEG_CHK(fmx_dev_alloc(&s.seg_rel, 4));
+      SEG_CHK(fmx_dev_alloc(&s.cseg, 4));
+      SEG_CHK(fmx_dev_alloc(&s.cdesc, sizeof(CDesc)));
     }
-    s.t_ent = reinterpret_cast<TEntry*>(vals_b); vals_b = nullptr;      // payload layout == TEntry
-  } else {
-    s.nseg = 0; s.ncseg = 0;
-    s.batch_seg.assign((size_t)n_batches + 1, 0);
-    s.cbatch.assign((size_t)n_batches + 1, 0);
-    SEG_CHK(hipMalloc(&s.t_ent, 8));
-    SEG_CHK(hipMalloc(&s.cseg, 4));
-    SEG_CHK(hipMalloc(&s.cdesc, sizeof(CDesc)));
-    SEG_CHK(hipStreamSynchronize(st));
+    s.batch_seg.resize(nb1); s.cbatch.resize(nb1); s.batch_base.resize(nb1);
+    SEG_CHK(hipMemcpyAsync(s.batch_seg.data(), s.d_batch_seg, nb1 * 4, hipMemcpyDeviceToHost, st));
+    SEG_CHK(hipMemcpyAsync(s.cbatch.data(), s.d_cbatch, nb1 * 4, hipMemcpyDeviceToHost, st));
+    SEG_CHK(hipMemcpyAsync(s.batch_base.data(), s.d_batch_base, nb1 * 8, hipMemcpyDeviceToHost, st));
+    SEG_CHK(hipStreamSynchronize(st));                           // host synchronisation 2 of 2: the per-batch tables
+    tp("fill + compact + tables");
+    s.seg_B = B;
   }
-  {  // first entry of every batch (row_ptr sampled at multiples of B)
-    std::vector<uint64_t> rp((size_t)s.n_rows + 1);
-    SEG_CHK(hipMemcpy(rp.data(), s.row_ptr, rp.size() * 8, hipMemcpyDeviceToHost));
-    s.batch_base.resize((size_t)n_batches + 1);
-    for (uint32_t b = 0; b <= n_batches; b++) s.batch_base[b] = rp[std::min<uint64_t>((uint64_t)b * B, s.n_rows)];
-  }
-  s.seg_B = B;
 done:
 #undef SEG_CHK
-  if (keys_a) hipFree(keys_a);
-  if (keys_b) hipFree(keys_b);
-  if (vals_a) hipFree(vals_a);
-  if (vals_b) hipFree(vals_b);
-  if (flags) hipFree(flags);
-  if (pos) hipFree(pos);
-  if (d_batch_seg) hipFree(d_batch_seg);
-  if (d_cbatch) hipFree(d_cbatch);
-  if (tmp) hipFree(tmp);
+  if (scratch) fmx_dev_free(scratch);
+  tp("frees");
   if (rc) free_segments(s);
   return rc;
 }
 
-// the device's error word after launches of k_scan_pit whose streams have been drained by the caller
+// the device's error word after launches of k_scan_pit whose streams have been drained by the caller.  Bit 4 = a grid-wide exchange ran
+// into its bound and one workgroup evaluated the batch's chain serially instead (fmx_kernels.h): the numbers are the rule's, so this is
+// not a failure -- the epoch reports FMX_STAT_SCAN_FALLBACK and the handle takes the one-wavefront chain from now on.  Only bit 4 is
+// cleared here (the hand-off's bits 1 and 2 belong to the epoch's own check).
 extern "C++" int scan_error_check(fmx_handle h) {
   if (!h->pit_used) return FMX_OK;
   h->pit_used = false;
   uint32_t e = 0;
   HIPCHK(h, hipMemcpy(&e, h->handoff_err, sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (e & 4u) {
-    (void)hipMemset(h->handoff_err, 0, sizeof(uint32_t));
-    return fail(h, FMX_E_HIP, "the grid-wide exchange of the parallel bias recurrence timed out (flags %u): the parameters of this epoch are "
-                              "not valid; FMX_SCAN=serial takes the one-wavefront chain instead", e);
+    const uint32_t rest_bits = e & ~4u;
+    (void)hipMemcpy(h->handoff_err, &rest_bits, sizeof(uint32_t), hipMemcpyHostToDevice);
+    h->scan_pit = false;
+    h->run_status |= FMX_STAT_SCAN_FALLBACK;
   }
   return FMX_OK;
+}
+
+// do the handle's two streams run concurrently?  (k_concurrency_probe, once per handle: ~50 us when they do, ~40 ms when they do not)
+extern "C++" bool streams_concurrent(fmx_handle h) {
+  if (h->concurrent >= 0) return h->concurrent != 0;
+  h->concurrent = 0;
+  if (!h->probe_flags && fmx_dev_alloc(&h->probe_flags, 4 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  unsigned res[4] = {0, 0, 0, 0};
+  hipError_t e = hipMemsetAsync(h->probe_flags, 0, 4 * sizeof(unsigned), h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream2);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_concurrency_probe, dim3(1), dim3(64), 0, h->stream2, h->probe_flags, 1u);
+    hipLaunchKernelGGL(k_concurrency_probe, dim3(1), dim3(64), 0, h->stream, h->probe_flags, 0u);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream2);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(res, h->probe_flags, sizeof(res), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  h->concurrent = (res[2] == 1u && res[3] == 1u) ? 1 : 0;
+  return h->concurrent != 0;
+}
+
+// workgroups of k_scan_pit that must be resident TOGETHER on the handle's device: every shard of a loopback group runs the whole
+// recurrence itself, on the same device (round-5 advisor: 16 loopback shards x 32 workgroups on 256 CUs waited for each other)
+static uint32_t pit_concurrent_kernels(fmx_handle h) {
+  uint32_t n = 1;
+  if (h->group && h->group->hs.size() > 1) {
+    n = 0;
+    for (fmx_handle m : h->group->hs) if (m && m->device == h->device) n++;
+    if (n == 0) n = 1;
+  }
+  return n;
 }
 
 static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
@@ -292,20 +338,55 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     // micro-chunks that are powers of two up to 1024 on batches of 4097 .. 262 144 examples -- every default.  Same result as the chain to
     // fp32 rounding; 40-80 us per 262 144 examples whatever the micro-chunk where the chain takes 0.18 ms (256) .. 0.5 ms (32).
     // (the arrival counters of its exchanges are zeroed on the launch's own stream, in front of it)
-    if (h->scan_pit && n_rows > 4096u && n_rows <= PIT_MAX_ROWS && chunk <= PIT_MAX_CHUNK && (chunk & (chunk - 1u)) == 0u) {
-      const uint32_t nwg = (n_rows + pit_seg(chunk) - 1) / pit_seg(chunk);
-      HIPCHK(h, hipMemsetAsync(h->pit_ctr, 0, (PIT_MAX_IT + 1) * sizeof(unsigned long long), st));
-      const PitSync ps{h->pit_ctr, h->pit_slots, h->handoff_err};
+    if (h->scan_pit && n_rows > 4096u && chunk <= PIT_MAX_CHUNK && (chunk & (chunk - 1u)) == 0u) {
+      // every workgroup of the launch spins on a grid-wide arrival counter: all of them must fit the device TOGETHER -- next to the same
+      // kernel of the other shards on this device.  112 KiB of LDS per workgroup = one per CU (asked once per handle).
+      if (h->pit_occ < 0) {
+        int per_cu = 0;
+        auto kf = k_scan_pit<false, 1>;
+        (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIT_LDS_BYTES);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kf, 256, PIT_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        h->pit_occ = per_cu * h->num_cu;
+      }
+      const uint32_t piece_rows = PIT_MAX_ROWS;
+      const uint32_t nwg_max = (std::min(n_rows, piece_rows) + pit_seg(chunk) - 1) / pit_seg(chunk);
+      static const bool trace_pit = getenv("FMX_TRACE_PIT") != nullptr;
+      if (trace_pit) fprintf(stderr, "[fmx pit] rows %u chunk %u: %u workgroups x %u kernels, device holds %d\n", n_rows, chunk, nwg_max, pit_concurrent_kernels(h), h->pit_occ);
+      if ((uint64_t)nwg_max * pit_concurrent_kernels(h) <= (uint64_t)std::max(h->pit_occ, 0)) {
+        // a batch longer than PIT_MAX_ROWS (an explicit batch, a HOGWILD macro-batch): pieces of PIT_MAX_ROWS examples, the bias handed from
+        // piece to piece on the launch's stream (round-5 advisor: such batches silently took the one-wavefront chain, 8x the steps at the new
+        // default micro-chunk); only the first piece waits for the hand-off counter, only the last one publishes
+        const uint32_t n_pieces = (n_rows + piece_rows - 1) / piece_rows;
+        if (n_pieces > 1 && !h->pit_tmp) HIPCHK(h, fmx_dev_alloc(&h->pit_tmp, 64 * sizeof(double)));
+        if (n_pieces <= 64) {
+          const PitSync ps{h->pit_ctr, h->pit_slots, h->handoff_err, h->pit_spins};   // (FMX_DEBUG_PIT_SPINS=0 at fmx_create: every exchange gives up at once -- the test of the fall-back)
+          for (uint32_t pc = 0; pc < n_pieces; pc++) {
+            const uint32_t r0 = pc * piece_rows, rn = std::min(piece_rows, n_rows - r0);
+            const uint32_t nwg = (rn + pit_seg(chunk) - 1) / pit_seg(chunk);
+            const double* pin = pc == 0 ? wi : h->pit_tmp + (pc - 1);
+            double* pout = pc + 1 == n_pieces ? wo : h->pit_tmp + pc;
+            Handoff ph{nullptr, 0ull, nullptr};                    // a piece in the middle: plain load, plain store, stream order
+            if (hw.ctr) {
+              if (pc == 0) ph = hw;                                // waits for the batch's rest[] (and stores with the hand-off store: harmless for pit_tmp)
+              else if (pc + 1 == n_pieces) ph = Handoff{hw.ctr, 0ull, hw.err};   // publishes; nothing left to wait for
+            }
+            HIPCHK(h, hipMemsetAsync(h->pit_ctr, 0, (PIT_MAX_IT + 1) * sizeof(unsigned long long), st));
+            float* mp = mult ? mult + r0 : nullptr;
 #define FMX_PIT(WM, TK) do { auto kf = k_scan_pit<WM, TK>;                                                                       \
-      if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIT_LDS_BYTES)); h->lds_raised.insert((const void*)kf); } \
-      hipLaunchKernelGGL(kf, dim3(nwg), dim3(256), PIT_LDS_BYTES, st, rest, target, n_rows, chunk, hy, wi, wo, mult, hw, ps); } while (0)
-      if (hy.task == 0) { if (mult) FMX_PIT(true, 0); else FMX_PIT(false, 0); }
-      else              { if (mult) FMX_PIT(true, 1); else FMX_PIT(false, 1); }
+            if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIT_LDS_BYTES)); h->lds_raised.insert((const void*)kf); } \
+            hipLaunchKernelGGL(kf, dim3(nwg), dim3(256), PIT_LDS_BYTES, st, rest + r0, target + r0, rn, chunk, hy, pin, pout, mp, ph, ps); } while (0)
+            if (hy.task == 0) { if (mult) FMX_PIT(true, 0); else FMX_PIT(false, 0); }
+            else              { if (mult) FMX_PIT(true, 1); else FMX_PIT(false, 1); }
 #undef FMX_PIT
-      h->pit_used = true;
-      HIPCHK(h, hipGetLastError());
-      return FMX_OK;
+          }
+          h->pit_used = true;
+          h->run_status |= FMX_STAT_SCAN_PIT;
+          HIPCHK(h, hipGetLastError());
+          return FMX_OK;
+        }
+      }
     }
+    h->run_status |= FMX_STAT_SCAN_SERIAL;
     // micro-chunks that are multiples of 256 examples: k_scan1 (one wavefront on the chain, four contiguous examples per lane, a 128 KiB
     // tile pipeline fed by the workgroup's four wavefronts); else, and for
     // batches of a few thousand rows (the 128 KiB-LDS workgroup costs more to place than the recurrence takes): one plain wavefront
@@ -347,7 +428,7 @@ extern "C++" int lag_flush(fmx_handle h) {                      // make h->w0 th
   HIPCHK(h, hipStreamSynchronize(h->stream2));
   HIPCHK(h, hipMemcpy(h->w0, h->w0_pp + (L.step % (L.depth + 1)), sizeof(double), hipMemcpyDeviceToDevice));
   L.active = false; L.step = 0;
-  return FMX_OK;
+  return scan_error_check(h);                                 // (callers that drive fmx_sgd_partial / _finish themselves and then read parameters)
 }
 // call BEFORE producing the rest buffer of this step on `st`; returns which of the d + 1 rest buffers to use
 static int lag_prepare(fmx_handle h, hipStream_t st, uint32_t depth, int* slot) {
@@ -610,14 +691,18 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   // i - 1, k_fused of batch b reads W[max(0, b - d + 1)], the recurrence of batch b reads W[b] and publishes W[b + 1].
   // (bias_lag 1 keeps the events: there every wavefront of k_fused WAITS for a slot the one-workgroup recurrence of the previous batch
   //  publishes, and nothing guarantees that kernel a CU once k_fused has filled the chip -- round-4 advisor; at lag >= 2 the slot is a batch old)
-  const bool handoff = side && h->handoff && hy.k0 && d >= 2 && !(opts->flags & FMX_FLAG_EVENT_SYNC);
+  // ... and only where the two streams really run side by side (streams_concurrent: probed once per handle): under serialised dispatch the
+  // waits of the hand-off are satisfied by LATER launches and every batch would run into its bound
+  const bool handoff = side && h->handoff && hy.k0 && d >= 2 && !(opts->flags & FMX_FLAG_EVENT_SYNC) && streams_concurrent(h);
+  if (side && hy.k0 && !handoff) h->run_status |= FMX_STAT_EVENT_SYNC;
+  if (!side && hy.k0) h->run_status |= FMX_STAT_SCAN_SERIAL;
   double* W = nullptr;
   unsigned long long hbase = 0;
   if (handoff) {
     if (h->w0_slots_cap < n_batch + 1) {
-      if (h->w0_slots) HIPCHK(h, hipFree(h->w0_slots));
+      if (h->w0_slots) HIPCHK(h, fmx_dev_free(h->w0_slots));
       h->w0_slots = nullptr; h->w0_slots_cap = 0;
-      HIPCHK(h, hipMalloc(&h->w0_slots, (size_t)(n_batch + 1) * sizeof(double)));
+      HIPCHK(h, fmx_dev_alloc(&h->w0_slots, (size_t)(n_batch + 1) * sizeof(double)));
       h->w0_slots_cap = n_batch + 1;
     }
     W = h->w0_slots;
@@ -714,7 +799,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   if (stats) memset(stats, 0, sizeof(*stats));
   if (s.n_rows == 0) return FMX_OK;
   if (!s.blocks.empty()) return fail(h, FMX_E_UNSUPPORTED, "relations are not supported with SGD");   // fm_learn_sgd.h:61-63
-  if (!(h->group && !h->owns_group)) h->setup_acc = 0.0;     // (a group clears its members' before the epoch)
+  if (!(h->group && !h->owns_group)) { h->setup_acc = 0.0; h->run_status = 0; }   // (a group clears its members' before the epoch)
   if (h->cfg.shard_world > 1 && opts->mode != FMX_SGD_MINIBATCH)
     return fail(h, FMX_E_UNSUPPORTED, "feature shards train with FMX_SGD_MINIBATCH (the split step)");
   if (h->cfg.shard_world > 1 || h->comm) return comm_sgd_epoch(h, slot, opts, stats);   // (a communicator of one rank drives the same schedule)
@@ -842,17 +927,29 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
-  if (h->handoff_err_host) {                                  // a hand-off wait ran into its bound (never seen; a hang would be worse)
-    const uint32_t e = h->handoff_err_host;
-    h->handoff_err_host = 0;
-    (void)hipMemset(h->handoff_err, 0, sizeof(uint32_t));
-    return fail(h, FMX_E_HIP, "the bias hand-off between the launch stream and the recurrence timed out (flags %u): the parameters of this "
-                              "epoch are not valid; FMX_HANDOFF=0 orders the streams with events instead", e);
-  }
   rc = lag_flush(h);
   if (rc) return rc;
   rc = scan_error_check(h);
   if (rc) return rc;
+  if (h->handoff_err_host & 3u) {
+    // a hand-off wait ran into its bound (the probe said the streams run side by side, and then they did not: the device is shared with
+    // work that starved one of them).  Nothing was computed from a bias that was not there: the examples concerned took no step, a
+    // recurrence that never saw its batch handed the bias on unchanged (fmx_kernels.h) -- every parameter is a valid number, but the
+    // epoch is not the rule's.  The handle orders its streams with events from now on.
+    const uint32_t e = h->handoff_err_host;
+    h->handoff_err_host = 0;
+    uint32_t dev = 0;
+    if (hipMemcpy(&dev, h->handoff_err, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+      dev &= ~3u;                                               // (only the hand-off's own bits: bit 4 belongs to scan_error_check)
+      (void)hipMemcpy(h->handoff_err, &dev, sizeof(uint32_t), hipMemcpyHostToDevice);
+    }
+    h->handoff = false;
+    h->run_status |= FMX_STAT_HANDOFF_TIMEOUT;
+    if (stats) stats->status = bi.status | h->run_status;
+    return fail(h, FMX_E_HIP, "the bias hand-off between the launch stream and the recurrence timed out (flags %u): the examples concerned took no "
+                              "step (the parameters are valid numbers, the epoch is not the batch rule's); the handle orders its streams with "
+                              "events from now on", e);
+  }
   if (kept_wside) s.wside_version = h->w_version;            // the epoch is complete: the stream holds this w
   if (stats) {
     float ms = 0;
@@ -865,6 +962,7 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     if (opts->mode == FMX_SGD_MINIBATCH || opts->mode == FMX_SGD_HOGWILD) {     // (HOGWILD: batch_used = the rows in flight)
       stats->batch_used = bi.batch; stats->collision_mass = bi.collision_mass; stats->batch_gain = bi.batch_gain; stats->status = bi.status;
     }
+    stats->status |= h->run_status;
     stats->setup_seconds = h->setup_acc;
     if (opts->mode != FMX_SGD_SEQUENTIAL) stats->w0_chunk_used = opts->w0_chunk ? opts->w0_chunk : default_w0_chunk(h->cfg);
     if (opts->mode == FMX_SGD_MINIBATCH && timed && opts->apply != FMX_APPLY_FUSED) {
@@ -888,10 +986,10 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
 // SGDA
 // ---------------------------------------------------------------------------------------------
 extern "C++" void sgda_free(fmx_handle h) {
-  if (h->sgda.gw) hipFree(h->sgda.gw);
-  if (h->sgda.gv) hipFree(h->sgda.gv);
-  if (h->sgda.reg) hipFree(h->sgda.reg);
-  if (h->sgda.dreg) hipFree(h->sgda.dreg);
+  if (h->sgda.gw) fmx_dev_free(h->sgda.gw);
+  if (h->sgda.gv) fmx_dev_free(h->sgda.gv);
+  if (h->sgda.reg) fmx_dev_free(h->sgda.reg);
+  if (h->sgda.dreg) fmx_dev_free(h->sgda.dreg);
   h->sgda = SgdaState();
 }
 
@@ -912,9 +1010,9 @@ int fmx_sgda_begin(fmx_handle h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   sgda_free(h);
   const size_t nv = h->n_local * (size_t)h->tb.rs, nreg = (size_t)h->num_groups * (1 + (size_t)h->KP);   // [G][1 + KP]
-  HIPCHK(h, hipMalloc(&h->sgda.gw, h->n_local * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->sgda.gv, nv * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->sgda.reg, nreg * sizeof(double)));
+  HIPCHK(h, fmx_dev_alloc(&h->sgda.gw, h->n_local * sizeof(float)));
+  HIPCHK(h, fmx_dev_alloc(&h->sgda.gv, nv * sizeof(float)));
+  HIPCHK(h, fmx_dev_alloc(&h->sgda.reg, nreg * sizeof(double)));
   HIPCHK(h, hipMemsetAsync(h->sgda.gw, 0, h->n_local * sizeof(float), h->stream));
   HIPCHK(h, hipMemsetAsync(h->sgda.gv, 0, nv * sizeof(float), h->stream));
   HIPCHK(h, hipMemsetAsync(h->sgda.reg, 0, nreg * sizeof(double), h->stream));
@@ -1019,8 +1117,8 @@ int fmx_sgda_epoch_minibatch(fmx_handle h, int train_slot, int validation_slot, 
   const uint32_t n_wg = (uint32_t)std::max<size_t>(64, std::min<size_t>(4096, ((size_t)8 << 20) / cells));
   if (do_lambda_steps && h->sgda.dreg_cap < (size_t)n_wg * cells) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->sgda.dreg) { hipFree(h->sgda.dreg); h->sgda.dreg = nullptr; h->sgda.dreg_cap = 0; }
-    HIPCHK(h, hipMalloc(&h->sgda.dreg, (size_t)n_wg * cells * sizeof(double)));
+    if (h->sgda.dreg) { fmx_dev_free(h->sgda.dreg); h->sgda.dreg = nullptr; h->sgda.dreg_cap = 0; }
+    HIPCHK(h, fmx_dev_alloc(&h->sgda.dreg, (size_t)n_wg * cells * sizeof(double)));
     h->sgda.dreg_cap = (size_t)n_wg * cells;
   }
   hipStream_t st = h->stream;

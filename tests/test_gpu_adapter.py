@@ -306,3 +306,92 @@ def test_reference_driver_with_feature_shards(oracle, devices, tmp_path):
         assert abs(final.w0 - m.w0) <= 1e-4 * abs(m.w0) + 1e-5
     np.testing.assert_allclose(finals[1][1], finals[0][1], rtol=1e-4, atol=5e-5)          # -out predictions
     assert np.abs(finals[1][2] - finals[0][2]).max() <= 2.0 / 100                          # per-epoch accuracy lines
+
+
+# ---- the reference's OWN driver, patched (adapter/libfm_gpu.patch -> oracle/_ref/libFM_gpu) -------------------------------------------
+STOCK = os.path.join(ROOT, "oracle", "_ref", "libFM")
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "libFM_gpu")
+
+
+def _model_numbers(path):
+    """every number of a -save_model file (fm_model::saveModel, fm_model.h:132-154), comment lines skipped"""
+    out = []
+    for ln in open(path):
+        if not ln.startswith("#"):
+            out += [float(x) for x in ln.split()]
+    return np.array(out)
+
+
+def _run_libfm(exe, td, tag, args):
+    out, model = os.path.join(td, tag + ".pred"), os.path.join(td, tag + ".model")
+    cmd = [exe] + args + ["-out", out]
+    if "mcmc" not in args:
+        cmd += ["-save_model", model]                          # (the reference refuses -save_model for mcmc, libfm.cpp:121-125)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0 and "ERROR" not in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("#Iter=")]
+    nums = np.array([[float(x.split("=")[1]) for x in ln.split("\t")[1:3]] for ln in lines])
+    return nums, np.loadtxt(out), (_model_numbers(model) if os.path.exists(model) else None), r.stdout
+
+
+@pytest.fixture(scope="module")
+def config0_files(oracle):
+    from conftest import GOLDEN_DIR
+    Z = np.load(os.path.join(GOLDEN_DIR, "c1_ml100k_shaped.npz"))
+    td = tempfile.mkdtemp(prefix="fmx_c0_")
+    trf, tef = os.path.join(td, "train.libfm"), os.path.join(td, "test.libfm")
+    oracle.Data(Z["train_entries"], Z["train_row_ptr"], Z["train_target"]).write_libsvm(trf)
+    oracle.Data(Z["test_entries"], Z["test_row_ptr"], Z["test_target"]).write_libsvm(tef)
+    yield td, trf, tef
+    import shutil
+    shutil.rmtree(td, ignore_errors=True)
+
+
+def _need_binaries():
+    if not (os.path.exists(STOCK) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref/libFM and libFM_gpu not built (need /root/reference at build time)")
+
+
+def test_patched_libfm_binary_sgd(config0_files):
+    """`libFM -gpu 1` = src/libfm/libfm.cpp with adapter/libfm_gpu.patch applied (libfm.cpp:76-102 the flags, :271-293 the learner), on
+    the BASELINE configs[0] stand-in with the stock binary's command line.  `-gpu_mode sequential` is the reference's trajectory: every
+    #Iter line, the -out file and the -save_model file equal the stock binary's at 1e-4; the default mode (the one-pass batch rule) ends
+    within 0.003 RMSE of it."""
+    _need_binaries()
+    td, trf, tef = config0_files
+    args = ["-task", "r", "-train", trf, "-test", tef, "-dim", "1,1,8", "-iter", "20", "-method", "sgd", "-learn_rate", "0.01",
+            "-regular", "0,0,0.01", "-init_stdev", "0.1", "-seed", "42"]
+    it0, out0, m0, _ = _run_libfm(STOCK, td, "stock_sgd", args)
+    it1, out1, m1, so = _run_libfm(PATCHED, td, "gpu_seq", args + ["-gpu", "1", "-gpu_mode", "sequential"])
+    assert it0.shape == it1.shape == (20, 2)
+    np.testing.assert_allclose(it1, it0, rtol=1e-4)
+    np.testing.assert_allclose(out1, out0, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(m1, m0, rtol=1e-4, atol=2e-5)
+    it2, out2, m2, _ = _run_libfm(PATCHED, td, "gpu_default", args + ["-gpu", "1"])
+    assert np.abs(it2[-1] - it0[-1]).max() <= 0.003, (it2[-1], it0[-1])
+    assert np.abs(it2[2:] - it0[2:]).max() <= 0.01
+    assert np.sqrt(np.mean((out2 - out0) ** 2)) < 0.05
+    # two feature shards on this device through the same binary (-gpu_devices 0,0): the same batch rule
+    it3, out3, m3, _ = _run_libfm(PATCHED, td, "gpu_shards", args + ["-gpu", "1", "-gpu_devices", "0,0"])
+    np.testing.assert_allclose(it3, it2, rtol=2e-4)
+    np.testing.assert_allclose(m3, m2, rtol=1e-3, atol=5e-5)
+
+
+def test_patched_libfm_binary_als_and_mcmc(config0_files):
+    """the same for `-method als` (coordinate descent: the stock binary's numbers at 1e-4: #Iter lines, -out, -save_model) and `-method mcmc`
+    (a sampled chain with the device's own noise: its running-mean test RMSE after 30 draws within 0.01 of the stock chain's)."""
+    _need_binaries()
+    td, trf, tef = config0_files
+    base = ["-task", "r", "-train", trf, "-test", tef, "-dim", "1,1,8", "-init_stdev", "0.1", "-seed", "42"]
+    als = base + ["-iter", "8", "-method", "als", "-regular", "0,1,10"]
+    it0, out0, m0, _ = _run_libfm(STOCK, td, "stock_als", als)
+    it1, out1, m1, _ = _run_libfm(PATCHED, td, "gpu_als", als + ["-gpu", "1"])
+    np.testing.assert_allclose(it1, it0, rtol=1e-4)
+    np.testing.assert_allclose(out1, out0, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(m1, m0, rtol=1e-4, atol=2e-5)
+    mc = base + ["-iter", "30", "-method", "mcmc"]
+    it0, out0, _, _ = _run_libfm(STOCK, td, "stock_mcmc", mc)
+    it1, out1, _, _ = _run_libfm(PATCHED, td, "gpu_mcmc", mc + ["-gpu", "1"])
+    assert it0.shape == it1.shape == (30, 2)
+    assert abs(it1[-1, 1] - it0[-1, 1]) <= 0.01, (it1[-1], it0[-1])
+    assert np.sqrt(np.mean((out1 - out0) ** 2)) < 0.05

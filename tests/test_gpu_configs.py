@@ -54,7 +54,7 @@ def test_config1_sgd_n1e7_k32_nnz16(capi, oracle):
     src = oracle.synth_rows(606, 3_000_000, rows, nnz, n)
     d, m, ids = sub_model(oracle, h, src.entries, src.row_ptr, src.target, k, (0.0, 0.0, 0.001))
     st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)
-    assert st.batch_used == 262144 and st.status == 0 and st.batches == 2
+    assert st.batch_used == 262144 and st.status & capi.STAT_WARN == 0 and st.batches == 2
     assert st.deferred_features > 1.5 * rows                      # most examples leave their sums behind at this shape
     oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, 262144, st.w0_chunk_used, bias_lag=lag)
     assert_rows(h, m, ids)

@@ -99,7 +99,7 @@ def test_fused_minibatch_at_the_bench_batch_against_oracle(capi, oracle):
     h.synth_rows(0, 2024, 40_000_000, rows, NNZ)
     d, m, ids = submodel_minibatch(capi, oracle, h, 2024, 40_000_000, rows, batch, capi.default_w0_chunk(0.01, 1), lag)
     st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)       # batch 0 / chunk 0: what bench.py passes
-    assert st.batch_used == batch and st.status == 0 and st.batches == 2 and st.w0_chunk_used == capi.default_w0_chunk(0.01, 1) <= 64
+    assert st.batch_used == batch and st.status & capi.STAT_WARN == 0 and st.batches == 2 and st.w0_chunk_used == capi.default_w0_chunk(0.01, 1) <= 64
     assert 1.0 * rows < st.deferred_features < 1.5 * rows
     w, v = h.get_param_rows(ids)
     np.testing.assert_allclose(v, m.v, rtol=1e-4, atol=1e-6)

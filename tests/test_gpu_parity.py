@@ -179,7 +179,7 @@ def test_minibatch_kilo_chunks(capi, oracle, task, batch, chunk, lag):
 @pytest.mark.parametrize("scan", ["pit", "serial"])
 def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name, scan, monkeypatch):
     """the bias recurrence of batches beyond one wavefront's reach, in both device forms -- parallel in time (k_scan_pit: micro-chunks that are
-    powers of two up to 2048 on batches of 4097 .. 262 144 rows) and the one-wavefront chain (FMX_SCAN=serial: k_scan1 for multiples of 256 and,
+    powers of two up to 1024 -- PIT_MAX_CHUNK; (16385, 2048) takes the chain in both legs -- on batches of more than 4096 rows) and the one-wavefront chain (FMX_SCAN=serial: k_scan1 for multiples of 256 and,
     sub-piece form, 16 .. 128; k_scan otherwise): whole and ragged segments / tiles, a batch that starts at a row that is not a multiple of four
     (the dword path of the LDS-DMA fetch), with the multipliers written (two-pass form) and without (one-pass form), regression with the clamp
     active and classification -- against the oracle's rule."""
@@ -199,8 +199,14 @@ def test_tiled_recurrence_kernel(capi, oracle, task, batch, chunk, apply_name, s
     h.upload_rows(0, ent, row_ptr, y)
     ap = capi.APPLY_FUSED if apply_name == "fused" else capi.APPLY_SEGMENTED
     for _ in range(2):
-        h.sgd_epoch(0, capi.SGD_MINIBATCH, ap, batch, chunk, capi.FLAG_BIAS_LAG, 1)
+        st = h.sgd_epoch(0, capi.SGD_MINIBATCH, ap, batch, chunk, capi.FLAG_BIAS_LAG, 1)
         oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, chunk, bias_lag=1)
+    # which form of the recurrence actually ran (fmx_epoch_stats::status, ABI 7; round-5 advisor: nothing asserted it): the one-pass form of
+    # a batch below 32 768 rows carries the recurrence inside the deferred-feature launch (one wavefront) whatever the knob says
+    pit_expected = scan == "pit" and apply_name == "segmented" and chunk <= 1024 and (chunk & (chunk - 1)) == 0 and batch > 4096
+    assert bool(st.status & capi.STAT_SCAN_PIT) == pit_expected, (st.status, scan, apply_name, batch, chunk)
+    assert st.status & capi.STAT_SCAN_SERIAL or pit_expected      # (the ragged last batch of a pit leg may be short enough for the chain)
+    assert not st.status & (capi.STAT_SCAN_FALLBACK | capi.STAT_HANDOFF_TIMEOUT)
     w0, w, v = h.get_params()
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
@@ -237,6 +243,10 @@ def test_side_stream_recurrence_of_the_one_pass_form(capi, oracle, task, batch, 
     for _ in range(2):
         st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, chunk, capi.FLAG_EVENT_SYNC if events else 0, lag)
         assert st.batches == (rows + batch - 1) // batch and st.w0_chunk_used == used
+        # the ordering of the two streams that actually ran: events when asked for and at lag 1, the device-side hand-off otherwise
+        assert bool(st.status & capi.STAT_EVENT_SYNC) == (events or lag < 2), (st.status, events, lag)
+        assert bool(st.status & capi.STAT_SCAN_PIT) == (scan == "pit" and used <= 1024 and (used & (used - 1)) == 0)
+        assert not st.status & (capi.STAT_SCAN_FALLBACK | capi.STAT_HANDOFF_TIMEOUT)
         oracle.sgd_epoch_minibatch(m, d, task, lr, lo, hi, batch, used, bias_lag=lag)
     w0, w, v = h.get_params()
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5

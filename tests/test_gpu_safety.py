@@ -1,0 +1,158 @@
+"""GPU: the in-launch waits of the one-pass step are safe where they cannot be satisfied (round-5 verdict item 5, round-5 advisor).
+
+* the device-side hand-off between the launch stream and the recurrence's side stream needs both streams RESIDENT at the same time; under
+  serialised dispatch (AMD_SERIALIZE_KERNEL, a counter-collecting profiler) its waits would only be satisfied by later launches.  The handle
+  probes that once (k_concurrency_probe) and orders the streams with events instead: same numbers, normal time.
+* k_scan_pit's grid-wide exchanges need all of its workgroups resident: the launch is gated on the device's occupancy (incl. the shards of a
+  loopback group that run the same kernel next to it); an exchange that runs into its bound all the same hands the batch to ONE workgroup's
+  serial chain -- the result is still the rule's -- and the handle stops using the kernel.
+* batches longer than one k_scan_pit launch covers are solved in pieces."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import datagen
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from libfm_amd import capi as c
+    if c.load().fmx_device_count() == 0:
+        pytest.fail("no HIP device: the GPU tests must run on the MI355X box")
+    return c
+
+_CHILD = r'''
+import sys, json, time
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import datagen
+from libfm_amd import capi
+from oracle import oracle as O
+n, nnz, rows, k, batch, lag = 39996, 6, 90001, 8, 32768, 2
+ent, row_ptr, y = datagen.onehot_fields(n, nnz, rows, seed=77, classification=True)
+d = O.Data(ent, row_ptr, y)
+m = O.Model(n, k, True, True, 0.002, 0.001, 0.003)
+m.v[:] = O.init_values(5, n, k, 0.05); m.w0 = 0.05
+h = capi.Handle(n, k, True, True, 1, 0.002, 0.001, 0.003, 0.01, -1.0, 1.0)
+h.set_params(m.w0, m.w, m.v)
+h.upload_rows(0, ent, row_ptr, y)
+t0 = time.perf_counter()
+status = 0
+for _ in range(2):
+    st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, batch, 0, 0, lag)
+    status |= st.status
+    O.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, batch, st.w0_chunk_used, bias_lag=lag)
+h.synchronize()
+sec = time.perf_counter() - t0
+w0, w, v = h.get_params()
+ok = abs(w0 - m.w0) <= 1e-4 * abs(m.w0) + 1e-5 and np.allclose(w, m.w, rtol=1e-4, atol=1e-5) and np.allclose(v, m.v, rtol=1e-4, atol=1e-5)
+print(json.dumps({"ok": bool(ok), "status": int(status), "seconds": sec}))
+'''
+
+
+def _child(env_extra):
+    import json
+    env = dict(os.environ, **env_extra)
+    code = _CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_epoch_under_serialized_dispatch_takes_events_and_the_oracles_numbers(capi):
+    """AMD_SERIALIZE_KERNEL=3: every launch completes before the next one starts -- the two streams never run side by side.  The handle's
+    probe sees that, the epoch orders its streams with events (FMX_STAT_EVENT_SYNC), lands on the oracle's rule at 1e-4, and takes normal
+    time (the hand-off's waits used to run into seconds-long bounds per batch); the same process without the variable takes the hand-off."""
+    plain = _child({})
+    assert plain["ok"] and not plain["status"] & capi.STAT_EVENT_SYNC and not plain["status"] & capi.STAT_HANDOFF_TIMEOUT, plain
+    ser = _child({"AMD_SERIALIZE_KERNEL": "3"})
+    assert ser["ok"], ser
+    assert ser["status"] & capi.STAT_EVENT_SYNC and not ser["status"] & capi.STAT_HANDOFF_TIMEOUT, ser
+    assert ser["seconds"] < max(10.0, 20 * plain["seconds"]), (ser, plain)      # (oracle epochs included on both sides)
+
+
+def _rule_case(oracle, rows, n=39996, nnz=6, k=8, seed=5):
+    ent, row_ptr, y = datagen.onehot_fields(n, nnz, rows, seed=seed, classification=True)
+    d = oracle.Data(ent, row_ptr, y)
+    m = oracle.Model(n, k, True, True, 0.002, 0.001, 0.003)
+    m.v[:] = oracle.init_values(5, n, k, 0.05)
+    m.w0 = 0.05
+    return ent, row_ptr, y, d, m
+
+
+def _check(h, m):
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=1e-5)
+
+
+def test_an_exchange_that_gives_up_hands_the_batch_to_the_serial_chain(capi, oracle, monkeypatch):
+    """FMX_DEBUG_PIT_SPINS=0: every grid-wide exchange of k_scan_pit gives up at once (what a workgroup that is not resident looks like to the
+    others).  One workgroup claims the batch and evaluates the chain serially: the epoch still equals the oracle's rule, reports
+    FMX_STAT_SCAN_FALLBACK, and the next epoch of the handle takes the one-wavefront chain (no PIT bit) -- nothing fails, nothing hangs."""
+    monkeypatch.setenv("FMX_DEBUG_PIT_SPINS", "0")
+    n, k, rows, batch = 39996, 8, 50000, 20000
+    ent, row_ptr, y, d, m = _rule_case(oracle, rows)
+    h = capi.Handle(n, k, True, True, 1, 0.002, 0.001, 0.003, 0.01, -1.0, 1.0)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, row_ptr, y)
+    st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, 32, capi.FLAG_BIAS_LAG, 1)
+    assert st.status & capi.STAT_SCAN_PIT and st.status & capi.STAT_SCAN_FALLBACK, st.status
+    oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, batch, 32, bias_lag=1)
+    _check(h, m)
+    st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, batch, 32, capi.FLAG_BIAS_LAG, 1)
+    assert not st.status & capi.STAT_SCAN_PIT and st.status & capi.STAT_SCAN_SERIAL and not st.status & capi.STAT_SCAN_FALLBACK, st.status
+    oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, batch, 32, bias_lag=1)
+    _check(h, m)
+    h.close()
+
+
+def test_a_batch_longer_than_one_parallel_launch_is_solved_in_pieces(capi, oracle):
+    """an explicit batch of 300 000 rows at the default micro-chunk: two k_scan_pit launches, the bias handed from piece to piece (round-5
+    advisor: such batches silently took the one-wavefront chain, eight times the dependent steps at micro-chunk 32)."""
+    n, k, rows, batch = 39996, 8, 300000, 300000
+    ent, row_ptr, y, d, m = _rule_case(oracle, rows, seed=9)
+    h = capi.Handle(n, k, True, True, 1, 0.002, 0.001, 0.003, 0.002, -1.0, 1.0)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, row_ptr, y)
+    for ap, flags, lag in ((capi.APPLY_SEGMENTED, capi.FLAG_BIAS_LAG, 1), (capi.APPLY_FUSED, 0, 2)):
+        st = h.sgd_epoch(0, capi.SGD_MINIBATCH, ap, batch, 32, flags, lag)
+        assert st.status & capi.STAT_SCAN_PIT and not st.status & capi.STAT_SCAN_SERIAL, st.status
+        oracle.sgd_epoch_minibatch(m, d, 1, 0.002, -1.0, 1.0, batch, 32, bias_lag=lag)
+        _check(h, m)
+    h.close()
+
+
+def test_loopback_shards_whose_recurrences_do_not_fit_together_take_the_chain(capi, oracle):
+    """ten feature shards on ONE device, batch 262 144: every shard runs the batch's whole recurrence itself -- 10 x 32 workgroups of k_scan_pit
+    that spin on grid-wide counters do not fit 256 CUs together (round-5 advisor: they waited for each other into the seconds-long bound).
+    The launch is gated on the device's occupancy: this group takes the one-wavefront chain, four shards take k_scan_pit; same model."""
+    n, k, nnz, rows, batch = 60000, 8, 6, 262144, 262144
+    ent, row_ptr, y = datagen.onehot_fields(n, nnz, rows, seed=3, classification=True)
+    res = {}
+    for world in (10, 4):
+        hs = [capi.Handle(n, k, True, True, 1, 0.0, 0.0, 0.003, 0.002, -1.0, 1.0, device=0, shard_rank=r, shard_world=world, shard_hash=1) for r in range(world)]
+        g = capi.Group(hs)
+        for x in hs:
+            x.init_params(0.0, 0.05, 7)                        # (counter hash keyed by the GLOBAL feature id: the same model for every shard count)
+        g.upload_rows(0, ent, row_ptr, y)
+        st = g.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, batch, 32, capi.FLAG_BIAS_LAG, 2)
+        if world == 10:
+            assert st.status & capi.STAT_SCAN_SERIAL and not st.status & capi.STAT_SCAN_PIT, st.status
+        else:
+            assert st.status & capi.STAT_SCAN_PIT, st.status
+        assert not st.status & (capi.STAT_SCAN_FALLBACK | capi.STAT_HANDOFF_TIMEOUT)
+        res[world] = g.predict(0, rows)
+        g.close()
+        for x in hs:
+            x.close()
+    np.testing.assert_allclose(res[10], res[4], rtol=RTOL, atol=2e-5)
