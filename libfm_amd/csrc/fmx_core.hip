@@ -786,6 +786,10 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     CREATE_CHK(hipMemsetAsync(h->pit_slots, 0, (size_t)2 * PIT_MAX_WG * 4 * sizeof(double), h->stream));
     const char* sc = getenv("FMX_SCAN");
     h->scan_pit = !(sc && strcmp(sc, "serial") == 0);
+    const char* xe = getenv("FMX_XCD");
+    h->xcd = (xe && xe[0] == '1');                              // opt-in: measured slower than the two launches per batch (profiles/r06_criteo_hops.txt)
+    const char* xb = getenv("FMX_XCD_MAX_BATCH");
+    if (xb) h->xcd_max_batch = (uint32_t)strtoul(xb, nullptr, 10);
     const char* sp = getenv("FMX_DEBUG_PIT_SPINS");
     h->pit_spins = sp ? (uint32_t)strtoul(sp, nullptr, 10) : HANDOFF_SPINS;
   }
@@ -849,6 +853,8 @@ int fmx_destroy(fmx_handle h) {
   if (h->w0_pp) fmx_dev_free(h->w0_pp);
   if (h->handoff_ctr) fmx_dev_free(h->handoff_ctr);
   if (h->pit_ctr) fmx_dev_free(h->pit_ctr);
+  if (h->xcd_sync) fmx_dev_free(h->xcd_sync);
+  if (h->xcd_trace) fmx_dev_free(h->xcd_trace);
   if (h->probe_flags) fmx_dev_free(h->probe_flags);
   if (h->pit_tmp) fmx_dev_free(h->pit_tmp);
   if (h->pit_slots) fmx_dev_free(h->pit_slots);

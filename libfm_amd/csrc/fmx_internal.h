@@ -41,6 +41,7 @@ struct Slot {
   uint32_t* seg_feat = nullptr;
   uint32_t* seg_rel = nullptr;
   uint32_t  nseg = 0;
+  bool      all_ones = false;        // every value of the slot is 1.0f (found while the segments are built)
   uint32_t  max_seg_count = 0;       // occurrences of the most frequent feature inside one batch
   std::vector<uint32_t> batch_seg;   // [n_batches+1] first segment of every batch
   std::vector<uint64_t> batch_base;  // [n_batches+1] first entry of every batch
@@ -169,6 +170,11 @@ struct fmx_context_s {
   uint32_t    run_status = 0;               // FMX_STAT_SCAN_* / _EVENT_SYNC / _HANDOFF_TIMEOUT of the running epoch (launch_scan, sgd_epoch_fused)
   int         concurrent = -1;              // do the handle's two streams run concurrently? -1: not probed yet (streams_concurrent)
   unsigned*   probe_flags = nullptr;        // device: 4 words of k_concurrency_probe
+  // the XCD-resident epoch (fmx_xcd_kernels.h): small batches as one launch on one die
+  unsigned*   xcd_sync = nullptr;           // device: XCD_CTL_WORDS control words + XCD_MAX_MEMBERS barrier words
+  bool        xcd = false;                  // FMX_XCD=1 at fmx_create (opt-in: it measured SLOWER than the two launches per batch, profiles/r06_criteo_hops.txt); cleared when a launch could not assemble its members
+  uint32_t    xcd_max_batch = 4096;         // FMX_XCD_MAX_BATCH: larger batches are bandwidth, not latency -- they take the chip-wide launches
+  unsigned long long* xcd_trace = nullptr;  // FMX_XCD_TRACE=<file>: time stamps of the first batches
   uint32_t    pit_spins = 0;                // bound of a grid-wide exchange's wait (fmx_create: HANDOFF_SPINS, or FMX_DEBUG_PIT_SPINS from the environment)
   int         pit_occ = -1;                 // workgroups of k_scan_pit the device holds at once (occupancy x CUs); -1: not asked yet
   double*     pit_tmp = nullptr;            // bias between the pieces of a batch longer than PIT_MAX_ROWS

@@ -235,6 +235,19 @@ template <class T> __device__ __forceinline__ T load_stream8(const T* p) {
   return *p;
 }
 __device__ __forceinline__ float load_w(const float* p) { return *p; }
+// loads that are served by the L2 -- they bypass the per-CU L1, which no other CU's store ever refreshes: what a persistent kernel reads the
+// words of other workgroups OF ITS OWN DIE with (fmx_xcd_kernels.h).  Two forms skip the L1 (scripts/ubench/load_flavours.hip: 105-110 ns
+// per dependent load for either, 72 ns for an L1 hit): device scope (sc1) keeps the line in the L2 like a plain load -- for what is read
+// again soon (frequent rows, sums, multipliers, flags); non-temporal marks it to be evicted first -- for the rows that pass through once
+// (ld_l2_stream), so that they do not push the frequent rows out of the die's 4 MiB (profiles/r06_criteo_hops.txt).
+__device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_l2(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_l2(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float ld_l2_stream(const float* p) { return __builtin_nontemporal_load(p); }
+// (words that cross dies -- the membership counters of a launch -- are read at device scope)
+__device__ __forceinline__ unsigned ld_dev(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // loss multiplier, fm_learn_sgd_element.h:58-65
 __device__ __forceinline__ float multiplier(const Hyper& h, float p, float y) {
   if (h.task == 0) {
@@ -1340,10 +1353,12 @@ struct CDesc { uint32_t feat, a, b, loc; uint32_t e0; float x0; uint32_t e1; flo
 // (== TEntry in memory)
 static __global__ void __launch_bounds__(256)
 k_seg_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint32_t B, uint32_t fbits,
-           uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+           uint64_t* __restrict__ keys, uint64_t* __restrict__ vals, uint32_t* __restrict__ not_ones) {
+  // *not_ones is raised when an entry's value is not 1.0f: one-hot data (libFM's usual input) takes the multiplication-free row arithmetic
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  bool other = false;
   for (uint32_t r = wave0; r < n_rows; r += nwaves) {
     const uint64_t a = row_ptr[r], b = row_ptr[r + 1];
     const uint64_t hi = (uint64_t)(r / B) << fbits;
@@ -1352,8 +1367,10 @@ k_seg_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, 
       const Entry e = ent[i];
       keys[i] = hi | e.id;
       vals[i] = ((uint64_t)__float_as_uint(e.value) << 32) | eb;
+      other |= (e.value != 1.0f);
     }
   }
+  if (other) atomicOr(not_ones, 1u);
 }
 static __global__ void __launch_bounds__(256)
 k_seg_heads(const uint64_t* __restrict__ keys, uint64_t nnz, uint32_t* __restrict__ flags) {
@@ -1719,9 +1736,11 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
 // thousand examples) on one wavefront, straight from global memory -- k_scan's arithmetic (micro-chunks of `chunk` examples, every
 // example of a chunk sees the bias of the chunk start, fm_sgd.h:34-37 summed per chunk) without its LDS tiles
 struct ScanSmall { const float* rest; const float* target; const double* w0_in; double* w0_out; uint32_t n_rows, chunk; };
+// COH: rest[] and the incoming bias were written by other workgroups of THIS launch (the XCD-resident epoch): L2-served loads
+template <bool COH = false>
 __device__ __forceinline__ void scan_small(const ScanSmall sc, const Hyper& h) {
   const uint32_t lane = threadIdx.x & 63u;
-  double w0 = *sc.w0_in;
+  double w0 = COH ? ld_l2(sc.w0_in) : *sc.w0_in;
   if (sc.n_rows <= 1024u && ((sc.chunk & 63u) == 0 || sc.chunk == 32u || sc.chunk == 16u)) {
     // the whole batch in registers first (one round trip to memory, not one per micro-chunk): element c0 + i + 64 j of a chunk
     // sits in lane i, register (c0 / 64 + j)
@@ -1729,7 +1748,7 @@ __device__ __forceinline__ void scan_small(const ScanSmall sc, const Hyper& h) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const uint32_t i = (uint32_t)j * 64u + lane;
-      r[j] = (i < sc.n_rows) ? sc.rest[i] : 0.f;
+      r[j] = (i < sc.n_rows) ? (COH ? ld_l2(sc.rest + i) : sc.rest[i]) : 0.f;
       y[j] = (i < sc.n_rows) ? sc.target[i] : 0.f;
     }
     if (sc.chunk < 64u) {
@@ -1770,7 +1789,7 @@ __device__ __forceinline__ void scan_small(const ScanSmall sc, const Hyper& h) {
       const uint32_t nc = min(sc.chunk, sc.n_rows - c0);
       const float w0s = h.k0 ? (float)w0 : 0.f;
       float acc = 0.f;
-      for (uint32_t i = lane; i < nc; i += 64) acc += multiplier_fast(h, w0s + sc.rest[c0 + i], sc.target[c0 + i]);
+      for (uint32_t i = lane; i < nc; i += 64) acc += multiplier_fast(h, w0s + (COH ? ld_l2(sc.rest + c0 + i) : sc.rest[c0 + i]), sc.target[c0 + i]);
       const float tot = wave_sum_dpp(acc);
       if (h.k0) w0 -= (double)h.lr * ((double)tot + (double)nc * (double)h.reg0 * (double)w0s);
     }

@@ -1,6 +1,7 @@
 // fmx_sgd.hip -- C-ABI (include/fmx.h): the SGD family -- sequential / minibatch / hogwild epochs, the split step of
 // the multi-GPU driver, the bias-lag bookkeeping, the (batch, feature) segment build, and SGDA.
 #include "fmx_internal.h"
+#include "fmx_xcd_kernels.h"
 
 namespace {
 // default micro-chunk of the bias recurrence.  The reference moves w0 after EVERY example (fm_sgd.h:34-37); summing the
@@ -215,7 +216,7 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
     s.fused_cap = cap;
     SEG_CHK(hipMemsetAsync(d_counts, 0, 16, st));
     if (nnz) {
-      hipLaunchKernelGGL(k_seg_keys, dim3(wave_grid(s.n_rows)), dim3(256), 0, st, s.ent, s.row_ptr, s.n_rows, B, fbits, keys_a, vals_a);
+      hipLaunchKernelGGL(k_seg_keys, dim3(wave_grid(s.n_rows)), dim3(256), 0, st, s.ent, s.row_ptr, s.n_rows, B, fbits, keys_a, vals_a, d_counts + 3);
       size_t tb_ = tmp_bytes;
       SEG_CHK(hipcub::DeviceRadixSort::SortPairs(tmp, tb_, keys_a, keys_b, vals_a, vals_b, (int)nnz, 0, (int)fbits + bits_batch, st));
       hipLaunchKernelGGL(k_seg_heads, dim3(2048), dim3(256), 0, st, keys_b, nnz, flags);
@@ -241,7 +242,7 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
       SEG_CHK(hipStreamSynchronize(st));                         // host synchronisation 1 of 2: the sizes of the slot's arrays
       tp("scan + mark + counts");
       const uint32_t nseg = counts[0];
-      s.nseg = nseg; s.ncseg = counts[1]; s.max_seg_count = counts[2];
+      s.nseg = nseg; s.ncseg = counts[1]; s.max_seg_count = counts[2]; s.all_ones = counts[3] == 0u;
       SEG_CHK(fmx_dev_alloc(&s.seg_feat, (size_t)std::max<uint32_t>(nseg, 1) * 4));
       SEG_CHK(fmx_dev_alloc(&s.seg_rel, (size_t)std::max<uint32_t>(nseg, 1) * 4));
       SEG_CHK(fmx_dev_alloc(&s.cseg, (size_t)std::max<uint32_t>(s.ncseg, 1) * 4));
@@ -252,7 +253,7 @@ extern "C++" int ensure_segments(fmx_handle h, Slot& s, uint32_t B) {
       hipLaunchKernelGGL(k_seg_cbatch, dim3((n_batches + 256) / 256), dim3(256), 0, st, cpos, cflag, nseg, s.d_batch_seg, n_batches, s.d_cbatch);
       SEG_CHK(hipGetLastError());
     } else {
-      s.nseg = 0; s.ncseg = 0; s.max_seg_count = 0;
+      s.nseg = 0; s.ncseg = 0; s.max_seg_count = 0; s.all_ones = false;
       SEG_CHK(hipMemsetAsync(s.d_batch_seg, 0, nb1 * 4, st));
       SEG_CHK(hipMemsetAsync(s.d_cbatch, 0, nb1 * 4, st));
       SEG_CHK(hipMemsetAsync(s.d_batch_base, 0, nb1 * 8, st));
@@ -659,6 +660,86 @@ int fmx_predict_finish(fmx_handle h, uint32_t n_rows, const float* d_partial, fl
   return FMX_OK;
 }
 
+// ---- the XCD-resident epoch (fmx_xcd_kernels.h): every batch of the epoch in ONE launch whose workgroups sit on one die ----
+// returns FMX_OK with *ran = true when the epoch has been computed; *ran = false: nothing was touched (not eligible, or the launch could not
+// assemble its members -- the handle then stops trying) and the caller runs the two launches per batch
+static int xcd_epoch(fmx_handle h, Slot& s, const Hyper& hy, uint32_t B, uint32_t d, uint32_t chunk, uint64_t n_batch, bool* ran) {
+  *ran = false;
+  if (!h->xcd || B > h->xcd_max_batch || (h->KP != 64 && h->KP != 128) || s.max_row > 64u || !s.d_cbatch || !s.d_batch_base) return FMX_OK;
+  hipStream_t st = h->stream;
+  const uint32_t Bc = std::min<uint32_t>(B, s.n_rows);
+  if (!h->xcd_sync) HIPCHK(h, fmx_dev_alloc(&h->xcd_sync, (XCD_CTL_WORDS + XCD_MAX_MEMBERS) * sizeof(unsigned)));
+  static const char* trace_file = getenv("FMX_XCD_TRACE");
+  const uint32_t trace_batches = trace_file ? (uint32_t)std::min<uint64_t>(n_batch, 256) : 0u;
+  if (trace_file && !h->xcd_trace) {
+    HIPCHK(h, fmx_dev_alloc(&h->xcd_trace, 256 * 16 * sizeof(unsigned long long)));
+  }
+  if (trace_file) HIPCHK(h, hipMemsetAsync(h->xcd_trace, 0, 256 * 16 * sizeof(unsigned long long), st));
+  XcdEpoch ep;
+  ep.ent = s.ent; ep.row_ptr = s.row_ptr; ep.target = s.target; ep.cmask = (const uint64_t*)s.cmask;
+  ep.fixed_nnz = s.fixed_nnz; ep.n_rows = s.n_rows; ep.B = B; ep.n_batch = (uint32_t)n_batch; ep.d = d; ep.chunk = chunk; ep.Bc = Bc;
+  ep.cbatch = s.d_cbatch; ep.batch_base = s.d_batch_base; ep.t_ent = s.t_ent; ep.cdesc = s.cdesc;
+  ep.S = h->partial; ep.mult = h->mult; ep.rest = h->rest; ep.w0_ring = h->w0_pp;
+  { static const char* xf = getenv("FMX_XCD_FLAGS"); ep.flags = xf ? (uint32_t)strtoul(xf, nullptr, 10) : 0u; }
+  ep.trace = trace_file ? h->xcd_trace : nullptr; ep.trace_batches = trace_batches;
+  const XcdSync sy{h->xcd_sync, h->xcd_sync + XCD_CTL_WORDS, h->handoff_err, 1u << 22};
+  HIPCHK(h, hipMemsetAsync(h->xcd_sync, 0, (XCD_CTL_WORDS + XCD_MAX_MEMBERS) * sizeof(unsigned), st));
+  bool launched = false;
+  uint32_t grid_used = 0;
+#define FMX_XCD_LAUNCH1(KPV, ZRV, ON) do { auto kf = k_xcd_epoch<KPV, ZRV, ON>;                                                            \
+    int per_cu = 0;                                                                                                                        \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kf, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; } \
+    per_cu = std::min(per_cu, 4);        /* every workgroup of the launch must be resident: the member count is final only then */          \
+    if (per_cu >= 1) { const uint32_t grid = std::min<uint32_t>((uint32_t)per_cu * (uint32_t)h->num_cu, 8u * XCD_MAX_MEMBERS);              \
+      hipLaunchKernelGGL(kf, dim3(grid), dim3(256), 0, st, ep, h->tb, hy, sy); launched = true; grid_used = grid; } } while (0)
+#define FMX_XCD_LAUNCH(KPV, ZRV) do { if (h->KP == KPV && zr == ZRV) { if (s.all_ones) FMX_XCD_LAUNCH1(KPV, ZRV, true); else FMX_XCD_LAUNCH1(KPV, ZRV, false); } } while (0)
+  int zr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
+  if (s.max_row > (uint32_t)zr) return FMX_OK;                                   // (rows beyond the register path)
+  if (zr == 8) zr = 16;                                                         // (three instances per row width: 16, 40, 64 row slots)
+  if (zr == 32) zr = 40;
+  FMX_XCD_LAUNCH(64, 16);  FMX_XCD_LAUNCH(64, 40);  FMX_XCD_LAUNCH(64, 64);
+  FMX_XCD_LAUNCH(128, 16); FMX_XCD_LAUNCH(128, 40); FMX_XCD_LAUNCH(128, 64);
+#undef FMX_XCD_LAUNCH1
+#undef FMX_XCD_LAUNCH
+  if (!launched) return FMX_OK;
+  HIPCHK(h, hipGetLastError());
+  unsigned ctl[XCD_CTL_WORDS];
+  HIPCHK(h, hipMemcpyAsync(ctl, h->xcd_sync, sizeof(ctl), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (ctl[4] != 1u) {            // the members never saw every workgroup start (the device is shared, partitioned or profiled): nothing was touched
+    h->xcd = false;
+    return FMX_OK;
+  }
+  uint32_t e = 0;
+  HIPCHK(h, hipMemcpy(&e, h->handoff_err, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (e & XCD_ERR_BARRIER) {
+    const uint32_t rest_bits = e & ~XCD_ERR_BARRIER;
+    (void)hipMemcpy(h->handoff_err, &rest_bits, sizeof(uint32_t), hipMemcpyHostToDevice);
+    h->xcd = false;
+    return fail(h, FMX_E_HIP, "the XCD-resident epoch gave up at a barrier (%u members on die %u): the epoch is incomplete -- reload the parameters; "
+                              "the handle takes the two launches per batch from now on", ctl[1], ctl[0] ? ctl[0] - 1u : 0u);
+  }
+  if (trace_file) {
+    std::vector<unsigned long long> tr((size_t)trace_batches * 16);
+    HIPCHK(h, hipMemcpy(tr.data(), h->xcd_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_file, "a")) {
+      fprintf(f, "# XCD-resident epoch: grid %u workgroups, die %u, %u member workgroups (%u wavefronts), batch %u, %llu batches; member 0 / wavefront 0, 10 ns ticks -> us\n"
+                 "# columns (us): batch | examples: gather, rest | arrive | shadow: asked-for data here, then wait | owners: lists+multipliers, first sums rows, rest of the lockstep items, others | arrive | shadow: touches here, then wait | total\n",
+              grid_used, ctl[0] - 1u, ctl[1], ctl[1] * 4u, B, (unsigned long long)n_batch);
+      auto us = [](unsigned long long a, unsigned long long b) { return (b >= a && a) ? (double)(b - a) * 0.01 : 0.0; };
+      for (uint32_t b = 0; b < trace_batches; b++) {
+        const unsigned long long* t = tr.data() + (size_t)b * 16;
+        fprintf(f, "%6u | %5.2f %5.2f | %5.2f | %5.2f %5.2f | %5.2f %5.2f %5.2f %5.2f | %5.2f | %5.2f %5.2f | %6.2f\n", b,
+                us(t[0], t[8]), us(t[8], t[1]), us(t[1], t[2]), us(t[2], t[12]), us(t[12], t[3]),
+                us(t[3], t[9]), us(t[9], t[10]), us(t[10], t[11]), us(t[11], t[4]), us(t[4], t[5]), us(t[5], t[13]), us(t[13], t[6]), us(t[0], t[6]));
+      }
+      fclose(f);
+    }
+  }
+  *ran = true;
+  return FMX_OK;
+}
+
 // MINIBATCH rule, FMX_APPLY_FUSED: per batch ONE pass over the examples (k_fused<FUSED_EXACT>: gather, predict, multiplier,
 // write-back of every feature that occurs once in the batch) + k_apply_seg over the features that occur more than once.
 // The multipliers of batch b use the bias as it was after the recurrence of batch b - d (d = opts->bias_lag >= 1; oracle
@@ -727,6 +808,20 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     sw->cdesc = s.cdesc + c0;
     sw->done_ctr = nullptr; sw->done_val = 0ull;
   };
+  if (!side && !keep) {
+    bool ran = false;
+    rc = xcd_epoch(h, s, hy, B, d, chunk, n_batch, &ran);
+    if (rc) return rc;
+    if (ran) {
+      for (uint64_t b = 0; b < n_batch; b++) *deferred += s.cbatch[(size_t)b + 1] - s.cbatch[(size_t)b];
+      *batches += n_batch; *launches += 1;
+      h->run_status |= FMX_STAT_XCD_RESIDENT;
+      if (hy.k0) HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (n_batch % d), sizeof(double), hipMemcpyDeviceToDevice, st));
+      return FMX_OK;
+    }
+    HIPCHK(h, hipEventRecord(h->ev0, st));                  // (not eligible / could not start: the epoch's clock starts over)
+    for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
   for (uint64_t b = 0; b < n_batch; b++) {
     const uint64_t row0 = b * B;
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
