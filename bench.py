@@ -397,7 +397,7 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def bench_group(args, capi, criteo):
+def run_group(args, capi, criteo):
     """--gpus N from ONE process (the shape libFM has, libfm.cpp:271-293,415): N feature shards, one handle each, tied together by
     fmx_group_create -- RCCL between distinct devices, the loopback reduction when they share one (--same-device: the N > 1 code
     path on a one-GPU box) -- and driven by fmx_group_sgd_epoch.  The rule is the one N = 1 runs."""
@@ -472,7 +472,11 @@ def bench_group(args, capi, criteo):
     g.close()
     for h in hs:
         h.close()
-    print(json.dumps(out), flush=True)
+    return out
+
+
+def bench_group(args, capi, criteo):
+    print(json.dumps(run_group(args, capi, criteo)), flush=True)
 
 
 def main():
@@ -914,6 +918,20 @@ def main():
                 out[key] = {kk: o[kk] for kk in keep + ("one_time_setup_seconds",) if kk in o}
             except Exception as exc:
                 out[key] = {"error": str(exc)[:200]}
+        # BASELINE configs[2] AS IT IS WORDED ("V row-sharded across 8"): eight feature shards driven by fmx_group_sgd_epoch -- on this one GPU
+        # through the loopback exchange, so the eight shards' launches of a batch run one after the other on the device (a real node runs them
+        # side by side): the figure is the schedule's cost per 512-row batch, not a scaling number
+        try:
+            ga = argparse.Namespace(gpus=8, same_device=True, n=33_000_000, k=64, nnz=39, rows=1 << 17, steps=2, warmup=1, place=args.place,
+                                    exchange="allreduce", no_bias_lag=False, pipeline=False, bias_lag=2, batch=0, w0_chunk=0)
+            o = run_group(ga, capi, True)
+            out["criteo_8shard"] = {kk: o[kk] for kk in ("metric", "value", "unit", "n_gpus", "ms_per_step", "steps", "dtype", "config", "roofline", "exchange",
+                                                          "phases_ms_per_batch") if kk in o}
+            out["criteo_8shard"]["launches_per_shard_and_batch"] = 3
+            out["criteo_8shard"]["note"] = ("8 loopback shards on ONE device: 25 dependent launches per 512-row batch in one stream (1 sums + 2 update launches per shard, "
+                                            "1 reduction); round 5's general schedule made ~20 host calls per shard and batch (FMX_GROUP_IN_STREAM=0)")
+        except Exception as exc:
+            out["criteo_8shard"] = {"error": str(exc)[:200]}
         # the per-rank compute side of the sharded step at P = 2 / 4 / 8 (the only part of the 1/2/4/8-GPU metric one GPU can measure)
         try:
             out["shard_probe"] = shard_probe(capi, args.n, args.k, args.nnz, out["value"])

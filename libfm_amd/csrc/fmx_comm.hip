@@ -185,8 +185,22 @@ static int rccl_sum_piece(fmx_group g, int which, size_t off, size_t cnt, size_t
 //   RCCL: in-place all-reduce on the shard's own COMM stream (ordered behind the gather by an event), so that it can run
 //         under whatever the compute stream does next (FMX_FLAG_PIPELINE: the update of the previous batch);
 //   loopback (all shards on one device): a reduction kernel on shard 0's stream that leaves the sum in every shard's buffer.
-static int exchange_begin(fmx_group g, int which, size_t count) {
+// in_stream (small batches, fmx_group_sgd_epoch): no comm stream and no events -- RCCL: the all-reduce is enqueued on the shard's compute stream;
+// loopback: every shard's launches of the batch are on shard 0's stream already
+static int exchange_begin(fmx_group g, int which, size_t count, bool in_stream = false) {
   const size_t n = g->hs.size();
+  if (g->kind == GROUP_RCCL && in_stream) {
+    Rccl* R = rccl();
+    if (n > 1) NCCLCHK(g->hs[0], R->GroupStart());
+    for (size_t i = 0; i < n; i++) {
+      fmx_handle h = g->hs[i];
+      HIPCHK(h, hipSetDevice(h->device));
+      float* b = h->xbuf[which];
+      NCCLCHK(h, R->AllReduce(b, b, count, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream));
+    }
+    if (n > 1) NCCLCHK(g->hs[0], R->GroupEnd());
+    return FMX_OK;
+  }
   if (g->kind == GROUP_RCCL) {
     Rccl* R = rccl();
     for (size_t i = 0; i < n; i++) {
@@ -207,7 +221,7 @@ static int exchange_begin(fmx_group g, int which, size_t count) {
     BufList bl; bl.n = (int)n;
     for (size_t i = 0; i < n; i++) {
       bl.p[i] = g->hs[i]->xbuf[which];
-      if (i) { HIPCHK(h0, hipEventRecord(g->ev_part[i], g->hs[i]->stream)); HIPCHK(h0, hipStreamWaitEvent(h0->stream, g->ev_part[i], 0)); }
+      if (i && !in_stream) { HIPCHK(h0, hipEventRecord(g->ev_part[i], g->hs[i]->stream)); HIPCHK(h0, hipStreamWaitEvent(h0->stream, g->ev_part[i], 0)); }
     }
     if (h0->cfg.exchange_algo == FMX_EXCHANGE_RS_AG && count % (4 * n) == 0 && count > 0) {       // the two-phase form of the same sum
       const size_t n4 = count / 4 / n;
@@ -218,8 +232,10 @@ static int exchange_begin(fmx_group g, int which, size_t count) {
     hipLaunchKernelGGL(k_sum_shards, dim3((unsigned)std::min<size_t>((count / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, h0->stream,
                        bl, count / 4, count);
     HIPCHK(h0, hipGetLastError());
-    HIPCHK(h0, hipEventRecord(g->ev_sum, h0->stream));
-    for (size_t i = 1; i < n; i++) HIPCHK(h0, hipStreamWaitEvent(g->hs[i]->stream, g->ev_sum, 0));
+    if (!in_stream) {
+      HIPCHK(h0, hipEventRecord(g->ev_sum, h0->stream));
+      for (size_t i = 1; i < n; i++) HIPCHK(h0, hipStreamWaitEvent(g->hs[i]->stream, g->ev_sum, 0));
+    }
   }
   return FMX_OK;
 }
@@ -244,8 +260,8 @@ static int exchange_rows(fmx_group g, int which, size_t off_s, size_t cnt_s, siz
     }
   return FMX_OK;
 }
-static int exchange_end(fmx_group g, int which) {
-  if (g->kind == GROUP_RCCL)
+static int exchange_end(fmx_group g, int which, bool in_stream = false) {
+  if (g->kind == GROUP_RCCL && !in_stream)
     for (fmx_handle h : g->hs) { HIPCHK(h, hipSetDevice(h->device)); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_x[2 + which], 0)); }
   return FMX_OK;
 }
@@ -680,9 +696,23 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
   // a row do not depend on the other rows of the batch: nothing changes in the rule).  fmx_config::exchange_runs: runs per batch
   // (1 = one exchange per batch, as the loopback exchange always does).
   const uint32_t xchunks = g->hs[0]->cfg.exchange_runs ? g->hs[0]->cfg.exchange_runs : 4u;
+  // small batches (BASELINE configs[2] as it is worded: Criteo-shaped rows over 8 shards run 512 rows per batch): a batch is a few microseconds
+  // of work per shard, so every call the host makes for it counts.  In-stream schedule: one launch for the shard's sums, the exchange
+  // without a comm stream or events (RCCL: on the compute stream; loopback: every shard's launches go to shard 0's stream, in order), two
+  // launches for the update (sgd_finish_impl): 3 launches (+ 1 collective call) per shard and batch where the general schedule makes ~20 calls.
+  // FMX_GROUP_IN_STREAM=0 keeps the general schedule.
+  static const bool in_stream_ok = []() { const char* e = getenv("FMX_GROUP_IN_STREAM"); return !(e && e[0] == '0'); }();
+  bool small = in_stream_ok && B < 32768u && (opts.flags & FMX_FLAG_BIAS_LAG) && !pipeline && !(opts.flags & FMX_FLAG_TIME_MAIN_KERNEL && false);
+  if (small)
+    for (auto m : g->hs) small = small && multi_group_size(m->slots[slot], m->KP) != 0 && (opts.apply == FMX_APPLY_DEFAULT || opts.apply == FMX_APPLY_FUSED);
+  auto stream_of = [&](size_t i) -> void* { return (small && g->kind == GROUP_LOOPBACK) ? (void*)h0->stream : (void*)g->hs[i]->stream; };
   auto gather = [&](uint64_t b) -> int {
     const uint32_t nb = rows_of(b);
     const int which = (int)(b & 1);
+    if (small) {
+      for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_partial(cur, slot, b * B, nb, cur->xbuf[which], stream_of(i))); }
+      return exchange_begin(g, which, (size_t)nb * kp1, true);
+    }
     if (g->kind == GROUP_RCCL && xchunks > 1 && nb >= 64 * xchunks) {
       const uint32_t step = ((nb + xchunks - 1) / xchunks + 63u) & ~63u;
       for (uint32_t r0 = 0; r0 < nb; r0 += step) {
@@ -719,11 +749,11 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     return erc;
   };
   auto update = [&](uint64_t b) -> int {
-    int erc = exchange_end(g, (int)(b & 1));
+    int erc = exchange_end(g, (int)(b & 1), small);
     if (erc) return erc;
     erc = mark(b, 2);
     if (erc) return erc;
-    for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_finish(cur, slot, b * B, rows_of(b), sum_of(g, i, (int)(b & 1)), &opts, cur->stream)); }
+    for (size_t i = 0; i < n; i++) { cur = g->hs[i]; GCHK(g, fmx_sgd_finish(cur, slot, b * B, rows_of(b), sum_of(g, i, (int)(b & 1)), &opts, stream_of(i))); }
     return mark(b, 3);
   };
   int rc = FMX_OK;

@@ -115,6 +115,7 @@ struct LagState {                 // FMX_FLAG_BIAS_LAG bookkeeping (split step):
   uint64_t   step = 0;
   uint32_t   depth = 1;           // batches the multipliers' bias lags behind (fmx_sgd_opts::bias_lag)
   hipEvent_t ev_rest = nullptr, ev_scan[RING] = {};
+  hipStream_t in_stream = nullptr;  // small batches: the recurrences ride in the update's launches on THIS stream (not the side stream): lag_flush drains it
 };
 
 struct SgdaState { float* gw = nullptr; float* gv = nullptr; double* reg = nullptr; double* dreg = nullptr;   // dreg: [workgroups][G][1 + KP] partial lambda changes
@@ -229,6 +230,7 @@ int sgd_resolve_batch(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, fmx_batch
 int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st);   // fmx_sgd.hip
 int lag_flush(fmx_handle h);                                             // fmx_sgd.hip
 int scan_error_check(fmx_handle h);                                      // fmx_sgd.hip: the device's error word after k_scan_pit launches (streams drained)
+uint32_t multi_group_size(const Slot& s, int KP);                        // fmx_sgd.hip: examples per wavefront of the short-row kernels (0: rows are long)
 bool streams_concurrent(fmx_handle h);                                   // fmx_sgd.hip: probed once per handle
 void sgda_free(fmx_handle h);                                            // fmx_sgd.hip
 void als_free(fmx_handle h);                                             // fmx_als.hip

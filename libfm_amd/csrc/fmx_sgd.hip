@@ -29,18 +29,6 @@ template <int KP> uint32_t fused_row_cap_kp(uint32_t max_row) {
   return std::min<uint32_t>(64u, (uint32_t)fused_zr_select<KP>(max_row) * (uint32_t)Map<KP>::EPI);
 }
 
-// SHORT rows (a feature shard of P GPUs sees nnz / P entries per example): examples per wavefront of k_rowsums_multi / k_apply_multi --
-// about 24 entries per 32-slot round (mean + 1.7 sigma of a shard's binomial row lengths stays inside one round); 0 = rows are long enough
-// for the one-example-per-wavefront kernels (or KP < 64: several rows per wave-wide load, not built)
-uint32_t multi_group_size(const Slot& s, int KP) {
-  if (KP < 64 || s.n_rows == 0) return 0;
-  const double avg = (double)s.nnz / (double)s.n_rows;
-  if (avg > 12.0) return 0;
-  static const double fill = []() { const char* e = getenv("FMX_MULTI_FILL"); const double f = e ? atof(e) : 0.0; return (f >= 8.0 && f <= 32.0) ? f : 24.0; }();
-  const double g = avg > 0.0 ? fill / avg : (double)MULTI_GMAX;   // (FMX_MULTI_FILL: A/B knob for the probe, 8 .. 32)
-  return (uint32_t)std::max(2.0, std::min((double)MULTI_GMAX, std::floor(g)));
-}
-
 template <int KP, int VAR>
 int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0, uint32_t n_rows, hipStream_t st,
                     const double* w0_in, float* rest_out, const uint64_t* cmask = nullptr, float* S_out = nullptr,
@@ -62,6 +50,18 @@ int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0,
 }
 
 }  // namespace
+
+// SHORT rows (a feature shard of P GPUs sees nnz / P entries per example): examples per wavefront of k_rowsums_multi / k_apply_multi --
+// about 24 entries per 32-slot round (mean + 1.7 sigma of a shard's binomial row lengths stays inside one round); 0 = rows are long enough
+// for the one-example-per-wavefront kernels (or KP < 64: several rows per wave-wide load, not built)
+extern "C++" uint32_t multi_group_size(const Slot& s, int KP) {
+  if (KP < 64 || s.n_rows == 0) return 0;
+  const double avg = (double)s.nnz / (double)s.n_rows;
+  if (avg > 12.0) return 0;
+  static const double fill = []() { const char* e = getenv("FMX_MULTI_FILL"); const double f = e ? atof(e) : 0.0; return (f >= 8.0 && f <= 32.0) ? f : 24.0; }();
+  const double g = avg > 0.0 ? fill / avg : (double)MULTI_GMAX;   // (FMX_MULTI_FILL: A/B knob for the probe, 8 .. 32)
+  return (uint32_t)std::max(2.0, std::min((double)MULTI_GMAX, std::floor(g)));
+}
 
 extern "C" {
 
@@ -426,13 +426,16 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
 extern "C++" int lag_flush(fmx_handle h) {                      // make h->w0 the current bias again
   LagState& L = h->lag;
   if (!L.active) return FMX_OK;
+  if (L.in_stream) { HIPCHK(h, hipStreamSynchronize(L.in_stream)); L.in_stream = nullptr; }
   HIPCHK(h, hipStreamSynchronize(h->stream2));
   HIPCHK(h, hipMemcpy(h->w0, h->w0_pp + (L.step % (L.depth + 1)), sizeof(double), hipMemcpyDeviceToDevice));
   L.active = false; L.step = 0;
   return scan_error_check(h);                                 // (callers that drive fmx_sgd_partial / _finish themselves and then read parameters)
 }
+// the driver's batch is small (below the size at which the recurrence gets its own stream): in-stream schedule, see sgd_finish_impl
+static bool sgd_small_batch(const fmx_sgd_opts* opts) { return opts && opts->batch != 0 && opts->batch < 32768u && (opts->flags & FMX_FLAG_BIAS_LAG); }
 // call BEFORE producing the rest buffer of this step on `st`; returns which of the d + 1 rest buffers to use
-static int lag_prepare(fmx_handle h, hipStream_t st, uint32_t depth, int* slot) {
+static int lag_prepare(fmx_handle h, hipStream_t st, uint32_t depth, int* slot, bool in_stream = false) {
   LagState& L = h->lag;
   if (!L.ev_rest) {
     HIPCHK(h, hipEventCreateWithFlags(&L.ev_rest, hipEventDisableTiming));
@@ -443,7 +446,7 @@ static int lag_prepare(fmx_handle h, hipStream_t st, uint32_t depth, int* slot) 
     L.depth = depth;
     for (uint32_t r = 0; r <= depth; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
     L.active = true; L.step = 0;
-  } else if (L.step > depth) {
+  } else if (L.step > depth && !in_stream) {
     HIPCHK(h, hipStreamWaitEvent(st, L.ev_scan[(L.step - depth - 1) % LagState::RING], 0));   // recurrence (step - d - 1) is done with this rest buffer
   }
   *slot = (int)(L.step % (depth + 1));
@@ -520,6 +523,31 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
     // fused short-row step (bias-lag schedule on a feature shard): [wait for the bias of batch b - d] -> k_apply_multi<FUSED> (rest, multipliers,
     // update of the batch-unique features) -> the recurrence of this batch starts on the side stream -> the deferred features
     const uint32_t G = multi_group_size(s, h->KP);
+    if (sgd_small_batch(opts)) {
+      // small batches (what the stability cut leaves of rows with frequent features: BASELINE configs[2] runs 512 rows per batch): a batch is a
+      // few microseconds of work and every call the host makes for it costs as much again -- the recurrence leaves the side stream and rides
+      // in the launch of the deferred features (k_apply_seg_scan, as on an unsharded handle), no events: TWO launches per shard and batch.
+      // Same rule, same ring of bias slots: what a batch reads does not depend on which stream wrote it.
+      const LagState& L = h->lag;
+      const uint32_t R = L.depth + 1;
+      const size_t b = (size_t)seg_batch;
+      if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
+      KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_apply_multi<KP, true>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
+                                                                    h->tb, hy, lag_bias_slot(h), S, cpart, rest, h->mult, (const uint64_t*)s.cmask, G); } });
+      const uint32_t c0 = s.cbatch[b], c1 = s.cbatch[b + 1];
+      const uint32_t s0 = s.batch_seg[b], s1 = s.batch_seg[b + 1];
+      const uint64_t base = s.batch_base[b];
+      SegWork sw{s.t_ent + base, s.seg_feat + s0, s.seg_rel + s0, s.cseg + c0, c1 - c0, s1 - s0, (uint32_t)(s.batch_base[b + 1] - base), S, h->mult, s.cdesc + c0};
+      sw.done_ctr = nullptr; sw.done_val = 0ull;
+      const ScanSmall sc{rest, s.target + row0, h->w0_pp + (L.step % R), h->w0_pp + ((L.step + 1) % R), n_rows, chunk};
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_apply_seg_scan<KP, 8, 1>), dim3((sw.nseg + 3) / 4 + 1), dim3(256), 0, st, sw, h->tb, hy, sc));
+      h->lag.step++;
+      h->lag.in_stream = st;
+      h->run_status |= FMX_STAT_SCAN_SERIAL;
+      if (ev_b) HIPCHK(h, hipEventRecord(ev_b, st));
+      HIPCHK(h, hipGetLastError());
+      return FMX_OK;
+    }
     rc = lag_wait_bias(h, hy, st);
     if (rc) return rc;
     if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
@@ -616,9 +644,6 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
   if (lag_depth > 4) return fail(h, FMX_E_ARG, "bias_lag %u: at most 4 batches", lag_depth);
   rc = ensure_scratch(h, n_rows, (size_t)Bcap * (lag_depth + 1));
   if (rc) return rc;
-  int rslot = 0;
-  if (lag) { rc = lag_prepare(h, st, lag_depth, &rslot); if (rc) return rc; } else { rc = lag_flush(h); if (rc) return rc; }
-  float* rest_buf = h->rest + (size_t)rslot * Bcap;
   const float* S = d_partial;
   const float* c = d_partial + (size_t)n_rows * h->KP;
   int64_t seg_batch = -1;
@@ -632,6 +657,10 @@ int fmx_sgd_finish(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, const
     if (rc) return rc;
     seg_batch = (int64_t)(row0 / B);
   }
+  int rslot = 0;
+  if (lag) { rc = lag_prepare(h, st, lag_depth, &rslot, sgd_small_batch(opts) && short_row_update(h, s, opts, seg_batch)); if (rc) return rc; }
+  else { rc = lag_flush(h); if (rc) return rc; }
+  float* rest_buf = h->rest + (size_t)rslot * Bcap;
   // short rows under the bias-lag schedule: rest_e and the multipliers come out of the update kernel itself (no k_rest_from_partial, no k_mult)
   if (lag && short_row_update(h, s, opts, seg_batch))
     return sgd_finish_impl(h, s, row0, n_rows, S, rest_buf, opts, st, nullptr, nullptr, seg_batch, c);

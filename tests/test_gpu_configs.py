@@ -84,6 +84,42 @@ def test_config2_sgd_criteo_shaped_at_size(capi, oracle):
     h.close()
 
 
+def test_config2_eight_shards_criteo_shaped(capi, oracle):
+    """BASELINE configs[2] AS IT IS WORDED: 'Criteo-Kaggle-shaped: 3.3e7 features, k = 64, 39 entries per row, SGD, V row-sharded across 8':
+    eight feature shards (on one GPU: the loopback exchange) driven by fmx_group_sgd_epoch at the library's batch (512 rows at lr 0.01: the
+    in-stream schedule of small batches -- three launches per shard and batch) against ONE unsharded handle on the same rows and start
+    values, and against the oracle's rule on the sub-model of the touched features (1e-4).  The loop it stands for:
+    fm_learn_sgd_element.h:56-67."""
+    n, k, nnz, rows, lag, world = 33_000_000, 64, 39, 20_000, 2, 8
+    one = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+    one.init_params(0.0, 0.05, 19)
+    one.synth_rows(0, 123, 500_000, rows, nnz, capi.SYNTH_CRITEO)
+    ent, rp, y = one.download_rows(0)
+    d, m, ids = sub_model(oracle, one, ent, rp, y, k, (0.0, 0.0, 0.001))
+    bi = one.sgd_batch_info(0)
+    hs = [capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0, device=0, shard_rank=r, shard_world=world, shard_hash=1)
+          for r in range(world)]
+    for h in hs:
+        h.init_params(0.0, 0.05, 19)                              # (keyed by the GLOBAL feature id: a shard draws what the unsharded handle draws)
+        h.synth_rows(0, 123, 500_000, rows, nnz, capi.SYNTH_CRITEO)
+    grp = capi.Group(hs)
+    np.testing.assert_allclose(grp.predict(0, rows), one.predict(0, rows), rtol=1e-4, atol=2e-5)     # same start
+    for _ in range(2):
+        st1 = one.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)
+        st8 = grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, 0, 0, capi.FLAG_BIAS_LAG, lag)
+        assert st8.batch_used == st1.batch_used == bi.batch and 128 <= bi.batch <= 1024 and st8.batches == st1.batches >= 32
+        oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, bi.batch, st1.w0_chunk_used, bias_lag=lag)
+    p1, p8, po = one.predict(0, rows), grp.predict(0, rows), oracle.predict_raw(m, d)
+    assert np.abs(po).max() > 0.05
+    np.testing.assert_allclose(p1, po, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(p8, po, rtol=1e-4, atol=5e-5)
+    assert abs(hs[3].get_w0() - m.w0) <= 1e-4 * abs(m.w0) + 2e-5
+    grp.close()
+    for h in hs:
+        h.close()
+    one.close()
+
+
 def als_sub_model_sweeps(capi, oracle, n, k, nnz, rows, seed, sweeps, stdev=0.05):
     """`sweeps` iterations of fm_learn_mcmc with do_sample = 0 (fmx_als_sweep; split step on: every level holds `rows` >= 65 536
     entries) on the full-size table vs the oracle's learner (fmo_als_learn: fm_learn_mcmc.h:430-641 + _learn) on the sub-model"""
