@@ -83,7 +83,7 @@ k_als_eterms(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
             const uint32_t idx = i + u * EPI + g;
             const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
             xs[u] = bcast_f32<EPI>(en.value, idx & 63u);
-            if (idx < cnt) load_row<VEC, 4>(tb.V + (size_t)id * tb.rs + f * VEC, vr[u]);
+            if (idx < cnt) row_ld<VEC, 4>(tb, (size_t)id, f * VEC, vr[u]);
             else {
               xs[u] = 0.f;
 #pragma unroll
@@ -267,7 +267,7 @@ k_group_moments(const Tab tb, uint64_t n_local, int k1, const uint32_t* __restri
     if (j >= n_local) continue;
     double t[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; v++) t[v] = (double)tb.V[(size_t)j * tb.rs + fl * VEC + v];
+    for (int v = 0; v < VEC; v++) t[v] = (fl * VEC + v < tb.rs) ? (double)tb.V[(size_t)j * tb.rs + fl * VEC + v] : 0.0;   // (rows are tb.rs floats)
     const double tw = (k1 && fl == 0) ? (double)tb.w[(size_t)j * tb.ws] : 0.0;
     if (!GROUPED) {
 #pragma unroll
@@ -390,7 +390,11 @@ k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict
       for (int st = 0; st < STEPS; st++) {
         const uint32_t q = (uint32_t)st * EPI + sub;               // position inside the wavefront's 16
         const uint32_t feat = (uint32_t)__shfl((int)feat_l, (int)(q & 15u));
-        if (q < 16u && wv * 16u + q < np) load_vec<VEC>(tb.V + (size_t)feat * tb.rs + fl * VEC, vals[st]);
+        if (q < 16u && wv * 16u + q < np && fl * VEC < tb.rs) load_vec<VEC>(tb.V + (size_t)feat * tb.rs + fl * VEC, vals[st]);
+        else {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) vals[st][v] = 0.f;         // (beyond the row: rows are tb.rs floats, fmx_kernels.h row_ld)
+        }
       }
 #pragma unroll
       for (int st = 0; st < STEPS; st++) {
@@ -415,7 +419,7 @@ k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict
       for (int st = 0; st < STEPS; st++) {
         const uint32_t q = (uint32_t)st * EPI + sub;
         const uint32_t feat = (uint32_t)__shfl((int)feat_l, (int)(q & 15u));
-        if (q < 16u && wv * 16u + q < np) {
+        if (q < 16u && wv * 16u + q < np && fl * VEC < tb.rs) {
           float* row = tb.V + (size_t)feat * tb.rs + fl * VEC;
           if (k == (uint32_t)KP) {
             float o[VEC];

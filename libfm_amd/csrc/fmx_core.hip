@@ -704,7 +704,11 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   {
     // row layout: V rows of KP floats, the linear weights in an array of their own (co-locating w_j behind its row was measured
     // in rounds 1 and 2: HBM fetches 64-byte sectors, a 4-byte w costs one wherever it lives, and unaligned rows cost more)
+    // ... rows of num_factor floats rounded up to 16 (one 64-byte sector), not to the power of two KP of the lane mapping: k = 100 keeps rows of
+    // 112 floats (448 B) where the padded 128 moved 512 (round-5 verdict item 9; fmx_kernels.h row_ld).  FMX_ROW_STRIDE_KP=1: the padded rows.
     h->tb.rs = (uint32_t)h->KP;
+    { const char* rk = getenv("FMX_ROW_STRIDE_KP");
+      if (h->KP >= 32 && !(rk && rk[0] == '1')) h->tb.rs = std::min<uint32_t>((uint32_t)h->KP, ((uint32_t)cfg->num_factor + 15u) / 16u * 16u); }
     // Placement of the parameter tables: big ones (>= 2 GiB) in an arena of chunks from two memory classes (arena_build above).  Smaller
     // ones, and every table when the virtual-memory API fails: a table of >= 256 MB is allocated up to fmx_config::place_candidates
     // times (default 2; the earlier candidate is held meanwhile, so that the later one is other memory), each candidate is zeroed and

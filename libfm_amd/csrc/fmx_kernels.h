@@ -227,6 +227,20 @@ template <int VEC, int BIT> __device__ __forceinline__ void store_row(float* __r
   }
 }
 
+// a parameter row is tb.rs floats: the factor count rounded up to 16 floats (one 64-byte sector) -- NOT the power of two KP the lane mapping is
+// built on (k = 100: rows of 112 floats, 448 B, where the padded 128 moved 512).  The lanes whose elements lie beyond the row take no part in
+// row accesses: they read zeros (a sum over the lanes is unchanged) and store nothing.  rs == KP for every power of two.
+template <int VEC, int BIT> __device__ __forceinline__ void row_ld(const Tab& tb, size_t id, uint32_t off, float (&out)[VEC]) {
+  if (off < tb.rs) load_row<VEC, BIT>(tb.V + id * tb.rs + off, out);
+  else {
+#pragma unroll
+    for (int v = 0; v < VEC; v++) out[v] = 0.f;
+  }
+}
+template <int VEC, int BIT> __device__ __forceinline__ void row_st(const Tab& tb, size_t id, uint32_t off, const float (&in)[VEC]) {
+  if (off < tb.rs) store_row<VEC, BIT>(tb.V + id * tb.rs + off, in);
+}
+
 // the row entries ({id, value}, 8 bytes) and the 4-byte gathers of a linear weight: plain loads.  (Non-temporal / agent-scope variants of
 // both, write-through row stores, a sixth wavefront per SIMD and the in-launch publish of S_e were measured in rounds 1-4 and lost or
 // bought nothing: scripts/experiments/r04_variants.patch re-creates them, DESIGN.md section 4 has the numbers.)
@@ -385,7 +399,7 @@ __device__ __forceinline__ void row_sums(const Entry* __restrict__ ent, uint32_t
         const uint32_t id = bcast_u32<EPI>(e.id, idx & 63u);
         xs[u] = bcast_f32<EPI>(e.value, idx & 63u);
         if (idx < cnt) {
-          load_row<VEC, 4>(tb.V + (size_t)id * tb.rs + f * VEC, vr[u]);
+          row_ld<VEC, 4>(tb, (size_t)id, f * VEC, vr[u]);
         } else {
           xs[u] = 0.f;
 #pragma unroll
@@ -431,12 +445,12 @@ __device__ __forceinline__ void row_apply(const Entry* __restrict__ ent, uint32_
         const uint32_t idx = i + u * EPI + g;
         ids[u] = bcast_u32<EPI>(e.id, idx & 63u);
         xs[u] = bcast_f32<EPI>(e.value, idx & 63u);
-        if (idx < cnt) load_row<VEC, 8>(tb.V + (size_t)ids[u] * tb.rs + f * VEC, vr[u]);
+        if (idx < cnt) row_ld<VEC, 8>(tb, (size_t)ids[u], f * VEC, vr[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const uint32_t idx = i + u * EPI + g;
-        if (idx < cnt) {
+        if (idx < cnt && f * VEC < tb.rs) {
           float* p = tb.V + (size_t)ids[u] * tb.rs + f * VEC;
           const float x = xs[u];
           float nv[VEC];
@@ -546,7 +560,7 @@ k_rowsums_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_
 #pragma unroll
       for (int t = 0; t < MULTI_ZR; t++) {
         const uint32_t id = bcast_u32<1>(en.id, t);
-        if ((uint32_t)t < cnt) load_row<VEC, 4>(tb.V + (size_t)id * tb.rs + lane * VEC, vr[t]);
+        if ((uint32_t)t < cnt) row_ld<VEC, 4>(tb, (size_t)id, lane * VEC, vr[t]);
       }
 #pragma unroll
       for (int t = 0; t < MULTI_ZR; t++) {
@@ -659,7 +673,7 @@ k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
 #pragma unroll
       for (int t = 0; t < MULTI_ZR; t++) {
         const uint32_t id = bcast_u32<1>(en.id, t);
-        if ((uint32_t)t < cnt && !((defm >> t) & 1ull)) load_row<VEC, 8>(tb.V + (size_t)id * tb.rs + lane * VEC, vr[t]);
+        if ((uint32_t)t < cnt && !((defm >> t) & 1ull)) row_ld<VEC, 8>(tb, (size_t)id, lane * VEC, vr[t]);
       }
       if (upd_w) *pw = wv - h.lr * (ml * en.value + h.regw * wv);      // fm_sgd.h:38-43
 #pragma unroll
@@ -668,7 +682,7 @@ k_apply_multi(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
         const uint32_t ex_t = bcast_u32<1>(ex, t);
         const float x = bcast_f32<1>(en.value, t);
         const float m = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mreg), (int)ex_t));
-        if ((uint32_t)t < cnt && !((defm >> t) & 1ull)) {
+        if ((uint32_t)t < cnt && !((defm >> t) & 1ull) && lane * VEC < tb.rs) {
           float* pv = tb.V + (size_t)id * tb.rs + lane * VEC;
           float nv[VEC];
 #pragma unroll
@@ -1598,7 +1612,7 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
       wv0[u] = 0.f;
       if (idx < cnt) {
         if (h.k1 && f == 0) wv0[u] = tb.w[(size_t)j * tb.ws];
-        load_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, v0[u]);
+        row_ld<VEC, 8>(tb, (size_t)j, f * VEC, v0[u]);
         load_vec<VEC>(S + (size_t)e * KP + f * VEC, sf[u]);
         if (PRE2) {
           if (n2 >= 2) load_vec<VEC>(S + (size_t)e2 * KP + f * VEC, sf2[u]);
@@ -1707,8 +1721,10 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
             sh[v] = G[v] - vv * A;                               // sum over the occurrences of mult x (S_f - v x)  (:161)
             nv[v] = vv - h.lr * (sh[v] + nocc * 2.0f * (float)rg[1 + f * VEC + v] * vv);
           }
-          store_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
-          store_vec<VEC>(sx.gv + (size_t)j * tb.rs + f * VEC, sh);
+          if (f * VEC < tb.rs) {
+            store_vec<VEC>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
+            store_vec<VEC>(sx.gv + (size_t)j * tb.rs + f * VEC, sh);
+          }
           if (h.k1 && f == 0) {
             float* pw = tb.w + (size_t)j * tb.ws;
             const float wv = wv0[u];
@@ -1721,7 +1737,7 @@ __device__ __forceinline__ void apply_seg_block(const SegWork& sw, uint32_t blk,
             const float vv = v0[u][v];
             nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
           }
-          store_row<VEC, 8>(tb.V + (size_t)j * tb.rs + f * VEC, nv);
+          row_st<VEC, 8>(tb, (size_t)j, f * VEC, nv);
           if (h.k1 && f == 0) {
             float* pw = tb.w + (size_t)j * tb.ws;
             const float wv = wv0[u];
@@ -1898,7 +1914,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         const uint32_t idx = t * EPI + g;
         const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
         if (idx < size) {                                      // (APPLY: deferred rows are gathered too -- 4 % of them; a test per row slot costs more)
-          load_row<VEC, 1>(tb.V + (size_t)id * tb.rs + f * VEC, vr[t]);
+          row_ld<VEC, 1>(tb, (size_t)id, f * VEC, vr[t]);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
@@ -1960,7 +1976,7 @@ k_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, con
         const uint32_t idx = t * EPI + g;
         const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
         const float x = bcast_f32<EPI>(en.value, idx & 63u);
-        if (idx < size && !(MASKED && ((cm >> (idx & 63u)) & 1ull))) {
+        if (idx < size && !(MASKED && ((cm >> (idx & 63u)) & 1ull)) && f * VEC < tb.rs) {
           float* pv = tb.V + (size_t)id * tb.rs + f * VEC;
           float nv[VEC];
 #pragma unroll
@@ -2062,7 +2078,7 @@ k_sequential(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr
              uint32_t n_rows, const Tab tb, Hyper h, double* w0_ptr) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x;
-  const bool act = lane < LPR;
+  const bool act = lane < LPR && lane * VEC < tb.rs;           // (the lanes of the row's elements: rows are tb.rs floats, row_ld above)
   double w0 = *w0_ptr;
   for (uint32_t r = 0; r < n_rows; r++) {
     const uint64_t a = row_ptr[r];
@@ -2140,7 +2156,7 @@ k_sgda(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, cons
        const Tab tb, float* gw, float* gv, Hyper h, double* w0_ptr, double* reg, int do_lambda) {
   constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
   const uint32_t lane = threadIdx.x;
-  const bool act = lane < LPR;
+  const bool act = lane < LPR && lane * VEC < tb.rs;           // (the lanes of the row's elements: rows are tb.rs floats, row_ld above)
   double w0 = *w0_ptr;
   double reg_w = reg[0];
   double reg_v[VEC];
@@ -2301,7 +2317,7 @@ k_sgda_lambda(const Entry* __restrict__ vent, const uint64_t* __restrict__ vrow_
   double* sdfg = sfg + (size_t)G * KP;         //          [G][KP]     sum v' x v x
   double* acc = sdfg + (size_t)G * KP;         //          [G][1 + KP] this workgroup's changes
   const uint32_t lane = threadIdx.x;
-  const bool act = lane < LPR;
+  const bool act = lane < LPR && lane * VEC < tb.rs;           // (the lanes of the row's elements: rows are tb.rs floats, row_ld above)
   const double w0 = h.k0 ? *w0_ptr : 0.0;
   const uint32_t cells = G * (1 + KP);
   double acc_w = 0.0, acc_v[VEC];              // !GROUPED: the same in registers (lane 0 / factor lanes)
@@ -2504,7 +2520,7 @@ k_sgda_groups(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_pt
   double* sdfg = sfg + (size_t)G * KP;
   uint32_t* stamp = (uint32_t*)(sdfg + (size_t)G * KP);
   const uint32_t lane = threadIdx.x;
-  const bool act = lane < LPR;
+  const bool act = lane < LPR && lane * VEC < tb.rs;           // (the lanes of the row's elements: rows are tb.rs floats, row_ld above)
   for (uint32_t g = lane; g < G; g += 64) { regw[g] = reg[(size_t)g * (1 + KP)]; stamp[g] = 0; }
   for (uint32_t i = lane; i < G * KP; i += 64) regv[i] = reg[(size_t)(i / KP) * (1 + KP) + 1 + (i % KP)];
   __syncthreads();
@@ -2690,9 +2706,9 @@ k_yhat(const float* __restrict__ rest, uint32_t n_rows, int k0, const double* __
 // ----------------------------------------------------------------------------------------------
 static __global__ void k_stage_in(const double* __restrict__ stage, uint64_t j0, uint32_t cnt, int k, int KP, Shard sh, Tab tb) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t total = (uint64_t)cnt * KP;
+  const uint64_t total = (uint64_t)cnt * tb.rs;                  // (rows are tb.rs floats: the padding behind the k factors is zeroed)
   if (t >= total) return;
-  const uint32_t jj = (uint32_t)(t / KP); const int f = (int)(t % KP);
+  const uint32_t jj = (uint32_t)(t / tb.rs); const int f = (int)(t % tb.rs);
   uint32_t jl;
   if (!sh.place((uint32_t)(j0 + jj), &jl)) return;
   tb.V[(size_t)jl * tb.rs + f] = (f < k) ? (float)stage[(size_t)f * cnt + jj] : 0.f;

@@ -86,6 +86,19 @@ template <int VEC> __device__ __forceinline__ void st_stream_vec(float* p, const
     v2f t; t.x = in[0]; t.y = in[1]; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(p));
   }
 }
+// a parameter row through the die's L2 (rows are tb.rs floats: the lanes beyond take no part, fmx_kernels.h row_ld)
+template <int VEC> __device__ __forceinline__ void xcd_row_ld(const Tab& tb, size_t id, float (&out)[VEC]) {
+  const uint32_t off = (threadIdx.x & 63u) * VEC;
+  if (off < tb.rs) ld_l2_vec<VEC, false>(tb.V + id * tb.rs + off, out);
+  else {
+#pragma unroll
+    for (int v = 0; v < VEC; v++) out[v] = 0.f;
+  }
+}
+template <int VEC> __device__ __forceinline__ void xcd_row_st(const Tab& tb, size_t id, const float (&in)[VEC]) {
+  const uint32_t off = (threadIdx.x & 63u) * VEC;
+  if (off < tb.rs) store_vec<VEC>(tb.V + id * tb.rs + off, in);
+}
 // a plain 4-byte store (stays in the die's L2; an agent-scope atomic store would drop the line to the fabric)
 __device__ __forceinline__ void st_plain(unsigned* p, unsigned v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory"); }
 
@@ -171,7 +184,7 @@ __device__ __forceinline__ void xcd_rows_store(const Tab& tb, const Hyper& h, ui
           nv[v] = vv + (-h.lr * (mult * grad + h.regv * vv));
         }
       }
-      store_vec<VEC>(tb.V + (size_t)id * tb.rs + lane * VEC, nv);
+      xcd_row_st<VEC>(tb, (size_t)id, nv);
     }
     xcd_rows_store<KP, ZR, ONES, T + 1>(tb, h, ids, xs, size, cm, vr, sum, cbs, ca, mult);
   }
@@ -182,8 +195,7 @@ __device__ __forceinline__ void xcd_rows_load(const Tab& tb, uint32_t ids, uint3
   if constexpr (T < ZR) {
     if ((uint32_t)T < size) {
       const uint32_t id = lane_val<T>(ids);
-      const float* rp = tb.V + (size_t)id * tb.rs + (threadIdx.x & 63u) * VEC;
-      ld_l2_vec<VEC, false>(rp, vr[T]);
+      xcd_row_ld<VEC>(tb, (size_t)id, vr[T]);
     } else {
 #pragma unroll
       for (int v = 0; v < VEC; v++) vr[T][v] = 0.f;
@@ -258,7 +270,7 @@ __device__ __forceinline__ void xcd_rows_touch(const Tab& tb, uint32_t ids, uint
     for (int v = 0; v < VEC; v++) vt[T][v] = 0.f;
     if ((uint32_t)T < size && !((cm >> (uint32_t)T) & 1ull)) {     // (a deferred row is in the L2 already: its owner has just written it)
       const uint32_t id = lane_val<T>(ids);
-      ld_l2_vec<VEC, false>(tb.V + (size_t)id * tb.rs + (threadIdx.x & 63u) * VEC, vt[T]);
+      xcd_row_ld<VEC>(tb, (size_t)id, vt[T]);
     }
     xcd_rows_touch<KP, ZR, T + 1>(tb, ids, size, cm, vt);
   }
@@ -293,7 +305,7 @@ __device__ __forceinline__ void xcd_segment(const CDesc* __restrict__ dp, const 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t j = dp->feat, a = dp->a, b = dp->b;             // (wave-uniform: scalar loads of a read-only record)
   float v0[VEC];
-  ld_l2_vec<VEC>(tb.V + (size_t)j * tb.rs + lane * VEC, v0);
+  xcd_row_ld<VEC>(tb, (size_t)j, v0);
   const float wv0 = h.k1 ? ld_l2(tb.w + (size_t)j * tb.ws) : 0.f;
   float G[VEC]; float A = 0.f, Gw = 0.f;
 #pragma unroll
@@ -332,7 +344,7 @@ __device__ __forceinline__ void xcd_segment(const CDesc* __restrict__ dp, const 
     const float vv = v0[v];
     nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
   }
-  store_vec<VEC>(tb.V + (size_t)j * tb.rs + lane * VEC, nv);
+  xcd_row_st<VEC>(tb, (size_t)j, nv);
   if (h.k1 && lane == 0) tb.w[(size_t)j * tb.ws] = wv0 - h.lr * (Gw + nocc * h.regw * wv0);
 }
 
@@ -369,7 +381,7 @@ __device__ __forceinline__ void xcd_items_ask(XcdItems<Map<KP>::VEC>& it, const 
     for (int v = 0; v < VEC; v++) it.v0[i][v] = 0.f;
     if (it.cnt[i] != 0u && it.cnt[i] != 0xFFFFFFFFu) {
       if (lane < it.cnt[i]) it.te[i] = t_ent[a[i] + lane];
-      ld_l2_vec<VEC>(tb.V + (size_t)it.j[i] * tb.rs + lane * VEC, it.v0[i]);
+      xcd_row_ld<VEC>(tb, (size_t)it.j[i], it.v0[i]);
       if (h.k1) it.wv0[i] = ld_l2(tb.w + (size_t)it.j[i] * tb.ws);
     }
   }
@@ -447,7 +459,7 @@ __device__ __forceinline__ void xcd_items_finish(const XcdItems<Map<KP>::VEC>& i
       const float vv = it.v0[i][v];
       nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
     }
-    store_vec<VEC>(tb.V + (size_t)it.j[i] * tb.rs + lane * VEC, nv);
+    xcd_row_st<VEC>(tb, (size_t)it.j[i], nv);
     if (h.k1 && lane == 0) tb.w[(size_t)it.j[i] * tb.ws] = it.wv0[i] - h.lr * (Gw + nocc * h.regw * it.wv0[i]);
   }
 }

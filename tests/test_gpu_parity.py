@@ -438,8 +438,9 @@ def test_hogwild_converges_like_the_reference(capi, oracle, apply):
 # ---------------------------------------------------------------------------------------------
 # long ragged rows (> 64 entries: more than one wavefront-wide chunk), k not a power of two
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k", [0, 3, 10, 20, 100, 200, 256])
+@pytest.mark.parametrize("k", [0, 3, 10, 20, 40, 100, 130, 200, 256])
 def test_odd_k_and_long_rows(capi, oracle, k):
+    """... and rows of k rounded up to 16 floats, not to the power of two the lane mapping is built on (k = 100: 112 floats, 448 B)"""
     n = 500
     ent, row_ptr, y = datagen.ragged_real(n, 120, 150, seed=77 + k, classification=False)
     d = oracle.Data(ent, row_ptr, y)
@@ -450,6 +451,8 @@ def test_odd_k_and_long_rows(capi, oracle, k):
     m.w0 = 0.1
     lo, hi = float(y.min()), float(y.max())
     h = capi.Handle(n, k, True, True, 0, 0.001, 0.002, 0.003, 0.002, lo, hi)
+    if k >= 17:                                                   # (below: the power of two)
+        assert h.info().bytes_params == n * ((k + 15) // 16 * 16 + 1) * 4
     h.set_params(m.w0, m.w, m.v if k else None)
     h.upload_rows(0, ent, row_ptr, y)
     np.testing.assert_allclose(h.predict(0, d.n_rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5)
@@ -477,7 +480,7 @@ def test_odd_k_and_long_rows(capi, oracle, k):
     h.close()
 
 
-@pytest.mark.parametrize("k,nnz", [(3, 12), (20, 12), (100, 12), (200, 12), (256, 9), (64, 40), (32, 33)])
+@pytest.mark.parametrize("k,nnz", [(3, 12), (20, 12), (40, 12), (100, 12), (130, 12), (200, 12), (256, 9), (64, 40), (32, 33)])
 def test_batch_rule_register_paths_at_every_row_width(capi, oracle, k, nnz):
     """short rows (they fit the register path) at every padded factor count (KP = 4 .. 256: 1, 2 or 4 floats per lane, several
     entries per load instruction below KP = 64): the one-pass form (k_fused<EXACT> + deferred list), the split step's second
