@@ -373,10 +373,11 @@ template <int KP, bool PACK>
 __global__ void __launch_bounds__(256)
 k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict__ seg_feat, uint32_t nseg, const Tab tb,
              float* __restrict__ vt, size_t vt_stride, uint32_t k /* rows of vt: num_factor (<= KP) */) {
-  __shared__ float tile[64][KP + 1];                            // [position in block][factor], padded against bank conflicts
+  constexpr uint32_t TP = (KP > 512) ? 32u : 64u;               // positions per block (1024 factors: 32 -- the tile must fit the LDS)
+  __shared__ float tile[TP][KP + 1];                            // [position in block][factor], padded against bank conflicts
   const uint32_t tid = threadIdx.x;
-  for (uint32_t p0 = blockIdx.x * 64u; p0 < nseg; p0 += gridDim.x * 64u) {
-    const uint32_t np = min(64u, nseg - p0);
+  for (uint32_t p0 = blockIdx.x * TP; p0 < nseg; p0 += gridDim.x * TP) {
+    const uint32_t np = min(TP, nseg - p0);
     // the table side, a wavefront per 16 positions: the features' ids are looked up ONCE (two dependent 4-byte loads per position, not per
     // float), then whole rows move -- EPI rows per wave-wide access, all of a wavefront's rows in flight together (round 5: at configs[4]'s
     // shape the element-wise form ran at 1.5 TB/s packing and 0.8 TB/s unpacking, 48 ms of a 494 ms sweep)
@@ -405,13 +406,13 @@ k_als_shadow(const uint32_t* __restrict__ level_list, const uint32_t* __restrict
         }
       }
       __syncthreads();
-      for (uint32_t i = tid; i < k * 64u; i += 256) {             // per factor 64 consecutive positions
-        const uint32_t f = i / 64u, r = i % 64u;
+      for (uint32_t i = tid; i < k * TP; i += 256) {             // per factor TP consecutive positions
+        const uint32_t f = i / TP, r = i % TP;
         if (r < np) vt[(size_t)f * vt_stride + p0 + r] = tile[r][f];
       }
     } else {
-      for (uint32_t i = tid; i < k * 64u; i += 256) {
-        const uint32_t f = i / 64u, r = i % 64u;
+      for (uint32_t i = tid; i < k * TP; i += 256) {
+        const uint32_t f = i / TP, r = i % TP;
         if (r < np) tile[r][f] = vt[(size_t)f * vt_stride + p0 + r];
       }
       __syncthreads();

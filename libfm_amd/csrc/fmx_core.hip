@@ -666,7 +666,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
   if (cfg->num_attribute == 0) return fail(nullptr, FMX_E_ARG, "num_attribute must be > 0");
   if (cfg->num_attribute > 0xFFFFFFFFull) return fail(nullptr, FMX_E_ARG, "num_attribute must fit uint32 (fm_model.h:51)");
   if (cfg->num_factor < 0) return fail(nullptr, FMX_E_ARG, "num_factor must be >= 0");
-  if (cfg->num_factor > 256) return fail(nullptr, FMX_E_UNSUPPORTED, "num_factor > 256 is not supported yet");
+  if (cfg->num_factor > 1024) return fail(nullptr, FMX_E_UNSUPPORTED, "num_factor > 1024 is not supported");
   if (cfg->task != FMX_TASK_REGRESSION && cfg->task != FMX_TASK_CLASSIFICATION)
     return fail(nullptr, FMX_E_ARG, "unknown task");                       // fm_learn.h:81 "unknown task"
   if (cfg->shard_world < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_world)

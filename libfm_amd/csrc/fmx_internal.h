@@ -292,6 +292,8 @@ inline uint32_t wave_grid(uint64_t n_waves_wanted) {
     case 64:  { constexpr int KP = 64;  __VA_ARGS__; } break;          \
     case 128: { constexpr int KP = 128; __VA_ARGS__; } break;          \
     case 256: { constexpr int KP = 256; __VA_ARGS__; } break;          \
-    default: return fail(h, FMX_E_UNSUPPORTED, "num_factor > 256 is not supported yet");   \
+    case 512: { constexpr int KP = 512; __VA_ARGS__; } break;          \
+    case 1024: { constexpr int KP = 1024; __VA_ARGS__; } break;        \
+    default: return fail(h, FMX_E_UNSUPPORTED, "num_factor > 1024 is not supported");   \
   }
 

@@ -55,7 +55,7 @@ int launch_fused_zr(fmx_handle h, const Slot& s, const Hyper& hy, uint64_t row0,
 // about 24 entries per 32-slot round (mean + 1.7 sigma of a shard's binomial row lengths stays inside one round); 0 = rows are long enough
 // for the one-example-per-wavefront kernels (or KP < 64: several rows per wave-wide load, not built)
 extern "C++" uint32_t multi_group_size(const Slot& s, int KP) {
-  if (KP < 64 || s.n_rows == 0) return 0;
+  if (KP < 64 || KP > 256 || s.n_rows == 0) return 0;          // (beyond 256 factors the sums of a group of examples do not fit the LDS)
   const double avg = (double)s.nnz / (double)s.n_rows;
   if (avg > 12.0) return 0;
   static const double fill = []() { const char* e = getenv("FMX_MULTI_FILL"); const double f = e ? atof(e) : 0.0; return (f >= 8.0 && f <= 32.0) ? f : 24.0; }();
@@ -103,7 +103,7 @@ int fmx_sgd_partial(fmx_handle h, int slot, uint64_t row0, uint32_t n_rows, floa
 extern "C++" int sgd_partial_rows(fmx_handle h, const Slot& s, uint64_t row0, uint32_t n_rows, float* S, float* c, hipStream_t st) {
   if (n_rows == 0) return FMX_OK;
   if (const uint32_t G = multi_group_size(s, h->KP)) {          // short rows: several examples per wavefront
-    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_rowsums_multi<KP, true, false>), ((uint64_t)n_rows + G - 1) / G, st,
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64 && KP <= 256) { FMX_LAUNCH_WAVES((k_rowsums_multi<KP, true, false>), ((uint64_t)n_rows + G - 1) / G, st,
                                                                   s.ent, s.row_ptr, row0, n_rows, h->tb, h->cfg.k1, S, c, G); } });
     HIPCHK(h, hipGetLastError());
     return FMX_OK;
@@ -532,7 +532,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
       const uint32_t R = L.depth + 1;
       const size_t b = (size_t)seg_batch;
       if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
-      KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_apply_multi<KP, true>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
+      KP_SWITCH(h->KP, { if constexpr (KP >= 64 && KP <= 256) { FMX_LAUNCH_WAVES((k_apply_multi<KP, true>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
                                                                     h->tb, hy, lag_bias_slot(h), S, cpart, rest, h->mult, (const uint64_t*)s.cmask, G); } });
       const uint32_t c0 = s.cbatch[b], c1 = s.cbatch[b + 1];
       const uint32_t s0 = s.batch_seg[b], s1 = s.batch_seg[b + 1];
@@ -551,7 +551,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
     rc = lag_wait_bias(h, hy, st);
     if (rc) return rc;
     if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
-    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_apply_multi<KP, true>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64 && KP <= 256) { FMX_LAUNCH_WAVES((k_apply_multi<KP, true>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
                                                                   h->tb, hy, lag_bias_slot(h), S, cpart, rest, h->mult, (const uint64_t*)s.cmask, G); } });
     HIPCHK(h, hipGetLastError());
     rc = lag_start_scan(h, rest, s.target + row0, n_rows, chunk, hy, st);
@@ -569,7 +569,7 @@ static int sgd_finish_impl(fmx_handle h, const Slot& s, uint64_t row0, uint32_t 
   if (short_row_update(h, s, opts, seg_batch)) {                // (exact chunk coupling: the multipliers came out of the recurrence)
     const uint32_t G = multi_group_size(s, h->KP);
     if (ev_a) HIPCHK(h, hipEventRecord(ev_a, st));
-    KP_SWITCH(h->KP, { if constexpr (KP >= 64) { FMX_LAUNCH_WAVES((k_apply_multi<KP, false>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
+    KP_SWITCH(h->KP, { if constexpr (KP >= 64 && KP <= 256) { FMX_LAUNCH_WAVES((k_apply_multi<KP, false>), ((uint64_t)n_rows + G - 1) / G, st, s.ent, s.row_ptr, s.target, row0, n_rows,
                                                                   h->tb, hy, (const double*)h->w0, S, (const float*)nullptr, (float*)nullptr, h->mult, (const uint64_t*)s.cmask, G); } });
     HIPCHK(h, hipGetLastError());
     rc = launch_deferred(h, s, hy, S, (size_t)seg_batch, st);

@@ -149,7 +149,7 @@ def test_split_step_is_the_fused_step(oracle, monkeypatch, task, do_sample):
         np.testing.assert_allclose(other[3], res[0][3], rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("k", [100, 200])
+@pytest.mark.parametrize("k", [100, 200, 300, 700])
 def test_als_wide_rows_against_oracle(oracle, k, draw_form):
     """KP = 128 / 256 (two / four floats per lane; the re-prediction hands 8 / 4 rows of q_f per wavefront through LDS)"""
     from libfm_amd import learner as L

@@ -438,15 +438,16 @@ def test_hogwild_converges_like_the_reference(capi, oracle, apply):
 # ---------------------------------------------------------------------------------------------
 # long ragged rows (> 64 entries: more than one wavefront-wide chunk), k not a power of two
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k", [0, 3, 10, 20, 40, 100, 130, 200, 256])
+@pytest.mark.parametrize("k", [0, 3, 10, 20, 40, 100, 130, 200, 256, 300, 512, 1000])
 def test_odd_k_and_long_rows(capi, oracle, k):
     """... and rows of k rounded up to 16 floats, not to the power of two the lane mapping is built on (k = 100: 112 floats, 448 B)"""
     n = 500
+    atol = 2e-5 if k <= 256 else 6e-5                          # (rows of 120-150 real-valued entries x 300+ factors: the fp32 sums behind a step are that much noisier)
     ent, row_ptr, y = datagen.ragged_real(n, 120, 150, seed=77 + k, classification=False)
     d = oracle.Data(ent, row_ptr, y)
     m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.003)
     if k:
-        m.v[:] = oracle.init_values(1, n, k, 0.05)
+        m.v[:] = oracle.init_values(1, n, k, 0.05 if k <= 256 else 0.008)   # (150 entries x 500 factors at 0.05 start with |y-hat| in the hundreds and run away)
     m.w[:] = oracle.init_values(2, n, 1, 0.05)[0]
     m.w0 = 0.1
     lo, hi = float(y.min()), float(y.max())
@@ -460,27 +461,27 @@ def test_odd_k_and_long_rows(capi, oracle, k):
     oracle.sgd_epoch_online(m, d, 0, 0.002, lo, hi)
     w0, w, v = h.get_params()
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
-    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=atol)
     if k:
-        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=atol)
     h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 16, 4)
     oracle.sgd_epoch_minibatch(m, d, 0, 0.002, lo, hi, 16, 4)
     w0, w, v = h.get_params()
-    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=atol)
     if k:
-        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=atol)
     # the one-pass form: rows of 120..150 entries exceed its register path and are deferred whole
     h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 16, 4, 0, 2)
     oracle.sgd_epoch_minibatch(m, d, 0, 0.002, lo, hi, 16, 4, bias_lag=2)
     w0, w, v = h.get_params()
     assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
-    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=atol)
     if k:
-        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+        np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=atol)
     h.close()
 
 
-@pytest.mark.parametrize("k,nnz", [(3, 12), (20, 12), (40, 12), (100, 12), (130, 12), (200, 12), (256, 9), (64, 40), (32, 33)])
+@pytest.mark.parametrize("k,nnz", [(3, 12), (20, 12), (40, 12), (100, 12), (130, 12), (200, 12), (256, 9), (64, 40), (32, 33), (300, 6), (520, 12), (1024, 6)])
 def test_batch_rule_register_paths_at_every_row_width(capi, oracle, k, nnz):
     """short rows (they fit the register path) at every padded factor count (KP = 4 .. 256: 1, 2 or 4 floats per lane, several
     entries per load instruction below KP = 64): the one-pass form (k_fused<EXACT> + deferred list), the split step's second
