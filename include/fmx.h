@@ -17,8 +17,9 @@
  *     (fm_model.h:46-48, matrix.h:165-170: fm->v.value[0] is one contiguous k*n block).
  *   - host row layout is the reference's: one contiguous array of sparse_entry<float> {uint32 id; float value}
  *     in row order (fmatrix.h:34-42; Data.h:237-270 allocates exactly this) plus row offsets.
- *   - device layout (inside the library): V is FEATURE-major fp32, rows padded to a power of two,
- *     so one gathered row is one coalesced segment (256 B at k=64).  See DESIGN.md section 2.
+ *   - device layout (inside the library): V is FEATURE-major fp32, rows of k rounded up to 16 floats (one 64-byte
+ *     sector; the lanes of a wavefront are mapped on the next power of two, those beyond the row take no part),
+ *     so one gathered row is one coalesced segment (256 B at k=64, 448 B at k=100).  See DESIGN.md section 2.
  *   - single calling thread per handle (the reference is single threaded).
  *   - there is NO CPU fallback: without a HIP device every compute entry point fails with FMX_E_HIP.
  */
@@ -80,7 +81,7 @@ typedef struct fmx_context_s *fmx_handle;
 /* replaces the fields main() writes into fm_model / fm_learn (libfm.cpp:245-256, 294-309, 366-404) */
 typedef struct fmx_config {
   uint64_t num_attribute;   /* fm_model::num_attribute (global n)            fm_model.h:51 */
-  int32_t  num_factor;      /* fm_model::num_factor (k)                      fm_model.h:54 */
+  int32_t  num_factor;      /* fm_model::num_factor (k), 0 .. 1024           fm_model.h:54 */
   int32_t  k0;              /* use bias                                       fm_model.h:53 */
   int32_t  k1;              /* use 1-way interactions                         fm_model.h:53 */
   int32_t  task;            /* fm_learn::task                                 fm_learn.h:45 */
@@ -554,7 +555,7 @@ int fmx_sgda_end(fmx_handle h);
 /* ---- introspection --------------------------------------------------------------------------- */
 typedef struct fmx_info {
   uint64_t n_local;         /* features held by this handle */
-  int32_t  k_padded;        /* device row length in floats (power of two >= k) */
+  int32_t  k_padded;        /* floats per example in the partial-sum buffers: the power of two >= k (a device ROW is k rounded up to 16) */
   int32_t  device;
   uint64_t bytes_params;    /* device bytes of w + V */
   char     device_name[64];

@@ -6,6 +6,8 @@
 // creates a group with more than one device never loads it.
 #include "fmx_internal.h"
 
+#include <atomic>
+#include <thread>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -651,6 +653,87 @@ int fmx_group_upload_rows(fmx_group g, int slot, const void* entries, const uint
   return FMX_OK;
 }
 
+// ---- small batches, one host thread per shard -------------------------------------------------------------------------------------------
+// A 512-row batch on a feature shard is three launches of a few microseconds each; issued for eight shards by ONE thread the host is the
+// bottleneck twice over (its calls are serial, and on one stream so are the shards' launches).  Here every shard has its own host thread
+// and its own stream: per batch the thread enqueues the shard's sums, the exchange, the shard's update.  RCCL: the all-reduce goes onto the
+// shard's compute stream from its own thread (one communicator per thread, the usual one-thread-per-device form) -- no host synchronisation
+// at all.  Loopback (the shards share a device): shard 0's thread launches the reduction between two host barriers (the events it waits
+// for must have been RECORDED by the other threads; they wait for its event after the second).  A thread that fails keeps arriving at the
+// barriers and skips its work; the first error is reported.  Opt-in (FMX_GROUP_THREADS=1), see fmx_group_sgd_epoch for what it measured.
+namespace {
+struct SpinBarrier {
+  std::atomic<uint32_t> count{0}, gen{0};
+  uint32_t n;
+  explicit SpinBarrier(uint32_t n_) : n(n_) {}
+  void wait() {
+    const uint32_t g = gen.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { count.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release); }
+    else { uint32_t spins = 0; while (gen.load(std::memory_order_acquire) == g) { if (++spins > 4096) std::this_thread::yield(); } }
+  }
+};
+}  // namespace
+static int group_small_epoch_threads(fmx_group g, int slot, const fmx_sgd_opts& opts, uint32_t B, uint32_t n_rows, uint64_t n_batch,
+                                     uint64_t n_timed) {
+  const size_t n = g->hs.size();
+  const size_t kp1 = (size_t)g->hs[0]->KP + 1;
+  SpinBarrier bar((uint32_t)n);
+  std::atomic<int> failed{FMX_OK};
+  std::vector<int> rcs(n, FMX_OK);
+  const bool loop = g->kind == GROUP_LOOPBACK;
+  Rccl* R = loop ? nullptr : rccl();
+  auto body = [&](size_t i) {
+    fmx_handle h = g->hs[i];
+    fmx_handle h0 = g->hs[0];
+    int rc = FMX_OK;
+    auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == FMX_OK) rc = fail(h, FMX_E_HIP, "%s failed: %s", what, hipGetErrorString(e)); };
+    chk(hipSetDevice(h->device), "hipSetDevice");
+    for (uint64_t b = 0; b < n_batch; b++) {
+      const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_rows - b * B);
+      const int which = (int)(b & 1);
+      const bool ok = rc == FMX_OK && failed.load(std::memory_order_relaxed) == FMX_OK;
+      if (ok && i == 0 && b < n_timed) chk(hipEventRecord(h0->ev_pool[4 * b + 0], h0->stream), "hipEventRecord");
+      if (ok) { const int prc = fmx_sgd_partial(h, slot, b * B, nb, h->xbuf[which], h->stream); if (prc) rc = prc; }
+      if (ok && i == 0 && b < n_timed) chk(hipEventRecord(h0->ev_pool[4 * b + 1], h0->stream), "hipEventRecord");
+      if (loop) {
+        if (ok && rc == FMX_OK && i) chk(hipEventRecord(g->ev_part[i], h->stream), "hipEventRecord");
+        if (rc && failed.load() == FMX_OK) failed.store(rc);
+        bar.wait();                                              // every shard's "sums are enqueued" event has been recorded
+        if (i == 0 && failed.load() == FMX_OK) {
+          BufList bl; bl.n = (int)n;
+          for (size_t q = 0; q < n; q++) { bl.p[q] = g->hs[q]->xbuf[which]; if (q) chk(hipStreamWaitEvent(h0->stream, g->ev_part[q], 0), "hipStreamWaitEvent"); }
+          const size_t count = (size_t)nb * kp1;
+          hipLaunchKernelGGL(k_sum_shards, dim3((unsigned)std::min<size_t>((count / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, h0->stream, bl, count / 4, count);
+          chk(hipGetLastError(), "k_sum_shards");
+          chk(hipEventRecord(g->ev_sum, h0->stream), "hipEventRecord");
+          if (rc && failed.load() == FMX_OK) failed.store(rc);
+        }
+        bar.wait();                                              // the "sum is ready" event has been recorded
+        if (rc == FMX_OK && failed.load() == FMX_OK && i) chk(hipStreamWaitEvent(h->stream, g->ev_sum, 0), "hipStreamWaitEvent");
+      } else if (ok && rc == FMX_OK) {
+        float* xb = h->xbuf[which];
+        const ncclResult_t nr = R->AllReduce(xb, xb, (size_t)nb * kp1, ncclFloat32, ncclSum, (ncclComm_t)g->comms[i], h->stream);
+        if (nr != ncclSuccess) rc = fail(h, FMX_E_HIP, "ncclAllReduce failed: %s", R->GetErrorString(nr));
+      }
+      if (rc == FMX_OK && failed.load(std::memory_order_relaxed) == FMX_OK) {
+        if (i == 0 && b < n_timed) chk(hipEventRecord(h0->ev_pool[4 * b + 2], h0->stream), "hipEventRecord");
+        const int frc = fmx_sgd_finish(h, slot, b * B, nb, h->xbuf[which], &opts, h->stream);
+        if (frc) rc = frc;
+        if (i == 0 && b < n_timed) chk(hipEventRecord(h0->ev_pool[4 * b + 3], h0->stream), "hipEventRecord");
+      }
+      if (rc && failed.load() == FMX_OK) failed.store(rc);
+    }
+    rcs[i] = rc;
+  };
+  std::vector<std::thread> th;
+  th.reserve(n - 1);
+  for (size_t i = 1; i < n; i++) th.emplace_back(body, i);
+  body(0);
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < n; i++) if (rcs[i]) { g->err = g->hs[i]->err; return rcs[i]; }
+  return FMX_OK;
+}
+
 // one epoch of the minibatch rule over feature shards:  per batch  partial sums on every shard -> ONE exchange ->
 // multipliers / bias recurrence (redundantly on every shard) + update of the local rows.
 //   exact (default): the batch rule of oracle fmo_sgd_epoch_minibatch_ex -- identical, shard count aside, to what a single
@@ -757,8 +840,16 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
     return mark(b, 3);
   };
   int rc = FMX_OK;
+  // opt-in (FMX_GROUP_THREADS=1): on one device the runtime serialises the eight threads' calls and the step got SLOWER -- 8 loopback shards of
+  // BASELINE configs[2]: 1.16 M examples/s threaded against 2.28 M from one thread in one stream (1.08 M for the general schedule; round 6, call 17)
+  static const bool threads_ok = []() { const char* e = getenv("FMX_GROUP_THREADS"); return e && e[0] == '1'; }();
+  const bool threaded = small && threads_ok && n > 1;
+  if (threaded) {
+    rc = group_small_epoch_threads(g, slot, opts, B, n_rows, n_batch, n_timed);
+    HIPCHK(h0, hipSetDevice(h0->device));
+  }
   if (n_batch && pipeline) rc = gather_timed(0);
-  for (uint64_t b = 0; b < n_batch && rc == FMX_OK; b++) {
+  for (uint64_t b = 0; b < n_batch && rc == FMX_OK && !threaded; b++) {
     if (pipeline) { if (b + 1 < n_batch) rc = gather_timed(b + 1); }      // reads the parameters before update(b): one batch stale
     else rc = gather_timed(b);
     if (rc == FMX_OK) rc = update(b);
