@@ -882,6 +882,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       if (sw.nseg) {
         // segments per wavefront of the deferred-feature pass: 16 (measured best at the bench shape: 8 / 16 / 32 / 64 -> 244.5 / 245.0 /
         // 243.0 / 241.0 M examples/s), fewer when the list is short so that the pass still spreads over the chip
+        // (rows in flight per round: 8; round 6 measured 4 / 8 / 16 at the bench shape: 274.7 / 274.3 / 267.2 M examples/s)
         if (sw.nseg >= 16u * 2048u)     { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 16>), ((uint64_t)sw.nseg + 15) / 16, st, sw, h->tb, hy)); }
         else if (sw.nseg >= 4u * 2048u) { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 4>), ((uint64_t)sw.nseg + 3) / 4, st, sw, h->tb, hy)); }
         else                            { KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply_seg<KP, 8, 1>), (uint64_t)sw.nseg, st, sw, h->tb, hy)); }
