@@ -784,7 +784,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
   // without a comm stream or events (RCCL: on the compute stream; loopback: every shard's launches go to shard 0's stream, in order), two
   // launches for the update (sgd_finish_impl): 3 launches (+ 1 collective call) per shard and batch where the general schedule makes ~20 calls.
   // FMX_GROUP_IN_STREAM=0 keeps the general schedule.
-  static const bool in_stream_ok = []() { const char* e = getenv("FMX_GROUP_IN_STREAM"); return !(e && e[0] == '0'); }();
+  const bool in_stream_ok = []() { const char* e = getenv("FMX_GROUP_IN_STREAM"); return !(e && e[0] == '0'); }();   // (read per epoch: tests switch it)
   bool small = in_stream_ok && B < 32768u && (opts.flags & FMX_FLAG_BIAS_LAG) && !pipeline && !(opts.flags & FMX_FLAG_TIME_MAIN_KERNEL && false);
   if (small)
     for (auto m : g->hs) small = small && multi_group_size(m->slots[slot], m->KP) != 0 && (opts.apply == FMX_APPLY_DEFAULT || opts.apply == FMX_APPLY_FUSED);
@@ -842,7 +842,7 @@ int fmx_group_sgd_epoch(fmx_group g, int slot, const fmx_sgd_opts* opts_in, fmx_
   int rc = FMX_OK;
   // opt-in (FMX_GROUP_THREADS=1): on one device the runtime serialises the eight threads' calls and the step got SLOWER -- 8 loopback shards of
   // BASELINE configs[2]: 1.16 M examples/s threaded against 2.28 M from one thread in one stream (1.08 M for the general schedule; round 6, call 17)
-  static const bool threads_ok = []() { const char* e = getenv("FMX_GROUP_THREADS"); return e && e[0] == '1'; }();
+  const bool threads_ok = []() { const char* e = getenv("FMX_GROUP_THREADS"); return e && e[0] == '1'; }();
   const bool threaded = small && threads_ok && n > 1;
   if (threaded) {
     rc = group_small_epoch_threads(g, slot, opts, B, n_rows, n_batch, n_timed);

@@ -57,14 +57,6 @@ __device__ __forceinline__ uint32_t xcc_id() {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 0xfu;
 }
-// the address of a parameter row as a wave-uniform 64-bit value (two scalar registers): a load / store of the row is then "scalar base + lane
-// offset" -- no vector instruction is spent on the address (one XCD has an eighth of the chip's vector units: they are the budget here)
-__device__ __forceinline__ const float* uni_ptr(const float* p) {
-  const uint64_t u = (uint64_t)p;
-  const uint64_t r = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-  return (const float*)r;
-}
-__device__ __forceinline__ float* uni_ptr(float* p) { return const_cast<float*>(uni_ptr(const_cast<const float*>(p))); }
 template <int VEC, bool STREAM = false> __device__ __forceinline__ void ld_l2_vec(const float* p, float (&out)[VEC]) {
   static_assert(VEC == 1 || VEC == 2, "rows of 64 or 128 floats");
   if constexpr (STREAM) {
@@ -77,13 +69,6 @@ template <int VEC, bool STREAM = false> __device__ __forceinline__ void ld_l2_ve
   else {
     const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[0] = __uint_as_float((uint32_t)u); out[1] = __uint_as_float((uint32_t)(u >> 32));
-  }
-}
-template <int VEC> __device__ __forceinline__ void st_stream_vec(float* p, const float (&in)[VEC]) {
-  if constexpr (VEC == 1) __builtin_nontemporal_store(in[0], p);
-  else {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f t; t.x = in[0]; t.y = in[1]; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(p));
   }
 }
 // a parameter row through the die's L2 (rows are tb.rs floats: the lanes beyond take no part, fmx_kernels.h row_ld)

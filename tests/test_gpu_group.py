@@ -108,6 +108,36 @@ def test_short_rows_of_a_shard_several_examples_per_wavefront(capi, oracle, k, w
         h.close()
 
 
+@pytest.mark.parametrize("schedule", ["general", "in_stream", "threads"])
+def test_small_batch_schedules_of_the_group_driver_are_one_rule(capi, oracle, monkeypatch, schedule):
+    """a 512-row batch over 8 shards (BASELINE configs[2]'s shape of the step) through the three schedules fmx_group_sgd_epoch has for it:
+    the general one (~20 host calls per shard and batch: comm-stream events, the recurrence on the side stream), the in-stream one (default:
+    3 launches per shard and batch) and the in-stream one with a host thread per shard (FMX_GROUP_THREADS=1) -- the oracle's rule at 1e-4."""
+    monkeypatch.setenv("FMX_GROUP_IN_STREAM", "0" if schedule == "general" else "1")
+    monkeypatch.setenv("FMX_GROUP_THREADS", "1" if schedule == "threads" else "0")
+    import datagen as DG
+    rows, k, world, lag = 4000, 64, 8, 2
+    e, rp, y, n = DG.criteo_shaped(rows, 21, cat_ids=2000)
+    d = oracle.Data(e, rp, y)
+    m = oracle.Model(n, k, True, True, 0.0, 0.0005, 0.001)
+    m.v[:] = oracle.init_values(3, n, k, 0.05)
+    m.w0 = 0.03
+    hs, grp = make_group(capi, world, [0] * world, n, k, 1, (0.0, 0.0005, 0.001), 0.01, -1.0, 1.0, 1)
+    grp.set_params(m.w0, m.w, m.v)
+    grp.upload_rows(0, e, rp, y)
+    for _ in range(2):
+        st = grp.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_DEFAULT, 0, 0, capi.FLAG_BIAS_LAG, lag)
+        assert 64 <= st.batch_used <= 4096 and st.batches >= 4
+        oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -1.0, 1.0, st.batch_used, st.w0_chunk_used, bias_lag=lag)
+    w0, w, v = grp.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+    grp.close()
+    for h in hs:
+        h.close()
+
+
 def test_hashed_ownership_balances_structured_ids(capi):
     """ids that are all multiples of 8 (or all inside one residue class of any small modulus) land on ONE shard under
     `j mod P`; the permutation spreads them"""
