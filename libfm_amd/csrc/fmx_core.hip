@@ -4,6 +4,7 @@
 // No CPU fallback lives in this library: every compute entry point needs a HIP device and fails with FMX_E_HIP
 // otherwise.  Nothing here links or calls oracle/.
 #include "fmx_internal.h"
+#include <atomic>
 #include <mutex>
 
 static thread_local std::string g_create_error = "";
@@ -548,6 +549,7 @@ int fmx_abi_version(void) { return FMX_ABI_VERSION; }
 
 // ---- device allocations (fmx_internal.h: fmx_dev_alloc / fmx_dev_free) -----------------------------------------------------------
 namespace {
+std::atomic<uint64_t> g_devices_used{0};                              // devices fmx_create has opened a handle on in this process
 struct BigAlloc { size_t reserved = 0; int device = 0; std::vector<hipMemGenericAllocationHandle_t> hnd; std::vector<size_t> sz; };
 std::mutex g_big_mu;
 std::unordered_map<void*, BigAlloc> g_big;
@@ -592,13 +594,15 @@ bool big_alloc(void** p, size_t bytes) {
   }
   const double t_map = ms();
   if (ok) {
-    // read / write for the owning device and -- where the runtime grants it -- for its peers (fmx_group_upload_rows copies staged rows
-    // between devices); a peer the runtime refuses is not an error here
+    // read / write for the owning device and -- where the runtime grants it -- for the OTHER DEVICES THIS PROCESS HOLDS HANDLES ON
+    // (fmx_group_upload_rows copies staged rows between the devices of a one-process group); a peer the runtime refuses is not an error
+    // here.  A process that drives one GPU (one process per GPU: the multi-GPU bench) never touches another device.
     int ndev = 0; (void)hipGetDeviceCount(&ndev);
     hipMemAccessDesc acc = {}; acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
     ok = hipMemSetAccess(va, b.reserved, &acc, 1) == hipSuccess;
-    for (int d = 0; ok && d < ndev; d++) {
-      if (d == dev) continue;
+    const uint64_t used = g_devices_used.load(std::memory_order_relaxed);
+    for (int d = 0; ok && d < ndev && d < 64; d++) {
+      if (d == dev || !((used >> d) & 1ull)) continue;
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, d, dev) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
       acc.location.id = d;
@@ -697,6 +701,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
       fail(nullptr, FMX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));               \
       fmx_destroy(h); return FMX_E_HIP; } } while (0)
   CREATE_CHK(hipSetDevice(dev));
+  if (dev >= 0 && dev < 64) g_devices_used.fetch_or(1ull << dev, std::memory_order_relaxed);
   CREATE_CHK(hipGetDeviceProperties(&h->prop, dev));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_CHK(hipEventCreate(&h->ev0));
