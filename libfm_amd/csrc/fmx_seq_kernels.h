@@ -1,0 +1,434 @@
+// k_sequential_rows: the reference's own trajectory (fm_learn_sgd_element.h:56-67: one example at a time, in file order; fm_sgd.h:33-51) on ONE
+// wavefront, a row at a time instead of an entry at a time.
+//
+// k_sequential (fmx_kernels.h) walks a row entry by entry and drains the store queue after each: 32 dependent round trips per example,
+// 46 us per example at the bench shape -- slower than the CPU it is the parity instrument for (21.8 k vs 26.8 k examples/s).  The loop of
+// the reference does not need that: its update of entry i reads the sums of the WHOLE row (fm.m_sum, taken before the first update) and the
+// parameter v_{j_i, f} itself, which only an EARLIER entry of the same row with the same id can have changed.  So for a row without a
+// repeated id (every one-hot row; checked per row) the example is: gather all its rows at once (one round trip), sums in fp64 in entry
+// order, multiplier, bias step, every row updated from its registers, stored.  What the NEXT example must see is only what it shares with
+// this one -- so its rows are asked for BEFORE this example's stores are issued (their latency runs under this example's arithmetic) and
+// the few it shares with this example (found by comparing the ids) are read again after the stores have drained.
+// Rows with a repeated id, and rows beyond the register path, take the entry-by-entry loop (seq_row_entries: k_sequential's body).
+// The update arithmetic is fp32 with its per-example constants formed in fp64 (the parameters are fp32; the sums stay fp64).
+#pragma once
+
+namespace fmx {
+
+// one row, entry by entry, every store drained before the next entry (k_sequential's loop body: repeated ids see their own earlier update)
+template <int KP>
+__device__ __forceinline__ void seq_row_entries(const Entry* __restrict__ ent, uint64_t a, uint32_t size, float yf, const Tab& tb, const Hyper& h, double& w0) {
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool act = lane < LPR && lane * VEC < tb.rs;
+  double sum[VEC]; double sq = 0.0, lin = 0.0;
+#pragma unroll
+  for (int v = 0; v < VEC; v++) sum[v] = 0.0;
+  for (uint32_t i = 0; i < size; i++) {
+    const Entry e = ent[a + i];
+    if (h.k1 && lane == 0) lin += (double)ld_l2(tb.w + (size_t)e.id * tb.ws) * (double)e.value;
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        const double d = (double)ld_l2(tb.V + (size_t)e.id * tb.rs + lane * VEC + v) * (double)e.value;
+        sum[v] += d;
+        sq += d * d;
+      }
+    }
+  }
+  double part = lin - 0.5 * sq;
+  if (act) {
+#pragma unroll
+    for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+  }
+  double p = (h.k0 ? w0 : 0.0) + wave_sum_d(part);
+  const double y = (double)yf;
+  double mult;
+  if (h.task == 0) { p = fmin(h.max_d, p); p = fmax(h.min_d, p); mult = -(y - p); }
+  else mult = -y * (1.0 - 1.0 / (1.0 + exp(-y * p)));
+  if (h.k0) w0 -= h.lr_d * (mult + h.reg0_d * w0);
+  for (uint32_t i = 0; i < size; i++) {
+    const Entry e = ent[a + i];
+    const double x = (double)e.value;
+    if (h.k1 && lane == 0) {
+      const double wv = (double)ld_l2(tb.w + (size_t)e.id * tb.ws);
+      tb.w[(size_t)e.id * tb.ws] = (float)(wv - h.lr_d * (mult * x + h.regw_d * wv));
+    }
+    if (act) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        float* pv = tb.V + (size_t)e.id * tb.rs + lane * VEC + v;
+        const double vv = (double)ld_l2(pv);
+        const double grad = sum[v] * x - vv * x * x;
+        *pv = (float)(vv - h.lr_d * (mult * grad + h.regv_d * vv));
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // a later entry of this row (repeated id) and the next row must observe these stores
+  }
+}
+
+struct SeqRow { uint64_t a; uint32_t size; float y; Entry en; };
+__device__ __forceinline__ SeqRow seq_meta(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint32_t r, uint32_t n_rows) {
+  SeqRow m; m.a = 0; m.size = 0; m.y = 0.f; m.en.id = 0; m.en.value = 0.f;
+  if (r < n_rows) {
+    const uint32_t lane = threadIdx.x & 63u;
+    m.a = row_ptr[r];
+    m.size = uni((uint32_t)(row_ptr[r + 1] - m.a));
+    m.y = __uint_as_float(uni(__float_as_uint(target[r])));
+    if (lane < m.size && m.size <= 64u) m.en = ent[m.a + lane];
+  }
+  return m;
+}
+// rows (and weights) of an example into registers, L2-served
+template <int KP, int ZR, int T>
+__device__ __forceinline__ void seq_rows_load(const Tab& tb, uint32_t ids, uint32_t size, float (&vr)[ZR][Map<KP>::VEC]) {
+  constexpr int VEC = Map<KP>::VEC;
+  if constexpr (T < ZR) {
+    if ((uint32_t)T < size) xcd_row_ld<VEC>(tb, (size_t)lane_val<T>(ids), vr[T]);
+    else {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) vr[T][v] = 0.f;
+    }
+    seq_rows_load<KP, ZR, T + 1>(tb, ids, size, vr);
+  }
+}
+// the rows of the NEXT example that this example has just written (bit t of `again`): read once more
+template <int KP, int ZR, int T>
+__device__ __forceinline__ void seq_rows_again(const Tab& tb, uint32_t ids, uint64_t again, float (&vr)[ZR][Map<KP>::VEC]) {
+  constexpr int VEC = Map<KP>::VEC;
+  if constexpr (T < ZR) {
+    if ((again >> T) & 1ull) xcd_row_ld<VEC>(tb, (size_t)lane_val<T>(ids), vr[T]);
+    seq_rows_again<KP, ZR, T + 1>(tb, ids, again, vr);
+  }
+}
+template <int KP, int ZR, int T>
+__device__ __forceinline__ void seq_rows_sum(uint32_t xs, uint32_t size, const float (&vr)[ZR][Map<KP>::VEC], double (&sum)[Map<KP>::VEC], double& sq) {
+  constexpr int VEC = Map<KP>::VEC;
+  if constexpr (T < ZR) {
+    if ((uint32_t)T < size) {                                      // (wave-uniform; in entry order, like the reference's loop)
+      const double x = (double)__uint_as_float(lane_val<T>(xs));
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        const double d = (double)vr[T][v] * x;
+        sum[v] += d;
+        sq += d * d;
+      }
+    }
+    seq_rows_sum<KP, ZR, T + 1>(xs, size, vr, sum, sq);
+  }
+}
+template <int KP, int ZR, int T>
+__device__ __forceinline__ void seq_rows_store(const Tab& tb, uint32_t ids, uint32_t xs, uint32_t size, const float (&vr)[ZR][Map<KP>::VEC], const float (&sumf)[Map<KP>::VEC],
+                                               float lm, float lrv) {
+  constexpr int VEC = Map<KP>::VEC;
+  if constexpr (T < ZR) {
+    if ((uint32_t)T < size) {
+      const float x = __uint_as_float(lane_val<T>(xs));
+      float nv[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {                              // fm_sgd.h:47-49: v -= lr (mult (sum x - v x x) + regv v)
+        const float vv = vr[T][v];
+        const float grad = sumf[v] * x - vv * x * x;
+        nv[v] = vv - (lm * grad + lrv * vv);
+      }
+      xcd_row_st<VEC>(tb, (size_t)lane_val<T>(ids), nv);
+    }
+    seq_rows_store<KP, ZR, T + 1>(tb, ids, xs, size, vr, sumf, lm, lrv);
+  }
+}
+
+// one example: `cur` with its rows in R / weights in wv (asked for while the previous example ran); asks for `nxt`'s rows into Rn / wn
+template <int KP, int ZR>
+__device__ __forceinline__ void seq_step(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint32_t r, uint32_t n_rows,
+                                         const Tab& tb, const Hyper& h, double& w0, SeqRow& cur, float (&R)[ZR][Map<KP>::VEC], float& wv, bool& have,
+                                         SeqRow& nxt, float (&Rn)[ZR][Map<KP>::VEC], float& wn, bool& have_n) {
+  constexpr int VEC = Map<KP>::VEC;
+  const uint32_t lane = threadIdx.x & 63u;
+  nxt = seq_meta(ent, row_ptr, target, r + 1, n_rows);            // read-only: asked for now, needed when this example is done
+  have_n = false;
+  if (r >= n_rows) return;
+  // the entry registers pass an empty statement: as "values of a load" the compiler would drain every outstanding load before each broadcast
+  const uint32_t ids = opaque(cur.en.id), xs = opaque(__float_as_uint(cur.en.value));
+  bool fast = have && cur.size <= (uint32_t)ZR;
+  if (fast) {                                                     // a repeated id inside the row: the entry-by-entry loop (fm_sgd.h:44-50 semantics)
+    bool dup = false;
+    for (uint32_t t = 1; t < cur.size; t++) {
+      const uint32_t idt = bcast_u32<1>(ids, t);
+      dup |= (lane < t) && (ids == idt);
+    }
+    if (__ballot(dup) != 0ull) fast = false;
+  }
+  if (!fast) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    seq_row_entries<KP>(ent, cur.a, cur.size, cur.y, tb, h, w0);  // (drains its own stores)
+    if (nxt.size && nxt.size <= (uint32_t)ZR) {                  // nothing is in flight: the next example's rows are read after this one's stores
+      const uint32_t idn = opaque(nxt.en.id);
+      wn = 0.f;
+      if (h.k1 && lane < nxt.size) wn = ld_l2(tb.w + (size_t)idn * tb.ws);
+      seq_rows_load<KP, ZR, 0>(tb, idn, nxt.size, Rn);
+      have_n = true;
+    }
+    return;
+  }
+  // ---- sums (fm_model.h:116-125) in fp64, in entry order ----
+  double sum[VEC]; double sq = 0.0;
+#pragma unroll
+  for (int v = 0; v < VEC; v++) sum[v] = 0.0;
+  seq_rows_sum<KP, ZR, 0>(xs, cur.size, R, sum, sq);
+  const float xl = __uint_as_float(xs);
+  double part = ((h.k1 && lane < cur.size) ? (double)wv * (double)xl : 0.0) - 0.5 * sq;
+  if (lane * VEC < tb.rs) {
+#pragma unroll
+    for (int v = 0; v < VEC; v++) part += 0.5 * sum[v] * sum[v];
+  }
+  double p = (h.k0 ? w0 : 0.0) + wave_sum_d(part);
+  const double y = (double)cur.y;
+  double mult;
+  if (h.task == 0) { p = fmin(h.max_d, p); p = fmax(h.min_d, p); mult = -(y - p); }
+  else mult = -y * (1.0 - 1.0 / (1.0 + exp(-y * p)));
+  if (h.k0) w0 -= h.lr_d * (mult + h.reg0_d * w0);                // fm_sgd.h:34-37
+  // ---- the next example's rows: asked for BEFORE this example's stores (their latency runs under the update below) ----
+  uint32_t idn = 0;
+  const bool pre = nxt.size != 0u && nxt.size <= (uint32_t)ZR;
+  // (what the PREVIOUS examples stored must be in memory before these loads are issued -- their stores were issued an example ago, the wait
+  //  is over before it starts; what THIS example is about to store is handled below)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (pre) {
+    idn = opaque(nxt.en.id);
+    wn = 0.f;
+    if (h.k1 && lane < nxt.size) wn = ld_l2(tb.w + (size_t)idn * tb.ws);
+    seq_rows_load<KP, ZR, 0>(tb, idn, nxt.size, Rn);
+    have_n = true;
+  }
+  // ---- update from the registers (fm_sgd.h:38-50), fp32 with the example's constants formed in fp64 ----
+  const float lm = (float)(h.lr_d * mult), lrv = (float)(h.lr_d * h.regv_d), lrw = (float)(h.lr_d * h.regw_d);
+  if (h.k1 && lane < cur.size) tb.w[(size_t)ids * tb.ws] = wv - (lm * xl + lrw * wv);
+  float sumf[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; v++) sumf[v] = (float)sum[v];
+  seq_rows_store<KP, ZR, 0>(tb, ids, xs, cur.size, R, sumf, lm, lrv);
+  // ---- what the next example shares with this one was read too early: once more, after the stores have drained ----
+  if (pre) {
+    bool hit = false;
+    for (uint32_t t = 0; t < cur.size; t++) {
+      const uint32_t idt = bcast_u32<1>(ids, t);
+      hit |= (idn == idt);
+    }
+    const uint64_t again = __ballot(hit && lane < nxt.size);
+    if (again != 0ull) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (h.k1 && lane < nxt.size && ((again >> lane) & 1ull)) wn = ld_l2(tb.w + (size_t)idn * tb.ws);
+      seq_rows_again<KP, ZR, 0>(tb, idn, again, Rn);
+    }
+  }
+}
+
+template <int KP, int ZR>
+__global__ void __launch_bounds__(64)
+k_sequential_rows(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
+                  uint32_t n_rows, const Tab tb, Hyper h, double* w0_ptr) {
+  static_assert(Map<KP>::EPI == 1, "one row per wave-wide load");
+  constexpr int VEC = Map<KP>::VEC;
+  const uint32_t lane = threadIdx.x & 63u;
+  double w0 = *w0_ptr;
+  float A[ZR][VEC], B[ZR][VEC];
+  float wA = 0.f, wB = 0.f;
+  bool haveA = false, haveB = false;
+  SeqRow ra = seq_meta(ent, row_ptr, target, 0, n_rows), rb;
+  if (ra.size && ra.size <= (uint32_t)ZR) {
+    const uint32_t id0 = opaque(ra.en.id);
+    if (h.k1 && lane < ra.size) wA = ld_l2(tb.w + (size_t)id0 * tb.ws);
+    seq_rows_load<KP, ZR, 0>(tb, id0, ra.size, A);
+    haveA = true;
+  }
+#pragma unroll 1
+  for (uint32_t r = 0; r < n_rows; r += 2) {
+    seq_step<KP, ZR>(ent, row_ptr, target, r, n_rows, tb, h, w0, ra, A, wA, haveA, rb, B, wB, haveB);
+    seq_step<KP, ZR>(ent, row_ptr, target, r + 1, n_rows, tb, h, w0, rb, B, wB, haveB, ra, A, wA, haveA);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) *w0_ptr = w0;
+}
+
+}  // namespace fmx
+
+namespace fmx {
+
+// ----------------------------------------------------------------------------------------------
+// k_sequential_wg: the same trajectory with EIGHT wavefronts on each example.  One wavefront issues ~3 000 instructions per 32-entry example
+// and nothing hides their latency (k_sequential_rows: 7.6 us per example); here wavefront w takes the entries t = w, w + 8, ... : its part
+// of the gathers, of the fp64 sums (combined through the LDS, one workgroup barrier per example), of the update.  Everything scalar -- the
+// prediction, the multiplier, the bias step -- is computed by every wavefront from the same numbers in the same order, so all of them hold
+// the same w0.  The next example's rows are asked for before this example's stores, as in k_sequential_rows; what the two share is found
+// through a table of stamps in the LDS (bucket = hash of the id; a false hit only costs a second read) and read again behind a second
+// barrier.  A repeated id inside a row (found the same way, confirmed exactly) or a row beyond 64 entries: the first wavefront runs the
+// entry-by-entry loop and hands the bias on.
+// ----------------------------------------------------------------------------------------------
+constexpr int SEQ_W = 8, SEQ_SLOTS = 8;                          // wavefronts per example, row slots per wavefront (64 entries)
+constexpr uint32_t SEQ_BUCKETS = 8192;
+template <int KP> struct SeqLds {
+  double sum[2][SEQ_W][KP];
+  double sq[2][SEQ_W][64];
+  uint32_t stamp[2][SEQ_BUCKETS];
+  uint32_t dup[SEQ_BUCKETS];
+  double w0;
+};
+__device__ __forceinline__ uint32_t seq_bucket(uint32_t id) { return (id * 0x9E3779B1u) >> 19; }   // 13 bits
+
+template <int KP>
+__device__ __forceinline__ void seq_wg_ask(const Tab& tb, const Hyper& h, const SeqRow& m, uint32_t ids, uint32_t wv, float (&R)[SEQ_SLOTS][Map<KP>::VEC], float& wl) {
+  constexpr int VEC = Map<KP>::VEC;
+  const uint32_t lane = threadIdx.x & 63u;
+  wl = 0.f;
+  if (h.k1 && lane < m.size) wl = ld_l2(tb.w + (size_t)ids * tb.ws);
+#pragma unroll
+  for (int i = 0; i < SEQ_SLOTS; i++) {
+    const uint32_t t = wv + (uint32_t)SEQ_W * i;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) R[i][v] = 0.f;
+    if (t < m.size) xcd_row_ld<VEC>(tb, (size_t)bcast_u32<1>(ids, t), R[i]);
+  }
+}
+
+template <int KP>
+__device__ __forceinline__ void seq_wg_step(SeqLds<KP>& L, const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
+                                            uint32_t r, uint32_t n_rows, const Tab& tb, const Hyper& h, double& w0,
+                                            SeqRow& cur, float (&R)[SEQ_SLOTS][Map<KP>::VEC], float& wl, bool& have,
+                                            SeqRow& nxt, float (&Rn)[SEQ_SLOTS][Map<KP>::VEC], float& wn, bool& have_n) {
+  constexpr int VEC = Map<KP>::VEC;
+  const uint32_t lane = threadIdx.x & 63u, wv = uni(threadIdx.x >> 6);
+  const uint32_t par = r & 1u;
+  nxt = seq_meta(ent, row_ptr, target, r + 1, n_rows);
+  have_n = false;
+  if (r >= n_rows) return;
+  const uint32_t ids = opaque(cur.en.id), xs = opaque(__float_as_uint(cur.en.value));
+  bool fast = have && cur.size <= 64u;
+  if (fast) {                                                     // a repeated id?  every wavefront asks the same table the same question
+    const uint32_t b = seq_bucket(ids);
+    volatile uint32_t* dupt = L.dup;                              // (volatile: the read must come from the LDS -- another LANE may have written the bucket)
+    if (lane < cur.size) dupt[b] = lane;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0)
+    bool maybe = lane < cur.size && dupt[b] != lane;
+    if (__ballot(maybe) != 0ull) {
+      bool dup = false;
+      for (uint32_t t = 1; t < cur.size; t++) dup |= (lane < t) && (ids == bcast_u32<1>(ids, t));
+      if (__ballot(dup) != 0ull) fast = false;
+    }
+  }
+  if (!fast) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wv == 0) {
+      seq_row_entries<KP>(ent, cur.a, cur.size, cur.y, tb, h, w0);
+      if (lane == 0) L.w0 = w0;
+    }
+    __syncthreads();
+    w0 = L.w0;
+    if (nxt.size && nxt.size <= 64u) { seq_wg_ask<KP>(tb, h, nxt, opaque(nxt.en.id), wv, Rn, wn); have_n = true; }
+    return;
+  }
+  // ---- this wavefront's part of the sums, fp64, in entry order ----
+  double sum[VEC]; double sq = 0.0;
+#pragma unroll
+  for (int v = 0; v < VEC; v++) sum[v] = 0.0;
+#pragma unroll
+  for (int i = 0; i < SEQ_SLOTS; i++) {
+    const uint32_t t = wv + (uint32_t)SEQ_W * i;
+    if (t < cur.size) {
+      const double x = (double)__uint_as_float(bcast_u32<1>(xs, t));
+#pragma unroll
+      for (int v = 0; v < VEC; v++) { const double d = (double)R[i][v] * x; sum[v] += d; sq += d * d; }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; v++) L.sum[par][wv][lane * VEC + v] = sum[v];
+  L.sq[par][wv][lane] = sq;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wavefront's stores of the previous example are in memory ...
+  __syncthreads();                                               // ... and so are everybody's; the partial sums are in the LDS
+  double tot[VEC]; double tsq = 0.0;
+#pragma unroll
+  for (int v = 0; v < VEC; v++) tot[v] = 0.0;
+#pragma unroll
+  for (int q = 0; q < SEQ_W; q++) {                              // (the same order in every wavefront: they all hold the same numbers)
+#pragma unroll
+    for (int v = 0; v < VEC; v++) tot[v] += L.sum[par][q][lane * VEC + v];
+    tsq += L.sq[par][q][lane];
+  }
+  const float xl = __uint_as_float(xs);
+  double part = ((h.k1 && lane < cur.size) ? (double)wl * (double)xl : 0.0) - 0.5 * tsq;
+#pragma unroll
+  for (int v = 0; v < VEC; v++) part += 0.5 * tot[v] * tot[v];
+  double p = (h.k0 ? w0 : 0.0) + wave_sum_d(part);
+  const double y = (double)cur.y;
+  double mult;
+  if (h.task == 0) { p = fmin(h.max_d, p); p = fmax(h.min_d, p); mult = -(y - p); }
+  else mult = -y * (1.0 - 1.0 / (1.0 + exp(-y * p)));
+  if (h.k0) w0 -= h.lr_d * (mult + h.reg0_d * w0);                // fm_sgd.h:34-37
+  // ---- the next example's rows, before this example's stores ----
+  const bool pre = nxt.size != 0u && nxt.size <= 64u;
+  uint32_t idn = 0;
+  if (pre) { idn = opaque(nxt.en.id); seq_wg_ask<KP>(tb, h, nxt, idn, wv, Rn, wn); have_n = true; }
+  // ---- this wavefront's part of the update (fm_sgd.h:38-50) ----
+  const float lm = (float)(h.lr_d * mult), lrv = (float)(h.lr_d * h.regv_d), lrw = (float)(h.lr_d * h.regw_d);
+  if (wv == 0 && h.k1 && lane < cur.size) tb.w[(size_t)ids * tb.ws] = wl - (lm * xl + lrw * wl);
+  float totf[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; v++) totf[v] = (float)tot[v];
+#pragma unroll
+  for (int i = 0; i < SEQ_SLOTS; i++) {
+    const uint32_t t = wv + (uint32_t)SEQ_W * i;
+    if (t < cur.size) {
+      const float x = __uint_as_float(bcast_u32<1>(xs, t));
+      float nv[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) { const float vv = R[i][v]; nv[v] = vv - (lm * (totf[v] * x - vv * x * x) + lrv * vv); }
+      xcd_row_st<VEC>(tb, (size_t)bcast_u32<1>(ids, t), nv);
+    }
+  }
+  // ---- what the next example shares with this one was read too early (every wavefront finds the same answer) ----
+  if (pre) {
+    volatile uint32_t* stt = L.stamp[par];
+    if (lane < cur.size) stt[seq_bucket(ids)] = r + 1u;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0)
+    const bool hit = lane < nxt.size && stt[seq_bucket(idn)] == r + 1u;
+    const uint64_t again = __ballot(hit);
+    if (again != 0ull) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                           // everybody's stores of this example are in memory
+      if (h.k1 && ((again >> lane) & 1ull)) wn = ld_l2(tb.w + (size_t)idn * tb.ws);
+#pragma unroll
+      for (int i = 0; i < SEQ_SLOTS; i++) {
+        const uint32_t t = wv + (uint32_t)SEQ_W * i;
+        if (t < nxt.size && ((again >> t) & 1ull)) xcd_row_ld<VEC>(tb, (size_t)bcast_u32<1>(idn, t), Rn[i]);
+      }
+    }
+  }
+}
+
+template <int KP>
+__global__ void __launch_bounds__(64 * SEQ_W)
+k_sequential_wg(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
+                uint32_t n_rows, const Tab tb, Hyper h, double* w0_ptr) {
+  static_assert(Map<KP>::EPI == 1, "one row per wave-wide load");
+  constexpr int VEC = Map<KP>::VEC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds_raw[];
+  SeqLds<KP>& L = *reinterpret_cast<SeqLds<KP>*>(seq_lds_raw);
+  const uint32_t wv = uni(threadIdx.x >> 6);
+  for (uint32_t i = threadIdx.x; i < SEQ_BUCKETS; i += blockDim.x) { L.stamp[0][i] = 0u; L.stamp[1][i] = 0u; L.dup[i] = 0u; }
+  __syncthreads();
+  double w0 = *w0_ptr;
+  float A[SEQ_SLOTS][VEC], B[SEQ_SLOTS][VEC];
+  float wA = 0.f, wB = 0.f;
+  bool haveA = false, haveB = false;
+  SeqRow ra = seq_meta(ent, row_ptr, target, 0, n_rows), rb;
+  if (ra.size && ra.size <= 64u) { seq_wg_ask<KP>(tb, h, ra, opaque(ra.en.id), wv, A, wA); haveA = true; }
+#pragma unroll 1
+  for (uint32_t r = 0; r < n_rows; r += 2) {
+    seq_wg_step<KP>(L, ent, row_ptr, target, r, n_rows, tb, h, w0, ra, A, wA, haveA, rb, B, wB, haveB);
+    seq_wg_step<KP>(L, ent, row_ptr, target, r + 1, n_rows, tb, h, w0, rb, B, wB, haveB, ra, A, wA, haveA);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) *w0_ptr = w0;
+}
+
+}  // namespace fmx

@@ -2,6 +2,7 @@
 // the multi-GPU driver, the bias-lag bookkeeping, the (batch, feature) segment build, and SGDA.
 #include "fmx_internal.h"
 #include "fmx_xcd_kernels.h"
+#include "fmx_seq_kernels.h"
 
 namespace {
 // default micro-chunk of the bias recurrence.  The reference moves w0 after EVERY example (fm_sgd.h:34-37); summing the
@@ -428,7 +429,12 @@ extern "C++" int lag_flush(fmx_handle h) {                      // make h->w0 th
   if (!L.active) return FMX_OK;
   if (L.in_stream) { HIPCHK(h, hipStreamSynchronize(L.in_stream)); L.in_stream = nullptr; }
   HIPCHK(h, hipStreamSynchronize(h->stream2));
-  HIPCHK(h, hipMemcpy(h->w0, h->w0_pp + (L.step % (L.depth + 1)), sizeof(double), hipMemcpyDeviceToDevice));
+  // on the handle's OWN stream, then drained: the streams are non-blocking, so a device-to-device hipMemcpy (null stream; it may return before
+  // the copy has run) is not ordered against what the next epoch enqueues on h->stream -- its ring of bias slots was then, once in a few
+  // thousand epochs, initialised from the bias of BEFORE this epoch (round 6: tests/test_gpu_fuzz.py seed 16 ended at w0 = -0.0076 instead of
+  // -0.0163: exactly the second epoch started from the first epoch's start value)
+  HIPCHK(h, hipMemcpyAsync(h->w0, h->w0_pp + (L.step % (L.depth + 1)), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   L.active = false; L.step = 0;
   return scan_error_check(h);                                 // (callers that drive fmx_sgd_partial / _finish themselves and then read parameters)
 }
@@ -967,6 +973,28 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   if (opts->mode == FMX_SGD_SEQUENTIAL) {
+    // rows of 64 / 128 lanes: a row at a time with the next example's rows in flight (fmx_seq_kernels.h: 20 k -> ~1 M examples/s on the
+    // reference's own trajectory); FMX_SEQ_ROWS=0 and the other row widths: entry by entry
+    static const bool seq_rows = []() { const char* e = getenv("FMX_SEQ_ROWS"); return !(e && e[0] == '0'); }();
+    static const bool seq_wg = []() { const char* e = getenv("FMX_SEQ_WG"); return !(e && e[0] == '0'); }();
+    if (seq_rows && seq_wg && (h->KP == 64 || h->KP == 128)) {
+      // eight wavefronts on each example (fmx_seq_kernels.h k_sequential_wg); FMX_SEQ_WG=0: one wavefront, a row at a time
+      if (h->KP == 64) {
+        auto kf = k_sequential_wg<64>;
+        if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<64>))); h->lds_raised.insert((const void*)kf); }
+        hipLaunchKernelGGL(kf, dim3(1), dim3(64 * SEQ_W), sizeof(SeqLds<64>), h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
+      } else {
+        auto kf = k_sequential_wg<128>;
+        if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<128>))); h->lds_raised.insert((const void*)kf); }
+        hipLaunchKernelGGL(kf, dim3(1), dim3(64 * SEQ_W), sizeof(SeqLds<128>), h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
+      }
+    } else if (seq_rows && (h->KP == 64 || h->KP == 128)) {
+      const bool wide = s.max_row > 32u;
+      if (h->KP == 64) { if (wide) hipLaunchKernelGGL((k_sequential_rows<64, 64>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
+                         else      hipLaunchKernelGGL((k_sequential_rows<64, 32>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0); }
+      else             { if (wide) hipLaunchKernelGGL((k_sequential_rows<128, 64>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
+                         else      hipLaunchKernelGGL((k_sequential_rows<128, 32>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0); }
+    } else
     KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr,
                                           s.target, s.n_rows, h->tb, hy, h->w0));
     HIPCHK(h, hipGetLastError());
