@@ -758,6 +758,20 @@ def main():
             extras["hogwild"] = {"mode": "hogwild (asynchronous one-pass step; parity only metric-level -- NOT the headline)",
                                  "batch": 262144, "value": timed_epochs(5, capi.SGD_HOGWILD, capi.APPLY_DEFAULT, 262144, args.w0_chunk, 0),
                                  "unit": "examples/s", "steps": 5}
+        # the reference's OWN trajectory (fm_learn_sgd_element.h:56-67: one example at a time, file order) on the device: the parity mode,
+        # exact to 1e-4 against the real reference's final parameters (tests/test_gpu_parity.py); eight wavefronts per example
+        try:
+            seq_rows = 1 << 16
+            h.synth_rows(1, 321, 0, seq_rows, args.nnz)
+            h.sgd_epoch(1, capi.SGD_SEQUENTIAL)
+            h.synchronize()
+            t1 = time.perf_counter()
+            h.sgd_epoch(1, capi.SGD_SEQUENTIAL)
+            h.synchronize()
+            extras["sequential"] = {"mode": "FMX_SGD_SEQUENTIAL: the reference's own example-by-example trajectory on the device (k_sequential_wg)",
+                                    "value": round(seq_rows / (time.perf_counter() - t1), 1), "unit": "examples/s", "rows": seq_rows}
+        except Exception as exc:
+            extras["sequential"] = {"error": str(exc)[:200]}
         if args.mode != "minibatch":
             extras["minibatch_two_pass"] = {"mode": "minibatch rule, two passes (k_rowsums + k_apply_seg), bias lag 1", "batch": 131072,
                                             "value": timed_epochs(3, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 131072, args.w0_chunk, capi.FLAG_BIAS_LAG),
@@ -879,6 +893,8 @@ def main():
             roof["predict_v_read_frac_cold"] = pr["without_side_stream"]["v_read_frac"]
             roof["predict_rows_per_s"] = pr["value"]
             roof["predict_rows_per_s_cold"] = pr["without_side_stream"]["value"]
+            if isinstance(extras.get("sequential"), dict) and "value" in extras["sequential"]:
+                roof["examples_per_s_sequential"] = extras["sequential"]["value"]
             roof["predict"] = {"v_read_frac": pr["v_read_frac"], "v_read_frac_cold": pr["without_side_stream"]["v_read_frac"],
                                "rows_per_s": pr["value"], "rows_per_s_cold": pr["without_side_stream"]["value"],
                                "cold": "no weight side stream (a pass that no epoch on the slot preceded)"}

@@ -290,16 +290,44 @@ __device__ __forceinline__ void seq_wg_ask(const Tab& tb, const Hyper& h, const 
   }
 }
 
+// the read-only part of an example, asked for TWO examples ahead: its entries start where the previous row's end (no dependent load: the
+// address is known), its end offset and label are single loads; nothing here is waited for before the example after next begins
+struct SeqAhead { uint64_t a, end; float y; Entry en; bool in; };
+__device__ __forceinline__ SeqAhead seq_ahead(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
+                                              uint32_t r, uint32_t n_rows, uint64_t a, uint64_t nnz) {
+  SeqAhead m; m.a = a; m.end = a; m.y = 0.f; m.en.id = 0; m.en.value = 0.f; m.in = r < n_rows;
+  if (m.in) {
+    const uint32_t lane = threadIdx.x & 63u;
+    m.end = row_ptr[r + 1];
+    m.y = target[r];
+    if (nnz) m.en = ent[min(a + lane, nnz - 1)];                 // (the lanes beyond the row are dropped when its length is known)
+  }
+  return m;
+}
+__device__ __forceinline__ SeqRow seq_finish(const SeqAhead& m) {
+  SeqRow o; o.a = m.a; o.size = 0; o.y = 0.f; o.en.id = 0; o.en.value = 0.f;
+  if (m.in) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t len = m.end - m.a;
+    o.size = uni((uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len));
+    o.y = __uint_as_float(uni(__float_as_uint(m.y)));
+    if (lane < o.size && o.size <= 64u) o.en = m.en;
+  }
+  return o;
+}
+
 template <int KP>
 __device__ __forceinline__ void seq_wg_step(SeqLds<KP>& L, const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
-                                            uint32_t r, uint32_t n_rows, const Tab& tb, const Hyper& h, double& w0,
-                                            SeqRow& cur, float (&R)[SEQ_SLOTS][Map<KP>::VEC], float& wl, bool& have,
-                                            SeqRow& nxt, float (&Rn)[SEQ_SLOTS][Map<KP>::VEC], float& wn, bool& have_n) {
+                                            uint32_t r, uint32_t n_rows, uint64_t nnz, const Tab& tb, const Hyper& h, double& w0,
+                                            const SeqRow& cur, float (&R)[SEQ_SLOTS][Map<KP>::VEC], float& wl, bool& have,
+                                            SeqRow& nxt, const SeqAhead& nxt_raw, float (&Rn)[SEQ_SLOTS][Map<KP>::VEC], float& wn, bool& have_n,
+                                            SeqAhead& after) {
   constexpr int VEC = Map<KP>::VEC;
   const uint32_t lane = threadIdx.x & 63u, wv = uni(threadIdx.x >> 6);
   const uint32_t par = r & 1u;
-  nxt = seq_meta(ent, row_ptr, target, r + 1, n_rows);
+  nxt = seq_finish(nxt_raw);                                      // (asked for a whole example ago)
   have_n = false;
+  after.in = false; after.a = nxt.a + nxt.size; after.end = after.a; after.y = 0.f; after.en.id = 0; after.en.value = 0.f;
   if (r >= n_rows) return;
   const uint32_t ids = opaque(cur.en.id), xs = opaque(__float_as_uint(cur.en.value));
   bool fast = have && cur.size <= 64u;
@@ -325,6 +353,7 @@ __device__ __forceinline__ void seq_wg_step(SeqLds<KP>& L, const Entry* __restri
     __syncthreads();
     w0 = L.w0;
     if (nxt.size && nxt.size <= 64u) { seq_wg_ask<KP>(tb, h, nxt, opaque(nxt.en.id), wv, Rn, wn); have_n = true; }
+    after = seq_ahead(ent, row_ptr, target, r + 2, n_rows, nxt.a + nxt.size, nnz);
     return;
   }
   // ---- this wavefront's part of the sums, fp64, in entry order ----
@@ -345,6 +374,12 @@ __device__ __forceinline__ void seq_wg_step(SeqLds<KP>& L, const Entry* __restri
   L.sq[par][wv][lane] = sq;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wavefront's stores of the previous example are in memory ...
   __syncthreads();                                               // ... and so are everybody's; the partial sums are in the LDS
+  // ---- asked for NOW: the next example's rows (before this example's stores: their latency runs under everything below), and the
+  //      read-only part of the example after it (nothing waits for that before the next barrier) ----
+  const bool pre = nxt.size != 0u && nxt.size <= 64u;
+  uint32_t idn = 0;
+  if (pre) { idn = opaque(nxt.en.id); seq_wg_ask<KP>(tb, h, nxt, idn, wv, Rn, wn); have_n = true; }
+  after = seq_ahead(ent, row_ptr, target, r + 2, n_rows, nxt.a + nxt.size, nnz);
   double tot[VEC]; double tsq = 0.0;
 #pragma unroll
   for (int v = 0; v < VEC; v++) tot[v] = 0.0;
@@ -364,10 +399,6 @@ __device__ __forceinline__ void seq_wg_step(SeqLds<KP>& L, const Entry* __restri
   if (h.task == 0) { p = fmin(h.max_d, p); p = fmax(h.min_d, p); mult = -(y - p); }
   else mult = -y * (1.0 - 1.0 / (1.0 + exp(-y * p)));
   if (h.k0) w0 -= h.lr_d * (mult + h.reg0_d * w0);                // fm_sgd.h:34-37
-  // ---- the next example's rows, before this example's stores ----
-  const bool pre = nxt.size != 0u && nxt.size <= 64u;
-  uint32_t idn = 0;
-  if (pre) { idn = opaque(nxt.en.id); seq_wg_ask<KP>(tb, h, nxt, idn, wv, Rn, wn); have_n = true; }
   // ---- this wavefront's part of the update (fm_sgd.h:38-50) ----
   const float lm = (float)(h.lr_d * mult), lrv = (float)(h.lr_d * h.regv_d), lrw = (float)(h.lr_d * h.regw_d);
   if (wv == 0 && h.k1 && lane < cur.size) tb.w[(size_t)ids * tb.ws] = wl - (lm * xl + lrw * wl);
@@ -408,7 +439,7 @@ __device__ __forceinline__ void seq_wg_step(SeqLds<KP>& L, const Entry* __restri
 template <int KP>
 __global__ void __launch_bounds__(64 * SEQ_W)
 k_sequential_wg(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target,
-                uint32_t n_rows, const Tab tb, Hyper h, double* w0_ptr) {
+                uint32_t n_rows, uint64_t nnz, const Tab tb, Hyper h, double* w0_ptr) {
   static_assert(Map<KP>::EPI == 1, "one row per wave-wide load");
   constexpr int VEC = Map<KP>::VEC;
   extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds_raw[];
@@ -420,12 +451,20 @@ k_sequential_wg(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_
   float A[SEQ_SLOTS][VEC], B[SEQ_SLOTS][VEC];
   float wA = 0.f, wB = 0.f;
   bool haveA = false, haveB = false;
-  SeqRow ra = seq_meta(ent, row_ptr, target, 0, n_rows), rb;
-  if (ra.size && ra.size <= 64u) { seq_wg_ask<KP>(tb, h, ra, opaque(ra.en.id), wv, A, wA); haveA = true; }
+  // three examples' read-only parts rotate (this one, the next: finished at its step's start, the one after: being read), two row buffers
+  SeqRow c0 = seq_meta(ent, row_ptr, target, 0, n_rows), c1, c2;
+  c1.a = 0; c1.size = 0; c1.y = 0.f; c1.en.id = 0; c1.en.value = 0.f; c2 = c1;
+  SeqAhead m0, m1 = seq_ahead(ent, row_ptr, target, 1, n_rows, c0.a + c0.size, nnz), m2;
+  m0 = m1; m0.in = false; m2 = m0;
+  if (c0.size && c0.size <= 64u) { seq_wg_ask<KP>(tb, h, c0, opaque(c0.en.id), wv, A, wA); haveA = true; }
 #pragma unroll 1
-  for (uint32_t r = 0; r < n_rows; r += 2) {
-    seq_wg_step<KP>(L, ent, row_ptr, target, r, n_rows, tb, h, w0, ra, A, wA, haveA, rb, B, wB, haveB);
-    seq_wg_step<KP>(L, ent, row_ptr, target, r + 1, n_rows, tb, h, w0, rb, B, wB, haveB, ra, A, wA, haveA);
+  for (uint32_t r = 0; r < n_rows; r += 6) {
+    seq_wg_step<KP>(L, ent, row_ptr, target, r + 0, n_rows, nnz, tb, h, w0, c0, A, wA, haveA, c1, m1, B, wB, haveB, m2);
+    seq_wg_step<KP>(L, ent, row_ptr, target, r + 1, n_rows, nnz, tb, h, w0, c1, B, wB, haveB, c2, m2, A, wA, haveA, m0);
+    seq_wg_step<KP>(L, ent, row_ptr, target, r + 2, n_rows, nnz, tb, h, w0, c2, A, wA, haveA, c0, m0, B, wB, haveB, m1);
+    seq_wg_step<KP>(L, ent, row_ptr, target, r + 3, n_rows, nnz, tb, h, w0, c0, B, wB, haveB, c1, m1, A, wA, haveA, m2);
+    seq_wg_step<KP>(L, ent, row_ptr, target, r + 4, n_rows, nnz, tb, h, w0, c1, A, wA, haveA, c2, m2, B, wB, haveB, m0);
+    seq_wg_step<KP>(L, ent, row_ptr, target, r + 5, n_rows, nnz, tb, h, w0, c2, B, wB, haveB, c0, m0, A, wA, haveA, m1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0) *w0_ptr = w0;

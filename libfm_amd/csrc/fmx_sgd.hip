@@ -982,11 +982,11 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
       if (h->KP == 64) {
         auto kf = k_sequential_wg<64>;
         if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<64>))); h->lds_raised.insert((const void*)kf); }
-        hipLaunchKernelGGL(kf, dim3(1), dim3(64 * SEQ_W), sizeof(SeqLds<64>), h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
+        hipLaunchKernelGGL(kf, dim3(1), dim3(64 * SEQ_W), sizeof(SeqLds<64>), h->stream, s.ent, s.row_ptr, s.target, s.n_rows, s.nnz, h->tb, hy, h->w0);
       } else {
         auto kf = k_sequential_wg<128>;
         if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<128>))); h->lds_raised.insert((const void*)kf); }
-        hipLaunchKernelGGL(kf, dim3(1), dim3(64 * SEQ_W), sizeof(SeqLds<128>), h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
+        hipLaunchKernelGGL(kf, dim3(1), dim3(64 * SEQ_W), sizeof(SeqLds<128>), h->stream, s.ent, s.row_ptr, s.target, s.n_rows, s.nnz, h->tb, hy, h->w0);
       }
     } else if (seq_rows && (h->KP == 64 || h->KP == 128)) {
       const bool wide = s.max_row > 32u;
