@@ -84,6 +84,24 @@ def test_config2_sgd_criteo_shaped_at_size(capi, oracle):
     h.close()
 
 
+def test_reference_trajectory_on_criteo_shaped_rows_at_size(capi, oracle):
+    """FMX_SGD_SEQUENTIAL -- the reference's own loop (fm_learn_sgd_element.h:56-67: one example at a time, file order) -- at BASELINE
+    configs[2]'s size: every example shares its 13 dense-field features with its neighbours, so k_sequential_wg reads those rows a
+    second time behind its second barrier for nearly every example; two epochs == the oracle's ONLINE loop on the sub-model at 1e-4."""
+    n, k, nnz, rows = 33_000_000, 64, 39, 12_000
+    h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+    h.init_params(0.0, 0.05, 23)
+    h.synth_rows(0, 77, 250_000, rows, nnz, capi.SYNTH_CRITEO)
+    ent, rp, y = h.download_rows(0)
+    d, m, ids = sub_model(oracle, h, ent, rp, y, k, (0.0, 0.0, 0.001))
+    for _ in range(2):
+        h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
+        oracle.sgd_epoch_online(m, d, 1, 0.01, -1.0, 1.0)
+    assert_rows(h, m, ids, atol=2e-5)
+    np.testing.assert_allclose(h.predict(0, rows), oracle.predict_raw(m, d), rtol=1e-4, atol=5e-5)
+    h.close()
+
+
 def test_config2_eight_shards_criteo_shaped(capi, oracle):
     """BASELINE configs[2] AS IT IS WORDED: 'Criteo-Kaggle-shaped: 3.3e7 features, k = 64, 39 entries per row, SGD, V row-sharded across 8':
     eight feature shards (on one GPU: the loopback exchange) driven by fmx_group_sgd_epoch at the library's batch (512 rows at lr 0.01: the
