@@ -48,9 +48,12 @@ enum { FMX_TASK_REGRESSION = 0, FMX_TASK_CLASSIFICATION = 1 };   /* fm_learn.h:4
 /* SGD update modes */
 enum {
   FMX_SGD_SEQUENTIAL = 0,  /* batch = 1, rows in storage order: the reference trajectory
-                              (fm_learn_sgd_element.h:56-67).  A PARITY mode, not a production mode: ONE wavefront,
-                              latency-bound, ~40x SLOWER than the reference on its own CPU (5.8 s vs 0.14 s on
-                              configs[0]).  Never make it a default; the adapters default to MINIBATCH. */
+                              (fm_learn_sgd_element.h:56-67), exact to 1e-4 against the reference's final parameters.  One
+                              example at a time on eight wavefronts (k <= 128; libfm_amd/csrc/fmx_seq_kernels.h): ~370 k
+                              examples/s whatever the shape -- 14x the reference on one core where its model misses the
+                              caches (BASELINE's headline shape: 26.8 k examples/s), 30x SLOWER than it where the model
+                              is cache-resident (configs[0]: 11 M examples/s on the CPU).  The parity mode; the adapters
+                              default to MINIBATCH. */
   FMX_SGD_MINIBATCH = 1,   /* restated batch rule (oracle/fm_oracle.h fmo_sgd_epoch_minibatch):
                               partial sums -> [all-reduce] -> w0 micro-chunks + multipliers -> scatter-add */
   FMX_SGD_HOGWILD = 2      /* fused single pass per example (gather, predict, update in registers);

@@ -977,9 +977,10 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     // reference's own trajectory); FMX_SEQ_ROWS=0 and the other row widths: entry by entry
     static const bool seq_rows = []() { const char* e = getenv("FMX_SEQ_ROWS"); return !(e && e[0] == '0'); }();
     static const bool seq_wg = []() { const char* e = getenv("FMX_SEQ_WG"); return !(e && e[0] == '0'); }();
-    if (seq_rows && seq_wg && (h->KP == 64 || h->KP == 128)) {
-      // eight wavefronts on each example (fmx_seq_kernels.h k_sequential_wg); FMX_SEQ_WG=0: one wavefront, a row at a time
-      if (h->KP == 64) {
+    if (seq_rows && seq_wg && h->KP <= 128) {
+      // eight wavefronts on each example (fmx_seq_kernels.h k_sequential_wg); FMX_SEQ_WG=0: one wavefront, a row at a time.
+      // Fewer than 33 factors run the 64-lane instance too: a row access masks the lanes beyond the row (tb.rs), whatever the lane mapping
+      if (h->KP <= 64) {
         auto kf = k_sequential_wg<64>;
         if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<64>))); h->lds_raised.insert((const void*)kf); }
         hipLaunchKernelGGL(kf, dim3(1), dim3(64 * SEQ_W), sizeof(SeqLds<64>), h->stream, s.ent, s.row_ptr, s.target, s.n_rows, s.nnz, h->tb, hy, h->w0);
@@ -988,9 +989,9 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
         if (!h->lds_raised.count((const void*)kf)) { HIPCHK(h, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<128>))); h->lds_raised.insert((const void*)kf); }
         hipLaunchKernelGGL(kf, dim3(1), dim3(64 * SEQ_W), sizeof(SeqLds<128>), h->stream, s.ent, s.row_ptr, s.target, s.n_rows, s.nnz, h->tb, hy, h->w0);
       }
-    } else if (seq_rows && (h->KP == 64 || h->KP == 128)) {
+    } else if (seq_rows && h->KP <= 128) {
       const bool wide = s.max_row > 32u;
-      if (h->KP == 64) { if (wide) hipLaunchKernelGGL((k_sequential_rows<64, 64>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
+      if (h->KP <= 64) { if (wide) hipLaunchKernelGGL((k_sequential_rows<64, 64>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
                          else      hipLaunchKernelGGL((k_sequential_rows<64, 32>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0); }
       else             { if (wide) hipLaunchKernelGGL((k_sequential_rows<128, 64>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0);
                          else      hipLaunchKernelGGL((k_sequential_rows<128, 32>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr, s.target, s.n_rows, h->tb, hy, h->w0); }
