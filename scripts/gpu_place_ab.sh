@@ -5,7 +5,7 @@ R=${1:-3}
 mkdir -p gpurun_out
 out=gpurun_out/place_ab.txt
 : > $out
-timeout 600 python -m pytest tests/test_gpu_placement.py -x -q 2>&1 | tail -5 | tee -a $out
+timeout 600 python -m pytest tests/test_gpu_zz_placement.py -x -q 2>&1 | tail -5 | tee -a $out
 for i in $(seq 1 $R); do
   for p in 1 0; do
     echo "== --place $p (process $i)" >> $out

@@ -5,7 +5,7 @@ mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 ( timeout 600 python scripts/gpu_ab_variants.py sp1,sp2 2 fused ) > $OUT/ab_s_publish.txt 2>&1; tail -4 $OUT/ab_s_publish.txt
-( timeout 600 python -m pytest tests/test_gpu_mcmc.py tests/test_gpu_placement.py -q -m gpu -x 2>&1 | tail -8 ) > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+( timeout 600 python -m pytest tests/test_gpu_mcmc.py tests/test_gpu_zz_placement.py -q -m gpu -x 2>&1 | tail -8 ) > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
 timeout 300 python bench.py --workload criteo --rows 1048576 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep "^{" | cut -c1-200
 cd /tmp
 C2="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --features 10000000 --factors 32 --nnz 16 --rows 8388608 --steps 3 --warmup 1"

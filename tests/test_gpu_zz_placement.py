@@ -1,5 +1,10 @@
 """fmx_create's placement of big parameter tables (an arena of 1 GiB chunks from two memory classes, fmx_config::place_candidates):
-what it reports, that results do not depend on it, that it gives its memory back."""
+what it reports, that results do not depend on it, that it gives its memory back.
+
+(The file sorts LAST on purpose: round 6 saw ONE abort inside fmx_create in test_candidate_bound_is_honoured in twelve runs of the whole
+suite -- SIGABRT from below the C-ABI, output lost to the capture; eighteen repetitions of this file alone and five more suite runs did
+not bring it back (scripts/calls/r6_call25.sh .. _call27.sh).  Until it is understood, whatever it is must not take the tests behind it
+along.)"""
 import numpy as np
 import pytest
 
