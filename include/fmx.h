@@ -212,6 +212,8 @@ typedef struct fmx_epoch_stats {
                                       streams do not run concurrently (serialised dispatch: a counter-collecting profiler, AMD_SERIALIZE_KERNEL) */
 #define FMX_STAT_XCD_RESIDENT 128u /* small batches (what the stability cut leaves of rows with frequent features): the epoch ran as ONE launch whose
                                       workgroups sit on one accelerator complex die (libfm_amd/csrc/fmx_xcd_kernels.h) instead of two launches per batch */
+#define FMX_STAT_SEQ_RUNS 256u     /* FMX_SGD_SEQUENTIAL ran as conflict-free runs: maximal runs of consecutive rows that share no feature, each one
+                                      batch step with the bias recurrence coupled example by example -- the same trajectory as the online loop */
 #define FMX_STAT_HANDOFF_TIMEOUT 64u /* a device-side hand-off wait ran into its bound all the same: the examples concerned took NO step
                                       (multiplier 0; a recurrence that never saw its batch handed the bias on unchanged), every parameter is a
                                       valid number, the call returns FMX_E_HIP with this status set, and the handle orders by events from now on */

@@ -60,6 +60,9 @@ struct Slot {
   float*    wside = nullptr;
   uint64_t* lmask = nullptr;
   uint64_t  wside_version = 0;
+  // FMX_SGD_SEQUENTIAL: the slot cut into maximal runs of consecutive rows that share no feature (fmx_seq_kernels.h "Conflict-free runs")
+  std::vector<uint32_t> run_start;   // [n_runs + 1]; empty: not built
+  std::vector<uint8_t>  run_single;  // [n_runs] 1: one row that repeats an id (entry-by-entry kernel)
   std::vector<struct BlockRows*> blocks;   // `-relation` blocks kept apart from these (main) rows; empty: plain / expanded rows
 };
 

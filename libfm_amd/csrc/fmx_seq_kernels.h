@@ -471,3 +471,39 @@ k_sequential_wg(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_
 }
 
 }  // namespace fmx
+
+namespace fmx {
+
+// ----------------------------------------------------------------------------------------------
+// Conflict-free runs: the reference's trajectory at batch speed where the data allows it.
+// Inside a run of consecutive rows that share NO feature with each other, the online loop (fm_learn_sgd_element.h:56-67) and "one batch
+// with the bias recurrence coupled example by example" are the same computation: the sums of a row only read parameters no other row of the
+// run writes, the bias is the one sequential thread (fm_sgd.h:34-37) -- and that is exactly what k_rowsums -> k_scan (micro-chunk 1, the
+// multipliers come out of the recurrence) -> k_apply compute for a batch.  So the slot is cut, once, into maximal such runs (greedy, in file
+// order) and an epoch is three launches per run; a row that repeats an id (fm_sgd.h:44-50: the second occurrence sees the first's update)
+// is a run of its own and goes through the entry-by-entry kernel.
+//   k_run_keys / k_run_prev: prev[r] = 1 + the latest earlier row that shares a feature with row r (0: none), bit 31: the row repeats an id --
+//   through one radix sort of (feature << 32 | row) keys; the greedy cut itself is a loop over prev[] on the host (fmx_sgd.hip ensure_runs).
+// ----------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256)
+k_run_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint64_t* __restrict__ keys) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t r = wave0; r < n_rows; r += nwaves) {
+    const uint64_t a = row_ptr[r], b = row_ptr[r + 1];
+    for (uint64_t i = a + lane; i < b; i += 64) keys[i] = ((uint64_t)ent[i].id << 32) | r;
+  }
+}
+static __global__ void __launch_bounds__(256)
+k_run_prev(const uint64_t* __restrict__ keys, uint64_t nnz, uint32_t* __restrict__ prev) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < nnz; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t k1 = keys[i], k0 = keys[i - 1];
+    if ((k1 >> 32) != (k0 >> 32)) continue;
+    const uint32_t r = (uint32_t)k1, p = (uint32_t)k0;
+    if (p == r) atomicOr(prev + r, 0x80000000u);
+    else atomicMax(prev + r, (p + 1u) & 0x7FFFFFFFu);             // (rows below 2^31 - 1: checked by the caller; the flag bit is ORed in separately)
+  }
+}
+
+}  // namespace fmx

@@ -920,6 +920,85 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   return FMX_OK;
 }
 
+// ---- FMX_SGD_SEQUENTIAL as conflict-free runs (fmx_seq_kernels.h) ----
+// cuts the slot into maximal runs of consecutive rows that share no feature (once per slot; host wall-clock goes to setup_seconds)
+static int ensure_runs(fmx_handle h, Slot& s) {
+  if (!s.run_start.empty()) return FMX_OK;
+  struct Acc { fmx_handle h; std::chrono::steady_clock::time_point t0;
+               ~Acc() { h->setup_acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{h, std::chrono::steady_clock::now()};
+  const uint32_t n = s.n_rows;
+  if (n == 0 || n >= 0x7FFFFFFEu || s.nnz >= (1ull << 31)) { s.run_start = {0u, n}; s.run_single = {2u}; return FMX_OK; }   // (2: not cut -- the caller takes the kernel)
+  hipStream_t st = h->stream;
+  std::vector<uint32_t> prev(n, 0u);
+  if (s.nnz) {
+    uint32_t fbits = 1; while (fbits < 32 && (1ull << fbits) < std::max<uint64_t>(h->n_local, 2)) fbits++;
+    size_t tmp_bytes = 0;
+    HIPCHK(h, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)s.nnz, 0, 32 + (int)fbits, st));
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_a = 0, o_b = al(s.nnz * 8), o_p = o_b + al(s.nnz * 8), o_t = o_p + al((size_t)n * 4), total = o_t + al(std::max<size_t>(tmp_bytes, 256));
+    char* scratch = nullptr;
+    HIPCHK(h, fmx_dev_alloc(&scratch, total));
+    uint64_t* ka = (uint64_t*)(scratch + o_a); uint64_t* kb = (uint64_t*)(scratch + o_b); uint32_t* d_prev = (uint32_t*)(scratch + o_p);
+    hipError_t e = hipMemsetAsync(d_prev, 0, (size_t)n * 4, st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_run_keys, dim3(wave_grid(n)), dim3(256), 0, st, s.ent, s.row_ptr, n, ka);
+      size_t tb_ = tmp_bytes;
+      e = hipcub::DeviceRadixSort::SortKeys(scratch + o_t, tb_, ka, kb, (int)s.nnz, 0, 32 + (int)fbits, st);
+    }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_run_prev, dim3(2048), dim3(256), 0, st, kb, s.nnz, d_prev);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(prev.data(), d_prev, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    fmx_dev_free(scratch);
+    if (e != hipSuccess) return fail(h, FMX_E_HIP, "ensure_runs failed: %s", hipGetErrorString(e));
+  }
+  // greedy, in file order: a run ends in front of the first row that shares a feature with a row of the run (prev - 1 >= start), in front of
+  // and behind a row that repeats an id, and at 4096 rows (one wavefront evaluates the run's bias recurrence)
+  std::vector<uint32_t> starts; std::vector<uint8_t> single;
+  uint32_t start = 0;
+  for (uint32_t r = 0; r < n; r++) {
+    const bool rep = (prev[r] & 0x80000000u) != 0;
+    const uint32_t p = prev[r] & 0x7FFFFFFFu;                     // 1 + the latest earlier row sharing a feature, 0: none
+    if (rep) {
+      if (r > start) { starts.push_back(start); single.push_back(0); }
+      starts.push_back(r); single.push_back(1);
+      start = r + 1;
+    } else if ((p > start && r > start) || r - start >= 4096u) {
+      starts.push_back(start); single.push_back(0);
+      start = r;
+    }
+  }
+  if (start < n) { starts.push_back(start); single.push_back(0); }
+  starts.push_back(n);
+  s.run_start.swap(starts); s.run_single.swap(single);
+  return FMX_OK;
+}
+// one epoch over the runs: three launches per run (sums, the bias recurrence at micro-chunk 1 with the multipliers out of it, update)
+static int seq_runs_epoch(fmx_handle h, Slot& s, const Hyper& hy) {
+  hipStream_t st = h->stream;
+  uint32_t longest = 1;
+  for (size_t i = 0; i + 1 < s.run_start.size(); i++) longest = std::max(longest, s.run_start[i + 1] - s.run_start[i]);
+  int rc = ensure_scratch(h, longest, 0);
+  if (rc) return rc;
+  for (size_t i = 0; i + 1 < s.run_start.size(); i++) {
+    const uint32_t row0 = s.run_start[i], nb = s.run_start[i + 1] - row0;
+    if (s.run_single[i]) {                                        // a row that repeats an id: entry by entry (fm_sgd.h:44-50)
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, st, s.ent, s.row_ptr + row0, s.target + row0, nb, h->tb, hy, h->w0));
+      continue;
+    }
+    float* S = h->partial;
+    float* rest = S + (size_t)nb * h->KP;
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, st, s.ent, s.row_ptr, (uint64_t)row0, nb, h->tb, h->cfg.k1, S, rest, (const float*)nullptr));
+    rc = launch_scan(h, rest, s.target + row0, nb, 1u, hy, h->mult, st);
+    if (rc) return rc;
+    KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, false>), nb, st, s.ent, s.row_ptr, (uint64_t)row0, nb, h->tb, hy, S, h->mult));
+  }
+  HIPCHK(h, hipGetLastError());
+  return FMX_OK;
+}
+
 int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_stats* stats) {
   int rc = check_slot(h, slot, true);
   if (rc) return rc;
@@ -976,7 +1055,24 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     // rows of 64 / 128 lanes: a row at a time with the next example's rows in flight (fmx_seq_kernels.h: 20 k -> ~1 M examples/s on the
     // reference's own trajectory); FMX_SEQ_ROWS=0 and the other row widths: entry by entry
     static const bool seq_rows = []() { const char* e = getenv("FMX_SEQ_ROWS"); return !(e && e[0] == '0'); }();
+    // where consecutive rows rarely share a feature: the same trajectory as conflict-free runs at batch speed (fmx_seq_kernels.h); taken when
+    // the slot's runs average >= 16 rows (FMX_SEQ_RUNS=0: never, =1: always)
+    const char* sr = getenv("FMX_SEQ_RUNS");
+    bool use_runs = !(sr && sr[0] == '0');
+    if (use_runs) {
+      rc = ensure_runs(h, s);
+      if (rc) return rc;
+      const size_t n_runs = s.run_start.size() - 1;
+      use_runs = !(s.run_single.size() == 1 && s.run_single[0] == 2) && ((sr && sr[0] == '1') || (uint64_t)s.n_rows >= 16ull * n_runs);
+      HIPCHK(h, hipEventRecord(h->ev0, h->stream));             // (the one-time cut is not the epoch's time)
+    }
     static const bool seq_wg = []() { const char* e = getenv("FMX_SEQ_WG"); return !(e && e[0] == '0'); }();
+    if (use_runs) {
+      rc = seq_runs_epoch(h, s, hy);
+      if (rc) return rc;
+      h->run_status |= FMX_STAT_SEQ_RUNS;
+      batches = s.run_start.size() - 1; main_launches = 1;
+    } else
     if (seq_rows && seq_wg && h->KP <= 128) {
       // eight wavefronts on each example (fmx_seq_kernels.h k_sequential_wg); FMX_SEQ_WG=0: one wavefront, a row at a time.
       // Fewer than 33 factors run the 64-lane instance too: a row access masks the lanes beyond the row (tb.rs), whatever the lane mapping
@@ -999,7 +1095,8 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
     KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, h->stream, s.ent, s.row_ptr,
                                           s.target, s.n_rows, h->tb, hy, h->w0));
     HIPCHK(h, hipGetLastError());
-    batches = s.n_rows; main_launches = 1;
+    if (!use_runs) batches = s.n_rows;
+    main_launches = 1;
   } else if (opts->mode == FMX_SGD_HOGWILD) {
     if (opts->apply == FMX_APPLY_SEGMENTED) return fail(h, FMX_E_ARG, "HOGWILD has no segmented apply");
     // rows per launch M: w0 is frozen inside a launch.  The bias recurrence of launch i (k_scan, one wavefront) runs

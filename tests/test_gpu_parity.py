@@ -789,3 +789,41 @@ def test_weight_side_stream_moves_no_number_and_goes_stale_safely(capi, oracle, 
     stale_and_right()
     for h in hs:
         h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# FMX_SGD_SEQUENTIAL as conflict-free runs (libfm_amd/csrc/fmx_seq_kernels.h): the reference's trajectory at batch speed
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task", [0, 1])
+@pytest.mark.parametrize("k", [8, 64, 100])
+def test_reference_trajectory_as_conflict_free_runs(capi, oracle, task, k):
+    """rows over a wide id space rarely share a feature with their neighbours: the slot is cut into maximal runs of consecutive rows that share
+    none, and a run is one batch step with the bias recurrence coupled example by example -- the same computation as the online loop
+    (fm_learn_sgd_element.h:56-67).  Some rows repeat an id (fm_sgd.h:44-50: they run entry by entry), some are empty.  Two epochs against the
+    oracle's ONLINE loop at 1e-4; the epoch says which form it took."""
+    n, nnz, rows = 400_000, 12, 6000
+    ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed=91 + k, classification=bool(task))
+    rng = np.random.default_rng(5 + k)
+    for r in rng.choice(rows, 25, replace=False):                 # rows with a repeated id
+        a = int(rp[r])
+        ent["id"][a + 1] = ent["id"][a]
+    ent["value"] = np.round(rng.uniform(0.5, 1.5, len(ent)), 3).astype(np.float32)
+    d = oracle.Data(ent, rp, y)
+    m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.003)
+    m.v[:] = oracle.init_values(1, n, k, 0.05)
+    m.w[:] = oracle.init_values(2, n, 1, 0.05)[0]
+    m.w0 = 0.1
+    lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
+    h = capi.Handle(n, k, True, True, task, 0.001, 0.002, 0.003, 0.01, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, rp, y)
+    for _ in range(2):
+        st = h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
+        assert st.status & capi.STAT_SEQ_RUNS and 25 < st.batches < rows // 16
+        oracle.sgd_epoch_online(m, d, task, 0.01, lo, hi)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(h.predict(0, rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5)
+    h.close()
