@@ -485,6 +485,169 @@ namespace fmx {
 //   k_run_keys / k_run_prev: prev[r] = 1 + the latest earlier row that shares a feature with row r (0: none), bit 31: the row repeats an id --
 //   through one radix sort of (feature << 32 | row) keys; the greedy cut itself is a loop over prev[] on the host (fmx_sgd.hip ensure_runs).
 // ----------------------------------------------------------------------------------------------
+// ---- a run's bias recurrence + update in ONE launch (k_run_apply) ----
+// The recurrence of a run (micro-chunk 1: the multiplier of example e is taken at the bias after example e - 1, fm_sgd.h:34-37) is a chain of
+// n dependent steps -- ~0.2 us each on k_scan's wavefront, 80 us for a run of 400 rows whose sums and update take 7 + 12 us.  It reads 8 bytes
+// per example, so EVERY workgroup of the update launch solves it for itself, parallel in time (Newton on the whole path with affine prefix
+// scans: k_scan_pit's arithmetic on one workgroup, fmx_kernels.h) -- the same instructions on the same numbers in every workgroup, so all
+// of them hold the same multipliers -- and then updates its rows from them.  While the recurrence is solved the rows the wavefront is going to
+// update are on their way into the L2 (run_touch_row).  Workgroup 0 stores the bias behind the run; it goes to ANOTHER slot than the one the
+// run started from (a workgroup that starts late still reads the start value).  Runs of up to RUN_FUSED_MAX rows; longer ones take
+// k_scan_pit on one workgroup between the two launches.
+constexpr uint32_t RUN_FUSED_MAX = 2048;
+
+template <int TASK>
+__device__ __forceinline__ void run_eval(const Hyper& h, float w0s, float d, float r, float y, float& m, float& dm) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float p = (w0s + d) + r;
+  if constexpr (TASK == 1) {
+    const float inv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(LOG2E * y * p));   // 1 / (1 + e^{y p})
+    m = -y * inv;                                                   // fm_learn_sgd_element.h:64
+    dm = (y * y) * inv * (1.0f - inv);
+  } else {
+    const float gs = h.sgda ? 2.0f : 1.0f;
+    const float pc = fmaxf(h.min_target, fminf(h.max_target, p));
+    m = gs * (pc - y);                                              // fm_learn_sgd_element.h:60-62
+    dm = (p > h.min_target && p < h.max_target) ? gs : 0.f;
+  }
+}
+
+// every thread of the workgroup (256) calls this; on return s_d[i] holds the multiplier of example i of the run and the return value is the bias
+// behind the run.  s_r, s_y, s_d, s_a, s_b: n floats each.
+template <int TASK>
+__device__ __forceinline__ double run_scan_wg(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n, const Hyper& h, double w0,
+                                              float* s_r, float* s_y, float* s_d, float* s_a, float* s_b, float (*s_map)[2], float* s_chg, double* s_end) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float w0s = (float)w0;
+  for (uint32_t i = tid; i < n; i += 256u) { s_r[i] = rest[i]; s_y[i] = target[i]; s_d[i] = 0.f; }
+  __syncthreads();
+  const uint32_t wseg = ((n + 255u) / 256u) * 64u;                  // examples per wavefront, whole vectors of 64
+  const uint32_t q0 = wv * wseg;
+  bool converged = false;
+  float x_end = 0.f;
+  for (uint32_t it = 0; it < PIT_MAX_IT; it++) {
+    // every example's step linearised at the current path (an affine map), the maps composed by a prefix scan: each example gets the
+    // composite of the wavefront's examples BEFORE it, `run` ends as the composite of all of them
+    AMap run = AMap{1.f, 0.f};
+    for (uint32_t cb = 0; cb < wseg; cb += 64u) {
+      const uint32_t i = q0 + cb + lane;
+      if (q0 + cb >= n) break;                                       // (wave-uniform)
+      float a = 1.f, b = 0.f;
+      if (i < n) {
+        const float d = s_d[i];
+        float m, dm;
+        run_eval<TASK>(h, w0s, d, s_r[i], s_y[i], m, dm);
+        const float F = fmaf(h.reg0, w0s + d, m), D = dm + h.reg0;
+        a = 1.0f - h.lr * D; b = -h.lr * (F - D * d);
+      }
+      amap_scan64(a, b);
+      const float ea = __shfl_up(a, 1u), eb = __shfl_up(b, 1u);
+      AMap ex = (lane == 0u) ? AMap{1.f, 0.f} : AMap{ea, eb};
+      ex = amap_after(run, ex);
+      if (i < n) { s_a[i] = ex.a; s_b[i] = ex.b; }
+      run = amap_after(run, AMap{bcast_f32<1>(a, 63), bcast_f32<1>(b, 63)});
+    }
+    if (lane == 0) { s_map[wv][0] = run.a; s_map[wv][1] = run.b; }
+    __syncthreads();
+    float x = 0.f;                                                   // path offset at the wavefront's first example
+    for (uint32_t w = 0; w < wv; w++) x = fmaf(s_map[w][0], x, s_map[w][1]);
+    float xe = x;
+    for (uint32_t w = wv; w < 4u; w++) xe = fmaf(s_map[w][0], xe, s_map[w][1]);   // ... behind the run's last one (the same chain of fmas in every wavefront)
+    float chg = 0.f;
+    for (uint32_t cb = lane; cb < wseg; cb += 64u) {
+      const uint32_t i = q0 + cb;
+      if (i < n) {
+        const float dn = fmaf(s_a[i], x, s_b[i]);
+        chg = nanmax(fabsf(dn - s_d[i]), chg);
+        s_d[i] = dn;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) chg = nanmax(__shfl_xor(chg, o), chg);
+    if (lane == 0) s_chg[wv] = chg;
+    __syncthreads();
+    const float tot = nanmax(nanmax(s_chg[0], s_chg[1]), nanmax(s_chg[2], s_chg[3]));
+    x_end = xe;
+    __syncthreads();                                                 // (s_map / s_chg are written again by the next iteration)
+    if (tot < PIT_TOL && xe - xe == 0.f) { converged = true; break; }   // the path moved by less than tol: what it moved TO is exact to ~tol^2
+  }
+  if (converged) {
+    for (uint32_t i = tid; i < n; i += 256u) {
+      float m, dm;
+      run_eval<TASK>(h, w0s, s_d[i], s_r[i], s_y[i], m, dm);
+      s_d[i] = m;
+    }
+    __syncthreads();
+    return w0 + (double)x_end;
+  }
+  // Newton did not settle (the chain itself oscillates): one thread walks it, k_scan's arithmetic
+  if (tid == 0) {
+    double w = w0;
+    for (uint32_t i = 0; i < n; i++) {
+      const float ws = (float)w;
+      const float m = multiplier_task<TASK>(h, ws + s_r[i], s_y[i]);
+      s_d[i] = m;
+      w -= (double)h.lr * ((double)m + (double)h.reg0 * (double)ws);
+    }
+    *s_end = w;
+  }
+  __syncthreads();
+  return *s_end;
+}
+
+// the rows an example is going to update, asked for (one dword per 128 bytes) so that they are in the L2 when row_apply reads them
+template <int KP>
+__device__ __forceinline__ float run_touch_row(const Entry* __restrict__ ent, uint32_t size, const Tab& tb, const Hyper& h) {
+  const uint32_t lane = threadIdx.x & 63u;
+  float acc = 0.f;
+  for (uint32_t base = 0; base < size; base += 64u) {
+    if (base + lane < size) {
+      const uint32_t id = ent[base + lane].id;
+      if (h.k1) acc += tb.w[(size_t)id * tb.ws];
+      const float* row = tb.V + (size_t)id * tb.rs;
+      for (uint32_t o = 0; o < tb.rs; o += 32u) acc += row[o];
+    }
+  }
+  return acc;
+}
+
+template <int KP, int TASK>
+__global__ void __launch_bounds__(256)
+k_run_apply(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint64_t row0, uint32_t n_rows, const Tab tb, Hyper h,
+            const float* __restrict__ S, const float* __restrict__ rest, const float* __restrict__ target,
+            const double* __restrict__ w0_in, double* __restrict__ w0_out) {
+  extern __shared__ float run_lds[];                                 // 5 x n_rows floats
+  __shared__ float s_map[4][2];
+  __shared__ float s_chg[4];
+  __shared__ double s_end;
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR;
+  const uint32_t lane = threadIdx.x & 63u, f = lane % LPR;
+  const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+  const uint32_t nwaves = gridDim.x * 4u;
+  float touched = 0.f;
+  if (wave0 < n_rows) {
+    const uint64_t a = row_ptr[row0 + wave0];
+    touched = run_touch_row<KP>(ent + a, (uint32_t)(row_ptr[row0 + wave0 + 1] - a), tb, h);
+  }
+  float* s_d = run_lds + 2 * (size_t)n_rows;
+  if (h.k0) {
+    const double w_end = run_scan_wg<TASK>(rest, target + row0, n_rows, h, *w0_in, run_lds, run_lds + n_rows, s_d, run_lds + 3 * (size_t)n_rows,
+                                           run_lds + 4 * (size_t)n_rows, s_map, s_chg, &s_end);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *w0_out = w_end;
+  } else {                                                           // no bias: the multipliers do not depend on each other
+    for (uint32_t i = threadIdx.x; i < n_rows; i += 256u) s_d[i] = multiplier_task<TASK>(h, rest[i], target[row0 + i]);
+    __syncthreads();
+  }
+  if (touched == 1.2345e-38f) s_chg[0] = touched;                    // (keeps the touching loads)
+  for (uint32_t e = wave0; e < n_rows; e += nwaves) {
+    const uint64_t a = row_ptr[row0 + e];
+    const uint32_t size = (uint32_t)(row_ptr[row0 + e + 1] - a);
+    float sum[VEC];
+    load_vec<VEC>(S + (size_t)e * KP + f * VEC, sum);
+    row_apply<KP, 8, false>(ent + a, size, tb, h, sum, s_d[e]);
+  }
+}
+
 static __global__ void __launch_bounds__(256)
 k_run_keys(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, uint32_t n_rows, uint64_t* __restrict__ keys) {
   const uint32_t lane = threadIdx.x & 63u;

@@ -332,7 +332,7 @@ static uint32_t pit_concurrent_kernels(fmx_handle h) {
 
 static int launch_scan(fmx_handle h, const float* rest, const float* target, uint32_t n_rows, uint32_t chunk,
                        const Hyper& hy, float* mult, hipStream_t st, const double* w0_in = nullptr, double* w0_out = nullptr,
-                       const Handoff hw = Handoff{nullptr, 0ull, nullptr}) {
+                       const Handoff hw = Handoff{nullptr, 0ull, nullptr}, bool short_pit = false) {
   if (hy.k0) {
     const double* wi = w0_in ? w0_in : h->w0;
     double* wo = w0_out ? w0_out : h->w0;
@@ -340,7 +340,7 @@ static int launch_scan(fmx_handle h, const float* rest, const float* target, uin
     // micro-chunks that are powers of two up to 1024 on batches of 4097 .. 262 144 examples -- every default.  Same result as the chain to
     // fp32 rounding; 40-80 us per 262 144 examples whatever the micro-chunk where the chain takes 0.18 ms (256) .. 0.5 ms (32).
     // (the arrival counters of its exchanges are zeroed on the launch's own stream, in front of it)
-    if (h->scan_pit && n_rows > 4096u && chunk <= PIT_MAX_CHUNK && (chunk & (chunk - 1u)) == 0u) {
+    if (h->scan_pit && (n_rows > 4096u || (short_pit && n_rows >= 256u)) && chunk <= PIT_MAX_CHUNK && (chunk & (chunk - 1u)) == 0u) {
       // every workgroup of the launch spins on a grid-wide arrival counter: all of them must fit the device TOGETHER -- next to the same
       // kernel of the other shards on this device.  112 KiB of LDS per workgroup = one per CU (asked once per handle).
       if (h->pit_occ < 0) {
@@ -975,26 +975,41 @@ static int ensure_runs(fmx_handle h, Slot& s) {
   s.run_start.swap(starts); s.run_single.swap(single);
   return FMX_OK;
 }
-// one epoch over the runs: three launches per run (sums, the bias recurrence at micro-chunk 1 with the multipliers out of it, update)
+// one epoch over the runs.  A run of up to RUN_FUSED_MAX rows is TWO launches: the sums, then the update whose every workgroup solves the run's
+// bias recurrence for itself (k_run_apply); a longer one three (sums, k_scan_pit on one workgroup at micro-chunk 1, update).
+// FMX_SEQ_RUNS_FUSED=0: always three, with the one-wavefront chain (what the first version did).
 static int seq_runs_epoch(fmx_handle h, Slot& s, const Hyper& hy) {
   hipStream_t st = h->stream;
+  static const bool fused = []() { const char* e = getenv("FMX_SEQ_RUNS_FUSED"); return !(e && e[0] == '0'); }();
   uint32_t longest = 1;
   for (size_t i = 0; i + 1 < s.run_start.size(); i++) longest = std::max(longest, s.run_start[i + 1] - s.run_start[i]);
   int rc = ensure_scratch(h, longest, 0);
   if (rc) return rc;
+  if (!h->pit_tmp) HIPCHK(h, fmx_dev_alloc(&h->pit_tmp, 64 * sizeof(double)));
+  double* bias[2] = {h->w0, h->pit_tmp};                          // k_run_apply reads the bias in one slot and leaves it in the other
+  int cur = 0;
   for (size_t i = 0; i + 1 < s.run_start.size(); i++) {
     const uint32_t row0 = s.run_start[i], nb = s.run_start[i + 1] - row0;
     if (s.run_single[i]) {                                        // a row that repeats an id: entry by entry (fm_sgd.h:44-50)
-      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, st, s.ent, s.row_ptr + row0, s.target + row0, nb, h->tb, hy, h->w0));
+      KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, st, s.ent, s.row_ptr + row0, s.target + row0, nb, h->tb, hy, bias[cur]));
       continue;
     }
     float* S = h->partial;
     float* rest = S + (size_t)nb * h->KP;
     KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_rowsums<KP, true, true>), nb, st, s.ent, s.row_ptr, (uint64_t)row0, nb, h->tb, h->cfg.k1, S, rest, (const float*)nullptr));
-    rc = launch_scan(h, rest, s.target + row0, nb, 1u, hy, h->mult, st);
+    if (fused && nb <= RUN_FUSED_MAX) {
+      const dim3 grid((nb + 3u) / 4u);
+      const size_t lds = (size_t)nb * 5 * sizeof(float);
+      if (hy.task == 0) { KP_SWITCH(h->KP, hipLaunchKernelGGL((k_run_apply<KP, 0>), grid, dim3(256), lds, st, s.ent, s.row_ptr, (uint64_t)row0, nb, h->tb, hy, S, rest, s.target, bias[cur], bias[cur ^ 1])); }
+      else              { KP_SWITCH(h->KP, hipLaunchKernelGGL((k_run_apply<KP, 1>), grid, dim3(256), lds, st, s.ent, s.row_ptr, (uint64_t)row0, nb, h->tb, hy, S, rest, s.target, bias[cur], bias[cur ^ 1])); }
+      if (hy.k0) cur ^= 1;
+      continue;
+    }
+    rc = launch_scan(h, rest, s.target + row0, nb, 1u, hy, h->mult, st, bias[cur], bias[cur], Handoff{nullptr, 0ull, nullptr}, fused);
     if (rc) return rc;
     KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, false>), nb, st, s.ent, s.row_ptr, (uint64_t)row0, nb, h->tb, hy, S, h->mult));
   }
+  if (cur) HIPCHK(h, hipMemcpyAsync(h->w0, h->pit_tmp, sizeof(double), hipMemcpyDeviceToDevice, st));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
 }

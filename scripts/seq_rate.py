@@ -14,5 +14,5 @@ for name, n, k, nnz, rows, shape in (("uniform n=1e8 k=64 nnz=32", 100_000_000, 
     st = h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
     h.synchronize()
     dt = time.perf_counter() - t0
-    print("%-36s %8.1f k examples/s (%.2f us per example)" % (name, rows / dt / 1e3, dt / rows * 1e6), flush=True)
+    print("%-36s %8.1f k examples/s (%.2f us per example; %d launches-groups, status %#x)" % (name, rows / dt / 1e3, dt / rows * 1e6, st.batches, st.status), flush=True)
     h.close()

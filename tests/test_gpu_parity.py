@@ -827,3 +827,32 @@ def test_reference_trajectory_as_conflict_free_runs(capi, oracle, task, k):
     np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
     np.testing.assert_allclose(h.predict(0, rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5)
     h.close()
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_reference_trajectory_long_runs(capi, oracle, task):
+    """a wide id space and short rows: runs of a few thousand rows -- beyond what one update launch solves for itself (RUN_FUSED_MAX), so
+    the recurrence runs parallel in time on one workgroup between the sums and the update, and up to the 4096-row bound of a run.  Against the
+    oracle's ONLINE loop (fm_learn_sgd_element.h:56-67) at 1e-4."""
+    n, nnz, rows, k = 20_000_000, 3, 30_000, 8
+    ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed=17, classification=bool(task))
+    d = oracle.Data(ent, rp, y)
+    m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.003)
+    m.v[:] = oracle.init_values(1, n, k, 0.05)
+    m.w[:] = oracle.init_values(2, n, 1, 0.05)[0]
+    m.w0 = 0.1
+    lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
+    h = capi.Handle(n, k, True, True, task, 0.001, 0.002, 0.003, 0.01, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, rp, y)
+    for _ in range(2):
+        st = h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
+        assert st.status & capi.STAT_SEQ_RUNS and st.batches < rows // 1000
+        oracle.sgd_epoch_online(m, d, task, 0.01, lo, hi)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    ids = np.unique(ent["id"])
+    np.testing.assert_allclose(w[ids], m.w[ids], rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(v[:, ids], m.v[:, ids], rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(h.predict(0, rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5)
+    h.close()
