@@ -761,15 +761,19 @@ def main():
         # the reference's OWN trajectory (fm_learn_sgd_element.h:56-67: one example at a time, file order) on the device: the parity mode,
         # exact to 1e-4 against the real reference's final parameters (tests/test_gpu_parity.py); eight wavefronts per example
         try:
-            seq_rows = 1 << 16
+            seq_rows = 1 << 20
             h.synth_rows(1, 321, 0, seq_rows, args.nnz)
-            h.sgd_epoch(1, capi.SGD_SEQUENTIAL)
+            h.sgd_epoch(1, capi.SGD_SEQUENTIAL)                    # (incl. the one-time cut of the slot into conflict-free runs)
             h.synchronize()
             t1 = time.perf_counter()
-            h.sgd_epoch(1, capi.SGD_SEQUENTIAL)
+            st = h.sgd_epoch(1, capi.SGD_SEQUENTIAL)
             h.synchronize()
-            extras["sequential"] = {"mode": "FMX_SGD_SEQUENTIAL: the reference's own example-by-example trajectory on the device (k_sequential_wg)",
-                                    "value": round(seq_rows / (time.perf_counter() - t1), 1), "unit": "examples/s", "rows": seq_rows}
+            as_runs = bool(st.status & capi.STAT_SEQ_RUNS)
+            extras["sequential"] = {"mode": "FMX_SGD_SEQUENTIAL: the reference's own example-by-example trajectory on the device ("
+                                            + ("conflict-free runs: k_rowsums + k_run_apply per run of consecutive rows that share no feature" if as_runs
+                                               else "k_sequential_wg: eight wavefronts per example") + ")",
+                                    "value": round(seq_rows / (time.perf_counter() - t1), 1), "unit": "examples/s", "rows": seq_rows,
+                                    "runs": int(st.batches) if as_runs else None}
         except Exception as exc:
             extras["sequential"] = {"error": str(exc)[:200]}
         if args.mode != "minibatch":
