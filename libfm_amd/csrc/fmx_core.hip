@@ -866,6 +866,7 @@ int fmx_destroy(fmx_handle h) {
   if (h->xcd_trace) fmx_dev_free(h->xcd_trace);
   if (h->probe_flags) fmx_dev_free(h->probe_flags);
   if (h->pit_tmp) fmx_dev_free(h->pit_tmp);
+  if (h->run_slots) fmx_dev_free(h->run_slots);
   if (h->pit_slots) fmx_dev_free(h->pit_slots);
   if (h->w0_slots) fmx_dev_free(h->w0_slots);
   if (h->stream2) hipStreamDestroy(h->stream2);

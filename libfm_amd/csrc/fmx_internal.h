@@ -205,6 +205,10 @@ struct fmx_context_s {
   hipEvent_t  ev_x[4] = {};
   std::unordered_map<const void*, int> occ_cache;   // resident_grid: occupancy per kernel on THIS handle's device
   std::unordered_set<const void*> lds_raised;       // kernels whose dynamic-LDS limit was raised on THIS handle's device
+  // FMX_SGD_SEQUENTIAL, a conflict-free run as ONE launch (k_run_fused): workgroups of the instance the device holds at once; off after a time-out
+  std::unordered_map<const void*, int> run_one_occ;
+  bool run_one = true, run_one_used = false;
+  unsigned long long* run_slots = nullptr;          // [RUN_ONE_MAX] {tag, rest_e} of a one-launch run's examples
 };
 
 // ---- helpers shared between the translation units -------------------------------------------------------------

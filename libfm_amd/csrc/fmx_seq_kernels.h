@@ -514,13 +514,16 @@ __device__ __forceinline__ void run_eval(const Hyper& h, float w0s, float d, flo
 
 // every thread of the workgroup (256) calls this; on return s_d[i] holds the multiplier of example i of the run and the return value is the bias
 // behind the run.  s_r, s_y, s_d, s_a, s_b: n floats each.
-template <int TASK>
+template <int TASK, bool PRELOADED = false>
 __device__ __forceinline__ double run_scan_wg(const float* __restrict__ rest, const float* __restrict__ target, uint32_t n, const Hyper& h, double w0,
                                               float* s_r, float* s_y, float* s_d, float* s_a, float* s_b, float (*s_map)[2], float* s_chg, double* s_end) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float w0s = (float)w0;
-  for (uint32_t i = tid; i < n; i += 256u) { s_r[i] = rest[i]; s_y[i] = target[i]; s_d[i] = 0.f; }
+  for (uint32_t i = tid; i < n; i += 256u) {
+    if (!PRELOADED) s_r[i] = rest[i];                                // (PRELOADED: the caller filled s_r -- k_run_fused, out of the run's tagged slots)
+    s_y[i] = target[i]; s_d[i] = 0.f;
+  }
   __syncthreads();
   const uint32_t wseg = ((n + 255u) / 256u) * 64u;                  // examples per wavefront, whole vectors of 64
   const uint32_t q0 = wv * wseg;
@@ -645,6 +648,120 @@ k_run_apply(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     float sum[VEC];
     load_vec<VEC>(S + (size_t)e * KP + f * VEC, sum);
     row_apply<KP, 8, false>(ent + a, size, tb, h, sum, s_d[e]);
+  }
+}
+
+// ---- a run in ONE launch (k_run_fused) ----
+// One wavefront per example, the example's rows stay in its registers (k_fused's layout): gather, sums, the example's rest_e published as ONE
+// 8-byte agent-scope store {tag of the run, rest_e} into the run's slot array -- no arrival counter: 400 read-modify-writes of one word from
+// eight dies serialise (measured: 12 .. 55 us per run with one) -- and every thread polls the slots it is going to need until they carry the
+// run's tag: the poll that succeeds IS the load of rest_e.  Then every workgroup solves the bias recurrence for itself (run_scan_wg) and
+// updates its rows from the registers.  V is read once and written once, and a run costs one launch boundary instead of two.  Every
+// workgroup of the launch must be resident at the same time (the host gates the launch on the occupancy query; runs of up to RUN_ONE_MAX
+// rows); a poll that runs into its bound all the same takes NO step for the workgroup's rows, raises RUN_ERR_EXCHANGE in the handle's error
+// word, and the epoch returns FMX_E_HIP (the handle takes two launches per run from then on).  Tags: 1 + the run's index in the epoch; the
+// slot array is zeroed at the start of every epoch.
+constexpr uint32_t RUN_ONE_MAX = 1024;
+constexpr uint32_t RUN_ERR_EXCHANGE = 32u;
+struct RunSync { unsigned long long* slots; uint32_t tag; uint32_t* err; uint32_t spins; };
+
+template <int KP, int ZR, int TASK>
+__global__ void __launch_bounds__(256)
+k_run_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint64_t row0, uint32_t n_rows,
+            const Tab tb, Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, const RunSync rs) {
+  static_assert(KP >= 64, "one entry per gather instruction");
+  extern __shared__ float run_lds[];                                 // 5 x n_rows floats
+  __shared__ float s_map[4][2];
+  __shared__ float s_chg[4];
+  __shared__ double s_end;
+  constexpr int VEC = Map<KP>::VEC;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+  const bool have = e < n_rows;
+  Entry en; en.id = 0; en.value = 0.f;
+  float wv = 0.f;
+  uint32_t size = 0;
+  float vr[ZR][VEC];
+  float sum[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; v++) sum[v] = 0.f;
+  if (have) {
+    const uint64_t a = row_ptr[row0 + e];
+    size = (uint32_t)(row_ptr[row0 + e + 1] - a);                    // (<= min(64, ZR): the host checked the slot's longest row)
+    if (lane < size) {
+      en = load_stream8(ent + a + lane);
+      if (h.k1) wv = load_w(tb.w + (size_t)en.id * tb.ws);
+    }
+#pragma unroll
+    for (int t = 0; t < ZR; t++) {
+      const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
+      if ((uint32_t)t < size) {
+        row_ld<VEC, 1>(tb, (size_t)id, lane * VEC, vr[t]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
+      }
+    }
+    float sq = 0.f;                                                  // fm_model.h:116-125
+#pragma unroll
+    for (int t = 0; t < ZR; t++) {
+      float x = bcast_f32<1>(en.value, (uint32_t)t & 63u);
+      if ((uint32_t)t >= size) x = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        const float d = vr[t][v] * x;
+        sum[v] += d;
+        sq = fmaf(d, d, sq);
+      }
+    }
+    float part = wv * en.value - 0.5f * sq;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+    const float rest = wave_sum_dpp(part);
+    if (lane == 0)
+      __hip_atomic_store(rs.slots + e, ((unsigned long long)rs.tag << 32) | (unsigned long long)__float_as_uint(rest), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  bool late = false;
+  for (uint32_t i = threadIdx.x; i < n_rows; i += 256u) {
+    unsigned long long u = __hip_atomic_load(rs.slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t t = 0; (uint32_t)(u >> 32) != rs.tag && t < rs.spins; t++) {
+      __builtin_amdgcn_s_sleep(4);
+      u = __hip_atomic_load(rs.slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    late |= (uint32_t)(u >> 32) != rs.tag;
+    run_lds[i] = __uint_as_float((uint32_t)u);
+  }
+  if (late) atomicOr(rs.err, RUN_ERR_EXCHANGE);
+  if (__syncthreads_or(late ? 1 : 0)) return;
+  float* s_d = run_lds + 2 * (size_t)n_rows;
+  if (h.k0) {
+    const double w_end = run_scan_wg<TASK, true>(nullptr, target + row0, n_rows, h, *w0_in, run_lds, run_lds + n_rows, s_d, run_lds + 3 * (size_t)n_rows,
+                                                 run_lds + 4 * (size_t)n_rows, s_map, s_chg, &s_end);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *w0_out = w_end;
+  } else {
+    for (uint32_t i = threadIdx.x; i < n_rows; i += 256u) s_d[i] = multiplier_task<TASK>(h, run_lds[i], target[row0 + i]);
+    __syncthreads();
+  }
+  if (!have) return;
+  const float mult = s_d[e];
+  if (h.k1 && lane < size) {                                         // fm_sgd.h:38-43
+    tb.w[(size_t)en.id * tb.ws] = wv - h.lr * (mult * en.value + h.regw * wv);
+  }
+#pragma unroll
+  for (int t = 0; t < ZR; t++) {                                     // fm_sgd.h:44-50 on the register-resident rows
+    const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
+    const float x = bcast_f32<1>(en.value, (uint32_t)t & 63u);
+    if ((uint32_t)t < size && lane * VEC < tb.rs) {
+      float* pv = tb.V + (size_t)id * tb.rs + lane * VEC;
+      float nv[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        const float vv = vr[t][v];
+        const float grad = sum[v] * x - vv * x * x;
+        nv[v] = vv - h.lr * (mult * grad + h.regv * vv);
+      }
+      store_row<VEC, 2>(pv, nv);
+    }
   }
 }
 

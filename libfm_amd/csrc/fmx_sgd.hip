@@ -975,24 +975,68 @@ static int ensure_runs(fmx_handle h, Slot& s) {
   s.run_start.swap(starts); s.run_single.swap(single);
   return FMX_OK;
 }
-// one epoch over the runs.  A run of up to RUN_FUSED_MAX rows is TWO launches: the sums, then the update whose every workgroup solves the run's
-// bias recurrence for itself (k_run_apply); a longer one three (sums, k_scan_pit on one workgroup at micro-chunk 1, update).
-// FMX_SEQ_RUNS_FUSED=0: always three, with the one-wavefront chain (what the first version did).
+// a run as ONE launch (k_run_fused): 1 = launched, 0 = not this run (rows too long for the registers, no instance, the device does not hold
+// the run's workgroups at once), < 0 = error
+static int launch_run_one(fmx_handle h, const Slot& s, const Hyper& hy, uint32_t row0, uint32_t nb, int zr, const double* bias_in, double* bias_out,
+                          unsigned long long* slots, uint32_t tag) {
+  hipStream_t st = h->stream;
+  const size_t lds = (size_t)nb * 5 * sizeof(float);
+  const dim3 grid((nb + 3u) / 4u);
+  const RunSync rs{slots, tag, h->handoff_err, 1u << 21};
+  int launched = 0;
+#define FMX_RUN1(KPV, ZRV, TK) do { if (h->KP == KPV && zr == ZRV && hy.task == TK) {                                                    \
+    auto kf = k_run_fused<KPV, ZRV, TK>;                                                                                                 \
+    auto it = h->run_one_occ.find((const void*)kf);                                                                                      \
+    if (it == h->run_one_occ.end()) {                                                                                                    \
+      int per_cu = 0;                                                                                                                    \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kf, 256, (size_t)RUN_ONE_MAX * 5 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; } \
+      it = h->run_one_occ.emplace((const void*)kf, per_cu * h->num_cu).first;                                                            \
+    }                                                                                                                                    \
+    if ((int)grid.x <= it->second) {                                                                                                     \
+      hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, s.ent, s.row_ptr, s.target, (uint64_t)row0, nb, h->tb, hy, bias_in, bias_out, rs); \
+      launched = 1; } } } while (0)
+  FMX_RUN1(64, 16, 0);  FMX_RUN1(64, 40, 0);  FMX_RUN1(64, 64, 0);  FMX_RUN1(64, 16, 1);  FMX_RUN1(64, 40, 1);  FMX_RUN1(64, 64, 1);
+  FMX_RUN1(128, 16, 0); FMX_RUN1(128, 40, 0); FMX_RUN1(128, 64, 0); FMX_RUN1(128, 16, 1); FMX_RUN1(128, 40, 1); FMX_RUN1(128, 64, 1);
+#undef FMX_RUN1
+  return launched;
+}
+
+// one epoch over the runs.  A run of up to RUN_ONE_MAX rows that fit the registers is ONE launch (k_run_fused: the rows stay in the wavefronts'
+// registers across the run's bias recurrence); up to RUN_FUSED_MAX rows TWO: the sums, then the update whose every workgroup solves the
+// recurrence for itself (k_run_apply); a longer one three (sums, k_scan_pit on one workgroup at micro-chunk 1, update).
+// FMX_SEQ_RUNS_FUSED=0: always three, with the one-wavefront chain (what the first version did); FMX_SEQ_RUNS_ONE=0: never one.
 static int seq_runs_epoch(fmx_handle h, Slot& s, const Hyper& hy) {
   hipStream_t st = h->stream;
   static const bool fused = []() { const char* e = getenv("FMX_SEQ_RUNS_FUSED"); return !(e && e[0] == '0'); }();
+  static const bool one_env = []() { const char* e = getenv("FMX_SEQ_RUNS_ONE"); return !(e && e[0] == '0'); }();
   uint32_t longest = 1;
   for (size_t i = 0; i + 1 < s.run_start.size(); i++) longest = std::max(longest, s.run_start[i + 1] - s.run_start[i]);
   int rc = ensure_scratch(h, longest, 0);
   if (rc) return rc;
   if (!h->pit_tmp) HIPCHK(h, fmx_dev_alloc(&h->pit_tmp, 64 * sizeof(double)));
-  double* bias[2] = {h->w0, h->pit_tmp};                          // k_run_apply reads the bias in one slot and leaves it in the other
+  double* bias[2] = {h->w0, h->pit_tmp + 48};                     // the fused forms read the bias in one slot and leave it in the other
+  if (!h->run_slots) HIPCHK(h, fmx_dev_alloc(&h->run_slots, (size_t)RUN_ONE_MAX * sizeof(unsigned long long)));
+  unsigned long long* slots = h->run_slots;                       // {tag, rest_e} of a one-launch run's examples
+  int zr = 0;
+  bool one = fused && one_env && h->run_one && (h->KP == 64 || h->KP == 128) && s.max_row <= 64u;
+  if (one) {
+    zr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
+    if (s.max_row > (uint32_t)zr) one = false;                    // (rows beyond the register path)
+    if (zr == 8) zr = 16;                                         // (three instances per row width: 16, 40, 64 row slots)
+    if (zr == 32) zr = 40;
+  }
+  if (one) HIPCHK(h, hipMemsetAsync(slots, 0, (size_t)RUN_ONE_MAX * sizeof(unsigned long long), st));
   int cur = 0;
   for (size_t i = 0; i + 1 < s.run_start.size(); i++) {
     const uint32_t row0 = s.run_start[i], nb = s.run_start[i + 1] - row0;
     if (s.run_single[i]) {                                        // a row that repeats an id: entry by entry (fm_sgd.h:44-50)
       KP_SWITCH(h->KP, hipLaunchKernelGGL((k_sequential<KP>), dim3(1), dim3(64), 0, st, s.ent, s.row_ptr + row0, s.target + row0, nb, h->tb, hy, bias[cur]));
       continue;
+    }
+    if (one && nb <= RUN_ONE_MAX) {
+      rc = launch_run_one(h, s, hy, row0, nb, zr, bias[cur], bias[cur ^ 1], slots, (uint32_t)i + 1u);
+      if (rc < 0) return rc;
+      if (rc == 1) { h->run_one_used = true; if (hy.k0) cur ^= 1; continue; }
     }
     float* S = h->partial;
     float* rest = S + (size_t)nb * h->KP;
@@ -1009,7 +1053,7 @@ static int seq_runs_epoch(fmx_handle h, Slot& s, const Hyper& hy) {
     if (rc) return rc;
     KP_SWITCH(h->KP, FMX_LAUNCH_WAVES((k_apply<KP, false>), nb, st, s.ent, s.row_ptr, (uint64_t)row0, nb, h->tb, hy, S, h->mult));
   }
-  if (cur) HIPCHK(h, hipMemcpyAsync(h->w0, h->pit_tmp, sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (cur) HIPCHK(h, hipMemcpyAsync(h->w0, bias[1], sizeof(double), hipMemcpyDeviceToDevice, st));
   HIPCHK(h, hipGetLastError());
   return FMX_OK;
 }
@@ -1197,6 +1241,21 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   if (rc) return rc;
   rc = scan_error_check(h);
   if (rc) return rc;
+  if (h->run_one_used) {                                        // one-launch runs of FMX_SGD_SEQUENTIAL: did every workgroup see its run arrive?
+    h->run_one_used = false;
+    uint32_t e = 0;
+    HIPCHK(h, hipMemcpy(&e, h->handoff_err, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (e & RUN_ERR_EXCHANGE) {
+      const uint32_t rest_bits = e & ~RUN_ERR_EXCHANGE;
+      (void)hipMemcpy(h->handoff_err, &rest_bits, sizeof(uint32_t), hipMemcpyHostToDevice);
+      h->run_one = false;
+      h->run_status |= FMX_STAT_HANDOFF_TIMEOUT;
+      if (stats) stats->status = bi.status | h->run_status;
+      return fail(h, FMX_E_HIP, "a conflict-free run never saw all of its workgroups (the device is shared or partitioned): the rows concerned took no "
+                                "step (the parameters are valid numbers, the epoch is not the reference's) -- reload the parameters; the handle takes "
+                                "two launches per run from now on");
+    }
+  }
   if (h->handoff_err_host & 3u) {
     // a hand-off wait ran into its bound (the probe said the streams run side by side, and then they did not: the device is shared with
     // work that starved one of them).  Nothing was computed from a bias that was not there: the examples concerned took no step, a
