@@ -668,7 +668,7 @@ struct RunSync { unsigned long long* slots; uint32_t tag; uint32_t* err; uint32_
 template <int KP, int ZR, int TASK>
 __global__ void __launch_bounds__(256)
 k_run_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint64_t row0, uint32_t n_rows,
-            const Tab tb, Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, const RunSync rs) {
+            const Tab tb, Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, const RunSync rs, uint32_t fixed_nnz) {
   static_assert(KP >= 64, "one entry per gather instruction");
   extern __shared__ float run_lds[];                                 // 5 x n_rows floats
   __shared__ float s_map[4][2];
@@ -686,8 +686,9 @@ k_run_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
 #pragma unroll
   for (int v = 0; v < VEC; v++) sum[v] = 0.f;
   if (have) {
-    const uint64_t a = row_ptr[row0 + e];
-    size = (uint32_t)(row_ptr[row0 + e + 1] - a);                    // (<= min(64, ZR): the host checked the slot's longest row)
+    // fixed_nnz != 0: every row of the slot holds that many entries -- the row_ptr round trip drops out of the chain row_ptr -> entries -> rows
+    const uint64_t a = fixed_nnz ? (row0 + e) * (uint64_t)fixed_nnz : row_ptr[row0 + e];
+    size = fixed_nnz ? fixed_nnz : (uint32_t)(row_ptr[row0 + e + 1] - a);   // (<= min(64, ZR): the host checked the slot's longest row)
     if (lane < size) {
       en = load_stream8(ent + a + lane);
       if (h.k1) wv = load_w(tb.w + (size_t)en.id * tb.ws);

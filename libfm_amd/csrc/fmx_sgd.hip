@@ -982,7 +982,7 @@ static int launch_run_one(fmx_handle h, const Slot& s, const Hyper& hy, uint32_t
   hipStream_t st = h->stream;
   const size_t lds = (size_t)nb * 5 * sizeof(float);
   const dim3 grid((nb + 3u) / 4u);
-  const RunSync rs{slots, tag, h->handoff_err, 1u << 21};
+  const RunSync rs{slots, tag, h->handoff_err, std::min<uint32_t>(h->pit_spins, 1u << 21)};   // (FMX_DEBUG_PIT_SPINS=0 at fmx_create: every poll gives up at once)
   int launched = 0;
 #define FMX_RUN1(KPV, ZRV, TK) do { if (h->KP == KPV && zr == ZRV && hy.task == TK) {                                                    \
     auto kf = k_run_fused<KPV, ZRV, TK>;                                                                                                 \
@@ -993,7 +993,7 @@ static int launch_run_one(fmx_handle h, const Slot& s, const Hyper& hy, uint32_t
       it = h->run_one_occ.emplace((const void*)kf, per_cu * h->num_cu).first;                                                            \
     }                                                                                                                                    \
     if ((int)grid.x <= it->second) {                                                                                                     \
-      hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, s.ent, s.row_ptr, s.target, (uint64_t)row0, nb, h->tb, hy, bias_in, bias_out, rs); \
+      hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, s.ent, s.row_ptr, s.target, (uint64_t)row0, nb, h->tb, hy, bias_in, bias_out, rs, s.fixed_nnz); \
       launched = 1; } } } while (0)
   FMX_RUN1(64, 16, 0);  FMX_RUN1(64, 40, 0);  FMX_RUN1(64, 64, 0);  FMX_RUN1(64, 16, 1);  FMX_RUN1(64, 40, 1);  FMX_RUN1(64, 64, 1);
   FMX_RUN1(128, 16, 0); FMX_RUN1(128, 40, 0); FMX_RUN1(128, 64, 0); FMX_RUN1(128, 16, 1); FMX_RUN1(128, 40, 1); FMX_RUN1(128, 64, 1);

@@ -156,3 +156,36 @@ def test_loopback_shards_whose_recurrences_do_not_fit_together_take_the_chain(ca
         for x in hs:
             x.close()
     np.testing.assert_allclose(res[10], res[4], rtol=RTOL, atol=2e-5)
+
+
+def test_a_run_that_never_sees_all_its_workgroups_takes_no_step_and_says_so(capi, oracle, monkeypatch):
+    """FMX_SGD_SEQUENTIAL as conflict-free runs, a run in ONE launch (k_run_fused): every workgroup polls the run's tagged slots until all
+    examples have arrived.  FMX_DEBUG_PIT_SPINS=0: a poll gives up at once (what a workgroup that is not resident looks like to the others).
+    The rows concerned take no step, the epoch fails with FMX_E_HIP (valid numbers, not the reference's epoch), and the handle takes two
+    launches per run from then on: after a reload the next epochs equal the oracle's ONLINE loop at 1e-4."""
+    monkeypatch.setenv("FMX_DEBUG_PIT_SPINS", "0")
+    n, nnz, rows, k = 2_000_000, 12, 8000, 64
+    ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed=3, classification=True)
+    d = oracle.Data(ent, rp, y)
+    m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.003)
+    m.v[:] = oracle.init_values(1, n, k, 0.05)
+    m.w[:] = oracle.init_values(2, n, 1, 0.05)[0]
+    m.w0 = 0.1
+    h = capi.Handle(n, k, True, True, 1, 0.001, 0.002, 0.003, 0.01, -1.0, 1.0)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, rp, y)
+    with pytest.raises(capi.FmxError) as ei:
+        h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
+    assert "conflict-free run" in str(ei.value)
+    w0, w, v = h.get_params()
+    assert np.isfinite(w0) and np.isfinite(w).all() and np.isfinite(v).all()
+    h.set_params(m.w0, m.w, m.v)
+    for _ in range(2):
+        st = h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
+        assert st.status & capi.STAT_SEQ_RUNS and not st.status & capi.STAT_HANDOFF_TIMEOUT
+        oracle.sgd_epoch_online(m, d, 1, 0.01, -1.0, 1.0)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+    h.close()
