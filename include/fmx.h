@@ -48,12 +48,17 @@ enum { FMX_TASK_REGRESSION = 0, FMX_TASK_CLASSIFICATION = 1 };   /* fm_learn.h:4
 /* SGD update modes */
 enum {
   FMX_SGD_SEQUENTIAL = 0,  /* batch = 1, rows in storage order: the reference trajectory
-                              (fm_learn_sgd_element.h:56-67), exact to 1e-4 against the reference's final parameters.  One
-                              example at a time on eight wavefronts (k <= 128; libfm_amd/csrc/fmx_seq_kernels.h): ~370 k
-                              examples/s whatever the shape -- 14x the reference on one core where its model misses the
-                              caches (BASELINE's headline shape: 26.8 k examples/s), 30x SLOWER than it where the model
-                              is cache-resident (configs[0]: 11 M examples/s on the CPU).  The parity mode; the adapters
-                              default to MINIBATCH. */
+                              (fm_learn_sgd_element.h:56-67), exact to 1e-4 against the reference's final parameters.
+                              Two forms (libfm_amd/csrc/fmx_seq_kernels.h), chosen per slot:
+                              - conflict-free runs (FMX_STAT_SEQ_RUNS), where consecutive rows rarely share a feature (the
+                                slot's runs average >= 16 rows): the slot is cut once into maximal runs of consecutive rows
+                                that share no feature; inside a run the online loop IS one batch step with the bias coupled
+                                example by example, and a run is one launch.  BASELINE's headline shape: ~26 M examples/s,
+                                ~1000x the reference on one core (24-27 k examples/s);
+                              - one example at a time on eight wavefronts (k <= 128) otherwise: ~360 k examples/s whatever
+                                the shape -- 14x the reference where its model misses the caches, 30x SLOWER than it where
+                                the model is cache-resident (configs[0]: 11 M examples/s on the CPU).
+                              The parity mode; the adapters default to MINIBATCH. */
   FMX_SGD_MINIBATCH = 1,   /* restated batch rule (oracle/fm_oracle.h fmo_sgd_epoch_minibatch):
                               partial sums -> [all-reduce] -> w0 micro-chunks + multipliers -> scatter-add */
   FMX_SGD_HOGWILD = 2      /* fused single pass per example (gather, predict, update in registers);
@@ -213,7 +218,10 @@ typedef struct fmx_epoch_stats {
 #define FMX_STAT_XCD_RESIDENT 128u /* small batches (what the stability cut leaves of rows with frequent features): the epoch ran as ONE launch whose
                                       workgroups sit on one accelerator complex die (libfm_amd/csrc/fmx_xcd_kernels.h) instead of two launches per batch */
 #define FMX_STAT_SEQ_RUNS 256u     /* FMX_SGD_SEQUENTIAL ran as conflict-free runs: maximal runs of consecutive rows that share no feature, each one
-                                      batch step with the bias recurrence coupled example by example -- the same trajectory as the online loop */
+                                      batch step with the bias recurrence coupled example by example -- the same trajectory as the online loop.
+                                      fmx_epoch_stats::batches = the number of runs.  (A run whose workgroups never all arrive -- a shared or
+                                      partitioned device -- takes no step for the rows concerned: FMX_E_HIP + FMX_STAT_HANDOFF_TIMEOUT, and the
+                                      handle takes two launches per run from then on.) */
 #define FMX_STAT_HANDOFF_TIMEOUT 64u /* a device-side hand-off wait ran into its bound all the same: the examples concerned took NO step
                                       (multiplier 0; a recurrence that never saw its batch handed the bias on unchanged), every parameter is a
                                       valid number, the call returns FMX_E_HIP with this status set, and the handle orders by events from now on */
