@@ -222,6 +222,8 @@ typedef struct fmx_epoch_stats {
                                       fmx_epoch_stats::batches = the number of runs.  (A run whose workgroups never all arrive -- a shared or
                                       partitioned device -- takes no step for the rows concerned: FMX_E_HIP + FMX_STAT_HANDOFF_TIMEOUT, and the
                                       handle takes two launches per run from then on.) */
+#define FMX_STAT_SMALL_ONE 512u    /* small batches (< 1 025 rows) of the one-pass minibatch rule ran as ONE launch per batch across all dies: examples,
+                                      deferred features and the bias recurrence exchange through tagged slots (libfm_amd/csrc/fmx_small_kernels.h) */
 #define FMX_STAT_HANDOFF_TIMEOUT 64u /* a device-side hand-off wait ran into its bound all the same: the examples concerned took NO step
                                       (multiplier 0; a recurrence that never saw its batch handed the bias on unchanged), every parameter is a
                                       valid number, the call returns FMX_E_HIP with this status set, and the handle orders by events from now on */

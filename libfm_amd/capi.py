@@ -23,7 +23,7 @@ FLAG_KEEP_WSIDE = 32
 EVAL_WSIDE = 1
 STAT_BATCH_CUT, STAT_UNSTABLE = 1, 2
 STAT_WARN = 3   # the two bits that say something about the RULE; the bits above are how the epoch ran (include/fmx.h, ABI 7)
-STAT_SCAN_PIT, STAT_SCAN_SERIAL, STAT_SCAN_FALLBACK, STAT_EVENT_SYNC, STAT_HANDOFF_TIMEOUT, STAT_XCD_RESIDENT, STAT_SEQ_RUNS = 4, 8, 16, 32, 64, 128, 256
+STAT_SCAN_PIT, STAT_SCAN_SERIAL, STAT_SCAN_FALLBACK, STAT_EVENT_SYNC, STAT_HANDOFF_TIMEOUT, STAT_XCD_RESIDENT, STAT_SEQ_RUNS, STAT_SMALL_ONE = 4, 8, 16, 32, 64, 128, 256, 512
 SYNTH_UNIFORM, SYNTH_CRITEO = 0, 1
 BLOCKS_EXPAND, BLOCKS_KEEP = 0, 1
 COMM_ID_BYTES = 128

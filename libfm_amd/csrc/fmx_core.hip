@@ -797,6 +797,8 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     h->scan_pit = !(sc && strcmp(sc, "serial") == 0);
     const char* xe = getenv("FMX_XCD");
     h->xcd = (xe && xe[0] == '1');                              // opt-in: measured slower than the two launches per batch (profiles/r06_criteo_hops.txt)
+    const char* so = getenv("FMX_SMALL_ONE");
+    h->small_one = (so && so[0] == '1');                        // small batches as one launch per batch (fmx_small_kernels.h)
     const char* xb = getenv("FMX_XCD_MAX_BATCH");
     if (xb) h->xcd_max_batch = (uint32_t)strtoul(xb, nullptr, 10);
     const char* sp = getenv("FMX_DEBUG_PIT_SPINS");
@@ -867,6 +869,7 @@ int fmx_destroy(fmx_handle h) {
   if (h->probe_flags) fmx_dev_free(h->probe_flags);
   if (h->pit_tmp) fmx_dev_free(h->pit_tmp);
   if (h->run_slots) fmx_dev_free(h->run_slots);
+  if (h->small_slots) fmx_dev_free(h->small_slots);
   if (h->pit_slots) fmx_dev_free(h->pit_slots);
   if (h->w0_slots) fmx_dev_free(h->w0_slots);
   if (h->stream2) hipStreamDestroy(h->stream2);

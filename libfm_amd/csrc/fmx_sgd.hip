@@ -3,6 +3,7 @@
 #include "fmx_internal.h"
 #include "fmx_xcd_kernels.h"
 #include "fmx_seq_kernels.h"
+#include "fmx_small_kernels.h"
 
 namespace {
 // default micro-chunk of the bias recurrence.  The reference moves w0 after EVERY example (fm_sgd.h:34-37); summing the
@@ -857,9 +858,52 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     HIPCHK(h, hipEventRecord(h->ev0, st));                  // (not eligible / could not start: the epoch's clock starts over)
     for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
   }
+  // small batches as ONE launch per batch across all dies (k_small_one, fmx_small_kernels.h): FMX_SMALL_ONE=1 at fmx_create
+  const bool small_one = !side && !keep && h->small_one && (h->KP == 64 || h->KP == 128) && s.cdesc && Bc <= SMALL_ONE_MAX && !hy.sgda;
+  int szr = 0, small_cap = 0;
+  static const uint32_t small_flags = []() { const char* e = getenv("FMX_SMALL_FLAGS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();
+  if (small_one) {
+    szr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
+    if (szr == 8) szr = 16;                                       // (three instances per row width: 16, 40, 64 row slots)
+    if (szr == 32) szr = 40;
+    if (!h->small_slots) HIPCHK(h, fmx_dev_alloc(&h->small_slots, (size_t)2 * SMALL_ONE_MAX * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemsetAsync(h->small_slots, 0, (size_t)2 * SMALL_ONE_MAX * sizeof(unsigned long long), st));
+  }
   for (uint64_t b = 0; b < n_batch; b++) {
     const uint64_t row0 = b * B;
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, s.n_rows - row0);
+    if (small_one) {
+      SegWork sw;
+      seg_work(b, &sw);
+      *deferred += sw.nseg;
+      float* S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
+      const ScanSmall sc{nullptr, s.target + row0, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d), nb, chunk};
+      const SmallSync sy{h->small_slots, h->small_slots + SMALL_ONE_MAX, (uint32_t)(b + 1), h->handoff_err, std::min<uint32_t>(h->pit_spins, 1u << 21), small_flags};
+      const uint32_t n_ex_wg = (nb + 3u) / 4u;
+      bool launched = false;
+#define FMX_SMALL1(KPV, ZRV) do { if (h->KP == KPV && szr == ZRV) {                                                                      \
+        auto kf = k_small_one<KPV, ZRV>;                                                                                                   \
+        if (!small_cap) {                                                                                                                  \
+          int per_cu = 0;                                                                                                                  \
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kf, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; } \
+          small_cap = std::max(1, per_cu * h->num_cu);                                                                                     \
+        }                                                                                                                                  \
+        const uint32_t room = (uint32_t)small_cap > n_ex_wg + 1u ? (uint32_t)small_cap - n_ex_wg - 1u : 1u;                                \
+        const uint32_t own_wg = sw.nseg ? std::max(1u, std::min((sw.nseg + 3u) / 4u, room)) : 0u;                                          \
+        hipLaunchKernelGGL(kf, dim3(n_ex_wg + own_wg + 1u), dim3(256), 0, st, s.ent, s.row_ptr, s.target, row0, nb, h->tb, hy,             \
+                           (const double*)(h->w0_pp + ((b + 1) % d)), (const uint64_t*)s.cmask, S, s.fixed_nnz, sw, sc, sy, n_ex_wg);      \
+        launched = true; } } while (0)
+      FMX_SMALL1(64, 16);  FMX_SMALL1(64, 40);  FMX_SMALL1(64, 64);
+      FMX_SMALL1(128, 16); FMX_SMALL1(128, 40); FMX_SMALL1(128, 64);
+#undef FMX_SMALL1
+      if (launched) {
+        HIPCHK(h, hipGetLastError());
+        h->small_one_used = true;
+        h->run_status |= FMX_STAT_SMALL_ONE;
+        (*batches)++; (*launches)++;
+        continue;
+      }
+    }
     // rest buffers: with events the launch of batch b waits for the recurrence of batch b - d, which was the last reader of buffer b % d;
     // with the hand-off k_fused writes rest[] BEFORE it asks for that bias, so it takes a buffer whose reader (batch b - d - 1) is known
     // to be done: every wavefront of the previous launch has consumed its result
@@ -1241,6 +1285,21 @@ int fmx_sgd_epoch(fmx_handle h, int slot, const fmx_sgd_opts* opts, fmx_epoch_st
   if (rc) return rc;
   rc = scan_error_check(h);
   if (rc) return rc;
+  if (h->small_one_used) {                                      // one launch per small batch: did every owner / the recurrence see its examples?
+    h->small_one_used = false;
+    uint32_t e = 0;
+    HIPCHK(h, hipMemcpy(&e, h->handoff_err, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (e & RUN_ERR_EXCHANGE) {
+      const uint32_t rest_bits = e & ~RUN_ERR_EXCHANGE;
+      (void)hipMemcpy(h->handoff_err, &rest_bits, sizeof(uint32_t), hipMemcpyHostToDevice);
+      h->small_one = false;
+      h->run_status |= FMX_STAT_HANDOFF_TIMEOUT;
+      if (stats) stats->status = bi.status | h->run_status;
+      return fail(h, FMX_E_HIP, "a one-launch batch never saw all of its examples (the device is shared or partitioned): the features concerned took no "
+                                "step (the parameters are valid numbers, the epoch is not the batch rule's) -- reload the parameters; the handle takes "
+                                "two launches per batch from now on");
+    }
+  }
   if (h->run_one_used) {                                        // one-launch runs of FMX_SGD_SEQUENTIAL: did every workgroup see its run arrive?
     h->run_one_used = false;
     uint32_t e = 0;

@@ -1,0 +1,217 @@
+// k_small_one: a SMALL batch of the minibatch rule (FMX_APPLY_FUSED; what the stability cut leaves of rows with frequent features: 512 rows of
+// Criteo-shaped data) as ONE launch across all dies -- examples, deferred features and the bias recurrence, where the in-stream schedule takes
+// two (k_fused<FUSED_EXACT>, then k_apply_seg_scan) and pays the launch boundary plus the drain of the first between them.
+//
+// Three roles by workgroup index:
+//   examples  (the first n_ex_wg workgroups, one wavefront per example): k_fused<FUSED_EXACT>'s body -- rows in registers, sums, multiplier,
+//             write-back of the features that occur once in the batch -- and what the others need goes out as it is known: {tag, rest_e} as one
+//             8-byte agent-scope store (the recurrence polls it), then S_e (a plain 256-byte store), a release fence, and {tag, mult_e} (the
+//             owners poll it).  Nothing an example waits for.
+//   owners    (one wavefront per deferred feature): the feature's row and its occurrence list are asked for at once (batch-start values,
+//             static tables); every lane polls the multiplier slot of ITS occurrence (the poll that succeeds is the load), then the S_e
+//             rows are read past this die's caches, TL at a time, and summed in occurrence order; one owner per row, written once.
+//             An example publishes its multiplier only after it has gathered all its rows, so when an owner has seen every occurrence's
+//             tag nobody will read the batch-start row again: the owner's store cannot overtake a reader.
+//   recurrence (the last workgroup, one wavefront): polls every example's rest_e into the LDS and runs scan_small -- the bias ring slot it
+//             writes is the one this batch's examples read (lag d), and they read it before they publish anything.
+// Waits only go examples <- {owners, recurrence}: no cycle, and every poll is bounded (RUN_ERR_EXCHANGE: the epoch fails loudly, the handle
+// goes back to two launches).  The exchange is the tagged-slot one of k_run_fused (fmx_seq_kernels.h): no read-modify-write, no barrier.
+// Same rule, same numbers to fp32 rounding as the two launches (tests/test_gpu_small_one.py).
+#pragma once
+
+namespace fmx {
+
+constexpr uint32_t SMALL_ONE_MAX = 1024;                              // examples per batch (the recurrence holds the batch in registers)
+struct SmallSync { unsigned long long* mslot; unsigned long long* rslot; uint32_t tag; uint32_t* err; uint32_t spins; uint32_t flags; };   // flags: FMX_SMALL_FLAGS (A/B timing knobs)
+
+__device__ __forceinline__ bool slot_wait(const unsigned long long* p, uint32_t tag, uint32_t spins, uint32_t& lo) {
+  unsigned long long u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t t = 0; (uint32_t)(u >> 32) != tag && t < spins; t++) {
+    __builtin_amdgcn_s_sleep(2);
+    u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  lo = (uint32_t)u;
+  return (uint32_t)(u >> 32) == tag;
+}
+__device__ __forceinline__ void slot_put(unsigned long long* p, uint32_t tag, float v) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int KP, int ZR>
+__global__ void __launch_bounds__(256)
+k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint64_t row0, uint32_t n_rows,
+            const Tab tb, Hyper h, const double* __restrict__ w0_ptr, const uint64_t* __restrict__ cmask, float* __restrict__ S_out,
+            uint32_t fixed_nnz, const SegWork sw, const ScanSmall sc, const SmallSync sy, uint32_t n_ex_wg) {
+  static_assert(KP >= 64, "one row per wave-wide load");
+  constexpr int VEC = Map<KP>::VEC;
+  __shared__ float s_rest[SMALL_ONE_MAX];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (blockIdx.x < n_ex_wg) {
+    // ---------------------------------------------------------------- an example
+    const uint32_t e = blockIdx.x * 4u + wv;
+    if (e >= n_rows) return;
+    const float w0s = h.k0 ? (float)(*w0_ptr) : 0.f;                 // (before anything is published: the recurrence rewrites this slot)
+    const uint64_t a = fixed_nnz ? (row0 + e) * (uint64_t)fixed_nnz : row_ptr[row0 + e];
+    const uint32_t size = fixed_nnz ? fixed_nnz : (uint32_t)(row_ptr[row0 + e + 1] - a);
+    const Entry* __restrict__ row = ent + a;
+    const float y = target[row0 + e];
+    const uint64_t cm = cmask[row0 + e];
+    if (size <= (uint32_t)ZR && size <= 64u) {
+      Entry en; en.id = 0; en.value = 0.f;
+      float wl = 0.f;
+      if (lane < size) {
+        en = load_stream8(row + lane);
+        if (h.k1) wl = load_w(tb.w + (size_t)en.id * tb.ws);
+      }
+      float vr[ZR][VEC];
+#pragma unroll
+      for (int t = 0; t < ZR; t++) {
+        const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
+        if ((uint32_t)t < size) {
+          row_ld<VEC, 1>(tb, (size_t)id, lane * VEC, vr[t]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
+        }
+      }
+      float sum[VEC]; float sq = 0.f;                               // fm_model.h:116-125
+#pragma unroll
+      for (int v = 0; v < VEC; v++) sum[v] = 0.f;
+#pragma unroll
+      for (int t = 0; t < ZR; t++) {
+        float x = bcast_f32<1>(en.value, (uint32_t)t & 63u);
+        if ((uint32_t)t >= size) x = 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const float d = vr[t][v] * x;
+          sum[v] += d;
+          sq = fmaf(d, d, sq);
+        }
+      }
+      float part = wl * en.value - 0.5f * sq;
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      const float rest = wave_sum_dpp(part);
+      if (lane == 0) slot_put(sy.rslot + e, sy.tag, rest);
+      const float mult = multiplier(h, w0s + rest, y);
+      if (cm != 0) {                                                // some feature of this example is finished by an owner
+        if (sy.flags & 1u) {                                         // (A/B: plain stores + a release fence)
+          store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        } else {                                                     // write-through stores, waited for: no write-back of the die's whole L2
+#pragma unroll
+          for (int v = 0; v < VEC; v++) __hip_atomic_store(S_out + (size_t)e * KP + lane * VEC + v, sum[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
+      }
+      if (h.k1 && lane < size && !((cm >> lane) & 1ull)) {            // fm_sgd.h:38-43
+        tb.w[(size_t)en.id * tb.ws] = wl - h.lr * (mult * en.value + h.regw * wl);
+      }
+#pragma unroll
+      for (int t = 0; t < ZR; t++) {                                 // fm_sgd.h:44-50 on the register-resident rows
+        const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
+        const float x = bcast_f32<1>(en.value, (uint32_t)t & 63u);
+        if ((uint32_t)t < size && !((cm >> ((uint32_t)t & 63u)) & 1ull) && lane * VEC < tb.rs) {
+          float* pv = tb.V + (size_t)id * tb.rs + lane * VEC;
+          float nv[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const float vv = vr[t][v];
+            const float grad = sum[v] * x - vv * x * x;
+            nv[v] = vv - h.lr * (mult * grad + h.regv * vv);
+          }
+          store_row<VEC, 2>(pv, nv);
+        }
+      }
+    } else {                                                         // a row beyond the register path: deferred as a whole (cm = all ones)
+      float sum[VEC], sq, lin;
+      row_sums<KP, 8>(row, size, tb, h.k1, sum, sq, lin);
+      float part = lin - 0.5f * sq;
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      const float rest = wave_sum_dpp(part);
+      if (lane == 0) slot_put(sy.rslot + e, sy.tag, rest);
+      const float mult = multiplier(h, w0s + rest, y);
+#pragma unroll
+      for (int v = 0; v < VEC; v++) __hip_atomic_store(S_out + (size_t)e * KP + lane * VEC + v, sum[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
+    }
+    return;
+  }
+  if (blockIdx.x == gridDim.x - 1) {
+    // ---------------------------------------------------------------- the bias recurrence
+    if (wv != 0 || !h.k0) return;
+    bool ok = true;
+    for (uint32_t i = lane; i < sc.n_rows; i += 64u) {
+      uint32_t lo;
+      ok &= slot_wait(sy.rslot + i, sy.tag, sy.spins, lo);
+      s_rest[i] = __uint_as_float(lo);
+    }
+    if (__any(!ok)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }
+    ScanSmall s2 = sc;
+    s2.rest = s_rest;
+    scan_small<false>(s2, h);
+    return;
+  }
+  // ------------------------------------------------------------------ an owner of deferred features
+  const uint32_t n_own_waves = (gridDim.x - 1u - n_ex_wg) * 4u;
+  if (sy.flags & 8u) return;                                         // (A/B, timing only: no owners)
+  for (uint32_t s = (blockIdx.x - n_ex_wg) * 4u + wv; s < sw.nseg; s += n_own_waves) {
+    const uint4 d0 = reinterpret_cast<const uint4*>(sw.cdesc + s)[0];
+    const uint32_t j = __builtin_amdgcn_readfirstlane(d0.x), a = __builtin_amdgcn_readfirstlane(d0.y), b = __builtin_amdgcn_readfirstlane(d0.z);
+    float v0[VEC];
+    row_ld<VEC, 8>(tb, (size_t)j, lane * VEC, v0);
+    float wv0 = 0.f;
+    if (h.k1 && lane == 0) wv0 = tb.w[(size_t)j * tb.ws];
+    float G[VEC]; float A = 0.f, Gw = 0.f;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) G[v] = 0.f;
+    constexpr int TL = (VEC == 1) ? 16 : 8;
+    for (uint32_t base = a; base < b; base += 64u) {
+      const uint32_t cc = min(64u, b - base);
+      TEntry te; te.e = 0; te.x = 0.f; float tm = 0.f;
+      bool ok = true;
+      if (lane < cc) {
+        te = load_stream8(sw.t_ent + base + lane);
+        uint32_t lo;
+        ok = slot_wait(sy.mslot + te.e, sy.tag, (sy.flags & 4u) ? 0u : sy.spins, lo);
+        if (sy.flags & 4u) ok = true;                                // (A/B, timing only: wrong numbers)
+        tm = __uint_as_float(lo);
+      }
+      if (__any(!ok)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }   // (the feature takes no step)
+      for (uint32_t q0 = 0; q0 < cc; q0 += TL) {
+        float s2[TL][VEC];
+#pragma unroll
+        for (int q = 0; q < TL; q++) {
+          const uint32_t e2 = bcast_u32<1>(te.e, (q0 + q) & 63u);
+#pragma unroll
+          for (int v = 0; v < VEC; v++) s2[q][v] = (q0 + q < cc && lane * VEC + v < KP) ? ld_l2(sw.S + (size_t)e2 * KP + lane * VEC + v) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < TL; q++) {
+          const float x2 = bcast_f32<1>(te.x, (q0 + q) & 63u), m2 = bcast_f32<1>(tm, (q0 + q) & 63u);
+          if (q0 + q < cc) {
+            const float mx2 = m2 * x2;
+#pragma unroll
+            for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[q][v], G[v]);
+            A = fmaf(mx2, x2, A); Gw += mx2;
+          }
+        }
+      }
+    }
+    const float nocc = (float)(b - a);
+    float nv[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+      const float vv = v0[v];
+      nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
+    }
+    row_st<VEC, 8>(tb, (size_t)j, lane * VEC, nv);
+    if (h.k1 && lane == 0) tb.w[(size_t)j * tb.ws] = wv0 - h.lr * (Gw + nocc * h.regw * wv0);
+  }
+}
+
+}  // namespace fmx
