@@ -798,7 +798,7 @@ int fmx_create(const fmx_config* cfg, fmx_handle* out) {
     const char* xe = getenv("FMX_XCD");
     h->xcd = (xe && xe[0] == '1');                              // opt-in: measured slower than the two launches per batch (profiles/r06_criteo_hops.txt)
     const char* so = getenv("FMX_SMALL_ONE");
-    h->small_one = (so && so[0] == '1');                        // small batches as one launch per batch (fmx_small_kernels.h)
+    h->small_one = !(so && so[0] == '0');                       // small batches as one launch per batch (fmx_small_kernels.h); FMX_SMALL_ONE=0: two
     const char* xb = getenv("FMX_XCD_MAX_BATCH");
     if (xb) h->xcd_max_batch = (uint32_t)strtoul(xb, nullptr, 10);
     const char* sp = getenv("FMX_DEBUG_PIT_SPINS");

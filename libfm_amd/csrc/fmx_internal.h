@@ -210,7 +210,7 @@ struct fmx_context_s {
   bool run_one = true, run_one_used = false;
   unsigned long long* run_slots = nullptr;          // [RUN_ONE_MAX] {tag, rest_e} of a one-launch run's examples
   // small batches of the minibatch rule as ONE launch per batch (k_small_one, fmx_small_kernels.h): {tag, mult_e} and {tag, rest_e} slots; off after a time-out
-  unsigned long long* small_slots = nullptr;        // [2 * SMALL_ONE_MAX]
+  unsigned long long* small_slots = nullptr;        // [3 * SMALL_ONE_MAX]: multipliers, rest_e of even / odd batches
   bool small_one = true, small_one_used = false;
 };
 

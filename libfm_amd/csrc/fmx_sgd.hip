@@ -858,7 +858,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     HIPCHK(h, hipEventRecord(h->ev0, st));                  // (not eligible / could not start: the epoch's clock starts over)
     for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
   }
-  // small batches as ONE launch per batch across all dies (k_small_one, fmx_small_kernels.h): FMX_SMALL_ONE=1 at fmx_create
+  // small batches as ONE launch per batch across all dies (k_small_one, fmx_small_kernels.h; FMX_SMALL_ONE=0 at fmx_create: two launches)
   const bool small_one = !side && !keep && h->small_one && (h->KP == 64 || h->KP == 128) && s.cdesc && Bc <= SMALL_ONE_MAX && !hy.sgda;
   int szr = 0, small_cap = 0;
   static const uint32_t small_flags = []() { const char* e = getenv("FMX_SMALL_FLAGS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();
@@ -866,8 +866,8 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     szr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
     if (szr == 8) szr = 16;                                       // (three instances per row width: 16, 40, 64 row slots)
     if (szr == 32) szr = 40;
-    if (!h->small_slots) HIPCHK(h, fmx_dev_alloc(&h->small_slots, (size_t)2 * SMALL_ONE_MAX * sizeof(unsigned long long)));
-    HIPCHK(h, hipMemsetAsync(h->small_slots, 0, (size_t)2 * SMALL_ONE_MAX * sizeof(unsigned long long), st));
+    if (!h->small_slots) HIPCHK(h, fmx_dev_alloc(&h->small_slots, (size_t)3 * SMALL_ONE_MAX * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemsetAsync(h->small_slots, 0, (size_t)3 * SMALL_ONE_MAX * sizeof(unsigned long long), st));
   }
   for (uint64_t b = 0; b < n_batch; b++) {
     const uint64_t row0 = b * B;
@@ -877,8 +877,14 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       seg_work(b, &sw);
       *deferred += sw.nseg;
       float* S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
-      const ScanSmall sc{nullptr, s.target + row0, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d), nb, chunk};
-      const SmallSync sy{h->small_slots, h->small_slots + SMALL_ONE_MAX, (uint32_t)(b + 1), h->handoff_err, std::min<uint32_t>(h->pit_spins, 1u << 21), small_flags};
+      // the recurrence: at lag >= 2 one launch behind (k_small_one), the last launch catches up
+      const bool defer = d >= 2u;
+      const bool own = !defer || b + 1 == n_batch, prev = defer && b >= 1;
+      const ScanSmall sc{nullptr, s.target + row0, h->w0_pp + (b % d), h->w0_pp + ((b + 1) % d), own ? nb : 0u, chunk};
+      const ScanSmall sc_prev{nullptr, s.target + (prev ? row0 - B : 0), h->w0_pp + ((b + d - 1) % d), h->w0_pp + (b % d), prev ? B : 0u, chunk};
+      unsigned long long* rs0 = h->small_slots + SMALL_ONE_MAX;
+      const SmallSync sy{h->small_slots, rs0 + (size_t)(b & 1) * SMALL_ONE_MAX, rs0 + (size_t)((b + 1) & 1) * SMALL_ONE_MAX, (uint32_t)(b + 1), (uint32_t)b,
+                         h->handoff_err, std::min<uint32_t>(h->pit_spins, 1u << 21), small_flags};
       const uint32_t n_ex_wg = (nb + 3u) / 4u;
       bool launched = false;
 #define FMX_SMALL1(KPV, ZRV) do { if (h->KP == KPV && szr == ZRV) {                                                                      \
@@ -891,7 +897,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
         const uint32_t room = (uint32_t)small_cap > n_ex_wg + 1u ? (uint32_t)small_cap - n_ex_wg - 1u : 1u;                                \
         const uint32_t own_wg = sw.nseg ? std::max(1u, std::min((sw.nseg + 3u) / 4u, room)) : 0u;                                          \
         hipLaunchKernelGGL(kf, dim3(n_ex_wg + own_wg + 1u), dim3(256), 0, st, s.ent, s.row_ptr, s.target, row0, nb, h->tb, hy,             \
-                           (const double*)(h->w0_pp + ((b + 1) % d)), (const uint64_t*)s.cmask, S, s.fixed_nnz, sw, sc, sy, n_ex_wg);      \
+                           (const double*)(h->w0_pp + ((b + 1) % d)), (const uint64_t*)s.cmask, S, s.fixed_nnz, sw, sc_prev, sc, sy, n_ex_wg); \
         launched = true; } } while (0)
       FMX_SMALL1(64, 16);  FMX_SMALL1(64, 40);  FMX_SMALL1(64, 64);
       FMX_SMALL1(128, 16); FMX_SMALL1(128, 40); FMX_SMALL1(128, 64);

@@ -12,8 +12,10 @@
 //             rows are read past this die's caches, TL at a time, and summed in occurrence order; one owner per row, written once.
 //             An example publishes its multiplier only after it has gathered all its rows, so when an owner has seen every occurrence's
 //             tag nobody will read the batch-start row again: the owner's store cannot overtake a reader.
-//   recurrence (the last workgroup, one wavefront): polls every example's rest_e into the LDS and runs scan_small -- the bias ring slot it
-//             writes is the one this batch's examples read (lag d), and they read it before they publish anything.
+//   recurrence (the last workgroup, one wavefront): at bias lag >= 2 the PREVIOUS batch's (its rest_e are complete and what it writes is read
+//             two launches on: off the critical path; the epoch's last launch runs its own batch's too); at lag 1 this batch's, polled into
+//             the LDS as the examples publish -- the bias ring slot it then writes is the one this batch's examples read, and they read it
+//             before they publish anything.
 // Waits only go examples <- {owners, recurrence}: no cycle, and every poll is bounded (RUN_ERR_EXCHANGE: the epoch fails loudly, the handle
 // goes back to two launches).  The exchange is the tagged-slot one of k_run_fused (fmx_seq_kernels.h): no read-modify-write, no barrier.
 // Same rule, same numbers to fp32 rounding as the two launches (tests/test_gpu_small_one.py).
@@ -22,7 +24,8 @@
 namespace fmx {
 
 constexpr uint32_t SMALL_ONE_MAX = 1024;                              // examples per batch (the recurrence holds the batch in registers)
-struct SmallSync { unsigned long long* mslot; unsigned long long* rslot; uint32_t tag; uint32_t* err; uint32_t spins; uint32_t flags; };   // flags: FMX_SMALL_FLAGS (A/B timing knobs)
+struct SmallSync { unsigned long long* mslot; unsigned long long* rslot; const unsigned long long* rslot_prev; uint32_t tag, tag_prev; uint32_t* err; uint32_t spins;
+                   uint32_t flags; };   // flags: FMX_SMALL_FLAGS (A/B timing knobs)
 
 __device__ __forceinline__ bool slot_wait(const unsigned long long* p, uint32_t tag, uint32_t spins, uint32_t& lo) {
   unsigned long long u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -41,7 +44,7 @@ template <int KP, int ZR>
 __global__ void __launch_bounds__(256)
 k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint64_t row0, uint32_t n_rows,
             const Tab tb, Hyper h, const double* __restrict__ w0_ptr, const uint64_t* __restrict__ cmask, float* __restrict__ S_out,
-            uint32_t fixed_nnz, const SegWork sw, const ScanSmall sc, const SmallSync sy, uint32_t n_ex_wg) {
+            uint32_t fixed_nnz, const SegWork sw, const ScanSmall sc_prev, const ScanSmall sc, const SmallSync sy, uint32_t n_ex_wg) {
   static_assert(KP >= 64, "one row per wave-wide load");
   constexpr int VEC = Map<KP>::VEC;
   __shared__ float s_rest[SMALL_ONE_MAX];
@@ -95,15 +98,13 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       const float rest = wave_sum_dpp(part);
       if (lane == 0) slot_put(sy.rslot + e, sy.tag, rest);
       const float mult = multiplier(h, w0s + rest, y);
-      if (cm != 0) {                                                // some feature of this example is finished by an owner
-        if (sy.flags & 1u) {                                         // (A/B: plain stores + a release fence)
-          store_vec<VEC>(S_out + (size_t)e * KP + lane * VEC, sum);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        } else {                                                     // write-through stores, waited for: no write-back of the die's whole L2
+      // what the owners need, BEFORE the example's own updates: S_e as write-through stores, waited for (a release fence would write back the
+      // die's whole L2: 22.6 vs 14.0 us per batch; publishing behind the own row stores waits for their acknowledgements too: 15.5 vs 13.1),
+      // then the tagged multiplier
+      if (cm != 0) {
 #pragma unroll
-          for (int v = 0; v < VEC; v++) __hip_atomic_store(S_out + (size_t)e * KP + lane * VEC + v, sum[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        for (int v = 0; v < VEC; v++) __hip_atomic_store(S_out + (size_t)e * KP + lane * VEC + v, sum[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
       }
       if (h.k1 && lane < size && !((cm >> lane) & 1ull)) {            // fm_sgd.h:38-43
@@ -143,17 +144,35 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
   }
   if (blockIdx.x == gridDim.x - 1) {
     // ---------------------------------------------------------------- the bias recurrence
+    // bias lag >= 2: the recurrence of the PREVIOUS batch runs here -- its rest_e are complete, nothing to wait for, and what it writes is
+    // read two launches on -- so the recurrence is off this launch's critical path; the epoch's last launch also runs its own batch's.
+    // Bias lag 1: this batch's, polled as the examples publish.
     if (wv != 0 || !h.k0) return;
-    bool ok = true;
-    for (uint32_t i = lane; i < sc.n_rows; i += 64u) {
-      uint32_t lo;
-      ok &= slot_wait(sy.rslot + i, sy.tag, sy.spins, lo);
-      s_rest[i] = __uint_as_float(lo);
+    if (sc_prev.n_rows) {
+      bool ok = true;
+      for (uint32_t i = lane; i < sc_prev.n_rows; i += 64u) {
+        uint32_t lo;
+        ok &= slot_wait(sy.rslot_prev + i, sy.tag_prev, sy.spins, lo);
+        s_rest[i] = __uint_as_float(lo);
+      }
+      if (__any(!ok)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }
+      ScanSmall s2 = sc_prev;
+      s2.rest = s_rest;
+      scan_small<false>(s2, h);
+      if (sc.n_rows) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // (the bias it left is what the next one starts from)
     }
-    if (__any(!ok)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }
-    ScanSmall s2 = sc;
-    s2.rest = s_rest;
-    scan_small<false>(s2, h);
+    if (sc.n_rows) {
+      bool ok = true;
+      for (uint32_t i = lane; i < sc.n_rows; i += 64u) {
+        uint32_t lo;
+        ok &= slot_wait(sy.rslot + i, sy.tag, sy.spins, lo);
+        s_rest[i] = __uint_as_float(lo);
+      }
+      if (__any(!ok)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }
+      ScanSmall s2 = sc;
+      s2.rest = s_rest;
+      scan_small<false>(s2, h);
+    }
     return;
   }
   // ------------------------------------------------------------------ an owner of deferred features
@@ -169,7 +188,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     float G[VEC]; float A = 0.f, Gw = 0.f;
 #pragma unroll
     for (int v = 0; v < VEC; v++) G[v] = 0.f;
-    constexpr int TL = (VEC == 1) ? 16 : 8;
+    constexpr int TL = (VEC == 1) ? 32 : 16;                         // S_e rows in flight per round
     for (uint32_t base = a; base < b; base += 64u) {
       const uint32_t cc = min(64u, b - base);
       TEntry te; te.e = 0; te.x = 0.f; float tm = 0.f;

@@ -1,5 +1,5 @@
 """GPU: small batches of the one-pass minibatch rule as ONE launch per batch across all dies (libfm_amd/csrc/fmx_small_kernels.h k_small_one;
-FMX_SMALL_ONE=1 at fmx_create) -- examples, deferred (frequent) features and the bias recurrence of a batch exchange through tagged 8-byte
+the default for batches of up to 1 024 rows; FMX_SMALL_ONE=0 at fmx_create: two launches) -- examples, deferred (frequent) features and the bias recurrence of a batch exchange through tagged 8-byte
 slots instead of a launch boundary (round-5 verdict item 2; fm_learn_sgd_element.h:56-67 is that chain at batch 1).
 
 It is the same batch rule as the two launches per batch (k_fused<EXACT> + k_apply_seg_scan): held against the oracle at 1e-4 and against
@@ -46,7 +46,7 @@ def run_case(capi, oracle, monkeypatch, k, task, lag, rows, make_ragged, epochs=
     m.w0 = 0.02
     out = {}
     for tag in ("one", "two_launches"):
-        monkeypatch.setenv("FMX_SMALL_ONE", "1" if tag == "one" else "0")   # (read by fmx_create; the default is the two launches per batch)
+        monkeypatch.setenv("FMX_SMALL_ONE", "1" if tag == "one" else "0")   # (read by fmx_create; the default is one launch per batch)
         h = capi.Handle(n, k, True, True, task, 0.0, 0.0005, 0.001, lr, -3.0, 3.0, device=0)
         h.set_params(m.w0, m.w, m.v)
         h.upload_rows(0, e, rp, y)
