@@ -859,7 +859,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   // small batches as ONE launch per batch across all dies (k_small_one, fmx_small_kernels.h; FMX_SMALL_ONE=0 at fmx_create: two launches)
-  const bool small_one = !side && !keep && h->small_one && (h->KP == 64 || h->KP == 128) && s.cdesc && Bc <= SMALL_ONE_MAX && !hy.sgda;
+  const bool small_one = !side && h->small_one && (h->KP == 64 || h->KP == 128) && s.cdesc && Bc <= SMALL_ONE_MAX && !hy.sgda;
   int szr = 0, small_cap = 0;
   static const uint32_t small_flags = []() { const char* e = getenv("FMX_SMALL_FLAGS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();
   if (small_one) {
@@ -897,7 +897,8 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
         const uint32_t room = (uint32_t)small_cap > n_ex_wg + 1u ? (uint32_t)small_cap - n_ex_wg - 1u : 1u;                                \
         const uint32_t own_wg = sw.nseg ? std::max(1u, std::min((sw.nseg + 3u) / 4u, room)) : 0u;                                          \
         hipLaunchKernelGGL(kf, dim3(n_ex_wg + own_wg + 1u), dim3(256), 0, st, s.ent, s.row_ptr, s.target, row0, nb, h->tb, hy,             \
-                           (const double*)(h->w0_pp + ((b + 1) % d)), (const uint64_t*)s.cmask, S, s.fixed_nnz, sw, sc_prev, sc, sy, n_ex_wg); \
+                           (const double*)(h->w0_pp + ((b + 1) % d)), (const uint64_t*)s.cmask, S, s.fixed_nnz, sw, sc_prev, sc, sy, n_ex_wg,  \
+                           (const uint64_t*)(keep ? s.lmask : nullptr), keep ? s.wside : (float*)nullptr);                                 \
         launched = true; } } while (0)
       FMX_SMALL1(64, 16);  FMX_SMALL1(64, 40);  FMX_SMALL1(64, 64);
       FMX_SMALL1(128, 16); FMX_SMALL1(128, 40); FMX_SMALL1(128, 64);

@@ -44,7 +44,9 @@ template <int KP, int ZR>
 __global__ void __launch_bounds__(256)
 k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint64_t row0, uint32_t n_rows,
             const Tab tb, Hyper h, const double* __restrict__ w0_ptr, const uint64_t* __restrict__ cmask, float* __restrict__ S_out,
-            uint32_t fixed_nnz, const SegWork sw, const ScanSmall sc_prev, const ScanSmall sc, const SmallSync sy, uint32_t n_ex_wg) {
+            uint32_t fixed_nnz, const SegWork sw, const ScanSmall sc_prev, const ScanSmall sc, const SmallSync sy, uint32_t n_ex_wg,
+            const uint64_t* __restrict__ lmask, float* __restrict__ wside) {
+  // wside != nullptr (FMX_FLAG_KEEP_WSIDE): the slot's weight side stream is kept current exactly as k_fused<FUSED_EXACT> keeps it
   static_assert(KP >= 64, "one row per wave-wide load");
   constexpr int VEC = Map<KP>::VEC;
   __shared__ float s_rest[SMALL_ONE_MAX];
@@ -60,6 +62,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     const Entry* __restrict__ row = ent + a;
     const float y = target[row0 + e];
     const uint64_t cm = cmask[row0 + e];
+    const uint64_t lm = wside ? lmask[row0 + e] : 0ull;
     if (size <= (uint32_t)ZR && size <= 64u) {
       Entry en; en.id = 0; en.value = 0.f;
       float wl = 0.f;
@@ -107,9 +110,12 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
       }
+      float w_keep = __builtin_nanf("");
       if (h.k1 && lane < size && !((cm >> lane) & 1ull)) {            // fm_sgd.h:38-43
-        tb.w[(size_t)en.id * tb.ws] = wl - h.lr * (mult * en.value + h.regw * wl);
+        w_keep = wl - h.lr * (mult * en.value + h.regw * wl);
+        tb.w[(size_t)en.id * tb.ws] = w_keep;
       }
+      if (wside && lane < size) __builtin_nontemporal_store(((lm >> lane) & 1ull) ? w_keep : __builtin_nanf(""), wside + a + lane);
 #pragma unroll
       for (int t = 0; t < ZR; t++) {                                 // fm_sgd.h:44-50 on the register-resident rows
         const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);

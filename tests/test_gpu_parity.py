@@ -725,15 +725,17 @@ def test_model_file_from_the_device_table(capi, oracle, name, tmp_path):
     h.close()
 
 
+@pytest.mark.parametrize("k", [16, 64])
 @pytest.mark.parametrize("shape", ["fields", "ragged_dups", "long_rows"])
-def test_weight_side_stream_moves_no_number_and_goes_stale_safely(capi, oracle, shape):
+def test_weight_side_stream_moves_no_number_and_goes_stale_safely(capi, oracle, shape, k):
     """FMX_FLAG_KEEP_WSIDE: after a one-pass epoch that kept the slot's weight side stream, fmx_predict / fmx_evaluate take w_j out of the
     stream where the entry is flagged (last occurrence of its feature in the slot, updated by its own example) and gather the rest --
     bit for bit the predictions of a twin handle that never heard of the stream; anything else that changes w (another epoch without
     the flag, a HOGWILD epoch, fmx_set_params, an ALS sweep, an epoch on ANOTHER slot) makes the stream stale and the pass gathers again.
     Shapes: one-hot fields whose ids repeat across batches; ragged rows with empty ones and repeated ids inside a row; rows longer than
-    the register path (their entries are never streamed)."""
-    k, lr = 16, 0.01
+    the register path (their entries are never streamed).  k = 64: the batches of 512 rows are one launch each (k_small_one keeps the stream
+    like k_fused does)."""
+    lr = 0.01
     if shape == "fields":
         n, nnz, rows = 4800, 12, 6000
         ent, rp, y = datagen.onehot_fields(n, nnz, rows, seed=77, zipf=0.7)

@@ -189,3 +189,36 @@ def test_a_run_that_never_sees_all_its_workgroups_takes_no_step_and_says_so(capi
     np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
     np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
     h.close()
+
+
+def test_a_one_launch_batch_whose_owners_give_up_takes_no_step_and_says_so(capi, oracle, monkeypatch):
+    """small batches of the one-pass rule as ONE launch per batch (k_small_one): the owners of the deferred features poll their examples'
+    tagged multipliers.  FMX_DEBUG_PIT_SPINS=0: a poll gives up at once.  The features concerned take no step, the epoch fails with
+    FMX_E_HIP (valid numbers, not the rule's epoch), and the handle takes two launches per batch from then on: after a reload the next epochs
+    equal the oracle's rule at 1e-4."""
+    monkeypatch.setenv("FMX_DEBUG_PIT_SPINS", "0")
+    rows, k, lag = 6000, 64, 2
+    e, rp, y, n = datagen.criteo_shaped(rows, 5, cat_ids=2000, classification=True)
+    d = oracle.Data(e, rp, y)
+    m = oracle.Model(n, k, True, True, 0.0, 0.0005, 0.001)
+    m.v[:] = oracle.init_values(1, n, k, 0.05)
+    m.w0 = 0.02
+    h = capi.Handle(n, k, True, True, 1, 0.0, 0.0005, 0.001, 0.01, -3.0, 3.0)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, e, rp, y)
+    with pytest.raises(capi.FmxError) as ei:
+        h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)
+    assert "one-launch batch" in str(ei.value)
+    w0, w, v = h.get_params()
+    assert np.isfinite(w0) and np.isfinite(w).all() and np.isfinite(v).all()
+    h.set_params(m.w0, m.w, m.v)
+    for _ in range(2):
+        st = h.sgd_epoch(0, capi.SGD_MINIBATCH, capi.APPLY_FUSED, 0, 0, 0, lag)
+        assert not st.status & capi.STAT_SMALL_ONE and not st.status & capi.STAT_HANDOFF_TIMEOUT
+        oracle.sgd_epoch_minibatch(m, d, 1, 0.01, -3.0, 3.0, st.batch_used, st.w0_chunk_used, bias_lag=lag)
+    _check_tol = dict(rtol=RTOL, atol=2e-5)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 2e-5
+    np.testing.assert_allclose(w, m.w, **_check_tol)
+    np.testing.assert_allclose(v, m.v, **_check_tol)
+    h.close()
