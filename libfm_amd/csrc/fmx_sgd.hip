@@ -861,13 +861,14 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
   // small batches as ONE launch per batch across all dies (k_small_one, fmx_small_kernels.h; FMX_SMALL_ONE=0 at fmx_create: two launches)
   const bool small_one = !side && h->small_one && (h->KP == 64 || h->KP == 128) && s.cdesc && Bc <= SMALL_ONE_MAX && !hy.sgda;
   int szr = 0, small_cap = 0;
-  static const uint32_t small_flags = []() { const char* e = getenv("FMX_SMALL_FLAGS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();
   if (small_one) {
     szr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
     if (szr == 8) szr = 16;                                       // (three instances per row width: 16, 40, 64 row slots)
     if (szr == 32) szr = 40;
     if (!h->small_slots) HIPCHK(h, fmx_dev_alloc(&h->small_slots, (size_t)3 * SMALL_ONE_MAX * sizeof(unsigned long long)));
     HIPCHK(h, hipMemsetAsync(h->small_slots, 0, (size_t)3 * SMALL_ONE_MAX * sizeof(unsigned long long), st));
+    // ... and the tagged S_e elements (the scratch may hold anything, e.g. last epoch's elements under the same tags)
+    HIPCHK(h, hipMemsetAsync(h->partial, 0, (size_t)Bc * (size_t)h->KP * sizeof(unsigned long long), st));
   }
   for (uint64_t b = 0; b < n_batch; b++) {
     const uint64_t row0 = b * B;
@@ -876,7 +877,8 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       SegWork sw;
       seg_work(b, &sw);
       *deferred += sw.nseg;
-      float* S = h->partial + (size_t)(b & 1) * Bc * (size_t)(h->KP + 1);
+      float* S = h->partial;                                      // [nb][KP] x {tag, value}: 8 bytes per element (the two batches' worth of the scratch)
+      sw.S = S;
       // the recurrence: at lag >= 2 one launch behind (k_small_one), the last launch catches up
       const bool defer = d >= 2u;
       const bool own = !defer || b + 1 == n_batch, prev = defer && b >= 1;
@@ -884,7 +886,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       const ScanSmall sc_prev{nullptr, s.target + (prev ? row0 - B : 0), h->w0_pp + ((b + d - 1) % d), h->w0_pp + (b % d), prev ? B : 0u, chunk};
       unsigned long long* rs0 = h->small_slots + SMALL_ONE_MAX;
       const SmallSync sy{h->small_slots, rs0 + (size_t)(b & 1) * SMALL_ONE_MAX, rs0 + (size_t)((b + 1) & 1) * SMALL_ONE_MAX, (uint32_t)(b + 1), (uint32_t)b,
-                         h->handoff_err, std::min<uint32_t>(h->pit_spins, 1u << 21), small_flags};
+                         h->handoff_err, std::min<uint32_t>(h->pit_spins, 1u << 21)};
       const uint32_t n_ex_wg = (nb + 3u) / 4u;
       bool launched = false;
 #define FMX_SMALL1(KPV, ZRV) do { if (h->KP == KPV && szr == ZRV) {                                                                      \

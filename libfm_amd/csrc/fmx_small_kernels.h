@@ -9,7 +9,8 @@
 //             owners poll it).  Nothing an example waits for.
 //   owners    (one wavefront per deferred feature): the feature's row and its occurrence list are asked for at once (batch-start values,
 //             static tables); every lane polls the multiplier slot of ITS occurrence (the poll that succeeds is the load), then the S_e
-//             rows are read past this die's caches, TL at a time, and summed in occurrence order; one owner per row, written once.
+//             rows are read past this die's caches, TL at a time, their tags checked (read again if an element is not there yet), and
+//             summed in occurrence order; one owner per row, written once.
 //             An example publishes its multiplier only after it has gathered all its rows, so when an owner has seen every occurrence's
 //             tag nobody will read the batch-start row again: the owner's store cannot overtake a reader.
 //   recurrence (the last workgroup, one wavefront): at bias lag >= 2 the PREVIOUS batch's (its rest_e are complete and what it writes is read
@@ -24,8 +25,7 @@
 namespace fmx {
 
 constexpr uint32_t SMALL_ONE_MAX = 1024;                              // examples per batch (the recurrence holds the batch in registers)
-struct SmallSync { unsigned long long* mslot; unsigned long long* rslot; const unsigned long long* rslot_prev; uint32_t tag, tag_prev; uint32_t* err; uint32_t spins;
-                   uint32_t flags; };   // flags: FMX_SMALL_FLAGS (A/B timing knobs)
+struct SmallSync { unsigned long long* mslot; unsigned long long* rslot; const unsigned long long* rslot_prev; uint32_t tag, tag_prev; uint32_t* err; uint32_t spins; };
 
 __device__ __forceinline__ bool slot_wait(const unsigned long long* p, uint32_t tag, uint32_t spins, uint32_t& lo) {
   unsigned long long u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -101,13 +101,15 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       const float rest = wave_sum_dpp(part);
       if (lane == 0) slot_put(sy.rslot + e, sy.tag, rest);
       const float mult = multiplier(h, w0s + rest, y);
-      // what the owners need, BEFORE the example's own updates: S_e as write-through stores, waited for (a release fence would write back the
-      // die's whole L2: 22.6 vs 14.0 us per batch; publishing behind the own row stores waits for their acknowledgements too: 15.5 vs 13.1),
-      // then the tagged multiplier
+      // what the owners need, BEFORE the example's own updates and without waiting for anything: every element of S_e as a self-validating
+      // 8-byte {tag, value} store, then the tagged multiplier.  (A release fence per example writes back the die's whole L2: 22.6 us per
+      // batch; plain write-through stores + s_waitcnt for their acknowledgement before the multiplier: 13.1-13.9.)
       if (cm != 0) {
+        unsigned long long* Sx = reinterpret_cast<unsigned long long*>(S_out);
 #pragma unroll
-        for (int v = 0; v < VEC; v++) __hip_atomic_store(S_out + (size_t)e * KP + lane * VEC + v, sum[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int v = 0; v < VEC; v++)
+          __hip_atomic_store(Sx + (size_t)e * KP + lane * VEC + v, ((unsigned long long)sy.tag << 32) | (unsigned long long)__float_as_uint(sum[v]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
       }
       float w_keep = __builtin_nanf("");
@@ -141,9 +143,11 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       const float rest = wave_sum_dpp(part);
       if (lane == 0) slot_put(sy.rslot + e, sy.tag, rest);
       const float mult = multiplier(h, w0s + rest, y);
+      unsigned long long* Sx = reinterpret_cast<unsigned long long*>(S_out);
 #pragma unroll
-      for (int v = 0; v < VEC; v++) __hip_atomic_store(S_out + (size_t)e * KP + lane * VEC + v, sum[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int v = 0; v < VEC; v++)
+        __hip_atomic_store(Sx + (size_t)e * KP + lane * VEC + v, ((unsigned long long)sy.tag << 32) | (unsigned long long)__float_as_uint(sum[v]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
     }
     return;
@@ -183,7 +187,6 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
   }
   // ------------------------------------------------------------------ an owner of deferred features
   const uint32_t n_own_waves = (gridDim.x - 1u - n_ex_wg) * 4u;
-  if (sy.flags & 8u) return;                                         // (A/B, timing only: no owners)
   for (uint32_t s = (blockIdx.x - n_ex_wg) * 4u + wv; s < sw.nseg; s += n_own_waves) {
     const uint4 d0 = reinterpret_cast<const uint4*>(sw.cdesc + s)[0];
     const uint32_t j = __builtin_amdgcn_readfirstlane(d0.x), a = __builtin_amdgcn_readfirstlane(d0.y), b = __builtin_amdgcn_readfirstlane(d0.z);
@@ -194,7 +197,8 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     float G[VEC]; float A = 0.f, Gw = 0.f;
 #pragma unroll
     for (int v = 0; v < VEC; v++) G[v] = 0.f;
-    constexpr int TL = (VEC == 1) ? 32 : 16;                         // S_e rows in flight per round
+    constexpr int TL = (VEC == 1) ? 16 : 8;                          // S_e rows in flight per round
+    const unsigned long long* Sx = reinterpret_cast<const unsigned long long*>(sw.S);
     for (uint32_t base = a; base < b; base += 64u) {
       const uint32_t cc = min(64u, b - base);
       TEntry te; te.e = 0; te.x = 0.f; float tm = 0.f;
@@ -202,26 +206,36 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       if (lane < cc) {
         te = load_stream8(sw.t_ent + base + lane);
         uint32_t lo;
-        ok = slot_wait(sy.mslot + te.e, sy.tag, (sy.flags & 4u) ? 0u : sy.spins, lo);
-        if (sy.flags & 4u) ok = true;                                // (A/B, timing only: wrong numbers)
+        ok = slot_wait(sy.mslot + te.e, sy.tag, sy.spins, lo);
         tm = __uint_as_float(lo);
       }
       if (__any(!ok)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }   // (the feature takes no step)
       for (uint32_t q0 = 0; q0 < cc; q0 += TL) {
-        float s2[TL][VEC];
+        // the S_e elements validate themselves: they left their example before its multiplier did, so they are normally here; else again
+        unsigned long long u[TL][VEC];
+        bool stale = false;
+        for (uint32_t t = 0; t <= sy.spins; t++) {
+          stale = false;
 #pragma unroll
-        for (int q = 0; q < TL; q++) {
-          const uint32_t e2 = bcast_u32<1>(te.e, (q0 + q) & 63u);
+          for (int q = 0; q < TL; q++) {
+            const uint32_t e2 = bcast_u32<1>(te.e, (q0 + q) & 63u);
 #pragma unroll
-          for (int v = 0; v < VEC; v++) s2[q][v] = (q0 + q < cc && lane * VEC + v < KP) ? ld_l2(sw.S + (size_t)e2 * KP + lane * VEC + v) : 0.f;
+            for (int v = 0; v < VEC; v++) {
+              u[q][v] = (q0 + q < cc) ? __hip_atomic_load(Sx + (size_t)e2 * KP + lane * VEC + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)sy.tag << 32);
+              stale |= (uint32_t)(u[q][v] >> 32) != sy.tag;
+            }
+          }
+          if (!__any(stale)) break;
+          __builtin_amdgcn_s_sleep(2);
         }
+        if (__any(stale)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }
 #pragma unroll
         for (int q = 0; q < TL; q++) {
           const float x2 = bcast_f32<1>(te.x, (q0 + q) & 63u), m2 = bcast_f32<1>(tm, (q0 + q) & 63u);
           if (q0 + q < cc) {
             const float mx2 = m2 * x2;
 #pragma unroll
-            for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, s2[q][v], G[v]);
+            for (int v = 0; v < VEC; v++) G[v] = fmaf(mx2, __uint_as_float((uint32_t)u[q][v]), G[v]);
             A = fmaf(mx2, x2, A); Gw += mx2;
           }
         }
