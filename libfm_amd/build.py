@@ -13,8 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SRC = [os.path.join(CSRC, f) for f in ("fmx_core.hip", "fmx_sgd.hip", "fmx_als.hip", "fmx_io.hip", "fmx_comm.hip")]
-DEPS = SRC + [os.path.join(CSRC, f) for f in ("fmx_internal.h", "fmx_kernels.h", "fmx_als_kernels.h")] + \
-    [os.path.join(ROOT, "include", "fmx.h")]
+DEPS = SRC + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "fmx.h")]   # every header under csrc/
 # experiments: FMX_DEFS="-DFMX_V_NT=1" FMX_OUT=libfmx_nt.so python -m libfm_amd.build --force ; run with FMX_LIB=<that file>
 EXTRA = os.environ.get("FMX_DEFS", "").split()
 OUT = os.path.join(HERE, os.environ.get("FMX_OUT", "libfmx.so"))

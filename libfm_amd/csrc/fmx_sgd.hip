@@ -865,10 +865,20 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     szr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
     if (szr == 8) szr = 16;                                       // (three instances per row width: 16, 40, 64 row slots)
     if (szr == 32) szr = 40;
-    if (!h->small_slots) HIPCHK(h, fmx_dev_alloc(&h->small_slots, (size_t)3 * SMALL_ONE_MAX * sizeof(unsigned long long)));
+    if (!h->small_slots) HIPCHK(h, fmx_dev_alloc(&h->small_slots, ((size_t)3 * SMALL_ONE_MAX + 16) * sizeof(unsigned long long)));
     HIPCHK(h, hipMemsetAsync(h->small_slots, 0, (size_t)3 * SMALL_ONE_MAX * sizeof(unsigned long long), st));
     // ... and the tagged S_e elements (the scratch may hold anything, e.g. last epoch's elements under the same tags)
     HIPCHK(h, hipMemsetAsync(h->partial, 0, (size_t)Bc * (size_t)h->KP * sizeof(unsigned long long), st));
+  }
+  // FMX_SMALL_TRACE=<file>: device time stamps of the epoch's middle batch (fmx_small_kernels.h SmallSync::trace), appended to the file
+  static const char* small_trace_file = getenv("FMX_SMALL_TRACE");
+  unsigned long long* small_trace = nullptr;
+  if (small_one && small_trace_file) {
+    small_trace = h->small_slots + (size_t)3 * SMALL_ONE_MAX;
+    unsigned long long init[16];
+    for (int i = 0; i < 16; i++) init[i] = (i == 0 || i == 5) ? ~0ull : 0ull;
+    HIPCHK(h, hipMemcpyAsync(small_trace, init, sizeof(init), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
   }
   for (uint64_t b = 0; b < n_batch; b++) {
     const uint64_t row0 = b * B;
@@ -886,7 +896,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       const ScanSmall sc_prev{nullptr, s.target + (prev ? row0 - B : 0), h->w0_pp + ((b + d - 1) % d), h->w0_pp + (b % d), prev ? B : 0u, chunk};
       unsigned long long* rs0 = h->small_slots + SMALL_ONE_MAX;
       const SmallSync sy{h->small_slots, rs0 + (size_t)(b & 1) * SMALL_ONE_MAX, rs0 + (size_t)((b + 1) & 1) * SMALL_ONE_MAX, (uint32_t)(b + 1), (uint32_t)b,
-                         h->handoff_err, std::min<uint32_t>(h->pit_spins, 1u << 21)};
+                         h->handoff_err, std::min<uint32_t>(h->pit_spins, 1u << 21), (small_trace && b == n_batch / 2) ? small_trace : nullptr};
       const uint32_t n_ex_wg = (nb + 3u) / 4u;
       bool launched = false;
 #define FMX_SMALL1(KPV, ZRV) do { if (h->KP == KPV && szr == ZRV) {                                                                      \
@@ -959,6 +969,18 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
       }
     }
     (*batches)++; (*launches)++;
+  }
+  if (small_trace) {
+    unsigned long long tr[16];
+    HIPCHK(h, hipMemcpyAsync(tr, small_trace, sizeof(tr), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (FILE* f = fopen(small_trace_file, "a")) {
+      const double t0 = (double)tr[0];
+      fprintf(f, "batch %llu of %llu (ns after the first example started): last example started %.0f, rows gathered %.0f, multiplier published %.0f, example done %.0f | "
+                 "first owner started %.0f, last owner saw its tags %.0f, holds its S rows %.0f, done %.0f | recurrence done %.0f | last owner started %.0f, has its entry list %.0f\n",
+              (unsigned long long)(n_batch / 2), (unsigned long long)n_batch, tr[1] - t0, tr[2] - t0, tr[3] - t0, tr[4] - t0, (double)tr[5] - t0, tr[6] - t0, tr[7] - t0, tr[8] - t0, tr[9] - t0, tr[10] - t0, tr[11] - t0);
+      fclose(f);
+    }
   }
   if (handoff) {                                              // ONE event per epoch: the last recurrence, then the bias goes home
     if (h->ev_sync.empty()) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_sync.push_back(e); }

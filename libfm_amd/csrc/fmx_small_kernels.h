@@ -25,7 +25,13 @@
 namespace fmx {
 
 constexpr uint32_t SMALL_ONE_MAX = 1024;                              // examples per batch (the recurrence holds the batch in registers)
-struct SmallSync { unsigned long long* mslot; unsigned long long* rslot; const unsigned long long* rslot_prev; uint32_t tag, tag_prev; uint32_t* err; uint32_t spins; };
+struct SmallSync { unsigned long long* mslot; unsigned long long* rslot; const unsigned long long* rslot_prev; uint32_t tag, tag_prev; uint32_t* err; uint32_t spins;
+                   unsigned long long* trace; };   // trace (FMX_SMALL_TRACE=<file>, one batch of the epoch): wall_clock64 time stamps (ns on this part), [0] first / [1] last example started,
+                                                   // [2] last rows gathered, [3] last multiplier published, [4] last example done, [5] first owner started,
+                                                   // [6] last owner saw its tags, [7] last owner holds its S_e rows, [8] last owner done, [9] recurrence done, [10] last owner started,
+                                                   // [11] last owner has its entry list
+__device__ __forceinline__ void trace_min(unsigned long long* t, int i) { if (t && (threadIdx.x & 63u) == 0) atomicMin(t + i, (unsigned long long)wall_clock64()); }
+__device__ __forceinline__ void trace_max(unsigned long long* t, int i) { if (t && (threadIdx.x & 63u) == 0) atomicMax(t + i, (unsigned long long)wall_clock64()); }
 
 __device__ __forceinline__ bool slot_wait(const unsigned long long* p, uint32_t tag, uint32_t spins, uint32_t& lo) {
   unsigned long long u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -57,6 +63,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     const uint32_t e = blockIdx.x * 4u + wv;
     if (e >= n_rows) return;
     const float w0s = h.k0 ? (float)(*w0_ptr) : 0.f;                 // (before anything is published: the recurrence rewrites this slot)
+    trace_min(sy.trace, 0); trace_max(sy.trace, 1);
     const uint64_t a = fixed_nnz ? (row0 + e) * (uint64_t)fixed_nnz : row_ptr[row0 + e];
     const uint32_t size = fixed_nnz ? fixed_nnz : (uint32_t)(row_ptr[row0 + e + 1] - a);
     const Entry* __restrict__ row = ent + a;
@@ -99,6 +106,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
 #pragma unroll
       for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
       const float rest = wave_sum_dpp(part);
+      trace_max(sy.trace, 2);
       if (lane == 0) slot_put(sy.rslot + e, sy.tag, rest);
       const float mult = multiplier(h, w0s + rest, y);
       // what the owners need, BEFORE the example's own updates and without waiting for anything: every element of S_e as a self-validating
@@ -111,6 +119,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
           __hip_atomic_store(Sx + (size_t)e * KP + lane * VEC + v, ((unsigned long long)sy.tag << 32) | (unsigned long long)__float_as_uint(sum[v]),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
+        trace_max(sy.trace, 3);
       }
       float w_keep = __builtin_nanf("");
       if (h.k1 && lane < size && !((cm >> lane) & 1ull)) {            // fm_sgd.h:38-43
@@ -134,6 +143,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
           store_row<VEC, 2>(pv, nv);
         }
       }
+      trace_max(sy.trace, 4);
     } else {                                                         // a row beyond the register path: deferred as a whole (cm = all ones)
       float sum[VEC], sq, lin;
       row_sums<KP, 8>(row, size, tb, h.k1, sum, sq, lin);
@@ -183,11 +193,13 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       s2.rest = s_rest;
       scan_small<false>(s2, h);
     }
+    trace_max(sy.trace, 9);
     return;
   }
   // ------------------------------------------------------------------ an owner of deferred features
   const uint32_t n_own_waves = (gridDim.x - 1u - n_ex_wg) * 4u;
   for (uint32_t s = (blockIdx.x - n_ex_wg) * 4u + wv; s < sw.nseg; s += n_own_waves) {
+    trace_min(sy.trace, 5); trace_max(sy.trace, 10);
     const uint4 d0 = reinterpret_cast<const uint4*>(sw.cdesc + s)[0];
     const uint32_t j = __builtin_amdgcn_readfirstlane(d0.x), a = __builtin_amdgcn_readfirstlane(d0.y), b = __builtin_amdgcn_readfirstlane(d0.z);
     float v0[VEC];
@@ -203,13 +215,16 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       const uint32_t cc = min(64u, b - base);
       TEntry te; te.e = 0; te.x = 0.f; float tm = 0.f;
       bool ok = true;
+      if (lane < cc) te = load_stream8(sw.t_ent + base + lane);
+      if (sy.trace && __any(te.e == 0xFFFFFFFFu)) return;            // (forces the entry list in before the stamp)
+      trace_max(sy.trace, 11);
       if (lane < cc) {
-        te = load_stream8(sw.t_ent + base + lane);
         uint32_t lo;
         ok = slot_wait(sy.mslot + te.e, sy.tag, sy.spins, lo);
         tm = __uint_as_float(lo);
       }
       if (__any(!ok)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }   // (the feature takes no step)
+      trace_max(sy.trace, 6);
       for (uint32_t q0 = 0; q0 < cc; q0 += TL) {
         // the S_e elements validate themselves: they left their example before its multiplier did, so they are normally here; else again
         unsigned long long u[TL][VEC];
@@ -229,6 +244,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
           __builtin_amdgcn_s_sleep(2);
         }
         if (__any(stale)) { if (lane == 0) atomicOr(sy.err, RUN_ERR_EXCHANGE); return; }
+        trace_max(sy.trace, 7);
 #pragma unroll
         for (int q = 0; q < TL; q++) {
           const float x2 = bcast_f32<1>(te.x, (q0 + q) & 63u), m2 = bcast_f32<1>(tm, (q0 + q) & 63u);
@@ -250,6 +266,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     }
     row_st<VEC, 8>(tb, (size_t)j, lane * VEC, nv);
     if (h.k1 && lane == 0) tb.w[(size_t)j * tb.ws] = wv0 - h.lr * (Gw + nocc * h.regw * wv0);
+    trace_max(sy.trace, 8);
   }
 }
 
