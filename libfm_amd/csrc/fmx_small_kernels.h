@@ -24,6 +24,9 @@
 
 namespace fmx {
 
+#ifndef FMX_SMALL_NT
+#define FMX_SMALL_NT 3                                                  // bit 1: the examples' row loads non-temporal, bit 2: their row stores
+#endif
 constexpr uint32_t SMALL_ONE_MAX = 1024;                              // examples per batch (the recurrence holds the batch in registers)
 struct SmallSync { unsigned long long* mslot; unsigned long long* rslot; const unsigned long long* rslot_prev; uint32_t tag, tag_prev; uint32_t* err; uint32_t spins;
                    unsigned long long* trace; };   // trace (FMX_SMALL_TRACE=<file>, one batch of the epoch): wall_clock64 time stamps (ns on this part), [0] first / [1] last example started,
@@ -82,7 +85,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       for (int t = 0; t < ZR; t++) {
         const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
         if ((uint32_t)t < size) {
-          row_ld<VEC, 1>(tb, (size_t)id, lane * VEC, vr[t]);
+          row_ld<VEC, (FMX_SMALL_NT & 1)>(tb, (size_t)id, lane * VEC, vr[t]);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
@@ -140,7 +143,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
             const float grad = sum[v] * x - vv * x * x;
             nv[v] = vv - h.lr * (mult * grad + h.regv * vv);
           }
-          store_row<VEC, 2>(pv, nv);
+          store_row<VEC, (FMX_SMALL_NT & 2)>(pv, nv);
         }
       }
       trace_max(sy.trace, 4);
