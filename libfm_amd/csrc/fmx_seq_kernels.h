@@ -11,6 +11,9 @@
 // the few it shares with this example (found by comparing the ids) are read again after the stores have drained.
 // Rows with a repeated id, and rows beyond the register path, take the entry-by-entry loop (seq_row_entries: k_sequential's body).
 // The update arithmetic is fp32 with its per-example constants formed in fp64 (the parameters are fp32; the sums stay fp64).
+//
+// Second half of the file: CONFLICT-FREE RUNS -- where consecutive rows rarely share a feature the same trajectory runs at batch speed, one
+// launch per run of a few hundred rows (k_run_fused, k_run_apply; ~70 x the rate of the kernels above at BASELINE's headline shape).
 #pragma once
 
 namespace fmx {
@@ -480,7 +483,8 @@ namespace fmx {
 // with the bias recurrence coupled example by example" are the same computation: the sums of a row only read parameters no other row of the
 // run writes, the bias is the one sequential thread (fm_sgd.h:34-37) -- and that is exactly what k_rowsums -> k_scan (micro-chunk 1, the
 // multipliers come out of the recurrence) -> k_apply compute for a batch.  So the slot is cut, once, into maximal such runs (greedy, in file
-// order) and an epoch is three launches per run; a row that repeats an id (fm_sgd.h:44-50: the second occurrence sees the first's update)
+// order) and an epoch is ONE launch per run where the rows fit the registers (k_run_fused, below), two or three otherwise (fmx_sgd.hip
+// seq_runs_epoch); a row that repeats an id (fm_sgd.h:44-50: the second occurrence sees the first's update)
 // is a run of its own and goes through the entry-by-entry kernel.
 //   k_run_keys / k_run_prev: prev[r] = 1 + the latest earlier row that shares a feature with row r (0: none), bit 31: the row repeats an id --
 //   through one radix sort of (feature << 32 | row) keys; the greedy cut itself is a loop over prev[] on the host (fmx_sgd.hip ensure_runs).
