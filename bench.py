@@ -207,7 +207,8 @@ def run_sgd_config(capi, name, n, k, nnz, rows, criteo, steps, warmup, with_cpu,
                       "batch_rule": {"batch": int(st.batch_used), "collision_mass": round(st.collision_mass, 6), "gain": round(st.batch_gain, 4),
                                      "cut": bool(st.status & capi.STAT_BATCH_CUT)},
                       "device": info.device_name.decode()},
-           "roofline": {"bound": "hbm", "kernel": "k_fused<%d,EXACT> + deferred features, per batch" % info.k_padded,
+           "roofline": {"bound": "hbm", "kernel": ("k_small_one<%d>: examples + deferred features + bias recurrence in ONE launch per batch" if st.status & capi.STAT_SMALL_ONE
+                                                   else "k_fused<%d,EXACT> + deferred features, per batch") % info.k_padded,
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "v_read_frac": v_read_fraction(per_launch / avg, k, nnz), "traffic": traffic, "traffic_source": tsrc,
                         "bytes_per_example": per_ex, "examples_per_launch": per_launch, "avg_launch_ms": round(avg * 1e3, 4),
@@ -965,6 +966,17 @@ def main():
             for kk in ("c2", "criteo", "als", "mcmc", "mcmc_c5", "criteo_8shard"):
                 if isinstance(out.get(kk), dict) and "value" in out[kk]:
                     out["roofline"]["examples_per_s_" + kk] = out[kk]["value"]
+            cr = out.get("criteo")
+            if isinstance(cr, dict) and "value" in cr and isinstance(cr.get("config"), dict):   # what a 512-row batch of Criteo-shaped rows costs (one launch: k_small_one)
+                try:
+                    out["roofline"]["us_per_batch_criteo"] = round(cr["config"]["batch_rule"]["batch"] / cr["value"] * 1e6, 3)
+                    out["roofline"]["batch_criteo"] = cr["config"]["batch_rule"]["batch"]
+                except (KeyError, TypeError, ZeroDivisionError):
+                    pass
+            sq = extras.get("sequential") if isinstance(extras, dict) else None
+            if isinstance(sq, dict) and sq.get("runs"):
+                out["roofline"]["sequential_runs"] = sq["runs"]
+                out["roofline"]["sequential_rows"] = sq["rows"]
             sp = out.get("shard_probe", {}).get("ranks", {})
             if "P8" in sp:
                 out["roofline"]["shard_p8_rank_examples_per_s"] = sp["P8"]["per_rank_examples_per_s"]
