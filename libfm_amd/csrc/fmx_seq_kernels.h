@@ -673,13 +673,13 @@ template <int KP, int ZR, int TASK>
 __global__ void __launch_bounds__(256)
 k_run_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr, const float* __restrict__ target, uint64_t row0, uint32_t n_rows,
             const Tab tb, Hyper h, const double* __restrict__ w0_in, double* __restrict__ w0_out, const RunSync rs, uint32_t fixed_nnz) {
-  static_assert(KP >= 64, "one entry per gather instruction");
+  // KP < 64 (k <= 32): EPI = 64 / KP rows per wave-wide load -- lane group g = lane / KP holds entry t * EPI + g of row slot t (k_fused's layout)
   extern __shared__ float run_lds[];                                 // 5 x n_rows floats
   __shared__ float s_map[4][2];
   __shared__ float s_chg[4];
   __shared__ double s_end;
-  constexpr int VEC = Map<KP>::VEC;
-  const uint32_t lane = threadIdx.x & 63u;
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
+  const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
   const bool have = e < n_rows;
   Entry en; en.id = 0; en.value = 0.f;
@@ -692,16 +692,17 @@ k_run_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
   if (have) {
     // fixed_nnz != 0: every row of the slot holds that many entries -- the row_ptr round trip drops out of the chain row_ptr -> entries -> rows
     const uint64_t a = fixed_nnz ? (row0 + e) * (uint64_t)fixed_nnz : row_ptr[row0 + e];
-    size = fixed_nnz ? fixed_nnz : (uint32_t)(row_ptr[row0 + e + 1] - a);   // (<= min(64, ZR): the host checked the slot's longest row)
+    size = fixed_nnz ? fixed_nnz : (uint32_t)(row_ptr[row0 + e + 1] - a);   // (<= min(64, ZR * EPI): the host checked the slot's longest row)
     if (lane < size) {
       en = load_stream8(ent + a + lane);
       if (h.k1) wv = load_w(tb.w + (size_t)en.id * tb.ws);
     }
 #pragma unroll
-    for (int t = 0; t < ZR; t++) {
-      const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
-      if ((uint32_t)t < size) {
-        row_ld<VEC, 1>(tb, (size_t)id, lane * VEC, vr[t]);
+    for (int t = 0; t < ZR; t++) {                                   // (cross-lane reads with every lane enabled: `have` is wave-uniform)
+      const uint32_t idx = (uint32_t)t * EPI + g;
+      const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
+      if (idx < size) {
+        row_ld<VEC, 1>(tb, (size_t)id, f * VEC, vr[t]);
       } else {
 #pragma unroll
         for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
@@ -710,8 +711,9 @@ k_run_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     float sq = 0.f;                                                  // fm_model.h:116-125
 #pragma unroll
     for (int t = 0; t < ZR; t++) {
-      float x = bcast_f32<1>(en.value, (uint32_t)t & 63u);
-      if ((uint32_t)t >= size) x = 0.f;
+      const uint32_t idx = (uint32_t)t * EPI + g;
+      float x = bcast_f32<EPI>(en.value, idx & 63u);
+      if (idx >= size) x = 0.f;
 #pragma unroll
       for (int v = 0; v < VEC; v++) {
         const float d = vr[t][v] * x;
@@ -719,9 +721,13 @@ k_run_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
         sq = fmaf(d, d, sq);
       }
     }
-    float part = wv * en.value - 0.5f * sq;
 #pragma unroll
-    for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+    for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
+    float part = wv * en.value - 0.5f * sq;
+    if (lane < LPR) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+    }
     const float rest = wave_sum_dpp(part);
     if (lane == 0)
       __hip_atomic_store(rs.slots + e, ((unsigned long long)rs.tag << 32) | (unsigned long long)__float_as_uint(rest), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -754,10 +760,11 @@ k_run_fused(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
   }
 #pragma unroll
   for (int t = 0; t < ZR; t++) {                                     // fm_sgd.h:44-50 on the register-resident rows
-    const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
-    const float x = bcast_f32<1>(en.value, (uint32_t)t & 63u);
-    if ((uint32_t)t < size && lane * VEC < tb.rs) {
-      float* pv = tb.V + (size_t)id * tb.rs + lane * VEC;
+    const uint32_t idx = (uint32_t)t * EPI + g;
+    const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
+    const float x = bcast_f32<EPI>(en.value, idx & 63u);
+    if (idx < size && f * VEC < tb.rs) {
+      float* pv = tb.V + (size_t)id * tb.rs + f * VEC;
       float nv[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; v++) {

@@ -859,12 +859,15 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
     for (uint32_t r = 0; r < d; r++) HIPCHK(h, hipMemcpyAsync(h->w0_pp + r, h->w0, sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   // small batches as ONE launch per batch across all dies (k_small_one, fmx_small_kernels.h; FMX_SMALL_ONE=0 at fmx_create: two launches)
-  const bool small_one = !side && h->small_one && (h->KP == 64 || h->KP == 128) && s.cdesc && Bc <= SMALL_ONE_MAX && !hy.sgda;
+  const bool small_one = !side && h->small_one && (h->KP == 8 || h->KP == 16 || h->KP == 32 || h->KP == 64 || h->KP == 128) && s.cdesc && Bc <= SMALL_ONE_MAX && !hy.sgda;
   int szr = 0, small_cap = 0;
   if (small_one) {
-    szr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
-    if (szr == 8) szr = 16;                                       // (three instances per row width: 16, 40, 64 row slots)
-    if (szr == 32) szr = 40;
+    if (h->KP < 64) szr = h->KP;                                  // (k <= 32: 64 / KP entries per row slot, KP slots hold any row of <= 64 entries)
+    else {
+      szr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
+      if (szr == 8) szr = 16;                                     // (three instances per row width: 16, 40, 64 row slots)
+      if (szr == 32) szr = 40;
+    }
     if (!h->small_slots) HIPCHK(h, fmx_dev_alloc(&h->small_slots, ((size_t)3 * SMALL_ONE_MAX + 16) * sizeof(unsigned long long)));
     HIPCHK(h, hipMemsetAsync(h->small_slots, 0, (size_t)3 * SMALL_ONE_MAX * sizeof(unsigned long long), st));
     // ... and the tagged S_e elements (the scratch may hold anything, e.g. last epoch's elements under the same tags)
@@ -912,6 +915,7 @@ static int sgd_epoch_fused(fmx_handle h, Slot& s, const fmx_sgd_opts* opts, cons
                            (const double*)(h->w0_pp + ((b + 1) % d)), (const uint64_t*)s.cmask, S, s.fixed_nnz, sw, sc_prev, sc, sy, n_ex_wg,  \
                            (const uint64_t*)(keep ? s.lmask : nullptr), keep ? s.wside : (float*)nullptr);                                 \
         launched = true; } } while (0)
+      FMX_SMALL1(8, 8);    FMX_SMALL1(16, 16);  FMX_SMALL1(32, 32);
       FMX_SMALL1(64, 16);  FMX_SMALL1(64, 40);  FMX_SMALL1(64, 64);
       FMX_SMALL1(128, 16); FMX_SMALL1(128, 40); FMX_SMALL1(128, 64);
 #undef FMX_SMALL1
@@ -1070,6 +1074,7 @@ static int launch_run_one(fmx_handle h, const Slot& s, const Hyper& hy, uint32_t
     if ((int)grid.x <= it->second) {                                                                                                     \
       hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, s.ent, s.row_ptr, s.target, (uint64_t)row0, nb, h->tb, hy, bias_in, bias_out, rs, s.fixed_nnz); \
       launched = 1; } } } while (0)
+  FMX_RUN1(8, 8, 0);    FMX_RUN1(16, 16, 0);  FMX_RUN1(32, 32, 0);  FMX_RUN1(8, 8, 1);    FMX_RUN1(16, 16, 1);  FMX_RUN1(32, 32, 1);
   FMX_RUN1(64, 16, 0);  FMX_RUN1(64, 40, 0);  FMX_RUN1(64, 64, 0);  FMX_RUN1(64, 16, 1);  FMX_RUN1(64, 40, 1);  FMX_RUN1(64, 64, 1);
   FMX_RUN1(128, 16, 0); FMX_RUN1(128, 40, 0); FMX_RUN1(128, 64, 0); FMX_RUN1(128, 16, 1); FMX_RUN1(128, 40, 1); FMX_RUN1(128, 64, 1);
 #undef FMX_RUN1
@@ -1093,8 +1098,9 @@ static int seq_runs_epoch(fmx_handle h, Slot& s, const Hyper& hy) {
   if (!h->run_slots) HIPCHK(h, fmx_dev_alloc(&h->run_slots, (size_t)RUN_ONE_MAX * sizeof(unsigned long long)));
   unsigned long long* slots = h->run_slots;                       // {tag, rest_e} of a one-launch run's examples
   int zr = 0;
-  bool one = fused && one_env && h->run_one && (h->KP == 64 || h->KP == 128) && s.max_row <= 64u;
-  if (one) {
+  bool one = fused && one_env && h->run_one && (h->KP == 8 || h->KP == 16 || h->KP == 32 || h->KP == 64 || h->KP == 128) && s.max_row <= 64u;
+  if (one && h->KP < 64) zr = h->KP;                              // (k <= 32: 64 / KP entries per row slot, KP slots hold any row of <= 64 entries)
+  else if (one) {
     zr = (h->KP == 64) ? fused_zr_select<64>(s.max_row) : fused_zr_select<128>(s.max_row);
     if (s.max_row > (uint32_t)zr) one = false;                    // (rows beyond the register path)
     if (zr == 8) zr = 16;                                         // (three instances per row width: 16, 40, 64 row slots)

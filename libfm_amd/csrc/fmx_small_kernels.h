@@ -56,10 +56,10 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
             uint32_t fixed_nnz, const SegWork sw, const ScanSmall sc_prev, const ScanSmall sc, const SmallSync sy, uint32_t n_ex_wg,
             const uint64_t* __restrict__ lmask, float* __restrict__ wside) {
   // wside != nullptr (FMX_FLAG_KEEP_WSIDE): the slot's weight side stream is kept current exactly as k_fused<FUSED_EXACT> keeps it
-  static_assert(KP >= 64, "one row per wave-wide load");
-  constexpr int VEC = Map<KP>::VEC;
+  // KP < 64 (k <= 32): EPI = 64 / KP rows per wave-wide load -- lane group g = lane / KP holds entry t * EPI + g of row slot t (k_fused's layout)
+  constexpr int VEC = Map<KP>::VEC, LPR = Map<KP>::LPR, EPI = Map<KP>::EPI;
   __shared__ float s_rest[SMALL_ONE_MAX];
-  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lane = threadIdx.x & 63u, g = lane / LPR, f = lane % LPR;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (blockIdx.x < n_ex_wg) {
     // ---------------------------------------------------------------- an example
@@ -73,7 +73,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     const float y = target[row0 + e];
     const uint64_t cm = cmask[row0 + e];
     const uint64_t lm = wside ? lmask[row0 + e] : 0ull;
-    if (size <= (uint32_t)ZR && size <= 64u) {
+    if (size <= (uint32_t)(ZR * EPI) && size <= 64u) {
       Entry en; en.id = 0; en.value = 0.f;
       float wl = 0.f;
       if (lane < size) {
@@ -82,10 +82,11 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       }
       float vr[ZR][VEC];
 #pragma unroll
-      for (int t = 0; t < ZR; t++) {
-        const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
-        if ((uint32_t)t < size) {
-          row_ld<VEC, (FMX_SMALL_NT & 1)>(tb, (size_t)id, lane * VEC, vr[t]);
+      for (int t = 0; t < ZR; t++) {                                 // (cross-lane reads with every lane enabled: outside the guards)
+        const uint32_t idx = (uint32_t)t * EPI + g;
+        const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
+        if (idx < size) {
+          row_ld<VEC, (FMX_SMALL_NT & 1)>(tb, (size_t)id, f * VEC, vr[t]);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; v++) vr[t][v] = 0.f;
@@ -96,8 +97,9 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       for (int v = 0; v < VEC; v++) sum[v] = 0.f;
 #pragma unroll
       for (int t = 0; t < ZR; t++) {
-        float x = bcast_f32<1>(en.value, (uint32_t)t & 63u);
-        if ((uint32_t)t >= size) x = 0.f;
+        const uint32_t idx = (uint32_t)t * EPI + g;
+        float x = bcast_f32<EPI>(en.value, idx & 63u);
+        if (idx >= size) x = 0.f;
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
           const float d = vr[t][v] * x;
@@ -105,9 +107,13 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
           sq = fmaf(d, d, sq);
         }
       }
-      float part = wl * en.value - 0.5f * sq;
 #pragma unroll
-      for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
+      float part = wl * en.value - 0.5f * sq;
+      if (lane < LPR) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      }
       const float rest = wave_sum_dpp(part);
       trace_max(sy.trace, 2);
       if (lane == 0) slot_put(sy.rslot + e, sy.tag, rest);
@@ -117,10 +123,12 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       // batch; plain write-through stores + s_waitcnt for their acknowledgement before the multiplier: 13.1-13.9.)
       if (cm != 0) {
         unsigned long long* Sx = reinterpret_cast<unsigned long long*>(S_out);
+        if (lane < LPR) {
 #pragma unroll
-        for (int v = 0; v < VEC; v++)
-          __hip_atomic_store(Sx + (size_t)e * KP + lane * VEC + v, ((unsigned long long)sy.tag << 32) | (unsigned long long)__float_as_uint(sum[v]),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int v = 0; v < VEC; v++)
+            __hip_atomic_store(Sx + (size_t)e * KP + lane * VEC + v, ((unsigned long long)sy.tag << 32) | (unsigned long long)__float_as_uint(sum[v]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
         trace_max(sy.trace, 3);
       }
@@ -132,10 +140,11 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       if (wside && lane < size) __builtin_nontemporal_store(((lm >> lane) & 1ull) ? w_keep : __builtin_nanf(""), wside + a + lane);
 #pragma unroll
       for (int t = 0; t < ZR; t++) {                                 // fm_sgd.h:44-50 on the register-resident rows
-        const uint32_t id = bcast_u32<1>(en.id, (uint32_t)t & 63u);
-        const float x = bcast_f32<1>(en.value, (uint32_t)t & 63u);
-        if ((uint32_t)t < size && !((cm >> ((uint32_t)t & 63u)) & 1ull) && lane * VEC < tb.rs) {
-          float* pv = tb.V + (size_t)id * tb.rs + lane * VEC;
+        const uint32_t idx = (uint32_t)t * EPI + g;
+        const uint32_t id = bcast_u32<EPI>(en.id, idx & 63u);
+        const float x = bcast_f32<EPI>(en.value, idx & 63u);
+        if (idx < size && !((cm >> (idx & 63u)) & 1ull) && f * VEC < tb.rs) {
+          float* pv = tb.V + (size_t)id * tb.rs + f * VEC;
           float nv[VEC];
 #pragma unroll
           for (int v = 0; v < VEC; v++) {
@@ -150,17 +159,23 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     } else {                                                         // a row beyond the register path: deferred as a whole (cm = all ones)
       float sum[VEC], sq, lin;
       row_sums<KP, 8>(row, size, tb, h.k1, sum, sq, lin);
-      float part = lin - 0.5f * sq;
 #pragma unroll
-      for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      for (int v = 0; v < VEC; v++) sum[v] = subgroup_allsum<LPR>(sum[v]);
+      float part = lin - 0.5f * sq;
+      if (lane < LPR) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) part = fmaf(0.5f * sum[v], sum[v], part);
+      }
       const float rest = wave_sum_dpp(part);
       if (lane == 0) slot_put(sy.rslot + e, sy.tag, rest);
       const float mult = multiplier(h, w0s + rest, y);
       unsigned long long* Sx = reinterpret_cast<unsigned long long*>(S_out);
+      if (lane < LPR) {
 #pragma unroll
-      for (int v = 0; v < VEC; v++)
-        __hip_atomic_store(Sx + (size_t)e * KP + lane * VEC + v, ((unsigned long long)sy.tag << 32) | (unsigned long long)__float_as_uint(sum[v]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int v = 0; v < VEC; v++)
+          __hip_atomic_store(Sx + (size_t)e * KP + lane * VEC + v, ((unsigned long long)sy.tag << 32) | (unsigned long long)__float_as_uint(sum[v]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (lane == 0) slot_put(sy.mslot + e, sy.tag, mult);
     }
     return;
@@ -205,8 +220,11 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
     trace_min(sy.trace, 5); trace_max(sy.trace, 10);
     const uint4 d0 = reinterpret_cast<const uint4*>(sw.cdesc + s)[0];
     const uint32_t j = __builtin_amdgcn_readfirstlane(d0.x), a = __builtin_amdgcn_readfirstlane(d0.y), b = __builtin_amdgcn_readfirstlane(d0.z);
+    const bool act = lane < LPR;                                     // (KP < 64: the row's lanes; one row per wave-wide load all the same)
     float v0[VEC];
-    row_ld<VEC, 8>(tb, (size_t)j, lane * VEC, v0);
+#pragma unroll
+    for (int v = 0; v < VEC; v++) v0[v] = 0.f;
+    if (act) row_ld<VEC, 8>(tb, (size_t)j, lane * VEC, v0);
     float wv0 = 0.f;
     if (h.k1 && lane == 0) wv0 = tb.w[(size_t)j * tb.ws];
     float G[VEC]; float A = 0.f, Gw = 0.f;
@@ -239,7 +257,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
             const uint32_t e2 = bcast_u32<1>(te.e, (q0 + q) & 63u);
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
-              u[q][v] = (q0 + q < cc) ? __hip_atomic_load(Sx + (size_t)e2 * KP + lane * VEC + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)sy.tag << 32);
+              u[q][v] = (q0 + q < cc && act) ? __hip_atomic_load(Sx + (size_t)e2 * KP + lane * VEC + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)sy.tag << 32);
               stale |= (uint32_t)(u[q][v] >> 32) != sy.tag;
             }
           }
@@ -267,7 +285,7 @@ k_small_one(const Entry* __restrict__ ent, const uint64_t* __restrict__ row_ptr,
       const float vv = v0[v];
       nv[v] = vv - h.lr * (G[v] - vv * A + nocc * h.regv * vv);
     }
-    row_st<VEC, 8>(tb, (size_t)j, lane * VEC, nv);
+    if (act) row_st<VEC, 8>(tb, (size_t)j, lane * VEC, nv);
     if (h.k1 && lane == 0) tb.w[(size_t)j * tb.ws] = wv0 - h.lr * (Gw + nocc * h.regw * wv0);
     trace_max(sy.trace, 8);
   }

@@ -3,7 +3,7 @@ the default for batches of up to 1 024 rows; FMX_SMALL_ONE=0 at fmx_create: two 
 slots instead of a launch boundary (round-5 verdict item 2; fm_learn_sgd_element.h:56-67 is that chain at batch 1).
 
 It is the same batch rule as the two launches per batch (k_fused<EXACT> + k_apply_seg_scan): held against the oracle at 1e-4 and against
-the two-launch path at fp32 rounding, for both tasks, bias lags 1 and 2, ragged rows, k = 64 and k = 100 (128-float rows)."""
+the two-launch path at fp32 rounding, for both tasks, bias lags 1 and 2, ragged rows, k = 64 and k = 100 (128-float rows), and k = 8 / 16 / 24 / 32 (several rows per wave-wide load)."""
 import numpy as np
 import pytest
 
@@ -72,7 +72,8 @@ def run_case(capi, oracle, monkeypatch, k, task, lag, rows, make_ragged, epochs=
     assert abs(w0 - w0b) <= 2e-5 * abs(w0b) + 2e-7
 
 
-@pytest.mark.parametrize("k,task,lag,make_ragged", [(64, 1, 2, False), (64, 1, 1, True), (64, 0, 2, True), (100, 1, 2, False), (100, 0, 1, True)])
+@pytest.mark.parametrize("k,task,lag,make_ragged", [(64, 1, 2, False), (64, 1, 1, True), (64, 0, 2, True), (100, 1, 2, False), (100, 0, 1, True),
+                                                     (8, 1, 2, False), (8, 0, 1, True), (16, 1, 2, True), (24, 1, 2, False), (32, 0, 2, True)])
 def test_one_launch_batches_is_the_batch_rule(capi, oracle, monkeypatch, k, task, lag, make_ragged):
     run_case(capi, oracle, monkeypatch, k, task, lag, 6000, make_ragged, lr=0.01 if task == 1 else 0.002)
 
