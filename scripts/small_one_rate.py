@@ -4,9 +4,10 @@ import os, sys, time
 sys.path.insert(0, ".")
 from libfm_amd import capi
 n, k, nnz, rows = 33_000_000, 64, 39, 1 << 18
+lr = float(os.environ.get("LR", "0.01"))                 # (a smaller step: a larger batch passes the stability cut)
 for tag, env in (("two launches per batch", "0"), ("one launch per batch", "1")):
     os.environ["FMX_SMALL_ONE"] = env
-    h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, 0.01, -1.0, 1.0)
+    h = capi.Handle(n, k, True, True, capi.TASK_CLASSIFICATION, 0.0, 0.0, 0.001, lr, -1.0, 1.0)
     h.init_params(0.0, 0.01, 1)
     h.synth_rows(0, 123, 0, rows, nnz, capi.SYNTH_CRITEO)
     for _ in range(2):
