@@ -781,6 +781,34 @@ def main():
             extras["minibatch_two_pass"] = {"mode": "minibatch rule, two passes (k_rowsums + k_apply_seg), bias lag 1", "batch": 131072,
                                             "value": timed_epochs(3, capi.SGD_MINIBATCH, capi.APPLY_SEGMENTED, 131072, args.w0_chunk, capi.FLAG_BIAS_LAG),
                                             "unit": "examples/s", "steps": 3}
+        # how far the headline rule ends from the reference's ONLINE loop -- MEASURED HERE, with the device on both sides: FMX_SGD_SEQUENTIAL is the
+        # reference's own trajectory (held at 1e-4 against the real reference's final parameters by tests/test_gpu_parity.py, test_gpu_configs.py)
+        # and, as conflict-free runs, fast enough to walk 1.18 M rows inside this run.  Same start values, same rows, one epoch each.
+        # (last of the extras: it starts the handle's parameters over)
+        if args.mode == "fused":
+            try:
+                import numpy as np
+                pv_rows = 1179648                                   # 4.5 batches: the rows of the committed CPU figure (profiles/r05_parity_vs_online.json)
+                h.synth_rows(1, 20240, 0, pv_rows, args.nnz)
+                h.init_params(0.0, 0.01, 1)
+                t1 = time.perf_counter()
+                st_seq = h.sgd_epoch(1, capi.SGD_SEQUENTIAL)
+                h.synchronize()
+                t_seq = time.perf_counter() - t1
+                p_on, w0_on = h.predict(1, pv_rows).astype(np.float64), h.get_w0()
+                h.init_params(0.0, 0.01, 1)
+                h.sgd_epoch(1, mode, apply_, args.batch, args.w0_chunk, lagf, bias_lag)
+                h.synchronize()
+                p_ru, w0_ru = h.predict(1, pv_rows).astype(np.float64), h.get_w0()
+                dp = np.abs(p_ru - p_on)
+                extras["parity_vs_online_live"] = {
+                    "rows": pv_rows, "epochs": 1, "pred_rms": round(float(np.sqrt(np.mean(p_on * p_on))), 6),
+                    "pred_mean_abs": round(float(dp.mean()), 6), "pred_max_abs": round(float(dp.max()), 6), "w0_abs": round(abs(w0_ru - w0_on), 6),
+                    "online_side": "FMX_SGD_SEQUENTIAL on the device" + (" (conflict-free runs: %d)" % st_seq.batches if st_seq.status & capi.STAT_SEQ_RUNS else ""),
+                    "online_side_seconds": round(t_seq, 4),
+                    "source": "measured in this run: the headline rule against the device's reference-trajectory mode, same start, same rows, one epoch each"}
+            except Exception as exc:
+                extras["parity_vs_online_live"] = {"error": str(exc)[:200]}
 
     if rank == 0:
         value = args.steps * args.rows / elapsed
@@ -859,7 +887,7 @@ def main():
                                 out["parity_vs_online"][key] = {kk: on[kk] for kk in ("pred_mean_abs", "pred_max_abs", "w0_abs", "v_max_rel_to_vmax", "w_max_abs")}
                         except (OSError, ValueError, KeyError):
                             pass
-                    out["parity_vs_online"]["source"] = "NOT measured in this run: profiles/r05_parity_vs_online.json (scripts/cpu_online_vs_rule.py, ~45 CPU-minutes: oracle rule vs oracle online loop on the sub-model of the rows' features); the device equals the rule at 1e-4 (tests/test_gpu_configs.py)"
+                    out["parity_vs_online"]["source"] = "NOT measured in this run (the key parity_vs_online_live is: the same comparison with the device on both sides): profiles/r05_parity_vs_online.json (scripts/cpu_online_vs_rule.py, ~45 CPU-minutes: oracle rule vs oracle online loop on the sub-model of the rows' features); the device equals the rule at 1e-4 (tests/test_gpu_configs.py)"
             except (OSError, ValueError, KeyError):
                 pass
         if not sharded and args.mode != "hogwild" and roof is not None:
@@ -900,6 +928,12 @@ def main():
             roof["predict_rows_per_s_cold"] = pr["without_side_stream"]["value"]
             if isinstance(extras.get("sequential"), dict) and "value" in extras["sequential"]:
                 roof["examples_per_s_sequential"] = extras["sequential"]["value"]
+            pl = extras.get("parity_vs_online_live")
+            if isinstance(pl, dict) and "pred_mean_abs" in pl:      # measured in this run (device on both sides)
+                roof["parity_vs_online_pred_mean_abs"] = pl["pred_mean_abs"]
+                roof["parity_vs_online_pred_max_abs"] = pl["pred_max_abs"]
+                roof["parity_vs_online_w0_abs"] = pl["w0_abs"]
+                roof["parity_vs_online_pred_rms"] = pl["pred_rms"]
             roof["predict"] = {"v_read_frac": pr["v_read_frac"], "v_read_frac_cold": pr["without_side_stream"]["v_read_frac"],
                                "rows_per_s": pr["value"], "rows_per_s_cold": pr["without_side_stream"]["value"],
                                "cold": "no weight side stream (a pass that no epoch on the slot preceded)"}
