@@ -285,6 +285,50 @@ def committed_traffic(kernel, examples_per_launch, k, nnz):
     return None, None
 
 
+def live_traffic(args, examples_per_launch):
+    """HBM bytes per launch of the headline's kernels MEASURED NOW: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE: one counter per pass, as
+    MI355X_MICROARCH.md prescribes) over a short run of this script in a child process, corrected as profiles/r06_pmc_summary.txt does it:
+    reads = 2 x FETCH_SIZE x 1024 (128-byte requests are tallied at 64 B) - the 4-byte w gathers, which really are 64-byte requests
+    (profiles/r02_w_gather.txt); writes = WRITE_SIZE x 1024.  Returns (k_fused bytes, deferred-pass bytes (upper bound), text) or None."""
+    import csv, glob, shutil, subprocess, tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fmx_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--no-extras", "--no-cpu-baseline", "--steps", "3", "--warmup", "1", "--features", str(args.n), "--factors", str(args.k), "--nnz", str(args.nnz),
+                   "--rows", str(args.rows), "--batch", str(args.batch), "--bias-lag", str(args.bias_lag)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            agg = {}
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    name = row.get("Kernel_Name", "")
+                    key = "fused" if "k_fused<" in name else ("seg" if "k_apply_seg<" in name else None)
+                    if key and row.get("Counter_Name") == ctr:
+                        a = agg.setdefault(key, [0, 0.0])
+                        a[0] += 1
+                        a[1] += float(row.get("Counter_Value", 0))
+            if "fused" not in agg:
+                return None
+            got[ctr] = {kk: v[1] / v[0] for kk, v in agg.items()}        # KB per launch
+        except (OSError, subprocess.SubprocessError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fused = 2 * got["FETCH_SIZE"]["fused"] * 1024 - examples_per_launch * args.nnz * 64 + got["WRITE_SIZE"]["fused"] * 1024
+    seg = 2 * got["FETCH_SIZE"].get("seg", 0.0) * 1024 + got["WRITE_SIZE"].get("seg", 0.0) * 1024
+    return int(fused), int(seg), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, over `bench.py --no-extras --steps 3` in a child process "
+                                  "(k_fused %.0f / %.0f KB per launch; reads = 2 x FETCH_SIZE - the 64-byte w requests, profiles/r06_pmc_summary.txt)"
+                                  % (got["FETCH_SIZE"]["fused"], got["WRITE_SIZE"]["fused"]))
+
+
 def als_bytes_per_sweep(n_rows, nnz_total, n_seen, k):
     """algorithmic bytes of one fm_learn_mcmc sweep as the device runs it: per coordinate family
     (w and each of the k factors) the column pass touches every entry twice (8-B entry + 16-B {e,q} gather for the sums,
@@ -526,6 +570,7 @@ def main():
     ap.add_argument("--no-bias-lag", action="store_true", help="minibatch: keep the w0 recurrence on the critical path (exact chunk coupling)")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic in this run")
     ap.add_argument("--place", type=int, default=None,
                     help="fmx_config::place_candidates: 0 = the library's placement (big tables: chunks of two memory classes), 1 = plain "
                          "allocations.  Default 0; with --same-device 1 (shards SHARING a device are the one case measured faster out of "
@@ -809,6 +854,14 @@ def main():
                     "source": "measured in this run: the headline rule against the device's reference-trajectory mode, same start, same rows, one epoch each"}
             except Exception as exc:
                 extras["parity_vs_online_live"] = {"error": str(exc)[:200]}
+        # the headline kernels' HBM bytes, MEASURED in this run (two counter passes in child processes; --no-live-traffic skips them)
+        if args.mode == "fused" and not args.no_live_traffic and args.traffic is None:
+            try:
+                lt = live_traffic(args, min(batch if batch else 262144, args.rows))
+                if lt:
+                    extras["_live_traffic"] = lt
+            except Exception:
+                pass
 
     if rank == 0:
         value = args.steps * args.rows / elapsed
@@ -822,6 +875,9 @@ def main():
                 ("k_apply_seg" if args.apply in ("default", "segmented") else "k_apply")
             traffic, tsrc = (args.traffic, "--traffic") if args.traffic is not None else \
                 committed_traffic(kname, rows_per_launch, args.k, args.nnz)
+            live = extras.pop("_live_traffic", None) if isinstance(extras, dict) else None
+            if live and args.traffic is None:
+                traffic, tsrc = live[0], live[2]
             roof = {"bound": "hbm", "kernel": kname,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -940,7 +996,7 @@ def main():
         if roof is not None and roof.get("traffic") and not sharded:
             try:
                 e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(roof["kernel"], {})
-                step_bytes = roof["traffic"] + e.get("deferred_pass_bytes_per_launch", 0)
+                step_bytes = roof["traffic"] + (live[1] if live and args.traffic is None else e.get("deferred_pass_bytes_per_launch", 0))
                 roof["step_traffic_ratio"] = round(step_bytes / (roof["bytes_per_example"] * roof["examples_per_launch"]), 4)
                 roof["step_traffic_ratio_source"] = roof["traffic_source"] + " (+ the deferred-feature pass); counter bytes / algorithmic bytes of one batch"
             except (OSError, ValueError, KeyError):
