@@ -294,6 +294,9 @@ def live_traffic(args, examples_per_launch):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None
+    # not from inside a profiled process (a profiler's environment would be inherited by the child's own profiler): the committed counters then
+    if any(kk.startswith(("ROCP_", "ROCPROF", "ROCTRACER", "HSA_TOOLS")) for kk in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     got = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="fmx_pmc_", dir="/tmp")
@@ -302,7 +305,7 @@ def live_traffic(args, examples_per_launch):
                    "--no-extras", "--no-cpu-baseline", "--steps", "3", "--warmup", "1", "--features", str(args.n), "--factors", str(args.k), "--nnz", str(args.nnz),
                    "--rows", str(args.rows), "--batch", str(args.batch), "--bias-lag", str(args.bias_lag)]
             env = dict(os.environ, TMPDIR="/tmp")
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None
