@@ -855,6 +855,43 @@ def main():
                     "online_side": "FMX_SGD_SEQUENTIAL on the device" + (" (conflict-free runs: %d)" % st_seq.batches if st_seq.status & capi.STAT_SEQ_RUNS else ""),
                     "online_side_seconds": round(t_seq, 4),
                     "source": "measured in this run: the headline rule against the device's reference-trajectory mode, same start, same rows, one epoch each"}
+                # ... and the YARDSTICK, measured the same way: the reference's trajectory against ITSELF when the rows inside every batch-sized window
+                # come in another order (same rows, same start): what the order of the rows is worth to online SGD
+                try:
+                    ent, rp, yy = h.download_rows(1)                    # fixed-length rows: entry list of row r = [r * nnz, (r + 1) * nnz)
+                    rng = np.random.default_rng(7)
+                    perm = np.arange(pv_rows)
+                    win = batch if batch else 262144
+                    for a0 in range(0, pv_rows, win):
+                        rng.shuffle(perm[a0:min(a0 + win, pv_rows)])
+                    h.upload_rows(2, ent.reshape(pv_rows, args.nnz)[perm].reshape(-1), rp, yy[perm])
+                    del ent
+                    h.init_params(0.0, 0.01, 1)
+                    h.sgd_epoch(2, capi.SGD_SEQUENTIAL)
+                    h.synchronize()
+                    p_sh, w0_sh = h.predict(1, pv_rows).astype(np.float64), h.get_w0()   # (the SAME rows in the same order as p_on)
+                    ds = np.abs(p_sh - p_on)
+                    extras["parity_vs_online_live"]["reference_vs_itself_with_rows_shuffled_inside_batch_sized_windows"] = {
+                        "pred_mean_abs": round(float(ds.mean()), 6), "pred_max_abs": round(float(ds.max()), 6), "w0_abs": round(abs(w0_sh - w0_on), 6),
+                        "window": int(win), "source": "measured in this run: FMX_SGD_SEQUENTIAL on the rows in file order vs on the rows shuffled inside windows"}
+                    # ... and under the SMALLEST change of order: every two neighbouring rows change places
+                    sw = np.arange(pv_rows)
+                    sw[0:pv_rows - pv_rows % 2:2] += 1
+                    sw[1:pv_rows:2] -= 1
+                    ent, rp, yy = h.download_rows(1)
+                    h.upload_rows(2, ent.reshape(pv_rows, args.nnz)[sw].reshape(-1), rp, yy[sw])
+                    del ent
+                    h.init_params(0.0, 0.01, 1)
+                    h.sgd_epoch(2, capi.SGD_SEQUENTIAL)
+                    h.synchronize()
+                    p_sw, w0_sw = h.predict(1, pv_rows).astype(np.float64), h.get_w0()
+                    dw = np.abs(p_sw - p_on)
+                    extras["parity_vs_online_live"]["reference_vs_itself_with_neighbouring_rows_swapped"] = {
+                        "pred_mean_abs": round(float(dw.mean()), 6), "pred_max_abs": round(float(dw.max()), 6), "w0_abs": round(abs(w0_sw - w0_on), 6),
+                        "source": "measured in this run: FMX_SGD_SEQUENTIAL on the rows in file order vs with rows 2i and 2i + 1 exchanged"}
+                    h.free_rows(2)
+                except Exception as exc:
+                    extras["parity_vs_online_live"]["reference_vs_itself_with_rows_shuffled_inside_batch_sized_windows"] = {"error": str(exc)[:200]}
             except Exception as exc:
                 extras["parity_vs_online_live"] = {"error": str(exc)[:200]}
         # the headline kernels' HBM bytes, MEASURED in this run (two counter passes in child processes; --no-live-traffic skips them)
@@ -993,6 +1030,15 @@ def main():
                 roof["parity_vs_online_pred_max_abs"] = pl["pred_max_abs"]
                 roof["parity_vs_online_w0_abs"] = pl["w0_abs"]
                 roof["parity_vs_online_pred_rms"] = pl["pred_rms"]
+                ys = pl.get("reference_vs_itself_with_rows_shuffled_inside_batch_sized_windows")
+                if isinstance(ys, dict) and "pred_mean_abs" in ys:  # the yardstick: the reference's trajectory against itself, rows reordered inside windows
+                    roof["order_noise_pred_mean_abs"] = ys["pred_mean_abs"]
+                    roof["order_noise_pred_max_abs"] = ys["pred_max_abs"]
+                    roof["order_noise_w0_abs"] = ys["w0_abs"]
+                yn = pl.get("reference_vs_itself_with_neighbouring_rows_swapped")
+                if isinstance(yn, dict) and "pred_mean_abs" in yn:
+                    roof["pair_swap_noise_pred_mean_abs"] = yn["pred_mean_abs"]
+                    roof["pair_swap_noise_w0_abs"] = yn["w0_abs"]
             roof["predict"] = {"v_read_frac": pr["v_read_frac"], "v_read_frac_cold": pr["without_side_stream"]["v_read_frac"],
                                "rows_per_s": pr["value"], "rows_per_s_cold": pr["without_side_stream"]["value"],
                                "cold": "no weight side stream (a pass that no epoch on the slot preceded)"}
