@@ -858,3 +858,34 @@ def test_reference_trajectory_long_runs(capi, oracle, task):
     np.testing.assert_allclose(v[:, ids], m.v[:, ids], rtol=RTOL, atol=2e-5)
     np.testing.assert_allclose(h.predict(0, rows), oracle.predict_raw(m, d), rtol=RTOL, atol=5e-5)
     h.close()
+
+
+@pytest.mark.parametrize("seed,k,task,n,max_nnz,dups", [(1, 8, 1, 300, 9, False), (2, 64, 0, 2000, 20, False), (3, 100, 1, 50000, 70, False),
+                                                        (4, 16, 0, 5000, 12, True), (5, 64, 1, 800, 6, True), (6, 4, 1, 4000, 10, False)])
+def test_runs_forced_on_rows_that_conflict_everywhere(capi, oracle, monkeypatch, seed, k, task, n, max_nnz, dups):
+    """FMX_SEQ_RUNS=1: the slot is cut into conflict-free runs whatever their length -- on small feature spaces nearly every row shares a feature with
+    its predecessor, so the runs are one to a few rows long, some rows are empty, some repeat an id (their own run, entry by entry), some are longer
+    than the register path (70 entries: two launches for their runs).  The cut and every form of a run against the oracle's ONLINE loop
+    (fm_learn_sgd_element.h:56-67) at 1e-4, values away from 1, two epochs."""
+    monkeypatch.setenv("FMX_SEQ_RUNS", "1")
+    rows = 1500
+    ent, rp, y = datagen.ragged_real(n, rows, max_nnz, seed=100 + seed, classification=bool(task), empty_every=11, duplicates=dups)
+    d = oracle.Data(ent, rp, y)
+    m = oracle.Model(n, k, True, True, 0.001, 0.002, 0.003)
+    m.v[:] = oracle.init_values(seed, n, k, 0.05)
+    m.w[:] = oracle.init_values(seed + 50, n, 1, 0.05)[0]
+    m.w0 = -0.05
+    lo, hi = (float(y.min()), float(y.max())) if task == 0 else (-1.0, 1.0)
+    lr = 0.01 if task == 1 else 0.002
+    h = capi.Handle(n, k, True, True, task, 0.001, 0.002, 0.003, lr, lo, hi)
+    h.set_params(m.w0, m.w, m.v)
+    h.upload_rows(0, ent, rp, y)
+    for _ in range(2):
+        st = h.sgd_epoch(0, capi.SGD_SEQUENTIAL)
+        assert st.status & capi.STAT_SEQ_RUNS and st.batches > rows // 40
+        oracle.sgd_epoch_online(m, d, task, lr, lo, hi)
+    w0, w, v = h.get_params()
+    assert abs(w0 - m.w0) <= RTOL * abs(m.w0) + 1e-5
+    np.testing.assert_allclose(w, m.w, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(v, m.v, rtol=RTOL, atol=2e-5)
+    h.close()
