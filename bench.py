@@ -906,6 +906,7 @@ def main():
     if rank == 0:
         value = args.steps * args.rows / elapsed
         roof = None
+        live = None                                          # (k_fused bytes, deferred-pass bytes, text) measured in this run, if it was
         if main_launches:
             # the shard sees nnz/world entries per example; k_apply / k_fused bytes scale with them
             per_ex = algorithmic_bytes(args.k, args.nnz, kind)
